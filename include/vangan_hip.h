@@ -1,0 +1,223 @@
+/* vangan_hip.h -- C ABI of libvangan_hip.so (MI355X / gfx950 only).
+ *
+ * The reference (psweens/VAN-GAN) has NO native plugin/FFI interface: its hot path sits behind
+ * the Python class VanGan (vangan.py:20-550) and executes inside TensorFlow.  These entry points
+ * are what a ctypes binding on the reference side would call in place of the TensorFlow ops of
+ * that path; each one cites the reference lines whose arithmetic it replaces.
+ *
+ * Rules of the boundary:
+ *   - every pointer is a DEVICE pointer owned by the caller, valid on `stream` for the call;
+ *   - the library never allocates/frees device memory and never synchronises: enqueue-only;
+ *   - every entry returns 0 on success, <0 on error (vg_status_string); no exception or abort
+ *     crosses the ABI;
+ *   - activations are NDHWC (channel innermost). "bf16" buffers hold 16-bit brain floats.
+ */
+#ifndef VANGAN_HIP_H
+#define VANGAN_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* vg_stream_t;          /* hipStream_t */
+
+#define VG_OK 0
+#define VG_EINVAL (-1)              /* bad argument / unsupported shape */
+#define VG_ELDS (-2)                /* tile does not fit the 160 KiB LDS */
+#define VG_ELAUNCH (-3)             /* HIP launch failure */
+
+#define VG_ACT_NONE 0
+#define VG_ACT_RELU 1
+#define VG_ACT_LRELU 2              /* LeakyReLU(0.2), discriminator.py:75 */
+
+#define VG_PAD_ZERO 0               /* Keras 'same' zero padding */
+#define VG_PAD_REFLECT 1            /* ReflectionPadding3D, building_blocks.py:30-39 */
+
+#define VG_MAX_TAPS 64
+
+const char* vg_status_string(int code);
+int vg_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Gather-convolution (implicit GEMM on bf16 MFMA).  One descriptor covers
+ *   - Conv3D forward for every variant on the path (resunet_model.py:42-143,
+ *     building_blocks.py:126-196, discriminator.py:50-117): k3/k1/k4, stride 1/2, reflect or zero
+ *     padding folded into the index math, InstanceNorm-apply + ReLU/LeakyReLU (+ channel-dropout,
+ *     + GaussianNoise) applied on read, nearest-2x upsample + concat read virtually
+ *     (resunet_model.py:175-181), bias / residual-add / tanh / next-InstanceNorm statistics in
+ *     the epilogue;
+ *   - its data gradient (what tf.GradientTape computes for d/d input of Conv3D): the same kernel
+ *     on dY with transposed packed weights, per output-parity class for stride 2.
+ * out[n, o*ostr+ooff, co] (+)= sum_taps sum_ci f(src[n, bnd(o*istr + tap), ci]) * W[tap][ci][co]
+ * --------------------------------------------------------------------------------------------- */
+typedef struct {
+    /* input: virtual concat of src0 (c_src0 channels) and src1 (c_src1 channels, may be 0) */
+    const void* src0;
+    const void* src1;
+    int32_t c_src0, c_src1;
+    int32_t src0_shift;      /* 1: src0 is stored at half resolution, read at (d>>1,h>>1,w>>1) */
+    int32_t src_f32;         /* 1: sources are float32 (only with a single input channel) */
+    int32_t N, D, H, W;      /* logical input grid (full resolution) */
+    const float* in_scale;   /* [N][Cin] on-read affine (InstanceNorm apply) or NULL */
+    const float* in_shift;
+    int32_t act;             /* VG_ACT_* applied after the affine */
+    const void* noise;       /* bf16 [N][D+2np][H+2np][W+2np][Cin] added after act, or NULL */
+    int32_t noise_pad;       /* np: 1 when the noise lives on the reflect-padded grid */
+    /* geometry */
+    int32_t istr;            /* input stride per output step */
+    int32_t pad_mode;        /* VG_PAD_* for out-of-range input positions */
+    int32_t ntaps;
+    int8_t tap_d[VG_MAX_TAPS], tap_h[VG_MAX_TAPS], tap_w[VG_MAX_TAPS];  /* input offset of tap */
+    int32_t OD, OH, OW;      /* iteration space: output positions per dim */
+    int32_t ostr, ooff_d, ooff_h, ooff_w;   /* buffer position = o*ostr + ooff */
+    int32_t BD, BH, BW;      /* output buffer grid */
+    int32_t Cout;
+    /* weights: bf16 [round_up(Cout,64)][Ktot], packed by vg_pack_weights with the same CK/taps */
+    const void* wpacked;
+    int32_t CK;              /* contraction channels staged per chunk (multiple of 16) */
+    const float* bias;       /* [Cout] or NULL */
+    /* epilogue */
+    const void* res;         /* bf16 [N][BD][BH][BW][Cout] residual operand or NULL */
+    const float* res_scale;  /* [N][Cout] affine on the residual (InstanceNorm of the shortcut) */
+    const float* res_shift;
+    int32_t tanh_out;
+    void* out;               /* bf16 (or f32 when out_f32) [N][BD][BH][BW][Cout] */
+    int32_t out_f32;
+    int32_t accumulate;      /* out += value (data-gradient accumulation) */
+    float* out_sums;         /* [N][Cout][2] += (sum, sum of squares) of the stored values, or NULL */
+} vg_conv_desc;
+
+int vg_conv3d(const vg_conv_desc* d, vg_stream_t stream);
+
+/* bytes of dynamic LDS the chosen tile needs, or <0 */
+int vg_conv3d_lds_bytes(const vg_conv_desc* d);
+
+/* Pack fp32 Keras DHWIO weights [T][Cin][Cout] to the bf16 layout vg_conv3d reads.
+ * transpose=0: rows = Cout, contraction = Cin (forward); transpose=1: rows = Cin, contraction =
+ * Cout (data gradient).  tap_idx[i] selects the source tap of packed tap i.  Returns Ktot>0. */
+int vg_pack_weights(const float* w, int T, int Cin, int Cout, const int32_t* tap_idx_dev, int ntaps,
+                    int transpose, int CK, void* out_bf16, vg_stream_t stream);
+int vg_packed_ktot(int ntaps, int C, int CK);
+int vg_packed_rows(int N);
+
+/* ---------------------------------------------------------------------------------------------
+ * Weight gradient of the same gather-convolution (tf.GradientTape d/dW of Conv3D, vangan.py:426-438):
+ * dW[tap][ci][co] += sum_{n,o} f(src[n, bnd(o*istr+tap), ci]) * dY[n,o,co];  db[co] += sum dY.
+ * Uses the input fields of vg_conv_desc (src*, transform, taps, OD/OH/OW); `dy` is bf16 (or f32 when
+ * dy_f32) [N][OD][OH][OW][Cout]; dw is fp32 DHWIO [T_total][Cin][Cout] indexed by tap_idx_host[i].
+ * --------------------------------------------------------------------------------------------- */
+int vg_conv3d_wgrad(const vg_conv_desc* d, const void* dy, int dy_f32, const int32_t* tap_idx_host,
+                    float* dw, float* db, vg_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * InstanceNorm helpers (tfa InstanceNormalization, resunet_model.py:36, building_blocks.py:190)
+ * --------------------------------------------------------------------------------------------- */
+/* scale/shift[n][c] for on-read normalisation from accumulated (sum,sumsq); channels [0,c0) come from
+ * sums0 (count0 voxels), [c0,c0+c1) from sums1.  mult[n][c] (SpatialDropout3D mask, >=0) optional.
+ * Also writes mean/rstd [N][C] when non-NULL (needed by the backward). */
+int vg_in_finalize(const float* sums0, int c0, float count0, const float* sums1, int c1, float count1,
+                   const float* gamma, const float* beta, const float* mult, int N, float eps,
+                   float* scale, float* shift, float* mean, float* rstd, vg_stream_t stream);
+
+/* Backward of  a = mult * act(x*scale+shift)  [InstanceNorm -> activation -> dropout], with the
+ * upstream gradient g read either plain ([N][D][H][W][C]) or folded from the reflect-padded grid
+ * ([N][D+2][H+2][W+2][C], transpose of ReflectionPadding3D).
+ * pass 1 (stats):  red[n][c][0] += sum dn,  red[n][c][1] += sum dn*xhat,   dn = g*mult*act'(.)
+ * pass 2 (apply):  dx (+)= gamma*rstd*(dn - mean(dn) - xhat*mean(dn*xhat))      (norm=1)
+ *                  dx (+)= dn                                                     (norm=0)
+ * x is bf16 (x_f32=0) ; g is bf16; dx is bf16 unless dx_f32. */
+typedef struct {
+    const void* g; int32_t g_padded;
+    const void* x; int32_t x_f32;            /* forward input of the norm (channels [0,c_x0) when x1 is set) */
+    const void* x1; int32_t c_x0; int32_t x0_shift;   /* virtual upsample+concat: x = [up(x), x1] */
+    int32_t N, D, H, W, C;
+    const float* scale; const float* shift;   /* on-read affine of the forward, [N][C], or NULL */
+    const float* mult;                        /* [N][C] or NULL */
+    int32_t act; int32_t norm;
+    const float* gamma; const float* mean; const float* rstd;   /* norm=1 */
+    float* red;                               /* [N][C][2] */
+    void* dx; int32_t dx_f32; int32_t accumulate;
+    int32_t dx_cstride, dx_coff;              /* dx channel stride / offset (write into a slice) */
+} vg_actnorm_bwd_desc;
+int vg_actnorm_bwd_stats(const vg_actnorm_bwd_desc* d, vg_stream_t stream);
+int vg_actnorm_bwd_apply(const vg_actnorm_bwd_desc* d, vg_stream_t stream);
+/* dgamma[c] += sum_n red[n][c][1], dbeta[c] += sum_n red[n][c][0] */
+int vg_in_param_grads(const float* red, int N, int C, float* dgamma, float* dbeta, vg_stream_t stream);
+
+/* Backward of the virtual upsample+concat (resunet_model.py:175-181): g is bf16 [N][D][H][W][Cu+Cs];
+ * dlow[N][D/2][H/2][W/2][Cu] += sum of the 8 children, dskip[N][D][H][W][Cs] += g[..., Cu:]. */
+int vg_concat_bwd(const void* g, int N, int D, int H, int W, int Cu, int Cs, void* dlow, void* dskip,
+                  vg_stream_t stream);
+
+/* d_pre = dy * (1 - y*y)   (tanh output activation, resunet_model.py:245), all fp32 */
+int vg_tanh_bwd(const float* dy, const float* y, float* dpre, int64_t n, vg_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Loss kernels (fp32 single-channel volumes [B][S])
+ * --------------------------------------------------------------------------------------------- */
+/* mm[b] = (min, max, n_min, n_max) -- utils.py:27-48 */
+int vg_minmax(const float* x, int B, int64_t S, float* mm4, vg_stream_t stream);
+int vg_minmax_apply(const float* x, const float* mm4, int B, int64_t S, float* y, vg_stream_t stream);
+/* dx = gy/(max-min) + [x==min] * sum(gy*(y-1))/(R n_min) - [x==max] * sum(gy*y)/(R n_max);
+ * tmp2[b][2] is scratch (zeroed by the caller) */
+int vg_minmax_bwd(const float* x, const float* y, const float* gy, const float* mm4, int B, int64_t S,
+                  float* tmp2, float* dx, vg_stream_t stream);
+/* BCE of loss_functions.py:185-190 on normalised volumes: acc[0] += sum bce; gp (+)= gscale*dbce/dp */
+int vg_bce(const float* t, const float* p, int64_t n, float* acc, float gscale, float* gp, int accumulate,
+           vg_stream_t stream);
+/* acc[0] += sum (a-b)^2 ; gb (+)= gscale * 2 (b-a) -- loss_functions.py:56-68 */
+int vg_mse(const float* a, const float* b, int64_t n, float* acc, float gscale, float* gb, int accumulate,
+           vg_stream_t stream);
+/* LSGAN terms on patch logits (loss_functions.py:273-274,306-308):
+ * acc[0] += sum (target - x)^2 ; gx (+)= gscale * 2 (x - target); x bf16 or f32 */
+int vg_mse_const(const void* x, int x_f32, float target, int64_t n, float* acc, float gscale, float* gx,
+                 int accumulate, vg_stream_t stream);
+/* SSIM (loss_functions.py:86-117): acc[0] += sum (1-ssim); part[3][B][S] = dL/d(mu_p, E[pp], E[tp]) */
+int vg_ssim_fwd(const float* t, const float* p, int B, int D, int H, int W, float* acc, float* part,
+                vg_stream_t stream);
+int vg_ssim_bwd(const float* t, const float* p, const float* part, int B, int D, int H, int W, float gscale,
+                float* gp, int accumulate, vg_stream_t stream);
+
+/* clDice soft skeleton (clDice_func.py:8-80).  imgs: [iters+2][B][S] receives img_0..img_{iters+1}
+ * (img_{j+1} = soft_erode(img_j)); skels: [iters+1][B][S] receives the skeleton after every step, the
+ * last slab is soft_skel(img, iters). */
+int vg_soft_skel_fwd(const float* img, int B, int D, int H, int W, int iters, float* imgs, float* skels,
+                     vg_stream_t stream);
+/* gimg += (d skel / d img)^T gskel; work: [3][B][S] scratch */
+int vg_soft_skel_bwd(const float* imgs, const float* skels, const float* gskel, int B, int D, int H, int W,
+                     int iters, float* work, float* gimg, vg_stream_t stream);
+/* Dice + clDice combination (clDice_func.py:83-149, loss_functions.py:223-226) without a host sync.
+ * sums7 = (sum skel_p*t, sum skel_p, sum t, sum skel_t*p, sum skel_t, sum p, sum t*p);
+ * coef6: gskel_p = c0*t - c1;  gp += c2*t + c3 + c4*skel_t;  c5 = w*((1-alpha)*dice + alpha*clDice). */
+int vg_cldice_coef(const float* sums7, float w, float alpha, float* coef6, vg_stream_t stream);
+int vg_cldice_grads(const float* t, const float* skel_t, const float* coef6, int64_t n, float* gskel_p, float* gp,
+                    int accumulate, vg_stream_t stream);
+/* sums[k] += (sum a*b, sum a, sum b) over n elements */
+int vg_dot_sums(const float* a, const float* b, int64_t n, float* sums3, vg_stream_t stream);
+/* y (+)= alpha*a + beta*b (b may be NULL) */
+int vg_axpby(const float* a, float alpha, const float* b, float beta, int64_t n, float* y, int accumulate,
+             vg_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Multi-tensor Adam with per-tensor clip-by-norm (tf.keras.optimizers.Adam(2e-4, 0.5, 0.9,
+ * clipnorm=100), vangan.py:220-235, applied by optimizer.minimize at vangan.py:426-438).
+ * w,g,m,v: flat fp32 buffers of `total` elements; seg_off[T+1] tensor boundaries (device int64);
+ * norms[T] scratch.  grad_scale multiplies g before clipping (1/world for mean, 1 for the
+ * reference's SUM all-reduce).
+ * --------------------------------------------------------------------------------------------- */
+int vg_adam_clip(float* w, const float* g, float* m, float* v, const int64_t* seg_off_dev, int T,
+                 int64_t total, float* norms, float lr_t, float beta1, float beta2, float eps,
+                 float clipnorm, float grad_scale, vg_stream_t stream);
+
+/* N(0,std) noise as bf16 and SpatialDropout3D channel masks {0,1/(1-rate)} (fp32), counter-based RNG */
+int vg_randn_bf16(void* out, int64_t n, float std, uint64_t seed, uint64_t offset, vg_stream_t stream);
+int vg_dropout_mask(float* out, int64_t n, float rate, uint64_t seed, uint64_t offset, vg_stream_t stream);
+
+/* f32 <-> bf16 copies */
+int vg_f32_to_bf16(const float* x, void* y, int64_t n, vg_stream_t stream);
+int vg_bf16_to_f32(const void* x, float* y, int64_t n, vg_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

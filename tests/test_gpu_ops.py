@@ -1,0 +1,364 @@
+"""GPU parity tests of the individual libvangan_hip.so entry points against the CPU oracle.
+
+Tolerances: the HIP kernels take bf16 operands (inputs and weights rounded to bf16 exactly as the oracle's
+``q`` hook does) and accumulate in fp32, so against a float64 oracle on the SAME rounded operands the only
+differences are fp32 accumulation order (~1e-6 relative) plus one bf16 rounding of the stored output
+(2^-9 relative).  Checks therefore use  |hip - ref| <= 1.2e-2*|ref| + 2e-3*max|ref|  for bf16 outputs and
+1e-4 relative (L2) for fp32 outputs/gradients unless stated otherwise.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import vangan_oracle as O  # noqa: E402
+
+
+def _dev():
+    return torch.device('cuda:0')
+
+
+def bf(x):
+    return x.to(torch.bfloat16).to(torch.float64)
+
+
+def close_bf16(got, ref, name=''):
+    got, ref = got.double().cpu(), ref.double().cpu()
+    tol = 1.2e-2 * ref.abs() + 2e-3 * ref.abs().max() + 1e-30
+    bad = (got - ref).abs() > tol
+    assert not bad.any(), '%s: %d/%d outside tolerance, max err %.3e (max ref %.3e)' % (
+        name, int(bad.sum()), bad.numel(), float((got - ref).abs().max()), float(ref.abs().max()))
+
+
+def rel_l2(got, ref):
+    got, ref = got.double().cpu(), ref.double().cpu()
+    return float((got - ref).norm() / (ref.norm() + 1e-30))
+
+
+def make_layer(k, cin, cout, stride, pad, dims, bias=True, seed=0):
+    from van_gan_amd.nets import ParamStore
+    from van_gan_amd.ops import ConvLayer
+    specs = [('c.w', (k, k, k, cin, cout), 'x')] + ([('c.b', (cout,), 'x')] if bias else [])
+    st = ParamStore(specs, _dev())
+    g = torch.Generator().manual_seed(seed)
+    w = torch.randn(k, k, k, cin, cout, generator=g) / math.sqrt(k ** 3 * cin)
+    st.param('c.w').copy_(w)
+    if bias:
+        st.param('c.b').copy_(torch.randn(cout, generator=g) * 0.1)
+    lay = ConvLayer(st, 'c', k, cin, cout, stride, pad, bias, dims)
+    lay.pack()
+    return st, lay
+
+
+def ref_conv(x_ncdhw, w_dhwio, b, stride, pad):
+    """float64 reference on already-rounded operands."""
+    xx = O.reflect_pad1(x_ncdhw) if pad == 'reflect' else x_ncdhw
+    return O.conv3d(xx, w_dhwio, b, stride, 'valid' if pad == 'reflect' else 'same')
+
+
+CONV_CASES = [
+    # k, cin, cout, stride, pad, dims
+    (3, 16, 16, 1, 'reflect', (8, 8, 16)),
+    (3, 32, 32, 1, 'reflect', (4, 8, 8)),
+    (3, 16, 32, 2, 'reflect', (8, 8, 16)),
+    (1, 16, 32, 2, 'same', (8, 8, 16)),
+    (1, 48, 16, 1, 'same', (4, 4, 16)),
+    (3, 64, 64, 1, 'reflect', (4, 4, 4)),
+    (3, 128, 128, 1, 'reflect', (2, 2, 2)),
+    (3, 1, 16, 1, 'reflect', (8, 8, 16)),
+    (1, 16, 1, 1, 'same', (8, 8, 16)),
+    (4, 1, 64, 2, 'reflect', (8, 8, 16)),
+    (4, 64, 128, 2, 'reflect', (4, 8, 8)),
+    (4, 32, 64, 1, 'same', (4, 4, 4)),
+    (3, 64, 1, 1, 'same', (4, 4, 4)),
+    (3, 96, 32, 1, 'reflect', (4, 4, 8)),
+]
+
+
+@pytest.mark.parametrize('k,cin,cout,stride,pad,dims', CONV_CASES)
+def test_conv_forward_dgrad_wgrad(k, cin, cout, stride, pad, dims):
+    """Conv3D forward (+ on-read IN/ReLU, bias, statistics), data gradient and weight gradient vs autograd."""
+    from van_gan_amd import ops
+    from van_gan_amd.ops import Src
+    dev = _dev()
+    N = 2
+    st, lay = make_layer(k, cin, cout, stride, pad, dims)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(N, *dims, cin, generator=g)
+    scale = torch.rand(N, cin, generator=g) + 0.5
+    shift = torch.randn(N, cin, generator=g) * 0.3
+    use_norm = cin > 1
+    f32_src = cin == 1
+    xs = x if f32_src else x.to(torch.bfloat16)
+    xd = xs.to(dev)
+    src = Src(xd, (N,) + dims, cin, f32=f32_src, scale=scale.to(dev) if use_norm else None,
+              shift=shift.to(dev) if use_norm else None, act=ops.ACT_RELU if use_norm else ops.ACT_NONE)
+    out_f32 = cout == 1
+    out = torch.zeros(N, *lay.out_dims, cout, dtype=torch.float32 if out_f32 else torch.bfloat16, device=dev)
+    sums = torch.zeros(N, cout, 2, device=dev)
+    lay.forward(src, out, sums=sums)
+    torch.cuda.synchronize()
+    # reference
+    xr = xs.double()
+    a = xr
+    if use_norm:
+        a = F.relu(xr * scale.double().view(N, 1, 1, 1, cin) + shift.double().view(N, 1, 1, 1, cin))
+    a = bf(a).requires_grad_(True)
+    w = bf(st.param('c.w').cpu()).requires_grad_(True)
+    b = st.param('c.b').cpu().double().requires_grad_(True)
+    y = ref_conv(O.to_ncdhw(a), w, b, stride, pad)
+    y_ndhwc = O.to_ndhwc(y)
+    if out_f32:
+        assert rel_l2(out, y_ndhwc) < 1e-4
+    else:
+        close_bf16(out, y_ndhwc, 'forward')
+    ref_sums = torch.stack([y_ndhwc.sum(dim=(1, 2, 3)), (y_ndhwc ** 2).sum(dim=(1, 2, 3))], dim=-1)
+    assert rel_l2(sums, ref_sums) < 2e-2
+    # backward
+    dy = torch.randn(y_ndhwc.shape, generator=g)
+    dys = dy if out_f32 else dy.to(torch.bfloat16)
+    (y_ndhwc * dys.double()).sum().backward()
+    dyd = dys.to(dev)
+    lay.wgrad(src, dyd)
+    torch.cuda.synchronize()
+    assert rel_l2(st.grad('c.w'), w.grad) < 2e-3, 'wgrad'
+    assert rel_l2(st.grad('c.b'), b.grad) < 2e-3, 'bgrad'
+    # data gradient: padded grid for reflect (fold on host for the check), plain for 'same'
+    dp = torch.zeros(N, *lay.buf_dims, cin, dtype=torch.bfloat16, device=dev)
+    lay.dgrad(dyd, N, dp, accumulate=False)
+    dxg = torch.zeros(N, *dims, cin, dtype=torch.float32 if cin == 1 else torch.bfloat16, device=dev)
+    ops.actnorm_bwd(dp, pad == 'reflect', None, (N,) + dims, cin, dxg, act=ops.ACT_NONE, norm=False, accumulate=False)
+    torch.cuda.synchronize()
+    ref_dx = a.grad
+    got = dxg.double().cpu()
+    tol = 2.5e-2 * ref_dx.abs() + 6e-3 * ref_dx.abs().max()
+    assert ((got - ref_dx).abs() <= tol).all(), 'dgrad max err %.3e' % float((got - ref_dx).abs().max())
+
+
+def test_conv_virtual_concat_residual_noise_tanh():
+    """Virtual upsample+concat input, residual*scale+shift epilogue, noise on the padded grid, tanh/f32 output."""
+    from van_gan_amd import ops
+    from van_gan_amd.ops import Src
+    dev = _dev()
+    N, dims, cu, cs, cout = 2, (4, 8, 8), 32, 16, 16
+    st, lay = make_layer(3, cu + cs, cout, 1, 'reflect', dims)
+    g = torch.Generator().manual_seed(2)
+    low = torch.randn(N, 2, 4, 4, cu, generator=g).to(torch.bfloat16)
+    skip = torch.randn(N, *dims, cs, generator=g).to(torch.bfloat16)
+    scale = torch.rand(N, cu + cs, generator=g) + 0.5
+    shift = torch.randn(N, cu + cs, generator=g) * 0.3
+    noise = (torch.randn(N, 6, 10, 10, cu + cs, generator=g) * 0.1).to(torch.bfloat16)
+    res = torch.randn(N, *dims, cout, generator=g).to(torch.bfloat16)
+    rs, rb = torch.rand(N, cout, generator=g) + 0.5, torch.randn(N, cout, generator=g)
+    src = Src(low.to(dev), (N,) + dims, cu, skip.to(dev), cs, shift0=1, scale=scale.to(dev), shift=shift.to(dev),
+              act=ops.ACT_LRELU, noise=noise.to(dev), noise_pad=1)
+    out = torch.zeros(N, *dims, cout, dtype=torch.bfloat16, device=dev)
+    sums = torch.zeros(N, cout, 2, device=dev)
+    lay.forward(src, out, sums=sums, res=res.to(dev), res_scale=rs.to(dev), res_shift=rb.to(dev))
+    torch.cuda.synchronize()
+    up = low.double().repeat_interleave(2, 1).repeat_interleave(2, 2).repeat_interleave(2, 3)
+    cat = torch.cat([up, skip.double()], dim=-1)
+    a = F.leaky_relu(cat * scale.double().view(N, 1, 1, 1, -1) + shift.double().view(N, 1, 1, 1, -1), 0.2)
+    ap = O.to_ndhwc(O.reflect_pad1(O.to_ncdhw(a))) + noise.double()
+    y = O.conv3d(O.to_ncdhw(bf(ap)), bf(st.param('c.w').cpu()), st.param('c.b').cpu().double(), 1, 'valid')
+    y = O.to_ndhwc(y) + res.double() * rs.double().view(N, 1, 1, 1, -1) + rb.double().view(N, 1, 1, 1, -1)
+    close_bf16(out, y, 'concat/res/noise forward')
+    # weight gradient through the same virtual operand
+    dy = torch.randn(y.shape, generator=g).to(torch.bfloat16)
+    lay.wgrad(src, dy.to(dev))
+    torch.cuda.synchronize()
+    apq = bf(ap).requires_grad_(False)
+    w = bf(st.param('c.w').cpu()).requires_grad_(True)
+    yy = O.to_ndhwc(O.conv3d(O.to_ncdhw(apq), w, None, 1, 'valid'))
+    (yy * dy.double()).sum().backward()
+    assert rel_l2(st.grad('c.w'), w.grad) < 2e-3
+    # tanh + f32 output on a 16->1 conv
+    st2, lay2 = make_layer(1, 16, 1, 1, 'same', dims, seed=3)
+    x = torch.randn(N, *dims, 16, generator=g).to(torch.bfloat16)
+    o2 = torch.zeros(N, *dims, 1, device=dev)
+    lay2.forward(Src(x.to(dev), (N,) + dims, 16), o2, tanh=True)
+    torch.cuda.synchronize()
+    y2 = torch.tanh(O.to_ndhwc(O.conv3d(O.to_ncdhw(x.double()), bf(st2.param('c.w').cpu()), st2.param('c.b').cpu().double(), 1, 'same')))
+    assert rel_l2(o2, y2) < 1e-4
+
+
+def test_in_finalize_and_actnorm_bwd():
+    """InstanceNorm scale/shift + (IN -> ReLU) backward with the reflect-pad transpose, vs autograd."""
+    from van_gan_amd import ops
+    dev = _dev()
+    N, dims, Cc = 2, (4, 6, 8), 16
+    g = torch.Generator().manual_seed(4)
+    x = (torch.randn(N, *dims, Cc, generator=g) * 2 + 0.5).to(torch.bfloat16)
+    gamma, beta = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g) * 0.2
+    xd = x.double()
+    sums = torch.stack([xd.sum(dim=(1, 2, 3)), (xd ** 2).sum(dim=(1, 2, 3))], dim=-1).float().to(dev)
+    scale, shift, mean, rstd = [torch.zeros(N, Cc, device=dev) for _ in range(4)]
+    S = dims[0] * dims[1] * dims[2]
+    ops.in_finalize(sums, Cc, S, gamma.to(dev), beta.to(dev), N, scale, shift, mean, rstd)
+    xr = xd.clone().requires_grad_(True)
+    gm, bt = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    nrm = O.to_ndhwc(O.instance_norm(O.to_ncdhw(xr), gm, bt))
+    torch.cuda.synchronize()
+    got_n = xd * scale.cpu().double().view(N, 1, 1, 1, Cc) + shift.cpu().double().view(N, 1, 1, 1, Cc)
+    assert rel_l2(got_n, nrm.detach()) < 1e-4
+    a = F.relu(nrm)
+    ap = O.to_ndhwc(O.reflect_pad1(O.to_ncdhw(a)))
+    gp = torch.randn(ap.shape, generator=g).to(torch.bfloat16)
+    (ap * gp.double()).sum().backward()
+    red = torch.zeros(N, Cc, 2, device=dev)
+    dx = torch.zeros(N, *dims, Cc, dtype=torch.bfloat16, device=dev)
+    dgam, dbet = torch.zeros(Cc, device=dev), torch.zeros(Cc, device=dev)
+    ops.actnorm_bwd(gp.to(dev), True, x.to(dev), (N,) + dims, Cc, dx, scale=scale, shift=shift, act=ops.ACT_RELU,
+                    norm=True, gamma=gamma.to(dev), mean=mean, rstd=rstd, red=red, accumulate=False, dgamma=dgam, dbeta=dbet)
+    torch.cuda.synchronize()
+    assert rel_l2(dx, xr.grad) < 1e-2
+    assert rel_l2(dgam, gm.grad) < 1e-3 and rel_l2(dbet, bt.grad) < 1e-3
+
+
+def test_concat_bwd_and_tanh_bwd():
+    from van_gan_amd import ops
+    dev = _dev()
+    N, D, H, W, Cu, Cs = 2, 4, 4, 8, 16, 8
+    g = torch.Generator().manual_seed(5)
+    gcat = torch.randn(N, D, H, W, Cu + Cs, generator=g).to(torch.bfloat16)
+    dlow = torch.randn(N, D // 2, H // 2, W // 2, Cu, generator=g).to(torch.bfloat16)
+    dskip = torch.randn(N, D, H, W, Cs, generator=g).to(torch.bfloat16)
+    dl, ds = dlow.to(dev).clone(), dskip.to(dev).clone()
+    ops.concat_bwd(gcat.to(dev), (N, D, H, W), Cu, Cs, dl, ds)
+    torch.cuda.synchronize()
+    gu = gcat[..., :Cu].double().view(N, D // 2, 2, H // 2, 2, W // 2, 2, Cu).sum(dim=(2, 4, 6))
+    close_bf16(dl, dlow.double() + gu, 'dlow')
+    close_bf16(ds, dskip.double() + gcat[..., Cu:].double(), 'dskip')
+    y = torch.tanh(torch.randn(1000, generator=g)); dy = torch.randn(1000, generator=g)
+    dp = torch.zeros(1000, device=dev)
+    ops.tanh_bwd(dy.to(dev), y.to(dev), dp)
+    assert rel_l2(dp, dy * (1 - y * y)) < 1e-6
+
+
+def test_losses_vs_oracle():
+    """min-max (fwd/bwd incl. ties), BCE, MSE, LSGAN terms, SSIM fwd/bwd vs the oracle's autograd."""
+    from van_gan_amd import ops
+    dev = _dev()
+    B, D, H, W = 2, 6, 8, 10
+    S = D * H * W
+    g = torch.Generator().manual_seed(6)
+    x = torch.tanh(torch.randn(B, D, H, W, 1, generator=g) * 2)
+    x[0, 0, 0, 0, 0] = x[0].max(); x[0, 1, 1, 1, 0] = x[0].max()           # tie at the max
+    t = (torch.rand(B, D, H, W, 1, generator=g) > 0.7).float()
+    xd, td = x.to(dev), t.to(dev)
+    mm, y = torch.zeros(B, 4, device=dev), torch.zeros(B, D, H, W, 1, device=dev)
+    ops.minmax(xd, B, S, mm); ops.minmax_apply(xd, mm, B, S, y)
+    xr = x.double().requires_grad_(True)
+    yr = O.min_max_norm(xr)
+    assert rel_l2(y, yr.detach()) < 1e-6
+    assert float(mm[0, 3]) == 2.0
+    # BCE
+    acc = torch.zeros(4, device=dev)
+    gy = torch.zeros_like(y)
+    ops.bce(td, y, acc[0:1], 0.37, gy)
+    lb = O.keras_bce(t.double(), yr).sum()
+    (0.37 * lb).backward()
+    assert abs(float(acc[0]) - float(lb)) < 1e-3 * abs(float(lb))
+    dx = torch.zeros_like(y); tmp2 = torch.zeros(B, 2, device=dev)
+    ops.minmax_bwd(xd, y, gy, mm, B, S, tmp2, dx)
+    torch.cuda.synchronize()
+    assert rel_l2(dx, xr.grad) < 2e-4
+    # MSE and LSGAN constants
+    a, b = torch.randn(B, S, generator=g), torch.randn(B, S, generator=g)
+    gb = torch.zeros(B, S, device=dev)
+    ops.mse(a.to(dev), b.to(dev), acc[1:2], 0.5, gb)
+    assert abs(float(acc[1]) - float(((a - b) ** 2).sum())) < 1e-3 * float(((a - b) ** 2).sum())
+    assert rel_l2(gb, 0.5 * 2 * (b - a)) < 1e-5
+    gx = torch.zeros(B, S, device=dev)
+    ops.mse_const(b.to(dev).to(torch.bfloat16), 1.0, acc[2:3], 2.0, gx)
+    bb = b.to(torch.bfloat16).float()
+    assert abs(float(acc[2]) - float(((bb - 1) ** 2).sum())) < 1e-3 * float(((bb - 1) ** 2).sum())
+    assert rel_l2(gx, 4 * (bb - 1)) < 1e-5
+    # SSIM
+    p = torch.rand(B, D, H, W, 1, generator=g); tt = torch.rand(B, D, H, W, 1, generator=g)
+    pr = p.double().requires_grad_(True)
+    ls = O.ssim_loss_3d(tt.double(), pr).sum()
+    ls.backward()
+    part = torch.zeros(3, B, D, H, W, 1, device=dev); gp = torch.zeros(B, D, H, W, 1, device=dev)
+    ops.ssim_fwd(tt.to(dev), p.to(dev), (B, D, H, W), acc[3:4], part)
+    ops.ssim_bwd(tt.to(dev), p.to(dev), part, (B, D, H, W), 1.0, gp)
+    torch.cuda.synchronize()
+    assert abs(float(acc[3]) - float(ls)) < 1e-3 * abs(float(ls))
+    assert rel_l2(gp, pr.grad) < 1e-3
+
+
+def test_soft_skeleton_and_cldice():
+    """soft_skel forward/backward and the Dice+clDice combination vs the oracle (continuous data: no ties)."""
+    from van_gan_amd import ops
+    dev = _dev()
+    B, D, H, W, it = 2, 8, 10, 12, 4
+    g = torch.Generator().manual_seed(7)
+    p = torch.rand(B, D, H, W, 1, generator=g)
+    t = (F.avg_pool3d(torch.rand(B, 1, D, H, W, generator=g), 3, 1, 1) > 0.52).float().permute(0, 2, 3, 4, 1).contiguous()
+    vol = (B, D, H, W, 1)
+    imgs_p, skels_p = torch.zeros((it + 2,) + vol, device=dev), torch.zeros((it + 1,) + vol, device=dev)
+    imgs_t, skels_t = torch.zeros((it + 2,) + vol, device=dev), torch.zeros((it + 1,) + vol, device=dev)
+    pd, td = p.to(dev), t.to(dev)
+    ops.soft_skel_fwd(pd, (B, D, H, W), it, imgs_p, skels_p)
+    ops.soft_skel_fwd(td, (B, D, H, W), it, imgs_t, skels_t)
+    pr = p.double().requires_grad_(True)
+    sk_p = O.soft_skel(pr[..., 0], it)
+    sk_t = O.soft_skel(t.double()[..., 0], it)
+    torch.cuda.synchronize()
+    assert rel_l2(skels_p[it][..., 0], sk_p.detach()) < 1e-6
+    assert rel_l2(skels_t[it][..., 0], sk_t) < 1e-6
+    w = 5.0
+    loss = O.soft_dice_cldice(t.double(), pr, it) * w
+    loss.backward()
+    sums, coef = torch.zeros(9, device=dev), torch.zeros(8, device=dev)
+    ops.dot_sums(skels_p[it], td, sums[0:3]); ops.dot_sums(skels_t[it], pd, sums[3:6]); ops.dot_sums(td, pd, sums[6:9])
+    ops.cldice_coef(sums, w, 0.5, coef)
+    gskel, gp = torch.zeros(vol, device=dev), torch.zeros(vol, device=dev)
+    ops.cldice_grads(td, skels_t[it], coef, gskel, gp)
+    work = torch.zeros((3,) + vol, device=dev)
+    ops.soft_skel_bwd(imgs_p, skels_p, gskel, (B, D, H, W), it, work, gp)
+    torch.cuda.synchronize()
+    assert abs(float(coef[5]) - float(loss)) < 1e-4 * abs(float(loss))
+    assert rel_l2(gp, pr.grad) < 1e-3
+
+
+def test_adam_clip():
+    from van_gan_amd import ops
+    from van_gan_amd.nets import ParamStore
+    specs = [('a', (1000,), 'x'), ('b', (3, 3, 3, 16, 16), 'x'), ('c', (7,), 'x'), ('d', (33, 65), 'x')]
+    st = ParamStore(specs, _dev())
+    g = torch.Generator().manual_seed(8)
+    P = {n: torch.randn(sh, generator=g) for n, sh, _ in specs}
+    G = {n: torch.randn(sh, generator=g) for n, sh, _ in specs}
+    G['b'] = G['b'] * 50.0                  # norm >> 100: clipped
+    st.load(P)
+    state = {}
+    for step in range(1, 3):
+        for n in P:
+            st.grad(n).copy_(G[n])
+        lr_t = 2e-4 * math.sqrt(1 - 0.9 ** step) / (1 - 0.5 ** step)
+        ops.adam_clip(st.w, st.g, st.m, st.v, st.seg_off, st.T, st.norms, lr_t, 0.5, 0.9, 1e-7, 100.0)
+        Pd = {n: v.double() for n, v in P.items()} if step == 1 else Pd
+        O.adam_step(Pd, {n: v.double() for n, v in G.items()}, state)
+    torch.cuda.synchronize()
+    out = st.export()
+    for n in P:
+        assert (out[n].double() - Pd[n]).abs().max() < 2e-7, n
+    assert abs(float(st.norms[1]) - float((G['b'].double() ** 2).sum())) < 1e-3 * float((G['b'].double() ** 2).sum())
+
+
+def test_rng_statistics():
+    from van_gan_amd import ops
+    dev = _dev()
+    z = torch.zeros(1 << 20, dtype=torch.bfloat16, device=dev)
+    ops.randn_bf16(z, 0.1, 1234, 0)
+    zf = z.float()
+    assert abs(float(zf.mean())) < 1e-3 and abs(float(zf.std()) - 0.1) < 2e-3
+    m = torch.zeros(1 << 16, device=dev)
+    ops.dropout_mask(m, 0.2, 99, 0)
+    keep = float((m > 0).float().mean())
+    assert abs(keep - 0.8) < 0.01 and abs(float(m.max()) - 1.25) < 1e-6

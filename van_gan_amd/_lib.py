@@ -1,0 +1,111 @@
+"""ctypes binding of libvangan_hip.so (include/vangan_hip.h).  There is NO fallback: if the library cannot be
+built or loaded, importing this module raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import build as _build
+
+VG_MAX_TAPS = 64
+ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
+PAD_ZERO, PAD_REFLECT = 0, 1
+
+c_void_p, c_int, c_float, c_i64, c_u64 = C.c_void_p, C.c_int32, C.c_float, C.c_int64, C.c_uint64
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ('src0', c_void_p), ('src1', c_void_p), ('c_src0', c_int), ('c_src1', c_int), ('src0_shift', c_int),
+        ('src_f32', c_int), ('N', c_int), ('D', c_int), ('H', c_int), ('W', c_int),
+        ('in_scale', c_void_p), ('in_shift', c_void_p), ('act', c_int), ('noise', c_void_p), ('noise_pad', c_int),
+        ('istr', c_int), ('pad_mode', c_int), ('ntaps', c_int),
+        ('tap_d', C.c_int8 * VG_MAX_TAPS), ('tap_h', C.c_int8 * VG_MAX_TAPS), ('tap_w', C.c_int8 * VG_MAX_TAPS),
+        ('OD', c_int), ('OH', c_int), ('OW', c_int), ('ostr', c_int), ('ooff_d', c_int), ('ooff_h', c_int),
+        ('ooff_w', c_int), ('BD', c_int), ('BH', c_int), ('BW', c_int), ('Cout', c_int),
+        ('wpacked', c_void_p), ('CK', c_int), ('bias', c_void_p),
+        ('res', c_void_p), ('res_scale', c_void_p), ('res_shift', c_void_p), ('tanh_out', c_int),
+        ('out', c_void_p), ('out_f32', c_int), ('accumulate', c_int), ('out_sums', c_void_p),
+    ]
+
+
+class ActNormBwdDesc(C.Structure):
+    _fields_ = [
+        ('g', c_void_p), ('g_padded', c_int), ('x', c_void_p), ('x_f32', c_int),
+        ('x1', c_void_p), ('c_x0', c_int), ('x0_shift', c_int),
+        ('N', c_int), ('D', c_int), ('H', c_int), ('W', c_int), ('C', c_int),
+        ('scale', c_void_p), ('shift', c_void_p), ('mult', c_void_p), ('act', c_int), ('norm', c_int),
+        ('gamma', c_void_p), ('mean', c_void_p), ('rstd', c_void_p), ('red', c_void_p),
+        ('dx', c_void_p), ('dx_f32', c_int), ('accumulate', c_int), ('dx_cstride', c_int), ('dx_coff', c_int),
+    ]
+
+
+_SIGS = {
+    'vg_version': ([], c_int),
+    'vg_conv3d': ([C.POINTER(ConvDesc), c_void_p], c_int),
+    'vg_conv3d_lds_bytes': ([C.POINTER(ConvDesc)], c_int),
+    'vg_pack_weights': ([c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p], c_int),
+    'vg_packed_ktot': ([c_int, c_int, c_int], c_int),
+    'vg_packed_rows': ([c_int], c_int),
+    'vg_conv3d_wgrad': ([C.POINTER(ConvDesc), c_void_p, c_int, C.POINTER(c_int), c_void_p, c_void_p, c_void_p], c_int),
+    'vg_in_finalize': ([c_void_p, c_int, c_float, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p, c_int,
+                        c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], c_int),
+    'vg_actnorm_bwd_stats': ([C.POINTER(ActNormBwdDesc), c_void_p], c_int),
+    'vg_actnorm_bwd_apply': ([C.POINTER(ActNormBwdDesc), c_void_p], c_int),
+    'vg_in_param_grads': ([c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p], c_int),
+    'vg_concat_bwd': ([c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p], c_int),
+    'vg_tanh_bwd': ([c_void_p, c_void_p, c_void_p, c_i64, c_void_p], c_int),
+    'vg_minmax': ([c_void_p, c_int, c_i64, c_void_p, c_void_p], c_int),
+    'vg_minmax_apply': ([c_void_p, c_void_p, c_int, c_i64, c_void_p, c_void_p], c_int),
+    'vg_minmax_bwd': ([c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_i64, c_void_p, c_void_p, c_void_p], c_int),
+    'vg_bce': ([c_void_p, c_void_p, c_i64, c_void_p, c_float, c_void_p, c_int, c_void_p], c_int),
+    'vg_mse': ([c_void_p, c_void_p, c_i64, c_void_p, c_float, c_void_p, c_int, c_void_p], c_int),
+    'vg_mse_const': ([c_void_p, c_int, c_float, c_i64, c_void_p, c_float, c_void_p, c_int, c_void_p], c_int),
+    'vg_ssim_fwd': ([c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p], c_int),
+    'vg_ssim_bwd': ([c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p], c_int),
+    'vg_soft_skel_fwd': ([c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p], c_int),
+    'vg_soft_skel_bwd': ([c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p], c_int),
+    'vg_cldice_coef': ([c_void_p, c_float, c_float, c_void_p, c_void_p], c_int),
+    'vg_cldice_grads': ([c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_int, c_void_p], c_int),
+    'vg_dot_sums': ([c_void_p, c_void_p, c_i64, c_void_p, c_void_p], c_int),
+    'vg_axpby': ([c_void_p, c_float, c_void_p, c_float, c_i64, c_void_p, c_int, c_void_p], c_int),
+    'vg_adam_clip': ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_i64, c_void_p, c_float, c_float,
+                      c_float, c_float, c_float, c_float, c_void_p], c_int),
+    'vg_randn_bf16': ([c_void_p, c_i64, c_float, c_u64, c_u64, c_void_p], c_int),
+    'vg_dropout_mask': ([c_void_p, c_i64, c_float, c_u64, c_u64, c_void_p], c_int),
+    'vg_f32_to_bf16': ([c_void_p, c_void_p, c_i64, c_void_p], c_int),
+    'vg_bf16_to_f32': ([c_void_p, c_void_p, c_i64, c_void_p], c_int),
+}
+
+EXPORTS = sorted(list(_SIGS.keys()) + ['vg_status_string'])
+
+
+def _load():
+    path = _build.LIB
+    if not os.path.exists(path) or (_build.needs_build() and os.environ.get('VG_NO_REBUILD') != '1'):
+        try:
+            _build.build()
+        except Exception:
+            if not os.path.exists(path):
+                raise
+    lib = C.CDLL(path)
+    for name, (args, ret) in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = ret
+    lib.vg_status_string.argtypes = [c_int]
+    lib.vg_status_string.restype = C.c_char_p
+    return lib
+
+
+lib = _load()
+
+
+class VgError(RuntimeError):
+    pass
+
+
+def check(rc: int, what: str = '') -> int:
+    if rc < 0:
+        raise VgError('%s failed: %s (%d)' % (what or 'libvangan_hip call', lib.vg_status_string(rc).decode(), rc))
+    return rc

@@ -1,0 +1,269 @@
+// vg_conv.hip -- gather-convolution as an implicit GEMM on bf16 MFMA (gfx950).
+//
+// Replaces, for the VAN-GAN hot path: ReflectionPadding3D (building_blocks.py:30-39) + InstanceNorm
+// apply + ReLU/LeakyReLU (resunet_model.py:23-39, building_blocks.py:190-195) + UpSampling3D/concatenate
+// (resunet_model.py:175-181) + GaussianNoise/SpatialDropout3D + Conv3D (resunet_model.py:42-143,
+// discriminator.py:50-117) + Add/tanh, and the data gradient of those convolutions.
+//
+// Structure per workgroup (256 threads = 4 waves, one output tile of TDxTHxTW voxels x BN channels):
+//   for each chunk of CK contraction channels:
+//     stage the input HALO tile once into LDS, already normalised/activated/noised and rounded
+//     to bf16 (every input element is transformed once, not once per tap);
+//     for each K-step of 32 (tap, channel-group) pairs: MFMA 16x16x32 bf16 with
+//       A = packed weights (rows = output channels, straight from L2) and
+//       B = halo rows (cols = voxels, ds_read_b128 of 8 channels of one voxel),
+//     so the accumulator holds 4 consecutive output channels of one voxel per lane and the
+//     epilogue stores 8 B per lane, 512 B contiguous per 16-voxel subtile.
+//   epilogue: bias, residual*scale+shift, tanh, bf16 round, per-(n,c) sum / sum-of-squares of
+//   the stored values (for the next InstanceNorm), store or accumulate.
+#include "vg_gather.h"
+
+struct ConvOut {
+    int OD, OH, OW, ostr, ood, ooh, oow, BD, BH, BW, Cout;
+    const bf16_t* wp; int Ktot, nchunks, kc_pad;
+    const float* bias; const bf16_t* res; const float* rs; const float* rb; int tanh_out;
+    void* out; int out_f32, accumulate; float* sums;
+};
+
+template <int BN, int MSUB>
+__global__ __launch_bounds__(256) void conv_kernel(const GatherIn g, const ConvOut p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = blockIdx.z, ntile = blockIdx.y;
+    int t = blockIdx.x;
+    const int tw_i = t % g.tiles_w; t /= g.tiles_w;
+    const int th_i = t % g.tiles_h; const int td_i = t / g.tiles_h;
+    const int TWm = (1 << g.twl) - 1, THm = (1 << g.thl) - 1;
+    const int od0 = td_i << g.tdl, oh0 = th_i << g.thl, ow0 = tw_i << g.twl;
+
+    char* halo = smem;
+    const int hbytes = g.HD * g.HH * g.HW * g.RS;
+    int* tapoff = (int*)(smem + hbytes);
+    float* scs = (float*)(smem + hbytes + 256);
+    float* stat = scs + 2 * g.CK;
+
+    if (tid < g.ntaps)
+        tapoff[tid] = (((g.td[tid] - g.tmin_d) * g.HH + (g.th[tid] - g.tmin_h)) * g.HW + (g.tw[tid] - g.tmin_w)) * g.RS;
+    if (tid < BN * 2) stat[tid] = 0.f;
+
+    int rowbase[MSUB];
+#pragma unroll
+    for (int i = 0; i < MSUB; ++i) {
+        const int m = (wave * MSUB + i) * 16 + (lane & 15);
+        const int w = m & TWm, h = (m >> g.twl) & THm, d = m >> (g.twl + g.thl);
+        rowbase[i] = ((d * g.istr * g.HH + h * g.istr) * g.HW + w * g.istr) * g.RS;
+    }
+    f32x4 acc[BN / 16][MSUB];
+#pragma unroll
+    for (int a = 0; a < BN / 16; ++a)
+#pragma unroll
+        for (int i = 0; i < MSUB; ++i) acc[a][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int gpc = g.CK >> 3;
+    const int ngroups = g.ntaps * gpc;
+    const int ksteps = (ngroups + 3) >> 2;
+    const bf16_t* wrow[BN / 16];
+#pragma unroll
+    for (int a = 0; a < BN / 16; ++a)
+        wrow[a] = p.wp + (size_t)(ntile * BN + a * 16 + (lane & 15)) * p.Ktot + 8 * (lane >> 4);
+
+    for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+        __syncthreads();
+        stage_scale_shift(g, scs, n, chunk, tid);
+        __syncthreads();
+        stage_halo(g, halo, scs, n, od0, oh0, ow0, chunk, tid, 256);
+        __syncthreads();
+        // ---- MFMA over (tap, channel-group) pairs of this chunk ----
+        int tap = 0, cg = lane >> 4;
+        while (cg >= gpc) { cg -= gpc; ++tap; }
+        const size_t kbase = (size_t)chunk * p.kc_pad;
+        for (int s = 0; s < ksteps; ++s) {
+            const int tp = tap < g.ntaps ? tap : g.ntaps - 1;      // padded K: weights are zero there
+            const int off = tapoff[tp] + cg * 16;
+            bf16x8 b[MSUB];
+#pragma unroll
+            for (int i = 0; i < MSUB; ++i) b[i] = *(const bf16x8*)(halo + rowbase[i] + off);
+            bf16x8 a[BN / 16];
+#pragma unroll
+            for (int q = 0; q < BN / 16; ++q) a[q] = *(const bf16x8*)(wrow[q] + kbase + s * 32);
+#pragma unroll
+            for (int q = 0; q < BN / 16; ++q)
+#pragma unroll
+                for (int i = 0; i < MSUB; ++i)
+                    acc[q][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[q], b[i], acc[q][i], 0, 0, 0);
+            cg += 4;
+            while (cg >= gpc) { cg -= gpc; ++tap; }
+        }
+    }
+
+    // ---- epilogue: lane holds out channels co0..co0+3 of voxel (lane&15) of each subtile ----
+    float s1[BN / 16][4], s2[BN / 16][4];
+#pragma unroll
+    for (int q = 0; q < BN / 16; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s1[q][r] = 0.f; s2[q][r] = 0.f; }
+
+#pragma unroll
+    for (int i = 0; i < MSUB; ++i) {
+        const int m = (wave * MSUB + i) * 16 + (lane & 15);
+        const int w = m & TWm, h = (m >> g.twl) & THm, d = m >> (g.twl + g.thl);
+        const int od = od0 + d, oh = oh0 + h, ow = ow0 + w;
+        const bool inr = od < p.OD && oh < p.OH && ow < p.OW;
+        const size_t vox = ((size_t)(n * p.BD + od * p.ostr + p.ood) * p.BH + oh * p.ostr + p.ooh) * p.BW + ow * p.ostr + p.oow;
+#pragma unroll
+        for (int q = 0; q < BN / 16; ++q) {
+            const int co0 = ntile * BN + q * 16 + 4 * (lane >> 4);
+            if (!inr || co0 >= p.Cout) continue;
+            const size_t idx = vox * p.Cout + co0;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + r;
+                float y = acc[q][i][r];
+                if (co < p.Cout) {
+                    if (p.bias) y += p.bias[co];
+                    if (p.res) y += bf2f(p.res[idx + r]) * p.rs[n * p.Cout + co] + p.rb[n * p.Cout + co];
+                    if (p.tanh_out) y = tanhf(y);
+                    if (p.accumulate) y += p.out_f32 ? ((float*)p.out)[idx + r] : bf2f(((bf16_t*)p.out)[idx + r]);
+                    if (!p.out_f32) y = bfround(y);
+                    s1[q][r] += y; s2[q][r] += y * y;
+                }
+                v[r] = y;
+            }
+            if (p.out_f32) {
+                float* o = (float*)p.out + idx;
+                if (co0 + 3 < p.Cout) { *(f32x4*)o = (f32x4){v[0], v[1], v[2], v[3]}; }
+                else { for (int r = 0; r < 4; ++r) if (co0 + r < p.Cout) o[r] = v[r]; }
+            } else {
+                bf16_t* o = (bf16_t*)p.out + idx;
+                if (co0 + 3 < p.Cout) {
+                    bf16x4 pk = {(short)f2bf(v[0]), (short)f2bf(v[1]), (short)f2bf(v[2]), (short)f2bf(v[3])};
+                    *(bf16x4*)o = pk;
+                } else { for (int r = 0; r < 4; ++r) if (co0 + r < p.Cout) o[r] = f2bf(v[r]); }
+            }
+        }
+    }
+    if (p.sums) {
+#pragma unroll
+        for (int q = 0; q < BN / 16; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float a = s1[q][r], b = s2[q][r];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+                if ((lane & 15) == 0) {
+                    const int cl = q * 16 + 4 * (lane >> 4) + r;
+                    atomicAdd(&stat[cl * 2], a);
+                    atomicAdd(&stat[cl * 2 + 1], b);
+                }
+            }
+        __syncthreads();
+        if (tid < BN * 2) {
+            const int co = ntile * BN + (tid >> 1);
+            if (co < p.Cout) atomicAdd(&p.sums[((size_t)n * p.Cout + co) * 2 + (tid & 1)], stat[tid]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+static int fill_conv(const vg_conv_desc* d, GatherIn& g, ConvOut& k, int& BN, int& MSUB, int& lds) {
+    if (!d || !d->out || !d->wpacked) return VG_EINVAL;
+    if (d->Cout < 1 || (d->Cout != 1 && (d->Cout % 4))) return VG_EINVAL;
+    if (d->ostr < 1 || d->ostr > 2) return VG_EINVAL;
+    if (d->res && (!d->res_scale || !d->res_shift)) return VG_EINVAL;
+    BN = d->Cout <= 16 ? 16 : (d->Cout <= 32 ? 32 : 64);
+    int rc = VG_ELDS;
+    for (MSUB = 2; MSUB >= 1; --MSUB) {
+        rc = fill_gather(d, g, d->CK, 64 * MSUB);
+        if (rc != VG_OK) return rc;
+        lds = halo_bytes(g) + 256 + 2 * d->CK * 4 + BN * 2 * 4;
+        if (lds <= VG_LDS_LIMIT) break;
+        rc = VG_ELDS;
+    }
+    if (rc != VG_OK) return rc;
+    k.OD = d->OD; k.OH = d->OH; k.OW = d->OW; k.ostr = d->ostr; k.ood = d->ooff_d; k.ooh = d->ooff_h; k.oow = d->ooff_w;
+    k.BD = d->BD; k.BH = d->BH; k.BW = d->BW; k.Cout = d->Cout;
+    k.wp = (const bf16_t*)d->wpacked;
+    const int Cpad = ((g.Cin + d->CK - 1) / d->CK) * d->CK;
+    k.nchunks = Cpad / d->CK;
+    k.kc_pad = ((d->ntaps * d->CK + 31) / 32) * 32;
+    k.Ktot = k.nchunks * k.kc_pad;
+    k.bias = d->bias; k.res = (const bf16_t*)d->res; k.rs = d->res_scale; k.rb = d->res_shift; k.tanh_out = d->tanh_out;
+    k.out = d->out; k.out_f32 = d->out_f32; k.accumulate = d->accumulate; k.sums = d->out_sums;
+    return VG_OK;
+}
+
+extern "C" int vg_conv3d_lds_bytes(const vg_conv_desc* d) {
+    GatherIn g; ConvOut k; int BN, MSUB, lds;
+    int rc = fill_conv(d, g, k, BN, MSUB, lds);
+    return rc == VG_OK ? lds : rc;
+}
+
+template <int BN, int MSUB>
+static int launch_conv(const GatherIn& g, const ConvOut& k, int lds, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)conv_kernel<BN, MSUB>, hipFuncAttributeMaxDynamicSharedMemorySize, VG_LDS_LIMIT);
+        attr_set = true;
+    }
+    dim3 grid(g.tiles_d * g.tiles_h * g.tiles_w, (k.Cout + BN - 1) / BN, g.N);
+    hipLaunchKernelGGL((conv_kernel<BN, MSUB>), grid, dim3(256), lds, s, g, k);
+    return vg_check_launch();
+}
+
+extern "C" int vg_conv3d(const vg_conv_desc* d, vg_stream_t stream) {
+    GatherIn g; ConvOut k; int BN, MSUB, lds;
+    int rc = fill_conv(d, g, k, BN, MSUB, lds);
+    if (rc != VG_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    if (BN == 16) return MSUB == 2 ? launch_conv<16, 2>(g, k, lds, s) : launch_conv<16, 1>(g, k, lds, s);
+    if (BN == 32) return MSUB == 2 ? launch_conv<32, 2>(g, k, lds, s) : launch_conv<32, 1>(g, k, lds, s);
+    return MSUB == 2 ? launch_conv<64, 2>(g, k, lds, s) : launch_conv<64, 1>(g, k, lds, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing: fp32 DHWIO [T][Cin][Cout] -> bf16 [rows_pad][Ktot], k = chunk*kc_pad + tap*CK + ch
+// ------------------------------------------------------------------------------------------------
+__global__ void pack_weights_kernel(const float* __restrict__ w, int Cin, int Cout, const int* __restrict__ tap_idx,
+                                    int ntaps, int transpose, int CK, int kc_pad, int Ktot, int rows_pad,
+                                    bf16_t* __restrict__ out) {
+    const size_t total = (size_t)rows_pad * Ktot;
+    const int NR = transpose ? Cin : Cout;     // logical rows
+    const int C = transpose ? Cout : Cin;      // contraction channels
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int row = (int)(i / Ktot), k = (int)(i % Ktot);
+        const int chunk = k / kc_pad, kl = k % kc_pad;
+        const int tap = kl / CK, ch = chunk * CK + kl % CK;
+        float v = 0.f;
+        if (row < NR && tap < ntaps && ch < C) {
+            const int ts = tap_idx[tap];
+            v = transpose ? w[((size_t)ts * Cin + row) * Cout + ch] : w[((size_t)ts * Cin + ch) * Cout + row];
+        }
+        out[i] = f2bf(v);
+    }
+}
+
+extern "C" int vg_packed_ktot(int ntaps, int C, int CK) {
+    if (ntaps < 1 || C < 1 || CK < 16 || (CK % 16)) return VG_EINVAL;
+    const int nchunks = (C + CK - 1) / CK;
+    return nchunks * (((ntaps * CK + 31) / 32) * 32);
+}
+extern "C" int vg_packed_rows(int N) { return ((N + 63) / 64) * 64; }
+
+extern "C" int vg_pack_weights(const float* w, int T, int Cin, int Cout, const int32_t* tap_idx_dev, int ntaps,
+                               int transpose, int CK, void* out_bf16, vg_stream_t stream) {
+    if (!w || !tap_idx_dev || !out_bf16 || ntaps < 1 || ntaps > T) return VG_EINVAL;
+    const int C = transpose ? Cout : Cin, NR = transpose ? Cin : Cout;
+    const int Ktot = vg_packed_ktot(ntaps, C, CK);
+    if (Ktot < 0) return Ktot;
+    const int kc_pad = ((ntaps * CK + 31) / 32) * 32;
+    const int rows_pad = vg_packed_rows(NR);
+    const size_t total = (size_t)rows_pad * Ktot;
+    int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, Cin, Cout,
+                       tap_idx_dev, ntaps, transpose, CK, kc_pad, Ktot, rows_pad, (bf16_t*)out_bf16);
+    int rc = vg_check_launch();
+    return rc == VG_OK ? Ktot : rc;
+}

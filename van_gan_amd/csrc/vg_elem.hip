@@ -1,0 +1,425 @@
+// vg_elem.hip -- HBM-bound elementwise / reduction kernels around the convolutions:
+// InstanceNorm scale/shift finalisation, the backward of (InstanceNorm -> activation -> dropout) with the
+// transpose of ReflectionPadding3D folded into the read, the backward of the virtual upsample+concat,
+// tanh backward, dtype copies and the counter-based RNG for GaussianNoise / SpatialDropout3D.
+#include "vg_common.h"
+
+// ------------------------------------------------------------------------------------------------
+// InstanceNorm finalise (tfa InstanceNormalization: biased variance, eps inside rsqrt)
+// ------------------------------------------------------------------------------------------------
+__global__ void in_finalize_kernel(const float* sums0, int c0, float cnt0, const float* sums1, int c1, float cnt1,
+                                   const float* gamma, const float* beta, const float* mult, int N, float eps,
+                                   float* scale, float* shift, float* mean_o, float* rstd_o) {
+    const int C = c0 + c1;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * C) return;
+    const int n = i / C, c = i % C;
+    float s, ss, cnt;
+    if (c < c0) { s = sums0[((size_t)n * c0 + c) * 2]; ss = sums0[((size_t)n * c0 + c) * 2 + 1]; cnt = cnt0; }
+    else { s = sums1[((size_t)n * c1 + (c - c0)) * 2]; ss = sums1[((size_t)n * c1 + (c - c0)) * 2 + 1]; cnt = cnt1; }
+    const float mean = s / cnt;
+    float var = ss / cnt - mean * mean;
+    var = var < 0.f ? 0.f : var;
+    const float rstd = rsqrtf(var + eps);
+    float sc = (gamma ? gamma[c] : 1.f) * rstd;
+    float sh = (beta ? beta[c] : 0.f) - mean * sc;
+    if (mult) { const float m = mult[i]; sc *= m; sh *= m; }
+    scale[i] = sc; shift[i] = sh;
+    if (mean_o) mean_o[i] = mean;
+    if (rstd_o) rstd_o[i] = rstd;
+}
+
+extern "C" int vg_in_finalize(const float* sums0, int c0, float count0, const float* sums1, int c1, float count1,
+                              const float* gamma, const float* beta, const float* mult, int N, float eps,
+                              float* scale, float* shift, float* mean, float* rstd, vg_stream_t stream) {
+    if (!sums0 || c0 < 1 || c1 < 0 || (c1 > 0 && !sums1) || !scale || !shift || N < 1) return VG_EINVAL;
+    const int total = N * (c0 + c1);
+    hipLaunchKernelGGL(in_finalize_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums0, c0,
+                       count0, sums1, c1, count1, gamma, beta, mult, N, eps, scale, shift, mean, rstd);
+    return vg_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward of a = mult*act(x*scale+shift): stats pass and apply pass
+// ------------------------------------------------------------------------------------------------
+struct ANB {
+    const bf16_t* g; int g_padded;
+    const void* x; int x_f32;
+    const bf16_t* x1; int c_x0, x0_shift;
+    int N, D, H, W, C;
+    const float* scale; const float* shift; const float* mult;
+    int act, norm;
+    const float* gamma; const float* mean; const float* rstd;
+    float* red;
+    void* dx; int dx_f32, accumulate, dx_cstride, dx_coff;
+    int gpc, vpb;      // channel groups per voxel, voxels per block-iteration
+};
+
+// folded upstream gradient for VEC channels at voxel (d,h,w): transpose of reflect-pad-1
+template <int VEC>
+__device__ __forceinline__ void load_g(const ANB& p, int n, int d, int h, int w, int c, float* out) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) out[j] = 0.f;
+    if (!p.g_padded) {
+        const size_t idx = ((((size_t)n * p.D + d) * p.H + h) * p.W + w) * p.C + c;
+        if (VEC == 8) {
+            const bf16x8 r = *(const bf16x8*)(p.g + idx);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) out[j] = bf2f((bf16_t)r[j]);
+        } else out[0] = bf2f(p.g[idx]);
+        return;
+    }
+    const int PD = p.D + 2, PH = p.H + 2, PW = p.W + 2;
+    int qd[3], qh[3], qw[3], nd = 0, nh = 0, nw = 0;
+    qd[nd++] = d + 1; if (d == 1) qd[nd++] = 0; if (d == p.D - 2) qd[nd++] = p.D + 1;
+    qh[nh++] = h + 1; if (h == 1) qh[nh++] = 0; if (h == p.H - 2) qh[nh++] = p.H + 1;
+    qw[nw++] = w + 1; if (w == 1) qw[nw++] = 0; if (w == p.W - 2) qw[nw++] = p.W + 1;
+    for (int a = 0; a < nd; ++a)
+        for (int b = 0; b < nh; ++b)
+            for (int e = 0; e < nw; ++e) {
+                const size_t idx = ((((size_t)n * PD + qd[a]) * PH + qh[b]) * PW + qw[e]) * p.C + c;
+                if (VEC == 8) {
+                    const bf16x8 r = *(const bf16x8*)(p.g + idx);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) out[j] += bf2f((bf16_t)r[j]);
+                } else out[0] += bf2f(p.g[idx]);
+            }
+}
+
+template <int VEC>
+__device__ __forceinline__ void load_x(const ANB& p, int n, int d, int h, int w, int c, float* x) {
+    if (VEC == 8) {
+        bf16x8 r;
+        if (p.x1) {
+            if (c < p.c_x0) {
+                const int sh = p.x0_shift;
+                const size_t idx = ((((size_t)n * (p.D >> sh) + (d >> sh)) * (p.H >> sh) + (h >> sh)) * (p.W >> sh) + (w >> sh)) * p.c_x0 + c;
+                r = *(const bf16x8*)((const bf16_t*)p.x + idx);
+            } else {
+                const size_t idx = ((((size_t)n * p.D + d) * p.H + h) * p.W + w) * (p.C - p.c_x0) + (c - p.c_x0);
+                r = *(const bf16x8*)(p.x1 + idx);
+            }
+        } else {
+            const size_t idx = ((((size_t)n * p.D + d) * p.H + h) * p.W + w) * p.C + c;
+            r = *(const bf16x8*)((const bf16_t*)p.x + idx);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = bf2f((bf16_t)r[j]);
+    } else {
+        const size_t idx = (((size_t)n * p.D + d) * p.H + h) * p.W + w;
+        x[0] = p.x_f32 ? ((const float*)p.x)[idx] : bf2f(((const bf16_t*)p.x)[idx]);
+    }
+}
+
+// dn for VEC channels; also returns xhat when norm
+template <int VEC>
+__device__ __forceinline__ void compute_dn(const ANB& p, int n, int d, int h, int w, int c, float* dn, float* xh) {
+    float g[VEC];
+    load_g<VEC>(p, n, d, h, w, c, g);
+    const bool need_x = p.act != VG_ACT_NONE || p.norm;
+    float x[VEC];
+    if (need_x) load_x<VEC>(p, n, d, h, w, c, x);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        const int nc = n * p.C + c + j;
+        float v = g[j];
+        if (p.mult) v *= p.mult[nc];
+        if (p.act != VG_ACT_NONE) {
+            const float pre = p.scale ? x[j] * p.scale[nc] + p.shift[nc] : x[j];
+            v *= vg_act_grad(pre, p.act);
+        }
+        dn[j] = v;
+        xh[j] = p.norm ? (x[j] - p.mean[nc]) * p.rstd[nc] : 0.f;
+    }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void actnorm_stats_kernel(const ANB p) {
+    __shared__ float red[256 * 2];          // [thread][2] staging for one channel slot at a time
+    const int n = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int nthr = p.gpc * p.vpb;
+    const int cg = tid % p.gpc, vl = tid / p.gpc;
+    const int S = p.D * p.H * p.W;
+    float s0[VEC], s1[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { s0[j] = 0.f; s1[j] = 0.f; }
+    if (tid < nthr) {
+        for (int v = blockIdx.x * p.vpb + vl; v < S; v += gridDim.x * p.vpb) {
+            const int w = v % p.W; const int t = v / p.W; const int h = t % p.H, d = t / p.H;
+            float dn[VEC], xh[VEC];
+            compute_dn<VEC>(p, n, d, h, w, cg * VEC, dn, xh);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) { s0[j] += dn[j]; s1[j] += dn[j] * xh[j]; }
+        }
+    }
+    // reduce over the threads that share a channel group
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        __syncthreads();
+        red[tid * 2] = tid < nthr ? s0[j] : 0.f; red[tid * 2 + 1] = tid < nthr ? s1[j] : 0.f;
+        __syncthreads();
+        if (tid < p.gpc) {
+            float a = 0.f, b = 0.f;
+            for (int k = tid; k < nthr; k += p.gpc) { a += red[k * 2]; b += red[k * 2 + 1]; }
+            const int c = tid * VEC + j;
+            atomicAdd(&p.red[((size_t)n * p.C + c) * 2], a);
+            atomicAdd(&p.red[((size_t)n * p.C + c) * 2 + 1], b);
+        }
+    }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void actnorm_apply_kernel(const ANB p) {
+    const int n = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int nthr = p.gpc * p.vpb;
+    if (tid >= nthr) return;
+    const int cg = tid % p.gpc, vl = tid / p.gpc;
+    const int S = p.D * p.H * p.W;
+    const int c = cg * VEC;
+    float k0[VEC], k1[VEC], k2[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        if (p.norm) {
+            const int nc = n * p.C + c + j;
+            const float gr = p.gamma[c + j] * p.rstd[nc];
+            k0[j] = gr; k1[j] = gr * p.red[(size_t)nc * 2] / (float)S; k2[j] = gr * p.red[(size_t)nc * 2 + 1] / (float)S;
+        } else { k0[j] = 1.f; k1[j] = 0.f; k2[j] = 0.f; }
+    }
+    for (int v = blockIdx.x * p.vpb + vl; v < S; v += gridDim.x * p.vpb) {
+        const int w = v % p.W; const int t = v / p.W; const int h = t % p.H, d = t / p.H;
+        float dn[VEC], xh[VEC], o[VEC];
+        compute_dn<VEC>(p, n, d, h, w, c, dn, xh);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) o[j] = k0[j] * dn[j] - k1[j] - k2[j] * xh[j];
+        const size_t oidx = ((size_t)n * S + v) * p.dx_cstride + p.dx_coff + c;
+        if (p.dx_f32) {
+            float* q = (float*)p.dx + oidx;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) q[j] = p.accumulate ? q[j] + o[j] : o[j];
+        } else if (VEC == 8) {
+            bf16x8* q = (bf16x8*)((bf16_t*)p.dx + oidx);
+            bf16x8 r;
+            if (p.accumulate) {
+                const bf16x8 old = *q;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) r[j] = (short)f2bf(bf2f((bf16_t)old[j]) + o[j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) r[j] = (short)f2bf(o[j]);
+            }
+            *q = r;
+        } else {
+            bf16_t* q = (bf16_t*)p.dx + oidx;
+            q[0] = f2bf(p.accumulate ? bf2f(q[0]) + o[0] : o[0]);
+        }
+    }
+}
+
+static int fill_anb(const vg_actnorm_bwd_desc* d, ANB& p, bool apply) {
+    if (!d || !d->g || d->N < 1 || d->C < 1) return VG_EINVAL;
+    if (d->C != 1 && (d->C % 8)) return VG_EINVAL;
+    if (d->x_f32 && d->C != 1) return VG_EINVAL;
+    if ((d->act != VG_ACT_NONE || d->norm) && !d->x) return VG_EINVAL;
+    if (d->norm && (!d->mean || !d->rstd || !d->red)) return VG_EINVAL;
+    if (apply && (!d->dx || (d->norm && !d->gamma))) return VG_EINVAL;
+    if (d->g_padded && (d->D < 2 || d->H < 2 || d->W < 2)) return VG_EINVAL;
+    if (d->x1 && (d->C == 1 || (d->c_x0 % 8) || d->c_x0 < 8 || d->c_x0 >= d->C)) return VG_EINVAL;
+    p.g = (const bf16_t*)d->g; p.g_padded = d->g_padded; p.x = d->x; p.x_f32 = d->x_f32;
+    p.x1 = (const bf16_t*)d->x1; p.c_x0 = d->c_x0; p.x0_shift = d->x1 ? (d->x0_shift ? 1 : 0) : 0;
+    p.N = d->N; p.D = d->D; p.H = d->H; p.W = d->W; p.C = d->C;
+    p.scale = d->scale; p.shift = d->shift; p.mult = d->mult; p.act = d->act; p.norm = d->norm;
+    p.gamma = d->gamma; p.mean = d->mean; p.rstd = d->rstd; p.red = d->red;
+    p.dx = d->dx; p.dx_f32 = d->dx_f32; p.accumulate = d->accumulate;
+    p.dx_cstride = d->dx_cstride > 0 ? d->dx_cstride : d->C; p.dx_coff = d->dx_coff;
+    p.gpc = d->C == 1 ? 1 : d->C / 8;
+    if (p.gpc > 256) return VG_EINVAL;
+    p.vpb = 256 / p.gpc;
+    if (!p.dx_f32 && d->C != 1 && ((p.dx_cstride % 8) || (p.dx_coff % 8))) return VG_EINVAL;
+    return VG_OK;
+}
+static dim3 anb_grid(const ANB& p) {
+    const int S = p.D * p.H * p.W;
+    int bx = (S + p.vpb - 1) / p.vpb;
+    const int cap = 2048 / (p.N > 0 ? p.N : 1) + 1;
+    if (bx > cap) bx = cap;
+    return dim3(bx, p.N);
+}
+
+extern "C" int vg_actnorm_bwd_stats(const vg_actnorm_bwd_desc* d, vg_stream_t stream) {
+    ANB p; int rc = fill_anb(d, p, false);
+    if (rc != VG_OK) return rc;
+    if (!p.red) return VG_EINVAL;
+    if (p.C == 1) hipLaunchKernelGGL(actnorm_stats_kernel<1>, anb_grid(p), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(actnorm_stats_kernel<8>, anb_grid(p), dim3(256), 0, (hipStream_t)stream, p);
+    return vg_check_launch();
+}
+extern "C" int vg_actnorm_bwd_apply(const vg_actnorm_bwd_desc* d, vg_stream_t stream) {
+    ANB p; int rc = fill_anb(d, p, true);
+    if (rc != VG_OK) return rc;
+    if (p.C == 1) hipLaunchKernelGGL(actnorm_apply_kernel<1>, anb_grid(p), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(actnorm_apply_kernel<8>, anb_grid(p), dim3(256), 0, (hipStream_t)stream, p);
+    return vg_check_launch();
+}
+
+__global__ void in_param_grads_kernel(const float* red, int N, int C, float* dgamma, float* dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float a = 0.f, b = 0.f;
+    for (int n = 0; n < N; ++n) { a += red[((size_t)n * C + c) * 2]; b += red[((size_t)n * C + c) * 2 + 1]; }
+    dbeta[c] += a; dgamma[c] += b;
+}
+extern "C" int vg_in_param_grads(const float* red, int N, int C, float* dgamma, float* dbeta, vg_stream_t stream) {
+    if (!red || !dgamma || !dbeta || N < 1 || C < 1) return VG_EINVAL;
+    hipLaunchKernelGGL(in_param_grads_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, red, N, C, dgamma, dbeta);
+    return vg_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward of UpSampling3D(2) + concatenate (resunet_model.py:175-181)
+// ------------------------------------------------------------------------------------------------
+__global__ void concat_bwd_kernel(const bf16_t* g, int N, int D, int H, int W, int Cu, int Cs, bf16_t* dlow, bf16_t* dskip) {
+    const int C = Cu + Cs;
+    const int gu = Cu / 8, gs = Cs / 8;
+    const size_t nlow = (size_t)N * (D / 2) * (H / 2) * (W / 2) * gu;
+    const size_t nskip = (size_t)N * D * H * W * gs;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nlow + nskip; i += (size_t)gridDim.x * blockDim.x) {
+        if (i < nlow) {
+            const int cg = (int)(i % gu); size_t v = i / gu;
+            const int w = (int)(v % (W / 2)); v /= (W / 2);
+            const int h = (int)(v % (H / 2)); v /= (H / 2);
+            const int d = (int)(v % (D / 2)); const int n = (int)(v / (D / 2));
+            float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) for (int e = 0; e < 2; ++e) {
+                const size_t idx = ((((size_t)n * D + 2 * d + a) * H + 2 * h + b) * W + 2 * w + e) * C + cg * 8;
+                const bf16x8 r = *(const bf16x8*)(g + idx);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s[j] += bf2f((bf16_t)r[j]);
+            }
+            bf16x8* q = (bf16x8*)(dlow + i * 8);
+            const bf16x8 old = *q; bf16x8 r;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] = (short)f2bf(bf2f((bf16_t)old[j]) + s[j]);
+            *q = r;
+        } else {
+            const size_t k = i - nlow;
+            const int cg = (int)(k % gs); const size_t v = k / gs;
+            const bf16x8 a = *(const bf16x8*)(g + v * C + Cu + cg * 8);
+            bf16x8* q = (bf16x8*)(dskip + k * 8);
+            const bf16x8 old = *q; bf16x8 r;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] = (short)f2bf(bf2f((bf16_t)old[j]) + bf2f((bf16_t)a[j]));
+            *q = r;
+        }
+    }
+}
+extern "C" int vg_concat_bwd(const void* g, int N, int D, int H, int W, int Cu, int Cs, void* dlow, void* dskip,
+                             vg_stream_t stream) {
+    if (!g || !dlow || !dskip || (Cu % 8) || (Cs % 8) || Cu < 8 || Cs < 8 || ((D | H | W) & 1)) return VG_EINVAL;
+    const size_t total = (size_t)N * (D / 2) * (H / 2) * (W / 2) * (Cu / 8) + (size_t)N * D * H * W * (Cs / 8);
+    int blocks = (int)((total + 255) / 256); if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(concat_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)g, N, D, H, W, Cu,
+                       Cs, (bf16_t*)dlow, (bf16_t*)dskip);
+    return vg_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------
+// small elementwise helpers
+// ------------------------------------------------------------------------------------------------
+__global__ void tanh_bwd_kernel(const float* dy, const float* y, float* dpre, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dpre[i] = dy[i] * (1.f - y[i] * y[i]);
+}
+__global__ void axpby_kernel(const float* a, float alpha, const float* b, float beta, int64_t n, float* y, int acc) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float v = alpha * a[i] + (b ? beta * b[i] : 0.f);
+        y[i] = acc ? y[i] + v : v;
+    }
+}
+__global__ void f32_to_bf16_kernel(const float* x, bf16_t* y, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) y[i] = f2bf(x[i]);
+}
+__global__ void bf16_to_f32_kernel(const bf16_t* x, float* y, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) y[i] = bf2f(x[i]);
+}
+static inline int ew_blocks(int64_t n) { int64_t b = (n + 255) / 256; return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b)); }
+
+extern "C" int vg_tanh_bwd(const float* dy, const float* y, float* dpre, int64_t n, vg_stream_t stream) {
+    if (!dy || !y || !dpre || n < 0) return VG_EINVAL;
+    hipLaunchKernelGGL(tanh_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, dy, y, dpre, n);
+    return vg_check_launch();
+}
+extern "C" int vg_axpby(const float* a, float alpha, const float* b, float beta, int64_t n, float* y, int accumulate,
+                        vg_stream_t stream) {
+    if (!a || !y || n < 0) return VG_EINVAL;
+    hipLaunchKernelGGL(axpby_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, alpha, b, beta, n, y, accumulate);
+    return vg_check_launch();
+}
+extern "C" int vg_f32_to_bf16(const float* x, void* y, int64_t n, vg_stream_t stream) {
+    if (!x || !y || n < 0) return VG_EINVAL;
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)y, n);
+    return vg_check_launch();
+}
+extern "C" int vg_bf16_to_f32(const void* x, float* y, int64_t n, vg_stream_t stream) {
+    if (!x || !y || n < 0) return VG_EINVAL;
+    hipLaunchKernelGGL(bf16_to_f32_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, y, n);
+    return vg_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------
+// counter-based RNG (Philox-4x32-10) for GaussianNoise / SpatialDropout3D
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+__device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+
+__global__ void randn_bf16_kernel(bf16_t* out, int64_t n, float std, uint64_t seed, uint64_t offset) {
+    const int64_t nq = (n + 3) / 4;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t ctr = offset + (uint64_t)q;
+        uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0x5eedu, 0u};
+        philox4(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+        const float r0 = sqrtf(-2.f * __logf(u01(c[0]))), r1 = sqrtf(-2.f * __logf(u01(c[2])));
+        const float t0 = 6.28318530718f * u01(c[1]), t1 = 6.28318530718f * u01(c[3]);
+        const float z[4] = {r0 * __cosf(t0), r0 * __sinf(t0), r1 * __cosf(t1), r1 * __sinf(t1)};
+        for (int j = 0; j < 4; ++j) if (q * 4 + j < n) out[q * 4 + j] = f2bf(std * z[j]);
+    }
+}
+__global__ void dropout_mask_kernel(float* out, int64_t n, float rate, uint64_t seed, uint64_t offset) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t ctr = offset + (uint64_t)i;
+        uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0xd60bu, 0u};
+        philox4(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+        out[i] = u01(c[0]) < rate ? 0.f : 1.f / (1.f - rate);
+    }
+}
+extern "C" int vg_randn_bf16(void* out, int64_t n, float std, uint64_t seed, uint64_t offset, vg_stream_t stream) {
+    if (!out || n < 0) return VG_EINVAL;
+    hipLaunchKernelGGL(randn_bf16_kernel, dim3(ew_blocks((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)out, n, std, seed, offset);
+    return vg_check_launch();
+}
+extern "C" int vg_dropout_mask(float* out, int64_t n, float rate, uint64_t seed, uint64_t offset, vg_stream_t stream) {
+    if (!out || n < 0 || rate < 0.f || rate >= 1.f) return VG_EINVAL;
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, out, n, rate, seed, offset);
+    return vg_check_launch();
+}
+
+extern "C" const char* vg_status_string(int code) {
+    switch (code) {
+        case VG_OK: return "ok";
+        case VG_EINVAL: return "invalid argument or unsupported shape";
+        case VG_ELDS: return "tile does not fit in LDS";
+        case VG_ELAUNCH: return "HIP launch failure";
+        default: return "unknown status";
+    }
+}
+extern "C" int vg_version(void) { return 1; }

@@ -1,0 +1,128 @@
+// vg_gather.h -- the input side shared by the forward/data-gradient kernel (vg_conv.hip) and the
+// weight-gradient kernel (vg_wgrad.hip): description of the gathered operand and the routine that
+// stages one halo tile of it into LDS (normalised, activated, noised, rounded to bf16).
+#pragma once
+#include "vg_common.h"
+
+struct GatherIn {
+    const void* src0; const void* src1;
+    int c0, c1, shift0, src_f32;
+    int N, D, H, W, Cin;
+    const float* in_scale; const float* in_shift; int act;
+    const bf16_t* noise; int npad;
+    int istr, pad_mode, ntaps;
+    int8_t td[VG_MAX_TAPS], th[VG_MAX_TAPS], tw[VG_MAX_TAPS];
+    int tmin_d, tmin_h, tmin_w, HD, HH, HW, RS, CK;
+    int tdl, thl, twl, tiles_d, tiles_h, tiles_w;
+};
+
+__device__ __forceinline__ bool resolve_pos(int& p, int n, int mode) {
+    if (mode == VG_PAD_REFLECT) {
+        if (p < 0) p = -p;
+        if (p >= n) p = 2 * n - 2 - p;
+        p = p < 0 ? 0 : (p >= n ? n - 1 : p);   // tile overhang only (those outputs are masked)
+        return true;
+    }
+    return p >= 0 && p < n;
+}
+
+// scs: LDS floats [2*CK] (scale then shift) for channels chunk*CK .. +CK of sample n.
+__device__ __forceinline__ void stage_scale_shift(const GatherIn& g, float* scs, int n, int chunk, int tid) {
+    if (tid < g.CK) {
+        const int c = chunk * g.CK + tid;
+        float sc = 1.f, sh = 0.f;
+        if (g.in_scale && c < g.Cin) { sc = g.in_scale[n * g.Cin + c]; sh = g.in_shift[n * g.Cin + c]; }
+        scs[tid] = sc; scs[g.CK + tid] = sh;
+    }
+}
+
+// Stage the halo tile whose output-tile origin is (od0,oh0,ow0): units of (halo voxel, 8 channels) = 16 B.
+__device__ __forceinline__ void stage_halo(const GatherIn& g, char* halo, const float* scs, int n, int od0, int oh0,
+                                           int ow0, int chunk, int tid, int nthreads) {
+    const int gpc = g.CK >> 3;
+    const int units = g.HD * g.HH * g.HW * gpc;
+    const int Ds = g.D >> g.shift0, Hs = g.H >> g.shift0, Ws = g.W >> g.shift0;
+    const int ND = g.D + 2 * g.npad, NH = g.H + 2 * g.npad, NW = g.W + 2 * g.npad;
+    for (int u = tid; u < units; u += nthreads) {
+        const int hv = u / gpc, cg = u - hv * gpc;
+        const int hw = hv % g.HW; const int t2 = hv / g.HW;
+        const int hh = t2 % g.HH, hd = t2 / g.HH;
+        int pd = od0 * g.istr + g.tmin_d + hd, ph = oh0 * g.istr + g.tmin_h + hh, pw = ow0 * g.istr + g.tmin_w + hw;
+        const int qd = pd + g.npad, qh = ph + g.npad, qw = pw + g.npad;        // position on the noise grid
+        bool valid = resolve_pos(pd, g.D, g.pad_mode);
+        valid &= resolve_pos(ph, g.H, g.pad_mode);
+        valid &= resolve_pos(pw, g.W, g.pad_mode);
+        const int c = chunk * g.CK + cg * 8;
+        bf16x8 v = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        if (valid && c < g.Cin) {
+            float x[8];
+            int nval = 8;
+            if (g.Cin == 1) {
+                nval = 1;
+                const size_t idx = ((size_t)(n * g.D + pd) * g.H + ph) * g.W + pw;
+                x[0] = g.src_f32 ? ((const float*)g.src0)[idx] : bf2f(((const bf16_t*)g.src0)[idx]);
+            } else {
+                bf16x8 raw;
+                if (c < g.c0) {
+                    const size_t idx = (((size_t)(n * Ds + (pd >> g.shift0)) * Hs + (ph >> g.shift0)) * Ws + (pw >> g.shift0)) * g.c0 + c;
+                    raw = *(const bf16x8*)((const bf16_t*)g.src0 + idx);
+                } else {
+                    const size_t idx = (((size_t)(n * g.D + pd) * g.H + ph) * g.W + pw) * g.c1 + (c - g.c0);
+                    raw = *(const bf16x8*)((const bf16_t*)g.src1 + idx);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] = bf2f((bf16_t)raw[j]);
+            }
+            const bool has_noise = g.noise && qd >= 0 && qd < ND && qh >= 0 && qh < NH && qw >= 0 && qw < NW;
+            const size_t nidx = has_noise ? ((((size_t)(n * ND + qd) * NH + qh) * NW + qw) * g.Cin + c) : 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (j < nval) {
+                    float y = vg_act(x[j] * scs[cg * 8 + j] + scs[g.CK + cg * 8 + j], g.act);
+                    if (has_noise) y += bf2f(g.noise[nidx + j]);
+                    v[j] = (short)f2bf(y);
+                }
+            }
+        }
+        *(bf16x8*)(halo + (size_t)hv * g.RS + cg * 16) = v;
+    }
+}
+
+// ---- host: validate the input side of a descriptor and derive the tile geometry for BM voxels ----
+static inline int fill_gather(const vg_conv_desc* d, GatherIn& g, int CK, int BM) {
+    if (!d || !d->src0) return VG_EINVAL;
+    const int Cin = d->c_src0 + d->c_src1;
+    if (Cin < 1 || d->ntaps < 1 || d->ntaps > VG_MAX_TAPS) return VG_EINVAL;
+    if (Cin != 1 && ((d->c_src0 % 8) || (d->c_src1 % 8))) return VG_EINVAL;
+    if (Cin == 1 && (d->src1 || d->src0_shift)) return VG_EINVAL;
+    if (d->src_f32 && Cin != 1) return VG_EINVAL;
+    if (d->c_src1 > 0 && !d->src1) return VG_EINVAL;
+    if (CK < 16 || (CK % 16) || CK > 128) return VG_EINVAL;
+    if (d->istr < 1 || d->istr > 2) return VG_EINVAL;
+    if (d->src0_shift && ((d->D | d->H | d->W) & 1)) return VG_EINVAL;
+    if (d->pad_mode == VG_PAD_REFLECT && (d->D < 2 || d->H < 2 || d->W < 2)) return VG_EINVAL;
+    if (d->N < 1 || d->OD < 1 || d->OH < 1 || d->OW < 1) return VG_EINVAL;
+    g.src0 = d->src0; g.src1 = d->src1; g.c0 = d->c_src0; g.c1 = d->c_src1; g.shift0 = d->src0_shift ? 1 : 0;
+    g.src_f32 = d->src_f32; g.N = d->N; g.D = d->D; g.H = d->H; g.W = d->W; g.Cin = Cin;
+    g.in_scale = d->in_scale; g.in_shift = d->in_shift; g.act = d->act;
+    g.noise = (const bf16_t*)d->noise; g.npad = d->noise ? d->noise_pad : 0;
+    g.istr = d->istr; g.pad_mode = d->pad_mode; g.ntaps = d->ntaps; g.CK = CK;
+    int mn[3] = {127, 127, 127}, mx[3] = {-128, -128, -128};
+    for (int i = 0; i < d->ntaps; ++i) {
+        g.td[i] = d->tap_d[i]; g.th[i] = d->tap_h[i]; g.tw[i] = d->tap_w[i];
+        const int v[3] = {d->tap_d[i], d->tap_h[i], d->tap_w[i]};
+        for (int a = 0; a < 3; ++a) { if (v[a] < mn[a]) mn[a] = v[a]; if (v[a] > mx[a]) mx[a] = v[a]; }
+    }
+    g.tmin_d = mn[0]; g.tmin_h = mn[1]; g.tmin_w = mn[2];
+    g.RS = CK * 2 + 16;
+    int TW = pow2_ceil(d->OW); if (TW > 16) TW = 16;
+    int TH = pow2_ceil(d->OH); if (TH > BM / TW) TH = BM / TW;
+    int TD = BM / (TW * TH);
+    g.twl = ilog2_exact(TW); g.thl = ilog2_exact(TH); g.tdl = ilog2_exact(TD);
+    g.tiles_w = (d->OW + TW - 1) / TW; g.tiles_h = (d->OH + TH - 1) / TH; g.tiles_d = (d->OD + TD - 1) / TD;
+    g.HD = (TD - 1) * d->istr + (mx[0] - mn[0]) + 1;
+    g.HH = (TH - 1) * d->istr + (mx[1] - mn[1]) + 1;
+    g.HW = (TW - 1) * d->istr + (mx[2] - mn[2]) + 1;
+    return VG_OK;
+}
+static inline int halo_bytes(const GatherIn& g) { return g.HD * g.HH * g.HW * g.RS; }

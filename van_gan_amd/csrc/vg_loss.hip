@@ -1,0 +1,426 @@
+// vg_loss.hip -- HBM-bound fp32 loss kernels on single-channel volumes [B][S]:
+// min_max_norm_tf (utils.py:27-48) fwd/bwd, Keras BCE (loss_functions.py:185-190), MSE / LSGAN terms
+// (loss_functions.py:56-68,273-274,306-308), 3-D SSIM (loss_functions.py:86-117) fwd/bwd, and the clDice
+// soft skeleton (clDice_func.py:8-149) fwd/bwd.
+#include "vg_common.h"
+
+static inline int lblocks(int64_t n, int per = 256) { int64_t b = (n + per - 1) / per; return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b)); }
+
+__device__ __forceinline__ float block_sum(float v, float* sm) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sm[wv] = v;
+    __syncthreads();
+    float r = 0.f;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) r += sm[i];
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// min-max normalisation
+// ------------------------------------------------------------------------------------------------
+__global__ void mm_init_kernel(float* mm4, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) { mm4[b * 4] = INFINITY; mm4[b * 4 + 1] = -INFINITY; mm4[b * 4 + 2] = 0.f; mm4[b * 4 + 3] = 0.f; }
+}
+__device__ __forceinline__ void atomic_min_f(float* a, float v) {
+    unsigned* ua = (unsigned*)a; unsigned old = *ua;
+    while (v < __uint_as_float(old)) { const unsigned prev = atomicCAS(ua, old, __float_as_uint(v)); if (prev == old) break; old = prev; }
+}
+__device__ __forceinline__ void atomic_max_f(float* a, float v) {
+    unsigned* ua = (unsigned*)a; unsigned old = *ua;
+    while (v > __uint_as_float(old)) { const unsigned prev = atomicCAS(ua, old, __float_as_uint(v)); if (prev == old) break; old = prev; }
+}
+__global__ void mm_reduce_kernel(const float* x, int64_t S, float* mm4) {
+    __shared__ float smn[4], smx[4];
+    const int b = blockIdx.y;
+    const float* xb = x + (size_t)b * S;
+    float mn = INFINITY, mx = -INFINITY;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < S; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = xb[i]; mn = fminf(mn, v); mx = fmaxf(mx, v);
+    }
+    mn = wave_min(mn); mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) { smn[threadIdx.x >> 6] = mn; smx[threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 4; ++i) { mn = fminf(mn, smn[i]); mx = fmaxf(mx, smx[i]); }
+        atomic_min_f(&mm4[b * 4], mn); atomic_max_f(&mm4[b * 4 + 1], mx);
+    }
+}
+__global__ void mm_count_kernel(const float* x, int64_t S, float* mm4) {
+    __shared__ float sm[4];
+    const int b = blockIdx.y;
+    const float* xb = x + (size_t)b * S;
+    const float mn = mm4[b * 4], mx = mm4[b * 4 + 1];
+    float c0 = 0.f, c1 = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < S; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = xb[i]; c0 += (v == mn) ? 1.f : 0.f; c1 += (v == mx) ? 1.f : 0.f;
+    }
+    c0 = block_sum(c0, sm); c1 = block_sum(c1, sm);
+    if (threadIdx.x == 0) { if (c0 != 0.f) atomicAdd(&mm4[b * 4 + 2], c0); if (c1 != 0.f) atomicAdd(&mm4[b * 4 + 3], c1); }
+}
+extern "C" int vg_minmax(const float* x, int B, int64_t S, float* mm4, vg_stream_t stream) {
+    if (!x || !mm4 || B < 1 || S < 1) return VG_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(mm_init_kernel, dim3((B + 63) / 64), dim3(64), 0, s, mm4, B);
+    const int bx = lblocks(S, 1024) > 512 ? 512 : lblocks(S, 1024);
+    hipLaunchKernelGGL(mm_reduce_kernel, dim3(bx, B), dim3(256), 0, s, x, S, mm4);
+    hipLaunchKernelGGL(mm_count_kernel, dim3(bx, B), dim3(256), 0, s, x, S, mm4);
+    return vg_check_launch();
+}
+__global__ void mm_apply_kernel(const float* x, const float* mm4, int64_t S, float* y) {
+    const int b = blockIdx.y;
+    const float mn = mm4[b * 4], r = mm4[b * 4 + 1] - mn;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < S; i += (int64_t)gridDim.x * blockDim.x)
+        y[(size_t)b * S + i] = (x[(size_t)b * S + i] - mn) / r;
+}
+extern "C" int vg_minmax_apply(const float* x, const float* mm4, int B, int64_t S, float* y, vg_stream_t stream) {
+    if (!x || !mm4 || !y || B < 1 || S < 1) return VG_EINVAL;
+    hipLaunchKernelGGL(mm_apply_kernel, dim3(lblocks(S), B), dim3(256), 0, (hipStream_t)stream, x, mm4, S, y);
+    return vg_check_launch();
+}
+__global__ void mm_bwd_sums_kernel(const float* y, const float* gy, int64_t S, float* tmp2) {
+    __shared__ float sm[4];
+    const int b = blockIdx.y;
+    float a = 0.f, c = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < S; i += (int64_t)gridDim.x * blockDim.x) {
+        const float g = gy[(size_t)b * S + i], v = y[(size_t)b * S + i];
+        a += g * (v - 1.f); c += g * v;
+    }
+    a = block_sum(a, sm); c = block_sum(c, sm);
+    if (threadIdx.x == 0) { atomicAdd(&tmp2[b * 2], a); atomicAdd(&tmp2[b * 2 + 1], c); }
+}
+__global__ void mm_bwd_apply_kernel(const float* x, const float* gy, const float* mm4, const float* tmp2, int64_t S, float* dx) {
+    const int b = blockIdx.y;
+    const float mn = mm4[b * 4], mx = mm4[b * 4 + 1], r = mx - mn;
+    const float gmn = tmp2[b * 2] / (r * mm4[b * 4 + 2]), gmx = -tmp2[b * 2 + 1] / (r * mm4[b * 4 + 3]);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < S; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = x[(size_t)b * S + i];
+        float g = gy[(size_t)b * S + i] / r;
+        if (v == mn) g += gmn;
+        if (v == mx) g += gmx;
+        dx[(size_t)b * S + i] = g;
+    }
+}
+extern "C" int vg_minmax_bwd(const float* x, const float* y, const float* gy, const float* mm4, int B, int64_t S,
+                             float* tmp2, float* dx, vg_stream_t stream) {
+    if (!x || !y || !gy || !mm4 || !tmp2 || !dx || B < 1 || S < 1) return VG_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const int bx = lblocks(S, 1024) > 512 ? 512 : lblocks(S, 1024);
+    hipLaunchKernelGGL(mm_bwd_sums_kernel, dim3(bx, B), dim3(256), 0, s, y, gy, S, tmp2);
+    hipLaunchKernelGGL(mm_bwd_apply_kernel, dim3(lblocks(S), B), dim3(256), 0, s, x, gy, mm4, tmp2, S, dx);
+    return vg_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------
+// BCE / MSE
+// ------------------------------------------------------------------------------------------------
+#define VG_BCE_EPS 1e-7f
+__global__ void bce_kernel(const float* t, const float* p, int64_t n, float* acc, float gscale, float* gp, int accum) {
+    __shared__ float sm[4];
+    float s = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float y = t[i], pr = p[i];
+        const float pc = fminf(fmaxf(pr, VG_BCE_EPS), 1.f - VG_BCE_EPS);
+        const float a = pc + VG_BCE_EPS, c = 1.f - pc + VG_BCE_EPS;
+        s += -(y * logf(a) + (1.f - y) * logf(c));
+        if (gp) {
+            const bool pass = pr >= VG_BCE_EPS && pr <= 1.f - VG_BCE_EPS;
+            const float g = pass ? gscale * (-(y / a) + (1.f - y) / c) : 0.f;
+            gp[i] = accum ? gp[i] + g : g;
+        }
+    }
+    s = block_sum(s, sm);
+    if (threadIdx.x == 0) atomicAdd(acc, s);
+}
+extern "C" int vg_bce(const float* t, const float* p, int64_t n, float* acc, float gscale, float* gp, int accumulate,
+                      vg_stream_t stream) {
+    if (!t || !p || !acc || n < 1) return VG_EINVAL;
+    hipLaunchKernelGGL(bce_kernel, dim3(lblocks(n, 1024)), dim3(256), 0, (hipStream_t)stream, t, p, n, acc, gscale, gp, accumulate);
+    return vg_check_launch();
+}
+__global__ void mse_kernel(const float* a, const float* b, int64_t n, float* acc, float gscale, float* gb, int accum) {
+    __shared__ float sm[4];
+    float s = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float d = b[i] - a[i];
+        s += d * d;
+        if (gb) { const float g = gscale * 2.f * d; gb[i] = accum ? gb[i] + g : g; }
+    }
+    s = block_sum(s, sm);
+    if (threadIdx.x == 0) atomicAdd(acc, s);
+}
+extern "C" int vg_mse(const float* a, const float* b, int64_t n, float* acc, float gscale, float* gb, int accumulate,
+                      vg_stream_t stream) {
+    if (!a || !b || !acc || n < 1) return VG_EINVAL;
+    hipLaunchKernelGGL(mse_kernel, dim3(lblocks(n, 1024)), dim3(256), 0, (hipStream_t)stream, a, b, n, acc, gscale, gb, accumulate);
+    return vg_check_launch();
+}
+__global__ void mse_const_kernel(const void* x, int x_f32, float target, int64_t n, float* acc, float gscale, float* gx, int accum) {
+    __shared__ float sm[4];
+    float s = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = x_f32 ? ((const float*)x)[i] : bf2f(((const bf16_t*)x)[i]);
+        const float d = v - target;
+        s += d * d;
+        if (gx) { const float g = gscale * 2.f * d; gx[i] = accum ? gx[i] + g : g; }
+    }
+    s = block_sum(s, sm);
+    if (threadIdx.x == 0) atomicAdd(acc, s);
+}
+extern "C" int vg_mse_const(const void* x, int x_f32, float target, int64_t n, float* acc, float gscale, float* gx,
+                            int accumulate, vg_stream_t stream) {
+    if (!x || !acc || n < 1) return VG_EINVAL;
+    hipLaunchKernelGGL(mse_const_kernel, dim3(lblocks(n, 1024)), dim3(256), 0, (hipStream_t)stream, x, x_f32, target, n, acc,
+                       gscale, gx, accumulate);
+    return vg_check_launch();
+}
+__global__ void dot_sums_kernel(const float* a, const float* b, int64_t n, float* sums3) {
+    __shared__ float sm[4];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float x = a[i], y = b[i]; s0 += x * y; s1 += x; s2 += y;
+    }
+    s0 = block_sum(s0, sm); s1 = block_sum(s1, sm); s2 = block_sum(s2, sm);
+    if (threadIdx.x == 0) { atomicAdd(&sums3[0], s0); atomicAdd(&sums3[1], s1); atomicAdd(&sums3[2], s2); }
+}
+extern "C" int vg_dot_sums(const float* a, const float* b, int64_t n, float* sums3, vg_stream_t stream) {
+    if (!a || !b || !sums3 || n < 1) return VG_EINVAL;
+    hipLaunchKernelGGL(dot_sums_kernel, dim3(lblocks(n, 1024)), dim3(256), 0, (hipStream_t)stream, a, b, n, sums3);
+    return vg_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------
+// SSIM with a 3^3 Gaussian (sigma 1.5), zero 'SAME' padding
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void gauss3(float* g) {
+    const float e = expf(-0.5f * (1.f / 1.5f) * (1.f / 1.5f));       // loss_functions.py:88-91
+    const float s = 1.f + 2.f * e;
+    g[0] = e / s; g[1] = 1.f / s; g[2] = e / s;
+}
+#define SSIM_C1 1e-4f
+#define SSIM_C2 9e-4f
+__global__ void ssim_fwd_kernel(const float* t, const float* p, int B, int D, int H, int W, float* acc, float* part) {
+    __shared__ float sm[4];
+    float g[3]; gauss3(g);
+    const int64_t S = (int64_t)D * H * W, total = (int64_t)B * S;
+    float loss = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int w = (int)(i % W); int64_t r = i / W; const int h = (int)(r % H); r /= H; const int d = (int)(r % D); const int b = (int)(r / D);
+        float mt = 0.f, mp = 0.f, ett = 0.f, epp = 0.f, etp = 0.f;
+        for (int a = -1; a <= 1; ++a) { const int dd = d + a; if (dd < 0 || dd >= D) continue;
+            for (int c = -1; c <= 1; ++c) { const int hh = h + c; if (hh < 0 || hh >= H) continue;
+                for (int e = -1; e <= 1; ++e) { const int ww = w + e; if (ww < 0 || ww >= W) continue;
+                    const float wt = g[a + 1] * g[c + 1] * g[e + 1];
+                    const size_t j = (size_t)b * S + ((size_t)dd * H + hh) * W + ww;
+                    const float tv = t[j], pv = p[j];
+                    mt += wt * tv; mp += wt * pv; ett += wt * tv * tv; epp += wt * pv * pv; etp += wt * tv * pv;
+                } } }
+        const float stt = ett - mt * mt, spp = epp - mp * mp, stp = etp - mt * mp;
+        const float A = 2.f * mt * mp + SSIM_C1, Bq = 2.f * stp + SSIM_C2;
+        const float Cq = mt * mt + mp * mp + SSIM_C1, Dq = stt + spp + SSIM_C2;
+        const float inv = 1.f / (Cq * Dq);
+        const float ssim = A * Bq * inv;
+        loss += 1.f - ssim;
+        if (part) {
+            const float dmu = (2.f * mt * Bq - 2.f * mt * A) * inv - ssim * (2.f * mp * Dq - 2.f * mp * Cq) * inv;
+            const float depp = -ssim / Dq;
+            const float detp = 2.f * A * inv;
+            part[i] = -dmu; part[total + i] = -depp; part[2 * total + i] = -detp;
+        }
+    }
+    loss = block_sum(loss, sm);
+    if (threadIdx.x == 0) atomicAdd(acc, loss);
+}
+extern "C" int vg_ssim_fwd(const float* t, const float* p, int B, int D, int H, int W, float* acc, float* part,
+                           vg_stream_t stream) {
+    if (!t || !p || !acc || B < 1 || D < 1 || H < 1 || W < 1) return VG_EINVAL;
+    hipLaunchKernelGGL(ssim_fwd_kernel, dim3(lblocks((int64_t)B * D * H * W)), dim3(256), 0, (hipStream_t)stream, t, p, B, D, H, W, acc, part);
+    return vg_check_launch();
+}
+__global__ void ssim_bwd_kernel(const float* t, const float* p, const float* part, int B, int D, int H, int W, float gscale,
+                                float* gp, int accum) {
+    float g[3]; gauss3(g);
+    const int64_t S = (int64_t)D * H * W, total = (int64_t)B * S;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int w = (int)(i % W); int64_t r = i / W; const int h = (int)(r % H); r /= H; const int d = (int)(r % D); const int b = (int)(r / D);
+        float f0 = 0.f, f1 = 0.f, f2 = 0.f;
+        for (int a = -1; a <= 1; ++a) { const int dd = d + a; if (dd < 0 || dd >= D) continue;
+            for (int c = -1; c <= 1; ++c) { const int hh = h + c; if (hh < 0 || hh >= H) continue;
+                for (int e = -1; e <= 1; ++e) { const int ww = w + e; if (ww < 0 || ww >= W) continue;
+                    const float wt = g[a + 1] * g[c + 1] * g[e + 1];
+                    const size_t j = (size_t)b * S + ((size_t)dd * H + hh) * W + ww;
+                    f0 += wt * part[j]; f1 += wt * part[total + j]; f2 += wt * part[2 * total + j];
+                } } }
+        const float v = gscale * (f0 + 2.f * p[i] * f1 + t[i] * f2);
+        gp[i] = accum ? gp[i] + v : v;
+    }
+}
+extern "C" int vg_ssim_bwd(const float* t, const float* p, const float* part, int B, int D, int H, int W, float gscale,
+                           float* gp, int accumulate, vg_stream_t stream) {
+    if (!t || !p || !part || !gp || B < 1) return VG_EINVAL;
+    hipLaunchKernelGGL(ssim_bwd_kernel, dim3(lblocks((int64_t)B * D * H * W)), dim3(256), 0, (hipStream_t)stream, t, p, part, B, D, H, W,
+                       gscale, gp, accumulate);
+    return vg_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------
+// clDice soft skeleton.  Candidate order = TF evaluation order (see oracle/_erode_offsets): the windows
+// (3,3,1), (3,1,3), (1,3,3) for soft_erode (19-voxel union), raster order for the 27-voxel soft_dilate.
+// TP: the gradient of each pooling goes to the FIRST candidate attaining the extremum.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void erode_at(const float* img, int D, int H, int W, int d, int h, int w, float& best, int& boff) {
+    best = INFINITY; boff = 0;
+#define VG_ER(a, b, c)                                                                                   \
+    { const int dd = d + (a), hh = h + (b), ww = w + (c);                                                 \
+      if (dd >= 0 && dd < D && hh >= 0 && hh < H && ww >= 0 && ww < W) {                                  \
+          const int off = ((a) * H + (b)) * W + (c); const float v = img[off];                           \
+          if (v < best) { best = v; boff = off; } } }
+    for (int a = -1; a <= 1; ++a) for (int b = -1; b <= 1; ++b) VG_ER(a, b, 0)
+    for (int a = -1; a <= 1; ++a) for (int c = -1; c <= 1; ++c) VG_ER(a, 0, c)
+    for (int b = -1; b <= 1; ++b) for (int c = -1; c <= 1; ++c) VG_ER(0, b, c)
+#undef VG_ER
+}
+__device__ __forceinline__ void dilate_at(const float* img, int D, int H, int W, int d, int h, int w, float& best, int& boff) {
+    best = -INFINITY; boff = 0;
+    for (int a = -1; a <= 1; ++a) { const int dd = d + a; if (dd < 0 || dd >= D) continue;
+        for (int b = -1; b <= 1; ++b) { const int hh = h + b; if (hh < 0 || hh >= H) continue;
+            for (int c = -1; c <= 1; ++c) { const int ww = w + c; if (ww < 0 || ww >= W) continue;
+                const int off = (a * H + b) * W + c; const float v = img[off];
+                if (v > best) { best = v; boff = off; } } } }
+}
+#define VG_VOX(i, W, H, D, w, h, d, b)                                                                     \
+    const int w = (int)((i) % (W)); int64_t r_ = (i) / (W); const int h = (int)(r_ % (H)); r_ /= (H);        \
+    const int d = (int)(r_ % (D)); const int b = (int)(r_ / (D)); (void)b;
+
+__global__ void erode_kernel(const float* in, int B, int D, int H, int W, float* out) {
+    const int64_t total = (int64_t)B * D * H * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        VG_VOX(i, W, H, D, w, h, d, b)
+        float v; int o; erode_at(in + i, D, H, W, d, h, w, v, o);
+        out[i] = v;
+    }
+}
+// step j: delta = relu(img_j - dilate(img_{j+1})); j==0: skel = delta, else skel = prev + relu(delta - prev*delta)
+__global__ void skel_update_kernel(const float* imgj, const float* imgj1, const float* prev, int B, int D, int H, int W, float* skel) {
+    const int64_t total = (int64_t)B * D * H * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        VG_VOX(i, W, H, D, w, h, d, b)
+        float dil; int o; dilate_at(imgj1 + i, D, H, W, d, h, w, dil, o);
+        const float delta = fmaxf(imgj[i] - dil, 0.f);
+        if (prev) { const float s = prev[i]; skel[i] = s + fmaxf(delta - s * delta, 0.f); }
+        else skel[i] = delta;
+    }
+}
+extern "C" int vg_soft_skel_fwd(const float* img, int B, int D, int H, int W, int iters, float* imgs, float* skels,
+                                vg_stream_t stream) {
+    if (!img || !imgs || !skels || B < 1 || iters < 0) return VG_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n = (int64_t)B * D * H * W;
+    const int blocks = lblocks(n);
+    if (hipMemcpyAsync(imgs, img, n * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return VG_ELAUNCH;
+    for (int j = 0; j <= iters; ++j)
+        hipLaunchKernelGGL(erode_kernel, dim3(blocks), dim3(256), 0, s, imgs + j * n, B, D, H, W, imgs + (j + 1) * n);
+    for (int j = 0; j <= iters; ++j)
+        hipLaunchKernelGGL(skel_update_kernel, dim3(blocks), dim3(256), 0, s, imgs + j * n, imgs + (j + 1) * n,
+                           j ? skels + (j - 1) * n : (const float*)nullptr, B, D, H, W, skels + j * n);
+    return vg_check_launch();
+}
+
+// backward step j, part 1: local gradients of the skeleton update
+__global__ void skel_bwd_local_kernel(const float* imgj, const float* imgj1, const float* prev, int B, int D, int H, int W,
+                                      float* gs, float* dimgj, float* dimgj1) {
+    const int64_t total = (int64_t)B * D * H * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        VG_VOX(i, W, H, D, w, h, d, b)
+        float dil; int o; dilate_at(imgj1 + i, D, H, W, d, h, w, dil, o);
+        const float raw = imgj[i] - dil;
+        const float delta = fmaxf(raw, 0.f);
+        const float g = gs[i];
+        float ddelta;
+        if (prev) {
+            const float s = prev[i];
+            const float u = delta - s * delta;
+            const float dr = u > 0.f ? g : 0.f;
+            ddelta = dr * (1.f - s);
+            gs[i] = g - dr * delta;             // d skel_{j-1}
+        } else ddelta = g;
+        const float e = raw > 0.f ? ddelta : 0.f;
+        if (e != 0.f) { dimgj[i] += e; atomicAdd(&dimgj1[i + o], -e); }
+    }
+}
+// part 2: d img_j += erode^T(d img_{j+1})
+__global__ void erode_bwd_kernel(const float* imgj, const float* dimgj1, int B, int D, int H, int W, float* dimgj) {
+    const int64_t total = (int64_t)B * D * H * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const float g = dimgj1[i];
+        if (g == 0.f) continue;
+        VG_VOX(i, W, H, D, w, h, d, b)
+        float v; int o; erode_at(imgj + i, D, H, W, d, h, w, v, o);
+        atomicAdd(&dimgj[i + o], g);
+    }
+}
+extern "C" int vg_soft_skel_bwd(const float* imgs, const float* skels, const float* gskel, int B, int D, int H, int W,
+                                int iters, float* work, float* gimg, vg_stream_t stream) {
+    if (!imgs || !skels || !gskel || !work || !gimg || B < 1 || iters < 0) return VG_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n = (int64_t)B * D * H * W;
+    const int blocks = lblocks(n);
+    float* gs = work; float* bufA = work + n; float* bufB = work + 2 * n;     // bufA = d img_{j+1}, bufB = d img_j
+    if (hipMemcpyAsync(gs, gskel, n * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return VG_ELAUNCH;
+    if (hipMemsetAsync(bufA, 0, 2 * n * sizeof(float), s) != hipSuccess) return VG_ELAUNCH;
+    for (int j = iters; j >= 0; --j) {
+        hipLaunchKernelGGL(skel_bwd_local_kernel, dim3(blocks), dim3(256), 0, s, imgs + j * n, imgs + (j + 1) * n,
+                           j ? skels + (j - 1) * n : (const float*)nullptr, B, D, H, W, gs, bufB, bufA);
+        hipLaunchKernelGGL(erode_bwd_kernel, dim3(blocks), dim3(256), 0, s, imgs + j * n, bufA, B, D, H, W, bufB);
+        if (j > 0) {
+            if (hipMemsetAsync(bufA, 0, n * sizeof(float), s) != hipSuccess) return VG_ELAUNCH;
+            float* t = bufA; bufA = bufB; bufB = t;
+        }
+    }
+    // bufB = d img_0
+    return vg_axpby(bufB, 1.f, nullptr, 0.f, n, gimg, 1, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// clDice / Dice combination (clDice_func.py:83-149) -- coefficients on device, no host sync
+// sums: [0..2] = (sum skel_p*t, sum skel_p, sum t) ; [3..5] = (sum skel_t*p, sum skel_t, sum p) ; [6] = sum t*p
+// coef: gskel_p = c0*t - c1 ;  gp += c2*t + c3 + c4*skel_t ;  coef[5] = loss value (already * w)
+// ------------------------------------------------------------------------------------------------
+__global__ void cldice_coef_kernel(const float* sums, float w, float alpha, float* coef) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float A = sums[0], Bp = sums[1], T = sums[2], Cc = sums[3], Dt = sums[4], P = sums[5], I = sums[6];
+    const float pres = (A + 1.f) / (Bp + 1.f), rec = (Cc + 1.f) / (Dt + 1.f);
+    const float cl = 1.f - 2.f * pres * rec / (pres + rec);
+    const float den = T + P + 1.f;
+    const float dice = 1.f - (2.f * I + 1.f) / den;
+    const float q = (pres + rec) * (pres + rec);
+    const float dcl_dpres = -2.f * rec * rec / q, dcl_drec = -2.f * pres * pres / q;
+    coef[0] = w * alpha * dcl_dpres / (Bp + 1.f);
+    coef[1] = w * alpha * dcl_dpres * (A + 1.f) / ((Bp + 1.f) * (Bp + 1.f));
+    coef[2] = -w * (1.f - alpha) * 2.f / den;
+    coef[3] = w * (1.f - alpha) * (2.f * I + 1.f) / (den * den);
+    coef[4] = w * alpha * dcl_drec / (Dt + 1.f);
+    coef[5] = w * ((1.f - alpha) * dice + alpha * cl);
+}
+__global__ void cldice_grads_kernel(const float* t, const float* skel_t, const float* coef, int64_t n, float* gskel_p, float* gp, int accum) {
+    const float c0 = coef[0], c1 = coef[1], c2 = coef[2], c3 = coef[3], c4 = coef[4];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float tv = t[i];
+        gskel_p[i] = c0 * tv - c1;
+        const float g = c2 * tv + c3 + c4 * skel_t[i];
+        gp[i] = accum ? gp[i] + g : g;
+    }
+}
+extern "C" int vg_cldice_coef(const float* sums7, float w, float alpha, float* coef6, vg_stream_t stream) {
+    if (!sums7 || !coef6) return VG_EINVAL;
+    hipLaunchKernelGGL(cldice_coef_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums7, w, alpha, coef6);
+    return vg_check_launch();
+}
+extern "C" int vg_cldice_grads(const float* t, const float* skel_t, const float* coef6, int64_t n, float* gskel_p, float* gp,
+                               int accumulate, vg_stream_t stream) {
+    if (!t || !skel_t || !coef6 || !gskel_p || !gp || n < 1) return VG_EINVAL;
+    hipLaunchKernelGGL(cldice_grads_kernel, dim3(lblocks(n)), dim3(256), 0, (hipStream_t)stream, t, skel_t, coef6, n, gskel_p, gp, accumulate);
+    return vg_check_launch();
+}

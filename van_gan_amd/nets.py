@@ -1,0 +1,471 @@
+"""ResUNet generator and 3-D PatchGAN discriminator of VAN-GAN as explicit forward/backward schedules of
+libvangan_hip.so kernels (no autograd, no torch arithmetic).
+
+Reference: resunet_model.py:185-249 as configured at vangan.py:112-122,151-162 (filters=16, num_layers=4,
+upsample_mode='simple', tanh) and discriminator.py:7-124 as configured at vangan.py:167-192.
+Parameter names/order/layout (Keras DHWIO) follow oracle/vangan_oracle.py::gen_param_specs/disc_param_specs
+so that weights can be exchanged with the oracle 1:1.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import ops
+from .ops import ACT_LRELU, ACT_NONE, ACT_RELU, Arena, ConvLayer, Src
+
+GEN_F = [16, 32, 64, 128, 256]
+
+
+def gen_param_specs() -> List[Tuple[str, Tuple[int, ...], str]]:
+    f = GEN_F
+    s: List[Tuple[str, Tuple[int, ...], str]] = []
+
+    def conv(name, k, ci, co, init):
+        s.append((name + '.w', (k, k, k, ci, co), init)); s.append((name + '.b', (co,), 'zeros'))
+
+    def inorm(name, c):
+        s.append((name + '.gamma', (c,), 'ones')); s.append((name + '.beta', (c,), 'zeros'))
+
+    conv('stem.conv1', 3, 1, f[0], 'glorot_uniform')
+    inorm('stem.cb.in', f[0]); conv('stem.cb.conv', 3, f[0], f[0], 'he_normal')
+    conv('stem.short', 1, 1, f[0], 'glorot_uniform'); inorm('stem.short.in', f[0])
+
+    def resblock(name, ci, co):
+        inorm(name + '.cb1.in', ci); conv(name + '.cb1.conv', 3, ci, co, 'he_normal')
+        inorm(name + '.cb2.in', co); conv(name + '.cb2.conv', 3, co, co, 'he_normal')
+        conv(name + '.short', 1, ci, co, 'he_normal'); inorm(name + '.short.in', co)
+
+    for e in range(1, 5):
+        resblock('enc%d' % e, f[e - 1], f[e])
+    inorm('bridge.cb1.in', f[4]); conv('bridge.cb1.conv', 3, f[4], f[4], 'he_normal')
+    inorm('bridge.cb2.in', f[4]); conv('bridge.cb2.conv', 3, f[4], f[4], 'he_normal')
+    for d in (3, 2, 1, 0):
+        resblock('dec%d' % d, f[d + 1] + f[d], f[d])
+    conv('out', 1, f[0], 1, 'glorot_uniform')
+    return s
+
+
+def disc_param_specs() -> List[Tuple[str, Tuple[int, ...], str]]:
+    s: List[Tuple[str, Tuple[int, ...], str]] = []
+    s.append(('conv0.w', (4, 4, 4, 1, 64), 'he_normal')); s.append(('conv0.b', (64,), 'zeros'))
+    s.append(('conv0.in.gamma', (64,), 'glorot_vec')); s.append(('conv0.in.beta', (64,), 'zeros'))
+    ci = 64
+    for i in range(3):
+        co = ci * 2
+        s.append(('down%d.w' % i, (4, 4, 4, ci, co), 'he_normal'))
+        s.append(('down%d.in.gamma' % i, (co,), 'glorot_vec')); s.append(('down%d.in.beta' % i, (co,), 'zeros'))
+        ci = co
+    s.append(('out.w', (3, 3, 3, 512, 1), 'he_normal')); s.append(('out.b', (1,), 'zeros'))
+    return s
+
+
+class ParamStore:
+    """One network's parameters as flat fp32 buffers (w, grad, Adam m/v) + per-tensor views.
+    The flat gradient buffer is the RCCL all-reduce bucket of that network."""
+
+    def __init__(self, specs, device):
+        self.specs = specs
+        self.offsets: Dict[str, Tuple[int, Tuple[int, ...]]] = {}
+        off = 0
+        bounds = [0]
+        for name, shape, _ in specs:
+            n = int(math.prod(shape))
+            self.offsets[name] = (off, tuple(shape))
+            off += n
+            bounds.append(off)
+        self.total = off
+        self.T = len(specs)
+        self.w = torch.zeros(off, dtype=torch.float32, device=device)
+        self.g = torch.zeros(off, dtype=torch.float32, device=device)
+        self.m = torch.zeros(off, dtype=torch.float32, device=device)
+        self.v = torch.zeros(off, dtype=torch.float32, device=device)
+        self.seg_off = torch.tensor(bounds, dtype=torch.int64, device=device)
+        self.norms = torch.zeros(self.T, dtype=torch.float32, device=device)
+        self.step = 0
+
+    def _view(self, buf, name):
+        off, shape = self.offsets[name]
+        return buf[off:off + int(math.prod(shape))].view(*shape)
+
+    def param(self, name):
+        return self._view(self.w, name)
+
+    def grad(self, name):
+        return self._view(self.g, name)
+
+    def load(self, tensors: Dict[str, torch.Tensor]):
+        for name, (off, shape) in self.offsets.items():
+            self.param(name).copy_(tensors[name].to(torch.float32).reshape(shape))
+
+    def export(self, buf=None) -> Dict[str, torch.Tensor]:
+        buf = self.w if buf is None else buf
+        return {name: self._view(buf, name).detach().cpu().clone() for name in self.offsets}
+
+
+def init_reference(store: ParamStore, seed: int):
+    """Reference initialisers on the host (setup only): he_normal / glorot_uniform / zeros / ones
+    (resunet_model.py:47,85-95,246; building_blocks.py:129; discriminator.py:11)."""
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for name, shape, init in store.specs:
+        if init == 'zeros':
+            t = torch.zeros(shape)
+        elif init == 'ones':
+            t = torch.ones(shape)
+        elif init == 'glorot_vec':
+            t = (torch.rand(shape, generator=g) * 2 - 1) * math.sqrt(3.0 / shape[0])
+        else:
+            rf = shape[0] * shape[1] * shape[2]
+            fan_in, fan_out = rf * shape[3], rf * shape[4]
+            if init == 'glorot_uniform':
+                t = (torch.rand(shape, generator=g) * 2 - 1) * math.sqrt(6.0 / (fan_in + fan_out))
+            else:
+                t = torch.empty(shape)
+                torch.nn.init.trunc_normal_(t, 0.0, 1.0, -2.0, 2.0, generator=g)
+                t = t * (math.sqrt(2.0 / fan_in) / 0.87962566103423978)
+        out[name] = t
+    store.load(out)
+
+
+class Act:
+    """A stored activation: bf16 data + per-(n,c) (sum, sumsq) accumulated by its producer's epilogue."""
+
+    def __init__(self, arena: Arena, N, dims, C_, dtype=torch.bfloat16, want_sums=True):
+        self.N, self.dims, self.C = N, tuple(dims), C_
+        self.data = arena.alloc((N,) + tuple(dims) + (C_,), dtype)
+        self.sums = arena.alloc((N, C_, 2), torch.float32, zero=True) if want_sums else None
+        self.count = float(dims[0] * dims[1] * dims[2])
+        self.grad = None
+
+    def alloc_grad(self, arena: Arena):
+        if self.grad is None:
+            self.grad = arena.alloc((self.N,) + self.dims + (self.C,), torch.bfloat16, zero=True)
+        return self.grad
+
+
+class Norm:
+    """InstanceNorm parameters + the per-application scale/shift/mean/rstd it produces."""
+
+    def __init__(self, store: ParamStore, name: str, C_: int):
+        self.name, self.C = name, C_
+        self.gamma, self.beta = store.param(name + '.gamma'), store.param(name + '.beta')
+        self.dgamma, self.dbeta = store.grad(name + '.gamma'), store.grad(name + '.beta')
+
+    def finalize(self, arena: Arena, a0: Act, a1: Optional[Act] = None, mult=None):
+        N = a0.N
+        st = {k: arena.alloc((N, self.C), torch.float32) for k in ('scale', 'shift', 'mean', 'rstd')}
+        ops.in_finalize(a0.sums, a0.C, a0.count, self.gamma, self.beta, N, st['scale'], st['shift'], st['mean'],
+                        st['rstd'], sums1=None if a1 is None else a1.sums, c1=0 if a1 is None else a1.C,
+                        count1=1.0 if a1 is None else a1.count, mult=mult)
+        st['mult'] = mult
+        return st
+
+
+# ======================================================================================================
+# Generator
+# ======================================================================================================
+class ResUNet:
+    def __init__(self, store: ParamStore, dims: Tuple[int, int, int]):
+        D, H, W = dims
+        if any(n % 16 or n < 32 for n in dims):
+            raise ValueError('spatial dims must be multiples of 16 and >= 32 (4 stride-2 stages + reflect pad)')
+        self.store, self.dims = store, tuple(dims)
+        f = GEN_F
+        lv = [tuple(n >> i for n in dims) for i in range(5)]
+        self.lv = lv
+        L = self.L = {}
+        Nn = self.Nn = {}
+        L['stem.conv1'] = ConvLayer(store, 'stem.conv1', 3, 1, f[0], 1, 'reflect', True, lv[0], need_dgrad=False)
+        L['stem.cb'] = ConvLayer(store, 'stem.cb.conv', 3, f[0], f[0], 1, 'reflect', True, lv[0])
+        L['stem.short'] = ConvLayer(store, 'stem.short', 1, 1, f[0], 1, 'same', True, lv[0], need_dgrad=False)
+        Nn['stem.cb'] = Norm(store, 'stem.cb.in', f[0]); Nn['stem.short'] = Norm(store, 'stem.short.in', f[0])
+
+        def resblock(name, ci, co, stride, in_dims, out_dims):
+            L[name + '.cb1'] = ConvLayer(store, name + '.cb1.conv', 3, ci, co, stride, 'reflect', True, in_dims)
+            L[name + '.cb2'] = ConvLayer(store, name + '.cb2.conv', 3, co, co, 1, 'reflect', True, out_dims)
+            L[name + '.short'] = ConvLayer(store, name + '.short', 1, ci, co, stride, 'same', True, in_dims)
+            Nn[name + '.cb1'] = Norm(store, name + '.cb1.in', ci)
+            Nn[name + '.cb2'] = Norm(store, name + '.cb2.in', co)
+            Nn[name + '.short'] = Norm(store, name + '.short.in', co)
+
+        for e in range(1, 5):
+            resblock('enc%d' % e, f[e - 1], f[e], 2, lv[e - 1], lv[e])
+        for b in ('bridge.cb1', 'bridge.cb2'):
+            L[b] = ConvLayer(store, b + '.conv', 3, f[4], f[4], 1, 'reflect', True, lv[4])
+            Nn[b] = Norm(store, b + '.in', f[4])
+        for d in (3, 2, 1, 0):
+            resblock('dec%d' % d, f[d + 1] + f[d], f[d], 1, lv[d], lv[d])
+        L['out'] = ConvLayer(store, 'out', 1, f[0], 1, 1, 'same', True, lv[0])
+
+    def pack(self):
+        for l in self.L.values():
+            l.pack()
+
+    # ---------------------------------------------------------------------------------------------
+    def _block_fwd(self, ar: Arena, name: str, N: int, src_raw: Src, nrm_inputs, out_dims, co, ctx):
+        """residual_block (resunet_model.py:103-143): out = conv2(relu(IN(conv1(relu(IN(x)))))) + IN(short(x))."""
+        L, Nn = self.L, self.Nn
+        n1 = Nn[name + '.cb1'].finalize(ar, *nrm_inputs)
+        s1 = Src(src_raw.x0, (N,) + tuple(L[name + '.cb1'].in_dims), src_raw.c0, src_raw.x1, src_raw.c1, src_raw.shift0,
+                 scale=n1['scale'], shift=n1['shift'], act=ACT_RELU)
+        r = Act(ar, N, out_dims, co)
+        L[name + '.cb1'].forward(s1, r.data, sums=r.sums)
+        sc = Act(ar, N, out_dims, co)
+        L[name + '.short'].forward(src_raw, sc.data, sums=sc.sums)
+        ns = Nn[name + '.short'].finalize(ar, sc)
+        n2 = Nn[name + '.cb2'].finalize(ar, r)
+        s2 = Src(r.data, (N,) + tuple(out_dims), co, scale=n2['scale'], shift=n2['shift'], act=ACT_RELU)
+        out = Act(ar, N, out_dims, co)
+        L[name + '.cb2'].forward(s2, out.data, sums=out.sums, res=sc.data, res_scale=ns['scale'], res_shift=ns['shift'])
+        ctx[name] = dict(n1=n1, s1=s1, r=r, sc=sc, ns=ns, n2=n2, s2=s2, out=out, src_raw=src_raw)
+        return out
+
+    def forward(self, ar: Arena, x: torch.Tensor, y: torch.Tensor, save: bool = True) -> dict:
+        """x: fp32 [N,D,H,W,1]; y: fp32 [N,D,H,W,1] output buffer (tanh).  Returns the context for backward."""
+        N = x.shape[0]
+        f, lv, L, Nn = GEN_F, self.lv, self.L, self.Nn
+        ctx = {'N': N, 'x': x, 'y': y}
+        sx = Src(x, (N,) + lv[0], 1, f32=True)
+        c1 = Act(ar, N, lv[0], f[0])
+        L['stem.conv1'].forward(sx, c1.data, sums=c1.sums)
+        sc = Act(ar, N, lv[0], f[0])
+        L['stem.short'].forward(sx, sc.data, sums=sc.sums)
+        ns = Nn['stem.short'].finalize(ar, sc)
+        n1 = Nn['stem.cb'].finalize(ar, c1)
+        s1 = Src(c1.data, (N,) + lv[0], f[0], scale=n1['scale'], shift=n1['shift'], act=ACT_RELU)
+        h = Act(ar, N, lv[0], f[0])
+        L['stem.cb'].forward(s1, h.data, sums=h.sums, res=sc.data, res_scale=ns['scale'], res_shift=ns['shift'])
+        ctx['stem'] = dict(sx=sx, c1=c1, sc=sc, ns=ns, n1=n1, s1=s1, out=h)
+        skips = [h]
+        for e in range(1, 5):
+            raw = Src(h.data, (N,) + lv[e - 1], f[e - 1])
+            h = self._block_fwd(ar, 'enc%d' % e, N, raw, (h,), lv[e], f[e], ctx)
+            ctx['enc%d' % e]['inp'] = (skips[-1],)
+            skips.append(h)
+        nb1 = Nn['bridge.cb1'].finalize(ar, h)
+        sb1 = Src(h.data, (N,) + lv[4], f[4], scale=nb1['scale'], shift=nb1['shift'], act=ACT_RELU)
+        b1 = Act(ar, N, lv[4], f[4])
+        L['bridge.cb1'].forward(sb1, b1.data, sums=b1.sums)
+        nb2 = Nn['bridge.cb2'].finalize(ar, b1)
+        sb2 = Src(b1.data, (N,) + lv[4], f[4], scale=nb2['scale'], shift=nb2['shift'], act=ACT_RELU)
+        b2 = Act(ar, N, lv[4], f[4])
+        L['bridge.cb2'].forward(sb2, b2.data, sums=b2.sums)
+        ctx['bridge'] = dict(inp=h, nb1=nb1, sb1=sb1, b1=b1, nb2=nb2, sb2=sb2, b2=b2)
+        h = b2
+        for d in (3, 2, 1, 0):
+            skip = skips[d]
+            raw = Src(h.data, (N,) + lv[d], h.C, skip.data, skip.C, shift0=1)       # virtual upsample + concat
+            low = h
+            h = self._block_fwd(ar, 'dec%d' % d, N, raw, (low, skip), lv[d], f[d], ctx)
+            ctx['dec%d' % d]['inp'] = (low, skip)
+        so = Src(h.data, (N,) + lv[0], f[0])
+        L['out'].forward(so, y, tanh=True)
+        ctx['out'] = dict(so=so, inp=h)
+        return ctx
+
+    # ---------------------------------------------------------------------------------------------
+    def _norm_bwd(self, ar, g, g_padded, src: Src, st, norm: Norm, dx, act, dx_cstride=0, accumulate=True):
+        """(IN -> act) backward of the operand described by `src` with statistics `st`."""
+        N = src.N
+        red = ar.alloc((N, src.C, 2), torch.float32, zero=True)
+        ops.actnorm_bwd(g, g_padded, src.x0, (N, src.D, src.H, src.W), src.C, dx, scale=st['scale'], shift=st['shift'],
+                        act=act, norm=True, gamma=norm.gamma, mean=st['mean'], rstd=st['rstd'], red=red,
+                        accumulate=accumulate, x1=src.x1, c_x0=src.c0 if src.x1 is not None else 0, x0_shift=src.shift0,
+                        dx_cstride=dx_cstride, dgamma=norm.dgamma, dbeta=norm.dbeta)
+
+    def _block_bwd(self, ar: Arena, name: str, c: dict, N: int):
+        """Backward of one residual block given the complete gradient of its output in c['out'].grad."""
+        L, Nn = self.L, self.Nn
+        out, r, sc = c['out'], c['r'], c['sc']
+        d_out = out.grad
+        cb1, cb2, short = L[name + '.cb1'], L[name + '.cb2'], L[name + '.short']
+        mk = ar.mark()
+        # shortcut InstanceNorm (no activation): d_sc
+        d_sc = ar.alloc(sc.data.shape, torch.bfloat16)
+        ssc = Src(sc.data, (N,) + sc.dims, sc.C)
+        self._norm_bwd(ar, d_out, False, ssc, c['ns'], Nn[name + '.short'], d_sc, ACT_NONE, accumulate=False)
+        # conv2: weights + data gradient on the padded grid, folded through relu(IN(r))
+        cb2.wgrad(c['s2'], d_out)
+        dp = ar.alloc((N,) + cb2.buf_dims + (r.C,), torch.bfloat16)
+        cb2.dgrad(d_out, N, dp, accumulate=False)
+        d_r = ar.alloc(r.data.shape, torch.bfloat16)
+        self._norm_bwd(ar, dp, True, c['s2'], c['n2'], Nn[name + '.cb2'], d_r, ACT_RELU, accumulate=False)
+        # conv1 and shortcut conv read the block input (possibly the virtual concat)
+        s1, raw = c['s1'], c['src_raw']
+        cb1.wgrad(s1, d_r)
+        short.wgrad(raw, d_sc)
+        dp1 = ar.alloc((N,) + cb1.buf_dims + (s1.C,), torch.bfloat16)
+        cb1.dgrad(d_r, N, dp1, accumulate=False)
+        inp = c['inp']
+        if len(inp) == 1:            # encoder block: accumulate into the input's gradient
+            gin = inp[0].alloc_grad(ar) if inp[0].grad is None else inp[0].grad
+            self._norm_bwd(ar, dp1, True, s1, c['n1'], Nn[name + '.cb1'], gin, ACT_RELU, accumulate=True)
+            short.dgrad(d_sc, N, gin, accumulate=True)
+        else:                        # decoder block: gradient of the virtual concat, then split / sum-pool
+            low, skip = inp
+            dcat = ar.alloc((N,) + tuple(cb1.in_dims) + (s1.C,), torch.bfloat16)
+            self._norm_bwd(ar, dp1, True, s1, c['n1'], Nn[name + '.cb1'], dcat, ACT_RELU, accumulate=False)
+            short.dgrad(d_sc, N, dcat, accumulate=True)
+            ops.concat_bwd(dcat, (N,) + tuple(cb1.in_dims), low.C, skip.C, low.grad, skip.grad)
+        ar.release(mk)
+
+    def backward(self, ar: Arena, ctx: dict, gy: torch.Tensor):
+        """gy: fp32 [N,D,H,W,1] gradient w.r.t. the tanh output.  Adds parameter gradients into store.g."""
+        N = ctx['N']
+        L, Nn = self.L, self.Nn
+        # gradient buffers of every tensor that has more than one consumer / is read across blocks
+        acts = [ctx['stem']['out']] + [ctx['enc%d' % e]['out'] for e in range(1, 5)] + \
+               [ctx['bridge']['b2']] + [ctx['dec%d' % d]['out'] for d in (3, 2, 1, 0)]
+        for a in acts:
+            a.grad = None
+            a.alloc_grad(ar)
+        # output conv + tanh
+        dpre = ar.alloc(gy.shape, torch.float32)
+        ops.tanh_bwd(gy, ctx['y'], dpre)
+        h = ctx['out']['inp']
+        L['out'].wgrad(ctx['out']['so'], dpre)
+        L['out'].dgrad(dpre, N, h.grad, accumulate=True)
+        for d in (0, 1, 2, 3):
+            self._block_bwd(ar, 'dec%d' % d, ctx['dec%d' % d], N)
+        # bridge
+        b = ctx['bridge']
+        mk = ar.mark()
+        cb2, cb1 = L['bridge.cb2'], L['bridge.cb1']
+        cb2.wgrad(b['sb2'], b['b2'].grad)
+        dp = ar.alloc((N,) + cb2.buf_dims + (b['b1'].C,), torch.bfloat16)
+        cb2.dgrad(b['b2'].grad, N, dp, accumulate=False)
+        d_b1 = ar.alloc(b['b1'].data.shape, torch.bfloat16)
+        self._norm_bwd(ar, dp, True, b['sb2'], b['nb2'], Nn['bridge.cb2'], d_b1, ACT_RELU, accumulate=False)
+        cb1.wgrad(b['sb1'], d_b1)
+        dp = ar.alloc((N,) + cb1.buf_dims + (b['inp'].C,), torch.bfloat16)
+        cb1.dgrad(d_b1, N, dp, accumulate=False)
+        self._norm_bwd(ar, dp, True, b['sb1'], b['nb1'], Nn['bridge.cb1'], b['inp'].grad, ACT_RELU, accumulate=True)
+        ar.release(mk)
+        for e in (4, 3, 2, 1):
+            self._block_bwd(ar, 'enc%d' % e, ctx['enc%d' % e], N)
+        # stem
+        s = ctx['stem']
+        d_out = s['out'].grad
+        d_sc = ar.alloc(s['sc'].data.shape, torch.bfloat16)
+        ssc = Src(s['sc'].data, (N,) + s['sc'].dims, s['sc'].C)
+        self._norm_bwd(ar, d_out, False, ssc, s['ns'], Nn['stem.short'], d_sc, ACT_NONE, accumulate=False)
+        cb = L['stem.cb']
+        cb.wgrad(s['s1'], d_out)
+        dp = ar.alloc((N,) + cb.buf_dims + (s['c1'].C,), torch.bfloat16)
+        cb.dgrad(d_out, N, dp, accumulate=False)
+        d_c1 = ar.alloc(s['c1'].data.shape, torch.bfloat16)
+        self._norm_bwd(ar, dp, True, s['s1'], s['n1'], Nn['stem.cb'], d_c1, ACT_RELU, accumulate=False)
+        L['stem.conv1'].wgrad(s['sx'], d_c1)
+        L['stem.short'].wgrad(s['sx'], d_sc)
+
+
+# ======================================================================================================
+# Discriminator
+# ======================================================================================================
+class PatchGAN:
+    """get_discriminator (discriminator.py:7-124): reflect-pad -> noise -> Conv(64,k4,s2,bias) -> IN -> LReLU ->
+    2 x downsample(k4,s2,'valid' after reflect pad) -> downsample(k4,s1,'same') -> noise -> Conv(1,k3,'same')."""
+
+    NAMES = ['conv0', 'down0', 'down1', 'down2', 'out']
+
+    def __init__(self, store: ParamStore, dims: Tuple[int, int, int]):
+        self.store, self.dims = store, tuple(dims)
+        lv = [tuple(n >> i for n in dims) for i in range(4)]
+        self.lv = lv
+        self.ch = [1, 64, 128, 256, 512]
+        L = self.L = {}
+        L['conv0'] = ConvLayer(store, 'conv0', 4, 1, 64, 2, 'reflect', True, lv[0])
+        L['down0'] = ConvLayer(store, 'down0', 4, 64, 128, 2, 'reflect', False, lv[1])
+        L['down1'] = ConvLayer(store, 'down1', 4, 128, 256, 2, 'reflect', False, lv[2])
+        L['down2'] = ConvLayer(store, 'down2', 4, 256, 512, 1, 'same', False, lv[3])
+        L['out'] = ConvLayer(store, 'out', 3, 512, 1, 1, 'same', True, lv[3])
+        self.Nn = {k: Norm(store, k + '.in', c) for k, c in zip(self.NAMES[:4], self.ch[1:])}
+
+    def pack(self):
+        for l in self.L.values():
+            l.pack()
+
+    def noise_shapes(self, N: int):
+        lv = self.lv
+        return {'conv0': (N,) + tuple(n + 2 for n in lv[0]) + (1,), 'down0': (N,) + tuple(n + 2 for n in lv[1]) + (64,),
+                'down1': (N,) + tuple(n + 2 for n in lv[2]) + (128,), 'down2': (N,) + lv[3] + (256,),
+                'out': (N,) + lv[3] + (512,)}
+
+    def forward(self, ar: Arena, x: torch.Tensor, logits: torch.Tensor, noise: Optional[dict] = None,
+                drop: Optional[dict] = None) -> dict:
+        """x: fp32 [N,D,H,W,1]; logits: fp32 [N,D/8,H/8,W/8,1].  noise[k]: bf16 tensors (noise_shapes) or None;
+        drop[k]: fp32 [N,C] channel multipliers for down0/1/2 or None."""
+        noise, drop = noise or {}, drop or {}
+        N = x.shape[0]
+        lv, L, Nn = self.lv, self.L, self.Nn
+        ctx = {'N': N, 'x': x}
+        src = Src(x, (N,) + lv[0], 1, f32=True, noise=noise.get('conv0'), noise_pad=1)
+        acts, srcs, sts = [], [src], []
+        h = Act(ar, N, lv[1], 64)
+        L['conv0'].forward(src, h.data, sums=h.sums)
+        acts.append(h)
+        prev_drop = None
+        for i, k in enumerate(['down0', 'down1', 'down2', 'out']):
+            st = Nn[self.NAMES[i]].finalize(ar, h, mult=prev_drop)
+            sts.append(st)
+            lay = L[k]
+            src = Src(h.data, (N,) + tuple(lay.in_dims), h.C, scale=st['scale'], shift=st['shift'], act=ACT_LRELU,
+                      noise=noise.get(k), noise_pad=1 if lay.pad == 'reflect' else 0)
+            srcs.append(src)
+            if k == 'out':
+                lay.forward(src, logits)
+            else:
+                h = Act(ar, N, lay.out_dims, lay.cout)
+                lay.forward(src, h.data, sums=h.sums)
+                acts.append(h)
+                prev_drop = drop.get(k)
+        ctx.update(acts=acts, srcs=srcs, sts=sts)
+        return ctx
+
+    def backward(self, ar: Arena, ctx: dict, dlogits: torch.Tensor, n0: int, n1: int, wgrad: bool,
+                 dx: Optional[torch.Tensor] = None):
+        """Backward for samples [n0,n1) with upstream dlogits (fp32 [n1-n0,...,1]).  wgrad: accumulate parameter
+        gradients; dx: if given (fp32 [n1-n0,D,H,W,1]) receives the gradient w.r.t. the input volume."""
+        L, Nn = self.L, self.Nn
+        N = n1 - n0
+        mk = ar.mark()
+
+        def sl(t):
+            return None if t is None else t[n0:n1]
+
+        def sub(src: Src) -> Src:
+            return Src(sl(src.x0), (N, src.D, src.H, src.W), src.c0, f32=src.f32, scale=sl(src.scale), shift=sl(src.shift),
+                       act=src.act, noise=sl(src.noise), noise_pad=src.noise_pad)
+
+        g = dlogits
+        names = ['out', 'down2', 'down1', 'down0']
+        for j, k in enumerate(names):
+            lay = L[k]
+            li = 4 - j                     # index into srcs; acts[li-1] is the input tensor of this conv
+            src = sub(ctx['srcs'][li])
+            if wgrad:
+                lay.wgrad(src, g)
+            a = ctx['acts'][li - 1]
+            dp = ar.alloc((N,) + tuple(lay.buf_dims) + (lay.cin,), torch.bfloat16)
+            lay.dgrad(g, N, dp, accumulate=False)
+            st = ctx['sts'][li - 1]
+            nrm = Nn[self.NAMES[li - 1]]
+            red = ar.alloc((N, a.C, 2), torch.float32, zero=True)
+            dxa = ar.alloc((N,) + a.dims + (a.C,), torch.bfloat16)
+            ops.actnorm_bwd(dp, lay.pad == 'reflect', sl(a.data), (N,) + a.dims, a.C, dxa, scale=sl(st['scale']),
+                            shift=sl(st['shift']), mult=sl(st['mult']), act=ACT_LRELU, norm=True, gamma=nrm.gamma,
+                            mean=sl(st['mean']), rstd=sl(st['rstd']), red=red, accumulate=False,
+                            dgamma=nrm.dgamma if wgrad else None, dbeta=nrm.dbeta if wgrad else None)
+            g = dxa
+        lay = L['conv0']
+        src = sub(ctx['srcs'][0])
+        if wgrad:
+            lay.wgrad(src, g)
+        if dx is not None:
+            dp = ar.alloc((N,) + tuple(lay.buf_dims) + (1,), torch.bfloat16)
+            lay.dgrad(g, N, dp, accumulate=False)
+            ops.actnorm_bwd(dp, True, None, (N,) + self.lv[0], 1, dx, act=ACT_NONE, norm=False, accumulate=False)
+        ar.release(mk)

@@ -1,0 +1,356 @@
+"""Thin host-side wrappers over the C ABI (include/vangan_hip.h): every function here only marshals
+torch-owned device buffers into libvangan_hip.so calls on torch's current HIP stream.  No arithmetic on
+the data path is done by torch."""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, PAD_REFLECT, PAD_ZERO, ActNormBwdDesc, ConvDesc, check, lib
+
+IN_EPS = 1e-3          # tfa InstanceNormalization default epsilon (resunet_model.py:36)
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+# ------------------------------------------------------------------------------------------------------
+# workspace arena: deterministic addresses, one allocation per engine
+# ------------------------------------------------------------------------------------------------------
+class Arena:
+    def __init__(self, nbytes: int, device):
+        self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        self.off = 0
+        self.peak = 0
+
+    def reset(self):
+        self.off = 0
+
+    def alloc(self, shape: Sequence[int], dtype: torch.dtype, zero: bool = False) -> torch.Tensor:
+        n = int(math.prod(shape))
+        nbytes = n * torch.empty((), dtype=dtype).element_size()
+        start = (self.off + 255) // 256 * 256
+        if start + nbytes > self.buf.numel():
+            raise MemoryError('arena exhausted: need %d more bytes' % (start + nbytes - self.buf.numel()))
+        self.off = start + nbytes
+        self.peak = max(self.peak, self.off)
+        t = self.buf[start:start + nbytes].view(dtype).view(*shape)
+        if zero:
+            t.zero_()
+        return t
+
+    def mark(self) -> int:
+        return self.off
+
+    def release(self, mark: int):
+        self.off = mark
+
+
+# ------------------------------------------------------------------------------------------------------
+# convolution geometry
+# ------------------------------------------------------------------------------------------------------
+def same_pad_before(n: int, k: int, s: int) -> int:
+    """TF 'SAME' (TP): total=max((ceil(n/s)-1)*s+k-n,0), before=total//2."""
+    out = -(-n // s)
+    return max((out - 1) * s + k - n, 0) // 2
+
+
+class Src:
+    """Input operand of a gather-convolution: (virtual concat of) tensor(s) + on-read transform."""
+
+    def __init__(self, x0: torch.Tensor, dims: Tuple[int, int, int, int], c0: int, x1: Optional[torch.Tensor] = None,
+                 c1: int = 0, shift0: int = 0, f32: bool = False, scale=None, shift=None, act: int = ACT_NONE,
+                 noise=None, noise_pad: int = 0):
+        self.x0, self.x1, self.c0, self.c1, self.shift0, self.f32 = x0, x1, c0, c1, shift0, f32
+        self.N, self.D, self.H, self.W = dims
+        self.scale, self.shift, self.act, self.noise, self.noise_pad = scale, shift, act, noise, noise_pad
+
+    @property
+    def C(self):
+        return self.c0 + self.c1
+
+    def fill(self, d: ConvDesc):
+        d.src0, d.src1 = _p(self.x0), _p(self.x1)
+        d.c_src0, d.c_src1, d.src0_shift, d.src_f32 = self.c0, self.c1, self.shift0, int(self.f32)
+        d.N, d.D, d.H, d.W = self.N, self.D, self.H, self.W
+        d.in_scale, d.in_shift, d.act = _p(self.scale), _p(self.shift), self.act
+        d.noise, d.noise_pad = _p(self.noise), self.noise_pad
+
+
+def _set_taps(d: ConvDesc, taps: List[Tuple[int, int, int]]):
+    d.ntaps = len(taps)
+    for i, (a, b, c) in enumerate(taps):
+        d.tap_d[i], d.tap_h[i], d.tap_w[i] = a, b, c
+
+
+def _ck_candidates(C_: int) -> List[int]:
+    if C_ == 1:
+        return [16]
+    return [c for c in (64, 48, 32, 16) if C_ % c == 0]
+
+
+class ConvLayer:
+    """One Conv3D of the reference (k^3, stride, 'reflect' = ReflectionPadding3D+valid, or 'same'), with its
+    packed bf16 weights for the forward and for every output-parity class of the data gradient."""
+
+    def __init__(self, store, name: str, k: int, cin: int, cout: int, stride: int, pad: str, bias: bool,
+                 in_dims: Tuple[int, int, int], need_dgrad: bool = True):
+        self.name, self.k, self.cin, self.cout, self.stride, self.pad, self.has_bias = name, k, cin, cout, stride, pad, bias
+        self.w, self.gw = store.param(name + '.w'), store.grad(name + '.w')
+        self.b, self.gb = (store.param(name + '.b'), store.grad(name + '.b')) if bias else (None, None)
+        dev = self.w.device
+        D, H, W = in_dims
+        self.in_dims = in_dims
+        if pad == 'reflect':
+            self.pb = (1, 1, 1)
+            self.out_dims = tuple((n + 2 - k) // stride + 1 for n in in_dims)
+            self.pad_mode = PAD_REFLECT
+        else:
+            self.pb = tuple(same_pad_before(n, k, stride) for n in in_dims)
+            self.out_dims = tuple(-(-n // stride) for n in in_dims)
+            self.pad_mode = PAD_ZERO
+        T = k * k * k
+        # ---- forward ----
+        self.f_taps = [(a - self.pb[0], b - self.pb[1], c - self.pb[2]) for a in range(k) for b in range(k) for c in range(k)]
+        self.f_idx_host = (C.c_int32 * T)(*range(T))
+        self.f_idx = torch.arange(T, dtype=torch.int32, device=dev)
+        self.f_ck = self._pick_ck(cin, self.f_taps, stride, in_dims, self.out_dims, cout)
+        self.f_ktot = check(lib.vg_packed_ktot(T, cin, self.f_ck), 'vg_packed_ktot')
+        self.f_wp = torch.zeros(lib.vg_packed_rows(cout), self.f_ktot, dtype=torch.bfloat16, device=dev)
+        # ---- data gradient: one class per output parity; buffer = padded grid for 'reflect' ----
+        self.d_classes = []
+        if need_dgrad:
+            padded = pad == 'reflect'
+            self.buf_dims = tuple(n + 2 for n in in_dims) if padded else tuple(in_dims)
+            per_dim = []
+            for ax in range(3):
+                pbe = 0 if padded else self.pb[ax]
+                lst = []
+                for pc in range(stride):
+                    taps = [(t, (pc + pbe - t) // stride) for t in range(k) if (pc + pbe - t) % stride == 0]
+                    cnt = -(-(self.buf_dims[ax] - pc) // stride)
+                    lst.append((pc, taps, cnt))
+                per_dim.append(lst)
+            for (pd, td, nd) in per_dim[0]:
+                for (ph, th, nh) in per_dim[1]:
+                    for (pw, tw, nw) in per_dim[2]:
+                        if not td or not th or not tw or min(nd, nh, nw) < 1:
+                            continue
+                        taps, idx = [], []
+                        for (a, oa) in td:
+                            for (b, ob) in th:
+                                for (c, oc) in tw:
+                                    taps.append((oa, ob, oc)); idx.append((a * k + b) * k + c)
+                        ck = self._pick_ck(cout, taps, 1, self.out_dims, (nd, nh, nw), cin)
+                        ktot = check(lib.vg_packed_ktot(len(taps), cout, ck), 'vg_packed_ktot')
+                        self.d_classes.append(dict(
+                            off=(pd, ph, pw), iters=(nd, nh, nw), taps=taps, ck=ck, ktot=ktot,
+                            idx=torch.tensor(idx, dtype=torch.int32, device=dev),
+                            wp=torch.zeros(lib.vg_packed_rows(cin), ktot, dtype=torch.bfloat16, device=dev)))
+
+    def _pick_ck(self, C_, taps, istr, in_dims, iters, rows) -> int:
+        d = ConvDesc()
+        d.src0 = d.out = d.wpacked = 1 << 20
+        d.c_src0, d.c_src1, d.N = C_, 0, 1
+        d.D, d.H, d.W = in_dims
+        d.istr, d.pad_mode, d.ostr = istr, PAD_ZERO, 1
+        _set_taps(d, taps)
+        d.OD, d.OH, d.OW = iters
+        d.BD, d.BH, d.BW = iters
+        d.Cout = rows
+        best = None
+        for ck in _ck_candidates(C_):
+            d.CK = ck
+            lds = lib.vg_conv3d_lds_bytes(C.byref(d))
+            if lds < 0:
+                continue
+            if lds <= 80 * 1024:
+                return ck
+            if best is None:
+                best = ck
+        if best is None:
+            raise _lib.VgError('no LDS-feasible tile for %s' % self.name)
+        return best
+
+    def pack(self):
+        """fp32 master weights -> bf16 packed operands (after every optimizer step)."""
+        T = self.k ** 3
+        s = stream()
+        check(lib.vg_pack_weights(_p(self.w), T, self.cin, self.cout, _p(self.f_idx), T, 0, self.f_ck, _p(self.f_wp), s), 'pack')
+        for c in self.d_classes:
+            check(lib.vg_pack_weights(_p(self.w), T, self.cin, self.cout, _p(c['idx']), len(c['taps']), 1, c['ck'],
+                                      _p(c['wp']), s), 'pack')
+
+    def _fwd_desc(self, src: Src) -> ConvDesc:
+        d = ConvDesc()
+        src.fill(d)
+        d.istr, d.pad_mode = self.stride, self.pad_mode
+        _set_taps(d, self.f_taps)
+        d.OD, d.OH, d.OW = self.out_dims
+        d.ostr, d.ooff_d, d.ooff_h, d.ooff_w = 1, 0, 0, 0
+        d.BD, d.BH, d.BW = self.out_dims
+        d.Cout, d.wpacked, d.CK = self.cout, _p(self.f_wp), self.f_ck
+        return d
+
+    def forward(self, src: Src, out: torch.Tensor, sums=None, res=None, res_scale=None, res_shift=None,
+                tanh: bool = False):
+        assert src.C == self.cin and (src.D, src.H, src.W) == tuple(self.in_dims)
+        d = self._fwd_desc(src)
+        d.bias = _p(self.b)
+        d.res, d.res_scale, d.res_shift = _p(res), _p(res_scale), _p(res_shift)
+        d.tanh_out = int(tanh)
+        d.out, d.out_f32, d.accumulate = _p(out), int(out.dtype == torch.float32), 0
+        d.out_sums = _p(sums)
+        check(lib.vg_conv3d(C.byref(d), stream()), 'vg_conv3d ' + self.name)
+
+    def wgrad(self, src: Src, dy: torch.Tensor):
+        d = self._fwd_desc(src)
+        check(lib.vg_conv3d_wgrad(C.byref(d), _p(dy), int(dy.dtype == torch.float32), self.f_idx_host, _p(self.gw),
+                                  _p(self.gb), stream()), 'vg_conv3d_wgrad ' + self.name)
+
+    def dgrad(self, dy: torch.Tensor, N: int, out: torch.Tensor, accumulate: bool):
+        """d/d input: writes the reflect-PADDED grid for 'reflect' convs (fold it with actnorm_bwd), the plain
+        input grid for 'same' convs.  out: [N, *buf_dims, cin] bf16 (or f32 when cin==1)."""
+        for c in self.d_classes:
+            d = ConvDesc()
+            d.src0, d.src1 = _p(dy), None
+            d.c_src0, d.c_src1, d.src0_shift, d.src_f32 = self.cout, 0, 0, int(dy.dtype == torch.float32)
+            d.N = N
+            d.D, d.H, d.W = self.out_dims
+            d.act, d.istr, d.pad_mode = ACT_NONE, 1, PAD_ZERO
+            _set_taps(d, c['taps'])
+            d.OD, d.OH, d.OW = c['iters']
+            d.ostr = self.stride
+            d.ooff_d, d.ooff_h, d.ooff_w = c['off']
+            d.BD, d.BH, d.BW = self.buf_dims
+            d.Cout, d.wpacked, d.CK = self.cin, _p(c['wp']), c['ck']
+            d.out, d.out_f32, d.accumulate = _p(out), int(out.dtype == torch.float32), int(accumulate)
+            check(lib.vg_conv3d(C.byref(d), stream()), 'vg_conv3d(dgrad) ' + self.name)
+
+
+# ------------------------------------------------------------------------------------------------------
+# InstanceNorm helpers
+# ------------------------------------------------------------------------------------------------------
+def in_finalize(sums0, c0, count0, gamma, beta, N, scale, shift, mean=None, rstd=None, sums1=None, c1=0, count1=1.0,
+                mult=None):
+    check(lib.vg_in_finalize(_p(sums0), c0, float(count0), _p(sums1), c1, float(count1), _p(gamma), _p(beta), _p(mult),
+                             N, IN_EPS, _p(scale), _p(shift), _p(mean), _p(rstd), stream()), 'vg_in_finalize')
+
+
+def actnorm_bwd(g, g_padded, x, dims, C_, dx, *, scale=None, shift=None, mult=None, act=ACT_NONE, norm=False,
+                gamma=None, mean=None, rstd=None, red=None, accumulate=False, x1=None, c_x0=0, x0_shift=0,
+                dx_cstride=0, dx_coff=0, dgamma=None, dbeta=None):
+    """stats + apply (+ parameter gradients) of the (InstanceNorm -> act -> dropout) backward."""
+    d = ActNormBwdDesc()
+    d.g, d.g_padded = _p(g), int(g_padded)
+    d.x, d.x_f32 = _p(x), int(x is not None and x.dtype == torch.float32)
+    d.x1, d.c_x0, d.x0_shift = _p(x1), c_x0, x0_shift
+    d.N, d.D, d.H, d.W = dims
+    d.C = C_
+    d.scale, d.shift, d.mult, d.act, d.norm = _p(scale), _p(shift), _p(mult), act, int(norm)
+    d.gamma, d.mean, d.rstd, d.red = _p(gamma), _p(mean), _p(rstd), _p(red)
+    d.dx, d.dx_f32, d.accumulate = _p(dx), int(dx.dtype == torch.float32), int(accumulate)
+    d.dx_cstride, d.dx_coff = dx_cstride, dx_coff
+    s = stream()
+    if norm:
+        check(lib.vg_actnorm_bwd_stats(C.byref(d), s), 'vg_actnorm_bwd_stats')
+        if dgamma is not None:
+            check(lib.vg_in_param_grads(_p(red), dims[0], C_, _p(dgamma), _p(dbeta), s), 'vg_in_param_grads')
+    check(lib.vg_actnorm_bwd_apply(C.byref(d), s), 'vg_actnorm_bwd_apply')
+
+
+def concat_bwd(g, dims, Cu, Cs, dlow, dskip):
+    N, D, H, W = dims
+    check(lib.vg_concat_bwd(_p(g), N, D, H, W, Cu, Cs, _p(dlow), _p(dskip), stream()), 'vg_concat_bwd')
+
+
+def tanh_bwd(dy, y, dpre):
+    check(lib.vg_tanh_bwd(_p(dy), _p(y), _p(dpre), dy.numel(), stream()), 'vg_tanh_bwd')
+
+
+# ------------------------------------------------------------------------------------------------------
+# losses
+# ------------------------------------------------------------------------------------------------------
+def minmax(x, B, S, mm4):
+    check(lib.vg_minmax(_p(x), B, S, _p(mm4), stream()), 'vg_minmax')
+
+
+def minmax_apply(x, mm4, B, S, y):
+    check(lib.vg_minmax_apply(_p(x), _p(mm4), B, S, _p(y), stream()), 'vg_minmax_apply')
+
+
+def minmax_bwd(x, y, gy, mm4, B, S, tmp2, dx):
+    check(lib.vg_minmax_bwd(_p(x), _p(y), _p(gy), _p(mm4), B, S, _p(tmp2), _p(dx), stream()), 'vg_minmax_bwd')
+
+
+def bce(t, p, acc, gscale=0.0, gp=None, accumulate=False):
+    check(lib.vg_bce(_p(t), _p(p), t.numel(), _p(acc), gscale, _p(gp), int(accumulate), stream()), 'vg_bce')
+
+
+def mse(a, b, acc, gscale=0.0, gb=None, accumulate=False):
+    check(lib.vg_mse(_p(a), _p(b), a.numel(), _p(acc), gscale, _p(gb), int(accumulate), stream()), 'vg_mse')
+
+
+def mse_const(x, target, acc, gscale=0.0, gx=None, accumulate=False):
+    check(lib.vg_mse_const(_p(x), int(x.dtype == torch.float32), target, x.numel(), _p(acc), gscale, _p(gx),
+                           int(accumulate), stream()), 'vg_mse_const')
+
+
+def ssim_fwd(t, p, dims, acc, part):
+    B, D, H, W = dims
+    check(lib.vg_ssim_fwd(_p(t), _p(p), B, D, H, W, _p(acc), _p(part), stream()), 'vg_ssim_fwd')
+
+
+def ssim_bwd(t, p, part, dims, gscale, gp, accumulate=False):
+    B, D, H, W = dims
+    check(lib.vg_ssim_bwd(_p(t), _p(p), _p(part), B, D, H, W, gscale, _p(gp), int(accumulate), stream()), 'vg_ssim_bwd')
+
+
+def soft_skel_fwd(img, dims, iters, imgs, skels):
+    B, D, H, W = dims
+    check(lib.vg_soft_skel_fwd(_p(img), B, D, H, W, iters, _p(imgs), _p(skels), stream()), 'vg_soft_skel_fwd')
+
+
+def soft_skel_bwd(imgs, skels, gskel, dims, iters, work, gimg):
+    B, D, H, W = dims
+    check(lib.vg_soft_skel_bwd(_p(imgs), _p(skels), _p(gskel), B, D, H, W, iters, _p(work), _p(gimg), stream()),
+          'vg_soft_skel_bwd')
+
+
+def cldice_coef(sums7, w, alpha, coef6):
+    check(lib.vg_cldice_coef(_p(sums7), w, alpha, _p(coef6), stream()), 'vg_cldice_coef')
+
+
+def cldice_grads(t, skel_t, coef6, gskel_p, gp, accumulate=False):
+    check(lib.vg_cldice_grads(_p(t), _p(skel_t), _p(coef6), t.numel(), _p(gskel_p), _p(gp), int(accumulate), stream()),
+          'vg_cldice_grads')
+
+
+def dot_sums(a, b, sums3):
+    check(lib.vg_dot_sums(_p(a), _p(b), a.numel(), _p(sums3), stream()), 'vg_dot_sums')
+
+
+def axpby(a, alpha, b, beta, y, accumulate=False):
+    check(lib.vg_axpby(_p(a), alpha, _p(b), beta, a.numel(), _p(y), int(accumulate), stream()), 'vg_axpby')
+
+
+def adam_clip(w, g, m, v, seg_off, T, norms, lr_t, beta1, beta2, eps, clipnorm, grad_scale=1.0):
+    check(lib.vg_adam_clip(_p(w), _p(g), _p(m), _p(v), _p(seg_off), T, w.numel(), _p(norms), lr_t, beta1, beta2, eps,
+                           clipnorm, grad_scale, stream()), 'vg_adam_clip')
+
+
+def randn_bf16(out, std, seed, offset):
+    check(lib.vg_randn_bf16(_p(out), out.numel(), std, seed, offset, stream()), 'vg_randn_bf16')
+
+
+def dropout_mask(out, rate, seed, offset):
+    check(lib.vg_dropout_mask(_p(out), out.numel(), rate, seed, offset, stream()), 'vg_dropout_mask')

@@ -1,0 +1,309 @@
+"""VanGan training engine for MI355X: the host-side mirror of the reference's ``VanGan`` class
+(vangan.py:20-550) for the default non-Wasserstein ResUNet path, scheduling libvangan_hip.so kernels.
+
+Same surface as the reference for the hot path: ``train_step(real_I, real_S) -> dict`` with the 10 result keys
+of vangan.py:338-351, ``test_step``, ``distributed_train_step`` (one process per GPU, RCCL SUM all-reduce of the
+four flat gradient buckets - the counterpart of MirroredStrategy's implicit all-reduce inside
+optimizer.minimize, vangan.py:426-438,475-490), ``save_checkpoint`` / ``load_checkpoint``, and the public
+attributes ``gen_IS, gen_SI, disc_I, disc_S, layer_noise, current_epoch``.
+"""
+from __future__ import annotations
+
+import math
+import os
+from typing import Dict, Optional
+
+import torch
+
+from . import ops
+from .nets import PatchGAN, ParamStore, ResUNet, disc_param_specs, gen_param_specs, init_reference
+from .ops import Arena
+
+RESULT_KEYS = ['total_IS_loss', 'total_SI_loss', 'D_I_loss', 'D_S_loss', 'gen_IS_loss', 'gen_SI_loss',
+               'cycle_gen_SIS_loss', 'cycle_gen_ISI_loss', 'seg_loss', 'reconstruction_loss_I']
+NETS = ['gen_IS', 'gen_SI', 'disc_I', 'disc_S']
+
+
+class VanGan:
+    def __init__(self, subvol_patch_size=(128, 128, 128), batch_size: int = 1, global_batch_size: Optional[int] = None,
+                 n_devices: int = 1, device: str = 'cuda:0', seed: int = 0, lambda_cycle: float = 10.0,
+                 lambda_reconstruction: float = 5.0, lambda_topology: float = 5.0, lr: float = 2e-4,
+                 beta_1: float = 0.5, beta_2: float = 0.9, clipnorm: float = 100.0, layer_noise: float = 0.1,
+                 dropout_rate: float = 0.2, skel_iters: int = 15, output_dir: Optional[str] = None,
+                 process_group=None, arena_bytes: Optional[int] = None):
+        if not torch.cuda.is_available():
+            raise RuntimeError('VanGan engine needs an MI355X (HIP device); there is no CPU fallback')
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        self.dims = tuple(subvol_patch_size)
+        self.batch_size = batch_size
+        self.n_devices = n_devices
+        self.global_batch_size = global_batch_size if global_batch_size is not None else batch_size * n_devices
+        self.lambda_cycle, self.lambda_reconstruction, self.lambda_topology = lambda_cycle, lambda_reconstruction, lambda_topology
+        self.lr, self.beta_1, self.beta_2, self.clipnorm = lr, beta_1, beta_2, clipnorm
+        self.adam_eps = 1e-7                      # TP: tf.keras Adam default epsilon
+        self.layer_noise = layer_noise            # vangan.py:77 (GanMonitor decays it per epoch)
+        self.dropout_rate = dropout_rate
+        self.skel_iters = skel_iters
+        self.current_epoch = 0
+        self.pg = process_group
+        self.seed = seed
+        self.rng_offset = 0
+        self.stores: Dict[str, ParamStore] = {}
+        for i, name in enumerate(NETS):
+            st = ParamStore(gen_param_specs() if name.startswith('gen') else disc_param_specs(), self.device)
+            init_reference(st, seed + i)
+            self.stores[name] = st
+        self.gen_IS = ResUNet(self.stores['gen_IS'], self.dims)
+        self.gen_SI = ResUNet(self.stores['gen_SI'], self.dims)
+        self.disc_I = PatchGAN(self.stores['disc_I'], self.dims)
+        self.disc_S = PatchGAN(self.stores['disc_S'], self.dims)
+        self.nets = {'gen_IS': self.gen_IS, 'gen_SI': self.gen_SI, 'disc_I': self.disc_I, 'disc_S': self.disc_S}
+        S = self.dims[0] * self.dims[1] * self.dims[2]
+        if arena_bytes is None:
+            arena_bytes = int(batch_size * S * 5200) + (512 << 20)      # measured peak ~4.3 KB / voxel-sample
+        self.arena = Arena(arena_bytes, self.device)
+        self.comm_stream = torch.cuda.Stream(device=self.device) if self.pg is not None else None
+        self.checkpoint_dir = None
+        if output_dir is not None:
+            self.checkpoint_dir = os.path.join(output_dir, 'checkpoints')
+            os.makedirs(self.checkpoint_dir, exist_ok=True)
+        self.repack()
+
+    # ------------------------------------------------------------------------------------------------
+    def repack(self):
+        for n in self.nets.values():
+            n.pack()
+
+    def load_weights(self, P: Dict[str, Dict[str, torch.Tensor]]):
+        for k in NETS:
+            self.stores[k].load({n: t.to(self.device) for n, t in P[k].items()})
+        self.repack()
+
+    def export_weights(self):
+        return {k: self.stores[k].export() for k in NETS}
+
+    def export_grads(self):
+        return {k: self.stores[k].export(self.stores[k].g) for k in NETS}
+
+    # ------------------------------------------------------------------------------------------------
+    def _make_noise(self, disc: PatchGAN, N: int, ar: Arena):
+        if self.layer_noise <= 0 and self.dropout_rate <= 0:
+            return None, None
+        noise, drop = {}, {}
+        if self.layer_noise > 0:
+            for k, shp in disc.noise_shapes(N).items():
+                t = ar.alloc(shp, torch.bfloat16)
+                ops.randn_bf16(t, self.layer_noise, self.seed + 7919, self.rng_offset)
+                self.rng_offset += (t.numel() + 3) // 4
+                noise[k] = t
+        if self.dropout_rate > 0:
+            for k, c in (('down0', 128), ('down1', 256), ('down2', 512)):
+                t = ar.alloc((N, c), torch.float32)
+                ops.dropout_mask(t, self.dropout_rate, self.seed + 104729, self.rng_offset)
+                self.rng_offset += t.numel()
+                drop[k] = t
+        return noise, drop
+
+    def _losses_and_backward(self, real_I, real_S, training: bool, noise, drop, do_backward: bool):
+        ar = self.arena
+        ar.reset()
+        B = real_I.shape[0]
+        D, H, W = self.dims
+        S = D * H * W
+        gbs = float(self.global_batch_size)
+        vol = (B, D, H, W, 1)
+        f32 = torch.float32
+        acc = ar.alloc((16,), f32, zero=True)
+        bufS, bufI = ar.alloc((2 * B, D, H, W, 1), f32), ar.alloc((2 * B, D, H, W, 1), f32)
+        bufS[:B].copy_(real_S); bufI[:B].copy_(real_I)
+        rI, rS, fake_S, fake_I = bufI[:B], bufS[:B], bufS[B:], bufI[B:]
+        cyc_S, cyc_I = ar.alloc(vol, f32), ar.alloc(vol, f32)
+        c1 = self.gen_IS.forward(ar, rI, fake_S)                     # vangan.py:295
+        c2 = self.gen_SI.forward(ar, rS, fake_I)                     # :297
+        c3 = self.gen_IS.forward(ar, fake_I, cyc_S)                  # :300
+        c4 = self.gen_SI.forward(ar, fake_S, cyc_I)                  # :305
+
+        # ---- cycle / segmentation losses on cycled_S (loss_functions.py:185-190, 211-226) ----
+        mmS, mmcS = ar.alloc((B, 4), f32), ar.alloc((B, 4), f32)
+        nS, ncS = ar.alloc(vol, f32), ar.alloc(vol, f32)
+        ops.minmax(rS, B, S, mmS); ops.minmax_apply(rS, mmS, B, S, nS)
+        ops.minmax(cyc_S, B, S, mmcS); ops.minmax_apply(cyc_S, mmcS, B, S, ncS)
+        g_ncS = ar.alloc(vol, f32) if do_backward else None
+        ops.bce(nS, ncS, acc[0:1], self.lambda_cycle / (B * S * gbs), g_ncS, accumulate=False)
+        it = self.skel_iters
+        dims4 = (B, D, H, W)
+        imgs_p, skels_p = ar.alloc((it + 2,) + vol, f32), ar.alloc((it + 1,) + vol, f32)
+        imgs_t, skels_t = ar.alloc((it + 2,) + vol, f32), ar.alloc((it + 1,) + vol, f32)
+        ops.soft_skel_fwd(ncS, dims4, it, imgs_p, skels_p)
+        ops.soft_skel_fwd(nS, dims4, it, imgs_t, skels_t)
+        skel_p, skel_t = skels_p[it], skels_t[it]
+        sums = ar.alloc((9,), f32, zero=True)
+        coef = ar.alloc((8,), f32, zero=True)
+        ops.dot_sums(skel_p, nS, sums[0:3]); ops.dot_sums(skel_t, ncS, sums[3:6]); ops.dot_sums(nS, ncS, sums[6:9])
+        ops.cldice_coef(sums, self.lambda_topology / self.n_devices, 0.5, coef)
+        if do_backward:
+            gskel = ar.alloc(vol, f32)
+            ops.cldice_grads(nS, skel_t, coef, gskel, g_ncS, accumulate=True)
+            work = ar.alloc((3,) + vol, f32)
+            ops.soft_skel_bwd(imgs_p, skels_p, gskel, dims4, it, work, g_ncS)
+            g_cS = ar.alloc(vol, f32)
+            tmp2 = ar.alloc((B, 2), f32, zero=True)
+            ops.minmax_bwd(cyc_S, ncS, g_ncS, mmcS, B, S, tmp2, g_cS)
+
+        # ---- cycle MSE + SSIM reconstruction on cycled_I (loss_functions.py:179-180, 193-208) ----
+        g_cI = ar.alloc(vol, f32) if do_backward else None
+        ops.mse(rI, cyc_I, acc[1:2], self.lambda_cycle / (S * gbs), g_cI, accumulate=False)
+        mmI, mmcI = ar.alloc((B, 4), f32), ar.alloc((B, 4), f32)
+        nI, ncI = ar.alloc(vol, f32), ar.alloc(vol, f32)
+        ops.minmax(rI, B, S, mmI); ops.minmax_apply(rI, mmI, B, S, nI)
+        ops.minmax(cyc_I, B, S, mmcI); ops.minmax_apply(cyc_I, mmcI, B, S, ncI)
+        part = ar.alloc((3,) + vol, f32) if do_backward else None
+        ops.ssim_fwd(nI, ncI, dims4, acc[2:3], part)
+        if do_backward:
+            g_ncI = ar.alloc(vol, f32)
+            ops.ssim_bwd(nI, ncI, part, dims4, self.lambda_reconstruction / (B * S * gbs), g_ncI, accumulate=False)
+            g_tmp = ar.alloc(vol, f32)
+            tmp2b = ar.alloc((B, 2), f32, zero=True)
+            ops.minmax_bwd(cyc_I, ncI, g_ncI, mmcI, B, S, tmp2b, g_tmp)
+            ops.axpby(g_tmp, 1.0, None, 0.0, g_cI, accumulate=True)
+
+        # ---- discriminators on [real; fake] (vangan.py:315-319) and LSGAN losses (:329-332) ----
+        ld = tuple(n // 8 for n in self.dims)
+        nps = ld[0] * ld[1] * ld[2]
+        logS, logI = ar.alloc((2 * B,) + ld + (1,), f32), ar.alloc((2 * B,) + ld + (1,), f32)
+        if training and noise is None:
+            nzS, dpS = self._make_noise(self.disc_S, 2 * B, ar)
+            nzI, dpI = self._make_noise(self.disc_I, 2 * B, ar)
+        else:
+            noise, drop = noise or {}, drop or {}
+            nzS, dpS, nzI, dpI = noise.get('S'), drop.get('S'), noise.get('I'), drop.get('I')
+        dS = self.disc_S.forward(ar, bufS, logS, nzS, dpS)
+        dI = self.disc_I.forward(ar, bufI, logI, nzI, dpI)
+        gd = 1.0 / (nps * gbs)
+        gS_D, gI_D = (ar.alloc(logS.shape, f32), ar.alloc(logI.shape, f32)) if do_backward else (None, None)
+        gS_G, gI_G = (ar.alloc(logS[B:].shape, f32), ar.alloc(logI[B:].shape, f32)) if do_backward else (None, None)
+        ops.mse_const(logS[B:], 1.0, acc[3:4], gd, gS_G)                                  # gen_IS_loss
+        ops.mse_const(logI[B:], 1.0, acc[4:5], gd, gI_G)                                  # gen_SI_loss
+        ops.mse_const(logS[:B], 1.0, acc[5:6], 0.5 * gd, None if gS_D is None else gS_D[:B])
+        ops.mse_const(logS[B:], 0.0, acc[6:7], 0.5 * gd, None if gS_D is None else gS_D[B:])
+        ops.mse_const(logI[:B], 1.0, acc[7:8], 0.5 * gd, None if gI_D is None else gI_D[:B])
+        ops.mse_const(logI[B:], 0.0, acc[8:9], 0.5 * gd, None if gI_D is None else gI_D[B:])
+
+        if do_backward:
+            for st in self.stores.values():
+                st.g.zero_()
+            # discriminator sweeps: D loss over [real;fake] (weights) and generator loss through the fake half
+            g_fS, g_fI = ar.alloc(vol, f32), ar.alloc(vol, f32)
+            self.disc_I.backward(ar, dI, gI_D, 0, 2 * B, wgrad=True)
+            self.disc_S.backward(ar, dS, gS_D, 0, 2 * B, wgrad=True)
+            self._start_allreduce(['disc_I', 'disc_S'])
+            self.disc_S.backward(ar, dS, gS_G, B, 2 * B, wgrad=False, dx=g_fS)
+            self.disc_I.backward(ar, dI, gI_G, B, 2 * B, wgrad=False, dx=g_fI)
+            mk = ar.mark()
+            self.gen_IS.backward(ar, c1, g_fS); ar.release(mk)        # adversarial application
+            self.gen_IS.backward(ar, c3, g_cS); ar.release(mk)        # cycle application
+            self._start_allreduce(['gen_IS'])
+            self.gen_SI.backward(ar, c2, g_fI); ar.release(mk)
+            self.gen_SI.backward(ar, c4, g_cI); ar.release(mk)
+            self._start_allreduce(['gen_SI'])
+        self._acc, self._coef = acc, coef
+        self._aux = dict(fake_S=fake_S, fake_I=fake_I, cycled_S=cyc_S, cycled_I=cyc_I, logits_S=logS, logits_I=logI)
+        return B, S, nps
+
+    def _results(self, B, S, nps) -> Dict[str, float]:
+        a = self._acc.cpu().tolist()        # the only host sync of the step
+        seg = float(self._coef[5].item())
+        gbs = float(self.global_batch_size)
+        cyc_I = a[0] / (B * S * gbs) * self.lambda_cycle
+        cyc_S = a[1] / (S * gbs) * self.lambda_cycle
+        rec = a[2] / (B * S * gbs) * self.lambda_reconstruction
+        gIS, gSI = a[3] / (nps * gbs), a[4] / (nps * gbs)
+        dS = 0.5 * (a[5] + a[6]) / (nps * gbs)
+        dI = 0.5 * (a[7] + a[8]) / (nps * gbs)
+        vals = [gIS + cyc_I + seg, gSI + cyc_S + rec, dI, dS, gIS, gSI, cyc_I, cyc_S, seg, rec]
+        return dict(zip(RESULT_KEYS, vals))
+
+    # ------------------------------------------------------------------------------------------------
+    def _start_allreduce(self, names):
+        if self.pg is None:
+            return
+        import torch.distributed as dist
+        ev = torch.cuda.Event()
+        ev.record()
+        self.comm_stream.wait_event(ev)
+        with torch.cuda.stream(self.comm_stream):
+            for n in names:
+                dist.all_reduce(self.stores[n].g, op=dist.ReduceOp.SUM, group=self.pg)
+
+    def _finish_allreduce(self):
+        if self.pg is not None:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+
+    def _apply_adam(self):
+        for name in NETS:
+            st = self.stores[name]
+            st.step += 1
+            t = st.step
+            lr_t = self.lr * math.sqrt(1.0 - self.beta_2 ** t) / (1.0 - self.beta_1 ** t)
+            ops.adam_clip(st.w, st.g, st.m, st.v, st.seg_off, st.T, st.norms, lr_t, self.beta_1, self.beta_2,
+                          self.adam_eps, self.clipnorm, 1.0)
+        self.repack()
+
+    # ------------------------------------------------------------------------------------------------
+    def train_step(self, real_I: torch.Tensor, real_S: torch.Tensor, noise=None, drop=None, apply: bool = True,
+                   sync: bool = True):
+        """vangan.py:380-440 (non-Wasserstein branch).  real_*: fp32 [B,D,H,W,1] on the device."""
+        B, S, nps = self._losses_and_backward(real_I, real_S, True, noise, drop, True)
+        self._finish_allreduce()
+        if apply:
+            self._apply_adam()
+        return self._results(B, S, nps) if sync else None
+
+    def test_step(self, real_I: torch.Tensor, real_S: torch.Tensor):
+        """vangan.py:442-457: training=False => no noise, no dropout, no backward."""
+        B, S, nps = self._losses_and_backward(real_I, real_S, False, {}, {}, False)
+        return self._results(B, S, nps)
+
+    def distributed_train_step(self, x, y):
+        """vangan.py:475-490: per-replica step + SUM of the result dict over replicas."""
+        res = self.train_step(x, y)
+        return self.reduce_dict(res)
+
+    def distributed_test_step(self, x, y):
+        return self.reduce_dict(self.test_step(x, y))
+
+    def reduce_dict(self, d: Dict[str, float]) -> Dict[str, float]:
+        if self.pg is None:
+            return d
+        import torch.distributed as dist
+        t = torch.tensor([d[k] for k in RESULT_KEYS], dtype=torch.float32, device=self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
+        return dict(zip(RESULT_KEYS, t.cpu().tolist()))
+
+    def broadcast_weights(self, src: int = 0):
+        if self.pg is None:
+            return
+        import torch.distributed as dist
+        for st in self.stores.values():
+            dist.broadcast(st.w, src=src, group=self.pg)
+        self.repack()
+
+    # ------------------------------------------------------------------------------------------------
+    def save_checkpoint(self, epoch: int):
+        """vangan.py:247-250 (own format: the TF tensor-bundle format is not readable without TF)."""
+        path = os.path.join(self.checkpoint_dir, 'checkpoint_e%d.pt' % (epoch + 1))
+        torch.save({k: dict(w=s.w.cpu(), m=s.m.cpu(), v=s.v.cpu(), step=s.step) for k, s in self.stores.items()}, path)
+        return path
+
+    def load_checkpoint(self, epoch: int, newpath: Optional[str] = None) -> bool:
+        d = newpath if newpath is not None else self.checkpoint_dir
+        path = os.path.join(d, 'checkpoint_e%d.pt' % epoch)
+        if not os.path.exists(path):
+            print('Error: Checkpoint not found!')                  # vangan.py:267-268: prints, does not raise
+            return False
+        ck = torch.load(path, map_location='cpu')
+        for k, s in self.stores.items():
+            s.w.copy_(ck[k]['w']); s.m.copy_(ck[k]['m']); s.v.copy_(ck[k]['v']); s.step = ck[k]['step']
+        self.repack()
+        return True
