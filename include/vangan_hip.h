@@ -85,6 +85,8 @@ typedef struct {
     int32_t out_f32;
     int32_t accumulate;      /* out += value (data-gradient accumulation) */
     float* out_sums;         /* [N][Cout][2] += (sum, sum of squares) of the stored values, or NULL */
+    int32_t f32;             /* exact-parity mode: every "bf16" buffer of this call (multi-channel sources, res, out,
+                                packed weights, and dy/dgrad operands) is float32 and the MFMA is the f32 16x16x4 form */
 } vg_conv_desc;
 
 int vg_conv3d(const vg_conv_desc* d, vg_stream_t stream);
@@ -96,7 +98,7 @@ int vg_conv3d_lds_bytes(const vg_conv_desc* d);
  * transpose=0: rows = Cout, contraction = Cin (forward); transpose=1: rows = Cin, contraction =
  * Cout (data gradient).  tap_idx[i] selects the source tap of packed tap i.  Returns Ktot>0. */
 int vg_pack_weights(const float* w, int T, int Cin, int Cout, const int32_t* tap_idx_dev, int ntaps,
-                    int transpose, int CK, void* out_bf16, vg_stream_t stream);
+                    int transpose, int CK, void* out, int out_f32, vg_stream_t stream);
 int vg_packed_ktot(int ntaps, int C, int CK);
 int vg_packed_rows(int N);
 
@@ -138,6 +140,7 @@ typedef struct {
     float* red;                               /* [N][C][2] */
     void* dx; int32_t dx_f32; int32_t accumulate;
     int32_t dx_cstride, dx_coff;              /* dx channel stride / offset (write into a slice) */
+    int32_t f32;                              /* exact-parity mode: g, x, x1 and dx are float32 */
 } vg_actnorm_bwd_desc;
 int vg_actnorm_bwd_stats(const vg_actnorm_bwd_desc* d, vg_stream_t stream);
 int vg_actnorm_bwd_apply(const vg_actnorm_bwd_desc* d, vg_stream_t stream);
@@ -147,7 +150,7 @@ int vg_in_param_grads(const float* red, int N, int C, float* dgamma, float* dbet
 /* Backward of the virtual upsample+concat (resunet_model.py:175-181): g is bf16 [N][D][H][W][Cu+Cs];
  * dlow[N][D/2][H/2][W/2][Cu] += sum of the 8 children, dskip[N][D][H][W][Cs] += g[..., Cu:]. */
 int vg_concat_bwd(const void* g, int N, int D, int H, int W, int Cu, int Cs, void* dlow, void* dskip,
-                  vg_stream_t stream);
+                  int f32, vg_stream_t stream);
 
 /* d_pre = dy * (1 - y*y)   (tanh output activation, resunet_model.py:245), all fp32 */
 int vg_tanh_bwd(const float* dy, const float* y, float* dpre, int64_t n, vg_stream_t stream);

@@ -25,7 +25,7 @@ class ConvDesc(C.Structure):
         ('ooff_w', c_int), ('BD', c_int), ('BH', c_int), ('BW', c_int), ('Cout', c_int),
         ('wpacked', c_void_p), ('CK', c_int), ('bias', c_void_p),
         ('res', c_void_p), ('res_scale', c_void_p), ('res_shift', c_void_p), ('tanh_out', c_int),
-        ('out', c_void_p), ('out_f32', c_int), ('accumulate', c_int), ('out_sums', c_void_p),
+        ('out', c_void_p), ('out_f32', c_int), ('accumulate', c_int), ('out_sums', c_void_p), ('f32', c_int),
     ]
 
 
@@ -37,6 +37,7 @@ class ActNormBwdDesc(C.Structure):
         ('scale', c_void_p), ('shift', c_void_p), ('mult', c_void_p), ('act', c_int), ('norm', c_int),
         ('gamma', c_void_p), ('mean', c_void_p), ('rstd', c_void_p), ('red', c_void_p),
         ('dx', c_void_p), ('dx_f32', c_int), ('accumulate', c_int), ('dx_cstride', c_int), ('dx_coff', c_int),
+        ('f32', c_int),
     ]
 
 
@@ -44,7 +45,7 @@ _SIGS = {
     'vg_version': ([], c_int),
     'vg_conv3d': ([C.POINTER(ConvDesc), c_void_p], c_int),
     'vg_conv3d_lds_bytes': ([C.POINTER(ConvDesc)], c_int),
-    'vg_pack_weights': ([c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p], c_int),
+    'vg_pack_weights': ([c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p], c_int),
     'vg_packed_ktot': ([c_int, c_int, c_int], c_int),
     'vg_packed_rows': ([c_int], c_int),
     'vg_conv3d_wgrad': ([C.POINTER(ConvDesc), c_void_p, c_int, C.POINTER(c_int), c_void_p, c_void_p, c_void_p], c_int),
@@ -53,7 +54,7 @@ _SIGS = {
     'vg_actnorm_bwd_stats': ([C.POINTER(ActNormBwdDesc), c_void_p], c_int),
     'vg_actnorm_bwd_apply': ([C.POINTER(ActNormBwdDesc), c_void_p], c_int),
     'vg_in_param_grads': ([c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p], c_int),
-    'vg_concat_bwd': ([c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p], c_int),
+    'vg_concat_bwd': ([c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p], c_int),
     'vg_tanh_bwd': ([c_void_p, c_void_p, c_void_p, c_i64, c_void_p], c_int),
     'vg_minmax': ([c_void_p, c_int, c_i64, c_void_p, c_void_p], c_int),
     'vg_minmax_apply': ([c_void_p, c_void_p, c_int, c_i64, c_void_p, c_void_p], c_int),

@@ -19,6 +19,37 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
 }
 __device__ __forceinline__ float bfround(float f) { return bf2f(f2bf(f)); }
 
+// ---- storage-type helpers: activations/gradients/weights are bf16 (product) or f32 (exact-parity mode) ----
+template <typename T> __device__ __forceinline__ void load8(const T* p, float* o);
+template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float* o) {
+    const bf16x8 r = *(const bf16x8*)p;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = bf2f((bf16_t)r[j]);
+}
+template <> __device__ __forceinline__ void load8<float>(const float* p, float* o) {
+    const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+    o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
+}
+template <typename T> __device__ __forceinline__ void store8(T* p, const float* v);
+template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float* v) {
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = (short)f2bf(v[j]);
+    *(bf16x8*)p = r;
+}
+template <> __device__ __forceinline__ void store8<float>(float* p, const float* v) {
+    *(f32x4*)p = (f32x4){v[0], v[1], v[2], v[3]}; *(f32x4*)(p + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+}
+template <typename T> __device__ __forceinline__ float ld1(const T* p);
+template <> __device__ __forceinline__ float ld1<bf16_t>(const bf16_t* p) { return bf2f(*p); }
+template <> __device__ __forceinline__ float ld1<float>(const float* p) { return *p; }
+template <typename T> __device__ __forceinline__ void st1(T* p, float v);
+template <> __device__ __forceinline__ void st1<bf16_t>(bf16_t* p, float v) { *p = f2bf(v); }
+template <> __device__ __forceinline__ void st1<float>(float* p, float v) { *p = v; }
+template <typename T> __device__ __forceinline__ float rnd(float v);          // value as it will be stored
+template <> __device__ __forceinline__ float rnd<bf16_t>(float v) { return bfround(v); }
+template <> __device__ __forceinline__ float rnd<float>(float v) { return v; }
+
 __device__ __forceinline__ float vg_act(float x, int act) {
     if (act == VG_ACT_RELU) return fmaxf(x, 0.f);
     if (act == VG_ACT_LRELU) return x > 0.f ? x : VG_LRELU * x;

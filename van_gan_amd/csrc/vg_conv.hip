@@ -20,13 +20,14 @@
 
 struct ConvOut {
     int OD, OH, OW, ostr, ood, ooh, oow, BD, BH, BW, Cout;
-    const bf16_t* wp; int Ktot, nchunks, kc_pad;
-    const float* bias; const bf16_t* res; const float* rs; const float* rb; int tanh_out;
+    const void* wp; int Ktot, nchunks, kc_pad;
+    const float* bias; const void* res; const float* rs; const float* rb; int tanh_out;
     void* out; int out_f32, accumulate; float* sums;
 };
 
-template <int BN, int MSUB>
+template <typename T, int BN, int MSUB>
 __global__ __launch_bounds__(256) void conv_kernel(const GatherIn g, const ConvOut p) {
+    constexpr bool F32 = sizeof(T) == 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = blockIdx.z, ntile = blockIdx.y;
@@ -62,21 +63,42 @@ __global__ __launch_bounds__(256) void conv_kernel(const GatherIn g, const ConvO
     const int gpc = g.CK >> 3;
     const int ngroups = g.ntaps * gpc;
     const int ksteps = (ngroups + 3) >> 2;
-    const bf16_t* wrow[BN / 16];
+    const T* wrow[BN / 16];
 #pragma unroll
     for (int a = 0; a < BN / 16; ++a)
-        wrow[a] = p.wp + (size_t)(ntile * BN + a * 16 + (lane & 15)) * p.Ktot + 8 * (lane >> 4);
+        wrow[a] = (const T*)p.wp + (size_t)(ntile * BN + a * 16 + (lane & 15)) * p.Ktot + (F32 ? 1 : 8) * (lane >> 4);
 
     for (int chunk = 0; chunk < p.nchunks; ++chunk) {
         __syncthreads();
         stage_scale_shift(g, scs, n, chunk, tid);
         __syncthreads();
-        stage_halo(g, halo, scs, n, od0, oh0, ow0, chunk, tid, 256);
+        stage_halo<T>(g, halo, scs, n, od0, oh0, ow0, chunk, tid, 256);
         __syncthreads();
+        const size_t kbase = (size_t)chunk * p.kc_pad;
+        if constexpr (F32) {
+            // exact-parity mode: f32 operands, v_mfma_f32_16x16x4_f32 (k = 4 consecutive channels of one tap)
+            int tap = 0, ch0 = 0;
+            const int nk4 = (g.ntaps * g.CK) >> 2;
+            for (int s = 0; s < nk4; ++s) {
+                const int off = tapoff[tap] + (ch0 + (lane >> 4)) * 4;
+                float b[MSUB], a[BN / 16];
+#pragma unroll
+                for (int i = 0; i < MSUB; ++i) b[i] = *(const float*)(halo + rowbase[i] + off);
+#pragma unroll
+                for (int q = 0; q < BN / 16; ++q) a[q] = wrow[q][kbase + s * 4];
+#pragma unroll
+                for (int q = 0; q < BN / 16; ++q)
+#pragma unroll
+                    for (int i = 0; i < MSUB; ++i)
+                        acc[q][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], b[i], acc[q][i], 0, 0, 0);
+                ch0 += 4;
+                if (ch0 >= g.CK) { ch0 = 0; ++tap; }
+            }
+            continue;
+        }
         // ---- MFMA over (tap, channel-group) pairs of this chunk ----
         int tap = 0, cg = lane >> 4;
         while (cg >= gpc) { cg -= gpc; ++tap; }
-        const size_t kbase = (size_t)chunk * p.kc_pad;
         for (int s = 0; s < ksteps; ++s) {
             const int tp = tap < g.ntaps ? tap : g.ntaps - 1;      // padded K: weights are zero there
             const int off = tapoff[tp] + cg * 16;
@@ -85,7 +107,7 @@ __global__ __launch_bounds__(256) void conv_kernel(const GatherIn g, const ConvO
             for (int i = 0; i < MSUB; ++i) b[i] = *(const bf16x8*)(halo + rowbase[i] + off);
             bf16x8 a[BN / 16];
 #pragma unroll
-            for (int q = 0; q < BN / 16; ++q) a[q] = *(const bf16x8*)(wrow[q] + kbase + s * 32);
+            for (int q = 0; q < BN / 16; ++q) a[q] = *(const bf16x8*)((const bf16_t*)wrow[q] + kbase + s * 32);
 #pragma unroll
             for (int q = 0; q < BN / 16; ++q)
 #pragma unroll
@@ -122,7 +144,7 @@ __global__ __launch_bounds__(256) void conv_kernel(const GatherIn g, const ConvO
                 float y = acc[q][i][r];
                 if (co < p.Cout) {
                     if (p.bias) y += p.bias[co];
-                    if (p.res) y += bf2f(p.res[idx + r]) * p.rs[n * p.Cout + co] + p.rb[n * p.Cout + co];
+                    if (p.res) y += ld1<T>((const T*)p.res + idx + r) * p.rs[n * p.Cout + co] + p.rb[n * p.Cout + co];
                     if (p.tanh_out) y = tanhf(y);
                     if (p.accumulate) y += p.out_f32 ? ((float*)p.out)[idx + r] : bf2f(((bf16_t*)p.out)[idx + r]);
                     if (!p.out_f32) y = bfround(y);
@@ -185,13 +207,13 @@ static int fill_conv(const vg_conv_desc* d, GatherIn& g, ConvOut& k, int& BN, in
     if (rc != VG_OK) return rc;
     k.OD = d->OD; k.OH = d->OH; k.OW = d->OW; k.ostr = d->ostr; k.ood = d->ooff_d; k.ooh = d->ooff_h; k.oow = d->ooff_w;
     k.BD = d->BD; k.BH = d->BH; k.BW = d->BW; k.Cout = d->Cout;
-    k.wp = (const bf16_t*)d->wpacked;
+    k.wp = d->wpacked;
     const int Cpad = ((g.Cin + d->CK - 1) / d->CK) * d->CK;
     k.nchunks = Cpad / d->CK;
     k.kc_pad = ((d->ntaps * d->CK + 31) / 32) * 32;
     k.Ktot = k.nchunks * k.kc_pad;
-    k.bias = d->bias; k.res = (const bf16_t*)d->res; k.rs = d->res_scale; k.rb = d->res_shift; k.tanh_out = d->tanh_out;
-    k.out = d->out; k.out_f32 = d->out_f32; k.accumulate = d->accumulate; k.sums = d->out_sums;
+    k.bias = d->bias; k.res = d->res; k.rs = d->res_scale; k.rb = d->res_shift; k.tanh_out = d->tanh_out;
+    k.out = d->out; k.out_f32 = (d->out_f32 || d->f32) ? 1 : 0; k.accumulate = d->accumulate; k.sums = d->out_sums;
     return VG_OK;
 }
 
@@ -201,16 +223,22 @@ extern "C" int vg_conv3d_lds_bytes(const vg_conv_desc* d) {
     return rc == VG_OK ? lds : rc;
 }
 
-template <int BN, int MSUB>
+template <typename T, int BN, int MSUB>
 static int launch_conv(const GatherIn& g, const ConvOut& k, int lds, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_kernel<BN, MSUB>, hipFuncAttributeMaxDynamicSharedMemorySize, VG_LDS_LIMIT);
+        (void)hipFuncSetAttribute((const void*)conv_kernel<T, BN, MSUB>, hipFuncAttributeMaxDynamicSharedMemorySize, VG_LDS_LIMIT);
         attr_set = true;
     }
     dim3 grid(g.tiles_d * g.tiles_h * g.tiles_w, (k.Cout + BN - 1) / BN, g.N);
-    hipLaunchKernelGGL((conv_kernel<BN, MSUB>), grid, dim3(256), lds, s, g, k);
+    hipLaunchKernelGGL((conv_kernel<T, BN, MSUB>), grid, dim3(256), lds, s, g, k);
     return vg_check_launch();
+}
+template <typename T>
+static int dispatch_conv(const GatherIn& g, const ConvOut& k, int BN, int MSUB, int lds, hipStream_t s) {
+    if (BN == 16) return MSUB == 2 ? launch_conv<T, 16, 2>(g, k, lds, s) : launch_conv<T, 16, 1>(g, k, lds, s);
+    if (BN == 32) return MSUB == 2 ? launch_conv<T, 32, 2>(g, k, lds, s) : launch_conv<T, 32, 1>(g, k, lds, s);
+    return MSUB == 2 ? launch_conv<T, 64, 2>(g, k, lds, s) : launch_conv<T, 64, 1>(g, k, lds, s);
 }
 
 extern "C" int vg_conv3d(const vg_conv_desc* d, vg_stream_t stream) {
@@ -218,9 +246,7 @@ extern "C" int vg_conv3d(const vg_conv_desc* d, vg_stream_t stream) {
     int rc = fill_conv(d, g, k, BN, MSUB, lds);
     if (rc != VG_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
-    if (BN == 16) return MSUB == 2 ? launch_conv<16, 2>(g, k, lds, s) : launch_conv<16, 1>(g, k, lds, s);
-    if (BN == 32) return MSUB == 2 ? launch_conv<32, 2>(g, k, lds, s) : launch_conv<32, 1>(g, k, lds, s);
-    return MSUB == 2 ? launch_conv<64, 2>(g, k, lds, s) : launch_conv<64, 1>(g, k, lds, s);
+    return d->f32 ? dispatch_conv<float>(g, k, BN, MSUB, lds, s) : dispatch_conv<bf16_t>(g, k, BN, MSUB, lds, s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -228,7 +254,7 @@ extern "C" int vg_conv3d(const vg_conv_desc* d, vg_stream_t stream) {
 // ------------------------------------------------------------------------------------------------
 __global__ void pack_weights_kernel(const float* __restrict__ w, int Cin, int Cout, const int* __restrict__ tap_idx,
                                     int ntaps, int transpose, int CK, int kc_pad, int Ktot, int rows_pad,
-                                    bf16_t* __restrict__ out) {
+                                    void* __restrict__ out, int out_f32) {
     const size_t total = (size_t)rows_pad * Ktot;
     const int NR = transpose ? Cin : Cout;     // logical rows
     const int C = transpose ? Cout : Cin;      // contraction channels
@@ -241,7 +267,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, int Cin, int Co
             const int ts = tap_idx[tap];
             v = transpose ? w[((size_t)ts * Cin + row) * Cout + ch] : w[((size_t)ts * Cin + ch) * Cout + row];
         }
-        out[i] = f2bf(v);
+        if (out_f32) ((float*)out)[i] = v; else ((bf16_t*)out)[i] = f2bf(v);
     }
 }
 
@@ -253,8 +279,8 @@ extern "C" int vg_packed_ktot(int ntaps, int C, int CK) {
 extern "C" int vg_packed_rows(int N) { return ((N + 63) / 64) * 64; }
 
 extern "C" int vg_pack_weights(const float* w, int T, int Cin, int Cout, const int32_t* tap_idx_dev, int ntaps,
-                               int transpose, int CK, void* out_bf16, vg_stream_t stream) {
-    if (!w || !tap_idx_dev || !out_bf16 || ntaps < 1 || ntaps > T) return VG_EINVAL;
+                               int transpose, int CK, void* out, int out_f32, vg_stream_t stream) {
+    if (!w || !tap_idx_dev || !out || ntaps < 1 || ntaps > T) return VG_EINVAL;
     const int C = transpose ? Cout : Cin, NR = transpose ? Cin : Cout;
     const int Ktot = vg_packed_ktot(ntaps, C, CK);
     if (Ktot < 0) return Ktot;
@@ -263,7 +289,7 @@ extern "C" int vg_pack_weights(const float* w, int T, int Cin, int Cout, const i
     const size_t total = (size_t)rows_pad * Ktot;
     int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, Cin, Cout,
-                       tap_idx_dev, ntaps, transpose, CK, kc_pad, Ktot, rows_pad, (bf16_t*)out_bf16);
+                       tap_idx_dev, ntaps, transpose, CK, kc_pad, Ktot, rows_pad, out, out_f32);
     int rc = vg_check_launch();
     return rc == VG_OK ? Ktot : rc;
 }

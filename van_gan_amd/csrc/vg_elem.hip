@@ -43,9 +43,9 @@ extern "C" int vg_in_finalize(const float* sums0, int c0, float count0, const fl
 // backward of a = mult*act(x*scale+shift): stats pass and apply pass
 // ------------------------------------------------------------------------------------------------
 struct ANB {
-    const bf16_t* g; int g_padded;
+    const void* g; int g_padded;
     const void* x; int x_f32;
-    const bf16_t* x1; int c_x0, x0_shift;
+    const void* x1; int c_x0, x0_shift;
     int N, D, H, W, C;
     const float* scale; const float* shift; const float* mult;
     int act, norm;
@@ -56,17 +56,15 @@ struct ANB {
 };
 
 // folded upstream gradient for VEC channels at voxel (d,h,w): transpose of reflect-pad-1
-template <int VEC>
+template <typename T, int VEC>
 __device__ __forceinline__ void load_g(const ANB& p, int n, int d, int h, int w, int c, float* out) {
 #pragma unroll
     for (int j = 0; j < VEC; ++j) out[j] = 0.f;
+    const T* gp = (const T*)p.g;
     if (!p.g_padded) {
         const size_t idx = ((((size_t)n * p.D + d) * p.H + h) * p.W + w) * p.C + c;
-        if (VEC == 8) {
-            const bf16x8 r = *(const bf16x8*)(p.g + idx);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) out[j] = bf2f((bf16_t)r[j]);
-        } else out[0] = bf2f(p.g[idx]);
+        if (VEC == 8) load8<T>(gp + idx, out);
+        else out[0] = ld1<T>(gp + idx);
         return;
     }
     const int PD = p.D + 2, PH = p.H + 2, PW = p.W + 2;
@@ -79,32 +77,29 @@ __device__ __forceinline__ void load_g(const ANB& p, int n, int d, int h, int w,
             for (int e = 0; e < nw; ++e) {
                 const size_t idx = ((((size_t)n * PD + qd[a]) * PH + qh[b]) * PW + qw[e]) * p.C + c;
                 if (VEC == 8) {
-                    const bf16x8 r = *(const bf16x8*)(p.g + idx);
+                    float r[8]; load8<T>(gp + idx, r);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) out[j] += bf2f((bf16_t)r[j]);
-                } else out[0] += bf2f(p.g[idx]);
+                    for (int j = 0; j < 8; ++j) out[j] += r[j];
+                } else out[0] += ld1<T>(gp + idx);
             }
 }
 
-template <int VEC>
+template <typename T, int VEC>
 __device__ __forceinline__ void load_x(const ANB& p, int n, int d, int h, int w, int c, float* x) {
     if (VEC == 8) {
-        bf16x8 r;
         if (p.x1) {
             if (c < p.c_x0) {
                 const int sh = p.x0_shift;
                 const size_t idx = ((((size_t)n * (p.D >> sh) + (d >> sh)) * (p.H >> sh) + (h >> sh)) * (p.W >> sh) + (w >> sh)) * p.c_x0 + c;
-                r = *(const bf16x8*)((const bf16_t*)p.x + idx);
+                load8<T>((const T*)p.x + idx, x);
             } else {
                 const size_t idx = ((((size_t)n * p.D + d) * p.H + h) * p.W + w) * (p.C - p.c_x0) + (c - p.c_x0);
-                r = *(const bf16x8*)(p.x1 + idx);
+                load8<T>((const T*)p.x1 + idx, x);
             }
         } else {
             const size_t idx = ((((size_t)n * p.D + d) * p.H + h) * p.W + w) * p.C + c;
-            r = *(const bf16x8*)((const bf16_t*)p.x + idx);
+            load8<T>((const T*)p.x + idx, x);
         }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) x[j] = bf2f((bf16_t)r[j]);
     } else {
         const size_t idx = (((size_t)n * p.D + d) * p.H + h) * p.W + w;
         x[0] = p.x_f32 ? ((const float*)p.x)[idx] : bf2f(((const bf16_t*)p.x)[idx]);
@@ -112,13 +107,13 @@ __device__ __forceinline__ void load_x(const ANB& p, int n, int d, int h, int w,
 }
 
 // dn for VEC channels; also returns xhat when norm
-template <int VEC>
+template <typename T, int VEC>
 __device__ __forceinline__ void compute_dn(const ANB& p, int n, int d, int h, int w, int c, float* dn, float* xh) {
     float g[VEC];
-    load_g<VEC>(p, n, d, h, w, c, g);
+    load_g<T, VEC>(p, n, d, h, w, c, g);
     const bool need_x = p.act != VG_ACT_NONE || p.norm;
     float x[VEC];
-    if (need_x) load_x<VEC>(p, n, d, h, w, c, x);
+    if (need_x) load_x<T, VEC>(p, n, d, h, w, c, x);
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
         const int nc = n * p.C + c + j;
@@ -133,7 +128,7 @@ __device__ __forceinline__ void compute_dn(const ANB& p, int n, int d, int h, in
     }
 }
 
-template <int VEC>
+template <typename T, int VEC>
 __global__ __launch_bounds__(256) void actnorm_stats_kernel(const ANB p) {
     __shared__ float red[256 * 2];          // [thread][2] staging for one channel slot at a time
     const int n = blockIdx.y;
@@ -148,7 +143,7 @@ __global__ __launch_bounds__(256) void actnorm_stats_kernel(const ANB p) {
         for (int v = blockIdx.x * p.vpb + vl; v < S; v += gridDim.x * p.vpb) {
             const int w = v % p.W; const int t = v / p.W; const int h = t % p.H, d = t / p.H;
             float dn[VEC], xh[VEC];
-            compute_dn<VEC>(p, n, d, h, w, cg * VEC, dn, xh);
+            compute_dn<T, VEC>(p, n, d, h, w, cg * VEC, dn, xh);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) { s0[j] += dn[j]; s1[j] += dn[j] * xh[j]; }
         }
@@ -169,7 +164,7 @@ __global__ __launch_bounds__(256) void actnorm_stats_kernel(const ANB p) {
     }
 }
 
-template <int VEC>
+template <typename T, int VEC>
 __global__ __launch_bounds__(256) void actnorm_apply_kernel(const ANB p) {
     const int n = blockIdx.y;
     const int tid = threadIdx.x;
@@ -190,7 +185,7 @@ __global__ __launch_bounds__(256) void actnorm_apply_kernel(const ANB p) {
     for (int v = blockIdx.x * p.vpb + vl; v < S; v += gridDim.x * p.vpb) {
         const int w = v % p.W; const int t = v / p.W; const int h = t % p.H, d = t / p.H;
         float dn[VEC], xh[VEC], o[VEC];
-        compute_dn<VEC>(p, n, d, h, w, c, dn, xh);
+        compute_dn<T, VEC>(p, n, d, h, w, c, dn, xh);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) o[j] = k0[j] * dn[j] - k1[j] - k2[j] * xh[j];
         const size_t oidx = ((size_t)n * S + v) * p.dx_cstride + p.dx_coff + c;
@@ -199,17 +194,13 @@ __global__ __launch_bounds__(256) void actnorm_apply_kernel(const ANB p) {
 #pragma unroll
             for (int j = 0; j < VEC; ++j) q[j] = p.accumulate ? q[j] + o[j] : o[j];
         } else if (VEC == 8) {
-            bf16x8* q = (bf16x8*)((bf16_t*)p.dx + oidx);
-            bf16x8 r;
+            bf16_t* q = (bf16_t*)p.dx + oidx;
             if (p.accumulate) {
-                const bf16x8 old = *q;
+                float old[8]; load8<bf16_t>(q, old);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) r[j] = (short)f2bf(bf2f((bf16_t)old[j]) + o[j]);
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) r[j] = (short)f2bf(o[j]);
+                for (int j = 0; j < 8; ++j) o[j] += old[j];
             }
-            *q = r;
+            store8<bf16_t>(q, o);
         } else {
             bf16_t* q = (bf16_t*)p.dx + oidx;
             q[0] = f2bf(p.accumulate ? bf2f(q[0]) + o[0] : o[0]);
@@ -220,18 +211,18 @@ __global__ __launch_bounds__(256) void actnorm_apply_kernel(const ANB p) {
 static int fill_anb(const vg_actnorm_bwd_desc* d, ANB& p, bool apply) {
     if (!d || !d->g || d->N < 1 || d->C < 1) return VG_EINVAL;
     if (d->C != 1 && (d->C % 8)) return VG_EINVAL;
-    if (d->x_f32 && d->C != 1) return VG_EINVAL;
+    if (d->x_f32 && d->C != 1 && !d->f32) return VG_EINVAL;
     if ((d->act != VG_ACT_NONE || d->norm) && !d->x) return VG_EINVAL;
     if (d->norm && (!d->mean || !d->rstd || !d->red)) return VG_EINVAL;
     if (apply && (!d->dx || (d->norm && !d->gamma))) return VG_EINVAL;
     if (d->g_padded && (d->D < 2 || d->H < 2 || d->W < 2)) return VG_EINVAL;
     if (d->x1 && (d->C == 1 || (d->c_x0 % 8) || d->c_x0 < 8 || d->c_x0 >= d->C)) return VG_EINVAL;
-    p.g = (const bf16_t*)d->g; p.g_padded = d->g_padded; p.x = d->x; p.x_f32 = d->x_f32;
-    p.x1 = (const bf16_t*)d->x1; p.c_x0 = d->c_x0; p.x0_shift = d->x1 ? (d->x0_shift ? 1 : 0) : 0;
+    p.g = d->g; p.g_padded = d->g_padded; p.x = d->x; p.x_f32 = (d->x_f32 || d->f32) ? 1 : 0;
+    p.x1 = d->x1; p.c_x0 = d->c_x0; p.x0_shift = d->x1 ? (d->x0_shift ? 1 : 0) : 0;
     p.N = d->N; p.D = d->D; p.H = d->H; p.W = d->W; p.C = d->C;
     p.scale = d->scale; p.shift = d->shift; p.mult = d->mult; p.act = d->act; p.norm = d->norm;
     p.gamma = d->gamma; p.mean = d->mean; p.rstd = d->rstd; p.red = d->red;
-    p.dx = d->dx; p.dx_f32 = d->dx_f32; p.accumulate = d->accumulate;
+    p.dx = d->dx; p.dx_f32 = (d->dx_f32 || d->f32) ? 1 : 0; p.accumulate = d->accumulate;
     p.dx_cstride = d->dx_cstride > 0 ? d->dx_cstride : d->C; p.dx_coff = d->dx_coff;
     p.gpc = d->C == 1 ? 1 : d->C / 8;
     if (p.gpc > 256) return VG_EINVAL;
@@ -251,15 +242,25 @@ extern "C" int vg_actnorm_bwd_stats(const vg_actnorm_bwd_desc* d, vg_stream_t st
     ANB p; int rc = fill_anb(d, p, false);
     if (rc != VG_OK) return rc;
     if (!p.red) return VG_EINVAL;
-    if (p.C == 1) hipLaunchKernelGGL(actnorm_stats_kernel<1>, anb_grid(p), dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(actnorm_stats_kernel<8>, anb_grid(p), dim3(256), 0, (hipStream_t)stream, p);
+    if (d->f32) {
+        if (p.C == 1) hipLaunchKernelGGL((actnorm_stats_kernel<float, 1>), anb_grid(p), dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((actnorm_stats_kernel<float, 8>), anb_grid(p), dim3(256), 0, (hipStream_t)stream, p);
+    } else {
+        if (p.C == 1) hipLaunchKernelGGL((actnorm_stats_kernel<bf16_t, 1>), anb_grid(p), dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((actnorm_stats_kernel<bf16_t, 8>), anb_grid(p), dim3(256), 0, (hipStream_t)stream, p);
+    }
     return vg_check_launch();
 }
 extern "C" int vg_actnorm_bwd_apply(const vg_actnorm_bwd_desc* d, vg_stream_t stream) {
     ANB p; int rc = fill_anb(d, p, true);
     if (rc != VG_OK) return rc;
-    if (p.C == 1) hipLaunchKernelGGL(actnorm_apply_kernel<1>, anb_grid(p), dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(actnorm_apply_kernel<8>, anb_grid(p), dim3(256), 0, (hipStream_t)stream, p);
+    if (d->f32) {
+        if (p.C == 1) hipLaunchKernelGGL((actnorm_apply_kernel<float, 1>), anb_grid(p), dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((actnorm_apply_kernel<float, 8>), anb_grid(p), dim3(256), 0, (hipStream_t)stream, p);
+    } else {
+        if (p.C == 1) hipLaunchKernelGGL((actnorm_apply_kernel<bf16_t, 1>), anb_grid(p), dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((actnorm_apply_kernel<bf16_t, 8>), anb_grid(p), dim3(256), 0, (hipStream_t)stream, p);
+    }
     return vg_check_launch();
 }
 
@@ -279,7 +280,8 @@ extern "C" int vg_in_param_grads(const float* red, int N, int C, float* dgamma, 
 // ------------------------------------------------------------------------------------------------
 // backward of UpSampling3D(2) + concatenate (resunet_model.py:175-181)
 // ------------------------------------------------------------------------------------------------
-__global__ void concat_bwd_kernel(const bf16_t* g, int N, int D, int H, int W, int Cu, int Cs, bf16_t* dlow, bf16_t* dskip) {
+template <typename T>
+__global__ void concat_bwd_kernel(const T* g, int N, int D, int H, int W, int Cu, int Cs, T* dlow, T* dskip) {
     const int C = Cu + Cs;
     const int gu = Cu / 8, gs = Cs / 8;
     const size_t nlow = (size_t)N * (D / 2) * (H / 2) * (W / 2) * gu;
@@ -293,34 +295,34 @@ __global__ void concat_bwd_kernel(const bf16_t* g, int N, int D, int H, int W, i
             float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) for (int e = 0; e < 2; ++e) {
                 const size_t idx = ((((size_t)n * D + 2 * d + a) * H + 2 * h + b) * W + 2 * w + e) * C + cg * 8;
-                const bf16x8 r = *(const bf16x8*)(g + idx);
+                float r[8]; load8<T>(g + idx, r);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) s[j] += bf2f((bf16_t)r[j]);
+                for (int j = 0; j < 8; ++j) s[j] += r[j];
             }
-            bf16x8* q = (bf16x8*)(dlow + i * 8);
-            const bf16x8 old = *q; bf16x8 r;
+            float old[8]; load8<T>(dlow + i * 8, old);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) r[j] = (short)f2bf(bf2f((bf16_t)old[j]) + s[j]);
-            *q = r;
+            for (int j = 0; j < 8; ++j) old[j] += s[j];
+            store8<T>(dlow + i * 8, old);
         } else {
             const size_t k = i - nlow;
             const int cg = (int)(k % gs); const size_t v = k / gs;
-            const bf16x8 a = *(const bf16x8*)(g + v * C + Cu + cg * 8);
-            bf16x8* q = (bf16x8*)(dskip + k * 8);
-            const bf16x8 old = *q; bf16x8 r;
+            float a[8], old[8];
+            load8<T>(g + v * C + Cu + cg * 8, a); load8<T>(dskip + k * 8, old);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) r[j] = (short)f2bf(bf2f((bf16_t)old[j]) + bf2f((bf16_t)a[j]));
-            *q = r;
+            for (int j = 0; j < 8; ++j) old[j] += a[j];
+            store8<T>(dskip + k * 8, old);
         }
     }
 }
 extern "C" int vg_concat_bwd(const void* g, int N, int D, int H, int W, int Cu, int Cs, void* dlow, void* dskip,
-                             vg_stream_t stream) {
+                             int f32, vg_stream_t stream) {
     if (!g || !dlow || !dskip || (Cu % 8) || (Cs % 8) || Cu < 8 || Cs < 8 || ((D | H | W) & 1)) return VG_EINVAL;
     const size_t total = (size_t)N * (D / 2) * (H / 2) * (W / 2) * (Cu / 8) + (size_t)N * D * H * W * (Cs / 8);
     int blocks = (int)((total + 255) / 256); if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(concat_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)g, N, D, H, W, Cu,
-                       Cs, (bf16_t*)dlow, (bf16_t*)dskip);
+    if (f32) hipLaunchKernelGGL(concat_bwd_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)g, N, D, H, W, Cu,
+                                Cs, (float*)dlow, (float*)dskip);
+    else hipLaunchKernelGGL(concat_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)g, N, D, H, W, Cu,
+                            Cs, (bf16_t*)dlow, (bf16_t*)dskip);
     return vg_check_launch();
 }
 

@@ -14,6 +14,7 @@ struct GatherIn {
     int8_t td[VG_MAX_TAPS], th[VG_MAX_TAPS], tw[VG_MAX_TAPS];
     int tmin_d, tmin_h, tmin_w, HD, HH, HW, RS, CK;
     int tdl, thl, twl, tiles_d, tiles_h, tiles_w;
+    int f32;        // storage type of multi-channel tensors / LDS tile: 0 bf16, 1 f32
 };
 
 __device__ __forceinline__ bool resolve_pos(int& p, int n, int mode) {
@@ -37,6 +38,7 @@ __device__ __forceinline__ void stage_scale_shift(const GatherIn& g, float* scs,
 }
 
 // Stage the halo tile whose output-tile origin is (od0,oh0,ow0): units of (halo voxel, 8 channels) = 16 B.
+template <typename T>
 __device__ __forceinline__ void stage_halo(const GatherIn& g, char* halo, const float* scs, int n, int od0, int oh0,
                                            int ow0, int chunk, int tid, int nthreads) {
     const int gpc = g.CK >> 3;
@@ -53,7 +55,7 @@ __device__ __forceinline__ void stage_halo(const GatherIn& g, char* halo, const 
         valid &= resolve_pos(ph, g.H, g.pad_mode);
         valid &= resolve_pos(pw, g.W, g.pad_mode);
         const int c = chunk * g.CK + cg * 8;
-        bf16x8 v = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (valid && c < g.Cin) {
             float x[8];
             int nval = 8;
@@ -62,16 +64,13 @@ __device__ __forceinline__ void stage_halo(const GatherIn& g, char* halo, const 
                 const size_t idx = ((size_t)(n * g.D + pd) * g.H + ph) * g.W + pw;
                 x[0] = g.src_f32 ? ((const float*)g.src0)[idx] : bf2f(((const bf16_t*)g.src0)[idx]);
             } else {
-                bf16x8 raw;
                 if (c < g.c0) {
                     const size_t idx = (((size_t)(n * Ds + (pd >> g.shift0)) * Hs + (ph >> g.shift0)) * Ws + (pw >> g.shift0)) * g.c0 + c;
-                    raw = *(const bf16x8*)((const bf16_t*)g.src0 + idx);
+                    load8<T>((const T*)g.src0 + idx, x);
                 } else {
                     const size_t idx = (((size_t)(n * g.D + pd) * g.H + ph) * g.W + pw) * g.c1 + (c - g.c0);
-                    raw = *(const bf16x8*)((const bf16_t*)g.src1 + idx);
+                    load8<T>((const T*)g.src1 + idx, x);
                 }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) x[j] = bf2f((bf16_t)raw[j]);
             }
             const bool has_noise = g.noise && qd >= 0 && qd < ND && qh >= 0 && qh < NH && qw >= 0 && qw < NW;
             const size_t nidx = has_noise ? ((((size_t)(n * ND + qd) * NH + qh) * NW + qw) * g.Cin + c) : 0;
@@ -80,17 +79,18 @@ __device__ __forceinline__ void stage_halo(const GatherIn& g, char* halo, const 
                 if (j < nval) {
                     float y = vg_act(x[j] * scs[cg * 8 + j] + scs[g.CK + cg * 8 + j], g.act);
                     if (has_noise) y += bf2f(g.noise[nidx + j]);
-                    v[j] = (short)f2bf(y);
+                    v[j] = y;
                 }
             }
         }
-        *(bf16x8*)(halo + (size_t)hv * g.RS + cg * 16) = v;
+        store8<T>((T*)(halo + (size_t)hv * g.RS) + cg * 8, v);
     }
 }
 
 // ---- host: validate the input side of a descriptor and derive the tile geometry for BM voxels ----
 static inline int fill_gather(const vg_conv_desc* d, GatherIn& g, int CK, int BM) {
     if (!d || !d->src0) return VG_EINVAL;
+    g.f32 = d->f32 ? 1 : 0;
     const int Cin = d->c_src0 + d->c_src1;
     if (Cin < 1 || d->ntaps < 1 || d->ntaps > VG_MAX_TAPS) return VG_EINVAL;
     if (Cin != 1 && ((d->c_src0 % 8) || (d->c_src1 % 8))) return VG_EINVAL;
@@ -114,7 +114,7 @@ static inline int fill_gather(const vg_conv_desc* d, GatherIn& g, int CK, int BM
         for (int a = 0; a < 3; ++a) { if (v[a] < mn[a]) mn[a] = v[a]; if (v[a] > mx[a]) mx[a] = v[a]; }
     }
     g.tmin_d = mn[0]; g.tmin_h = mn[1]; g.tmin_w = mn[2];
-    g.RS = CK * 2 + 16;
+    g.RS = CK * (d->f32 ? 4 : 2) + 16;
     int TW = pow2_ceil(d->OW); if (TW > 16) TW = 16;
     int TH = pow2_ceil(d->OH); if (TH > BM / TW) TH = BM / TW;
     int TD = BM / (TW * TH);

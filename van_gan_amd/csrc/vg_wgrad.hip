@@ -29,8 +29,9 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* base0, const char* base1) 
     return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
-template <int MAXI>
+template <typename T, int MAXI>
 __global__ __launch_bounds__(256) void wgrad_kernel(const GatherIn g, const WgradK p) {
+    constexpr bool F32 = sizeof(T) == 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lg = lane >> 4, li = lane & 15;
@@ -83,24 +84,20 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const GatherIn g, const Wgra
         __syncthreads();
         stage_scale_shift(g, scs, n, cib, tid);
         __syncthreads();
-        stage_halo(g, halo, scs, n, od0, oh0, ow0, cib, tid, 256);
+        stage_halo<T>(g, halo, scs, n, od0, oh0, ow0, cib, tid, 256);
         // ---- stage dY tile [BM][COB] (zero outside the grid / beyond Cout) ----
         for (int u = tid; u < BM * gco; u += 256) {
             const int m = u / gco, cg = u - m * gco;
             const int w = m & TWm, h = (m >> g.twl) & THm, d = m >> (g.twl + g.thl);
             const int od = od0 + d, oh = oh0 + h, ow = ow0 + w;
             const int c = cob * p.COB + cg * 8;
-            bf16x8 v = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+            float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             if (od < p.OD && oh < p.OH && ow < p.OW && c < p.Cout) {
                 const size_t vox = ((size_t)(n * p.OD + od) * p.OH + oh) * p.OW + ow;
-                if (p.Cout == 1) {
-                    const float f = p.dy_f32 ? ((const float*)p.dy)[vox] : bf2f(((const bf16_t*)p.dy)[vox]);
-                    v[0] = (short)f2bf(f);
-                } else {
-                    v = *(const bf16x8*)((const bf16_t*)p.dy + vox * p.Cout + c);
-                }
+                if (p.Cout == 1) v[0] = p.dy_f32 ? ((const float*)p.dy)[vox] : bf2f(((const bf16_t*)p.dy)[vox]);
+                else load8<T>((const T*)p.dy + vox * p.Cout + c, v);
             }
-            *(bf16x8*)(dyt + (size_t)m * p.DYS + cg * 16) = v;
+            store8<T>((T*)(dyt + (size_t)m * p.DYS) + cg * 8, v);
         }
         __syncthreads();
         if (do_db) {      // thread (row group, channel): partial column sums of the dY tile
@@ -108,9 +105,25 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const GatherIn g, const Wgra
             if (tid < nrg * p.COB) {
                 const int c = tid % p.COB;
                 float s = 0.f;
-                for (int m = tid / p.COB; m < BM; m += nrg) s += bf2f(*(const bf16_t*)(dyt + (size_t)m * p.DYS + c * 2));
+                for (int m = tid / p.COB; m < BM; m += nrg) s += ld1<T>((const T*)(dyt + (size_t)m * p.DYS) + c);
                 dbsum += s;
             }
+        }
+        if constexpr (F32) {
+            // exact-parity mode: v_mfma_f32_16x16x4_f32, k = 4 voxels; lane (lg, li): A[ci=li][k=lg], B[k=lg][co=li]
+            for (int s = 0; s < BM / 4; ++s) {
+                const int m0 = s * 4 + lg;
+                const int w0 = m0 & TWm, h0 = (m0 >> g.twl) & THm, d0 = m0 >> (g.twl + g.thl);
+                const int r0 = ((d0 * g.istr * g.HH + h0 * g.istr) * g.HW + w0 * g.istr) * g.RS;
+                const char* y0 = dyt + (size_t)m0 * p.DYS;
+#pragma unroll
+                for (int j = 0; j < MAXI; ++j) {
+                    const float a = *(const float*)(halo + r0 + tapoff[it_tap[j]] + (it_ci[j] * 16 + li) * 4);
+                    const float b = *(const float*)(y0 + (it_co[j] * 16 + li) * 4);
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[j], 0, 0, 0);
+                }
+            }
+            continue;
         }
         // ---- K loop over voxels, 32 per MFMA ----
         for (int s = 0; s < BM / 32; ++s) {
@@ -155,7 +168,7 @@ extern "C" int vg_conv3d_wgrad(const vg_conv_desc* d, const void* dy, int dy_f32
                                float* dw, float* db, vg_stream_t stream) {
     if (!d || !dy || !dw || !tap_idx_host) return VG_EINVAL;
     if (d->Cout < 1 || (d->Cout != 1 && (d->Cout % 8))) return VG_EINVAL;
-    if (dy_f32 && d->Cout != 1) return VG_EINVAL;
+    if (dy_f32 && d->Cout != 1 && !d->f32) return VG_EINVAL;
     const int Cin = d->c_src0 + d->c_src1;
     const int Cinp = ((Cin + 15) / 16) * 16, Coutp = ((d->Cout + 15) / 16) * 16;
     int CIB = 16;
@@ -168,7 +181,7 @@ extern "C" int vg_conv3d_wgrad(const vg_conv_desc* d, const void* dy, int dy_f32
     for (;;) {
         rc = fill_gather(d, g, CIB, BM);
         if (rc != VG_OK) return rc;
-        k.DYS = COB * 2 + 16;
+        k.DYS = COB * (d->f32 ? 4 : 2) + 16;
         lds = halo_bytes(g) + BM * k.DYS + 512 + 2 * CIB * 4;
         if (lds <= VG_LDS_LIMIT) break;
         if (BM > 64) BM = 64;
@@ -188,9 +201,11 @@ extern "C" int vg_conv3d_wgrad(const vg_conv_desc* d, const void* dy, int dy_f32
     int bx = 2048 / by; if (bx < 1) bx = 1; if (bx > k.total_tiles) bx = k.total_tiles;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)wgrad_kernel<MAXI>, hipFuncAttributeMaxDynamicSharedMemorySize, VG_LDS_LIMIT);
+        (void)hipFuncSetAttribute((const void*)wgrad_kernel<bf16_t, MAXI>, hipFuncAttributeMaxDynamicSharedMemorySize, VG_LDS_LIMIT);
+        (void)hipFuncSetAttribute((const void*)wgrad_kernel<float, MAXI>, hipFuncAttributeMaxDynamicSharedMemorySize, VG_LDS_LIMIT);
         attr_set = true;
     }
-    hipLaunchKernelGGL((wgrad_kernel<MAXI>), dim3(bx, by, 1), dim3(256), lds, (hipStream_t)stream, g, k);
+    if (d->f32) hipLaunchKernelGGL((wgrad_kernel<float, MAXI>), dim3(bx, by, 1), dim3(256), lds, (hipStream_t)stream, g, k);
+    else hipLaunchKernelGGL((wgrad_kernel<bf16_t, MAXI>), dim3(bx, by, 1), dim3(256), lds, (hipStream_t)stream, g, k);
     return vg_check_launch();
 }

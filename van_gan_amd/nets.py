@@ -142,7 +142,7 @@ class Act:
 
     def alloc_grad(self, arena: Arena):
         if self.grad is None:
-            self.grad = arena.alloc((self.N,) + self.dims + (self.C,), torch.bfloat16, zero=True)
+            self.grad = arena.alloc((self.N,) + self.dims + (self.C,), self.data.dtype, zero=True)
         return self.grad
 
 
@@ -168,7 +168,8 @@ class Norm:
 # Generator
 # ======================================================================================================
 class ResUNet:
-    def __init__(self, store: ParamStore, dims: Tuple[int, int, int]):
+    def __init__(self, store: ParamStore, dims: Tuple[int, int, int], dtype: torch.dtype = torch.bfloat16):
+        self.dtype = dtype
         D, H, W = dims
         if any(n % 16 or n < 32 for n in dims):
             raise ValueError('spatial dims must be multiples of 16 and >= 32 (4 stride-2 stages + reflect pad)')
@@ -178,15 +179,15 @@ class ResUNet:
         self.lv = lv
         L = self.L = {}
         Nn = self.Nn = {}
-        L['stem.conv1'] = ConvLayer(store, 'stem.conv1', 3, 1, f[0], 1, 'reflect', True, lv[0], need_dgrad=False)
-        L['stem.cb'] = ConvLayer(store, 'stem.cb.conv', 3, f[0], f[0], 1, 'reflect', True, lv[0])
-        L['stem.short'] = ConvLayer(store, 'stem.short', 1, 1, f[0], 1, 'same', True, lv[0], need_dgrad=False)
+        L['stem.conv1'] = ConvLayer(store, 'stem.conv1', 3, 1, f[0], 1, 'reflect', True, lv[0], need_dgrad=False, dtype=self.dtype)
+        L['stem.cb'] = ConvLayer(store, 'stem.cb.conv', 3, f[0], f[0], 1, 'reflect', True, lv[0], dtype=self.dtype)
+        L['stem.short'] = ConvLayer(store, 'stem.short', 1, 1, f[0], 1, 'same', True, lv[0], need_dgrad=False, dtype=self.dtype)
         Nn['stem.cb'] = Norm(store, 'stem.cb.in', f[0]); Nn['stem.short'] = Norm(store, 'stem.short.in', f[0])
 
         def resblock(name, ci, co, stride, in_dims, out_dims):
-            L[name + '.cb1'] = ConvLayer(store, name + '.cb1.conv', 3, ci, co, stride, 'reflect', True, in_dims)
-            L[name + '.cb2'] = ConvLayer(store, name + '.cb2.conv', 3, co, co, 1, 'reflect', True, out_dims)
-            L[name + '.short'] = ConvLayer(store, name + '.short', 1, ci, co, stride, 'same', True, in_dims)
+            L[name + '.cb1'] = ConvLayer(store, name + '.cb1.conv', 3, ci, co, stride, 'reflect', True, in_dims, dtype=self.dtype)
+            L[name + '.cb2'] = ConvLayer(store, name + '.cb2.conv', 3, co, co, 1, 'reflect', True, out_dims, dtype=self.dtype)
+            L[name + '.short'] = ConvLayer(store, name + '.short', 1, ci, co, stride, 'same', True, in_dims, dtype=self.dtype)
             Nn[name + '.cb1'] = Norm(store, name + '.cb1.in', ci)
             Nn[name + '.cb2'] = Norm(store, name + '.cb2.in', co)
             Nn[name + '.short'] = Norm(store, name + '.short.in', co)
@@ -194,11 +195,11 @@ class ResUNet:
         for e in range(1, 5):
             resblock('enc%d' % e, f[e - 1], f[e], 2, lv[e - 1], lv[e])
         for b in ('bridge.cb1', 'bridge.cb2'):
-            L[b] = ConvLayer(store, b + '.conv', 3, f[4], f[4], 1, 'reflect', True, lv[4])
+            L[b] = ConvLayer(store, b + '.conv', 3, f[4], f[4], 1, 'reflect', True, lv[4], dtype=self.dtype)
             Nn[b] = Norm(store, b + '.in', f[4])
         for d in (3, 2, 1, 0):
             resblock('dec%d' % d, f[d + 1] + f[d], f[d], 1, lv[d], lv[d])
-        L['out'] = ConvLayer(store, 'out', 1, f[0], 1, 1, 'same', True, lv[0])
+        L['out'] = ConvLayer(store, 'out', 1, f[0], 1, 1, 'same', True, lv[0], dtype=self.dtype)
 
     def pack(self):
         for l in self.L.values():
@@ -211,14 +212,14 @@ class ResUNet:
         n1 = Nn[name + '.cb1'].finalize(ar, *nrm_inputs)
         s1 = Src(src_raw.x0, (N,) + tuple(L[name + '.cb1'].in_dims), src_raw.c0, src_raw.x1, src_raw.c1, src_raw.shift0,
                  scale=n1['scale'], shift=n1['shift'], act=ACT_RELU)
-        r = Act(ar, N, out_dims, co)
+        r = Act(ar, N, out_dims, co, dtype=self.dtype)
         L[name + '.cb1'].forward(s1, r.data, sums=r.sums)
-        sc = Act(ar, N, out_dims, co)
+        sc = Act(ar, N, out_dims, co, dtype=self.dtype)
         L[name + '.short'].forward(src_raw, sc.data, sums=sc.sums)
         ns = Nn[name + '.short'].finalize(ar, sc)
         n2 = Nn[name + '.cb2'].finalize(ar, r)
         s2 = Src(r.data, (N,) + tuple(out_dims), co, scale=n2['scale'], shift=n2['shift'], act=ACT_RELU)
-        out = Act(ar, N, out_dims, co)
+        out = Act(ar, N, out_dims, co, dtype=self.dtype)
         L[name + '.cb2'].forward(s2, out.data, sums=out.sums, res=sc.data, res_scale=ns['scale'], res_shift=ns['shift'])
         ctx[name] = dict(n1=n1, s1=s1, r=r, sc=sc, ns=ns, n2=n2, s2=s2, out=out, src_raw=src_raw)
         return out
@@ -229,14 +230,14 @@ class ResUNet:
         f, lv, L, Nn = GEN_F, self.lv, self.L, self.Nn
         ctx = {'N': N, 'x': x, 'y': y}
         sx = Src(x, (N,) + lv[0], 1, f32=True)
-        c1 = Act(ar, N, lv[0], f[0])
+        c1 = Act(ar, N, lv[0], f[0], dtype=self.dtype)
         L['stem.conv1'].forward(sx, c1.data, sums=c1.sums)
-        sc = Act(ar, N, lv[0], f[0])
+        sc = Act(ar, N, lv[0], f[0], dtype=self.dtype)
         L['stem.short'].forward(sx, sc.data, sums=sc.sums)
         ns = Nn['stem.short'].finalize(ar, sc)
         n1 = Nn['stem.cb'].finalize(ar, c1)
         s1 = Src(c1.data, (N,) + lv[0], f[0], scale=n1['scale'], shift=n1['shift'], act=ACT_RELU)
-        h = Act(ar, N, lv[0], f[0])
+        h = Act(ar, N, lv[0], f[0], dtype=self.dtype)
         L['stem.cb'].forward(s1, h.data, sums=h.sums, res=sc.data, res_scale=ns['scale'], res_shift=ns['shift'])
         ctx['stem'] = dict(sx=sx, c1=c1, sc=sc, ns=ns, n1=n1, s1=s1, out=h)
         skips = [h]
@@ -247,11 +248,11 @@ class ResUNet:
             skips.append(h)
         nb1 = Nn['bridge.cb1'].finalize(ar, h)
         sb1 = Src(h.data, (N,) + lv[4], f[4], scale=nb1['scale'], shift=nb1['shift'], act=ACT_RELU)
-        b1 = Act(ar, N, lv[4], f[4])
+        b1 = Act(ar, N, lv[4], f[4], dtype=self.dtype)
         L['bridge.cb1'].forward(sb1, b1.data, sums=b1.sums)
         nb2 = Nn['bridge.cb2'].finalize(ar, b1)
         sb2 = Src(b1.data, (N,) + lv[4], f[4], scale=nb2['scale'], shift=nb2['shift'], act=ACT_RELU)
-        b2 = Act(ar, N, lv[4], f[4])
+        b2 = Act(ar, N, lv[4], f[4], dtype=self.dtype)
         L['bridge.cb2'].forward(sb2, b2.data, sums=b2.sums)
         ctx['bridge'] = dict(inp=h, nb1=nb1, sb1=sb1, b1=b1, nb2=nb2, sb2=sb2, b2=b2)
         h = b2
@@ -284,20 +285,20 @@ class ResUNet:
         cb1, cb2, short = L[name + '.cb1'], L[name + '.cb2'], L[name + '.short']
         mk = ar.mark()
         # shortcut InstanceNorm (no activation): d_sc
-        d_sc = ar.alloc(sc.data.shape, torch.bfloat16)
+        d_sc = ar.alloc(sc.data.shape, self.dtype)
         ssc = Src(sc.data, (N,) + sc.dims, sc.C)
         self._norm_bwd(ar, d_out, False, ssc, c['ns'], Nn[name + '.short'], d_sc, ACT_NONE, accumulate=False)
         # conv2: weights + data gradient on the padded grid, folded through relu(IN(r))
         cb2.wgrad(c['s2'], d_out)
-        dp = ar.alloc((N,) + cb2.buf_dims + (r.C,), torch.bfloat16)
+        dp = ar.alloc((N,) + cb2.buf_dims + (r.C,), self.dtype)
         cb2.dgrad(d_out, N, dp, accumulate=False)
-        d_r = ar.alloc(r.data.shape, torch.bfloat16)
+        d_r = ar.alloc(r.data.shape, self.dtype)
         self._norm_bwd(ar, dp, True, c['s2'], c['n2'], Nn[name + '.cb2'], d_r, ACT_RELU, accumulate=False)
         # conv1 and shortcut conv read the block input (possibly the virtual concat)
         s1, raw = c['s1'], c['src_raw']
         cb1.wgrad(s1, d_r)
         short.wgrad(raw, d_sc)
-        dp1 = ar.alloc((N,) + cb1.buf_dims + (s1.C,), torch.bfloat16)
+        dp1 = ar.alloc((N,) + cb1.buf_dims + (s1.C,), self.dtype)
         cb1.dgrad(d_r, N, dp1, accumulate=False)
         inp = c['inp']
         if len(inp) == 1:            # encoder block: accumulate into the input's gradient
@@ -306,7 +307,7 @@ class ResUNet:
             short.dgrad(d_sc, N, gin, accumulate=True)
         else:                        # decoder block: gradient of the virtual concat, then split / sum-pool
             low, skip = inp
-            dcat = ar.alloc((N,) + tuple(cb1.in_dims) + (s1.C,), torch.bfloat16)
+            dcat = ar.alloc((N,) + tuple(cb1.in_dims) + (s1.C,), self.dtype)
             self._norm_bwd(ar, dp1, True, s1, c['n1'], Nn[name + '.cb1'], dcat, ACT_RELU, accumulate=False)
             short.dgrad(d_sc, N, dcat, accumulate=True)
             ops.concat_bwd(dcat, (N,) + tuple(cb1.in_dims), low.C, skip.C, low.grad, skip.grad)
@@ -335,12 +336,12 @@ class ResUNet:
         mk = ar.mark()
         cb2, cb1 = L['bridge.cb2'], L['bridge.cb1']
         cb2.wgrad(b['sb2'], b['b2'].grad)
-        dp = ar.alloc((N,) + cb2.buf_dims + (b['b1'].C,), torch.bfloat16)
+        dp = ar.alloc((N,) + cb2.buf_dims + (b['b1'].C,), self.dtype)
         cb2.dgrad(b['b2'].grad, N, dp, accumulate=False)
-        d_b1 = ar.alloc(b['b1'].data.shape, torch.bfloat16)
+        d_b1 = ar.alloc(b['b1'].data.shape, self.dtype)
         self._norm_bwd(ar, dp, True, b['sb2'], b['nb2'], Nn['bridge.cb2'], d_b1, ACT_RELU, accumulate=False)
         cb1.wgrad(b['sb1'], d_b1)
-        dp = ar.alloc((N,) + cb1.buf_dims + (b['inp'].C,), torch.bfloat16)
+        dp = ar.alloc((N,) + cb1.buf_dims + (b['inp'].C,), self.dtype)
         cb1.dgrad(d_b1, N, dp, accumulate=False)
         self._norm_bwd(ar, dp, True, b['sb1'], b['nb1'], Nn['bridge.cb1'], b['inp'].grad, ACT_RELU, accumulate=True)
         ar.release(mk)
@@ -349,14 +350,14 @@ class ResUNet:
         # stem
         s = ctx['stem']
         d_out = s['out'].grad
-        d_sc = ar.alloc(s['sc'].data.shape, torch.bfloat16)
+        d_sc = ar.alloc(s['sc'].data.shape, self.dtype)
         ssc = Src(s['sc'].data, (N,) + s['sc'].dims, s['sc'].C)
         self._norm_bwd(ar, d_out, False, ssc, s['ns'], Nn['stem.short'], d_sc, ACT_NONE, accumulate=False)
         cb = L['stem.cb']
         cb.wgrad(s['s1'], d_out)
-        dp = ar.alloc((N,) + cb.buf_dims + (s['c1'].C,), torch.bfloat16)
+        dp = ar.alloc((N,) + cb.buf_dims + (s['c1'].C,), self.dtype)
         cb.dgrad(d_out, N, dp, accumulate=False)
-        d_c1 = ar.alloc(s['c1'].data.shape, torch.bfloat16)
+        d_c1 = ar.alloc(s['c1'].data.shape, self.dtype)
         self._norm_bwd(ar, dp, True, s['s1'], s['n1'], Nn['stem.cb'], d_c1, ACT_RELU, accumulate=False)
         L['stem.conv1'].wgrad(s['sx'], d_c1)
         L['stem.short'].wgrad(s['sx'], d_sc)
@@ -371,17 +372,18 @@ class PatchGAN:
 
     NAMES = ['conv0', 'down0', 'down1', 'down2', 'out']
 
-    def __init__(self, store: ParamStore, dims: Tuple[int, int, int]):
+    def __init__(self, store: ParamStore, dims: Tuple[int, int, int], dtype: torch.dtype = torch.bfloat16):
+        self.dtype = dtype
         self.store, self.dims = store, tuple(dims)
         lv = [tuple(n >> i for n in dims) for i in range(4)]
         self.lv = lv
         self.ch = [1, 64, 128, 256, 512]
         L = self.L = {}
-        L['conv0'] = ConvLayer(store, 'conv0', 4, 1, 64, 2, 'reflect', True, lv[0])
-        L['down0'] = ConvLayer(store, 'down0', 4, 64, 128, 2, 'reflect', False, lv[1])
-        L['down1'] = ConvLayer(store, 'down1', 4, 128, 256, 2, 'reflect', False, lv[2])
-        L['down2'] = ConvLayer(store, 'down2', 4, 256, 512, 1, 'same', False, lv[3])
-        L['out'] = ConvLayer(store, 'out', 3, 512, 1, 1, 'same', True, lv[3])
+        L['conv0'] = ConvLayer(store, 'conv0', 4, 1, 64, 2, 'reflect', True, lv[0], dtype=self.dtype)
+        L['down0'] = ConvLayer(store, 'down0', 4, 64, 128, 2, 'reflect', False, lv[1], dtype=self.dtype)
+        L['down1'] = ConvLayer(store, 'down1', 4, 128, 256, 2, 'reflect', False, lv[2], dtype=self.dtype)
+        L['down2'] = ConvLayer(store, 'down2', 4, 256, 512, 1, 'same', False, lv[3], dtype=self.dtype)
+        L['out'] = ConvLayer(store, 'out', 3, 512, 1, 1, 'same', True, lv[3], dtype=self.dtype)
         self.Nn = {k: Norm(store, k + '.in', c) for k, c in zip(self.NAMES[:4], self.ch[1:])}
 
     def pack(self):
@@ -404,7 +406,7 @@ class PatchGAN:
         ctx = {'N': N, 'x': x}
         src = Src(x, (N,) + lv[0], 1, f32=True, noise=noise.get('conv0'), noise_pad=1)
         acts, srcs, sts = [], [src], []
-        h = Act(ar, N, lv[1], 64)
+        h = Act(ar, N, lv[1], 64, dtype=self.dtype)
         L['conv0'].forward(src, h.data, sums=h.sums)
         acts.append(h)
         prev_drop = None
@@ -418,7 +420,7 @@ class PatchGAN:
             if k == 'out':
                 lay.forward(src, logits)
             else:
-                h = Act(ar, N, lay.out_dims, lay.cout)
+                h = Act(ar, N, lay.out_dims, lay.cout, dtype=self.dtype)
                 lay.forward(src, h.data, sums=h.sums)
                 acts.append(h)
                 prev_drop = drop.get(k)
@@ -449,12 +451,12 @@ class PatchGAN:
             if wgrad:
                 lay.wgrad(src, g)
             a = ctx['acts'][li - 1]
-            dp = ar.alloc((N,) + tuple(lay.buf_dims) + (lay.cin,), torch.bfloat16)
+            dp = ar.alloc((N,) + tuple(lay.buf_dims) + (lay.cin,), self.dtype)
             lay.dgrad(g, N, dp, accumulate=False)
             st = ctx['sts'][li - 1]
             nrm = Nn[self.NAMES[li - 1]]
             red = ar.alloc((N, a.C, 2), torch.float32, zero=True)
-            dxa = ar.alloc((N,) + a.dims + (a.C,), torch.bfloat16)
+            dxa = ar.alloc((N,) + a.dims + (a.C,), self.dtype)
             ops.actnorm_bwd(dp, lay.pad == 'reflect', sl(a.data), (N,) + a.dims, a.C, dxa, scale=sl(st['scale']),
                             shift=sl(st['shift']), mult=sl(st['mult']), act=ACT_LRELU, norm=True, gamma=nrm.gamma,
                             mean=sl(st['mean']), rstd=sl(st['rstd']), red=red, accumulate=False,
@@ -465,7 +467,7 @@ class PatchGAN:
         if wgrad:
             lay.wgrad(src, g)
         if dx is not None:
-            dp = ar.alloc((N,) + tuple(lay.buf_dims) + (1,), torch.bfloat16)
+            dp = ar.alloc((N,) + tuple(lay.buf_dims) + (1,), self.dtype)
             lay.dgrad(g, N, dp, accumulate=False)
             ops.actnorm_bwd(dp, True, None, (N,) + self.lv[0], 1, dx, act=ACT_NONE, norm=False, accumulate=False)
         ar.release(mk)

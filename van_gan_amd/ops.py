@@ -103,7 +103,8 @@ class ConvLayer:
     packed bf16 weights for the forward and for every output-parity class of the data gradient."""
 
     def __init__(self, store, name: str, k: int, cin: int, cout: int, stride: int, pad: str, bias: bool,
-                 in_dims: Tuple[int, int, int], need_dgrad: bool = True):
+                 in_dims: Tuple[int, int, int], need_dgrad: bool = True, dtype: torch.dtype = torch.bfloat16):
+        self.dtype, self.f32 = dtype, int(dtype == torch.float32)
         self.name, self.k, self.cin, self.cout, self.stride, self.pad, self.has_bias = name, k, cin, cout, stride, pad, bias
         self.w, self.gw = store.param(name + '.w'), store.grad(name + '.w')
         self.b, self.gb = (store.param(name + '.b'), store.grad(name + '.b')) if bias else (None, None)
@@ -125,7 +126,7 @@ class ConvLayer:
         self.f_idx = torch.arange(T, dtype=torch.int32, device=dev)
         self.f_ck = self._pick_ck(cin, self.f_taps, stride, in_dims, self.out_dims, cout)
         self.f_ktot = check(lib.vg_packed_ktot(T, cin, self.f_ck), 'vg_packed_ktot')
-        self.f_wp = torch.zeros(lib.vg_packed_rows(cout), self.f_ktot, dtype=torch.bfloat16, device=dev)
+        self.f_wp = torch.zeros(lib.vg_packed_rows(cout), self.f_ktot, dtype=dtype, device=dev)
         # ---- data gradient: one class per output parity; buffer = padded grid for 'reflect' ----
         self.d_classes = []
         if need_dgrad:
@@ -155,7 +156,7 @@ class ConvLayer:
                         self.d_classes.append(dict(
                             off=(pd, ph, pw), iters=(nd, nh, nw), taps=taps, ck=ck, ktot=ktot,
                             idx=torch.tensor(idx, dtype=torch.int32, device=dev),
-                            wp=torch.zeros(lib.vg_packed_rows(cin), ktot, dtype=torch.bfloat16, device=dev)))
+                            wp=torch.zeros(lib.vg_packed_rows(cin), ktot, dtype=dtype, device=dev)))
 
     def _pick_ck(self, C_, taps, istr, in_dims, iters, rows) -> int:
         d = ConvDesc()
@@ -167,6 +168,7 @@ class ConvLayer:
         d.OD, d.OH, d.OW = iters
         d.BD, d.BH, d.BW = iters
         d.Cout = rows
+        d.f32 = self.f32
         best = None
         for ck in _ck_candidates(C_):
             d.CK = ck
@@ -185,10 +187,11 @@ class ConvLayer:
         """fp32 master weights -> bf16 packed operands (after every optimizer step)."""
         T = self.k ** 3
         s = stream()
-        check(lib.vg_pack_weights(_p(self.w), T, self.cin, self.cout, _p(self.f_idx), T, 0, self.f_ck, _p(self.f_wp), s), 'pack')
+        check(lib.vg_pack_weights(_p(self.w), T, self.cin, self.cout, _p(self.f_idx), T, 0, self.f_ck, _p(self.f_wp),
+                                  self.f32, s), 'pack')
         for c in self.d_classes:
             check(lib.vg_pack_weights(_p(self.w), T, self.cin, self.cout, _p(c['idx']), len(c['taps']), 1, c['ck'],
-                                      _p(c['wp']), s), 'pack')
+                                      _p(c['wp']), self.f32, s), 'pack')
 
     def _fwd_desc(self, src: Src) -> ConvDesc:
         d = ConvDesc()
@@ -199,6 +202,7 @@ class ConvLayer:
         d.ostr, d.ooff_d, d.ooff_h, d.ooff_w = 1, 0, 0, 0
         d.BD, d.BH, d.BW = self.out_dims
         d.Cout, d.wpacked, d.CK = self.cout, _p(self.f_wp), self.f_ck
+        d.f32 = self.f32
         return d
 
     def forward(self, src: Src, out: torch.Tensor, sums=None, res=None, res_scale=None, res_shift=None,
@@ -223,7 +227,7 @@ class ConvLayer:
         for c in self.d_classes:
             d = ConvDesc()
             d.src0, d.src1 = _p(dy), None
-            d.c_src0, d.c_src1, d.src0_shift, d.src_f32 = self.cout, 0, 0, int(dy.dtype == torch.float32)
+            d.c_src0, d.c_src1, d.src0_shift, d.src_f32 = self.cout, 0, 0, int(dy.dtype == torch.float32 and self.cout == 1)
             d.N = N
             d.D, d.H, d.W = self.out_dims
             d.act, d.istr, d.pad_mode = ACT_NONE, 1, PAD_ZERO
@@ -233,6 +237,7 @@ class ConvLayer:
             d.ooff_d, d.ooff_h, d.ooff_w = c['off']
             d.BD, d.BH, d.BW = self.buf_dims
             d.Cout, d.wpacked, d.CK = self.cin, _p(c['wp']), c['ck']
+            d.f32 = self.f32
             d.out, d.out_f32, d.accumulate = _p(out), int(out.dtype == torch.float32), int(accumulate)
             check(lib.vg_conv3d(C.byref(d), stream()), 'vg_conv3d(dgrad) ' + self.name)
 
@@ -260,6 +265,7 @@ def actnorm_bwd(g, g_padded, x, dims, C_, dx, *, scale=None, shift=None, mult=No
     d.gamma, d.mean, d.rstd, d.red = _p(gamma), _p(mean), _p(rstd), _p(red)
     d.dx, d.dx_f32, d.accumulate = _p(dx), int(dx.dtype == torch.float32), int(accumulate)
     d.dx_cstride, d.dx_coff = dx_cstride, dx_coff
+    d.f32 = int(g.dtype == torch.float32)
     s = stream()
     if norm:
         check(lib.vg_actnorm_bwd_stats(C.byref(d), s), 'vg_actnorm_bwd_stats')
@@ -270,7 +276,8 @@ def actnorm_bwd(g, g_padded, x, dims, C_, dx, *, scale=None, shift=None, mult=No
 
 def concat_bwd(g, dims, Cu, Cs, dlow, dskip):
     N, D, H, W = dims
-    check(lib.vg_concat_bwd(_p(g), N, D, H, W, Cu, Cs, _p(dlow), _p(dskip), stream()), 'vg_concat_bwd')
+    check(lib.vg_concat_bwd(_p(g), N, D, H, W, Cu, Cs, _p(dlow), _p(dskip), int(g.dtype == torch.float32), stream()),
+          'vg_concat_bwd')
 
 
 def tanh_bwd(dy, y, dpre):

@@ -30,9 +30,13 @@ class VanGan:
                  lambda_reconstruction: float = 5.0, lambda_topology: float = 5.0, lr: float = 2e-4,
                  beta_1: float = 0.5, beta_2: float = 0.9, clipnorm: float = 100.0, layer_noise: float = 0.1,
                  dropout_rate: float = 0.2, skel_iters: int = 15, output_dir: Optional[str] = None,
-                 process_group=None, arena_bytes: Optional[int] = None):
+                 process_group=None, arena_bytes: Optional[int] = None, precision: str = 'bf16'):
         if not torch.cuda.is_available():
             raise RuntimeError('VanGan engine needs an MI355X (HIP device); there is no CPU fallback')
+        if precision not in ('bf16', 'fp32'):
+            raise ValueError("precision must be 'bf16' (product path) or 'fp32' (exact-parity mode)")
+        self.precision = precision
+        self.dtype = torch.bfloat16 if precision == 'bf16' else torch.float32
         self.device = torch.device(device)
         torch.cuda.set_device(self.device)
         self.dims = tuple(subvol_patch_size)
@@ -54,14 +58,14 @@ class VanGan:
             st = ParamStore(gen_param_specs() if name.startswith('gen') else disc_param_specs(), self.device)
             init_reference(st, seed + i)
             self.stores[name] = st
-        self.gen_IS = ResUNet(self.stores['gen_IS'], self.dims)
-        self.gen_SI = ResUNet(self.stores['gen_SI'], self.dims)
-        self.disc_I = PatchGAN(self.stores['disc_I'], self.dims)
-        self.disc_S = PatchGAN(self.stores['disc_S'], self.dims)
+        self.gen_IS = ResUNet(self.stores['gen_IS'], self.dims, self.dtype)
+        self.gen_SI = ResUNet(self.stores['gen_SI'], self.dims, self.dtype)
+        self.disc_I = PatchGAN(self.stores['disc_I'], self.dims, self.dtype)
+        self.disc_S = PatchGAN(self.stores['disc_S'], self.dims, self.dtype)
         self.nets = {'gen_IS': self.gen_IS, 'gen_SI': self.gen_SI, 'disc_I': self.disc_I, 'disc_S': self.disc_S}
         S = self.dims[0] * self.dims[1] * self.dims[2]
         if arena_bytes is None:
-            arena_bytes = int(batch_size * S * 5200) + (512 << 20)      # measured peak ~4.3 KB / voxel-sample
+            arena_bytes = int(batch_size * S * 5200 * (2 if precision == 'fp32' else 1)) + (512 << 20)
         self.arena = Arena(arena_bytes, self.device)
         self.comm_stream = torch.cuda.Stream(device=self.device) if self.pg is not None else None
         self.checkpoint_dir = None
