@@ -1,0 +1,161 @@
+"""bench.py -- VAN-GAN train_step throughput on MI355X (BASELINE.json metric: train-steps/s + Mvoxels/s at 128^3 bf16).
+
+A "step" is one full VanGan.train_step (4 generator forwards, 4 discriminator forwards on [real;fake], all losses
+incl. the clDice soft skeleton, the four backward sweeps, 4x Adam, weight repack) on one batch of synthetic volumes
+that are already resident in HBM.  N=1: 128^3, batch 1 (the per-GPU workload of BASELINE config 4).  N>1: one
+process per GPU (torch.distributed.run), batch 1 per GPU, RCCL SUM all-reduce of the four gradient buckets on a side
+stream => weak scaling.
+
+Prints ONE JSON line on rank 0 (see the task contract) with two extra objects:
+  roofline     : the dominant kernel family (the bf16 MFMA gather-convolution: forward + data-gradient + weight-gradient
+                 launches of one step), algorithmic conv FLOPs of those launches / their summed HIP-event durations,
+                 against the 2.5 PFLOP/s dense bf16 MFMA peak;
+  cpu_baseline : the oracle (fp32 torch-CPU restatement of the reference graph -- NOT TensorFlow, which is not
+                 installable here) timed on this box's host cores on a bounded 32^3 sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+CONV_FLOP_PER_VOXEL = 2530548.0    # 12 F_G + 14 F_D per voxel-sample-step
+
+
+def synth_on_device(B, dims, seed, device):
+    """SURVEY 8d synthetic volumes, generated once on the host (setup, untimed) and moved to HBM."""
+    from oracle.vangan_oracle import synth_volumes     # input generator shared with the tests
+    rI, rS = synth_volumes(B, *dims, seed=seed)
+    return rI.to(device), rS.to(device)
+
+
+def cpu_baseline(budget_s=12.0):
+    import torch
+    from oracle import vangan_oracle as O
+    dims, B = (32, 32, 32), 1
+    P = O.make_models(0)
+    rI, rS = O.synth_volumes(B, *dims, seed=1234)
+    cfg = O.Cfg(B, 1)
+    state = {}
+    O.train_step(P, state, rI, rS, cfg)                 # warm-up (allocator, thread pool)
+    n, t0 = 0, time.time()
+    while True:
+        O.train_step(P, state, rI, rS, cfg)
+        n += 1
+        el = time.time() - t0
+        if el >= budget_s or n >= 8:
+            break
+    sps = n / el
+    return {'value': sps * B * dims[0] * dims[1] * dims[2] / 1e6, 'unit': 'Mvoxels/s', 'steps_per_s': sps,
+            'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': 'oracle.train_step (fp32 torch-CPU restatement of the reference graph, not TensorFlow) at '
+                      '32x32x32 batch 1, %d steps in %.1f s on %d host threads' % (n, el, torch.get_num_threads())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--size', type=int, default=128)
+    ap.add_argument('--batch', type=int, default=1, help='per-GPU batch')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ...'
+                             % (args.gpus, args.gpus))
+    torch.cuda.set_device(local)
+    device = 'cuda:%d' % local
+    pg = None
+    if world > 1:
+        dist.init_process_group('nccl', device_id=torch.device(device))
+        pg = dist.group.WORLD
+
+    from van_gan_amd import VanGan, ops
+    dims = (args.size,) * 3
+    B = args.batch
+    eng = VanGan(dims, batch_size=B, n_devices=world, device=device, seed=0, process_group=pg)
+    eng.broadcast_weights(0)
+    rI, rS = synth_on_device(B, dims, 1234 + rank, device)
+
+    for _ in range(args.warmup):
+        eng.train_step(rI, rS, sync=False)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = None
+    for i in range(args.steps):
+        res = eng.train_step(rI, rS, sync=(i == args.steps - 1))
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    ms_per_step = el / args.steps * 1e3
+    S = dims[0] * dims[1] * dims[2]
+    gbatch = B * world
+    steps_per_s = args.steps / el
+    mvox = steps_per_s * gbatch * S / 1e6
+
+    roof = None
+    if rank == 0 and not args.no_roofline:
+        ops.PROF = ops.KernelProfile()
+        eng.train_step(rI, rS, sync=True)
+        summ = ops.PROF.summary()
+        ops.PROF = None
+        tot_fl = sum(v['flops'] for v in summ.values())
+        tot_ms = sum(v['ms'] for v in summ.values())
+        n = sum(v['launches'] for v in summ.values())
+        ach = tot_fl / (tot_ms * 1e-3) / 1e12
+        roof = {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS,
+                'traffic': None,
+                'kernel': 'conv_kernel<bf16,*> + wgrad_kernel<bf16,*> (all gather-convolution launches of one step)',
+                'launches_per_step': n, 'avg_launch_ms': tot_ms / n, 'kernel_ms_per_step': tot_ms,
+                'algorithmic_gflop_per_step': tot_fl / 1e9,
+                'by_kind': {k: {'launches': v['launches'], 'ms': round(v['ms'], 3),
+                                'tflops': (v['flops'] / (v['ms'] * 1e-3) / 1e12) if v['ms'] > 0 else None} for k, v in summ.items()},
+                'whole_step_conv_tflops': steps_per_s * gbatch / world * S * CONV_FLOP_PER_VOXEL / 1e12}
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()
+
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        out = {
+            'metric': 'train Mvoxels/s (VanGan.train_step, 128^3 bf16)' if args.size == 128 else 'train Mvoxels/s (VanGan.train_step, %d^3 bf16)' % args.size,
+            'value': mvox, 'unit': 'Mvoxels/s', 'train_steps_per_sec': steps_per_s,
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'config': {'workload': 'VanGan.train_step, %dx%dx%d volumes, batch %d per GPU (global %d), clDice on, disc noise+dropout on'
+                                   % (dims + (B, gbatch)), 'parallelism': 'dp%d' % world},
+            'losses': res, 'roofline': roof, 'cpu_baseline': cpu,
+            'arena_peak_gb': eng.arena.peak / 1e9,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -35,6 +35,11 @@ typedef void* vg_stream_t;          /* hipStream_t */
 
 #define VG_MAX_TAPS 64
 
+/* Per-(n,c) reduction buffers (InstanceNorm sums, backward reductions) are STRIPED: [VG_STRIPES][N][C][2]; a
+ * workgroup adds into stripe (its index mod VG_STRIPES) so that float atomics from 10^4 workgroups do not serialise
+ * on one 128-byte line; consumers sum the stripes. */
+#define VG_STRIPES 8
+
 const char* vg_status_string(int code);
 int vg_version(void);
 
@@ -84,7 +89,7 @@ typedef struct {
     void* out;               /* bf16 (or f32 when out_f32) [N][BD][BH][BW][Cout] */
     int32_t out_f32;
     int32_t accumulate;      /* out += value (data-gradient accumulation) */
-    float* out_sums;         /* [N][Cout][2] += (sum, sum of squares) of the stored values, or NULL */
+    float* out_sums;         /* [VG_STRIPES][N][Cout][2] += (sum, sum of squares) of the stored values, or NULL */
     int32_t f32;             /* exact-parity mode: every "bf16" buffer of this call (multi-channel sources, res, out,
                                 packed weights, and dy/dgrad operands) is float32 and the MFMA is the f32 16x16x4 form */
 } vg_conv_desc;
@@ -109,13 +114,15 @@ int vg_packed_rows(int N);
  * dy_f32) [N][OD][OH][OW][Cout]; dw is fp32 DHWIO [T_total][Cin][Cout] indexed by tap_idx_host[i].
  * --------------------------------------------------------------------------------------------- */
 int vg_conv3d_wgrad(const vg_conv_desc* d, const void* dy, int dy_f32, const int32_t* tap_idx_host,
-                    float* dw, float* db, vg_stream_t stream);
+                    int T_total, float* dw, float* db, float* scratch, int64_t scratch_bytes, vg_stream_t stream);
+/* scratch (optional, device): when many workgroups share one dW element their slabs are stored to
+ * scratch[workgroup column][T_total*Cin*Cout] and summed in a fixed order by a second kernel instead of float atomics. */
 
 /* ---------------------------------------------------------------------------------------------
  * InstanceNorm helpers (tfa InstanceNormalization, resunet_model.py:36, building_blocks.py:190)
  * --------------------------------------------------------------------------------------------- */
-/* scale/shift[n][c] for on-read normalisation from accumulated (sum,sumsq); channels [0,c0) come from
- * sums0 (count0 voxels), [c0,c0+c1) from sums1.  mult[n][c] (SpatialDropout3D mask, >=0) optional.
+/* scale/shift[n][c] for on-read normalisation from accumulated striped (sum,sumsq) [VG_STRIPES][N][c][2]; channels
+ * [0,c0) come from sums0 (count0 voxels), [c0,c0+c1) from sums1.  mult[n][c] (SpatialDropout3D mask, >=0) optional.
  * Also writes mean/rstd [N][C] when non-NULL (needed by the backward). */
 int vg_in_finalize(const float* sums0, int c0, float count0, const float* sums1, int c1, float count1,
                    const float* gamma, const float* beta, const float* mult, int N, float eps,
@@ -137,14 +144,14 @@ typedef struct {
     const float* mult;                        /* [N][C] or NULL */
     int32_t act; int32_t norm;
     const float* gamma; const float* mean; const float* rstd;   /* norm=1 */
-    float* red;                               /* [N][C][2] */
+    float* red;                               /* [VG_STRIPES][N][C][2], zeroed by the caller */
     void* dx; int32_t dx_f32; int32_t accumulate;
     int32_t dx_cstride, dx_coff;              /* dx channel stride / offset (write into a slice) */
     int32_t f32;                              /* exact-parity mode: g, x, x1 and dx are float32 */
 } vg_actnorm_bwd_desc;
 int vg_actnorm_bwd_stats(const vg_actnorm_bwd_desc* d, vg_stream_t stream);
 int vg_actnorm_bwd_apply(const vg_actnorm_bwd_desc* d, vg_stream_t stream);
-/* dgamma[c] += sum_n red[n][c][1], dbeta[c] += sum_n red[n][c][0] */
+/* dgamma[c] += sum_{stripes,n} red[.][n][c][1], dbeta[c] += sum red[.][n][c][0] */
 int vg_in_param_grads(const float* red, int N, int C, float* dgamma, float* dbeta, vg_stream_t stream);
 
 /* Backward of the virtual upsample+concat (resunet_model.py:175-181): g is bf16 [N][D][H][W][Cu+Cs];

@@ -99,9 +99,10 @@ def test_conv_forward_dgrad_wgrad(k, cin, cout, stride, pad, dims):
               shift=shift.to(dev) if use_norm else None, act=ops.ACT_RELU if use_norm else ops.ACT_NONE)
     out_f32 = cout == 1
     out = torch.zeros(N, *lay.out_dims, cout, dtype=torch.float32 if out_f32 else torch.bfloat16, device=dev)
-    sums = torch.zeros(N, cout, 2, device=dev)
+    sums = torch.zeros(8, N, cout, 2, device=dev)
     lay.forward(src, out, sums=sums)
     torch.cuda.synchronize()
+    sums = sums.sum(0)
     # reference
     xr = xs.double()
     a = xr
@@ -157,7 +158,7 @@ def test_conv_virtual_concat_residual_noise_tanh():
     src = Src(low.to(dev), (N,) + dims, cu, skip.to(dev), cs, shift0=1, scale=scale.to(dev), shift=shift.to(dev),
               act=ops.ACT_LRELU, noise=noise.to(dev), noise_pad=1)
     out = torch.zeros(N, *dims, cout, dtype=torch.bfloat16, device=dev)
-    sums = torch.zeros(N, cout, 2, device=dev)
+    sums = torch.zeros(8, N, cout, 2, device=dev)
     lay.forward(src, out, sums=sums, res=res.to(dev), res_scale=rs.to(dev), res_shift=rb.to(dev))
     torch.cuda.synchronize()
     up = low.double().repeat_interleave(2, 1).repeat_interleave(2, 2).repeat_interleave(2, 3)
@@ -195,7 +196,10 @@ def test_in_finalize_and_actnorm_bwd():
     x = (torch.randn(N, *dims, Cc, generator=g) * 2 + 0.5).to(torch.bfloat16)
     gamma, beta = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g) * 0.2
     xd = x.double()
-    sums = torch.stack([xd.sum(dim=(1, 2, 3)), (xd ** 2).sum(dim=(1, 2, 3))], dim=-1).float().to(dev)
+    sums = torch.zeros(8, N, Cc, 2)
+    sums[3] = torch.stack([xd.sum(dim=(1, 2, 3)), (xd ** 2).sum(dim=(1, 2, 3))], dim=-1).float() * 0.25
+    sums[5] = sums[3] * 3.0          # striped partial sums
+    sums = sums.to(dev)
     scale, shift, mean, rstd = [torch.zeros(N, Cc, device=dev) for _ in range(4)]
     S = dims[0] * dims[1] * dims[2]
     ops.in_finalize(sums, Cc, S, gamma.to(dev), beta.to(dev), N, scale, shift, mean, rstd)
@@ -209,7 +213,7 @@ def test_in_finalize_and_actnorm_bwd():
     ap = O.to_ndhwc(O.reflect_pad1(O.to_ncdhw(a)))
     gp = torch.randn(ap.shape, generator=g).to(torch.bfloat16)
     (ap * gp.double()).sum().backward()
-    red = torch.zeros(N, Cc, 2, device=dev)
+    red = torch.zeros(8, N, Cc, 2, device=dev)
     dx = torch.zeros(N, *dims, Cc, dtype=torch.bfloat16, device=dev)
     dgam, dbet = torch.zeros(Cc, device=dev), torch.zeros(Cc, device=dev)
     ops.actnorm_bwd(gp.to(dev), True, x.to(dev), (N,) + dims, Cc, dx, scale=scale, shift=shift, act=ops.ACT_RELU,

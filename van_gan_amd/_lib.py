@@ -48,7 +48,8 @@ _SIGS = {
     'vg_pack_weights': ([c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p], c_int),
     'vg_packed_ktot': ([c_int, c_int, c_int], c_int),
     'vg_packed_rows': ([c_int], c_int),
-    'vg_conv3d_wgrad': ([C.POINTER(ConvDesc), c_void_p, c_int, C.POINTER(c_int), c_void_p, c_void_p, c_void_p], c_int),
+    'vg_conv3d_wgrad': ([C.POINTER(ConvDesc), c_void_p, c_int, C.POINTER(c_int), c_int, c_void_p, c_void_p, c_void_p, c_i64,
+                         c_void_p], c_int),
     'vg_in_finalize': ([c_void_p, c_int, c_float, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p, c_int,
                         c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], c_int),
     'vg_actnorm_bwd_stats': ([C.POINTER(ActNormBwdDesc), c_void_p], c_int),

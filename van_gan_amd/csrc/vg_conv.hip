@@ -182,7 +182,8 @@ __global__ __launch_bounds__(256) void conv_kernel(const GatherIn g, const ConvO
         __syncthreads();
         if (tid < BN * 2) {
             const int co = ntile * BN + (tid >> 1);
-            if (co < p.Cout) atomicAdd(&p.sums[((size_t)n * p.Cout + co) * 2 + (tid & 1)], stat[tid]);
+            const int stripe = blockIdx.x & (VG_STRIPES - 1);
+            if (co < p.Cout) atomicAdd(&p.sums[(((size_t)stripe * gridDim.z + n) * p.Cout + co) * 2 + (tid & 1)], stat[tid]);
         }
     }
 }

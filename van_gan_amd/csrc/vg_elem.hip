@@ -3,6 +3,7 @@
 // transpose of ReflectionPadding3D folded into the read, the backward of the virtual upsample+concat,
 // tanh backward, dtype copies and the counter-based RNG for GaussianNoise / SpatialDropout3D.
 #include "vg_common.h"
+#include <stdlib.h>
 
 // ------------------------------------------------------------------------------------------------
 // InstanceNorm finalise (tfa InstanceNormalization: biased variance, eps inside rsqrt)
@@ -14,9 +15,14 @@ __global__ void in_finalize_kernel(const float* sums0, int c0, float cnt0, const
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N * C) return;
     const int n = i / C, c = i % C;
-    float s, ss, cnt;
-    if (c < c0) { s = sums0[((size_t)n * c0 + c) * 2]; ss = sums0[((size_t)n * c0 + c) * 2 + 1]; cnt = cnt0; }
-    else { s = sums1[((size_t)n * c1 + (c - c0)) * 2]; ss = sums1[((size_t)n * c1 + (c - c0)) * 2 + 1]; cnt = cnt1; }
+    float s = 0.f, ss = 0.f, cnt;
+    if (c < c0) {
+        for (int t = 0; t < VG_STRIPES; ++t) { s += sums0[(((size_t)t * N + n) * c0 + c) * 2]; ss += sums0[(((size_t)t * N + n) * c0 + c) * 2 + 1]; }
+        cnt = cnt0;
+    } else {
+        for (int t = 0; t < VG_STRIPES; ++t) { s += sums1[(((size_t)t * N + n) * c1 + (c - c0)) * 2]; ss += sums1[(((size_t)t * N + n) * c1 + (c - c0)) * 2 + 1]; }
+        cnt = cnt1;
+    }
     const float mean = s / cnt;
     float var = ss / cnt - mean * mean;
     var = var < 0.f ? 0.f : var;
@@ -130,8 +136,10 @@ __device__ __forceinline__ void compute_dn(const ANB& p, int n, int d, int h, in
 
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void actnorm_stats_kernel(const ANB p) {
-    __shared__ float red[256 * 2];          // [thread][2] staging for one channel slot at a time
+    __shared__ float red[512 * 2];          // [channel][2] block accumulators (C <= 512)
     const int n = blockIdx.y;
+    for (int i = threadIdx.x; i < p.C * 2; i += 256) red[i] = 0.f;
+    __syncthreads();
     const int tid = threadIdx.x;
     const int nthr = p.gpc * p.vpb;
     const int cg = tid % p.gpc, vl = tid / p.gpc;
@@ -148,20 +156,18 @@ __global__ __launch_bounds__(256) void actnorm_stats_kernel(const ANB p) {
             for (int j = 0; j < VEC; ++j) { s0[j] += dn[j]; s1[j] += dn[j] * xh[j]; }
         }
     }
-    // reduce over the threads that share a channel group
+    // block reduction through LDS float atomics, then ONE contiguous global atomic per (channel, moment)
+    if (tid < nthr) {
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-        __syncthreads();
-        red[tid * 2] = tid < nthr ? s0[j] : 0.f; red[tid * 2 + 1] = tid < nthr ? s1[j] : 0.f;
-        __syncthreads();
-        if (tid < p.gpc) {
-            float a = 0.f, b = 0.f;
-            for (int k = tid; k < nthr; k += p.gpc) { a += red[k * 2]; b += red[k * 2 + 1]; }
-            const int c = tid * VEC + j;
-            atomicAdd(&p.red[((size_t)n * p.C + c) * 2], a);
-            atomicAdd(&p.red[((size_t)n * p.C + c) * 2 + 1], b);
+        for (int j = 0; j < VEC; ++j) {
+            atomicAdd(&red[(cg * VEC + j) * 2], s0[j]);
+            atomicAdd(&red[(cg * VEC + j) * 2 + 1], s1[j]);
         }
     }
+    __syncthreads();
+    const int stripe = blockIdx.x & (VG_STRIPES - 1);
+    float* dst = p.red + ((size_t)stripe * p.N + n) * p.C * 2;
+    for (int i = tid; i < p.C * 2; i += 256) atomicAdd(&dst[i], red[i]);
 }
 
 template <typename T, int VEC>
@@ -179,7 +185,9 @@ __global__ __launch_bounds__(256) void actnorm_apply_kernel(const ANB p) {
         if (p.norm) {
             const int nc = n * p.C + c + j;
             const float gr = p.gamma[c + j] * p.rstd[nc];
-            k0[j] = gr; k1[j] = gr * p.red[(size_t)nc * 2] / (float)S; k2[j] = gr * p.red[(size_t)nc * 2 + 1] / (float)S;
+            float r0 = 0.f, r1 = 0.f;
+            for (int t = 0; t < VG_STRIPES; ++t) { r0 += p.red[((size_t)t * p.N * p.C + nc) * 2]; r1 += p.red[((size_t)t * p.N * p.C + nc) * 2 + 1]; }
+            k0[j] = gr; k1[j] = gr * r0 / (float)S; k2[j] = gr * r1 / (float)S;
         } else { k0[j] = 1.f; k1[j] = 0.f; k2[j] = 0.f; }
     }
     for (int v = blockIdx.x * p.vpb + vl; v < S; v += gridDim.x * p.vpb) {
@@ -225,15 +233,20 @@ static int fill_anb(const vg_actnorm_bwd_desc* d, ANB& p, bool apply) {
     p.dx = d->dx; p.dx_f32 = (d->dx_f32 || d->f32) ? 1 : 0; p.accumulate = d->accumulate;
     p.dx_cstride = d->dx_cstride > 0 ? d->dx_cstride : d->C; p.dx_coff = d->dx_coff;
     p.gpc = d->C == 1 ? 1 : d->C / 8;
-    if (p.gpc > 256) return VG_EINVAL;
+    if (p.gpc > 256 || d->C > 512) return VG_EINVAL;
     p.vpb = 256 / p.gpc;
     if (!p.dx_f32 && d->C != 1 && ((p.dx_cstride % 8) || (p.dx_coff % 8))) return VG_EINVAL;
     return VG_OK;
 }
-static dim3 anb_grid(const ANB& p) {
+static dim3 anb_grid(const ANB& p, bool stats = false) {
     const int S = p.D * p.H * p.W;
     int bx = (S + p.vpb - 1) / p.vpb;
-    const int cap = 2048 / (p.N > 0 ? p.N : 1) + 1;
+    static int cap_total = -1, cap_stats = -1;
+    if (cap_total < 0) {
+        const char* e = getenv("VG_ANB_GRID_CAP"); cap_total = e ? atoi(e) : 2048;
+        const char* e2 = getenv("VG_ANB_STATS_CAP"); cap_stats = e2 ? atoi(e2) : 1024;
+    }
+    const int cap = (stats ? cap_stats : cap_total) / (p.N > 0 ? p.N : 1) + 1;
     if (bx > cap) bx = cap;
     return dim3(bx, p.N);
 }
@@ -243,11 +256,11 @@ extern "C" int vg_actnorm_bwd_stats(const vg_actnorm_bwd_desc* d, vg_stream_t st
     if (rc != VG_OK) return rc;
     if (!p.red) return VG_EINVAL;
     if (d->f32) {
-        if (p.C == 1) hipLaunchKernelGGL((actnorm_stats_kernel<float, 1>), anb_grid(p), dim3(256), 0, (hipStream_t)stream, p);
-        else hipLaunchKernelGGL((actnorm_stats_kernel<float, 8>), anb_grid(p), dim3(256), 0, (hipStream_t)stream, p);
+        if (p.C == 1) hipLaunchKernelGGL((actnorm_stats_kernel<float, 1>), anb_grid(p, true), dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((actnorm_stats_kernel<float, 8>), anb_grid(p, true), dim3(256), 0, (hipStream_t)stream, p);
     } else {
-        if (p.C == 1) hipLaunchKernelGGL((actnorm_stats_kernel<bf16_t, 1>), anb_grid(p), dim3(256), 0, (hipStream_t)stream, p);
-        else hipLaunchKernelGGL((actnorm_stats_kernel<bf16_t, 8>), anb_grid(p), dim3(256), 0, (hipStream_t)stream, p);
+        if (p.C == 1) hipLaunchKernelGGL((actnorm_stats_kernel<bf16_t, 1>), anb_grid(p, true), dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((actnorm_stats_kernel<bf16_t, 8>), anb_grid(p, true), dim3(256), 0, (hipStream_t)stream, p);
     }
     return vg_check_launch();
 }
@@ -268,7 +281,7 @@ __global__ void in_param_grads_kernel(const float* red, int N, int C, float* dga
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     float a = 0.f, b = 0.f;
-    for (int n = 0; n < N; ++n) { a += red[((size_t)n * C + c) * 2]; b += red[((size_t)n * C + c) * 2 + 1]; }
+    for (int n = 0; n < N * VG_STRIPES; ++n) { a += red[((size_t)n * C + c) * 2]; b += red[((size_t)n * C + c) * 2 + 1]; }
     dbeta[c] += a; dgamma[c] += b;
 }
 extern "C" int vg_in_param_grads(const float* red, int N, int C, float* dgamma, float* dbeta, vg_stream_t stream) {

@@ -3,6 +3,7 @@
 // stages one halo tile of it into LDS (normalised, activated, noised, rounded to bf16).
 #pragma once
 #include "vg_common.h"
+#include <stdlib.h>
 
 struct GatherIn {
     const void* src0; const void* src1;
@@ -15,6 +16,7 @@ struct GatherIn {
     int tmin_d, tmin_h, tmin_w, HD, HH, HW, RS, CK;
     int tdl, thl, twl, tiles_d, tiles_h, tiles_w;
     int f32;        // storage type of multi-channel tensors / LDS tile: 0 bf16, 1 f32
+    int dbg;        // development ablation flags (VG_DEBUG env): 1 skip halo staging, 2 skip dY staging, 4 skip MFMA
 };
 
 __device__ __forceinline__ bool resolve_pos(int& p, int n, int mode) {
@@ -87,10 +89,109 @@ __device__ __forceinline__ void stage_halo(const GatherIn& g, char* halo, const 
     }
 }
 
+// Unit table: the (halo voxel, channel group) decomposition of a tile is the same for every tile, so a persistent
+// workgroup computes it once (no integer divisions in the per-tile loop).  utab[u] = hd | hh<<8 | hw<<16 | cg<<24.
+__device__ __forceinline__ void build_unit_table(const GatherIn& g, int* utab, int tid, int nthreads) {
+    const int gpc = g.CK >> 3;
+    const int units = g.HD * g.HH * g.HW * gpc;
+    for (int u = tid; u < units; u += nthreads) {
+        const int hv = u / gpc, cg = u - hv * gpc;
+        const int hw = hv % g.HW; const int t2 = hv / g.HW;
+        const int hh = t2 % g.HH, hd = t2 / g.HH;
+        utab[u] = hd | (hh << 8) | (hw << 16) | (cg << 24);
+    }
+}
+
+// raw 8-channel vector as loaded from global memory
+template <typename T> struct Raw8;
+template <> struct Raw8<bf16_t> { bf16x8 v; };
+template <> struct Raw8<float> { f32x4 a, b; };
+__device__ __forceinline__ void raw_load(Raw8<bf16_t>& r, const bf16_t* p) { r.v = *(const bf16x8*)p; }
+__device__ __forceinline__ void raw_load(Raw8<float>& r, const float* p) { r.a = *(const f32x4*)p; r.b = *(const f32x4*)(p + 4); }
+__device__ __forceinline__ void raw_unpack(const Raw8<bf16_t>& r, float* o) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = bf2f((bf16_t)r.v[j]);
+}
+__device__ __forceinline__ void raw_unpack(const Raw8<float>& r, float* o) {
+    o[0] = r.a[0]; o[1] = r.a[1]; o[2] = r.a[2]; o[3] = r.a[3]; o[4] = r.b[0]; o[5] = r.b[1]; o[6] = r.b[2]; o[7] = r.b[3];
+}
+
+// Table-driven staging, UB units per thread per batch: all global loads of a batch are issued before the first one is
+// consumed (the per-unit load->wait->transform chain of the simple loop exposes one HBM latency per unit).
+template <typename T, int UB = 4>
+__device__ __forceinline__ void stage_halo_tab(const GatherIn& g, char* halo, const float* scs, const int* utab, int n,
+                                               int od0, int oh0, int ow0, int chunk, int tid, int nthreads) {
+    const int gpc = g.CK >> 3;
+    const int units = g.HD * g.HH * g.HW * gpc;
+    const int Ds = g.D >> g.shift0, Hs = g.H >> g.shift0, Ws = g.W >> g.shift0;
+    const int ND = g.D + 2 * g.npad, NH = g.H + 2 * g.npad, NW = g.W + 2 * g.npad;
+    const int bd = od0 * g.istr + g.tmin_d, bh = oh0 * g.istr + g.tmin_h, bw = ow0 * g.istr + g.tmin_w;
+    const bool c1mode = g.Cin == 1;
+    for (int u0 = tid; u0 < units; u0 += nthreads * UB) {
+        Raw8<T> raw[UB];
+        float x1[UB];
+        int meta[UB];              // LDS element offset (in 8-channel groups) | flags
+        bool ok[UB];
+        size_t nidx[UB];
+#pragma unroll
+        for (int k = 0; k < UB; ++k) {
+            const int u = u0 + k * nthreads;
+            ok[k] = false; meta[k] = -1; nidx[k] = ~(size_t)0; x1[k] = 0.f;
+            if (u < units) {
+                const int e = utab[u];
+                const int hd = e & 255, hh = (e >> 8) & 255, hw = (e >> 16) & 255, cg = e >> 24;
+                int pd = bd + hd, ph = bh + hh, pw = bw + hw;
+                const int qd = pd + g.npad, qh = ph + g.npad, qw = pw + g.npad;
+                bool valid = resolve_pos(pd, g.D, g.pad_mode);
+                valid &= resolve_pos(ph, g.H, g.pad_mode);
+                valid &= resolve_pos(pw, g.W, g.pad_mode);
+                const int c = chunk * g.CK + cg * 8;
+                meta[k] = (((hd * g.HH + hh) * g.HW + hw) << 4) | cg;
+                ok[k] = valid && c < g.Cin;
+                if (ok[k]) {
+                    if (c1mode) {
+                        const size_t idx = ((size_t)(n * g.D + pd) * g.H + ph) * g.W + pw;
+                        x1[k] = g.src_f32 ? ((const float*)g.src0)[idx] : bf2f(((const bf16_t*)g.src0)[idx]);
+                    } else if (c < g.c0) {
+                        const size_t idx = (((size_t)(n * Ds + (pd >> g.shift0)) * Hs + (ph >> g.shift0)) * Ws + (pw >> g.shift0)) * g.c0 + c;
+                        raw_load(raw[k], (const T*)g.src0 + idx);
+                    } else {
+                        const size_t idx = (((size_t)(n * g.D + pd) * g.H + ph) * g.W + pw) * g.c1 + (c - g.c0);
+                        raw_load(raw[k], (const T*)g.src1 + idx);
+                    }
+                    if (g.noise && qd >= 0 && qd < ND && qh >= 0 && qh < NH && qw >= 0 && qw < NW)
+                        nidx[k] = (((size_t)(n * ND + qd) * NH + qh) * NW + qw) * g.Cin + c;
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < UB; ++k) {
+            if (meta[k] < 0) continue;
+            const int cg = meta[k] & 15, hv = meta[k] >> 4;
+            float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (ok[k]) {
+                float x[8];
+                if (c1mode) { x[0] = x1[k]; } else raw_unpack(raw[k], x);
+                const int nval = c1mode ? 1 : 8;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (j < nval) {
+                        float y = vg_act(x[j] * scs[cg * 8 + j] + scs[g.CK + cg * 8 + j], g.act);
+                        if (nidx[k] != ~(size_t)0) y += bf2f(g.noise[nidx[k] + j]);
+                        v[j] = y;
+                    }
+                }
+            }
+            store8<T>((T*)(halo + (size_t)hv * g.RS) + cg * 8, v);
+        }
+    }
+}
+
 // ---- host: validate the input side of a descriptor and derive the tile geometry for BM voxels ----
 static inline int fill_gather(const vg_conv_desc* d, GatherIn& g, int CK, int BM) {
     if (!d || !d->src0) return VG_EINVAL;
     g.f32 = d->f32 ? 1 : 0;
+    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("VG_DEBUG"); dbg = e ? atoi(e) : 0; } g.dbg = dbg; }
     const int Cin = d->c_src0 + d->c_src1;
     if (Cin < 1 || d->ntaps < 1 || d->ntaps > VG_MAX_TAPS) return VG_EINVAL;
     if (Cin != 1 && ((d->c_src0 % 8) || (d->c_src1 % 8))) return VG_EINVAL;

@@ -7,8 +7,13 @@
 // GEMM view: M = ci, N = co, K = voxels.  Both operands are stored [voxel][channel] (channel innermost),
 // i.e. K is the SLOW axis of both, so the MFMA fragments (8 consecutive k per lane) are fetched with the
 // gfx950 transposing LDS read ds_read_b64_tr_b16: 4 voxel rows x 16 channels per 16-lane group, delivered
-// column-major.  A workgroup owns a (tap-group, ci-block, co-block) slab of dW and walks a strided set of
-// voxel tiles, keeping the slab in accumulators; it adds the slab to dW with fp32 atomics once at the end.
+// column-major.
+//
+// A persistent workgroup owns a slab of dW = (tap group) x (ci block) x (co block of 16*Q channels) and walks a strided
+// set of voxel tiles.  A wave owns "rows" r = (tap, 16 ci) of the slab (r = wave, wave+4, ...) times all Q co-blocks:
+// per 32-voxel K-step it reads the Q dY fragments once and one P fragment per row, so LDS traffic per MFMA is
+// (2R+2Q)/(RQ) transposing reads instead of 4.  The slab lives in accumulators for the whole walk and is added to dW
+// with fp32 atomics once at the end.
 #include "vg_gather.h"
 
 struct WgradK {
@@ -18,6 +23,7 @@ struct WgradK {
     int tap_src[VG_MAX_TAPS];               // packed tap -> source tap index in dW
     float* dw; float* db;
     int total_tiles, DYS;
+    float* part; int dw_elems;              // per-workgroup-column partial slabs (no atomics) or NULL
 };
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
@@ -29,20 +35,20 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* base0, const char* base1) 
     return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
-template <typename T, int MAXI>
+template <typename T, int RMAX, int Q>
 __global__ __launch_bounds__(256) void wgrad_kernel(const GatherIn g, const WgradK p) {
     constexpr bool F32 = sizeof(T) == 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lg = lane >> 4, li = lane & 15;
-    // blockIdx.y -> (tap group, ci block, co block)
     int by = blockIdx.y;
     const int cob = by % p.ncob; by /= p.ncob;
     const int cib = by % p.ncib; const int tg = by / p.ncib;
     const int tap0 = tg * p.tpg;
     const int ntap_here = min(p.tpg, g.ntaps - tap0);
-    const int tci = p.CIB >> 4, tco = p.COB >> 4;
-    const int nitems = ntap_here * tci * tco;
+    const int tci = p.CIB >> 4;
+    const int nrows = ntap_here * tci;
 
     const int BM = 1 << (g.tdl + g.thl + g.twl);
     char* halo = smem;
@@ -52,28 +58,33 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const GatherIn g, const Wgra
     int* tapoff = (int*)(dyt + dybytes);
     int* tapsrc = tapoff + 64;
     float* scs = (float*)((char*)tapoff + 512);
+    int* utab = (int*)(scs + 2 * g.CK);
 
     if (tid < g.ntaps)
         tapoff[tid] = (((g.td[tid] - g.tmin_d) * g.HH + (g.th[tid] - g.tmin_h)) * g.HW + (g.tw[tid] - g.tmin_w)) * g.RS;
     if (tid < VG_MAX_TAPS) tapsrc[tid] = p.tap_src[tid];
+    build_unit_table(g, utab, tid, 256);
+    __syncthreads();
 
-    // per-wave items: item = wave + 4*j -> (tap, ci16, co16)
-    int it_tap[MAXI], it_ci[MAXI], it_co[MAXI];
+    // rows of this wave: r = wave + 4*j -> (tap, ci16); byte offset of the row's P fragment inside the halo tile
+    int aoff[RMAX];
 #pragma unroll
-    for (int j = 0; j < MAXI; ++j) {
-        int item = wave + 4 * j;
-        if (item >= nitems) item = nitems - 1;         // idle slot: computed but not written
-        it_co[j] = item % tco; item /= tco;
-        it_ci[j] = item % tci; it_tap[j] = tap0 + item / tci;
+    for (int j = 0; j < RMAX; ++j) {
+        const int r = wave + 4 * j;
+        const int rr = r < nrows ? r : 0;
+        aoff[j] = tapoff[tap0 + rr / tci] + (rr % tci) * 16 * (int)sizeof(T);
     }
-    f32x4 acc[MAXI];
+    f32x4 acc[RMAX][Q];
 #pragma unroll
-    for (int j = 0; j < MAXI; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < RMAX; ++j)
+#pragma unroll
+        for (int q = 0; q < Q; ++q) acc[j][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float dbsum = 0.f;
+    int cur_n = -1;
 
     const int TWm = (1 << g.twl) - 1, THm = (1 << g.thl) - 1;
     const int tiles_per_n = g.tiles_d * g.tiles_h * g.tiles_w;
-    const int gco = p.COB >> 3;                 // 8-channel groups per dY row
+    constexpr int gcol = (Q * 16) >> 3, gcol_l = Q == 1 ? 1 : (Q == 2 ? 2 : 3);     // 8-channel groups per dY row
     const bool do_db = p.db && cib == 0 && tg == 0;
 
     for (int tile = blockIdx.x; tile < p.total_tiles; tile += gridDim.x) {
@@ -82,22 +93,41 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const GatherIn g, const Wgra
         const int th_i = t % g.tiles_h; const int td_i = t / g.tiles_h;
         const int od0 = td_i << g.tdl, oh0 = th_i << g.thl, ow0 = tw_i << g.twl;
         __syncthreads();
-        stage_scale_shift(g, scs, n, cib, tid);
-        __syncthreads();
-        stage_halo<T>(g, halo, scs, n, od0, oh0, ow0, cib, tid, 256);
-        // ---- stage dY tile [BM][COB] (zero outside the grid / beyond Cout) ----
-        for (int u = tid; u < BM * gco; u += 256) {
-            const int m = u / gco, cg = u - m * gco;
-            const int w = m & TWm, h = (m >> g.twl) & THm, d = m >> (g.twl + g.thl);
-            const int od = od0 + d, oh = oh0 + h, ow = ow0 + w;
-            const int c = cob * p.COB + cg * 8;
-            float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            if (od < p.OD && oh < p.OH && ow < p.OW && c < p.Cout) {
-                const size_t vox = ((size_t)(n * p.OD + od) * p.OH + oh) * p.OW + ow;
-                if (p.Cout == 1) v[0] = p.dy_f32 ? ((const float*)p.dy)[vox] : bf2f(((const bf16_t*)p.dy)[vox]);
-                else load8<T>((const T*)p.dy + vox * p.Cout + c, v);
+        if (n != cur_n) {                      // block-uniform: the on-read affine depends on the sample only
+            stage_scale_shift(g, scs, n, cib, tid);
+            cur_n = n;
+            __syncthreads();
+        }
+        if (!(g.dbg & 1) || tile == (int)blockIdx.x) stage_halo_tab<T>(g, halo, scs, utab, n, od0, oh0, ow0, cib, tid, 256);
+        if (!(g.dbg & 2) || tile == (int)blockIdx.x)
+        // ---- stage dY tile [BM][16*Q] (zero outside the grid / beyond Cout): all loads first ----
+        for (int u0 = tid; u0 < BM * gcol; u0 += 256 * 4) {
+            Raw8<T> raw[4]; float y1[4]; int mm[4]; bool ok[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int u = u0 + k * 256;
+                mm[k] = -1; ok[k] = false; y1[k] = 0.f;
+                if (u < BM * gcol) {
+                    const int m = u >> gcol_l, cg = u & (gcol - 1);
+                    const int w = m & TWm, h = (m >> g.twl) & THm, d = m >> (g.twl + g.thl);
+                    const int od = od0 + d, oh = oh0 + h, ow = ow0 + w;
+                    const int c = cob * p.COB + cg * 8;
+                    mm[k] = (m << 4) | cg;
+                    ok[k] = od < p.OD && oh < p.OH && ow < p.OW && c < p.Cout;
+                    if (ok[k]) {
+                        const size_t vox = ((size_t)(n * p.OD + od) * p.OH + oh) * p.OW + ow;
+                        if (p.Cout == 1) y1[k] = p.dy_f32 ? ((const float*)p.dy)[vox] : bf2f(((const bf16_t*)p.dy)[vox]);
+                        else raw_load(raw[k], (const T*)p.dy + vox * p.Cout + c);
+                    }
+                }
             }
-            store8<T>((T*)(dyt + (size_t)m * p.DYS) + cg * 8, v);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (mm[k] < 0) continue;
+                float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if (ok[k]) { if (p.Cout == 1) v[0] = y1[k]; else raw_unpack(raw[k], v); }
+                store8<T>((T*)(dyt + (size_t)(mm[k] >> 4) * p.DYS) + (mm[k] & 15) * 8, v);
+            }
         }
         __syncthreads();
         if (do_db) {      // thread (row group, channel): partial column sums of the dY tile
@@ -109,103 +139,182 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const GatherIn g, const Wgra
                 dbsum += s;
             }
         }
+        if (g.dbg & 4) continue;
         if constexpr (F32) {
             // exact-parity mode: v_mfma_f32_16x16x4_f32, k = 4 voxels; lane (lg, li): A[ci=li][k=lg], B[k=lg][co=li]
             for (int s = 0; s < BM / 4; ++s) {
                 const int m0 = s * 4 + lg;
                 const int w0 = m0 & TWm, h0 = (m0 >> g.twl) & THm, d0 = m0 >> (g.twl + g.thl);
-                const int r0 = ((d0 * g.istr * g.HH + h0 * g.istr) * g.HW + w0 * g.istr) * g.RS;
-                const char* y0 = dyt + (size_t)m0 * p.DYS;
+                const int r0 = ((d0 * g.istr * g.HH + h0 * g.istr) * g.HW + w0 * g.istr) * g.RS + li * 4;
+                const char* y0 = dyt + (size_t)m0 * p.DYS + li * 4;
+                float b[Q];
 #pragma unroll
-                for (int j = 0; j < MAXI; ++j) {
-                    const float a = *(const float*)(halo + r0 + tapoff[it_tap[j]] + (it_ci[j] * 16 + li) * 4);
-                    const float b = *(const float*)(y0 + (it_co[j] * 16 + li) * 4);
-                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[j], 0, 0, 0);
+                for (int q = 0; q < Q; ++q) b[q] = *(const float*)(y0 + q * 64);
+#pragma unroll
+                for (int j = 0; j < RMAX; ++j) {
+                    if (wave + 4 * j < nrows) {
+                        const float a = *(const float*)(halo + r0 + aoff[j]);
+#pragma unroll
+                        for (int q = 0; q < Q; ++q) acc[j][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[q], acc[j][q], 0, 0, 0);
+                    }
                 }
             }
-            continue;
-        }
-        // ---- K loop over voxels, 32 per MFMA ----
-        for (int s = 0; s < BM / 32; ++s) {
-            // this lane supplies the address of voxel row m0 (and m0+4) for the transposed block reads
-            const int m0 = s * 32 + 8 * lg + (li >> 2);
-            const int m1 = m0 + 4;
-            const int w0 = m0 & TWm, h0 = (m0 >> g.twl) & THm, d0 = m0 >> (g.twl + g.thl);
-            const int w1 = m1 & TWm, h1 = (m1 >> g.twl) & THm, d1 = m1 >> (g.twl + g.thl);
-            const int r0 = ((d0 * g.istr * g.HH + h0 * g.istr) * g.HW + w0 * g.istr) * g.RS + 8 * (li & 3);
-            const int r1 = ((d1 * g.istr * g.HH + h1 * g.istr) * g.HW + w1 * g.istr) * g.RS + 8 * (li & 3);
-            const char* y0 = dyt + (size_t)m0 * p.DYS + 8 * (li & 3);
-            const char* y1 = dyt + (size_t)m1 * p.DYS + 8 * (li & 3);
+        } else {
+            // ---- K loop over voxels, 32 per MFMA ----
+            for (int s = 0; s < BM / 32; ++s) {
+                // this lane supplies the address of voxel row m0 (and m0+4) for the transposed block reads
+                const int m0 = s * 32 + 8 * lg + (li >> 2);
+                const int m1 = m0 + 4;
+                const int w0 = m0 & TWm, h0 = (m0 >> g.twl) & THm, d0 = m0 >> (g.twl + g.thl);
+                const int w1 = m1 & TWm, h1 = (m1 >> g.twl) & THm, d1 = m1 >> (g.twl + g.thl);
+                const int r0 = ((d0 * g.istr * g.HH + h0 * g.istr) * g.HW + w0 * g.istr) * g.RS + 8 * (li & 3);
+                const int r1 = ((d1 * g.istr * g.HH + h1 * g.istr) * g.HW + w1 * g.istr) * g.RS + 8 * (li & 3);
+                const char* y0 = dyt + (size_t)m0 * p.DYS + 8 * (li & 3);
+                const char* y1 = dyt + (size_t)m1 * p.DYS + 8 * (li & 3);
+                bf16x8 b[Q];
 #pragma unroll
-            for (int j = 0; j < MAXI; ++j) {
-                const int to = tapoff[it_tap[j]] + it_ci[j] * 32;
-                const bf16x8 a = tr_frag(halo + r0 + to, halo + r1 + to);          // A[ci][k=voxel]
-                const bf16x8 b = tr_frag(y0 + it_co[j] * 32, y1 + it_co[j] * 32);  // B[k=voxel][co]
-                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[j], 0, 0, 0);
+                for (int q = 0; q < Q; ++q) b[q] = tr_frag(y0 + q * 32, y1 + q * 32);          // B[k=voxel][co]
+#pragma unroll
+                for (int j = 0; j < RMAX; ++j) {
+                    if (wave + 4 * j < nrows) {
+                        const bf16x8 a = tr_frag(halo + r0 + aoff[j], halo + r1 + aoff[j]);  // A[ci][k=voxel]
+#pragma unroll
+                        for (int q = 0; q < Q; ++q) acc[j][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[q], acc[j][q], 0, 0, 0);
+                    }
+                }
             }
         }
     }
     // ---- add the slab: lane holds dW rows ci = 4*lg + r, column co = li ----
 #pragma unroll
-    for (int j = 0; j < MAXI; ++j) {
-        if (wave + 4 * j >= nitems) continue;
-        const int co = cob * p.COB + it_co[j] * 16 + li;
-        if (co >= p.Cout) continue;
+    for (int j = 0; j < RMAX; ++j) {
+        const int r = wave + 4 * j;
+        if (r >= nrows) continue;
+        const int tap = tap0 + r / tci, ci0 = cib * p.CIB + (r % tci) * 16 + 4 * lg;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int ci = cib * p.CIB + it_ci[j] * 16 + 4 * lg + r;
-            if (ci < g.Cin)
-                atomicAdd(&p.dw[((size_t)tapsrc[it_tap[j]] * g.Cin + ci) * p.Cout + co], acc[j][r]);
+        for (int q = 0; q < Q; ++q) {
+            const int co = cob * p.COB + q * 16 + li;
+            if (co >= p.Cout) continue;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (ci0 + e < g.Cin) {
+                    const size_t i = ((size_t)tapsrc[tap] * g.Cin + ci0 + e) * p.Cout + co;
+                    if (p.part) p.part[(size_t)blockIdx.x * p.dw_elems + i] = acc[j][q][e];
+                    else atomicAdd(&p.dw[i], acc[j][q][e]);
+                }
         }
     }
-    if (do_db && tid < (256 / p.COB) * p.COB) {
-        const int co = cob * p.COB + tid % p.COB;
-        if (co < p.Cout) atomicAdd(&p.db[co], dbsum);
+    if (do_db) {        // block-reduce the bias partials in LDS first: one contiguous atomic per channel per workgroup
+        __syncthreads();
+        float* red = (float*)halo;
+        if (tid < p.COB) red[tid] = 0.f;
+        __syncthreads();
+        if (tid < (256 / p.COB) * p.COB) atomicAdd(&red[tid % p.COB], dbsum);
+        __syncthreads();
+        if (tid < p.COB) {
+            const int co = cob * p.COB + tid;
+            if (co < p.Cout) atomicAdd(&p.db[co], red[tid]);
+        }
     }
 }
 
+// dw[i] += sum_b part[b][i]  (fixed order per element: bitwise reproducible, unlike the atomic path).
+// Block = 4 waves x 64 consecutive elements; wave w sums slabs b = w, w+4, ... with 8 independent loads in flight.
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* part, int nb, int n, float* dw) {
+    __shared__ float sm[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lane;
+    float s = 0.f;
+    if (i < n) {
+        int b = w;
+        for (; b + 28 < nb; b += 32) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = part[(size_t)(b + 4 * k) * n + i];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += v[k];
+        }
+        for (; b < nb; b += 4) s += part[(size_t)b * n + i];
+    }
+    sm[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && i < n) dw[i] += sm[0][lane] + sm[1][lane] + sm[2][lane] + sm[3][lane];
+}
+
+template <typename T, int RMAX, int Q>
+static void launch_wgrad(const GatherIn& g, const WgradK& k, dim3 grid, int lds, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)wgrad_kernel<T, RMAX, Q>, hipFuncAttributeMaxDynamicSharedMemorySize, VG_LDS_LIMIT);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((wgrad_kernel<T, RMAX, Q>), grid, dim3(256), lds, s, g, k);
+}
+
 extern "C" int vg_conv3d_wgrad(const vg_conv_desc* d, const void* dy, int dy_f32, const int32_t* tap_idx_host,
-                               float* dw, float* db, vg_stream_t stream) {
+                               int T_total, float* dw, float* db, float* scratch, int64_t scratch_bytes,
+                               vg_stream_t stream) {
     if (!d || !dy || !dw || !tap_idx_host) return VG_EINVAL;
     if (d->Cout < 1 || (d->Cout != 1 && (d->Cout % 8))) return VG_EINVAL;
     if (dy_f32 && d->Cout != 1 && !d->f32) return VG_EINVAL;
     const int Cin = d->c_src0 + d->c_src1;
     const int Cinp = ((Cin + 15) / 16) * 16, Coutp = ((d->Cout + 15) / 16) * 16;
-    int CIB = 16;
-    for (int c = 64; c >= 16; c -= 16) if (Cinp % c == 0) { CIB = c; break; }
-    int COB = 16;
-    for (int c = 64; c >= 16; c -= 16) if (Coutp % c == 0) { COB = c; break; }
-    constexpr int MAXI = 16;
+    const int COB = Coutp >= 64 ? 64 : (Coutp >= 32 ? 32 : 16);
+    if (Coutp % COB) return VG_EINVAL;
+    const int Q = COB / 16;
+    const int RMAX = Q == 1 ? 24 : (Q == 2 ? 12 : 6);
+    const int esz = d->f32 ? 4 : 2;
     GatherIn g; WgradK k;
-    int BM = 128, lds = 0, rc;
-    for (;;) {
-        rc = fill_gather(d, g, CIB, BM);
-        if (rc != VG_OK) return rc;
-        k.DYS = COB * (d->f32 ? 4 : 2) + 16;
-        lds = halo_bytes(g) + BM * k.DYS + 512 + 2 * CIB * 4;
-        if (lds <= VG_LDS_LIMIT) break;
-        if (BM > 64) BM = 64;
-        else if (CIB > 16) CIB = (CIB == 48) ? 16 : CIB / 2;
-        else return VG_ELDS;
+    // candidate (BM, CIB) in order of preference: large tile + all channels, LDS <= 80 KiB so that two workgroups fit a CU
+    int best_bm = 0, best_cib = 0, best_lds = 0;
+    for (int pass = 0; pass < 2 && !best_bm; ++pass) {
+        const int limit = pass == 0 ? 80 * 1024 : VG_LDS_LIMIT;
+        for (int bm = 128; bm >= 64 && !best_bm; bm -= 64)
+            for (int c = 64; c >= 16; c -= 16) {
+                if (Cinp % c) continue;
+                int rc = fill_gather(d, g, c, bm);
+                if (rc != VG_OK) return rc;
+                const int lds = halo_bytes(g) + bm * (COB * esz + 16) + 512 + 2 * c * 4 + g.HD * g.HH * g.HW * (c / 8) * 4;
+                if (lds <= limit) { best_bm = bm; best_cib = c; best_lds = lds; break; }
+            }
     }
+    if (!best_bm) return VG_ELDS;
+    const int CIB = best_cib, lds = best_lds;
+    int rc = fill_gather(d, g, CIB, best_bm);
+    if (rc != VG_OK) return rc;
+    k.DYS = COB * esz + 16;
     k.dy = dy; k.dy_f32 = dy_f32; k.Cout = d->Cout; k.OD = d->OD; k.OH = d->OH; k.OW = d->OW;
     k.CIB = CIB; k.COB = COB; k.ncib = Cinp / CIB; k.ncob = Coutp / COB;
-    const int per_tap = (CIB / 16) * (COB / 16);
-    k.tpg = (MAXI * 4) / per_tap; if (k.tpg < 1) return VG_EINVAL;
+    const int rows_per_tap = CIB / 16;
+    k.tpg = (4 * RMAX) / rows_per_tap; if (k.tpg < 1) return VG_EINVAL;
     if (k.tpg > d->ntaps) k.tpg = d->ntaps;
     k.ntg = (d->ntaps + k.tpg - 1) / k.tpg;
+    k.tpg = (d->ntaps + k.ntg - 1) / k.ntg;                  // balance the tap groups
     for (int i = 0; i < VG_MAX_TAPS; ++i) k.tap_src[i] = i < d->ntaps ? tap_idx_host[i] : 0;
     k.dw = dw; k.db = db;
     k.total_tiles = d->N * g.tiles_d * g.tiles_h * g.tiles_w;
     const int by = k.ntg * k.ncib * k.ncob;
-    int bx = 2048 / by; if (bx < 1) bx = 1; if (bx > k.total_tiles) bx = k.total_tiles;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)wgrad_kernel<bf16_t, MAXI>, hipFuncAttributeMaxDynamicSharedMemorySize, VG_LDS_LIMIT);
-        (void)hipFuncSetAttribute((const void*)wgrad_kernel<float, MAXI>, hipFuncAttributeMaxDynamicSharedMemorySize, VG_LDS_LIMIT);
-        attr_set = true;
+    static int wg_target = -1;
+    if (wg_target < 0) { const char* e = getenv("VG_WGRAD_WGS"); wg_target = e ? atoi(e) : 512; }
+    int bx = wg_target / by; if (bx < 1) bx = 1; if (bx > k.total_tiles) bx = k.total_tiles;
+    // many workgroups per dW element: float atomics on a few-KB dW serialise (measured 0.7 ms on a 27 KB dW from 1024
+    // workgroups), so each workgroup column stores its slab to a private partial buffer that a second kernel sums
+    k.dw_elems = T_total * Cin * d->Cout;
+    k.part = nullptr;
+    if (bx > 8 && scratch && (int64_t)bx * k.dw_elems * 4 <= scratch_bytes) k.part = scratch;
+    const dim3 grid(bx, by, 1);
+    hipStream_t s = (hipStream_t)stream;
+    if (d->f32) {
+        if (Q == 1) launch_wgrad<float, 24, 1>(g, k, grid, lds, s);
+        else if (Q == 2) launch_wgrad<float, 12, 2>(g, k, grid, lds, s);
+        else launch_wgrad<float, 6, 4>(g, k, grid, lds, s);
+    } else {
+        if (Q == 1) launch_wgrad<bf16_t, 24, 1>(g, k, grid, lds, s);
+        else if (Q == 2) launch_wgrad<bf16_t, 12, 2>(g, k, grid, lds, s);
+        else launch_wgrad<bf16_t, 6, 4>(g, k, grid, lds, s);
     }
-    if (d->f32) hipLaunchKernelGGL((wgrad_kernel<float, MAXI>), dim3(bx, by, 1), dim3(256), lds, (hipStream_t)stream, g, k);
-    else hipLaunchKernelGGL((wgrad_kernel<bf16_t, MAXI>), dim3(bx, by, 1), dim3(256), lds, (hipStream_t)stream, g, k);
+    if (k.part) {
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((k.dw_elems + 63) / 64), dim3(256), 0, s, k.part, bx, k.dw_elems, dw);
+    }
     return vg_check_launch();
 }

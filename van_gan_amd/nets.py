@@ -136,7 +136,7 @@ class Act:
     def __init__(self, arena: Arena, N, dims, C_, dtype=torch.bfloat16, want_sums=True):
         self.N, self.dims, self.C = N, tuple(dims), C_
         self.data = arena.alloc((N,) + tuple(dims) + (C_,), dtype)
-        self.sums = arena.alloc((N, C_, 2), torch.float32, zero=True) if want_sums else None
+        self.sums = arena.alloc((ops.STRIPES, N, C_, 2), torch.float32, zero=True) if want_sums else None
         self.count = float(dims[0] * dims[1] * dims[2])
         self.grad = None
 
@@ -271,7 +271,7 @@ class ResUNet:
     def _norm_bwd(self, ar, g, g_padded, src: Src, st, norm: Norm, dx, act, dx_cstride=0, accumulate=True):
         """(IN -> act) backward of the operand described by `src` with statistics `st`."""
         N = src.N
-        red = ar.alloc((N, src.C, 2), torch.float32, zero=True)
+        red = ar.alloc((ops.STRIPES, N, src.C, 2), torch.float32, zero=True)
         ops.actnorm_bwd(g, g_padded, src.x0, (N, src.D, src.H, src.W), src.C, dx, scale=st['scale'], shift=st['shift'],
                         act=act, norm=True, gamma=norm.gamma, mean=st['mean'], rstd=st['rstd'], red=red,
                         accumulate=accumulate, x1=src.x1, c_x0=src.c0 if src.x1 is not None else 0, x0_shift=src.shift0,
@@ -455,7 +455,7 @@ class PatchGAN:
             lay.dgrad(g, N, dp, accumulate=False)
             st = ctx['sts'][li - 1]
             nrm = Nn[self.NAMES[li - 1]]
-            red = ar.alloc((N, a.C, 2), torch.float32, zero=True)
+            red = ar.alloc((ops.STRIPES, N, a.C, 2), torch.float32, zero=True)
             dxa = ar.alloc((N,) + a.dims + (a.C,), self.dtype)
             ops.actnorm_bwd(dp, lay.pad == 'reflect', sl(a.data), (N,) + a.dims, a.C, dxa, scale=sl(st['scale']),
                             shift=sl(st['shift']), mult=sl(st['mult']), act=ACT_LRELU, norm=True, gamma=nrm.gamma,

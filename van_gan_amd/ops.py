@@ -13,6 +13,7 @@ from . import _lib
 from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, PAD_REFLECT, PAD_ZERO, ActNormBwdDesc, ConvDesc, check, lib
 
 IN_EPS = 1e-3          # tfa InstanceNormalization default epsilon (resunet_model.py:36)
+STRIPES = 8            # VG_STRIPES of include/vangan_hip.h
 
 
 def _p(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -21,6 +22,37 @@ def _p(t: Optional[torch.Tensor]) -> Optional[int]:
 
 def stream() -> int:
     return torch.cuda.current_stream().cuda_stream
+
+
+class KernelProfile:
+    """Optional per-launch HIP-event timing of the MFMA kernels on the stream they are launched on (torch's current
+    stream), with the algorithmic FLOPs of every launch.  Used by bench.py for the roofline object."""
+
+    def __init__(self):
+        self.rows = {}          # kind -> [launches, flops, [(ev0, ev1), ...]]
+
+    def begin(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def end(self, kind: str, flops: float, e0):
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        r = self.rows.setdefault(kind, [0, 0.0, []])
+        r[0] += 1; r[1] += flops; r[2].append((e0, e1))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for k, (n, fl, evs) in self.rows.items():
+            ms = sum(a.elapsed_time(b) for a, b in evs)
+            out[k] = dict(launches=n, flops=fl, ms=ms)
+        return out
+
+
+PROF: Optional[KernelProfile] = None
+WGRAD_SCRATCH = {}     # device -> fp32 scratch for the partial-slab weight-gradient reduction (256 MB)
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -214,12 +246,21 @@ class ConvLayer:
         d.tanh_out = int(tanh)
         d.out, d.out_f32, d.accumulate = _p(out), int(out.dtype == torch.float32), 0
         d.out_sums = _p(sums)
+        e0 = PROF.begin() if PROF is not None else None
         check(lib.vg_conv3d(C.byref(d), stream()), 'vg_conv3d ' + self.name)
+        if e0 is not None:
+            PROF.end('conv_fwd', 2.0 * src.N * math.prod(self.out_dims) * self.cout * self.cin * self.k ** 3, e0)
 
     def wgrad(self, src: Src, dy: torch.Tensor):
         d = self._fwd_desc(src)
-        check(lib.vg_conv3d_wgrad(C.byref(d), _p(dy), int(dy.dtype == torch.float32), self.f_idx_host, _p(self.gw),
-                                  _p(self.gb), stream()), 'vg_conv3d_wgrad ' + self.name)
+        e0 = PROF.begin() if PROF is not None else None
+        sc = WGRAD_SCRATCH.get(dy.device)
+        if sc is None:
+            sc = WGRAD_SCRATCH[dy.device] = torch.empty(64 << 20, dtype=torch.float32, device=dy.device)
+        check(lib.vg_conv3d_wgrad(C.byref(d), _p(dy), int(dy.dtype == torch.float32), self.f_idx_host, self.k ** 3,
+                                  _p(self.gw), _p(self.gb), _p(sc), sc.numel() * 4, stream()), 'vg_conv3d_wgrad ' + self.name)
+        if e0 is not None:
+            PROF.end('conv_wgrad', 2.0 * src.N * math.prod(self.out_dims) * self.cout * self.cin * self.k ** 3, e0)
 
     def dgrad(self, dy: torch.Tensor, N: int, out: torch.Tensor, accumulate: bool):
         """d/d input: writes the reflect-PADDED grid for 'reflect' convs (fold it with actnorm_bwd), the plain
@@ -239,7 +280,10 @@ class ConvLayer:
             d.Cout, d.wpacked, d.CK = self.cin, _p(c['wp']), c['ck']
             d.f32 = self.f32
             d.out, d.out_f32, d.accumulate = _p(out), int(out.dtype == torch.float32), int(accumulate)
+            e0 = PROF.begin() if PROF is not None else None
             check(lib.vg_conv3d(C.byref(d), stream()), 'vg_conv3d(dgrad) ' + self.name)
+            if e0 is not None:      # algorithmic FLOPs of this parity class: its taps only
+                PROF.end('conv_dgrad', 2.0 * N * math.prod(c['iters']) * self.cin * self.cout * len(c['taps']), e0)
 
 
 # ------------------------------------------------------------------------------------------------------
