@@ -13,7 +13,8 @@ Stated tolerances (bf16 operands, fp32 accumulation, bf16 gradient tensors):
                              an InstanceNorm have an analytically ZERO gradient and are checked absolutely).
                              generator (30 convs, 28 InstanceNorms, ReLU masks): bf16 rounding makes the gradient itself
                              chaotic -- the oracle's OWN gradient moves by rel 0.30 / cos 0.95 under the 1e-6 jitter --
-                             so only the whole-network cosine is asserted (>= 0.9); per-tensor numbers are printed.
+                             (and, through two generators in series, gen_SI's by rel 0.6-0.9 / cos 0.61-0.83), so only the
+                             whole-network cosine is asserted against that measured floor; per-tensor numbers are printed.
                              The exact backward arithmetic of every kernel is pinned in test_gpu_ops.py, and the
                              end-to-end wiring at fp32 tolerance in test_gpu_fp32.py (fp32 storage mode).
 """
@@ -181,7 +182,9 @@ def _engine_vs_oracle(dims, B, steps=1):
         got = eng.export_grads()
         for net in ('disc_I', 'disc_S', 'gen_IS', 'gen_SI'):
             cos = grad_report(got[net], grads[net], net, check=False)
-            assert cos > (0.99 if net.startswith('disc') else 0.9), (net, cos)
+            # oracle-vs-jittered-oracle floor at 32^3 (measured): gen_IS cos 0.93-0.96, gen_SI 0.61-0.83
+            floor = {'disc_I': 0.99, 'disc_S': 0.99, 'gen_IS': 0.85, 'gen_SI': 0.5}[net]
+            assert cos > floor, (net, cos)
         W = eng.export_weights()
         for net in W:
             for n in W[net]:

@@ -23,29 +23,44 @@ struct ConvOut {
     const void* wp; int Ktot, nchunks, kc_pad;
     const float* bias; const void* res; const float* rs; const float* rb; int tanh_out;
     void* out; int out_f32, accumulate; float* sums;
+    int w_lds;          // 1: the BN x Ktot weight panel of this workgroup is copied to LDS once (row stride WRS bytes)
+    int WRS;
 };
 
+// Persistent workgroup: blockIdx.z = sample, blockIdx.y = BN-channel panel, blockIdx.x walks the output tiles of the
+// sample.  Per workgroup ONCE: tap offsets, the (halo voxel, channel group) unit table, the weight panel (if it fits in
+// LDS); per tile: stage halo (batched global loads), MFMA loop, epilogue; InstanceNorm statistics are carried in
+// registers across tiles and flushed once.
 template <typename T, int BN, int MSUB>
 __global__ __launch_bounds__(256) void conv_kernel(const GatherIn g, const ConvOut p) {
     constexpr bool F32 = sizeof(T) == 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = blockIdx.z, ntile = blockIdx.y;
-    int t = blockIdx.x;
-    const int tw_i = t % g.tiles_w; t /= g.tiles_w;
-    const int th_i = t % g.tiles_h; const int td_i = t / g.tiles_h;
     const int TWm = (1 << g.twl) - 1, THm = (1 << g.thl) - 1;
-    const int od0 = td_i << g.tdl, oh0 = th_i << g.thl, ow0 = tw_i << g.twl;
 
     char* halo = smem;
     const int hbytes = g.HD * g.HH * g.HW * g.RS;
     int* tapoff = (int*)(smem + hbytes);
     float* scs = (float*)(smem + hbytes + 256);
     float* stat = scs + 2 * g.CK;
+    int* utab = (int*)(stat + BN * 2);
+    const int nunits = g.HD * g.HH * g.HW * (g.CK >> 3);
+    char* wlds = (char*)(utab + nunits);
+    wlds = (char*)(((size_t)wlds + 15) & ~(size_t)15);
 
     if (tid < g.ntaps)
         tapoff[tid] = (((g.td[tid] - g.tmin_d) * g.HH + (g.th[tid] - g.tmin_h)) * g.HW + (g.tw[tid] - g.tmin_w)) * g.RS;
     if (tid < BN * 2) stat[tid] = 0.f;
+    build_unit_table(g, utab, tid, 256);
+    if (p.w_lds) {          // weight panel -> LDS, 16 B per thread per step
+        const int per_row = (p.Ktot * (int)sizeof(T)) >> 4;
+        for (int u = tid; u < BN * per_row; u += 256) {
+            const int r = u / per_row, c = u - r * per_row;
+            *(f32x4*)(wlds + (size_t)r * p.WRS + c * 16) =
+                *(const f32x4*)((const char*)p.wp + ((size_t)(ntile * BN + r) * p.Ktot) * sizeof(T) + c * 16);
+        }
+    }
 
     int rowbase[MSUB];
 #pragma unroll
@@ -54,114 +69,125 @@ __global__ __launch_bounds__(256) void conv_kernel(const GatherIn g, const ConvO
         const int w = m & TWm, h = (m >> g.twl) & THm, d = m >> (g.twl + g.thl);
         rowbase[i] = ((d * g.istr * g.HH + h * g.istr) * g.HW + w * g.istr) * g.RS;
     }
-    f32x4 acc[BN / 16][MSUB];
-#pragma unroll
-    for (int a = 0; a < BN / 16; ++a)
-#pragma unroll
-        for (int i = 0; i < MSUB; ++i) acc[a][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
     const int gpc = g.CK >> 3;
     const int ngroups = g.ntaps * gpc;
     const int ksteps = (ngroups + 3) >> 2;
+    // weight fragment source: LDS panel or global (L2) rows
     const T* wrow[BN / 16];
 #pragma unroll
-    for (int a = 0; a < BN / 16; ++a)
-        wrow[a] = (const T*)p.wp + (size_t)(ntile * BN + a * 16 + (lane & 15)) * p.Ktot + (F32 ? 1 : 8) * (lane >> 4);
-
-    for (int chunk = 0; chunk < p.nchunks; ++chunk) {
-        __syncthreads();
-        stage_scale_shift(g, scs, n, chunk, tid);
-        __syncthreads();
-        stage_halo<T>(g, halo, scs, n, od0, oh0, ow0, chunk, tid, 256);
-        __syncthreads();
-        const size_t kbase = (size_t)chunk * p.kc_pad;
-        if constexpr (F32) {
-            // exact-parity mode: f32 operands, v_mfma_f32_16x16x4_f32 (k = 4 consecutive channels of one tap)
-            int tap = 0, ch0 = 0;
-            const int nk4 = (g.ntaps * g.CK) >> 2;
-            for (int s = 0; s < nk4; ++s) {
-                const int off = tapoff[tap] + (ch0 + (lane >> 4)) * 4;
-                float b[MSUB], a[BN / 16];
-#pragma unroll
-                for (int i = 0; i < MSUB; ++i) b[i] = *(const float*)(halo + rowbase[i] + off);
-#pragma unroll
-                for (int q = 0; q < BN / 16; ++q) a[q] = wrow[q][kbase + s * 4];
-#pragma unroll
-                for (int q = 0; q < BN / 16; ++q)
-#pragma unroll
-                    for (int i = 0; i < MSUB; ++i)
-                        acc[q][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], b[i], acc[q][i], 0, 0, 0);
-                ch0 += 4;
-                if (ch0 >= g.CK) { ch0 = 0; ++tap; }
-            }
-            continue;
-        }
-        // ---- MFMA over (tap, channel-group) pairs of this chunk ----
-        int tap = 0, cg = lane >> 4;
-        while (cg >= gpc) { cg -= gpc; ++tap; }
-        for (int s = 0; s < ksteps; ++s) {
-            const int tp = tap < g.ntaps ? tap : g.ntaps - 1;      // padded K: weights are zero there
-            const int off = tapoff[tp] + cg * 16;
-            bf16x8 b[MSUB];
-#pragma unroll
-            for (int i = 0; i < MSUB; ++i) b[i] = *(const bf16x8*)(halo + rowbase[i] + off);
-            bf16x8 a[BN / 16];
-#pragma unroll
-            for (int q = 0; q < BN / 16; ++q) a[q] = *(const bf16x8*)((const bf16_t*)wrow[q] + kbase + s * 32);
-#pragma unroll
-            for (int q = 0; q < BN / 16; ++q)
-#pragma unroll
-                for (int i = 0; i < MSUB; ++i)
-                    acc[q][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[q], b[i], acc[q][i], 0, 0, 0);
-            cg += 4;
-            while (cg >= gpc) { cg -= gpc; ++tap; }
-        }
+    for (int a = 0; a < BN / 16; ++a) {
+        if (p.w_lds) wrow[a] = (const T*)(wlds + (size_t)(a * 16 + (lane & 15)) * p.WRS) + (F32 ? 1 : 8) * (lane >> 4);
+        else wrow[a] = (const T*)p.wp + (size_t)(ntile * BN + a * 16 + (lane & 15)) * p.Ktot + (F32 ? 1 : 8) * (lane >> 4);
     }
-
-    // ---- epilogue: lane holds out channels co0..co0+3 of voxel (lane&15) of each subtile ----
     float s1[BN / 16][4], s2[BN / 16][4];
 #pragma unroll
     for (int q = 0; q < BN / 16; ++q)
 #pragma unroll
         for (int r = 0; r < 4; ++r) { s1[q][r] = 0.f; s2[q][r] = 0.f; }
+    if (p.nchunks == 1) stage_scale_shift(g, scs, n, 0, tid);
+    __syncthreads();
 
+    const int tiles_per_n = g.tiles_d * g.tiles_h * g.tiles_w;
+    for (int tile = blockIdx.x; tile < tiles_per_n; tile += gridDim.x) {
+        int t = tile;
+        const int tw_i = t % g.tiles_w; t /= g.tiles_w;
+        const int th_i = t % g.tiles_h; const int td_i = t / g.tiles_h;
+        const int od0 = td_i << g.tdl, oh0 = th_i << g.thl, ow0 = tw_i << g.twl;
+        f32x4 acc[BN / 16][MSUB];
 #pragma unroll
-    for (int i = 0; i < MSUB; ++i) {
-        const int m = (wave * MSUB + i) * 16 + (lane & 15);
-        const int w = m & TWm, h = (m >> g.twl) & THm, d = m >> (g.twl + g.thl);
-        const int od = od0 + d, oh = oh0 + h, ow = ow0 + w;
-        const bool inr = od < p.OD && oh < p.OH && ow < p.OW;
-        const size_t vox = ((size_t)(n * p.BD + od * p.ostr + p.ood) * p.BH + oh * p.ostr + p.ooh) * p.BW + ow * p.ostr + p.oow;
+        for (int a = 0; a < BN / 16; ++a)
 #pragma unroll
-        for (int q = 0; q < BN / 16; ++q) {
-            const int co0 = ntile * BN + q * 16 + 4 * (lane >> 4);
-            if (!inr || co0 >= p.Cout) continue;
-            const size_t idx = vox * p.Cout + co0;
-            float v[4];
+            for (int i = 0; i < MSUB; ++i) acc[a][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+        for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+            __syncthreads();                       // previous readers of the halo tile are done
+            if (p.nchunks > 1) { stage_scale_shift(g, scs, n, chunk, tid); __syncthreads(); }
+            if (!(g.dbg & 1)) stage_halo_tab<T>(g, halo, scs, utab, n, od0, oh0, ow0, chunk, tid, 256);
+            __syncthreads();
+            const size_t kbase = (size_t)chunk * p.kc_pad;
+            if (g.dbg & 4) continue;
+            if constexpr (F32) {
+                // exact-parity mode: f32 operands, v_mfma_f32_16x16x4_f32 (k = 4 consecutive channels of one tap)
+                int tap = 0, ch0 = 0;
+                const int nk4 = (g.ntaps * g.CK) >> 2;
+                for (int s = 0; s < nk4; ++s) {
+                    const int off = tapoff[tap] + (ch0 + (lane >> 4)) * 4;
+                    float b[MSUB], a[BN / 16];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int co = co0 + r;
-                float y = acc[q][i][r];
-                if (co < p.Cout) {
-                    if (p.bias) y += p.bias[co];
-                    if (p.res) y += ld1<T>((const T*)p.res + idx + r) * p.rs[n * p.Cout + co] + p.rb[n * p.Cout + co];
-                    if (p.tanh_out) y = tanhf(y);
-                    if (p.accumulate) y += p.out_f32 ? ((float*)p.out)[idx + r] : bf2f(((bf16_t*)p.out)[idx + r]);
-                    if (!p.out_f32) y = bfround(y);
-                    s1[q][r] += y; s2[q][r] += y * y;
+                    for (int i = 0; i < MSUB; ++i) b[i] = *(const float*)(halo + rowbase[i] + off);
+#pragma unroll
+                    for (int q = 0; q < BN / 16; ++q) a[q] = wrow[q][kbase + s * 4];
+#pragma unroll
+                    for (int q = 0; q < BN / 16; ++q)
+#pragma unroll
+                        for (int i = 0; i < MSUB; ++i)
+                            acc[q][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], b[i], acc[q][i], 0, 0, 0);
+                    ch0 += 4;
+                    if (ch0 >= g.CK) { ch0 = 0; ++tap; }
                 }
-                v[r] = y;
-            }
-            if (p.out_f32) {
-                float* o = (float*)p.out + idx;
-                if (co0 + 3 < p.Cout) { *(f32x4*)o = (f32x4){v[0], v[1], v[2], v[3]}; }
-                else { for (int r = 0; r < 4; ++r) if (co0 + r < p.Cout) o[r] = v[r]; }
             } else {
-                bf16_t* o = (bf16_t*)p.out + idx;
-                if (co0 + 3 < p.Cout) {
-                    bf16x4 pk = {(short)f2bf(v[0]), (short)f2bf(v[1]), (short)f2bf(v[2]), (short)f2bf(v[3])};
-                    *(bf16x4*)o = pk;
-                } else { for (int r = 0; r < 4; ++r) if (co0 + r < p.Cout) o[r] = f2bf(v[r]); }
+                // ---- MFMA over (tap, channel-group) pairs of this chunk ----
+                int tap = 0, cg = lane >> 4;
+                while (cg >= gpc) { cg -= gpc; ++tap; }
+                for (int s = 0; s < ksteps; ++s) {
+                    const int tp = tap < g.ntaps ? tap : g.ntaps - 1;      // padded K: weights are zero there
+                    const int off = tapoff[tp] + cg * 16;
+                    bf16x8 b[MSUB];
+#pragma unroll
+                    for (int i = 0; i < MSUB; ++i) b[i] = *(const bf16x8*)(halo + rowbase[i] + off);
+                    bf16x8 a[BN / 16];
+#pragma unroll
+                    for (int q = 0; q < BN / 16; ++q) a[q] = *(const bf16x8*)((const bf16_t*)wrow[q] + kbase + s * 32);
+#pragma unroll
+                    for (int q = 0; q < BN / 16; ++q)
+#pragma unroll
+                        for (int i = 0; i < MSUB; ++i)
+                            acc[q][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[q], b[i], acc[q][i], 0, 0, 0);
+                    cg += 4;
+                    while (cg >= gpc) { cg -= gpc; ++tap; }
+                }
+            }
+        }
+        if (g.dbg & 8) continue;
+        // ---- epilogue: lane holds out channels co0..co0+3 of voxel (lane&15) of each subtile ----
+#pragma unroll
+        for (int i = 0; i < MSUB; ++i) {
+            const int m = (wave * MSUB + i) * 16 + (lane & 15);
+            const int w = m & TWm, h = (m >> g.twl) & THm, d = m >> (g.twl + g.thl);
+            const int od = od0 + d, oh = oh0 + h, ow = ow0 + w;
+            const bool inr = od < p.OD && oh < p.OH && ow < p.OW;
+            const size_t vox = ((size_t)(n * p.BD + od * p.ostr + p.ood) * p.BH + oh * p.ostr + p.ooh) * p.BW + ow * p.ostr + p.oow;
+#pragma unroll
+            for (int q = 0; q < BN / 16; ++q) {
+                const int co0 = ntile * BN + q * 16 + 4 * (lane >> 4);
+                if (!inr || co0 >= p.Cout) continue;
+                const size_t idx = vox * p.Cout + co0;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = co0 + r;
+                    float y = acc[q][i][r];
+                    if (co < p.Cout) {
+                        if (p.bias) y += p.bias[co];
+                        if (p.res) y += ld1<T>((const T*)p.res + idx + r) * p.rs[n * p.Cout + co] + p.rb[n * p.Cout + co];
+                        if (p.tanh_out) y = tanhf(y);
+                        if (p.accumulate) y += p.out_f32 ? ((float*)p.out)[idx + r] : bf2f(((bf16_t*)p.out)[idx + r]);
+                        if (!p.out_f32) y = bfround(y);
+                        s1[q][r] += y; s2[q][r] += y * y;
+                    }
+                    v[r] = y;
+                }
+                if (p.out_f32) {
+                    float* o = (float*)p.out + idx;
+                    if (co0 + 3 < p.Cout) { *(f32x4*)o = (f32x4){v[0], v[1], v[2], v[3]}; }
+                    else { for (int r = 0; r < 4; ++r) if (co0 + r < p.Cout) o[r] = v[r]; }
+                } else {
+                    bf16_t* o = (bf16_t*)p.out + idx;
+                    if (co0 + 3 < p.Cout) {
+                        bf16x4 pk = {(short)f2bf(v[0]), (short)f2bf(v[1]), (short)f2bf(v[2]), (short)f2bf(v[3])};
+                        *(bf16x4*)o = pk;
+                    } else { for (int r = 0; r < 4; ++r) if (co0 + r < p.Cout) o[r] = f2bf(v[r]); }
+                }
             }
         }
     }
@@ -191,28 +217,61 @@ __global__ __launch_bounds__(256) void conv_kernel(const GatherIn g, const ConvO
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
+static int conv_lds_bytes(const GatherIn& g, int BN, int CK, int wbytes) {
+    const int nunits = g.HD * g.HH * g.HW * (CK >> 3);
+    return halo_bytes(g) + 256 + 2 * CK * 4 + BN * 2 * 4 + nunits * 4 + 16 + wbytes;
+}
+
 static int fill_conv(const vg_conv_desc* d, GatherIn& g, ConvOut& k, int& BN, int& MSUB, int& lds) {
     if (!d || !d->out || !d->wpacked) return VG_EINVAL;
     if (d->Cout < 1 || (d->Cout != 1 && (d->Cout % 4))) return VG_EINVAL;
     if (d->ostr < 1 || d->ostr > 2) return VG_EINVAL;
     if (d->res && (!d->res_scale || !d->res_shift)) return VG_EINVAL;
-    BN = d->Cout <= 16 ? 16 : (d->Cout <= 32 ? 32 : 64);
-    int rc = VG_ELDS;
-    for (MSUB = 2; MSUB >= 1; --MSUB) {
-        rc = fill_gather(d, g, d->CK, 64 * MSUB);
-        if (rc != VG_OK) return rc;
-        lds = halo_bytes(g) + 256 + 2 * d->CK * 4 + BN * 2 * 4;
-        if (lds <= VG_LDS_LIMIT) break;
-        rc = VG_ELDS;
+    const int Cin = d->c_src0 + d->c_src1;
+    const int Cpad = ((Cin + d->CK - 1) / d->CK) * d->CK;
+    k.nchunks = Cpad / d->CK;
+    k.kc_pad = ((d->ntaps * d->CK + 31) / 32) * 32;
+    k.Ktot = k.nchunks * k.kc_pad;
+    const int esz = d->f32 ? 4 : 2;
+    k.WRS = k.Ktot * esz + 16;
+    // Tile choice.  Efficiency wants a wide channel panel (BN) and a big voxel tile (MSUB*64: fewer halo voxels per
+    // output voxel, more MFMAs per staged byte); the chip wants >= ~2 workgroups per CU.  Small grids (16^3, 8^3 levels)
+    // therefore take narrow panels / small tiles.  Within a class, prefer <= 80 KiB of LDS (two workgroups per CU).
+    static int force_msub = -1, no_wlds = -1, force_bn = -1;
+    if (force_msub < 0) {
+        const char* e = getenv("VG_CONV_MSUB"); force_msub = e ? atoi(e) : 0;
+        const char* e2 = getenv("VG_CONV_NOWLDS"); no_wlds = e2 ? atoi(e2) : 0;
+        const char* e3 = getenv("VG_CONV_BN"); force_bn = e3 ? atoi(e3) : 0;
     }
+    const int bn_max = d->Cout <= 16 ? 16 : (d->Cout <= 32 ? 32 : 64);
+    int found = 0, rc = VG_ELDS;
+    long best_score = -1;
+    int best_bn = 0, best_ms = 0, best_wl = 0, best_lds = 0;
+    for (int bn = bn_max; bn >= 16; bn >>= 1) {
+        if (force_bn && bn != force_bn && bn != bn_max) continue;
+        for (int ms = (bn <= 32 ? 4 : 2); ms >= 1; ms >>= 1) {
+            if (force_msub && ms != force_msub) continue;
+            rc = fill_gather(d, g, d->CK, 64 * ms);
+            if (rc != VG_OK) return rc;
+            const long wgs = (long)g.tiles_d * g.tiles_h * g.tiles_w * ((d->Cout + bn - 1) / bn) * d->N;
+            const int wbytes = bn * k.WRS;
+            int wl = (wbytes <= 56 * 1024 && !no_wlds) ? 1 : 0;
+            int need = conv_lds_bytes(g, bn, d->CK, wl ? wbytes : 0);
+            if (need > 80 * 1024 && wl) { const int n2 = conv_lds_bytes(g, bn, d->CK, 0); if (n2 <= 80 * 1024 || need > VG_LDS_LIMIT) { wl = 0; need = n2; } }
+            if (need > VG_LDS_LIMIT) continue;
+            // score: reaching 512 workgroups dominates, then work per workgroup-tile (bn*ms), then small LDS
+            const long fill = wgs >= 512 ? 512 : wgs;
+            const long score = fill * 100000 + (long)bn * ms * 100 + (need <= 80 * 1024 ? 50 : 0);
+            if (score > best_score) { best_score = score; best_bn = bn; best_ms = ms; best_wl = wl; best_lds = need; found = 1; }
+        }
+    }
+    if (found) { BN = best_bn; MSUB = best_ms; k.w_lds = best_wl; lds = best_lds; }
+    if (!found) return VG_ELDS;
+    rc = fill_gather(d, g, d->CK, 64 * MSUB);
     if (rc != VG_OK) return rc;
     k.OD = d->OD; k.OH = d->OH; k.OW = d->OW; k.ostr = d->ostr; k.ood = d->ooff_d; k.ooh = d->ooff_h; k.oow = d->ooff_w;
     k.BD = d->BD; k.BH = d->BH; k.BW = d->BW; k.Cout = d->Cout;
     k.wp = d->wpacked;
-    const int Cpad = ((g.Cin + d->CK - 1) / d->CK) * d->CK;
-    k.nchunks = Cpad / d->CK;
-    k.kc_pad = ((d->ntaps * d->CK + 31) / 32) * 32;
-    k.Ktot = k.nchunks * k.kc_pad;
     k.bias = d->bias; k.res = d->res; k.rs = d->res_scale; k.rb = d->res_shift; k.tanh_out = d->tanh_out;
     k.out = d->out; k.out_f32 = (d->out_f32 || d->f32) ? 1 : 0; k.accumulate = d->accumulate; k.sums = d->out_sums;
     return VG_OK;
@@ -231,14 +290,19 @@ static int launch_conv(const GatherIn& g, const ConvOut& k, int lds, hipStream_t
         (void)hipFuncSetAttribute((const void*)conv_kernel<T, BN, MSUB>, hipFuncAttributeMaxDynamicSharedMemorySize, VG_LDS_LIMIT);
         attr_set = true;
     }
-    dim3 grid(g.tiles_d * g.tiles_h * g.tiles_w, (k.Cout + BN - 1) / BN, g.N);
+    static int wg_target = -1;
+    if (wg_target < 0) { const char* e = getenv("VG_CONV_WGS"); wg_target = e ? atoi(e) : 2048; }
+    const int tiles = g.tiles_d * g.tiles_h * g.tiles_w;
+    const int ny = (k.Cout + BN - 1) / BN;
+    int bx = wg_target / (ny * g.N); if (bx < 1) bx = 1; if (bx > tiles) bx = tiles;
+    dim3 grid(bx, ny, g.N);
     hipLaunchKernelGGL((conv_kernel<T, BN, MSUB>), grid, dim3(256), lds, s, g, k);
     return vg_check_launch();
 }
 template <typename T>
 static int dispatch_conv(const GatherIn& g, const ConvOut& k, int BN, int MSUB, int lds, hipStream_t s) {
-    if (BN == 16) return MSUB == 2 ? launch_conv<T, 16, 2>(g, k, lds, s) : launch_conv<T, 16, 1>(g, k, lds, s);
-    if (BN == 32) return MSUB == 2 ? launch_conv<T, 32, 2>(g, k, lds, s) : launch_conv<T, 32, 1>(g, k, lds, s);
+    if (BN == 16) return MSUB == 4 ? launch_conv<T, 16, 4>(g, k, lds, s) : (MSUB == 2 ? launch_conv<T, 16, 2>(g, k, lds, s) : launch_conv<T, 16, 1>(g, k, lds, s));
+    if (BN == 32) return MSUB == 4 ? launch_conv<T, 32, 4>(g, k, lds, s) : (MSUB == 2 ? launch_conv<T, 32, 2>(g, k, lds, s) : launch_conv<T, 32, 1>(g, k, lds, s));
     return MSUB == 2 ? launch_conv<T, 64, 2>(g, k, lds, s) : launch_conv<T, 64, 1>(g, k, lds, s);
 }
 

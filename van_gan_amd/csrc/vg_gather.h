@@ -216,9 +216,23 @@ static inline int fill_gather(const vg_conv_desc* d, GatherIn& g, int CK, int BM
     }
     g.tmin_d = mn[0]; g.tmin_h = mn[1]; g.tmin_w = mn[2];
     g.RS = CK * (d->f32 ? 4 : 2) + 16;
-    int TW = pow2_ceil(d->OW); if (TW > 16) TW = 16;
-    int TH = pow2_ceil(d->OH); if (TH > BM / TW) TH = BM / TW;
-    int TD = BM / (TW * TH);
+    // tile shape: powers of two with product BM that minimise the halo volume (staging work and L2 traffic scale with
+    // it); the innermost extent stays >= 8 voxels where the grid allows so that rows remain long contiguous runs
+    int TW = 1, TH = 1, TD = 1;
+    {
+        const int ex[3] = {mx[0] - mn[0] + 1, mx[1] - mn[1] + 1, mx[2] - mn[2] + 1};
+        const int capd = pow2_ceil(d->OD), caph = pow2_ceil(d->OH), capw = pow2_ceil(d->OW) < 16 ? pow2_ceil(d->OW) : 16;
+        long best = -1;
+        for (int tw = 1; tw <= capw && tw <= BM; tw <<= 1) {
+            if (tw < 8 && tw < capw) continue;
+            for (int th = 1; th <= caph && tw * th <= BM; th <<= 1) {
+                const int td = BM / (tw * th);
+                long vol = (long)((td - 1) * d->istr + ex[0]) * ((th - 1) * d->istr + ex[1]) * ((tw - 1) * d->istr + ex[2]);
+                if (td > capd) vol *= 4;          // overhang in D wastes whole planes: only when nothing else fits
+                if (best < 0 || vol < best || (vol == best && tw > TW)) { best = vol; TW = tw; TH = th; TD = td; }
+            }
+        }
+    }
     g.twl = ilog2_exact(TW); g.thl = ilog2_exact(TH); g.tdl = ilog2_exact(TD);
     g.tiles_w = (d->OW + TW - 1) / TW; g.tiles_h = (d->OH + TH - 1) / TH; g.tiles_d = (d->OD + TD - 1) / TD;
     g.HD = (TD - 1) * d->istr + (mx[0] - mn[0]) + 1;
