@@ -16,6 +16,7 @@ from typing import Dict, Optional
 import torch
 
 from . import ops
+from .dist import GradSync
 from .nets import PatchGAN, ParamStore, ResUNet, disc_param_specs, gen_param_specs, init_reference
 from .ops import Arena
 
@@ -67,7 +68,7 @@ class VanGan:
         if arena_bytes is None:
             arena_bytes = int(batch_size * S * 5200 * (2 if precision == 'fp32' else 1)) + (512 << 20)
         self.arena = Arena(arena_bytes, self.device)
-        self.comm_stream = torch.cuda.Stream(device=self.device) if self.pg is not None else None
+        self.sync = GradSync({k: s.g for k, s in self.stores.items()}, self.pg, {k: s.w for k, s in self.stores.items()})
         self.checkpoint_dir = None
         if output_dir is not None:
             self.checkpoint_dir = os.path.join(output_dir, 'checkpoints')
@@ -230,19 +231,10 @@ class VanGan:
 
     # ------------------------------------------------------------------------------------------------
     def _start_allreduce(self, names):
-        if self.pg is None:
-            return
-        import torch.distributed as dist
-        ev = torch.cuda.Event()
-        ev.record()
-        self.comm_stream.wait_event(ev)
-        with torch.cuda.stream(self.comm_stream):
-            for n in names:
-                dist.all_reduce(self.stores[n].g, op=dist.ReduceOp.SUM, group=self.pg)
+        self.sync.start(names)
 
     def _finish_allreduce(self):
-        if self.pg is not None:
-            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        self.sync.finish()
 
     def _apply_adam(self):
         for name in NETS:
@@ -278,19 +270,10 @@ class VanGan:
         return self.reduce_dict(self.test_step(x, y))
 
     def reduce_dict(self, d: Dict[str, float]) -> Dict[str, float]:
-        if self.pg is None:
-            return d
-        import torch.distributed as dist
-        t = torch.tensor([d[k] for k in RESULT_KEYS], dtype=torch.float32, device=self.device)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
-        return dict(zip(RESULT_KEYS, t.cpu().tolist()))
+        return self.sync.reduce_dict(d, RESULT_KEYS)
 
     def broadcast_weights(self, src: int = 0):
-        if self.pg is None:
-            return
-        import torch.distributed as dist
-        for st in self.stores.values():
-            dist.broadcast(st.w, src=src, group=self.pg)
+        self.sync.broadcast_weights(src)
         self.repack()
 
     # ------------------------------------------------------------------------------------------------
