@@ -5,6 +5,9 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+import torch  # noqa: F401  -- MUST precede the CDLL below: the process must use the HIP runtime torch ships, otherwise
+#                         libvangan_hip.so binds /opt/rocm's libamdhip64 first and torch then runs on a second copy
+
 from . import build as _build
 
 VG_MAX_TAPS = 64

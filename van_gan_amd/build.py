@@ -19,12 +19,26 @@ def _hipcc() -> str:
     raise RuntimeError('hipcc not found: libvangan_hip.so cannot be built')
 
 
+HASHFILE = LIB + '.srchash'
+
+
+def _src_hash() -> str:
+    """Content hash of every source that goes into the library (mtimes do not survive the copy to the GPU box)."""
+    import hashlib
+    h = hashlib.sha256()
+    deps = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC)) + [os.path.join(HERE, '..', 'include', 'vangan_hip.h')]
+    for d in deps:
+        h.update(os.path.basename(d).encode())
+        with open(d, 'rb') as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def needs_build() -> bool:
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(HASHFILE):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, '..', 'include', 'vangan_hip.h')]
-    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+    with open(HASHFILE) as f:
+        return f.read().strip() != _src_hash()
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -45,10 +59,14 @@ def build(force: bool = False, verbose: bool = False) -> str:
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError('hipcc failed on %s:\n%s' % (s, out.decode()))
-    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+    tmp = LIB + '.tmp.%d' % os.getpid()
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', tmp] + objs
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:
         raise RuntimeError('link failed:\n' + r.stdout.decode())
+    os.replace(tmp, LIB)          # atomic: a process that already mapped the old library keeps its inode
+    with open(HASHFILE, 'w') as f:
+        f.write(_src_hash())
     return LIB
 
 

@@ -54,6 +54,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* w, const float* g, flo
 extern "C" int vg_adam_clip(float* w, const float* g, float* m, float* v, const int64_t* seg_off_dev, int T, int64_t total,
                             float* norms, float lr_t, float beta1, float beta2, float eps, float clipnorm, float grad_scale,
                             vg_stream_t stream) {
+    vg_begin();
     if (!w || !g || !m || !v || !seg_off_dev || !norms || T < 1 || total < 1) return VG_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     if (hipMemsetAsync(norms, 0, T * sizeof(float), s) != hipSuccess) return VG_ELAUNCH;

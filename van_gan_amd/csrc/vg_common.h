@@ -77,6 +77,8 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// a sticky error left by an earlier, unrelated HIP call in this thread must not be blamed on our launch
+static inline void vg_begin() { (void)hipGetLastError(); }
 static inline int vg_check_launch() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? VG_OK : VG_ELAUNCH;

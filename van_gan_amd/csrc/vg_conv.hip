@@ -278,6 +278,7 @@ static int fill_conv(const vg_conv_desc* d, GatherIn& g, ConvOut& k, int& BN, in
 }
 
 extern "C" int vg_conv3d_lds_bytes(const vg_conv_desc* d) {
+    vg_begin();
     GatherIn g; ConvOut k; int BN, MSUB, lds;
     int rc = fill_conv(d, g, k, BN, MSUB, lds);
     return rc == VG_OK ? lds : rc;
@@ -307,6 +308,7 @@ static int dispatch_conv(const GatherIn& g, const ConvOut& k, int BN, int MSUB, 
 }
 
 extern "C" int vg_conv3d(const vg_conv_desc* d, vg_stream_t stream) {
+    vg_begin();
     GatherIn g; ConvOut k; int BN, MSUB, lds;
     int rc = fill_conv(d, g, k, BN, MSUB, lds);
     if (rc != VG_OK) return rc;
@@ -337,14 +339,17 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, int Cin, int Co
 }
 
 extern "C" int vg_packed_ktot(int ntaps, int C, int CK) {
+    vg_begin();
     if (ntaps < 1 || C < 1 || CK < 16 || (CK % 16)) return VG_EINVAL;
     const int nchunks = (C + CK - 1) / CK;
     return nchunks * (((ntaps * CK + 31) / 32) * 32);
 }
-extern "C" int vg_packed_rows(int N) { return ((N + 63) / 64) * 64; }
+extern "C" int vg_packed_rows(int N) {
+    vg_begin(); return ((N + 63) / 64) * 64; }
 
 extern "C" int vg_pack_weights(const float* w, int T, int Cin, int Cout, const int32_t* tap_idx_dev, int ntaps,
                                int transpose, int CK, void* out, int out_f32, vg_stream_t stream) {
+    vg_begin();
     if (!w || !tap_idx_dev || !out || ntaps < 1 || ntaps > T) return VG_EINVAL;
     const int C = transpose ? Cout : Cin, NR = transpose ? Cin : Cout;
     const int Ktot = vg_packed_ktot(ntaps, C, CK);

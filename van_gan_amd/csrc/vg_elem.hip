@@ -38,6 +38,7 @@ __global__ void in_finalize_kernel(const float* sums0, int c0, float cnt0, const
 extern "C" int vg_in_finalize(const float* sums0, int c0, float count0, const float* sums1, int c1, float count1,
                               const float* gamma, const float* beta, const float* mult, int N, float eps,
                               float* scale, float* shift, float* mean, float* rstd, vg_stream_t stream) {
+    vg_begin();
     if (!sums0 || c0 < 1 || c1 < 0 || (c1 > 0 && !sums1) || !scale || !shift || N < 1) return VG_EINVAL;
     const int total = N * (c0 + c1);
     hipLaunchKernelGGL(in_finalize_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums0, c0,
@@ -252,6 +253,7 @@ static dim3 anb_grid(const ANB& p, bool stats = false) {
 }
 
 extern "C" int vg_actnorm_bwd_stats(const vg_actnorm_bwd_desc* d, vg_stream_t stream) {
+    vg_begin();
     ANB p; int rc = fill_anb(d, p, false);
     if (rc != VG_OK) return rc;
     if (!p.red) return VG_EINVAL;
@@ -265,6 +267,7 @@ extern "C" int vg_actnorm_bwd_stats(const vg_actnorm_bwd_desc* d, vg_stream_t st
     return vg_check_launch();
 }
 extern "C" int vg_actnorm_bwd_apply(const vg_actnorm_bwd_desc* d, vg_stream_t stream) {
+    vg_begin();
     ANB p; int rc = fill_anb(d, p, true);
     if (rc != VG_OK) return rc;
     if (d->f32) {
@@ -285,6 +288,7 @@ __global__ void in_param_grads_kernel(const float* red, int N, int C, float* dga
     dbeta[c] += a; dgamma[c] += b;
 }
 extern "C" int vg_in_param_grads(const float* red, int N, int C, float* dgamma, float* dbeta, vg_stream_t stream) {
+    vg_begin();
     if (!red || !dgamma || !dbeta || N < 1 || C < 1) return VG_EINVAL;
     hipLaunchKernelGGL(in_param_grads_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, red, N, C, dgamma, dbeta);
     return vg_check_launch();
@@ -329,6 +333,7 @@ __global__ void concat_bwd_kernel(const T* g, int N, int D, int H, int W, int Cu
 }
 extern "C" int vg_concat_bwd(const void* g, int N, int D, int H, int W, int Cu, int Cs, void* dlow, void* dskip,
                              int f32, vg_stream_t stream) {
+    vg_begin();
     if (!g || !dlow || !dskip || (Cu % 8) || (Cs % 8) || Cu < 8 || Cs < 8 || ((D | H | W) & 1)) return VG_EINVAL;
     const size_t total = (size_t)N * (D / 2) * (H / 2) * (W / 2) * (Cu / 8) + (size_t)N * D * H * W * (Cs / 8);
     int blocks = (int)((total + 255) / 256); if (blocks > 8192) blocks = 8192;
@@ -361,22 +366,26 @@ __global__ void bf16_to_f32_kernel(const bf16_t* x, float* y, int64_t n) {
 static inline int ew_blocks(int64_t n) { int64_t b = (n + 255) / 256; return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b)); }
 
 extern "C" int vg_tanh_bwd(const float* dy, const float* y, float* dpre, int64_t n, vg_stream_t stream) {
+    vg_begin();
     if (!dy || !y || !dpre || n < 0) return VG_EINVAL;
     hipLaunchKernelGGL(tanh_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, dy, y, dpre, n);
     return vg_check_launch();
 }
 extern "C" int vg_axpby(const float* a, float alpha, const float* b, float beta, int64_t n, float* y, int accumulate,
                         vg_stream_t stream) {
+    vg_begin();
     if (!a || !y || n < 0) return VG_EINVAL;
     hipLaunchKernelGGL(axpby_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, alpha, b, beta, n, y, accumulate);
     return vg_check_launch();
 }
 extern "C" int vg_f32_to_bf16(const float* x, void* y, int64_t n, vg_stream_t stream) {
+    vg_begin();
     if (!x || !y || n < 0) return VG_EINVAL;
     hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)y, n);
     return vg_check_launch();
 }
 extern "C" int vg_bf16_to_f32(const void* x, float* y, int64_t n, vg_stream_t stream) {
+    vg_begin();
     if (!x || !y || n < 0) return VG_EINVAL;
     hipLaunchKernelGGL(bf16_to_f32_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, y, n);
     return vg_check_launch();
@@ -418,11 +427,13 @@ __global__ void dropout_mask_kernel(float* out, int64_t n, float rate, uint64_t 
     }
 }
 extern "C" int vg_randn_bf16(void* out, int64_t n, float std, uint64_t seed, uint64_t offset, vg_stream_t stream) {
+    vg_begin();
     if (!out || n < 0) return VG_EINVAL;
     hipLaunchKernelGGL(randn_bf16_kernel, dim3(ew_blocks((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)out, n, std, seed, offset);
     return vg_check_launch();
 }
 extern "C" int vg_dropout_mask(float* out, int64_t n, float rate, uint64_t seed, uint64_t offset, vg_stream_t stream) {
+    vg_begin();
     if (!out || n < 0 || rate < 0.f || rate >= 1.f) return VG_EINVAL;
     hipLaunchKernelGGL(dropout_mask_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, out, n, rate, seed, offset);
     return vg_check_launch();
@@ -437,4 +448,5 @@ extern "C" const char* vg_status_string(int code) {
         default: return "unknown status";
     }
 }
-extern "C" int vg_version(void) { return 1; }
+extern "C" int vg_version(void) {
+    vg_begin(); return 1; }

@@ -61,6 +61,7 @@ __global__ void mm_count_kernel(const float* x, int64_t S, float* mm4) {
     if (threadIdx.x == 0) { if (c0 != 0.f) atomicAdd(&mm4[b * 4 + 2], c0); if (c1 != 0.f) atomicAdd(&mm4[b * 4 + 3], c1); }
 }
 extern "C" int vg_minmax(const float* x, int B, int64_t S, float* mm4, vg_stream_t stream) {
+    vg_begin();
     if (!x || !mm4 || B < 1 || S < 1) return VG_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(mm_init_kernel, dim3((B + 63) / 64), dim3(64), 0, s, mm4, B);
@@ -76,6 +77,7 @@ __global__ void mm_apply_kernel(const float* x, const float* mm4, int64_t S, flo
         y[(size_t)b * S + i] = (x[(size_t)b * S + i] - mn) / r;
 }
 extern "C" int vg_minmax_apply(const float* x, const float* mm4, int B, int64_t S, float* y, vg_stream_t stream) {
+    vg_begin();
     if (!x || !mm4 || !y || B < 1 || S < 1) return VG_EINVAL;
     hipLaunchKernelGGL(mm_apply_kernel, dim3(lblocks(S), B), dim3(256), 0, (hipStream_t)stream, x, mm4, S, y);
     return vg_check_launch();
@@ -105,6 +107,7 @@ __global__ void mm_bwd_apply_kernel(const float* x, const float* gy, const float
 }
 extern "C" int vg_minmax_bwd(const float* x, const float* y, const float* gy, const float* mm4, int B, int64_t S,
                              float* tmp2, float* dx, vg_stream_t stream) {
+    vg_begin();
     if (!x || !y || !gy || !mm4 || !tmp2 || !dx || B < 1 || S < 1) return VG_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     const int bx = lblocks(S, 1024) > 512 ? 512 : lblocks(S, 1024);
@@ -136,6 +139,7 @@ __global__ void bce_kernel(const float* t, const float* p, int64_t n, float* acc
 }
 extern "C" int vg_bce(const float* t, const float* p, int64_t n, float* acc, float gscale, float* gp, int accumulate,
                       vg_stream_t stream) {
+    vg_begin();
     if (!t || !p || !acc || n < 1) return VG_EINVAL;
     hipLaunchKernelGGL(bce_kernel, dim3(lblocks(n, 1024)), dim3(256), 0, (hipStream_t)stream, t, p, n, acc, gscale, gp, accumulate);
     return vg_check_launch();
@@ -153,6 +157,7 @@ __global__ void mse_kernel(const float* a, const float* b, int64_t n, float* acc
 }
 extern "C" int vg_mse(const float* a, const float* b, int64_t n, float* acc, float gscale, float* gb, int accumulate,
                       vg_stream_t stream) {
+    vg_begin();
     if (!a || !b || !acc || n < 1) return VG_EINVAL;
     hipLaunchKernelGGL(mse_kernel, dim3(lblocks(n, 1024)), dim3(256), 0, (hipStream_t)stream, a, b, n, acc, gscale, gb, accumulate);
     return vg_check_launch();
@@ -171,6 +176,7 @@ __global__ void mse_const_kernel(const void* x, int x_f32, float target, int64_t
 }
 extern "C" int vg_mse_const(const void* x, int x_f32, float target, int64_t n, float* acc, float gscale, float* gx,
                             int accumulate, vg_stream_t stream) {
+    vg_begin();
     if (!x || !acc || n < 1) return VG_EINVAL;
     hipLaunchKernelGGL(mse_const_kernel, dim3(lblocks(n, 1024)), dim3(256), 0, (hipStream_t)stream, x, x_f32, target, n, acc,
                        gscale, gx, accumulate);
@@ -186,6 +192,7 @@ __global__ void dot_sums_kernel(const float* a, const float* b, int64_t n, float
     if (threadIdx.x == 0) { atomicAdd(&sums3[0], s0); atomicAdd(&sums3[1], s1); atomicAdd(&sums3[2], s2); }
 }
 extern "C" int vg_dot_sums(const float* a, const float* b, int64_t n, float* sums3, vg_stream_t stream) {
+    vg_begin();
     if (!a || !b || !sums3 || n < 1) return VG_EINVAL;
     hipLaunchKernelGGL(dot_sums_kernel, dim3(lblocks(n, 1024)), dim3(256), 0, (hipStream_t)stream, a, b, n, sums3);
     return vg_check_launch();
@@ -235,6 +242,7 @@ __global__ void ssim_fwd_kernel(const float* t, const float* p, int B, int D, in
 }
 extern "C" int vg_ssim_fwd(const float* t, const float* p, int B, int D, int H, int W, float* acc, float* part,
                            vg_stream_t stream) {
+    vg_begin();
     if (!t || !p || !acc || B < 1 || D < 1 || H < 1 || W < 1) return VG_EINVAL;
     hipLaunchKernelGGL(ssim_fwd_kernel, dim3(lblocks((int64_t)B * D * H * W)), dim3(256), 0, (hipStream_t)stream, t, p, B, D, H, W, acc, part);
     return vg_check_launch();
@@ -259,6 +267,7 @@ __global__ void ssim_bwd_kernel(const float* t, const float* p, const float* par
 }
 extern "C" int vg_ssim_bwd(const float* t, const float* p, const float* part, int B, int D, int H, int W, float gscale,
                            float* gp, int accumulate, vg_stream_t stream) {
+    vg_begin();
     if (!t || !p || !part || !gp || B < 1) return VG_EINVAL;
     hipLaunchKernelGGL(ssim_bwd_kernel, dim3(lblocks((int64_t)B * D * H * W)), dim3(256), 0, (hipStream_t)stream, t, p, part, B, D, H, W,
                        gscale, gp, accumulate);
@@ -315,6 +324,7 @@ __global__ void skel_update_kernel(const float* imgj, const float* imgj1, const 
 }
 extern "C" int vg_soft_skel_fwd(const float* img, int B, int D, int H, int W, int iters, float* imgs, float* skels,
                                 vg_stream_t stream) {
+    vg_begin();
     if (!img || !imgs || !skels || B < 1 || iters < 0) return VG_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     const int64_t n = (int64_t)B * D * H * W;
@@ -363,6 +373,7 @@ __global__ void erode_bwd_kernel(const float* imgj, const float* dimgj1, int B, 
 }
 extern "C" int vg_soft_skel_bwd(const float* imgs, const float* skels, const float* gskel, int B, int D, int H, int W,
                                 int iters, float* work, float* gimg, vg_stream_t stream) {
+    vg_begin();
     if (!imgs || !skels || !gskel || !work || !gimg || B < 1 || iters < 0) return VG_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     const int64_t n = (int64_t)B * D * H * W;
@@ -414,12 +425,14 @@ __global__ void cldice_grads_kernel(const float* t, const float* skel_t, const f
     }
 }
 extern "C" int vg_cldice_coef(const float* sums7, float w, float alpha, float* coef6, vg_stream_t stream) {
+    vg_begin();
     if (!sums7 || !coef6) return VG_EINVAL;
     hipLaunchKernelGGL(cldice_coef_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums7, w, alpha, coef6);
     return vg_check_launch();
 }
 extern "C" int vg_cldice_grads(const float* t, const float* skel_t, const float* coef6, int64_t n, float* gskel_p, float* gp,
                                int accumulate, vg_stream_t stream) {
+    vg_begin();
     if (!t || !skel_t || !coef6 || !gskel_p || !gp || n < 1) return VG_EINVAL;
     hipLaunchKernelGGL(cldice_grads_kernel, dim3(lblocks(n)), dim3(256), 0, (hipStream_t)stream, t, skel_t, coef6, n, gskel_p, gp, accumulate);
     return vg_check_launch();

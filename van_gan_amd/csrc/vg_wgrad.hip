@@ -254,6 +254,7 @@ static void launch_wgrad(const GatherIn& g, const WgradK& k, dim3 grid, int lds,
 extern "C" int vg_conv3d_wgrad(const vg_conv_desc* d, const void* dy, int dy_f32, const int32_t* tap_idx_host,
                                int T_total, float* dw, float* db, float* scratch, int64_t scratch_bytes,
                                vg_stream_t stream) {
+    vg_begin();
     if (!d || !dy || !dw || !tap_idx_host) return VG_EINVAL;
     if (d->Cout < 1 || (d->Cout != 1 && (d->Cout % 8))) return VG_EINVAL;
     if (dy_f32 && d->Cout != 1 && !d->f32) return VG_EINVAL;
