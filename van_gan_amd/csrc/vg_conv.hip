@@ -34,8 +34,12 @@ struct ConvOut {
 template <typename T, int BN, int MSUB>
 __global__ __launch_bounds__(256) void conv_kernel(const GatherIn g, const ConvOut p) {
     constexpr bool F32 = sizeof(T) == 4;
+    // wave decomposition: WN waves along the channel panel (one 16-channel sub-tile each, so a weight fragment is
+    // fetched by exactly one wave: L1 delivers 64 B/clk, LDS 256 B/clk), WM waves along the voxels
+    constexpr int WN = BN / 16, WM = 4 / WN, MW = MSUB * WN;     // MW voxel sub-tiles per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_n = wave % WN, wave_m = wave / WN;
     const int n = blockIdx.z, ntile = blockIdx.y;
     const int TWm = (1 << g.twl) - 1, THm = (1 << g.thl) - 1;
 
@@ -45,14 +49,14 @@ __global__ __launch_bounds__(256) void conv_kernel(const GatherIn g, const ConvO
     float* scs = (float*)(smem + hbytes + 256);
     float* stat = scs + 2 * g.CK;
     int* utab = (int*)(stat + BN * 2);
-    const int nunits = g.HD * g.HH * g.HW * (g.CK >> 3);
+    const int nunits = g.HD * g.HH * g.HW * 3;
     char* wlds = (char*)(utab + nunits);
     wlds = (char*)(((size_t)wlds + 15) & ~(size_t)15);
 
     if (tid < g.ntaps)
         tapoff[tid] = (((g.td[tid] - g.tmin_d) * g.HH + (g.th[tid] - g.tmin_h)) * g.HW + (g.tw[tid] - g.tmin_w)) * g.RS;
     if (tid < BN * 2) stat[tid] = 0.f;
-    build_unit_table(g, utab, tid, 256);
+    build_voxel_table(g, utab, tid, 256);
     if (p.w_lds) {          // weight panel -> LDS, 16 B per thread per step
         const int per_row = (p.Ktot * (int)sizeof(T)) >> 4;
         for (int u = tid; u < BN * per_row; u += 256) {
@@ -62,10 +66,10 @@ __global__ __launch_bounds__(256) void conv_kernel(const GatherIn g, const ConvO
         }
     }
 
-    int rowbase[MSUB];
+    int rowbase[MW];
 #pragma unroll
-    for (int i = 0; i < MSUB; ++i) {
-        const int m = (wave * MSUB + i) * 16 + (lane & 15);
+    for (int i = 0; i < MW; ++i) {
+        const int m = (wave_m * MW + i) * 16 + (lane & 15);
         const int w = m & TWm, h = (m >> g.twl) & THm, d = m >> (g.twl + g.thl);
         rowbase[i] = ((d * g.istr * g.HH + h * g.istr) * g.HW + w * g.istr) * g.RS;
     }
@@ -73,17 +77,12 @@ __global__ __launch_bounds__(256) void conv_kernel(const GatherIn g, const ConvO
     const int ngroups = g.ntaps * gpc;
     const int ksteps = (ngroups + 3) >> 2;
     // weight fragment source: LDS panel or global (L2) rows
-    const T* wrow[BN / 16];
+    const T* wrow;
+    if (p.w_lds) wrow = (const T*)(wlds + (size_t)(wave_n * 16 + (lane & 15)) * p.WRS) + (F32 ? 1 : 8) * (lane >> 4);
+    else wrow = (const T*)p.wp + (size_t)(ntile * BN + wave_n * 16 + (lane & 15)) * p.Ktot + (F32 ? 1 : 8) * (lane >> 4);
+    float s1[4], s2[4];
 #pragma unroll
-    for (int a = 0; a < BN / 16; ++a) {
-        if (p.w_lds) wrow[a] = (const T*)(wlds + (size_t)(a * 16 + (lane & 15)) * p.WRS) + (F32 ? 1 : 8) * (lane >> 4);
-        else wrow[a] = (const T*)p.wp + (size_t)(ntile * BN + a * 16 + (lane & 15)) * p.Ktot + (F32 ? 1 : 8) * (lane >> 4);
-    }
-    float s1[BN / 16][4], s2[BN / 16][4];
-#pragma unroll
-    for (int q = 0; q < BN / 16; ++q)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { s1[q][r] = 0.f; s2[q][r] = 0.f; }
+    for (int r = 0; r < 4; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
     if (p.nchunks == 1) stage_scale_shift(g, scs, n, 0, tid);
     __syncthreads();
 
@@ -93,16 +92,14 @@ __global__ __launch_bounds__(256) void conv_kernel(const GatherIn g, const ConvO
         const int tw_i = t % g.tiles_w; t /= g.tiles_w;
         const int th_i = t % g.tiles_h; const int td_i = t / g.tiles_h;
         const int od0 = td_i << g.tdl, oh0 = th_i << g.thl, ow0 = tw_i << g.twl;
-        f32x4 acc[BN / 16][MSUB];
+        f32x4 acc[MW];
 #pragma unroll
-        for (int a = 0; a < BN / 16; ++a)
-#pragma unroll
-            for (int i = 0; i < MSUB; ++i) acc[a][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < MW; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
         for (int chunk = 0; chunk < p.nchunks; ++chunk) {
             __syncthreads();                       // previous readers of the halo tile are done
             if (p.nchunks > 1) { stage_scale_shift(g, scs, n, chunk, tid); __syncthreads(); }
-            if (!(g.dbg & 1)) stage_halo_tab<T>(g, halo, scs, utab, n, od0, oh0, ow0, chunk, tid, 256);
+            if (!(g.dbg & 1)) stage_halo_v3<T>(g, halo, scs, utab, n, od0, oh0, ow0, chunk, tid);
             __syncthreads();
             const size_t kbase = (size_t)chunk * p.kc_pad;
             if (g.dbg & 4) continue;
@@ -112,16 +109,12 @@ __global__ __launch_bounds__(256) void conv_kernel(const GatherIn g, const ConvO
                 const int nk4 = (g.ntaps * g.CK) >> 2;
                 for (int s = 0; s < nk4; ++s) {
                     const int off = tapoff[tap] + (ch0 + (lane >> 4)) * 4;
-                    float b[MSUB], a[BN / 16];
+                    float b[MW];
 #pragma unroll
-                    for (int i = 0; i < MSUB; ++i) b[i] = *(const float*)(halo + rowbase[i] + off);
+                    for (int i = 0; i < MW; ++i) b[i] = *(const float*)(halo + rowbase[i] + off);
+                    const float a = wrow[kbase + s * 4];
 #pragma unroll
-                    for (int q = 0; q < BN / 16; ++q) a[q] = wrow[q][kbase + s * 4];
-#pragma unroll
-                    for (int q = 0; q < BN / 16; ++q)
-#pragma unroll
-                        for (int i = 0; i < MSUB; ++i)
-                            acc[q][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], b[i], acc[q][i], 0, 0, 0);
+                    for (int i = 0; i < MW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[i], acc[i], 0, 0, 0);
                     ch0 += 4;
                     if (ch0 >= g.CK) { ch0 = 0; ++tap; }
                 }
@@ -132,79 +125,69 @@ __global__ __launch_bounds__(256) void conv_kernel(const GatherIn g, const ConvO
                 for (int s = 0; s < ksteps; ++s) {
                     const int tp = tap < g.ntaps ? tap : g.ntaps - 1;      // padded K: weights are zero there
                     const int off = tapoff[tp] + cg * 16;
-                    bf16x8 b[MSUB];
+                    bf16x8 b[MW];
 #pragma unroll
-                    for (int i = 0; i < MSUB; ++i) b[i] = *(const bf16x8*)(halo + rowbase[i] + off);
-                    bf16x8 a[BN / 16];
+                    for (int i = 0; i < MW; ++i) b[i] = *(const bf16x8*)(halo + rowbase[i] + off);
+                    const bf16x8 a = *(const bf16x8*)((const bf16_t*)wrow + kbase + s * 32);
 #pragma unroll
-                    for (int q = 0; q < BN / 16; ++q) a[q] = *(const bf16x8*)((const bf16_t*)wrow[q] + kbase + s * 32);
-#pragma unroll
-                    for (int q = 0; q < BN / 16; ++q)
-#pragma unroll
-                        for (int i = 0; i < MSUB; ++i)
-                            acc[q][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[q], b[i], acc[q][i], 0, 0, 0);
+                    for (int i = 0; i < MW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[i], acc[i], 0, 0, 0);
                     cg += 4;
                     while (cg >= gpc) { cg -= gpc; ++tap; }
                 }
             }
         }
         if (g.dbg & 8) continue;
-        // ---- epilogue: lane holds out channels co0..co0+3 of voxel (lane&15) of each subtile ----
+        // ---- epilogue: lane holds out channels co0..co0+3 of voxel (lane&15) of each of the wave's sub-tiles ----
+        const int co0 = ntile * BN + wave_n * 16 + 4 * (lane >> 4);
 #pragma unroll
-        for (int i = 0; i < MSUB; ++i) {
-            const int m = (wave * MSUB + i) * 16 + (lane & 15);
+        for (int i = 0; i < MW; ++i) {
+            const int m = (wave_m * MW + i) * 16 + (lane & 15);
             const int w = m & TWm, h = (m >> g.twl) & THm, d = m >> (g.twl + g.thl);
             const int od = od0 + d, oh = oh0 + h, ow = ow0 + w;
             const bool inr = od < p.OD && oh < p.OH && ow < p.OW;
+            if (!inr || co0 >= p.Cout) continue;
             const size_t vox = ((size_t)(n * p.BD + od * p.ostr + p.ood) * p.BH + oh * p.ostr + p.ooh) * p.BW + ow * p.ostr + p.oow;
+            const size_t idx = vox * p.Cout + co0;
+            float v[4];
 #pragma unroll
-            for (int q = 0; q < BN / 16; ++q) {
-                const int co0 = ntile * BN + q * 16 + 4 * (lane >> 4);
-                if (!inr || co0 >= p.Cout) continue;
-                const size_t idx = vox * p.Cout + co0;
-                float v[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int co = co0 + r;
-                    float y = acc[q][i][r];
-                    if (co < p.Cout) {
-                        if (p.bias) y += p.bias[co];
-                        if (p.res) y += ld1<T>((const T*)p.res + idx + r) * p.rs[n * p.Cout + co] + p.rb[n * p.Cout + co];
-                        if (p.tanh_out) y = tanhf(y);
-                        if (p.accumulate) y += p.out_f32 ? ((float*)p.out)[idx + r] : bf2f(((bf16_t*)p.out)[idx + r]);
-                        if (!p.out_f32) y = bfround(y);
-                        s1[q][r] += y; s2[q][r] += y * y;
-                    }
-                    v[r] = y;
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + r;
+                float y = acc[i][r];
+                if (co < p.Cout) {
+                    if (p.bias) y += p.bias[co];
+                    if (p.res) y += ld1<T>((const T*)p.res + idx + r) * p.rs[n * p.Cout + co] + p.rb[n * p.Cout + co];
+                    if (p.tanh_out) y = tanhf(y);
+                    if (p.accumulate) y += p.out_f32 ? ((float*)p.out)[idx + r] : bf2f(((bf16_t*)p.out)[idx + r]);
+                    if (!p.out_f32) y = bfround(y);
+                    s1[r] += y; s2[r] += y * y;
                 }
-                if (p.out_f32) {
-                    float* o = (float*)p.out + idx;
-                    if (co0 + 3 < p.Cout) { *(f32x4*)o = (f32x4){v[0], v[1], v[2], v[3]}; }
-                    else { for (int r = 0; r < 4; ++r) if (co0 + r < p.Cout) o[r] = v[r]; }
-                } else {
-                    bf16_t* o = (bf16_t*)p.out + idx;
-                    if (co0 + 3 < p.Cout) {
-                        bf16x4 pk = {(short)f2bf(v[0]), (short)f2bf(v[1]), (short)f2bf(v[2]), (short)f2bf(v[3])};
-                        *(bf16x4*)o = pk;
-                    } else { for (int r = 0; r < 4; ++r) if (co0 + r < p.Cout) o[r] = f2bf(v[r]); }
-                }
+                v[r] = y;
+            }
+            if (p.out_f32) {
+                float* o = (float*)p.out + idx;
+                if (co0 + 3 < p.Cout) { *(f32x4*)o = (f32x4){v[0], v[1], v[2], v[3]}; }
+                else { for (int r = 0; r < 4; ++r) if (co0 + r < p.Cout) o[r] = v[r]; }
+            } else {
+                bf16_t* o = (bf16_t*)p.out + idx;
+                if (co0 + 3 < p.Cout) {
+                    bf16x4 pk = {(short)f2bf(v[0]), (short)f2bf(v[1]), (short)f2bf(v[2]), (short)f2bf(v[3])};
+                    *(bf16x4*)o = pk;
+                } else { for (int r = 0; r < 4; ++r) if (co0 + r < p.Cout) o[r] = f2bf(v[r]); }
             }
         }
     }
     if (p.sums) {
 #pragma unroll
-        for (int q = 0; q < BN / 16; ++q)
+        for (int r = 0; r < 4; ++r) {
+            float a = s1[r], b = s2[r];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float a = s1[q][r], b = s2[q][r];
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
-                if ((lane & 15) == 0) {
-                    const int cl = q * 16 + 4 * (lane >> 4) + r;
-                    atomicAdd(&stat[cl * 2], a);
-                    atomicAdd(&stat[cl * 2 + 1], b);
-                }
+            for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+            if ((lane & 15) == 0) {
+                const int cl = wave_n * 16 + 4 * (lane >> 4) + r;
+                atomicAdd(&stat[cl * 2], a);
+                atomicAdd(&stat[cl * 2 + 1], b);
             }
+        }
         __syncthreads();
         if (tid < BN * 2) {
             const int co = ntile * BN + (tid >> 1);
@@ -218,7 +201,7 @@ __global__ __launch_bounds__(256) void conv_kernel(const GatherIn g, const ConvO
 // host side
 // ------------------------------------------------------------------------------------------------
 static int conv_lds_bytes(const GatherIn& g, int BN, int CK, int wbytes) {
-    const int nunits = g.HD * g.HH * g.HW * (CK >> 3);
+    const int nunits = g.HD * g.HH * g.HW * 3;
     return halo_bytes(g) + 256 + 2 * CK * 4 + BN * 2 * 4 + nunits * 4 + 16 + wbytes;
 }
 

@@ -187,6 +187,129 @@ __device__ __forceinline__ void stage_halo_tab(const GatherIn& g, char* halo, co
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Staging v3: per-halo-voxel table + one fixed 8-channel group per thread.
+//   vtab[hv] = { hd | hh<<8 | hw<<16, element offset into src0 (half-res aware), element offset into src1 }
+// Thread t owns channel group cg = t % gpc for the whole chunk (its 8 scale/shift pairs sit in registers) and walks the
+// halo voxels vl, vl+vstride, ...  Interior tiles (no padding / reflection inside the halo, no noise, multi-channel
+// source) take the fast path: address = tile base + table offset, transform, one 16-byte LDS store.  Everything else
+// (border tiles, single-channel sources, noise) takes the general path with the same thread mapping.
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void build_voxel_table(const GatherIn& g, int* vtab, int tid, int nthreads) {
+    const int nvox = g.HD * g.HH * g.HW;
+    const int sh = g.shift0;
+    const int Hs = g.H >> sh, Ws = g.W >> sh;
+    const int par_d = g.tmin_d & sh, par_h = g.tmin_h & sh, par_w = g.tmin_w & sh;    // parity of the tile base
+    for (int hv = tid; hv < nvox; hv += nthreads) {
+        const int hw = hv % g.HW; const int t2 = hv / g.HW;
+        const int hh = t2 % g.HH, hd = t2 / g.HH;
+        vtab[hv * 3] = hd | (hh << 8) | (hw << 16);
+        vtab[hv * 3 + 1] = ((((hd + par_d) >> sh) * Hs + ((hh + par_h) >> sh)) * Ws + ((hw + par_w) >> sh)) * g.c0;
+        vtab[hv * 3 + 2] = ((hd * g.H + hh) * g.W + hw) * g.c1;
+    }
+}
+
+template <typename T, int UB = 4>
+__device__ __forceinline__ void stage_halo_v3(const GatherIn& g, char* halo, const float* scs, const int* vtab, int n,
+                                              int od0, int oh0, int ow0, int chunk, int tid) {
+    const int gpc = g.CK >> 3;
+    const int vstride = 256 / gpc;                      // voxels handled in parallel
+    if (tid >= vstride * gpc) return;
+    const int cg = tid % gpc, vl = tid / gpc;
+    const int nvox = g.HD * g.HH * g.HW;
+    const int c = chunk * g.CK + cg * 8;
+    const int pd0 = od0 * g.istr + g.tmin_d, ph0 = oh0 * g.istr + g.tmin_h, pw0 = ow0 * g.istr + g.tmin_w;
+    const bool interior = pd0 >= 0 && ph0 >= 0 && pw0 >= 0 && pd0 + g.HD <= g.D && ph0 + g.HH <= g.H && pw0 + g.HW <= g.W;
+    const bool tile_even = ((g.tdl > 0) || !(g.istr & 1)) && ((g.thl > 0) || !(g.istr & 1)) && ((g.twl > 0) || !(g.istr & 1));
+    const bool fast = interior && !g.noise && g.Cin != 1 && (g.shift0 == 0 || tile_even);
+    const bool plain = !g.in_scale && g.act == VG_ACT_NONE;          // data-gradient operand: pure copy
+    T* dst0 = (T*)halo + cg * 8;
+    if (fast) {
+        if (c >= g.Cin) {                               // channel padding of the last chunk
+            const float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int hv = vl; hv < nvox; hv += vstride) store8<T>((T*)(halo + (size_t)hv * g.RS) + cg * 8, z);
+            return;
+        }
+        const bool from0 = c < g.c0;
+        const int sh = g.shift0;
+        const T* base;
+        if (from0) base = (const T*)g.src0 + ((((size_t)n * (g.D >> sh) + (pd0 >> sh)) * (g.H >> sh) + (ph0 >> sh)) * (g.W >> sh) + (pw0 >> sh)) * g.c0 + c;
+        else base = (const T*)g.src1 + ((((size_t)n * g.D + pd0) * g.H + ph0) * g.W + pw0) * g.c1 + (c - g.c0);
+        const int sel = from0 ? 1 : 2;
+        float sc[8], sf[8];
+        if (!plain) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { sc[j] = scs[cg * 8 + j]; sf[j] = scs[g.CK + cg * 8 + j]; }
+        }
+        for (int hv0 = vl; hv0 < nvox; hv0 += vstride * UB) {
+            Raw8<T> raw[UB];
+#pragma unroll
+            for (int k = 0; k < UB; ++k) {
+                const int hv = hv0 + k * vstride;
+                if (hv < nvox) raw_load(raw[k], base + vtab[hv * 3 + sel]);
+            }
+#pragma unroll
+            for (int k = 0; k < UB; ++k) {
+                const int hv = hv0 + k * vstride;
+                if (hv < nvox) {
+                    T* dst = (T*)(halo + (size_t)hv * g.RS) + cg * 8;
+                    if (plain) { *(Raw8<T>*)dst = raw[k]; }
+                    else {
+                        float x[8];
+                        raw_unpack(raw[k], x);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) x[j] = vg_act(x[j] * sc[j] + sf[j], g.act);
+                        store8<T>(dst, x);
+                    }
+                }
+            }
+        }
+        return;
+    }
+    // ---- general path (border tiles, single-channel sources, noise): same thread mapping, one unit at a time (batching
+    // these loads as well was measured to cost more in registers/occupancy than it gained) ----
+    const int Ds = g.D >> g.shift0, Hs = g.H >> g.shift0, Ws = g.W >> g.shift0;
+    const int ND = g.D + 2 * g.npad, NH = g.H + 2 * g.npad, NW = g.W + 2 * g.npad;
+    const bool c1mode = g.Cin == 1;
+    (void)dst0;
+    for (int hv = vl; hv < nvox; hv += vstride) {
+        const int e = vtab[hv * 3];
+        const int hd = e & 255, hh = (e >> 8) & 255, hw = e >> 16;
+        int pd = pd0 + hd, ph = ph0 + hh, pw = pw0 + hw;
+        const int qd = pd + g.npad, qh = ph + g.npad, qw = pw + g.npad;
+        bool valid = resolve_pos(pd, g.D, g.pad_mode);
+        valid &= resolve_pos(ph, g.H, g.pad_mode);
+        valid &= resolve_pos(pw, g.W, g.pad_mode);
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (valid && c < g.Cin) {
+            float x[8];
+            int nval = 8;
+            if (c1mode) {
+                nval = 1;
+                const size_t idx = ((size_t)(n * g.D + pd) * g.H + ph) * g.W + pw;
+                x[0] = g.src_f32 ? ((const float*)g.src0)[idx] : bf2f(((const bf16_t*)g.src0)[idx]);
+            } else if (c < g.c0) {
+                const size_t idx = (((size_t)(n * Ds + (pd >> g.shift0)) * Hs + (ph >> g.shift0)) * Ws + (pw >> g.shift0)) * g.c0 + c;
+                load8<T>((const T*)g.src0 + idx, x);
+            } else {
+                const size_t idx = (((size_t)(n * g.D + pd) * g.H + ph) * g.W + pw) * g.c1 + (c - g.c0);
+                load8<T>((const T*)g.src1 + idx, x);
+            }
+            const bool has_noise = g.noise && qd >= 0 && qd < ND && qh >= 0 && qh < NH && qw >= 0 && qw < NW;
+            const size_t nidx = has_noise ? ((((size_t)(n * ND + qd) * NH + qh) * NW + qw) * g.Cin + c) : 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (j < nval) {
+                    float y = vg_act(x[j] * scs[cg * 8 + j] + scs[g.CK + cg * 8 + j], g.act);
+                    if (has_noise) y += bf2f(g.noise[nidx + j]);
+                    v[j] = y;
+                }
+            }
+        }
+        store8<T>((T*)(halo + (size_t)hv * g.RS) + cg * 8, v);
+    }
+}
+
 // ---- host: validate the input side of a descriptor and derive the tile geometry for BM voxels ----
 static inline int fill_gather(const vg_conv_desc* d, GatherIn& g, int CK, int BM) {
     if (!d || !d->src0) return VG_EINVAL;

@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const GatherIn g, const Wgra
     if (tid < g.ntaps)
         tapoff[tid] = (((g.td[tid] - g.tmin_d) * g.HH + (g.th[tid] - g.tmin_h)) * g.HW + (g.tw[tid] - g.tmin_w)) * g.RS;
     if (tid < VG_MAX_TAPS) tapsrc[tid] = p.tap_src[tid];
-    build_unit_table(g, utab, tid, 256);
+    build_voxel_table(g, utab, tid, 256);
     __syncthreads();
 
     // rows of this wave: r = wave + 4*j -> (tap, ci16); byte offset of the row's P fragment inside the halo tile
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const GatherIn g, const Wgra
             cur_n = n;
             __syncthreads();
         }
-        if (!(g.dbg & 1) || tile == (int)blockIdx.x) stage_halo_tab<T>(g, halo, scs, utab, n, od0, oh0, ow0, cib, tid, 256);
+        if (!(g.dbg & 1) || tile == (int)blockIdx.x) stage_halo_v3<T>(g, halo, scs, utab, n, od0, oh0, ow0, cib, tid);
         if (!(g.dbg & 2) || tile == (int)blockIdx.x)
         // ---- stage dY tile [BM][16*Q] (zero outside the grid / beyond Cout): all loads first ----
         for (int u0 = tid; u0 < BM * gcol; u0 += 256 * 4) {
@@ -275,7 +275,7 @@ extern "C" int vg_conv3d_wgrad(const vg_conv_desc* d, const void* dy, int dy_f32
                 if (Cinp % c) continue;
                 int rc = fill_gather(d, g, c, bm);
                 if (rc != VG_OK) return rc;
-                const int lds = halo_bytes(g) + bm * (COB * esz + 16) + 512 + 2 * c * 4 + g.HD * g.HH * g.HW * (c / 8) * 4;
+                const int lds = halo_bytes(g) + bm * (COB * esz + 16) + 512 + 2 * c * 4 + g.HD * g.HH * g.HW * 3 * 4;
                 if (lds <= limit) { best_bm = bm; best_cib = c; best_lds = lds; break; }
             }
     }
