@@ -62,7 +62,12 @@ def main():
             src = Src(low, (N,) + dims, cat[0], skip, cat[1], shift0=1, scale=scale, shift=shift, act=ops.ACT_RELU)
         else:
             x = torch.randn(N, *dims, cin, device=dev).to(torch.bfloat16)
-            src = Src(x, (N,) + dims, cin, scale=scale, shift=shift, act=ops.ACT_RELU)
+            nz = None
+            if name.startswith('D.'):
+                npad = 1 if pad == 'reflect' else 0
+                nz = (torch.randn(N, *[d_ + 2 * npad for d_ in dims], cin, device=dev) * 0.1).to(torch.bfloat16)
+            src = Src(x, (N,) + dims, cin, scale=scale, shift=shift, act=ops.ACT_LRELU if nz is not None else ops.ACT_RELU,
+                      noise=nz, noise_pad=1 if pad == 'reflect' else 0)
         out = torch.zeros(N, *lay.out_dims, cout, dtype=torch.bfloat16, device=dev)
         sums = torch.zeros(8, N, cout, 2, device=dev)
         dy = torch.randn(N, *lay.out_dims, cout, device=dev).to(torch.bfloat16)

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void conv_kernel(const GatherIn g, const ConvO
     float* scs = (float*)(smem + hbytes + 256);
     float* stat = scs + 2 * g.CK;
     int* utab = (int*)(stat + BN * 2);
-    const int nunits = g.HD * g.HH * g.HW * 3;
+    const int nunits = g.HD * g.HH * g.HW * 4;
     char* wlds = (char*)(utab + nunits);
     wlds = (char*)(((size_t)wlds + 15) & ~(size_t)15);
 
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void conv_kernel(const GatherIn g, const ConvO
 // host side
 // ------------------------------------------------------------------------------------------------
 static int conv_lds_bytes(const GatherIn& g, int BN, int CK, int wbytes) {
-    const int nunits = g.HD * g.HH * g.HW * 3;
+    const int nunits = g.HD * g.HH * g.HW * 4;
     return halo_bytes(g) + 256 + 2 * CK * 4 + BN * 2 * 4 + nunits * 4 + 16 + wbytes;
 }
 

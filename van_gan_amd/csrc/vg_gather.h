@@ -189,7 +189,7 @@ __device__ __forceinline__ void stage_halo_tab(const GatherIn& g, char* halo, co
 
 // ------------------------------------------------------------------------------------------------------------------
 // Staging v3: per-halo-voxel table + one fixed 8-channel group per thread.
-//   vtab[hv] = { hd | hh<<8 | hw<<16, element offset into src0 (half-res aware), element offset into src1 }
+//   vtab[hv] = { hd | hh<<8 | hw<<16, element offset into src0 (half-res aware), into src1, into the noise grid }
 // Thread t owns channel group cg = t % gpc for the whole chunk (its 8 scale/shift pairs sit in registers) and walks the
 // halo voxels vl, vl+vstride, ...  Interior tiles (no padding / reflection inside the halo, no noise, multi-channel
 // source) take the fast path: address = tile base + table offset, transform, one 16-byte LDS store.  Everything else
@@ -203,9 +203,10 @@ __device__ __forceinline__ void build_voxel_table(const GatherIn& g, int* vtab, 
     for (int hv = tid; hv < nvox; hv += nthreads) {
         const int hw = hv % g.HW; const int t2 = hv / g.HW;
         const int hh = t2 % g.HH, hd = t2 / g.HH;
-        vtab[hv * 3] = hd | (hh << 8) | (hw << 16);
-        vtab[hv * 3 + 1] = ((((hd + par_d) >> sh) * Hs + ((hh + par_h) >> sh)) * Ws + ((hw + par_w) >> sh)) * g.c0;
-        vtab[hv * 3 + 2] = ((hd * g.H + hh) * g.W + hw) * g.c1;
+        vtab[hv * 4] = hd | (hh << 8) | (hw << 16);
+        vtab[hv * 4 + 1] = ((((hd + par_d) >> sh) * Hs + ((hh + par_h) >> sh)) * Ws + ((hw + par_w) >> sh)) * g.c0;
+        vtab[hv * 4 + 2] = ((hd * g.H + hh) * g.W + hw) * g.c1;
+        vtab[hv * 4 + 3] = ((hd * (g.H + 2 * g.npad) + hh) * (g.W + 2 * g.npad) + hw) * g.Cin;
     }
 }
 
@@ -221,8 +222,8 @@ __device__ __forceinline__ void stage_halo_v3(const GatherIn& g, char* halo, con
     const int pd0 = od0 * g.istr + g.tmin_d, ph0 = oh0 * g.istr + g.tmin_h, pw0 = ow0 * g.istr + g.tmin_w;
     const bool interior = pd0 >= 0 && ph0 >= 0 && pw0 >= 0 && pd0 + g.HD <= g.D && ph0 + g.HH <= g.H && pw0 + g.HW <= g.W;
     const bool tile_even = ((g.tdl > 0) || !(g.istr & 1)) && ((g.thl > 0) || !(g.istr & 1)) && ((g.twl > 0) || !(g.istr & 1));
-    const bool fast = interior && !g.noise && g.Cin != 1 && (g.shift0 == 0 || tile_even);
-    const bool plain = !g.in_scale && g.act == VG_ACT_NONE;          // data-gradient operand: pure copy
+    const bool fast = interior && g.Cin != 1 && (g.shift0 == 0 || tile_even);
+    const bool plain = !g.in_scale && g.act == VG_ACT_NONE && !g.noise;          // data-gradient operand: pure copy
     T* dst0 = (T*)halo + cg * 8;
     if (fast) {
         if (c >= g.Cin) {                               // channel padding of the last chunk
@@ -236,6 +237,8 @@ __device__ __forceinline__ void stage_halo_v3(const GatherIn& g, char* halo, con
         if (from0) base = (const T*)g.src0 + ((((size_t)n * (g.D >> sh) + (pd0 >> sh)) * (g.H >> sh) + (ph0 >> sh)) * (g.W >> sh) + (pw0 >> sh)) * g.c0 + c;
         else base = (const T*)g.src1 + ((((size_t)n * g.D + pd0) * g.H + ph0) * g.W + pw0) * g.c1 + (c - g.c0);
         const int sel = from0 ? 1 : 2;
+        // noise lives on the (D+2np)^3 grid: an interior halo never leaves it
+        const bf16_t* nbase = g.noise ? g.noise + ((((size_t)n * (g.D + 2 * g.npad) + pd0 + g.npad) * (g.H + 2 * g.npad) + ph0 + g.npad) * (g.W + 2 * g.npad) + pw0 + g.npad) * g.Cin + c : nullptr;
         float sc[8], sf[8];
         if (!plain) {
 #pragma unroll
@@ -243,10 +246,14 @@ __device__ __forceinline__ void stage_halo_v3(const GatherIn& g, char* halo, con
         }
         for (int hv0 = vl; hv0 < nvox; hv0 += vstride * UB) {
             Raw8<T> raw[UB];
+            Raw8<bf16_t> nz[UB];
 #pragma unroll
             for (int k = 0; k < UB; ++k) {
                 const int hv = hv0 + k * vstride;
-                if (hv < nvox) raw_load(raw[k], base + vtab[hv * 3 + sel]);
+                if (hv < nvox) {
+                    raw_load(raw[k], base + vtab[hv * 4 + sel]);
+                    if (nbase) raw_load(nz[k], nbase + vtab[hv * 4 + 3]);
+                }
             }
 #pragma unroll
             for (int k = 0; k < UB; ++k) {
@@ -259,6 +266,12 @@ __device__ __forceinline__ void stage_halo_v3(const GatherIn& g, char* halo, con
                         raw_unpack(raw[k], x);
 #pragma unroll
                         for (int j = 0; j < 8; ++j) x[j] = vg_act(x[j] * sc[j] + sf[j], g.act);
+                        if (nbase) {
+                            float z[8];
+                            raw_unpack(nz[k], z);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) x[j] += z[j];
+                        }
                         store8<T>(dst, x);
                     }
                 }
@@ -273,7 +286,7 @@ __device__ __forceinline__ void stage_halo_v3(const GatherIn& g, char* halo, con
     const bool c1mode = g.Cin == 1;
     (void)dst0;
     for (int hv = vl; hv < nvox; hv += vstride) {
-        const int e = vtab[hv * 3];
+        const int e = vtab[hv * 4];
         const int hd = e & 255, hh = (e >> 8) & 255, hw = e >> 16;
         int pd = pd0 + hd, ph = ph0 + hh, pw = pw0 + hw;
         const int qd = pd + g.npad, qh = ph + g.npad, qw = pw + g.npad;

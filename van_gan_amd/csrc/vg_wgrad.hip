@@ -275,7 +275,7 @@ extern "C" int vg_conv3d_wgrad(const vg_conv_desc* d, const void* dy, int dy_f32
                 if (Cinp % c) continue;
                 int rc = fill_gather(d, g, c, bm);
                 if (rc != VG_OK) return rc;
-                const int lds = halo_bytes(g) + bm * (COB * esz + 16) + 512 + 2 * c * 4 + g.HD * g.HH * g.HW * 3 * 4;
+                const int lds = halo_bytes(g) + bm * (COB * esz + 16) + 512 + 2 * c * 4 + g.HD * g.HH * g.HW * 4 * 4;
                 if (lds <= limit) { best_bm = bm; best_cib = c; best_lds = lds; break; }
             }
     }
