@@ -104,6 +104,13 @@ int vg_conv3d_lds_bytes(const vg_conv_desc* d);
  * Cout (data gradient).  tap_idx[i] selects the source tap of packed tap i.  Returns Ktot>0. */
 int vg_pack_weights(const float* w, int T, int Cin, int Cout, const int32_t* tap_idx_dev, int ntaps,
                     int transpose, int CK, void* out, int out_f32, vg_stream_t stream);
+/* Table-driven repack of every packed operand of a network in ONE launch: items_dev is a device array of n
+ * vg_pack_item (all pointers device pointers). */
+typedef struct {
+    const float* w; const int32_t* tap_idx; void* out;
+    int32_t Cin, Cout, ntaps, transpose, CK, out_f32;
+} vg_pack_item;
+int vg_pack_weights_multi(const vg_pack_item* items_dev, int n, vg_stream_t stream);
 int vg_packed_ktot(int ntaps, int C, int CK);
 int vg_packed_rows(int N);
 

@@ -32,6 +32,11 @@ class ConvDesc(C.Structure):
     ]
 
 
+class PackItem(C.Structure):
+    _fields_ = [('w', c_void_p), ('tap_idx', c_void_p), ('out', c_void_p), ('Cin', c_int), ('Cout', c_int), ('ntaps', c_int),
+                ('transpose', c_int), ('CK', c_int), ('out_f32', c_int)]
+
+
 class ActNormBwdDesc(C.Structure):
     _fields_ = [
         ('g', c_void_p), ('g_padded', c_int), ('x', c_void_p), ('x_f32', c_int),
@@ -49,6 +54,7 @@ _SIGS = {
     'vg_conv3d': ([C.POINTER(ConvDesc), c_void_p], c_int),
     'vg_conv3d_lds_bytes': ([C.POINTER(ConvDesc)], c_int),
     'vg_pack_weights': ([c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p], c_int),
+    'vg_pack_weights_multi': ([c_void_p, c_int, c_void_p], c_int),
     'vg_packed_ktot': ([c_int, c_int, c_int], c_int),
     'vg_packed_rows': ([c_int], c_int),
     'vg_conv3d_wgrad': ([C.POINTER(ConvDesc), c_void_p, c_int, C.POINTER(c_int), c_int, c_void_p, c_void_p, c_void_p, c_i64,

@@ -31,7 +31,7 @@ struct ConvOut {
 // sample.  Per workgroup ONCE: tap offsets, the (halo voxel, channel group) unit table, the weight panel (if it fits in
 // LDS); per tile: stage halo (batched global loads), MFMA loop, epilogue; InstanceNorm statistics are carried in
 // registers across tiles and flushed once.
-template <typename T, int BN, int MSUB>
+template <typename T, int BN, int MSUB, bool NOISE>
 __global__ __launch_bounds__(256) void conv_kernel(const GatherIn g, const ConvOut p) {
     constexpr bool F32 = sizeof(T) == 4;
     // wave decomposition: WN waves along the channel panel (one 16-channel sub-tile each, so a weight fragment is
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void conv_kernel(const GatherIn g, const ConvO
         for (int chunk = 0; chunk < p.nchunks; ++chunk) {
             __syncthreads();                       // previous readers of the halo tile are done
             if (p.nchunks > 1) { stage_scale_shift(g, scs, n, chunk, tid); __syncthreads(); }
-            if (!(g.dbg & 1)) stage_halo_v3<T>(g, halo, scs, utab, n, od0, oh0, ow0, chunk, tid);
+            if (!(g.dbg & 1)) stage_halo_v3<T, NOISE>(g, halo, scs, utab, n, od0, oh0, ow0, chunk, tid);
             __syncthreads();
             const size_t kbase = (size_t)chunk * p.kc_pad;
             if (g.dbg & 4) continue;
@@ -267,11 +267,11 @@ extern "C" int vg_conv3d_lds_bytes(const vg_conv_desc* d) {
     return rc == VG_OK ? lds : rc;
 }
 
-template <typename T, int BN, int MSUB>
-static int launch_conv(const GatherIn& g, const ConvOut& k, int lds, hipStream_t s) {
+template <typename T, int BN, int MSUB, bool NOISE>
+static int launch_conv2(const GatherIn& g, const ConvOut& k, int lds, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_kernel<T, BN, MSUB>, hipFuncAttributeMaxDynamicSharedMemorySize, VG_LDS_LIMIT);
+        (void)hipFuncSetAttribute((const void*)conv_kernel<T, BN, MSUB, NOISE>, hipFuncAttributeMaxDynamicSharedMemorySize, VG_LDS_LIMIT);
         attr_set = true;
     }
     static int wg_target = -1;
@@ -280,8 +280,12 @@ static int launch_conv(const GatherIn& g, const ConvOut& k, int lds, hipStream_t
     const int ny = (k.Cout + BN - 1) / BN;
     int bx = wg_target / (ny * g.N); if (bx < 1) bx = 1; if (bx > tiles) bx = tiles;
     dim3 grid(bx, ny, g.N);
-    hipLaunchKernelGGL((conv_kernel<T, BN, MSUB>), grid, dim3(256), lds, s, g, k);
+    hipLaunchKernelGGL((conv_kernel<T, BN, MSUB, NOISE>), grid, dim3(256), lds, s, g, k);
     return vg_check_launch();
+}
+template <typename T, int BN, int MSUB>
+static int launch_conv(const GatherIn& g, const ConvOut& k, int lds, hipStream_t s) {
+    return g.noise ? launch_conv2<T, BN, MSUB, true>(g, k, lds, s) : launch_conv2<T, BN, MSUB, false>(g, k, lds, s);
 }
 template <typename T>
 static int dispatch_conv(const GatherIn& g, const ConvOut& k, int BN, int MSUB, int lds, hipStream_t s) {
@@ -319,6 +323,33 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, int Cin, int Co
         }
         if (out_f32) ((float*)out)[i] = v; else ((bf16_t*)out)[i] = f2bf(v);
     }
+}
+
+__global__ void pack_weights_multi_kernel(const vg_pack_item* __restrict__ items) {
+    const vg_pack_item it = items[blockIdx.y];
+    const int C = it.transpose ? it.Cout : it.Cin, NR = it.transpose ? it.Cin : it.Cout;
+    const int nchunks = (C + it.CK - 1) / it.CK;
+    const int kc_pad = ((it.ntaps * it.CK + 31) / 32) * 32;
+    const int Ktot = nchunks * kc_pad;
+    const int rows_pad = ((NR + 63) / 64) * 64;
+    const size_t total = (size_t)rows_pad * Ktot;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int row = (int)(i / Ktot), k = (int)(i % Ktot);
+        const int chunk = k / kc_pad, kl = k % kc_pad;
+        const int tap = kl / it.CK, ch = chunk * it.CK + kl % it.CK;
+        float v = 0.f;
+        if (row < NR && tap < it.ntaps && ch < C) {
+            const int ts = it.tap_idx[tap];
+            v = it.transpose ? it.w[((size_t)ts * it.Cin + row) * it.Cout + ch] : it.w[((size_t)ts * it.Cin + ch) * it.Cout + row];
+        }
+        if (it.out_f32) ((float*)it.out)[i] = v; else ((bf16_t*)it.out)[i] = f2bf(v);
+    }
+}
+extern "C" int vg_pack_weights_multi(const vg_pack_item* items_dev, int n, vg_stream_t stream) {
+    vg_begin();
+    if (!items_dev || n < 1) return VG_EINVAL;
+    hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(48, n), dim3(256), 0, (hipStream_t)stream, items_dev);
+    return vg_check_launch();
 }
 
 extern "C" int vg_packed_ktot(int ntaps, int C, int CK) {

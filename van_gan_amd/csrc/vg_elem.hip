@@ -113,9 +113,22 @@ __device__ __forceinline__ void load_x(const ANB& p, int n, int d, int h, int w,
     }
 }
 
+// per-thread channel constants (the thread owns channels c..c+VEC-1 of sample n for its whole walk)
+template <int VEC> struct ChanK { float sc[VEC], sh[VEC], mu[VEC], rs[VEC], ml[VEC]; };
+template <int VEC>
+__device__ __forceinline__ void load_chank(const ANB& p, int n, int c, ChanK<VEC>& k) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        const int nc = n * p.C + c + j;
+        k.sc[j] = p.scale ? p.scale[nc] : 1.f; k.sh[j] = p.scale ? p.shift[nc] : 0.f;
+        k.mu[j] = p.norm ? p.mean[nc] : 0.f; k.rs[j] = p.norm ? p.rstd[nc] : 0.f;
+        k.ml[j] = p.mult ? p.mult[nc] : 1.f;
+    }
+}
+
 // dn for VEC channels; also returns xhat when norm
 template <typename T, int VEC>
-__device__ __forceinline__ void compute_dn(const ANB& p, int n, int d, int h, int w, int c, float* dn, float* xh) {
+__device__ __forceinline__ void compute_dn(const ANB& p, const ChanK<VEC>& k, int n, int d, int h, int w, int c, float* dn, float* xh) {
     float g[VEC];
     load_g<T, VEC>(p, n, d, h, w, c, g);
     const bool need_x = p.act != VG_ACT_NONE || p.norm;
@@ -123,15 +136,10 @@ __device__ __forceinline__ void compute_dn(const ANB& p, int n, int d, int h, in
     if (need_x) load_x<T, VEC>(p, n, d, h, w, c, x);
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
-        const int nc = n * p.C + c + j;
-        float v = g[j];
-        if (p.mult) v *= p.mult[nc];
-        if (p.act != VG_ACT_NONE) {
-            const float pre = p.scale ? x[j] * p.scale[nc] + p.shift[nc] : x[j];
-            v *= vg_act_grad(pre, p.act);
-        }
+        float v = g[j] * k.ml[j];
+        if (p.act != VG_ACT_NONE) v *= vg_act_grad(x[j] * k.sc[j] + k.sh[j], p.act);
         dn[j] = v;
-        xh[j] = p.norm ? (x[j] - p.mean[nc]) * p.rstd[nc] : 0.f;
+        xh[j] = p.norm ? (x[j] - k.mu[j]) * k.rs[j] : 0.f;
     }
 }
 
@@ -149,10 +157,13 @@ __global__ __launch_bounds__(256) void actnorm_stats_kernel(const ANB p) {
 #pragma unroll
     for (int j = 0; j < VEC; ++j) { s0[j] = 0.f; s1[j] = 0.f; }
     if (tid < nthr) {
+        ChanK<VEC> ck;
+        load_chank<VEC>(p, n, cg * VEC, ck);
+#pragma unroll 2
         for (int v = blockIdx.x * p.vpb + vl; v < S; v += gridDim.x * p.vpb) {
             const int w = v % p.W; const int t = v / p.W; const int h = t % p.H, d = t / p.H;
             float dn[VEC], xh[VEC];
-            compute_dn<T, VEC>(p, n, d, h, w, cg * VEC, dn, xh);
+            compute_dn<T, VEC>(p, ck, n, d, h, w, cg * VEC, dn, xh);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) { s0[j] += dn[j]; s1[j] += dn[j] * xh[j]; }
         }
@@ -191,10 +202,13 @@ __global__ __launch_bounds__(256) void actnorm_apply_kernel(const ANB p) {
             k0[j] = gr; k1[j] = gr * r0 / (float)S; k2[j] = gr * r1 / (float)S;
         } else { k0[j] = 1.f; k1[j] = 0.f; k2[j] = 0.f; }
     }
+    ChanK<VEC> ck;
+    load_chank<VEC>(p, n, c, ck);
+#pragma unroll 2
     for (int v = blockIdx.x * p.vpb + vl; v < S; v += gridDim.x * p.vpb) {
         const int w = v % p.W; const int t = v / p.W; const int h = t % p.H, d = t / p.H;
         float dn[VEC], xh[VEC], o[VEC];
-        compute_dn<T, VEC>(p, n, d, h, w, c, dn, xh);
+        compute_dn<T, VEC>(p, ck, n, d, h, w, c, dn, xh);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) o[j] = k0[j] * dn[j] - k1[j] - k2[j] * xh[j];
         const size_t oidx = ((size_t)n * S + v) * p.dx_cstride + p.dx_coff + c;

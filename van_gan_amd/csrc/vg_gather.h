@@ -210,7 +210,7 @@ __device__ __forceinline__ void build_voxel_table(const GatherIn& g, int* vtab, 
     }
 }
 
-template <typename T, int UB = 4>
+template <typename T, bool NOISE, int UB = 4>
 __device__ __forceinline__ void stage_halo_v3(const GatherIn& g, char* halo, const float* scs, const int* vtab, int n,
                                               int od0, int oh0, int ow0, int chunk, int tid) {
     const int gpc = g.CK >> 3;
@@ -223,7 +223,7 @@ __device__ __forceinline__ void stage_halo_v3(const GatherIn& g, char* halo, con
     const bool interior = pd0 >= 0 && ph0 >= 0 && pw0 >= 0 && pd0 + g.HD <= g.D && ph0 + g.HH <= g.H && pw0 + g.HW <= g.W;
     const bool tile_even = ((g.tdl > 0) || !(g.istr & 1)) && ((g.thl > 0) || !(g.istr & 1)) && ((g.twl > 0) || !(g.istr & 1));
     const bool fast = interior && g.Cin != 1 && (g.shift0 == 0 || tile_even);
-    const bool plain = !g.in_scale && g.act == VG_ACT_NONE && !g.noise;          // data-gradient operand: pure copy
+    const bool plain = !g.in_scale && g.act == VG_ACT_NONE && !NOISE;          // data-gradient operand: pure copy
     T* dst0 = (T*)halo + cg * 8;
     if (fast) {
         if (c >= g.Cin) {                               // channel padding of the last chunk
@@ -238,7 +238,7 @@ __device__ __forceinline__ void stage_halo_v3(const GatherIn& g, char* halo, con
         else base = (const T*)g.src1 + ((((size_t)n * g.D + pd0) * g.H + ph0) * g.W + pw0) * g.c1 + (c - g.c0);
         const int sel = from0 ? 1 : 2;
         // noise lives on the (D+2np)^3 grid: an interior halo never leaves it
-        const bf16_t* nbase = g.noise ? g.noise + ((((size_t)n * (g.D + 2 * g.npad) + pd0 + g.npad) * (g.H + 2 * g.npad) + ph0 + g.npad) * (g.W + 2 * g.npad) + pw0 + g.npad) * g.Cin + c : nullptr;
+        const bf16_t* nbase = NOISE ? g.noise + ((((size_t)n * (g.D + 2 * g.npad) + pd0 + g.npad) * (g.H + 2 * g.npad) + ph0 + g.npad) * (g.W + 2 * g.npad) + pw0 + g.npad) * g.Cin + c : nullptr;
         float sc[8], sf[8];
         if (!plain) {
 #pragma unroll
@@ -252,7 +252,7 @@ __device__ __forceinline__ void stage_halo_v3(const GatherIn& g, char* halo, con
                 const int hv = hv0 + k * vstride;
                 if (hv < nvox) {
                     raw_load(raw[k], base + vtab[hv * 4 + sel]);
-                    if (nbase) raw_load(nz[k], nbase + vtab[hv * 4 + 3]);
+                    if (NOISE) raw_load(nz[k], nbase + vtab[hv * 4 + 3]);
                 }
             }
 #pragma unroll
@@ -266,7 +266,7 @@ __device__ __forceinline__ void stage_halo_v3(const GatherIn& g, char* halo, con
                         raw_unpack(raw[k], x);
 #pragma unroll
                         for (int j = 0; j < 8; ++j) x[j] = vg_act(x[j] * sc[j] + sf[j], g.act);
-                        if (nbase) {
+                        if (NOISE) {
                             float z[8];
                             raw_unpack(nz[k], z);
 #pragma unroll
@@ -308,7 +308,7 @@ __device__ __forceinline__ void stage_halo_v3(const GatherIn& g, char* halo, con
                 const size_t idx = (((size_t)(n * g.D + pd) * g.H + ph) * g.W + pw) * g.c1 + (c - g.c0);
                 load8<T>((const T*)g.src1 + idx, x);
             }
-            const bool has_noise = g.noise && qd >= 0 && qd < ND && qh >= 0 && qh < NH && qw >= 0 && qw < NW;
+            const bool has_noise = NOISE && g.noise && qd >= 0 && qd < ND && qh >= 0 && qh < NH && qw >= 0 && qw < NW;
             const size_t nidx = has_noise ? ((((size_t)(n * ND + qd) * NH + qh) * NW + qw) * g.Cin + c) : 0;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {

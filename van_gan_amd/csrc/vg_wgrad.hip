@@ -35,7 +35,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* base0, const char* base1) 
     return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
-template <typename T, int RMAX, int Q>
+template <typename T, int RMAX, int Q, bool NOISE>
 __global__ __launch_bounds__(256) void wgrad_kernel(const GatherIn g, const WgradK p) {
     constexpr bool F32 = sizeof(T) == 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const GatherIn g, const Wgra
             cur_n = n;
             __syncthreads();
         }
-        if (!(g.dbg & 1) || tile == (int)blockIdx.x) stage_halo_v3<T>(g, halo, scs, utab, n, od0, oh0, ow0, cib, tid);
+        if (!(g.dbg & 1) || tile == (int)blockIdx.x) stage_halo_v3<T, NOISE>(g, halo, scs, utab, n, od0, oh0, ow0, cib, tid);
         if (!(g.dbg & 2) || tile == (int)blockIdx.x)
         // ---- stage dY tile [BM][16*Q] (zero outside the grid / beyond Cout): all loads first ----
         for (int u0 = tid; u0 < BM * gcol; u0 += 256 * 4) {
@@ -241,14 +241,18 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* part,
     if (w == 0 && i < n) dw[i] += sm[0][lane] + sm[1][lane] + sm[2][lane] + sm[3][lane];
 }
 
-template <typename T, int RMAX, int Q>
-static void launch_wgrad(const GatherIn& g, const WgradK& k, dim3 grid, int lds, hipStream_t s) {
+template <typename T, int RMAX, int Q, bool NOISE>
+static void launch_wgrad2(const GatherIn& g, const WgradK& k, dim3 grid, int lds, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)wgrad_kernel<T, RMAX, Q>, hipFuncAttributeMaxDynamicSharedMemorySize, VG_LDS_LIMIT);
+        (void)hipFuncSetAttribute((const void*)wgrad_kernel<T, RMAX, Q, NOISE>, hipFuncAttributeMaxDynamicSharedMemorySize, VG_LDS_LIMIT);
         attr_set = true;
     }
-    hipLaunchKernelGGL((wgrad_kernel<T, RMAX, Q>), grid, dim3(256), lds, s, g, k);
+    hipLaunchKernelGGL((wgrad_kernel<T, RMAX, Q, NOISE>), grid, dim3(256), lds, s, g, k);
+}
+template <typename T, int RMAX, int Q>
+static void launch_wgrad(const GatherIn& g, const WgradK& k, dim3 grid, int lds, hipStream_t s) {
+    if (g.noise) launch_wgrad2<T, RMAX, Q, true>(g, k, grid, lds, s); else launch_wgrad2<T, RMAX, Q, false>(g, k, grid, lds, s);
 }
 
 extern "C" int vg_conv3d_wgrad(const vg_conv_desc* d, const void* dy, int dy_f32, const int32_t* tap_idx_host,

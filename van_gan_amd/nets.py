@@ -202,8 +202,9 @@ class ResUNet:
         L['out'] = ConvLayer(store, 'out', 1, f[0], 1, 1, 'same', True, lv[0], dtype=self.dtype)
 
     def pack(self):
-        for l in self.L.values():
-            l.pack()
+        if getattr(self, '_ptab', None) is None:
+            self._ptab = ops.PackTable(list(self.L.values()), self.store.w.device)
+        self._ptab.run()
 
     # ---------------------------------------------------------------------------------------------
     def _block_fwd(self, ar: Arena, name: str, N: int, src_raw: Src, nrm_inputs, out_dims, co, ctx):
@@ -387,8 +388,9 @@ class PatchGAN:
         self.Nn = {k: Norm(store, k + '.in', c) for k, c in zip(self.NAMES[:4], self.ch[1:])}
 
     def pack(self):
-        for l in self.L.values():
-            l.pack()
+        if getattr(self, '_ptab', None) is None:
+            self._ptab = ops.PackTable(list(self.L.values()), self.store.w.device)
+        self._ptab.run()
 
     def noise_shapes(self, N: int):
         lv = self.lv

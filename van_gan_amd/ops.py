@@ -59,17 +59,31 @@ WGRAD_SCRATCH = {}     # device -> fp32 scratch for the partial-slab weight-grad
 # workspace arena: deterministic addresses, one allocation per engine
 # ------------------------------------------------------------------------------------------------------
 class Arena:
+    ZPOOL = 8 << 20         # small zero-initialised allocations come from one pool cleared by a single memset per step
+
     def __init__(self, nbytes: int, device):
-        self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        self.buf = torch.empty(nbytes + self.ZPOOL, dtype=torch.uint8, device=device)
+        self.zpool = self.buf[nbytes:]
+        self.buf = self.buf[:nbytes]
         self.off = 0
+        self.zoff = 0
         self.peak = 0
+        self.zpool.zero_()
 
     def reset(self):
         self.off = 0
+        if self.zoff:
+            self.zpool[:self.zoff].zero_()
+        self.zoff = 0
 
     def alloc(self, shape: Sequence[int], dtype: torch.dtype, zero: bool = False) -> torch.Tensor:
         n = int(math.prod(shape))
         nbytes = n * torch.empty((), dtype=dtype).element_size()
+        if zero and nbytes <= 65536:
+            zs = (self.zoff + 255) // 256 * 256
+            if zs + nbytes <= self.ZPOOL:
+                self.zoff = zs + nbytes
+                return self.zpool[zs:zs + nbytes].view(dtype).view(*shape)
         start = (self.off + 255) // 256 * 256
         if start + nbytes > self.buf.numel():
             raise MemoryError('arena exhausted: need %d more bytes' % (start + nbytes - self.buf.numel()))
@@ -215,6 +229,14 @@ class ConvLayer:
             raise _lib.VgError('no LDS-feasible tile for %s' % self.name)
         return best
 
+    def pack_items(self):
+        """(w, tap_idx, out, Cin, Cout, ntaps, transpose, CK, f32) of every packed operand, for PackTable."""
+        T = self.k ** 3
+        items = [(self.w, self.f_idx, self.f_wp, self.cin, self.cout, T, 0, self.f_ck, self.f32)]
+        for c in self.d_classes:
+            items.append((self.w, c['idx'], c['wp'], self.cin, self.cout, len(c['taps']), 1, c['ck'], self.f32))
+        return items
+
     def pack(self):
         """fp32 master weights -> bf16 packed operands (after every optimizer step)."""
         T = self.k ** 3
@@ -284,6 +306,24 @@ class ConvLayer:
             check(lib.vg_conv3d(C.byref(d), stream()), 'vg_conv3d(dgrad) ' + self.name)
             if e0 is not None:      # algorithmic FLOPs of this parity class: its taps only
                 PROF.end('conv_dgrad', 2.0 * N * math.prod(c['iters']) * self.cin * self.cout * len(c['taps']), e0)
+
+
+class PackTable:
+    """All packed operands of a network repacked by ONE kernel launch (vg_pack_weights_multi)."""
+
+    def __init__(self, layers, device):
+        items = [it for l in layers for it in l.pack_items()]
+        arr = (_lib.PackItem * len(items))()
+        for a, (w, idx, out, cin, cout, ntaps, tr, ck, f32) in zip(arr, items):
+            a.w, a.tap_idx, a.out = w.data_ptr(), idx.data_ptr(), out.data_ptr()
+            a.Cin, a.Cout, a.ntaps, a.transpose, a.CK, a.out_f32 = cin, cout, ntaps, tr, ck, f32
+        raw = bytes(arr)
+        self.keep = items
+        self.n = len(items)
+        self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+
+    def run(self):
+        check(lib.vg_pack_weights_multi(_p(self.table), self.n, stream()), 'vg_pack_weights_multi')
 
 
 # ------------------------------------------------------------------------------------------------------
