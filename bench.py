@@ -57,6 +57,31 @@ def cpu_baseline(budget_s=12.0):
                       '32x32x32 batch 1, %d steps in %.1f s on %d host threads' % (n, el, torch.get_num_threads())}
 
 
+def bench_infer(args, device):
+    """Config 5: one 256x256x128 volume, 128^3 windows, stride 50, symmetric pad 0.1, 10 % border crop
+    (post_training.py:38-39; custom_callback.py:47-223): 50 windows, bf16 generator, overlap-add on the GPU."""
+    import torch
+    from van_gan_amd import VanGan
+    eng = VanGan((128, 128, 128), batch_size=2, device=device, seed=0)
+    vol = (torch.rand(256, 256, 128, 1, generator=torch.Generator().manual_seed(1)) * 2 - 1).to(device)
+    kw = dict(stride=(50, 50, 50), complete=True, padFactor=0.1, process_img=True, window_batch=2)
+    for _ in range(max(args.warmup, 1)):
+        eng.stitch_subvolumes('gen_IS', vol, (128, 128, 128), **kw)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = eng.stitch_subvolumes('gen_IS', vol, (128, 128, 128), **kw)
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / args.steps
+    print(json.dumps({'metric': 'sliding-window inference Mvoxels/s (256x256x128 volume, 50 windows of 128^3, bf16)',
+                      'value': 256 * 256 * 128 / el / 1e6, 'unit': 'Mvoxels/s', 'volumes_per_sec': 1.0 / el, 'n_gpus': 1,
+                      'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': el * 1e3, 'higher_is_better': True,
+                      'dtype': 'bf16', 'data': 'synthetic', 'windows': 50,
+                      'generator_tflops': 50 * 2 * 149.65e9 / el / 1e12,
+                      'config': {'workload': 'GanMonitor.stitch_subvolumes 256x256x128, 128^3 windows, stride 50, pad 0.1'},
+                      'finite': bool(torch.isfinite(out).all())}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -66,6 +91,7 @@ def main():
     ap.add_argument('--batch', type=int, default=1, help='per-GPU batch')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--infer', action='store_true', help='BASELINE config 5 instead: 256x256x128 sliding-window generator inference')
     args = ap.parse_args()
 
     import torch
@@ -86,6 +112,8 @@ def main():
         pg = dist.group.WORLD
 
     from van_gan_amd import VanGan, ops
+    if args.infer:
+        return bench_infer(args, device)
     dims = (args.size,) * 3
     B = args.batch
     eng = VanGan(dims, batch_size=B, n_devices=world, device=device, seed=0, process_group=pg)

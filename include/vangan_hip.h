@@ -215,6 +215,14 @@ int vg_dot_sums(const float* a, const float* b, int64_t n, float* sums3, vg_stre
 int vg_axpby(const float* a, float alpha, const float* b, float beta, int64_t n, float* y, int accumulate,
              vg_stream_t stream);
 
+/* Sliding-window inference (GanMonitor.stitch_subvolumes, custom_callback.py:47-223): pred/cnt [X][Y][Z] fp32.
+ * vg_overlap_add: pred[box] += window[crop], cnt[box] += 1 for the border-cropped box of one k^3 window at (x0,y0,z0)
+ * (custom_callback.py:165-183); vg_divide_crop: out = pred/cnt on the un-padded sub-box (:192-200; 0/0 = NaN as numpy). */
+int vg_overlap_add(const float* win, int kx, int ky, int kz, int px, int py, int pz, int x0, int y0, int z0,
+                   int X, int Y, int Z, float* pred, float* cnt, vg_stream_t stream);
+int vg_divide_crop(const float* pred, const float* cnt, int X, int Y, int Z, int sx, int sy, int sz, int ox, int oy,
+                   int oz, float* out, vg_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Multi-tensor Adam with per-tensor clip-by-norm (tf.keras.optimizers.Adam(2e-4, 0.5, 0.9,
  * clipnorm=100), vangan.py:220-235, applied by optimizer.minimize at vangan.py:426-438).

@@ -1,0 +1,42 @@
+"""Sliding-window inference (SURVEY 8 a26 / BASELINE config 5): GPU stitch vs the numpy restatement of
+GanMonitor.stitch_subvolumes driven by the oracle generator.  fp32 storage mode => tolerance 0.05 on the 0..255 output."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import stitch_oracle as S  # noqa: E402
+from oracle import vangan_oracle as O  # noqa: E402
+
+
+@pytest.mark.parametrize('process_img', [False, True])
+def test_stitch_subvolumes_matches_oracle(process_img):
+    from van_gan_amd import VanGan
+    k = (32, 32, 32)
+    eng = VanGan(k, batch_size=4, device='cuda:0', seed=5, precision='fp32')
+    P = eng.export_weights()['gen_IS']
+    g = torch.Generator().manual_seed(3)
+    vol = torch.rand(56, 48, 40, 1, generator=g) * 2 - 1
+
+    def gen(a):
+        with torch.no_grad():
+            return O.resunet_forward(P, torch.from_numpy(np.ascontiguousarray(a)).float()).numpy()
+
+    ref = S.stitch_subvolumes(gen, vol.numpy(), (1,) + k + (1,), stride=(20, 20, 16), complete=True, padFactor=0.25,
+                              process_img=process_img)
+    got = eng.stitch_subvolumes('gen_IS', vol, k, stride=(20, 20, 16), complete=True, padFactor=0.25,
+                                process_img=process_img, window_batch=3).cpu().numpy()
+    assert got.shape == ref.shape == (56, 48, 40, 1)
+    assert not np.isnan(ref).any()
+    err = np.abs(got - ref).max()
+    print('stitch max abs err (0..255 scale): %.4f' % err)
+    assert err < 0.05
+
+
+def test_window_origins_follow_reference_loop():
+    from van_gan_amd.inference import window_origins
+    # 256x256x128 volume, padFactor 0.1, stride 50 (post_training.py:38-39): 306x306x152 padded -> 5 x 5 x 2 windows
+    assert window_origins(306, 128, 50) == [0, 50, 100, 150, 178] and window_origins(152, 128, 50) == [0, 24]
+    # clamped duplicates are kept (they are counted twice by pix_tracker, as in the reference)
+    assert window_origins(128, 128, 25) == [0, 0]

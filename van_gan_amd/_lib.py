@@ -79,6 +79,8 @@ _SIGS = {
     'vg_cldice_coef': ([c_void_p, c_float, c_float, c_void_p, c_void_p], c_int),
     'vg_cldice_grads': ([c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_int, c_void_p], c_int),
     'vg_dot_sums': ([c_void_p, c_void_p, c_i64, c_void_p, c_void_p], c_int),
+    'vg_overlap_add': ([c_void_p] + [c_int] * 12 + [c_void_p, c_void_p, c_void_p], c_int),
+    'vg_divide_crop': ([c_void_p, c_void_p] + [c_int] * 9 + [c_void_p, c_void_p], c_int),
     'vg_axpby': ([c_void_p, c_float, c_void_p, c_float, c_i64, c_void_p, c_int, c_void_p], c_int),
     'vg_adam_clip': ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_i64, c_void_p, c_float, c_float,
                       c_float, c_float, c_float, c_float, c_void_p], c_int),

@@ -437,3 +437,48 @@ extern "C" int vg_cldice_grads(const float* t, const float* skel_t, const float*
     hipLaunchKernelGGL(cldice_grads_kernel, dim3(lblocks(n)), dim3(256), 0, (hipStream_t)stream, t, skel_t, coef6, n, gskel_p, gp, accumulate);
     return vg_check_launch();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Sliding-window inference (custom_callback.py:47-223, stitch_subvolumes): overlap-add of border-cropped window
+// predictions with a coverage counter, then division.  Volumes are [X][Y][Z] fp32 (single channel).
+// ------------------------------------------------------------------------------------------------
+__global__ void overlap_add_kernel(const float* win, int kx, int ky, int kz, int px, int py, int pz, int x0, int y0, int z0,
+                                   int Y, int Z, float* pred, float* cnt) {
+    const int cx = kx - 2 * px, cy = ky - 2 * py, cz = kz - 2 * pz;
+    const int64_t total = (int64_t)cx * cy * cz;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int z = (int)(i % cz); int64_t r = i / cz; const int y = (int)(r % cy); const int x = (int)(r / cy);
+        const float v = win[((size_t)(x + px) * ky + (y + py)) * kz + (z + pz)];
+        const size_t o = ((size_t)(x0 + px + x) * Y + (y0 + py + y)) * Z + (z0 + pz + z);
+        pred[o] += v;                 // windows of one call are added by successive launches on one stream: no race
+        cnt[o] += 1.f;
+    }
+}
+extern "C" int vg_overlap_add(const float* win, int kx, int ky, int kz, int px, int py, int pz, int x0, int y0, int z0,
+                              int X, int Y, int Z, float* pred, float* cnt, vg_stream_t stream) {
+    vg_begin();
+    if (!win || !pred || !cnt || kx - 2 * px < 1 || ky - 2 * py < 1 || kz - 2 * pz < 1) return VG_EINVAL;
+    if (x0 < 0 || y0 < 0 || z0 < 0 || x0 + kx > X || y0 + ky > Y || z0 + kz > Z) return VG_EINVAL;
+    const int64_t total = (int64_t)(kx - 2 * px) * (ky - 2 * py) * (kz - 2 * pz);
+    hipLaunchKernelGGL(overlap_add_kernel, dim3(lblocks(total)), dim3(256), 0, (hipStream_t)stream, win, kx, ky, kz, px, py, pz,
+                       x0, y0, z0, Y, Z, pred, cnt);
+    return vg_check_launch();
+}
+// out[x][y][z] = pred/cnt on the un-padded sub-box (np.true_divide: 0/0 -> NaN, as the reference)
+__global__ void divide_crop_kernel(const float* pred, const float* cnt, int Y, int Z, int sx, int sy, int sz, int ox, int oy, int oz,
+                                   float* out) {
+    const int64_t total = (int64_t)ox * oy * oz;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int z = (int)(i % oz); int64_t r = i / oz; const int y = (int)(r % oy); const int x = (int)(r / oy);
+        const size_t o = ((size_t)(x + sx) * Y + (y + sy)) * Z + (z + sz);
+        out[i] = pred[o] / cnt[o];
+    }
+}
+extern "C" int vg_divide_crop(const float* pred, const float* cnt, int X, int Y, int Z, int sx, int sy, int sz, int ox, int oy,
+                              int oz, float* out, vg_stream_t stream) {
+    vg_begin();
+    if (!pred || !cnt || !out || sx + ox > X || sy + oy > Y || sz + oz > Z || ox < 1 || oy < 1 || oz < 1) return VG_EINVAL;
+    hipLaunchKernelGGL(divide_crop_kernel, dim3(lblocks((int64_t)ox * oy * oz)), dim3(256), 0, (hipStream_t)stream, pred, cnt, Y, Z,
+                       sx, sy, sz, ox, oy, oz, out);
+    return vg_check_launch();
+}

@@ -276,6 +276,11 @@ class VanGan:
         self.sync.broadcast_weights(src)
         self.repack()
 
+    def stitch_subvolumes(self, gen: str, img, subvol_size=None, **kw):
+        """GanMonitor.stitch_subvolumes (custom_callback.py:47-223) on the GPU; see van_gan_amd/inference.py."""
+        from .inference import stitch_subvolumes as _st
+        return _st(self, gen, img, tuple(subvol_size) if subvol_size is not None else self.dims, **kw)
+
     # ------------------------------------------------------------------------------------------------
     def save_checkpoint(self, epoch: int):
         """vangan.py:247-250 (own format: the TF tensor-bundle format is not readable without TF)."""
