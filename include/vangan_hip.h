@@ -41,6 +41,8 @@ typedef void* vg_stream_t;          /* hipStream_t */
 #define VG_STRIPES 8
 
 const char* vg_status_string(int code);
+/* diagnostic builds only: device buffer receiving s_memtime stamps of the conv kernel phases (NULL = off) */
+int vg_set_stamp_buffer(void* dev_u64);
 int vg_version(void);
 
 /* ---------------------------------------------------------------------------------------------

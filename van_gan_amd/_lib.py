@@ -51,6 +51,7 @@ class ActNormBwdDesc(C.Structure):
 
 _SIGS = {
     'vg_version': ([], c_int),
+    'vg_set_stamp_buffer': ([c_void_p], c_int),
     'vg_conv3d': ([C.POINTER(ConvDesc), c_void_p], c_int),
     'vg_conv3d_lds_bytes': ([C.POINTER(ConvDesc)], c_int),
     'vg_pack_weights': ([c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p], c_int),

@@ -18,6 +18,10 @@
 //   the stored values (for the next InstanceNorm), store or accumulate.
 #include "vg_gather.h"
 
+unsigned long long* g_vg_stamps = nullptr;
+extern "C" int vg_set_stamp_buffer(void* p) { g_vg_stamps = (unsigned long long*)p; return VG_OK; }
+#define VG_STAMP(slot) do { if (g.stamps && tid == 0 && it < 8) g.stamps[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 64 + it * 8 + (slot)] = __builtin_readcyclecounter(); } while (0)
+
 struct ConvOut {
     int OD, OH, OW, ostr, ood, ooh, oow, BD, BH, BW, Cout;
     const void* wp; int Ktot, nchunks, kc_pad;
@@ -50,13 +54,22 @@ __global__ __launch_bounds__(256) void conv_kernel(const GatherIn g, const ConvO
     float* stat = scs + 2 * g.CK;
     int* utab = (int*)(stat + BN * 2);
     const int nunits = g.HD * g.HH * g.HW * 4;
-    char* wlds = (char*)(utab + nunits);
+    const int gpc = g.CK >> 3;
+    const int ngroups = g.ntaps * gpc;
+    const int ksteps = (ngroups + 3) >> 2;
+    int* koff = utab + nunits;                       // byte offset of the B fragment of (K-step, lane>>4) inside the halo tile
+    char* wlds = (char*)(koff + ksteps * 4);
     wlds = (char*)(((size_t)wlds + 15) & ~(size_t)15);
 
     if (tid < g.ntaps)
         tapoff[tid] = (((g.td[tid] - g.tmin_d) * g.HH + (g.th[tid] - g.tmin_h)) * g.HW + (g.tw[tid] - g.tmin_w)) * g.RS;
     if (tid < BN * 2) stat[tid] = 0.f;
     build_voxel_table(g, utab, tid, 256);
+    for (int i = tid; i < ksteps * 4; i += 256) {
+        int G = i; if (G >= ngroups) G = ngroups - 1;                       // padded K: weights are zero there
+        const int tp = G / gpc, cgq = G - tp * gpc;
+        koff[i] = (((g.td[tp] - g.tmin_d) * g.HH + (g.th[tp] - g.tmin_h)) * g.HW + (g.tw[tp] - g.tmin_w)) * g.RS + cgq * 16;
+    }
     if (p.w_lds) {          // weight panel -> LDS, 16 B per thread per step
         const int per_row = (p.Ktot * (int)sizeof(T)) >> 4;
         for (int u = tid; u < BN * per_row; u += 256) {
@@ -73,9 +86,6 @@ __global__ __launch_bounds__(256) void conv_kernel(const GatherIn g, const ConvO
         const int w = m & TWm, h = (m >> g.twl) & THm, d = m >> (g.twl + g.thl);
         rowbase[i] = ((d * g.istr * g.HH + h * g.istr) * g.HW + w * g.istr) * g.RS;
     }
-    const int gpc = g.CK >> 3;
-    const int ngroups = g.ntaps * gpc;
-    const int ksteps = (ngroups + 3) >> 2;
     // weight fragment source: LDS panel or global (L2) rows
     const T* wrow;
     if (p.w_lds) wrow = (const T*)(wlds + (size_t)(wave_n * 16 + (lane & 15)) * p.WRS) + (F32 ? 1 : 8) * (lane >> 4);
@@ -83,11 +93,24 @@ __global__ __launch_bounds__(256) void conv_kernel(const GatherIn g, const ConvO
     float s1[4], s2[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
+    // per-lane epilogue constants: this lane always produces channels co0..co0+3
+    const int co0 = ntile * BN + wave_n * 16 + 4 * (lane >> 4);
+    float e_bias[4], e_rs[4], e_rb[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int co = co0 + r;
+        e_bias[r] = (p.bias && co < p.Cout) ? p.bias[co] : 0.f;
+        e_rs[r] = (p.res && co < p.Cout) ? p.rs[n * p.Cout + co] : 0.f;
+        e_rb[r] = (p.res && co < p.Cout) ? p.rb[n * p.Cout + co] : 0.f;
+    }
     if (p.nchunks == 1) stage_scale_shift(g, scs, n, 0, tid);
     __syncthreads();
 
     const int tiles_per_n = g.tiles_d * g.tiles_h * g.tiles_w;
+    int it = -1;
     for (int tile = blockIdx.x; tile < tiles_per_n; tile += gridDim.x) {
+        ++it;
+        VG_STAMP(0);
         int t = tile;
         const int tw_i = t % g.tiles_w; t /= g.tiles_w;
         const int th_i = t % g.tiles_h; const int td_i = t / g.tiles_h;
@@ -100,7 +123,9 @@ __global__ __launch_bounds__(256) void conv_kernel(const GatherIn g, const ConvO
             __syncthreads();                       // previous readers of the halo tile are done
             if (p.nchunks > 1) { stage_scale_shift(g, scs, n, chunk, tid); __syncthreads(); }
             if (!(g.dbg & 1)) stage_halo_v3<T, NOISE>(g, halo, scs, utab, n, od0, oh0, ow0, chunk, tid);
+            if (chunk == 0) VG_STAMP(1);
             __syncthreads();
+            if (chunk == 0) VG_STAMP(2);
             const size_t kbase = (size_t)chunk * p.kc_pad;
             if (g.dbg & 4) continue;
             if constexpr (F32) {
@@ -119,26 +144,37 @@ __global__ __launch_bounds__(256) void conv_kernel(const GatherIn g, const ConvO
                     if (ch0 >= g.CK) { ch0 = 0; ++tap; }
                 }
             } else {
-                // ---- MFMA over (tap, channel-group) pairs of this chunk ----
-                int tap = 0, cg = lane >> 4;
-                while (cg >= gpc) { cg -= gpc; ++tap; }
-                for (int s = 0; s < ksteps; ++s) {
-                    const int tp = tap < g.ntaps ? tap : g.ntaps - 1;      // padded K: weights are zero there
-                    const int off = tapoff[tp] + cg * 16;
-                    bf16x8 b[MW];
+                // ---- MFMA over (tap, channel-group) pairs of this chunk: K-steps are processed KU at a time, all their
+                // operand fetches (offset table, weight fragments, halo fragments) issued before the first MFMA ----
+                constexpr int KU = MW >= 8 ? 2 : 4;
+                const int kg = lane >> 4;
+                for (int s0 = 0; s0 < ksteps; s0 += KU) {
+                    int off[KU];
+                    bf16x8 a[KU];
 #pragma unroll
-                    for (int i = 0; i < MW; ++i) b[i] = *(const bf16x8*)(halo + rowbase[i] + off);
-                    const bf16x8 a = *(const bf16x8*)((const bf16_t*)wrow + kbase + s * 32);
+                    for (int u = 0; u < KU; ++u) {
+                        const int su = s0 + u < ksteps ? s0 + u : ksteps - 1;
+                        off[u] = koff[su * 4 + kg];
+                        a[u] = *(const bf16x8*)((const bf16_t*)wrow + kbase + su * 32);
+                    }
+                    bf16x8 b[KU][MW];
 #pragma unroll
-                    for (int i = 0; i < MW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[i], acc[i], 0, 0, 0);
-                    cg += 4;
-                    while (cg >= gpc) { cg -= gpc; ++tap; }
+                    for (int u = 0; u < KU; ++u)
+#pragma unroll
+                        for (int i = 0; i < MW; ++i) b[u][i] = *(const bf16x8*)(halo + rowbase[i] + off[u]);
+#pragma unroll
+                    for (int u = 0; u < KU; ++u) {
+                        if (s0 + u < ksteps) {
+#pragma unroll
+                            for (int i = 0; i < MW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u], b[u][i], acc[i], 0, 0, 0);
+                        }
+                    }
                 }
             }
         }
+        VG_STAMP(3);
         if (g.dbg & 8) continue;
         // ---- epilogue: lane holds out channels co0..co0+3 of voxel (lane&15) of each of the wave's sub-tiles ----
-        const int co0 = ntile * BN + wave_n * 16 + 4 * (lane >> 4);
 #pragma unroll
         for (int i = 0; i < MW; ++i) {
             const int m = (wave_m * MW + i) * 16 + (lane & 15);
@@ -154,8 +190,8 @@ __global__ __launch_bounds__(256) void conv_kernel(const GatherIn g, const ConvO
                 const int co = co0 + r;
                 float y = acc[i][r];
                 if (co < p.Cout) {
-                    if (p.bias) y += p.bias[co];
-                    if (p.res) y += ld1<T>((const T*)p.res + idx + r) * p.rs[n * p.Cout + co] + p.rb[n * p.Cout + co];
+                    y += e_bias[r];
+                    if (p.res) y += ld1<T>((const T*)p.res + idx + r) * e_rs[r] + e_rb[r];
                     if (p.tanh_out) y = tanhf(y);
                     if (p.accumulate) y += p.out_f32 ? ((float*)p.out)[idx + r] : bf2f(((bf16_t*)p.out)[idx + r]);
                     if (!p.out_f32) y = bfround(y);
@@ -175,6 +211,7 @@ __global__ __launch_bounds__(256) void conv_kernel(const GatherIn g, const ConvO
                 } else { for (int r = 0; r < 4; ++r) if (co0 + r < p.Cout) o[r] = f2bf(v[r]); }
             }
         }
+        VG_STAMP(4);
     }
     if (p.sums) {
 #pragma unroll
@@ -202,7 +239,8 @@ __global__ __launch_bounds__(256) void conv_kernel(const GatherIn g, const ConvO
 // ------------------------------------------------------------------------------------------------
 static int conv_lds_bytes(const GatherIn& g, int BN, int CK, int wbytes) {
     const int nunits = g.HD * g.HH * g.HW * 4;
-    return halo_bytes(g) + 256 + 2 * CK * 4 + BN * 2 * 4 + nunits * 4 + 16 + wbytes;
+    const int ksteps = (g.ntaps * (CK >> 3) + 3) >> 2;
+    return halo_bytes(g) + 256 + 2 * CK * 4 + BN * 2 * 4 + nunits * 4 + ksteps * 16 + 16 + wbytes;
 }
 
 static int fill_conv(const vg_conv_desc* d, GatherIn& g, ConvOut& k, int& BN, int& MSUB, int& lds) {

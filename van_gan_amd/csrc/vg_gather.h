@@ -17,7 +17,10 @@ struct GatherIn {
     int tdl, thl, twl, tiles_d, tiles_h, tiles_w;
     int f32;        // storage type of multi-channel tensors / LDS tile: 0 bf16, 1 f32
     int dbg;        // development ablation flags (VG_DEBUG env): 1 skip halo staging, 2 skip dY staging, 4 skip MFMA
+    unsigned long long* stamps;   // diagnostic build only (vg_set_stamp_buffer): s_memtime stamps per phase, else NULL
 };
+
+extern unsigned long long* g_vg_stamps;
 
 __device__ __forceinline__ bool resolve_pos(int& p, int n, int mode) {
     if (mode == VG_PAD_REFLECT) {
@@ -328,6 +331,7 @@ static inline int fill_gather(const vg_conv_desc* d, GatherIn& g, int CK, int BM
     if (!d || !d->src0) return VG_EINVAL;
     g.f32 = d->f32 ? 1 : 0;
     { static int dbg = -1; if (dbg < 0) { const char* e = getenv("VG_DEBUG"); dbg = e ? atoi(e) : 0; } g.dbg = dbg; }
+    g.stamps = g_vg_stamps;
     const int Cin = d->c_src0 + d->c_src1;
     if (Cin < 1 || d->ntaps < 1 || d->ntaps > VG_MAX_TAPS) return VG_EINVAL;
     if (Cin != 1 && ((d->c_src0 % 8) || (d->c_src1 % 8))) return VG_EINVAL;
