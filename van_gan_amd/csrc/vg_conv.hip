@@ -53,7 +53,8 @@ __global__ __launch_bounds__(256) void conv_kernel(const GatherIn g, const ConvO
     float* scs = (float*)(smem + hbytes + 256);
     float* stat = scs + 2 * g.CK;
     int* utab = (int*)(stat + BN * 2);
-    const int nunits = g.HD * g.HH * g.HW * 4;
+    const int nunits = g.HD * g.HH * g.HW + g.HD + g.HH + g.HW;      // voxel table + per-tile resolved axis tables
+    int* rtab = utab + g.HD * g.HH * g.HW;
     const int gpc = g.CK >> 3;
     const int ngroups = g.ntaps * gpc;
     const int ksteps = (ngroups + 3) >> 2;
@@ -121,8 +122,10 @@ __global__ __launch_bounds__(256) void conv_kernel(const GatherIn g, const ConvO
 
         for (int chunk = 0; chunk < p.nchunks; ++chunk) {
             __syncthreads();                       // previous readers of the halo tile are done
-            if (p.nchunks > 1) { stage_scale_shift(g, scs, n, chunk, tid); __syncthreads(); }
-            if (!(g.dbg & 1)) stage_halo_v3<T, NOISE>(g, halo, scs, utab, n, od0, oh0, ow0, chunk, tid);
+            if (p.nchunks > 1) stage_scale_shift(g, scs, n, chunk, tid);
+            if (chunk == 0) stage_resolve_axes(g, rtab, od0, oh0, ow0, tid);
+            if (p.nchunks > 1 || chunk == 0) __syncthreads();
+            if (!(g.dbg & 1)) stage_halo_tile<T, NOISE>(g, halo, scs, utab, rtab, n, od0, oh0, ow0, chunk, tid);
             if (chunk == 0) VG_STAMP(1);
             __syncthreads();
             if (chunk == 0) VG_STAMP(2);
@@ -238,7 +241,7 @@ __global__ __launch_bounds__(256) void conv_kernel(const GatherIn g, const ConvO
 // host side
 // ------------------------------------------------------------------------------------------------
 static int conv_lds_bytes(const GatherIn& g, int BN, int CK, int wbytes) {
-    const int nunits = g.HD * g.HH * g.HW * 4;
+    const int nunits = g.HD * g.HH * g.HW + g.HD + g.HH + g.HW;
     const int ksteps = (g.ntaps * (CK >> 3) + 3) >> 2;
     return halo_bytes(g) + 256 + 2 * CK * 4 + BN * 2 * 4 + nunits * 4 + ksteps * 16 + 16 + wbytes;
 }

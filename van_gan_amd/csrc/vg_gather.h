@@ -42,69 +42,6 @@ __device__ __forceinline__ void stage_scale_shift(const GatherIn& g, float* scs,
     }
 }
 
-// Stage the halo tile whose output-tile origin is (od0,oh0,ow0): units of (halo voxel, 8 channels) = 16 B.
-template <typename T>
-__device__ __forceinline__ void stage_halo(const GatherIn& g, char* halo, const float* scs, int n, int od0, int oh0,
-                                           int ow0, int chunk, int tid, int nthreads) {
-    const int gpc = g.CK >> 3;
-    const int units = g.HD * g.HH * g.HW * gpc;
-    const int Ds = g.D >> g.shift0, Hs = g.H >> g.shift0, Ws = g.W >> g.shift0;
-    const int ND = g.D + 2 * g.npad, NH = g.H + 2 * g.npad, NW = g.W + 2 * g.npad;
-    for (int u = tid; u < units; u += nthreads) {
-        const int hv = u / gpc, cg = u - hv * gpc;
-        const int hw = hv % g.HW; const int t2 = hv / g.HW;
-        const int hh = t2 % g.HH, hd = t2 / g.HH;
-        int pd = od0 * g.istr + g.tmin_d + hd, ph = oh0 * g.istr + g.tmin_h + hh, pw = ow0 * g.istr + g.tmin_w + hw;
-        const int qd = pd + g.npad, qh = ph + g.npad, qw = pw + g.npad;        // position on the noise grid
-        bool valid = resolve_pos(pd, g.D, g.pad_mode);
-        valid &= resolve_pos(ph, g.H, g.pad_mode);
-        valid &= resolve_pos(pw, g.W, g.pad_mode);
-        const int c = chunk * g.CK + cg * 8;
-        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (valid && c < g.Cin) {
-            float x[8];
-            int nval = 8;
-            if (g.Cin == 1) {
-                nval = 1;
-                const size_t idx = ((size_t)(n * g.D + pd) * g.H + ph) * g.W + pw;
-                x[0] = g.src_f32 ? ((const float*)g.src0)[idx] : bf2f(((const bf16_t*)g.src0)[idx]);
-            } else {
-                if (c < g.c0) {
-                    const size_t idx = (((size_t)(n * Ds + (pd >> g.shift0)) * Hs + (ph >> g.shift0)) * Ws + (pw >> g.shift0)) * g.c0 + c;
-                    load8<T>((const T*)g.src0 + idx, x);
-                } else {
-                    const size_t idx = (((size_t)(n * g.D + pd) * g.H + ph) * g.W + pw) * g.c1 + (c - g.c0);
-                    load8<T>((const T*)g.src1 + idx, x);
-                }
-            }
-            const bool has_noise = g.noise && qd >= 0 && qd < ND && qh >= 0 && qh < NH && qw >= 0 && qw < NW;
-            const size_t nidx = has_noise ? ((((size_t)(n * ND + qd) * NH + qh) * NW + qw) * g.Cin + c) : 0;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                if (j < nval) {
-                    float y = vg_act(x[j] * scs[cg * 8 + j] + scs[g.CK + cg * 8 + j], g.act);
-                    if (has_noise) y += bf2f(g.noise[nidx + j]);
-                    v[j] = y;
-                }
-            }
-        }
-        store8<T>((T*)(halo + (size_t)hv * g.RS) + cg * 8, v);
-    }
-}
-
-// Unit table: the (halo voxel, channel group) decomposition of a tile is the same for every tile, so a persistent
-// workgroup computes it once (no integer divisions in the per-tile loop).  utab[u] = hd | hh<<8 | hw<<16 | cg<<24.
-__device__ __forceinline__ void build_unit_table(const GatherIn& g, int* utab, int tid, int nthreads) {
-    const int gpc = g.CK >> 3;
-    const int units = g.HD * g.HH * g.HW * gpc;
-    for (int u = tid; u < units; u += nthreads) {
-        const int hv = u / gpc, cg = u - hv * gpc;
-        const int hw = hv % g.HW; const int t2 = hv / g.HW;
-        const int hh = t2 % g.HH, hd = t2 / g.HH;
-        utab[u] = hd | (hh << 8) | (hw << 16) | (cg << 24);
-    }
-}
-
 // raw 8-channel vector as loaded from global memory
 template <typename T> struct Raw8;
 template <> struct Raw8<bf16_t> { bf16x8 v; };
@@ -119,210 +56,131 @@ __device__ __forceinline__ void raw_unpack(const Raw8<float>& r, float* o) {
     o[0] = r.a[0]; o[1] = r.a[1]; o[2] = r.a[2]; o[3] = r.a[3]; o[4] = r.b[0]; o[5] = r.b[1]; o[6] = r.b[2]; o[7] = r.b[3];
 }
 
-// Table-driven staging, UB units per thread per batch: all global loads of a batch are issued before the first one is
-// consumed (the per-unit load->wait->transform chain of the simple loop exposes one HBM latency per unit).
-template <typename T, int UB = 4>
-__device__ __forceinline__ void stage_halo_tab(const GatherIn& g, char* halo, const float* scs, const int* utab, int n,
-                                               int od0, int oh0, int ow0, int chunk, int tid, int nthreads) {
-    const int gpc = g.CK >> 3;
-    const int units = g.HD * g.HH * g.HW * gpc;
-    const int Ds = g.D >> g.shift0, Hs = g.H >> g.shift0, Ws = g.W >> g.shift0;
-    const int ND = g.D + 2 * g.npad, NH = g.H + 2 * g.npad, NW = g.W + 2 * g.npad;
-    const int bd = od0 * g.istr + g.tmin_d, bh = oh0 * g.istr + g.tmin_h, bw = ow0 * g.istr + g.tmin_w;
-    const bool c1mode = g.Cin == 1;
-    for (int u0 = tid; u0 < units; u0 += nthreads * UB) {
-        Raw8<T> raw[UB];
-        float x1[UB];
-        int meta[UB];              // LDS element offset (in 8-channel groups) | flags
-        bool ok[UB];
-        size_t nidx[UB];
-#pragma unroll
-        for (int k = 0; k < UB; ++k) {
-            const int u = u0 + k * nthreads;
-            ok[k] = false; meta[k] = -1; nidx[k] = ~(size_t)0; x1[k] = 0.f;
-            if (u < units) {
-                const int e = utab[u];
-                const int hd = e & 255, hh = (e >> 8) & 255, hw = (e >> 16) & 255, cg = e >> 24;
-                int pd = bd + hd, ph = bh + hh, pw = bw + hw;
-                const int qd = pd + g.npad, qh = ph + g.npad, qw = pw + g.npad;
-                bool valid = resolve_pos(pd, g.D, g.pad_mode);
-                valid &= resolve_pos(ph, g.H, g.pad_mode);
-                valid &= resolve_pos(pw, g.W, g.pad_mode);
-                const int c = chunk * g.CK + cg * 8;
-                meta[k] = (((hd * g.HH + hh) * g.HW + hw) << 4) | cg;
-                ok[k] = valid && c < g.Cin;
-                if (ok[k]) {
-                    if (c1mode) {
-                        const size_t idx = ((size_t)(n * g.D + pd) * g.H + ph) * g.W + pw;
-                        x1[k] = g.src_f32 ? ((const float*)g.src0)[idx] : bf2f(((const bf16_t*)g.src0)[idx]);
-                    } else if (c < g.c0) {
-                        const size_t idx = (((size_t)(n * Ds + (pd >> g.shift0)) * Hs + (ph >> g.shift0)) * Ws + (pw >> g.shift0)) * g.c0 + c;
-                        raw_load(raw[k], (const T*)g.src0 + idx);
-                    } else {
-                        const size_t idx = (((size_t)(n * g.D + pd) * g.H + ph) * g.W + pw) * g.c1 + (c - g.c0);
-                        raw_load(raw[k], (const T*)g.src1 + idx);
-                    }
-                    if (g.noise && qd >= 0 && qd < ND && qh >= 0 && qh < NH && qw >= 0 && qw < NW)
-                        nidx[k] = (((size_t)(n * ND + qd) * NH + qh) * NW + qw) * g.Cin + c;
-                }
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < UB; ++k) {
-            if (meta[k] < 0) continue;
-            const int cg = meta[k] & 15, hv = meta[k] >> 4;
-            float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            if (ok[k]) {
-                float x[8];
-                if (c1mode) { x[0] = x1[k]; } else raw_unpack(raw[k], x);
-                const int nval = c1mode ? 1 : 8;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    if (j < nval) {
-                        float y = vg_act(x[j] * scs[cg * 8 + j] + scs[g.CK + cg * 8 + j], g.act);
-                        if (nidx[k] != ~(size_t)0) y += bf2f(g.noise[nidx[k] + j]);
-                        v[j] = y;
-                    }
-                }
-            }
-            store8<T>((T*)(halo + (size_t)hv * g.RS) + cg * 8, v);
-        }
-    }
-}
 
 // ------------------------------------------------------------------------------------------------------------------
-// Staging v3: per-halo-voxel table + one fixed 8-channel group per thread.
-//   vtab[hv] = { hd | hh<<8 | hw<<16, element offset into src0 (half-res aware), into src1, into the noise grid }
-// Thread t owns channel group cg = t % gpc for the whole chunk (its 8 scale/shift pairs sit in registers) and walks the
-// halo voxels vl, vl+vstride, ...  Interior tiles (no padding / reflection inside the halo, no noise, multi-channel
-// source) take the fast path: address = tile base + table offset, transform, one 16-byte LDS store.  Everything else
-// (border tiles, single-channel sources, noise) takes the general path with the same thread mapping.
+// Halo staging: ONE path for interior and border tiles.  Padding/reflection is separable per axis, so each tile first
+// resolves its HD+HH+HW halo coordinates into three tiny LDS tables (resolved source coordinate, or -1 = zero fill);
+// every unit then computes its address with a few integer ops and no branches, and the global loads of UB units are
+// issued before the first is consumed -- border tiles (the majority on 32^3 and smaller grids) no longer serialise one
+// load per unit.  rtab: LDS ints [HD + HH + HW]; must be filled (stage_resolve_axes) and synchronised before use.
 // ------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void build_voxel_table(const GatherIn& g, int* vtab, int tid, int nthreads) {
-    const int nvox = g.HD * g.HH * g.HW;
-    const int sh = g.shift0;
-    const int Hs = g.H >> sh, Ws = g.W >> sh;
-    const int par_d = g.tmin_d & sh, par_h = g.tmin_h & sh, par_w = g.tmin_w & sh;    // parity of the tile base
-    for (int hv = tid; hv < nvox; hv += nthreads) {
-        const int hw = hv % g.HW; const int t2 = hv / g.HW;
-        const int hh = t2 % g.HH, hd = t2 / g.HH;
-        vtab[hv * 4] = hd | (hh << 8) | (hw << 16);
-        vtab[hv * 4 + 1] = ((((hd + par_d) >> sh) * Hs + ((hh + par_h) >> sh)) * Ws + ((hw + par_w) >> sh)) * g.c0;
-        vtab[hv * 4 + 2] = ((hd * g.H + hh) * g.W + hw) * g.c1;
-        vtab[hv * 4 + 3] = ((hd * (g.H + 2 * g.npad) + hh) * (g.W + 2 * g.npad) + hw) * g.Cin;
+__device__ __forceinline__ void stage_resolve_axes(const GatherIn& g, int* rtab, int od0, int oh0, int ow0, int tid) {
+    const int pd0 = od0 * g.istr + g.tmin_d, ph0 = oh0 * g.istr + g.tmin_h, pw0 = ow0 * g.istr + g.tmin_w;
+    for (int i = tid; i < g.HD + g.HH + g.HW; i += 256) {       // HD alone can exceed the workgroup on thin deep tiles
+        int p, ext;
+        if (i < g.HD) { p = pd0 + i; ext = g.D; }
+        else if (i < g.HD + g.HH) { p = ph0 + i - g.HD; ext = g.H; }
+        else { p = pw0 + i - g.HD - g.HH; ext = g.W; }
+        rtab[i] = resolve_pos(p, ext, g.pad_mode) ? p : -1;
     }
 }
 
 template <typename T, bool NOISE, int UB = 4>
-__device__ __forceinline__ void stage_halo_v3(const GatherIn& g, char* halo, const float* scs, const int* vtab, int n,
-                                              int od0, int oh0, int ow0, int chunk, int tid) {
+__device__ __forceinline__ void stage_halo_tile(const GatherIn& g, char* halo, const float* scs, const int* vtab, const int* rtab,
+                                              int n, int od0, int oh0, int ow0, int chunk, int tid) {
     const int gpc = g.CK >> 3;
-    const int vstride = 256 / gpc;                      // voxels handled in parallel
+    const int vstride = 256 / gpc;
     if (tid >= vstride * gpc) return;
     const int cg = tid % gpc, vl = tid / gpc;
     const int nvox = g.HD * g.HH * g.HW;
     const int c = chunk * g.CK + cg * 8;
-    const int pd0 = od0 * g.istr + g.tmin_d, ph0 = oh0 * g.istr + g.tmin_h, pw0 = ow0 * g.istr + g.tmin_w;
-    const bool interior = pd0 >= 0 && ph0 >= 0 && pw0 >= 0 && pd0 + g.HD <= g.D && ph0 + g.HH <= g.H && pw0 + g.HW <= g.W;
-    const bool tile_even = ((g.tdl > 0) || !(g.istr & 1)) && ((g.thl > 0) || !(g.istr & 1)) && ((g.twl > 0) || !(g.istr & 1));
-    const bool fast = interior && g.Cin != 1 && (g.shift0 == 0 || tile_even);
-    const bool plain = !g.in_scale && g.act == VG_ACT_NONE && !NOISE;          // data-gradient operand: pure copy
-    T* dst0 = (T*)halo + cg * 8;
-    if (fast) {
-        if (c >= g.Cin) {                               // channel padding of the last chunk
-            const float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            for (int hv = vl; hv < nvox; hv += vstride) store8<T>((T*)(halo + (size_t)hv * g.RS) + cg * 8, z);
-            return;
-        }
-        const bool from0 = c < g.c0;
-        const int sh = g.shift0;
-        const T* base;
-        if (from0) base = (const T*)g.src0 + ((((size_t)n * (g.D >> sh) + (pd0 >> sh)) * (g.H >> sh) + (ph0 >> sh)) * (g.W >> sh) + (pw0 >> sh)) * g.c0 + c;
-        else base = (const T*)g.src1 + ((((size_t)n * g.D + pd0) * g.H + ph0) * g.W + pw0) * g.c1 + (c - g.c0);
-        const int sel = from0 ? 1 : 2;
-        // noise lives on the (D+2np)^3 grid: an interior halo never leaves it
-        const bf16_t* nbase = NOISE ? g.noise + ((((size_t)n * (g.D + 2 * g.npad) + pd0 + g.npad) * (g.H + 2 * g.npad) + ph0 + g.npad) * (g.W + 2 * g.npad) + pw0 + g.npad) * g.Cin + c : nullptr;
-        float sc[8], sf[8];
-        if (!plain) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { sc[j] = scs[cg * 8 + j]; sf[j] = scs[g.CK + cg * 8 + j]; }
-        }
-        for (int hv0 = vl; hv0 < nvox; hv0 += vstride * UB) {
-            Raw8<T> raw[UB];
-            Raw8<bf16_t> nz[UB];
-#pragma unroll
-            for (int k = 0; k < UB; ++k) {
-                const int hv = hv0 + k * vstride;
-                if (hv < nvox) {
-                    raw_load(raw[k], base + vtab[hv * 4 + sel]);
-                    if (NOISE) raw_load(nz[k], nbase + vtab[hv * 4 + 3]);
+    const int ND = g.D + 2 * g.npad, NH = g.H + 2 * g.npad, NW = g.W + 2 * g.npad;
+    const int qd0 = od0 * g.istr + g.tmin_d + g.npad, qh0 = oh0 * g.istr + g.tmin_h + g.npad, qw0 = ow0 * g.istr + g.tmin_w + g.npad;
+    if (c >= g.Cin) {                                   // channel padding of the last chunk / second group of a 1-channel source
+        const float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int hv = vl; hv < nvox; hv += vstride) store8<T>((T*)(halo + (size_t)hv * g.RS) + cg * 8, z);
+        return;
+    }
+    if (g.Cin == 1) {                                   // single-channel source (fp32 or bf16 volume): one scalar per voxel
+        const float sc0 = scs[0], sf0 = scs[g.CK];
+        const size_t nb = (size_t)n * g.D * g.H * g.W;
+        for (int hv = vl; hv < nvox; hv += vstride) {
+            const int e = vtab[hv];
+            const int hd = e & 2047, hh = (e >> 11) & 2047, hw = e >> 22;
+            const int rd = rtab[hd], rh = rtab[g.HD + hh], rw = rtab[g.HD + g.HH + hw];
+            float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if ((rd | rh | rw) >= 0) {
+                const size_t idx = nb + ((size_t)rd * g.H + rh) * g.W + rw;
+                const float x = g.src_f32 ? ((const float*)g.src0)[idx] : bf2f(((const bf16_t*)g.src0)[idx]);
+                float y = vg_act(x * sc0 + sf0, g.act);
+                if (NOISE) {
+                    const int qd = qd0 + hd, qh = qh0 + hh, qw = qw0 + hw;
+                    if (g.noise && qd >= 0 && qd < ND && qh >= 0 && qh < NH && qw >= 0 && qw < NW)
+                        y += bf2f(g.noise[((size_t)(n * ND + qd) * NH + qh) * NW + qw]);
                 }
+                v[0] = y;
             }
+            store8<T>((T*)(halo + (size_t)hv * g.RS) + cg * 8, v);
+        }
+        return;
+    }
+    const bool plain = !g.in_scale && g.act == VG_ACT_NONE && !NOISE;     // data-gradient operand: pure copy
+    const int sh = g.shift0;
+    const bool from0 = c < g.c0;
+    const int Hs = from0 ? (g.H >> sh) : g.H, Ws = from0 ? (g.W >> sh) : g.W, Dsz = from0 ? (g.D >> sh) : g.D;
+    const int cs = from0 ? g.c0 : g.c1;
+    const int ssh = from0 ? sh : 0;
+    const T* base = from0 ? (const T*)g.src0 + (size_t)n * Dsz * Hs * Ws * cs + c
+                          : (const T*)g.src1 + (size_t)n * Dsz * Hs * Ws * cs + (c - g.c0);
+    float sc[8], sf[8];
+    if (!plain) {
 #pragma unroll
-            for (int k = 0; k < UB; ++k) {
-                const int hv = hv0 + k * vstride;
-                if (hv < nvox) {
-                    T* dst = (T*)(halo + (size_t)hv * g.RS) + cg * 8;
-                    if (plain) { *(Raw8<T>*)dst = raw[k]; }
-                    else {
-                        float x[8];
-                        raw_unpack(raw[k], x);
+        for (int j = 0; j < 8; ++j) { sc[j] = scs[cg * 8 + j]; sf[j] = scs[g.CK + cg * 8 + j]; }
+    }
+    for (int hv0 = vl; hv0 < nvox; hv0 += vstride * UB) {
+        Raw8<T> raw[UB];
+        Raw8<bf16_t> nz[NOISE ? UB : 1];
+        int st[UB];                 // -1: beyond the tile, 0: zero fill, 1: data, 3: data + noise
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) x[j] = vg_act(x[j] * sc[j] + sf[j], g.act);
-                        if (NOISE) {
-                            float z[8];
-                            raw_unpack(nz[k], z);
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) x[j] += z[j];
+        for (int k = 0; k < UB; ++k) {
+            const int hv = hv0 + k * vstride;
+            st[k] = -1;
+            if (hv < nvox) {
+                const int e = vtab[hv];
+                const int hd = e & 2047, hh = (e >> 11) & 2047, hw = e >> 22;
+                const int rd = rtab[hd], rh = rtab[g.HD + hh], rw = rtab[g.HD + g.HH + hw];
+                st[k] = ((rd | rh | rw) >= 0) ? 1 : 0;
+                if (st[k]) {
+                    const int idx = (((rd >> ssh) * Hs + (rh >> ssh)) * Ws + (rw >> ssh)) * cs;      // < 2^31 elements per sample
+                    raw_load(raw[k], base + idx);
+                    if (NOISE) {
+                        const int qd = qd0 + hd, qh = qh0 + hh, qw = qw0 + hw;
+                        if (g.noise && qd >= 0 && qd < ND && qh >= 0 && qh < NH && qw >= 0 && qw < NW) {
+                            raw_load(nz[k], g.noise + (((size_t)(n * ND + qd) * NH + qh) * NW + qw) * g.Cin + c);
+                            st[k] = 3;
                         }
-                        store8<T>(dst, x);
                     }
                 }
             }
         }
-        return;
-    }
-    // ---- general path (border tiles, single-channel sources, noise): same thread mapping, one unit at a time (batching
-    // these loads as well was measured to cost more in registers/occupancy than it gained) ----
-    const int Ds = g.D >> g.shift0, Hs = g.H >> g.shift0, Ws = g.W >> g.shift0;
-    const int ND = g.D + 2 * g.npad, NH = g.H + 2 * g.npad, NW = g.W + 2 * g.npad;
-    const bool c1mode = g.Cin == 1;
-    (void)dst0;
-    for (int hv = vl; hv < nvox; hv += vstride) {
-        const int e = vtab[hv * 4];
-        const int hd = e & 255, hh = (e >> 8) & 255, hw = e >> 16;
-        int pd = pd0 + hd, ph = ph0 + hh, pw = pw0 + hw;
-        const int qd = pd + g.npad, qh = ph + g.npad, qw = pw + g.npad;
-        bool valid = resolve_pos(pd, g.D, g.pad_mode);
-        valid &= resolve_pos(ph, g.H, g.pad_mode);
-        valid &= resolve_pos(pw, g.W, g.pad_mode);
-        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (valid && c < g.Cin) {
-            float x[8];
-            int nval = 8;
-            if (c1mode) {
-                nval = 1;
-                const size_t idx = ((size_t)(n * g.D + pd) * g.H + ph) * g.W + pw;
-                x[0] = g.src_f32 ? ((const float*)g.src0)[idx] : bf2f(((const bf16_t*)g.src0)[idx]);
-            } else if (c < g.c0) {
-                const size_t idx = (((size_t)(n * Ds + (pd >> g.shift0)) * Hs + (ph >> g.shift0)) * Ws + (pw >> g.shift0)) * g.c0 + c;
-                load8<T>((const T*)g.src0 + idx, x);
-            } else {
-                const size_t idx = (((size_t)(n * g.D + pd) * g.H + ph) * g.W + pw) * g.c1 + (c - g.c0);
-                load8<T>((const T*)g.src1 + idx, x);
-            }
-            const bool has_noise = NOISE && g.noise && qd >= 0 && qd < ND && qh >= 0 && qh < NH && qw >= 0 && qw < NW;
-            const size_t nidx = has_noise ? ((((size_t)(n * ND + qd) * NH + qh) * NW + qw) * g.Cin + c) : 0;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                if (j < nval) {
-                    float y = vg_act(x[j] * scs[cg * 8 + j] + scs[g.CK + cg * 8 + j], g.act);
-                    if (has_noise) y += bf2f(g.noise[nidx + j]);
+        for (int k = 0; k < UB; ++k) {
+            if (st[k] < 0) continue;
+            const int hv = hv0 + k * vstride;
+            T* dst = (T*)(halo + (size_t)hv * g.RS) + cg * 8;
+            if (plain && st[k] > 0) { *(Raw8<T>*)dst = raw[k]; continue; }
+            float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (st[k] > 0) {
+                float x[8], z[8];
+                raw_unpack(raw[k], x);
+                if (NOISE && st[k] == 3) raw_unpack(nz[k], z);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float y = vg_act(x[j] * sc[j] + sf[j], g.act);
+                    if (NOISE && st[k] == 3) y += z[j];
                     v[j] = y;
                 }
             }
+            store8<T>(dst, v);
         }
-        store8<T>((T*)(halo + (size_t)hv * g.RS) + cg * 8, v);
+    }
+}
+
+__device__ __forceinline__ void build_voxel_table(const GatherIn& g, int* vtab, int tid, int nthreads) {
+    const int nvox = g.HD * g.HH * g.HW;
+    for (int hv = tid; hv < nvox; hv += nthreads) {
+        const int hw = hv % g.HW; const int t2 = hv / g.HW;
+        vtab[hv] = (t2 / g.HH) | ((t2 % g.HH) << 11) | (hw << 22);
     }
 }
 

@@ -27,6 +27,7 @@ struct WgradK {
 };
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+#define VG_WSTAMP(slot) do { if (g.stamps && tid == 0 && it < 8) g.stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 64 + it * 8 + (slot)] = __builtin_readcyclecounter(); } while (0)
 
 __device__ __forceinline__ bf16x8 tr_frag(const char* base0, const char* base1) {
     // two transposed 4x16 block reads -> 8 consecutive k for this lane's column
@@ -59,6 +60,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const GatherIn g, const Wgra
     int* tapsrc = tapoff + 64;
     float* scs = (float*)((char*)tapoff + 512);
     int* utab = (int*)(scs + 2 * g.CK);
+    int* rtab = utab + g.HD * g.HH * g.HW;
 
     if (tid < g.ntaps)
         tapoff[tid] = (((g.td[tid] - g.tmin_d) * g.HH + (g.th[tid] - g.tmin_h)) * g.HW + (g.tw[tid] - g.tmin_w)) * g.RS;
@@ -87,7 +89,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const GatherIn g, const Wgra
     constexpr int gcol = (Q * 16) >> 3, gcol_l = Q == 1 ? 1 : (Q == 2 ? 2 : 3);     // 8-channel groups per dY row
     const bool do_db = p.db && cib == 0 && tg == 0;
 
+    int it = -1;
     for (int tile = blockIdx.x; tile < p.total_tiles; tile += gridDim.x) {
+        ++it;
+        VG_WSTAMP(0);
         const int n = tile / tiles_per_n; int t = tile - n * tiles_per_n;
         const int tw_i = t % g.tiles_w; t /= g.tiles_w;
         const int th_i = t % g.tiles_h; const int td_i = t / g.tiles_h;
@@ -96,9 +101,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const GatherIn g, const Wgra
         if (n != cur_n) {                      // block-uniform: the on-read affine depends on the sample only
             stage_scale_shift(g, scs, n, cib, tid);
             cur_n = n;
-            __syncthreads();
         }
-        if (!(g.dbg & 1) || tile == (int)blockIdx.x) stage_halo_v3<T, NOISE>(g, halo, scs, utab, n, od0, oh0, ow0, cib, tid);
+        stage_resolve_axes(g, rtab, od0, oh0, ow0, tid);
+        __syncthreads();
+        if (!(g.dbg & 1) || tile == (int)blockIdx.x) stage_halo_tile<T, NOISE, 2>(g, halo, scs, utab, rtab, n, od0, oh0, ow0, cib, tid);
         if (!(g.dbg & 2) || tile == (int)blockIdx.x)
         // ---- stage dY tile [BM][16*Q] (zero outside the grid / beyond Cout): all loads first ----
         for (int u0 = tid; u0 < BM * gcol; u0 += 256 * 4) {
@@ -129,7 +135,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const GatherIn g, const Wgra
                 store8<T>((T*)(dyt + (size_t)(mm[k] >> 4) * p.DYS) + (mm[k] & 15) * 8, v);
             }
         }
+        VG_WSTAMP(1);
         __syncthreads();
+        VG_WSTAMP(2);
         if (do_db) {      // thread (row group, channel): partial column sums of the dY tile
             const int nrg = 256 / p.COB;
             if (tid < nrg * p.COB) {
@@ -184,8 +192,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const GatherIn g, const Wgra
                 }
             }
         }
+        VG_WSTAMP(3);
     }
     // ---- add the slab: lane holds dW rows ci = 4*lg + r, column co = li ----
+    { const int it = 7; VG_WSTAMP(7); }
 #pragma unroll
     for (int j = 0; j < RMAX; ++j) {
         const int r = wave + 4 * j;
@@ -279,7 +289,7 @@ extern "C" int vg_conv3d_wgrad(const vg_conv_desc* d, const void* dy, int dy_f32
                 if (Cinp % c) continue;
                 int rc = fill_gather(d, g, c, bm);
                 if (rc != VG_OK) return rc;
-                const int lds = halo_bytes(g) + bm * (COB * esz + 16) + 512 + 2 * c * 4 + g.HD * g.HH * g.HW * 4 * 4;
+                const int lds = halo_bytes(g) + bm * (COB * esz + 16) + 512 + 2 * c * 4 + (g.HD * g.HH * g.HW + g.HD + g.HH + g.HW) * 4;
                 if (lds <= limit) { best_bm = bm; best_cib = c; best_lds = lds; break; }
             }
     }
