@@ -31,12 +31,93 @@ struct ConvOut {
     int WRS;
 };
 
+// 4 consecutive channels as stored (epilogue operands)
+template <typename T> struct Vec4;
+template <> struct Vec4<bf16_t> { bf16x4 v; };
+template <> struct Vec4<float> { f32x4 v; };
+__device__ __forceinline__ void vec4_load(Vec4<bf16_t>& r, const bf16_t* p) { r.v = *(const __attribute__((address_space(1))) bf16x4*)(uintptr_t)p; }
+__device__ __forceinline__ void vec4_load(Vec4<float>& r, const float* p) { r.v = *(const __attribute__((address_space(1))) f32x4*)(uintptr_t)p; }
+__device__ __forceinline__ void vec4_unpack(const Vec4<bf16_t>& r, float* o) { for (int j = 0; j < 4; ++j) o[j] = bf2f((bf16_t)r.v[j]); }
+__device__ __forceinline__ void vec4_unpack(const Vec4<float>& r, float* o) { for (int j = 0; j < 4; ++j) o[j] = r.v[j]; }
+
+#ifndef VG_CONV_WAVES
+#define VG_CONV_WAVES 3      // waves per SIMD the register allocation must allow (3 workgroups per CU)
+#endif
+template <typename T> using lds_ptr = const __attribute__((address_space(3))) T*;
+template <typename T> using glb_ptr = const __attribute__((address_space(1))) T*;
+
+// MFMA over the (tap, channel-group) pairs of one channel chunk.  w points at this lane's fragment of K-step 0 (LDS
+// panel or global row: WP carries the address space).  bf16: K-steps are processed KU at a time, all operand fetches of
+// a group issued before its first MFMA, the halo offsets of the NEXT group fetched meanwhile; the remainder steps run
+// one by one afterwards so that no MFMA sits under a condition (conditional MFMAs made the compiler shuttle the
+// accumulators between AGPRs and VGPRs around every group).
+template <typename T, int MW, typename WP>
+__device__ __forceinline__ void conv_mfma_chunk(f32x4 (&acc)[MW], WP w, const char* halo, const int (&rowbase)[MW],
+                                                const int* tapoff, const int* koff, int ksteps, int ntaps, int CK, int lane) {
+    if constexpr (sizeof(T) == 4) {
+        // exact-parity mode: f32 operands, v_mfma_f32_16x16x4_f32 (k = 4 consecutive channels of one tap)
+        int tap = 0, ch0 = 0;
+        const int nk4 = (ntaps * CK) >> 2;
+        for (int s = 0; s < nk4; ++s) {
+            const int off = tapoff[tap] + (ch0 + (lane >> 4)) * 4;
+            float b[MW];
+#pragma unroll
+            for (int i = 0; i < MW; ++i) b[i] = *(const float*)(halo + rowbase[i] + off);
+            const float a = w[s * 4];
+#pragma unroll
+            for (int i = 0; i < MW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[i], acc[i], 0, 0, 0);
+            ch0 += 4;
+            if (ch0 >= CK) { ch0 = 0; ++tap; }
+        }
+    } else {
+        // explicit two-stage software pipeline: while the MFMAs of K-step s run, the operand fragments of step s+1 are
+        // already on their way from LDS (and the halo offset of step s+2 is being fetched); sched_barriers keep the
+        // compiler from sinking the prefetch below the MFMAs again to save registers.
+        typedef const __attribute__((address_space(3))) bf16x8 lds_frag;
+        typedef const __attribute__((address_space(1))) bf16x8 glb_frag;
+        auto wfrag = [&](int step) -> bf16x8 {
+            if constexpr (__is_same(WP, lds_ptr<T>)) return *(lds_frag*)(w + step * 32);
+            else return *(glb_frag*)(w + step * 32);
+        };
+        const int kg = lane >> 4;
+        const int last = ksteps - 1;
+        const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+        bf16x8 a0 = wfrag(0), a1;
+        bf16x8 b0[MW], b1[MW];
+        {
+            const int o0 = koff[kg];
+#pragma unroll
+            for (int i = 0; i < MW; ++i) b0[i] = *(const bf16x8*)(halo + rowbase[i] + o0);
+        }
+        int o1 = koff[min(1, last) * 4 + kg];
+        for (int s = 0; s < ksteps; s += 2) {
+            const int o2 = koff[min(s + 2, last) * 4 + kg];
+            a1 = wfrag(min(s + 1, last));
+#pragma unroll
+            for (int i = 0; i < MW; ++i) b1[i] = *(const bf16x8*)(halo + rowbase[i] + o1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < MW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0[i], acc[i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            o1 = koff[min(s + 3, last) * 4 + kg];
+            a0 = wfrag(min(s + 2, last));
+#pragma unroll
+            for (int i = 0; i < MW; ++i) b0[i] = *(const bf16x8*)(halo + rowbase[i] + o2);
+            if (s + 1 >= ksteps) a1 = zero8;                       // odd K-step count: the phantom step adds zero
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < MW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1[i], acc[i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
 // Persistent workgroup: blockIdx.z = sample, blockIdx.y = BN-channel panel, blockIdx.x walks the output tiles of the
 // sample.  Per workgroup ONCE: tap offsets, the (halo voxel, channel group) unit table, the weight panel (if it fits in
 // LDS); per tile: stage halo (batched global loads), MFMA loop, epilogue; InstanceNorm statistics are carried in
 // registers across tiles and flushed once.
-template <typename T, int BN, int MSUB, bool NOISE>
-__global__ __launch_bounds__(256) void conv_kernel(const GatherIn g, const ConvOut p) {
+template <typename T, int BN, int MSUB, bool NOISE, bool WL>
+__global__ __launch_bounds__(256, ((BN / 16) * MSUB >= 8 ? 2 : VG_CONV_WAVES)) void conv_kernel(const GatherIn g, const ConvOut p) {
     constexpr bool F32 = sizeof(T) == 4;
     // wave decomposition: WN waves along the channel panel (one 16-channel sub-tile each, so a weight fragment is
     // fetched by exactly one wave: L1 delivers 64 B/clk, LDS 256 B/clk), WM waves along the voxels
@@ -53,8 +134,9 @@ __global__ __launch_bounds__(256) void conv_kernel(const GatherIn g, const ConvO
     float* scs = (float*)(smem + hbytes + 256);
     float* stat = scs + 2 * g.CK;
     int* utab = (int*)(stat + BN * 2);
-    const int nunits = g.HD * g.HH * g.HW + g.HD + g.HH + g.HW;      // voxel table + per-tile resolved axis tables
-    int* rtab = utab + g.HD * g.HH * g.HW;
+    const int ncols = stage_ncols(g);
+    const int nunits = 2 * ncols + 3 * (g.HH + g.HW);               // column table + per-tile axis tables
+    int* rtab = utab + 2 * ncols;
     const int gpc = g.CK >> 3;
     const int ngroups = g.ntaps * gpc;
     const int ksteps = (ngroups + 3) >> 2;
@@ -65,13 +147,13 @@ __global__ __launch_bounds__(256) void conv_kernel(const GatherIn g, const ConvO
     if (tid < g.ntaps)
         tapoff[tid] = (((g.td[tid] - g.tmin_d) * g.HH + (g.th[tid] - g.tmin_h)) * g.HW + (g.tw[tid] - g.tmin_w)) * g.RS;
     if (tid < BN * 2) stat[tid] = 0.f;
-    build_voxel_table(g, utab, tid, 256);
+    build_column_table(g, utab, tid);
     for (int i = tid; i < ksteps * 4; i += 256) {
         int G = i; if (G >= ngroups) G = ngroups - 1;                       // padded K: weights are zero there
         const int tp = G / gpc, cgq = G - tp * gpc;
         koff[i] = (((g.td[tp] - g.tmin_d) * g.HH + (g.th[tp] - g.tmin_h)) * g.HW + (g.tw[tp] - g.tmin_w)) * g.RS + cgq * 16;
     }
-    if (p.w_lds) {          // weight panel -> LDS, 16 B per thread per step
+    if (WL) {               // weight panel -> LDS, 16 B per thread per step
         const int per_row = (p.Ktot * (int)sizeof(T)) >> 4;
         for (int u = tid; u < BN * per_row; u += 256) {
             const int r = u / per_row, c = u - r * per_row;
@@ -87,10 +169,10 @@ __global__ __launch_bounds__(256) void conv_kernel(const GatherIn g, const ConvO
         const int w = m & TWm, h = (m >> g.twl) & THm, d = m >> (g.twl + g.thl);
         rowbase[i] = ((d * g.istr * g.HH + h * g.istr) * g.HW + w * g.istr) * g.RS;
     }
-    // weight fragment source: LDS panel or global (L2) rows
-    const T* wrow;
-    if (p.w_lds) wrow = (const T*)(wlds + (size_t)(wave_n * 16 + (lane & 15)) * p.WRS) + (F32 ? 1 : 8) * (lane >> 4);
-    else wrow = (const T*)p.wp + (size_t)(ntile * BN + wave_n * 16 + (lane & 15)) * p.Ktot + (F32 ? 1 : 8) * (lane >> 4);
+    // weight fragment source: LDS panel or global (L2) rows -- kept as two address-space-typed pointers (a pointer
+    // selected between the two becomes generic and every fragment fetch a flat_load)
+    const lds_ptr<T> wrow_l = (lds_ptr<T>)(wlds + (size_t)(wave_n * 16 + (lane & 15)) * p.WRS) + (F32 ? 1 : 8) * (lane >> 4);
+    const glb_ptr<T> wrow_g = (glb_ptr<T>)p.wp + (size_t)(ntile * BN + wave_n * 16 + (lane & 15)) * p.Ktot + (F32 ? 1 : 8) * (lane >> 4);
     float s1[4], s2[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
@@ -104,6 +186,16 @@ __global__ __launch_bounds__(256) void conv_kernel(const GatherIn g, const ConvO
         e_rs[r] = (p.res && co < p.Cout) ? p.rs[n * p.Cout + co] : 0.f;
         e_rb[r] = (p.res && co < p.Cout) ? p.rb[n * p.Cout + co] : 0.f;
     }
+    // output position of (sub-tile i, this lane) relative to the tile origin: element offset and packed (d, h, w)
+    int ooff[MW], dhw[MW];
+#pragma unroll
+    for (int i = 0; i < MW; ++i) {
+        const int m = (wave_m * MW + i) * 16 + (lane & 15);
+        const int w = m & TWm, h = (m >> g.twl) & THm, d = m >> (g.twl + g.thl);
+        ooff[i] = ((d * p.ostr * p.BH + h * p.ostr) * p.BW + w * p.ostr) * p.Cout + co0;
+        dhw[i] = d | (h << 10) | (w << 20);
+    }
+    const bool vec_epi = (p.Cout & 3) == 0 && !(p.tanh_out && p.accumulate);   // every lane owns 4 whole channels: vector loads/stores
     if (p.nchunks == 1) stage_scale_shift(g, scs, n, 0, tid);
     __syncthreads();
 
@@ -123,61 +215,86 @@ __global__ __launch_bounds__(256) void conv_kernel(const GatherIn g, const ConvO
         for (int chunk = 0; chunk < p.nchunks; ++chunk) {
             __syncthreads();                       // previous readers of the halo tile are done
             if (p.nchunks > 1) stage_scale_shift(g, scs, n, chunk, tid);
-            if (chunk == 0) stage_resolve_axes(g, rtab, od0, oh0, ow0, tid);
+            if (chunk == 0) stage_resolve_axes(g, rtab, oh0, ow0, tid);
             if (p.nchunks > 1 || chunk == 0) __syncthreads();
-            if (!(g.dbg & 1)) stage_halo_tile<T, NOISE>(g, halo, scs, utab, rtab, n, od0, oh0, ow0, chunk, tid);
+            if (!(g.dbg & 1)) stage_halo_tile<T, NOISE>(g, halo, scs, utab, rtab, n, od0, chunk, tid);
             if (chunk == 0) VG_STAMP(1);
             __syncthreads();
             if (chunk == 0) VG_STAMP(2);
             const size_t kbase = (size_t)chunk * p.kc_pad;
             if (g.dbg & 4) continue;
-            if constexpr (F32) {
-                // exact-parity mode: f32 operands, v_mfma_f32_16x16x4_f32 (k = 4 consecutive channels of one tap)
-                int tap = 0, ch0 = 0;
-                const int nk4 = (g.ntaps * g.CK) >> 2;
-                for (int s = 0; s < nk4; ++s) {
-                    const int off = tapoff[tap] + (ch0 + (lane >> 4)) * 4;
-                    float b[MW];
-#pragma unroll
-                    for (int i = 0; i < MW; ++i) b[i] = *(const float*)(halo + rowbase[i] + off);
-                    const float a = wrow[kbase + s * 4];
-#pragma unroll
-                    for (int i = 0; i < MW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[i], acc[i], 0, 0, 0);
-                    ch0 += 4;
-                    if (ch0 >= g.CK) { ch0 = 0; ++tap; }
-                }
-            } else {
-                // ---- MFMA over (tap, channel-group) pairs of this chunk: K-steps are processed KU at a time, all their
-                // operand fetches (offset table, weight fragments, halo fragments) issued before the first MFMA ----
-                constexpr int KU = MW >= 8 ? 2 : 4;
-                const int kg = lane >> 4;
-                for (int s0 = 0; s0 < ksteps; s0 += KU) {
-                    int off[KU];
-                    bf16x8 a[KU];
-#pragma unroll
-                    for (int u = 0; u < KU; ++u) {
-                        const int su = s0 + u < ksteps ? s0 + u : ksteps - 1;
-                        off[u] = koff[su * 4 + kg];
-                        a[u] = *(const bf16x8*)((const bf16_t*)wrow + kbase + su * 32);
-                    }
-                    bf16x8 b[KU][MW];
-#pragma unroll
-                    for (int u = 0; u < KU; ++u)
-#pragma unroll
-                        for (int i = 0; i < MW; ++i) b[u][i] = *(const bf16x8*)(halo + rowbase[i] + off[u]);
-#pragma unroll
-                    for (int u = 0; u < KU; ++u) {
-                        if (s0 + u < ksteps) {
-#pragma unroll
-                            for (int i = 0; i < MW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u], b[u][i], acc[i], 0, 0, 0);
-                        }
-                    }
-                }
-            }
+            if constexpr (WL) conv_mfma_chunk<T, MW>(acc, wrow_l + kbase, halo, rowbase, tapoff, koff, ksteps, g.ntaps, g.CK, lane);
+            else conv_mfma_chunk<T, MW>(acc, wrow_g + kbase, halo, rowbase, tapoff, koff, ksteps, g.ntaps, g.CK, lane);
         }
         VG_STAMP(3);
         if (g.dbg & 8) continue;
         // ---- epilogue: lane holds out channels co0..co0+3 of voxel (lane&15) of each of the wave's sub-tiles ----
+        if (vec_epi) {
+            // tile base (wave-uniform, 64-bit) + per-lane constant offset: no per-voxel index math; residual / accumulate
+            // operands of all sub-tiles are fetched up front as 4-channel vectors
+            const size_t tbase = (((size_t)(n * p.BD + od0 * p.ostr + p.ood) * p.BH + oh0 * p.ostr + p.ooh) * p.BW + ow0 * p.ostr + p.oow) * p.Cout;
+            const int remd = p.OD - od0, remh = p.OH - oh0, remw = p.OW - ow0;
+            const bool cok = co0 < p.Cout;
+            bool inr[MW];
+#pragma unroll
+            for (int i = 0; i < MW; ++i)
+                inr[i] = cok && (dhw[i] & 1023) < remd && ((dhw[i] >> 10) & 1023) < remh && (dhw[i] >> 20) < remw;
+            float add[MW][4];
+#pragma unroll
+            for (int i = 0; i < MW; ++i) { add[i][0] = e_bias[0]; add[i][1] = e_bias[1]; add[i][2] = e_bias[2]; add[i][3] = e_bias[3]; }
+            if (p.res) {
+                const T* rp = (const T*)p.res + tbase;
+                Vec4<T> rv[MW];
+#pragma unroll
+                for (int i = 0; i < MW; ++i) vec4_load(rv[i], rp + (inr[i] ? ooff[i] : 0));
+#pragma unroll
+                for (int i = 0; i < MW; ++i) {
+                    float x[4]; vec4_unpack(rv[i], x);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) add[i][r] += x[r] * e_rs[r] + e_rb[r];
+                }
+            }
+            if (p.accumulate) {
+                if (p.out_f32) {
+                    const float* op = (const float*)p.out + tbase;
+                    Vec4<float> ov[MW];
+#pragma unroll
+                    for (int i = 0; i < MW; ++i) vec4_load(ov[i], op + (inr[i] ? ooff[i] : 0));
+#pragma unroll
+                    for (int i = 0; i < MW; ++i) { float x[4]; vec4_unpack(ov[i], x); for (int r = 0; r < 4; ++r) add[i][r] += x[r]; }
+                } else {
+                    const bf16_t* op = (const bf16_t*)p.out + tbase;
+                    Vec4<bf16_t> ov[MW];
+#pragma unroll
+                    for (int i = 0; i < MW; ++i) vec4_load(ov[i], op + (inr[i] ? ooff[i] : 0));
+#pragma unroll
+                    for (int i = 0; i < MW; ++i) { float x[4]; vec4_unpack(ov[i], x); for (int r = 0; r < 4; ++r) add[i][r] += x[r]; }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < MW; ++i) {
+                if (inr[i]) {
+                    float v[4];
+                    if (p.tanh_out && !p.accumulate) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = tanhf(acc[i][r] + add[i][r]);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = acc[i][r] + add[i][r];
+                    }
+                    if (p.out_f32) {
+                        *(f32x4*)((float*)p.out + tbase + ooff[i]) = (f32x4){v[0], v[1], v[2], v[3]};
+                    } else {
+                        const bf16x4 pk = {(short)f2bf(v[0]), (short)f2bf(v[1]), (short)f2bf(v[2]), (short)f2bf(v[3])};
+                        *(bf16x4*)((bf16_t*)p.out + tbase + ooff[i]) = pk;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = bf2f((bf16_t)pk[r]);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { s1[r] += v[r]; s2[r] += v[r] * v[r]; }
+                }
+            }
+        } else
 #pragma unroll
         for (int i = 0; i < MW; ++i) {
             const int m = (wave_m * MW + i) * 16 + (lane & 15);
@@ -241,7 +358,7 @@ __global__ __launch_bounds__(256) void conv_kernel(const GatherIn g, const ConvO
 // host side
 // ------------------------------------------------------------------------------------------------
 static int conv_lds_bytes(const GatherIn& g, int BN, int CK, int wbytes) {
-    const int nunits = g.HD * g.HH * g.HW + g.HD + g.HH + g.HW;
+    const int nunits = stage_table_ints(g);
     const int ksteps = (g.ntaps * (CK >> 3) + 3) >> 2;
     return halo_bytes(g) + 256 + 2 * CK * 4 + BN * 2 * 4 + nunits * 4 + ksteps * 16 + 16 + wbytes;
 }
@@ -279,7 +396,7 @@ static int fill_conv(const vg_conv_desc* d, GatherIn& g, ConvOut& k, int& BN, in
             if (rc != VG_OK) return rc;
             const long wgs = (long)g.tiles_d * g.tiles_h * g.tiles_w * ((d->Cout + bn - 1) / bn) * d->N;
             const int wbytes = bn * k.WRS;
-            int wl = (wbytes <= 56 * 1024 && !no_wlds) ? 1 : 0;
+            int wl = (wbytes <= 56 * 1024 && !no_wlds && !d->f32) ? 1 : 0;       // exact-parity mode reads weights from L2
             int need = conv_lds_bytes(g, bn, d->CK, wl ? wbytes : 0);
             if (need > 80 * 1024 && wl) { const int n2 = conv_lds_bytes(g, bn, d->CK, 0); if (n2 <= 80 * 1024 || need > VG_LDS_LIMIT) { wl = 0; need = n2; } }
             if (need > VG_LDS_LIMIT) continue;
@@ -308,11 +425,11 @@ extern "C" int vg_conv3d_lds_bytes(const vg_conv_desc* d) {
     return rc == VG_OK ? lds : rc;
 }
 
-template <typename T, int BN, int MSUB, bool NOISE>
-static int launch_conv2(const GatherIn& g, const ConvOut& k, int lds, hipStream_t s) {
+template <typename T, int BN, int MSUB, bool NOISE, bool WL>
+static int launch_conv3(const GatherIn& g, const ConvOut& k, int lds, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_kernel<T, BN, MSUB, NOISE>, hipFuncAttributeMaxDynamicSharedMemorySize, VG_LDS_LIMIT);
+        (void)hipFuncSetAttribute((const void*)conv_kernel<T, BN, MSUB, NOISE, WL>, hipFuncAttributeMaxDynamicSharedMemorySize, VG_LDS_LIMIT);
         attr_set = true;
     }
     static int wg_target = -1;
@@ -321,8 +438,13 @@ static int launch_conv2(const GatherIn& g, const ConvOut& k, int lds, hipStream_
     const int ny = (k.Cout + BN - 1) / BN;
     int bx = wg_target / (ny * g.N); if (bx < 1) bx = 1; if (bx > tiles) bx = tiles;
     dim3 grid(bx, ny, g.N);
-    hipLaunchKernelGGL((conv_kernel<T, BN, MSUB, NOISE>), grid, dim3(256), lds, s, g, k);
+    hipLaunchKernelGGL((conv_kernel<T, BN, MSUB, NOISE, WL>), grid, dim3(256), lds, s, g, k);
     return vg_check_launch();
+}
+template <typename T, int BN, int MSUB, bool NOISE>
+static int launch_conv2(const GatherIn& g, const ConvOut& k, int lds, hipStream_t s) {
+    if constexpr (sizeof(T) == 2) { if (k.w_lds) return launch_conv3<T, BN, MSUB, NOISE, true>(g, k, lds, s); }
+    return launch_conv3<T, BN, MSUB, NOISE, false>(g, k, lds, s);
 }
 template <typename T, int BN, int MSUB>
 static int launch_conv(const GatherIn& g, const ConvOut& k, int lds, hipStream_t s) {

@@ -46,8 +46,13 @@ __device__ __forceinline__ void stage_scale_shift(const GatherIn& g, float* scs,
 template <typename T> struct Raw8;
 template <> struct Raw8<bf16_t> { bf16x8 v; };
 template <> struct Raw8<float> { f32x4 a, b; };
-__device__ __forceinline__ void raw_load(Raw8<bf16_t>& r, const bf16_t* p) { r.v = *(const bf16x8*)p; }
-__device__ __forceinline__ void raw_load(Raw8<float>& r, const float* p) { r.a = *(const f32x4*)p; r.b = *(const f32x4*)(p + 4); }
+// global address space stated explicitly: a source pointer selected per lane (virtual concat) would otherwise be generic
+// and the load a flat_load (slower, and it ties up the LDS counter as well)
+__device__ __forceinline__ void raw_load(Raw8<bf16_t>& r, const bf16_t* p) { r.v = *(const __attribute__((address_space(1))) bf16x8*)(uintptr_t)p; }
+__device__ __forceinline__ void raw_load(Raw8<float>& r, const float* p) {
+    const __attribute__((address_space(1))) f32x4* q = (const __attribute__((address_space(1))) f32x4*)(uintptr_t)p;
+    r.a = q[0]; r.b = q[1];
+}
 __device__ __forceinline__ void raw_unpack(const Raw8<bf16_t>& r, float* o) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = bf2f((bf16_t)r.v[j]);
@@ -57,130 +62,224 @@ __device__ __forceinline__ void raw_unpack(const Raw8<float>& r, float* o) {
 }
 
 
+__device__ __forceinline__ void raw_mask(Raw8<bf16_t>& r, bool keep) { if (!keep) r.v = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0}; }
+__device__ __forceinline__ void raw_mask(Raw8<float>& r, bool keep) { if (!keep) { r.a = (f32x4){0.f, 0.f, 0.f, 0.f}; r.b = r.a; } }
+
 // ------------------------------------------------------------------------------------------------------------------
-// Halo staging: ONE path for interior and border tiles.  Padding/reflection is separable per axis, so each tile first
-// resolves its HD+HH+HW halo coordinates into three tiny LDS tables (resolved source coordinate, or -1 = zero fill);
-// every unit then computes its address with a few integer ops and no branches, and the global loads of UB units are
-// issued before the first is consumed -- border tiles (the majority on 32^3 and smaller grids) no longer serialise one
-// load per unit.  rtab: LDS ints [HD + HH + HW]; must be filled (stage_resolve_axes) and synchronised before use.
+// Halo staging by COLUMNS.  A column is one (hh, hw, 8-channel group) of the halo tile; a thread owns whole columns and
+// walks them along D.  Everything per-lane is resolved once per column (H/W reflection or zero padding, source of the
+// virtual concat, upsample shift, noise position: separable per axis, kept in small LDS axis tables); the D axis is
+// wave-uniform and costs scalar instructions only.  The loop body is straight-line: addresses of invalid units are
+// clamped and their data zeroed afterwards, so the loads of UB units are really in flight together (a conditional load
+// makes the compiler drain vmcnt before the next one) and the per-unit VALU cost is the transform itself.
+//   ctab: LDS ints [2 * ncols]: {hh | hw<<10 | cg<<20, byte offset of the column inside one halo D-plane}; built once.
+//   rtab: LDS ints [3][HH + HW]: element offsets (or -1) along H and W for src0, src1 and the noise tensor; per tile.
 // ------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void stage_resolve_axes(const GatherIn& g, int* rtab, int od0, int oh0, int ow0, int tid) {
-    const int pd0 = od0 * g.istr + g.tmin_d, ph0 = oh0 * g.istr + g.tmin_h, pw0 = ow0 * g.istr + g.tmin_w;
-    for (int i = tid; i < g.HD + g.HH + g.HW; i += 256) {       // HD alone can exceed the workgroup on thin deep tiles
-        int p, ext;
-        if (i < g.HD) { p = pd0 + i; ext = g.D; }
-        else if (i < g.HD + g.HH) { p = ph0 + i - g.HD; ext = g.H; }
-        else { p = pw0 + i - g.HD - g.HH; ext = g.W; }
-        rtab[i] = resolve_pos(p, ext, g.pad_mode) ? p : -1;
+__host__ __device__ __forceinline__ int stage_ncols(const GatherIn& g) { return g.HH * g.HW * (g.Cin == 1 ? 1 : (g.CK >> 3)); }
+
+__device__ __forceinline__ void build_column_table(const GatherIn& g, int* ctab, int tid) {
+    const int gpc = g.Cin == 1 ? 1 : (g.CK >> 3);
+    const int ncols = g.HH * g.HW * gpc;
+    for (int col = tid; col < ncols; col += 256) {
+        const int v = col / gpc, cg = col - v * gpc;
+        const int hh = v / g.HW, hw = v - hh * g.HW;
+        ctab[2 * col] = hh | (hw << 10) | (cg << 20);
+        ctab[2 * col + 1] = v * g.RS + cg * 16 * (g.f32 ? 2 : 1);
+    }
+}
+
+__device__ __forceinline__ void stage_resolve_axes(const GatherIn& g, int* rtab, int oh0, int ow0, int tid) {
+    const int L = g.HH + g.HW;
+    const int ph0 = oh0 * g.istr + g.tmin_h, pw0 = ow0 * g.istr + g.tmin_w;
+    const int cs0 = g.Cin == 1 ? 1 : g.c0;
+    for (int set = 0; set < 3; ++set) {
+        if (set == 1 && g.c1 == 0) continue;
+        if (set == 2 && !g.noise) continue;
+        for (int j = tid; j < L; j += 256) {
+            const bool isH = j < g.HH;
+            int p = isH ? ph0 + j : pw0 + j - g.HH;
+            const int q = p + g.npad;
+            bool valid = resolve_pos(p, isH ? g.H : g.W, g.pad_mode);
+            int off;
+            if (set == 0) { const int ps = p >> g.shift0; off = isH ? ps * (g.W >> g.shift0) * cs0 : ps * cs0; }
+            else if (set == 1) off = isH ? p * g.W * g.c1 : p * g.c1;
+            else {
+                const int next = (isH ? g.H : g.W) + 2 * g.npad;
+                valid = valid && q >= 0 && q < next;
+                off = isH ? q * (g.W + 2 * g.npad) * g.Cin : q * g.Cin;
+            }
+            rtab[set * L + j] = valid ? off : -1;
+        }
+    }
+}
+
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+// y = act(x * sc + sf) on 8 channels, branch-free: act(y) = max(y, slope * y) with slope 1 (none), 0 (ReLU), 0.2 (leaky)
+__device__ __forceinline__ void stage_affine_act(float* x, const f32x2* sc, const f32x2* sf, float slope) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f32x2 v = {x[2 * j], x[2 * j + 1]};
+        v = v * sc[j] + sf[j];
+        const f32x2 t = v * slope;
+        x[2 * j] = fmaxf(v[0], t[0]); x[2 * j + 1] = fmaxf(v[1], t[1]);
+    }
+}
+
+__device__ __forceinline__ float ld_global(const float* p) { return *(const __attribute__((address_space(1))) float*)(uintptr_t)p; }
+__device__ __forceinline__ float ld_global(const bf16_t* p) { return bf2f(*(const __attribute__((address_space(1))) bf16_t*)(uintptr_t)p); }
+
+// single-channel source of element type S (the fp32 input volumes, bf16 logits/gradients)
+template <typename T, typename S, bool NOISE, int UB>
+__device__ __forceinline__ void stage_halo_c1(const GatherIn& g, char* halo, const float* scs, const int* ctab, const int* rtab,
+                                              int n, int pd0, int tid) {
+    const int L = g.HH + g.HW;
+    const int ncols = g.HH * g.HW;
+    const int plane = g.HH * g.HW * g.RS;
+    const float slope = g.act == VG_ACT_RELU ? 0.f : (g.act == VG_ACT_LRELU ? VG_LRELU : 1.f);
+    const int ND = g.D + 2 * g.npad;
+    const int nplane = (g.H + 2 * g.npad) * (g.W + 2 * g.npad);
+    const float sc0 = scs[0], sf0 = scs[g.CK];
+    const int splane = g.H * g.W;
+    const S* sbase = (const S*)g.src0 + (size_t)n * g.D * splane;
+    const bf16_t* nbase = NOISE ? g.noise + (size_t)n * ND * nplane : nullptr;
+    const int ngrp = g.CK >> 3;
+    for (int col = tid; col < ncols; col += 256) {
+        const int e = ctab[2 * col], hoff = ctab[2 * col + 1];
+        const int hh = e & 1023, hw = (e >> 10) & 1023;
+        const int oh = rtab[hh], ow = rtab[g.HH + hw];
+        const bool cvalid = (oh | ow) >= 0;
+        const int coff = cvalid ? oh + ow : 0;
+        int noff = 0; bool nvalid = false;
+        if (NOISE) { const int nh = rtab[2 * L + hh], nw = rtab[2 * L + g.HH + hw]; nvalid = (nh | nw) >= 0; noff = nvalid ? nh + nw : 0; }
+        for (int hd0 = 0; hd0 < g.HD; hd0 += UB) {
+            float xv[UB], zv[UB]; bool ok[UB];
+#pragma unroll
+            for (int k = 0; k < UB; ++k) {
+                const int hd = hd0 + k < g.HD ? hd0 + k : g.HD - 1;
+                int rd = pd0 + hd;
+                const int qd = rd + g.npad;
+                const bool dvalid = resolve_pos(rd, g.D, g.pad_mode);
+                xv[k] = ld_global(sbase + (dvalid ? rd * splane : 0) + coff);
+                ok[k] = dvalid && cvalid;
+                zv[k] = 0.f;
+                if (NOISE) {
+                    const bool nd = dvalid && qd >= 0 && qd < ND;
+                    const float z = ld_global(nbase + (nd ? qd * nplane : 0) + noff);
+                    zv[k] = (nd && nvalid) ? z : 0.f;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < UB; ++k) {
+                if (hd0 + k < g.HD) {
+                    float y = xv[k] * sc0 + sf0;
+                    y = fmaxf(y, y * slope) + zv[k];
+                    const float v[8] = {ok[k] ? y : 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    const float z8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    T* row = (T*)(halo + (size_t)(hd0 + k) * plane + hoff);
+                    store8<T>(row, v);
+                    for (int b = 1; b < ngrp; ++b) store8<T>(row + 8 * b, z8);
+                }
+            }
+        }
     }
 }
 
 template <typename T, bool NOISE, int UB = 4>
-__device__ __forceinline__ void stage_halo_tile(const GatherIn& g, char* halo, const float* scs, const int* vtab, const int* rtab,
-                                              int n, int od0, int oh0, int ow0, int chunk, int tid) {
-    const int gpc = g.CK >> 3;
-    const int vstride = 256 / gpc;
-    if (tid >= vstride * gpc) return;
-    const int cg = tid % gpc, vl = tid / gpc;
-    const int nvox = g.HD * g.HH * g.HW;
-    const int c = chunk * g.CK + cg * 8;
-    const int ND = g.D + 2 * g.npad, NH = g.H + 2 * g.npad, NW = g.W + 2 * g.npad;
-    const int qd0 = od0 * g.istr + g.tmin_d + g.npad, qh0 = oh0 * g.istr + g.tmin_h + g.npad, qw0 = ow0 * g.istr + g.tmin_w + g.npad;
-    if (c >= g.Cin) {                                   // channel padding of the last chunk / second group of a 1-channel source
-        const float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int hv = vl; hv < nvox; hv += vstride) store8<T>((T*)(halo + (size_t)hv * g.RS) + cg * 8, z);
+__device__ __forceinline__ void stage_halo_tile(const GatherIn& g, char* halo, const float* scs, const int* ctab, const int* rtab,
+                                                int n, int od0, int chunk, int tid) {
+    const int L = g.HH + g.HW;
+    const int ncols = stage_ncols(g);
+    const int plane = g.HH * g.HW * g.RS;                      // bytes of one halo D-plane
+    const int pd0 = od0 * g.istr + g.tmin_d;
+    const float slope = g.act == VG_ACT_RELU ? 0.f : (g.act == VG_ACT_LRELU ? VG_LRELU : 1.f);
+    const bool zero_mode = g.pad_mode != VG_PAD_REFLECT;
+    const int ND = g.D + 2 * g.npad;
+    const int nplane = (g.H + 2 * g.npad) * (g.W + 2 * g.npad) * g.Cin;       // noise elements per D-plane
+
+    if (g.Cin == 1) {
+        // single-channel source (fp32 or bf16 volume): one scalar per voxel -> channel 0 of an otherwise zero row
+        if (g.src_f32) stage_halo_c1<T, float, NOISE, UB>(g, halo, scs, ctab, rtab, n, pd0, tid);
+        else stage_halo_c1<T, bf16_t, NOISE, UB>(g, halo, scs, ctab, rtab, n, pd0, tid);
         return;
     }
-    if (g.Cin == 1) {                                   // single-channel source (fp32 or bf16 volume): one scalar per voxel
-        const float sc0 = scs[0], sf0 = scs[g.CK];
-        const size_t nb = (size_t)n * g.D * g.H * g.W;
-        for (int hv = vl; hv < nvox; hv += vstride) {
-            const int e = vtab[hv];
-            const int hd = e & 2047, hh = (e >> 11) & 2047, hw = e >> 22;
-            const int rd = rtab[hd], rh = rtab[g.HD + hh], rw = rtab[g.HD + g.HH + hw];
-            float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            if ((rd | rh | rw) >= 0) {
-                const size_t idx = nb + ((size_t)rd * g.H + rh) * g.W + rw;
-                const float x = g.src_f32 ? ((const float*)g.src0)[idx] : bf2f(((const bf16_t*)g.src0)[idx]);
-                float y = vg_act(x * sc0 + sf0, g.act);
-                if (NOISE) {
-                    const int qd = qd0 + hd, qh = qh0 + hh, qw = qw0 + hw;
-                    if (g.noise && qd >= 0 && qd < ND && qh >= 0 && qh < NH && qw >= 0 && qw < NW)
-                        y += bf2f(g.noise[((size_t)(n * ND + qd) * NH + qh) * NW + qw]);
-                }
-                v[0] = y;
-            }
-            store8<T>((T*)(halo + (size_t)hv * g.RS) + cg * 8, v);
-        }
-        return;
-    }
+
     const bool plain = !g.in_scale && g.act == VG_ACT_NONE && !NOISE;     // data-gradient operand: pure copy
     const int sh = g.shift0;
-    const bool from0 = c < g.c0;
-    const int Hs = from0 ? (g.H >> sh) : g.H, Ws = from0 ? (g.W >> sh) : g.W, Dsz = from0 ? (g.D >> sh) : g.D;
-    const int cs = from0 ? g.c0 : g.c1;
-    const int ssh = from0 ? sh : 0;
-    const T* base = from0 ? (const T*)g.src0 + (size_t)n * Dsz * Hs * Ws * cs + c
-                          : (const T*)g.src1 + (size_t)n * Dsz * Hs * Ws * cs + (c - g.c0);
-    float sc[8], sf[8];
-    if (!plain) {
+    const int dpl0 = (g.H >> sh) * (g.W >> sh) * g.c0, dpl1 = g.H * g.W * g.c1;      // source elements per D-plane
+    const T* b0 = (const T*)g.src0 + (size_t)n * (g.D >> sh) * dpl0;
+    const T* b1 = (const T*)g.src1 + (size_t)n * g.D * dpl1;
+    const bf16_t* nb = NOISE ? g.noise + (size_t)n * ND * nplane : nullptr;
+    for (int col = tid; col < ncols; col += 256) {
+        const int e = ctab[2 * col], hoff = ctab[2 * col + 1];
+        const int hh = e & 1023, hw = (e >> 10) & 1023, cg = e >> 20;
+        const int c = chunk * g.CK + cg * 8;
+        const bool from0 = c < g.c0;
+        const int set = from0 ? 0 : L;
+        const int oh = rtab[set + hh], ow = rtab[set + g.HH + hw];
+        const bool cvalid = c < g.Cin && (oh | ow) >= 0;
+        const T* pc = cvalid ? (from0 ? b0 + c : b1 + (c - g.c0)) + (oh + ow) : b0;      // invalid columns read a dummy, then zero
+        const bf16_t* pn = nullptr; bool nvalid = false;
+        if (NOISE) {
+            const int nh = rtab[2 * L + hh], nw = rtab[2 * L + g.HH + hw];
+            nvalid = cvalid && (nh | nw) >= 0;
+            pn = nb + (nvalid ? nh + nw + c : 0);
+        }
+        f32x2 sc[4], sf[4];
+        if (!plain) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { sc[j] = scs[cg * 8 + j]; sf[j] = scs[g.CK + cg * 8 + j]; }
-    }
-    for (int hv0 = vl; hv0 < nvox; hv0 += vstride * UB) {
-        Raw8<T> raw[UB];
-        Raw8<bf16_t> nz[NOISE ? UB : 1];
-        int st[UB];                 // -1: beyond the tile, 0: zero fill, 1: data, 3: data + noise
+            for (int j = 0; j < 4; ++j) {
+                sc[j] = (f32x2){scs[cg * 8 + 2 * j], scs[cg * 8 + 2 * j + 1]};
+                sf[j] = (f32x2){scs[g.CK + cg * 8 + 2 * j], scs[g.CK + cg * 8 + 2 * j + 1]};
+            }
+        }
+        for (int hd0 = 0; hd0 < g.HD; hd0 += UB) {
+            Raw8<T> raw[UB];
+            Raw8<bf16_t> nz[NOISE ? UB : 1];
+            bool ok[UB], nok[UB];
 #pragma unroll
-        for (int k = 0; k < UB; ++k) {
-            const int hv = hv0 + k * vstride;
-            st[k] = -1;
-            if (hv < nvox) {
-                const int e = vtab[hv];
-                const int hd = e & 2047, hh = (e >> 11) & 2047, hw = e >> 22;
-                const int rd = rtab[hd], rh = rtab[g.HD + hh], rw = rtab[g.HD + g.HH + hw];
-                st[k] = ((rd | rh | rw) >= 0) ? 1 : 0;
-                if (st[k]) {
-                    const int idx = (((rd >> ssh) * Hs + (rh >> ssh)) * Ws + (rw >> ssh)) * cs;      // < 2^31 elements per sample
-                    raw_load(raw[k], base + idx);
-                    if (NOISE) {
-                        const int qd = qd0 + hd, qh = qh0 + hh, qw = qw0 + hw;
-                        if (g.noise && qd >= 0 && qd < ND && qh >= 0 && qh < NH && qw >= 0 && qw < NW) {
-                            raw_load(nz[k], g.noise + (((size_t)(n * ND + qd) * NH + qh) * NW + qw) * g.Cin + c);
-                            st[k] = 3;
+            for (int k = 0; k < UB; ++k) {
+                const int hd = hd0 + k < g.HD ? hd0 + k : g.HD - 1;
+                int rd = pd0 + hd;
+                const int qd = rd + g.npad;
+                const bool dvalid = resolve_pos(rd, g.D, g.pad_mode);          // wave-uniform
+                const int s0 = dvalid ? (rd >> sh) * dpl0 : 0, s1 = dvalid ? rd * dpl1 : 0;
+                raw_load(raw[k], pc + (from0 ? s0 : s1));
+                ok[k] = dvalid && cvalid;
+                nok[k] = false;
+                if (NOISE) {
+                    const bool nd = dvalid && qd >= 0 && qd < ND;
+                    raw_load(nz[k], pn + (nd ? qd * nplane : 0));
+                    nok[k] = nd && nvalid;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < UB; ++k) {
+                if (hd0 + k < g.HD) {
+                    T* dst = (T*)(halo + (size_t)(hd0 + k) * plane + hoff);
+                    if (plain) {
+                        Raw8<T> r = raw[k];
+                        if (zero_mode || g.Cin % g.CK) raw_mask(r, ok[k]);
+                        *(Raw8<T>*)dst = r;
+                    } else {
+                        float x[8];
+                        raw_unpack(raw[k], x);
+                        stage_affine_act(x, sc, sf, slope);
+                        if (NOISE) {
+                            float z[8];
+                            raw_unpack(nz[k], z);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) x[j] += nok[k] ? z[j] : 0.f;
                         }
+                        if (zero_mode || g.Cin % g.CK) {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) x[j] = ok[k] ? x[j] : 0.f;
+                        }
+                        store8<T>(dst, x);
                     }
                 }
             }
         }
-#pragma unroll
-        for (int k = 0; k < UB; ++k) {
-            if (st[k] < 0) continue;
-            const int hv = hv0 + k * vstride;
-            T* dst = (T*)(halo + (size_t)hv * g.RS) + cg * 8;
-            if (plain && st[k] > 0) { *(Raw8<T>*)dst = raw[k]; continue; }
-            float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            if (st[k] > 0) {
-                float x[8], z[8];
-                raw_unpack(raw[k], x);
-                if (NOISE && st[k] == 3) raw_unpack(nz[k], z);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    float y = vg_act(x[j] * sc[j] + sf[j], g.act);
-                    if (NOISE && st[k] == 3) y += z[j];
-                    v[j] = y;
-                }
-            }
-            store8<T>(dst, v);
-        }
-    }
-}
-
-__device__ __forceinline__ void build_voxel_table(const GatherIn& g, int* vtab, int tid, int nthreads) {
-    const int nvox = g.HD * g.HH * g.HW;
-    for (int hv = tid; hv < nvox; hv += nthreads) {
-        const int hw = hv % g.HW; const int t2 = hv / g.HW;
-        vtab[hv] = (t2 / g.HH) | ((t2 % g.HH) << 11) | (hw << 22);
     }
 }
 
@@ -239,3 +338,5 @@ static inline int fill_gather(const vg_conv_desc* d, GatherIn& g, int CK, int BM
     return VG_OK;
 }
 static inline int halo_bytes(const GatherIn& g) { return g.HD * g.HH * g.HW * g.RS; }
+// LDS ints of the staging tables (column table + per-tile axis tables)
+static inline int stage_table_ints(const GatherIn& g) { return 2 * stage_ncols(g) + 3 * (g.HH + g.HW); }

@@ -60,12 +60,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const GatherIn g, const Wgra
     int* tapsrc = tapoff + 64;
     float* scs = (float*)((char*)tapoff + 512);
     int* utab = (int*)(scs + 2 * g.CK);
-    int* rtab = utab + g.HD * g.HH * g.HW;
+    int* rtab = utab + 2 * stage_ncols(g);
 
     if (tid < g.ntaps)
         tapoff[tid] = (((g.td[tid] - g.tmin_d) * g.HH + (g.th[tid] - g.tmin_h)) * g.HW + (g.tw[tid] - g.tmin_w)) * g.RS;
     if (tid < VG_MAX_TAPS) tapsrc[tid] = p.tap_src[tid];
-    build_voxel_table(g, utab, tid, 256);
+    build_column_table(g, utab, tid);
     __syncthreads();
 
     // rows of this wave: r = wave + 4*j -> (tap, ci16); byte offset of the row's P fragment inside the halo tile
@@ -102,37 +102,40 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const GatherIn g, const Wgra
             stage_scale_shift(g, scs, n, cib, tid);
             cur_n = n;
         }
-        stage_resolve_axes(g, rtab, od0, oh0, ow0, tid);
+        stage_resolve_axes(g, rtab, oh0, ow0, tid);
         __syncthreads();
-        if (!(g.dbg & 1) || tile == (int)blockIdx.x) stage_halo_tile<T, NOISE, 2>(g, halo, scs, utab, rtab, n, od0, oh0, ow0, cib, tid);
+        if (!(g.dbg & 1) || tile == (int)blockIdx.x) stage_halo_tile<T, NOISE, 2>(g, halo, scs, utab, rtab, n, od0, cib, tid);
         if (!(g.dbg & 2) || tile == (int)blockIdx.x)
-        // ---- stage dY tile [BM][16*Q] (zero outside the grid / beyond Cout): all loads first ----
+        // ---- stage dY tile [BM][16*Q] (zero outside the grid / beyond Cout).  Straight-line: out-of-range units load a
+        // clamped address and are zeroed afterwards, so the four loads of a batch are in flight together ----
         for (int u0 = tid; u0 < BM * gcol; u0 += 256 * 4) {
-            Raw8<T> raw[4]; float y1[4]; int mm[4]; bool ok[4];
+            Raw8<T> raw[4]; float y1[4]; bool ok[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const int u = u0 + k * 256;
-                mm[k] = -1; ok[k] = false; y1[k] = 0.f;
-                if (u < BM * gcol) {
-                    const int m = u >> gcol_l, cg = u & (gcol - 1);
-                    const int w = m & TWm, h = (m >> g.twl) & THm, d = m >> (g.twl + g.thl);
-                    const int od = od0 + d, oh = oh0 + h, ow = ow0 + w;
-                    const int c = cob * p.COB + cg * 8;
-                    mm[k] = (m << 4) | cg;
-                    ok[k] = od < p.OD && oh < p.OH && ow < p.OW && c < p.Cout;
-                    if (ok[k]) {
-                        const size_t vox = ((size_t)(n * p.OD + od) * p.OH + oh) * p.OW + ow;
-                        if (p.Cout == 1) y1[k] = p.dy_f32 ? ((const float*)p.dy)[vox] : bf2f(((const bf16_t*)p.dy)[vox]);
-                        else raw_load(raw[k], (const T*)p.dy + vox * p.Cout + c);
-                    }
-                }
+                const int u = min(u0 + k * 256, BM * gcol - 1);
+                const int m = u >> gcol_l, cg = u & (gcol - 1);
+                const int w = m & TWm, h = (m >> g.twl) & THm, d = m >> (g.twl + g.thl);
+                const int od = od0 + d, oh = oh0 + h, ow = ow0 + w;
+                const int c = cob * p.COB + cg * 8;
+                ok[k] = od < p.OD && oh < p.OH && ow < p.OW && c < p.Cout;
+                const size_t vox = ok[k] ? ((size_t)(n * p.OD + od) * p.OH + oh) * p.OW + ow : 0;
+                if (p.Cout == 1) y1[k] = p.dy_f32 ? ((const float*)p.dy)[vox] : bf2f(((const bf16_t*)p.dy)[vox]);
+                else raw_load(raw[k], (const T*)p.dy + vox * p.Cout + (ok[k] ? c : 0));
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                if (mm[k] < 0) continue;
-                float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                if (ok[k]) { if (p.Cout == 1) v[0] = y1[k]; else raw_unpack(raw[k], v); }
-                store8<T>((T*)(dyt + (size_t)(mm[k] >> 4) * p.DYS) + (mm[k] & 15) * 8, v);
+                const int u = u0 + k * 256;
+                if (u < BM * gcol) {
+                    const int m = u >> gcol_l, cg = u & (gcol - 1);
+                    T* dst = (T*)(dyt + (size_t)m * p.DYS) + cg * 8;
+                    if (p.Cout == 1) {
+                        const float v[8] = {ok[k] ? y1[k] : 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        store8<T>(dst, v);
+                    } else {
+                        raw_mask(raw[k], ok[k]);
+                        *(Raw8<T>*)dst = raw[k];
+                    }
+                }
             }
         }
         VG_WSTAMP(1);
@@ -289,7 +292,7 @@ extern "C" int vg_conv3d_wgrad(const vg_conv_desc* d, const void* dy, int dy_f32
                 if (Cinp % c) continue;
                 int rc = fill_gather(d, g, c, bm);
                 if (rc != VG_OK) return rc;
-                const int lds = halo_bytes(g) + bm * (COB * esz + 16) + 512 + 2 * c * 4 + (g.HD * g.HH * g.HW + g.HD + g.HH + g.HW) * 4;
+                const int lds = halo_bytes(g) + bm * (COB * esz + 16) + 512 + 2 * c * 4 + stage_table_ints(g) * 4;
                 if (lds <= limit) { best_bm = bm; best_cib = c; best_lds = lds; break; }
             }
     }
