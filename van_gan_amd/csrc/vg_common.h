@@ -86,3 +86,30 @@ static inline int vg_check_launch() {
 static inline int ilog2_exact(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 static inline int pow2_ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// raw 8-channel vector as loaded from global memory
+template <typename T> struct Raw8;
+template <> struct Raw8<bf16_t> { bf16x8 v; };
+template <> struct Raw8<float> { f32x4 a, b; };
+// global address space stated explicitly: a source pointer selected per lane (virtual concat) would otherwise be generic
+// and the load a flat_load (slower, and it ties up the LDS counter as well)
+__device__ __forceinline__ void raw_load(Raw8<bf16_t>& r, const bf16_t* p) { r.v = *(const __attribute__((address_space(1))) bf16x8*)(uintptr_t)p; }
+__device__ __forceinline__ void raw_load(Raw8<float>& r, const float* p) {
+    const __attribute__((address_space(1))) f32x4* q = (const __attribute__((address_space(1))) f32x4*)(uintptr_t)p;
+    r.a = q[0]; r.b = q[1];
+}
+__device__ __forceinline__ void raw_unpack(const Raw8<bf16_t>& r, float* o) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = bf2f((bf16_t)r.v[j]);
+}
+__device__ __forceinline__ void raw_unpack(const Raw8<float>& r, float* o) {
+    o[0] = r.a[0]; o[1] = r.a[1]; o[2] = r.a[2]; o[3] = r.a[3]; o[4] = r.b[0]; o[5] = r.b[1]; o[6] = r.b[2]; o[7] = r.b[3];
+}
+
+
+__device__ __forceinline__ void raw_mask(Raw8<bf16_t>& r, bool keep) { if (!keep) r.v = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0}; }
+__device__ __forceinline__ void raw_mask(Raw8<float>& r, bool keep) { if (!keep) { r.a = (f32x4){0.f, 0.f, 0.f, 0.f}; r.b = r.a; } }
+
+__device__ __forceinline__ float ld_global(const float* p) { return *(const __attribute__((address_space(1))) float*)(uintptr_t)p; }
+__device__ __forceinline__ float ld_global(const bf16_t* p) { return bf2f(*(const __attribute__((address_space(1))) bf16_t*)(uintptr_t)p); }
+

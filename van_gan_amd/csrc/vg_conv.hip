@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256, ((BN / 16) * MSUB >= 8 ? 2 : VG_CONV_WAVES)) v
             if (p.nchunks > 1) stage_scale_shift(g, scs, n, chunk, tid);
             if (chunk == 0) stage_resolve_axes(g, rtab, oh0, ow0, tid);
             if (p.nchunks > 1 || chunk == 0) __syncthreads();
-            if (!(g.dbg & 1)) stage_halo_tile<T, NOISE>(g, halo, scs, utab, rtab, n, od0, chunk, tid);
+            if (!(g.dbg & 1)) stage_halo_tile<T, NOISE, (NOISE ? 4 : 6)>(g, halo, scs, utab, rtab, n, od0, chunk, tid);
             if (chunk == 0) VG_STAMP(1);
             __syncthreads();
             if (chunk == 0) VG_STAMP(2);

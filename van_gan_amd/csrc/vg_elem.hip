@@ -62,124 +62,190 @@ struct ANB {
     int gpc, vpb;      // channel groups per voxel, voxels per block-iteration
 };
 
-// folded upstream gradient for VEC channels at voxel (d,h,w): transpose of reflect-pad-1
-template <typename T, int VEC>
-__device__ __forceinline__ void load_g(const ANB& p, int n, int d, int h, int w, int c, float* out) {
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) out[j] = 0.f;
-    const T* gp = (const T*)p.g;
-    if (!p.g_padded) {
-        const size_t idx = ((((size_t)n * p.D + d) * p.H + h) * p.W + w) * p.C + c;
-        if (VEC == 8) load8<T>(gp + idx, out);
-        else out[0] = ld1<T>(gp + idx);
-        return;
-    }
-    const int PD = p.D + 2, PH = p.H + 2, PW = p.W + 2;
-    int qd[3], qh[3], qw[3], nd = 0, nh = 0, nw = 0;
-    qd[nd++] = d + 1; if (d == 1) qd[nd++] = 0; if (d == p.D - 2) qd[nd++] = p.D + 1;
-    qh[nh++] = h + 1; if (h == 1) qh[nh++] = 0; if (h == p.H - 2) qh[nh++] = p.H + 1;
-    qw[nw++] = w + 1; if (w == 1) qw[nw++] = 0; if (w == p.W - 2) qw[nw++] = p.W + 1;
-    for (int a = 0; a < nd; ++a)
-        for (int b = 0; b < nh; ++b)
-            for (int e = 0; e < nw; ++e) {
-                const size_t idx = ((((size_t)n * PD + qd[a]) * PH + qh[b]) * PW + qw[e]) * p.C + c;
-                if (VEC == 8) {
-                    float r[8]; load8<T>(gp + idx, r);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) out[j] += r[j];
-                } else out[0] += ld1<T>(gp + idx);
-            }
-}
-
-template <typename T, int VEC>
-__device__ __forceinline__ void load_x(const ANB& p, int n, int d, int h, int w, int c, float* x) {
-    if (VEC == 8) {
-        if (p.x1) {
-            if (c < p.c_x0) {
-                const int sh = p.x0_shift;
-                const size_t idx = ((((size_t)n * (p.D >> sh) + (d >> sh)) * (p.H >> sh) + (h >> sh)) * (p.W >> sh) + (w >> sh)) * p.c_x0 + c;
-                load8<T>((const T*)p.x + idx, x);
-            } else {
-                const size_t idx = ((((size_t)n * p.D + d) * p.H + h) * p.W + w) * (p.C - p.c_x0) + (c - p.c_x0);
-                load8<T>((const T*)p.x1 + idx, x);
-            }
-        } else {
-            const size_t idx = ((((size_t)n * p.D + d) * p.H + h) * p.W + w) * p.C + c;
-            load8<T>((const T*)p.x + idx, x);
-        }
-    } else {
-        const size_t idx = (((size_t)n * p.D + d) * p.H + h) * p.W + w;
-        x[0] = p.x_f32 ? ((const float*)p.x)[idx] : bf2f(((const bf16_t*)p.x)[idx]);
-    }
-}
-
 // per-thread channel constants (the thread owns channels c..c+VEC-1 of sample n for its whole walk)
 template <int VEC> struct ChanK { float sc[VEC], sh[VEC], mu[VEC], rs[VEC], ml[VEC]; };
+__device__ __forceinline__ void ldvec(const float* p, float* o, int n) {       // n = 8 (two 16-byte loads) or 1
+    if (n == 8) {
+        const __attribute__((address_space(1))) f32x4* q = (const __attribute__((address_space(1))) f32x4*)(uintptr_t)p;
+        const f32x4 a = q[0], b = q[1];
+        o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
+    } else o[0] = *p;
+}
 template <int VEC>
 __device__ __forceinline__ void load_chank(const ANB& p, int n, int c, ChanK<VEC>& k) {
+    const int nc = n * p.C + c;
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-        const int nc = n * p.C + c + j;
-        k.sc[j] = p.scale ? p.scale[nc] : 1.f; k.sh[j] = p.scale ? p.shift[nc] : 0.f;
-        k.mu[j] = p.norm ? p.mean[nc] : 0.f; k.rs[j] = p.norm ? p.rstd[nc] : 0.f;
-        k.ml[j] = p.mult ? p.mult[nc] : 1.f;
-    }
+    for (int j = 0; j < VEC; ++j) { k.sc[j] = 1.f; k.sh[j] = 0.f; k.mu[j] = 0.f; k.rs[j] = 0.f; k.ml[j] = 1.f; }
+    if (p.scale) { ldvec(p.scale + nc, k.sc, VEC); ldvec(p.shift + nc, k.sh, VEC); }
+    if (p.norm) { ldvec(p.mean + nc, k.mu, VEC); ldvec(p.rstd + nc, k.rs, VEC); }
+    if (p.mult) ldvec(p.mult + nc, k.ml, VEC);
 }
 
-// dn for VEC channels; also returns xhat when norm
-template <typename T, int VEC>
-__device__ __forceinline__ void compute_dn(const ANB& p, const ChanK<VEC>& k, int n, int d, int h, int w, int c, float* dn, float* xh) {
-    float g[VEC];
-    load_g<T, VEC>(p, n, d, h, w, c, g);
+template <typename T, int VEC> struct RawV;
+template <typename T> struct RawV<T, 8> { Raw8<T> r; };
+template <typename T> struct RawV<T, 1> { float r; };
+template <typename T> __device__ __forceinline__ void rawv_load(RawV<T, 8>& o, const T* p) { raw_load(o.r, p); }
+template <typename T> __device__ __forceinline__ void rawv_load(RawV<T, 1>& o, const T* p) { o.r = ld_global(p); }
+template <typename T> __device__ __forceinline__ void rawv_unpack(const RawV<T, 8>& o, float* v) { raw_unpack(o.r, v); }
+template <typename T> __device__ __forceinline__ void rawv_unpack(const RawV<T, 1>& o, float* v) { v[0] = o.r; }
+
+// The walk shared by the statistics and the apply pass.  A thread owns VEC channels and visits voxels
+// v0, v0 + stride, ...; UB voxels are handled per iteration with all their loads (upstream gradient at the interior
+// position of the padded grid, pre-activation input) issued back to back on clamped addresses -- a conditional load
+// makes the compiler drain the memory counter before the next one, which is what made the first version of these
+// kernels latency-bound at ~1 TB/s.  (d, h, w) advance incrementally (no per-voxel division).  The transpose of the
+// reflection pad only adds terms on the two planes next to each face: a rare divergent tail after the main loads.
+template <typename T, int VEC, int UB, typename F>
+__device__ __forceinline__ void anb_walk(const ANB& p, int n, int c, int vl, const ChanK<VEC>& ck, F&& consume) {
+    const int S = p.D * p.H * p.W;
+    const int stride = gridDim.x * p.vpb;
+    int v = blockIdx.x * p.vpb + vl;
+    if (v >= S) return;
+    int w = v % p.W, t0 = v / p.W; int h = t0 % p.H, d = t0 / p.H;
+    const int sw = stride % p.W, t1 = stride / p.W; const int sh_ = t1 % p.H, sd = t1 / p.H;
+    const int PH = p.H + 2, PW = p.W + 2;
+    const T* gp = (const T*)p.g + (p.g_padded ? (size_t)n * (p.D + 2) * PH * PW * p.C : (size_t)n * S * p.C) + c;
     const bool need_x = p.act != VG_ACT_NONE || p.norm;
-    float x[VEC];
-    if (need_x) load_x<T, VEC>(p, n, d, h, w, c, x);
+    const bool cat0 = p.x1 && c < p.c_x0;                 // virtual concat: low-resolution source (nearest upsample)
+    const int xs = p.x1 ? p.x0_shift : 0;
+    const int Hs = p.H >> xs, Ws = p.W >> xs;
+    const int cx = p.x1 ? (cat0 ? p.c_x0 : p.C - p.c_x0) : p.C;
+    const T* xp = nullptr;
+    if (VEC == 8) xp = p.x1 ? (cat0 ? (const T*)p.x + (size_t)n * (p.D >> xs) * Hs * Ws * cx + c : (const T*)p.x1 + (size_t)n * S * cx + (c - p.c_x0))
+                            : (const T*)p.x + (size_t)n * S * cx + c;
+    const void* x1p = (const char*)p.x + (size_t)n * S * (p.x_f32 ? 4 : 2);      // VEC == 1: f32 or bf16 volume
+    for (; v < S; v += UB * stride) {
+        RawV<T, VEC> gr[UB], xr[UB];
+        float x1v[UB];
+        int vv[UB], dd[UB], hh[UB], ww[UB];
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-        float v = g[j] * k.ml[j];
-        if (p.act != VG_ACT_NONE) v *= vg_act_grad(x[j] * k.sc[j] + k.sh[j], p.act);
-        dn[j] = v;
-        xh[j] = p.norm ? (x[j] - k.mu[j]) * k.rs[j] : 0.f;
+        for (int k = 0; k < UB; ++k) {
+            const bool ok = v + k * stride < S;
+            vv[k] = ok ? v + k * stride : -1;
+            dd[k] = d; hh[k] = h; ww[k] = w;
+            const int vc = ok ? v + k * stride : v;                       // clamped: re-reads voxel 0 of the batch
+            const int dc = ok ? d : dd[0], hc = ok ? h : hh[0], wc = ok ? w : ww[0];
+            const size_t gi = p.g_padded ? ((size_t)((dc + 1) * PH + hc + 1) * PW + wc + 1) * p.C : (size_t)vc * p.C;
+            rawv_load(gr[k], gp + gi);
+            if (need_x) {
+                if (VEC == 8) {
+                    const size_t xi = cat0 ? ((size_t)((dc >> xs) * Hs + (hc >> xs)) * Ws + (wc >> xs)) * cx : (size_t)vc * cx;
+                    rawv_load(xr[k], xp + xi);
+                } else {
+                    x1v[k] = p.x_f32 ? ld_global((const float*)x1p + vc) : ld_global((const bf16_t*)x1p + vc);
+                }
+            }
+            // advance (d, h, w) by the stride
+            w += sw; if (w >= p.W) { w -= p.W; ++h; }
+            h += sh_; if (h >= p.H) { h -= p.H; ++d; }
+            d += sd;
+        }
+#pragma unroll
+        for (int k = 0; k < UB; ++k) {
+            if (vv[k] < 0) continue;
+            float g[VEC], x[VEC];
+            rawv_unpack(gr[k], g);
+            if (need_x) { if (VEC == 8) rawv_unpack(xr[k], x); else x[0] = x1v[k]; }
+            if (p.g_padded) {
+                const int dk = dd[k], hk = hh[k], wk = ww[k];
+                const bool dhb = dk == 1 || dk == p.D - 2 || hk == 1 || hk == p.H - 2;
+                const bool wb = wk == 1 || wk == p.W - 2;
+                if (dhb) {
+                    // reflected copies: every combination of {own, mirrored} per axis except the all-own one (already loaded)
+                    int qd[3], qh[3], qw[3], nd = 0, nh = 0, nw = 0;
+                    qd[nd++] = dk + 1; if (dk == 1) qd[nd++] = 0; if (dk == p.D - 2) qd[nd++] = p.D + 1;
+                    qh[nh++] = hk + 1; if (hk == 1) qh[nh++] = 0; if (hk == p.H - 2) qh[nh++] = p.H + 1;
+                    qw[nw++] = wk + 1; if (wk == 1) qw[nw++] = 0; if (wk == p.W - 2) qw[nw++] = p.W + 1;
+                    for (int a = 0; a < nd; ++a)
+                        for (int b = 0; b < nh; ++b)
+                            for (int e = 0; e < nw; ++e) {
+                                if ((a | b | e) == 0) continue;
+                                const size_t idx = ((size_t)(qd[a] * PH + qh[b]) * PW + qw[e]) * p.C;
+                                if (VEC == 8) {
+                                    float r[8]; load8<T>(gp + idx, r);
+#pragma unroll
+                                    for (int j = 0; j < 8; ++j) g[j] += r[j];
+                                } else g[0] += ld1<T>(gp + idx);
+                            }
+                } else if (wb) {
+                    // the common border case (two voxels of every row): one or two mirrored copies along W only
+                    const size_t rowi = (size_t)((dk + 1) * PH + hk + 1) * PW;
+                    float r[VEC];
+                    if (wk == 1) {
+                        if (VEC == 8) load8<T>(gp + rowi * p.C, r); else r[0] = ld1<T>(gp + rowi * p.C);
+#pragma unroll
+                        for (int j = 0; j < VEC; ++j) g[j] += r[j];
+                    }
+                    if (wk == p.W - 2) {
+                        if (VEC == 8) load8<T>(gp + (rowi + p.W + 1) * p.C, r); else r[0] = ld1<T>(gp + (rowi + p.W + 1) * p.C);
+#pragma unroll
+                        for (int j = 0; j < VEC; ++j) g[j] += r[j];
+                    }
+                }
+            }
+            float dn[VEC], xh[VEC];
+            const float slope = p.act == VG_ACT_RELU ? 0.f : (p.act == VG_ACT_LRELU ? VG_LRELU : 1.f);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                float gv = g[j] * ck.ml[j];
+                if (need_x) {
+                    const float pre = x[j] * ck.sc[j] + ck.sh[j];
+                    gv *= (pre > 0.f || p.act == VG_ACT_NONE) ? 1.f : slope;      // TP: LeakyRelu/ReLU grad uses pre > 0
+                    xh[j] = (x[j] - ck.mu[j]) * ck.rs[j];
+                } else xh[j] = 0.f;
+                dn[j] = gv;
+            }
+            consume(vv[k], dn, xh);
+        }
     }
 }
 
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void actnorm_stats_kernel(const ANB p) {
-    __shared__ float red[512 * 2];          // [channel][2] block accumulators (C <= 512)
+    __shared__ float part[16 * 256];         // [value j][thread]: this block's per-thread partial sums
+    __shared__ float red[512 * 2];           // [channel][2] block result (C <= 512)
     const int n = blockIdx.y;
-    for (int i = threadIdx.x; i < p.C * 2; i += 256) red[i] = 0.f;
-    __syncthreads();
     const int tid = threadIdx.x;
     const int nthr = p.gpc * p.vpb;
     const int cg = tid % p.gpc, vl = tid / p.gpc;
-    const int S = p.D * p.H * p.W;
     float s0[VEC], s1[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) { s0[j] = 0.f; s1[j] = 0.f; }
     if (tid < nthr) {
         ChanK<VEC> ck;
         load_chank<VEC>(p, n, cg * VEC, ck);
-#pragma unroll 2
-        for (int v = blockIdx.x * p.vpb + vl; v < S; v += gridDim.x * p.vpb) {
-            const int w = v % p.W; const int t = v / p.W; const int h = t % p.H, d = t / p.H;
-            float dn[VEC], xh[VEC];
-            compute_dn<T, VEC>(p, ck, n, d, h, w, cg * VEC, dn, xh);
+        anb_walk<T, VEC, 4>(p, n, cg * VEC, vl, ck, [&](int, const float* dn, const float* xh) {
 #pragma unroll
             for (int j = 0; j < VEC; ++j) { s0[j] += dn[j]; s1[j] += dn[j] * xh[j]; }
-        }
+        });
     }
-    // block reduction through LDS float atomics, then ONE contiguous global atomic per (channel, moment)
-    if (tid < nthr) {
+    // block reduction without atomics: partials to LDS (value-major: conflict-free), then thread (channel, moment)
+    // adds the vpb partials of its channel group in a fixed order; ONE contiguous global atomic per (channel, moment)
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-            atomicAdd(&red[(cg * VEC + j) * 2], s0[j]);
-            atomicAdd(&red[(cg * VEC + j) * 2 + 1], s1[j]);
-        }
+    for (int j = 0; j < VEC; ++j) { part[(2 * j) * 256 + tid] = tid < nthr ? s0[j] : 0.f; part[(2 * j + 1) * 256 + tid] = tid < nthr ? s1[j] : 0.f; }
+    __syncthreads();
+    for (int o = tid; o < p.C * 2; o += 256) {
+        const int ch = o >> 1, mom = o & 1;
+        const int g8 = ch / VEC, j = ch - g8 * VEC;
+        const float* src = part + (2 * j + mom) * 256 + g8;
+        float a = 0.f;
+        for (int t = 0; t < p.vpb; ++t) a += src[t * p.gpc];
+        red[o] = a;
     }
     __syncthreads();
     const int stripe = blockIdx.x & (VG_STRIPES - 1);
     float* dst = p.red + ((size_t)stripe * p.N + n) * p.C * 2;
     for (int i = tid; i < p.C * 2; i += 256) atomicAdd(&dst[i], red[i]);
+}
+
+// stripe 0 += stripes 1..7, which are then cleared (a later sum over all stripes stays correct): the apply pass and the
+// parameter-gradient kernel read 2 values per channel instead of 16
+__global__ void anb_fold_stripes_kernel(float* red, int total) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    float a = red[i];
+    for (int t = 1; t < VG_STRIPES; ++t) { a += red[(size_t)t * total + i]; red[(size_t)t * total + i] = 0.f; }
+    red[i] = a;
 }
 
 template <typename T, int VEC>
@@ -191,24 +257,24 @@ __global__ __launch_bounds__(256) void actnorm_apply_kernel(const ANB p) {
     const int cg = tid % p.gpc, vl = tid / p.gpc;
     const int S = p.D * p.H * p.W;
     const int c = cg * VEC;
+    // coefficients of dx = k0*dn - k1 - k2*xhat; the striped sums were folded into stripe 0 after the statistics pass
     float k0[VEC], k1[VEC], k2[VEC];
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-        if (p.norm) {
-            const int nc = n * p.C + c + j;
-            const float gr = p.gamma[c + j] * p.rstd[nc];
-            float r0 = 0.f, r1 = 0.f;
-            for (int t = 0; t < VG_STRIPES; ++t) { r0 += p.red[((size_t)t * p.N * p.C + nc) * 2]; r1 += p.red[((size_t)t * p.N * p.C + nc) * 2 + 1]; }
-            k0[j] = gr; k1[j] = gr * r0 / (float)S; k2[j] = gr * r1 / (float)S;
-        } else { k0[j] = 1.f; k1[j] = 0.f; k2[j] = 0.f; }
+    for (int j = 0; j < VEC; ++j) { k0[j] = 1.f; k1[j] = 0.f; k2[j] = 0.f; }
+    if (p.norm) {
+        const int nc = n * p.C + c;
+        float gm[VEC], rs[VEC], r[2 * VEC];
+        ldvec(p.gamma + c, gm, VEC); ldvec(p.rstd + nc, rs, VEC);
+        ldvec(p.red + (size_t)nc * 2, r, VEC);
+        if (VEC == 8) ldvec(p.red + (size_t)nc * 2 + 8, r + 8, VEC); else r[1] = p.red[(size_t)nc * 2 + 1];
+        const float cnt = (float)S;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { const float gr = gm[j] * rs[j]; k0[j] = gr; k1[j] = gr * r[2 * j] / cnt; k2[j] = gr * r[2 * j + 1] / cnt; }
     }
     ChanK<VEC> ck;
     load_chank<VEC>(p, n, c, ck);
-#pragma unroll 2
-    for (int v = blockIdx.x * p.vpb + vl; v < S; v += gridDim.x * p.vpb) {
-        const int w = v % p.W; const int t = v / p.W; const int h = t % p.H, d = t / p.H;
-        float dn[VEC], xh[VEC], o[VEC];
-        compute_dn<T, VEC>(p, ck, n, d, h, w, c, dn, xh);
+    anb_walk<T, VEC, 4>(p, n, c, vl, ck, [&](int v, const float* dn, const float* xh) {
+        float o[VEC];
 #pragma unroll
         for (int j = 0; j < VEC; ++j) o[j] = k0[j] * dn[j] - k1[j] - k2[j] * xh[j];
         const size_t oidx = ((size_t)n * S + v) * p.dx_cstride + p.dx_coff + c;
@@ -228,7 +294,7 @@ __global__ __launch_bounds__(256) void actnorm_apply_kernel(const ANB p) {
             bf16_t* q = (bf16_t*)p.dx + oidx;
             q[0] = f2bf(p.accumulate ? bf2f(q[0]) + o[0] : o[0]);
         }
-    }
+    });
 }
 
 static int fill_anb(const vg_actnorm_bwd_desc* d, ANB& p, bool apply) {
@@ -261,7 +327,9 @@ static dim3 anb_grid(const ANB& p, bool stats = false) {
         const char* e = getenv("VG_ANB_GRID_CAP"); cap_total = e ? atoi(e) : 2048;
         const char* e2 = getenv("VG_ANB_STATS_CAP"); cap_stats = e2 ? atoi(e2) : 1024;
     }
-    const int cap = (stats ? cap_stats : cap_total) / (p.N > 0 ? p.N : 1) + 1;
+    // whole launch resident at once (8 blocks per CU): one block more than that runs alone afterwards and doubles the time
+    int cap = (stats ? cap_stats : cap_total) / (p.N > 0 ? p.N : 1);
+    if (cap < 1) cap = 1;
     if (bx > cap) bx = cap;
     return dim3(bx, p.N);
 }
@@ -278,6 +346,8 @@ extern "C" int vg_actnorm_bwd_stats(const vg_actnorm_bwd_desc* d, vg_stream_t st
         if (p.C == 1) hipLaunchKernelGGL((actnorm_stats_kernel<bf16_t, 1>), anb_grid(p, true), dim3(256), 0, (hipStream_t)stream, p);
         else hipLaunchKernelGGL((actnorm_stats_kernel<bf16_t, 8>), anb_grid(p, true), dim3(256), 0, (hipStream_t)stream, p);
     }
+    const int total = p.N * p.C * 2;
+    hipLaunchKernelGGL(anb_fold_stripes_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, p.red, total);
     return vg_check_launch();
 }
 extern "C" int vg_actnorm_bwd_apply(const vg_actnorm_bwd_desc* d, vg_stream_t stream) {

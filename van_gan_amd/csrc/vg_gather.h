@@ -42,29 +42,6 @@ __device__ __forceinline__ void stage_scale_shift(const GatherIn& g, float* scs,
     }
 }
 
-// raw 8-channel vector as loaded from global memory
-template <typename T> struct Raw8;
-template <> struct Raw8<bf16_t> { bf16x8 v; };
-template <> struct Raw8<float> { f32x4 a, b; };
-// global address space stated explicitly: a source pointer selected per lane (virtual concat) would otherwise be generic
-// and the load a flat_load (slower, and it ties up the LDS counter as well)
-__device__ __forceinline__ void raw_load(Raw8<bf16_t>& r, const bf16_t* p) { r.v = *(const __attribute__((address_space(1))) bf16x8*)(uintptr_t)p; }
-__device__ __forceinline__ void raw_load(Raw8<float>& r, const float* p) {
-    const __attribute__((address_space(1))) f32x4* q = (const __attribute__((address_space(1))) f32x4*)(uintptr_t)p;
-    r.a = q[0]; r.b = q[1];
-}
-__device__ __forceinline__ void raw_unpack(const Raw8<bf16_t>& r, float* o) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = bf2f((bf16_t)r.v[j]);
-}
-__device__ __forceinline__ void raw_unpack(const Raw8<float>& r, float* o) {
-    o[0] = r.a[0]; o[1] = r.a[1]; o[2] = r.a[2]; o[3] = r.a[3]; o[4] = r.b[0]; o[5] = r.b[1]; o[6] = r.b[2]; o[7] = r.b[3];
-}
-
-
-__device__ __forceinline__ void raw_mask(Raw8<bf16_t>& r, bool keep) { if (!keep) r.v = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0}; }
-__device__ __forceinline__ void raw_mask(Raw8<float>& r, bool keep) { if (!keep) { r.a = (f32x4){0.f, 0.f, 0.f, 0.f}; r.b = r.a; } }
-
 // ------------------------------------------------------------------------------------------------------------------
 // Halo staging by COLUMNS.  A column is one (hh, hw, 8-channel group) of the halo tile; a thread owns whole columns and
 // walks them along D.  Everything per-lane is resolved once per column (H/W reflection or zero padding, source of the
@@ -126,8 +103,20 @@ __device__ __forceinline__ void stage_affine_act(float* x, const f32x2* sc, cons
     }
 }
 
-__device__ __forceinline__ float ld_global(const float* p) { return *(const __attribute__((address_space(1))) float*)(uintptr_t)p; }
-__device__ __forceinline__ float ld_global(const bf16_t* p) { return bf2f(*(const __attribute__((address_space(1))) bf16_t*)(uintptr_t)p); }
+// Work split of a tile: few columns (thin tiles) are additionally split into D segments so that all 256 threads carry
+// loads; otherwise threads take whole columns round-robin.  Returns this thread's first column, column stride, and D range.
+struct StageSplit { int col0, cstride, hd_lo, hd_hi; };
+__device__ __forceinline__ StageSplit stage_split(int ncols, int HD, int tid) {
+    StageSplit sp = {tid, 256, 0, HD};
+    if (ncols <= 128) {
+        int nseg = 256 / ncols; if (nseg > HD) nseg = HD;
+        const int seglen = (HD + nseg - 1) / nseg;
+        const int seg = tid / ncols;
+        sp.col0 = seg < nseg ? tid - seg * ncols : ncols;         // surplus threads idle
+        sp.hd_lo = seg * seglen; sp.hd_hi = min(HD, sp.hd_lo + seglen);
+    }
+    return sp;
+}
 
 // single-channel source of element type S (the fp32 input volumes, bf16 logits/gradients)
 template <typename T, typename S, bool NOISE, int UB>
@@ -144,7 +133,8 @@ __device__ __forceinline__ void stage_halo_c1(const GatherIn& g, char* halo, con
     const S* sbase = (const S*)g.src0 + (size_t)n * g.D * splane;
     const bf16_t* nbase = NOISE ? g.noise + (size_t)n * ND * nplane : nullptr;
     const int ngrp = g.CK >> 3;
-    for (int col = tid; col < ncols; col += 256) {
+    const StageSplit sp = stage_split(ncols, g.HD, tid);
+    for (int col = sp.col0; col < ncols; col += sp.cstride) {
         const int e = ctab[2 * col], hoff = ctab[2 * col + 1];
         const int hh = e & 1023, hw = (e >> 10) & 1023;
         const int oh = rtab[hh], ow = rtab[g.HH + hw];
@@ -152,11 +142,11 @@ __device__ __forceinline__ void stage_halo_c1(const GatherIn& g, char* halo, con
         const int coff = cvalid ? oh + ow : 0;
         int noff = 0; bool nvalid = false;
         if (NOISE) { const int nh = rtab[2 * L + hh], nw = rtab[2 * L + g.HH + hw]; nvalid = (nh | nw) >= 0; noff = nvalid ? nh + nw : 0; }
-        for (int hd0 = 0; hd0 < g.HD; hd0 += UB) {
+        for (int hd0 = sp.hd_lo; hd0 < sp.hd_hi; hd0 += UB) {
             float xv[UB], zv[UB]; bool ok[UB];
 #pragma unroll
             for (int k = 0; k < UB; ++k) {
-                const int hd = hd0 + k < g.HD ? hd0 + k : g.HD - 1;
+                const int hd = hd0 + k < sp.hd_hi ? hd0 + k : sp.hd_hi - 1;
                 int rd = pd0 + hd;
                 const int qd = rd + g.npad;
                 const bool dvalid = resolve_pos(rd, g.D, g.pad_mode);
@@ -171,7 +161,7 @@ __device__ __forceinline__ void stage_halo_c1(const GatherIn& g, char* halo, con
             }
 #pragma unroll
             for (int k = 0; k < UB; ++k) {
-                if (hd0 + k < g.HD) {
+                if (hd0 + k < sp.hd_hi) {
                     float y = xv[k] * sc0 + sf0;
                     y = fmaxf(y, y * slope) + zv[k];
                     const float v[8] = {ok[k] ? y : 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -210,7 +200,8 @@ __device__ __forceinline__ void stage_halo_tile(const GatherIn& g, char* halo, c
     const T* b0 = (const T*)g.src0 + (size_t)n * (g.D >> sh) * dpl0;
     const T* b1 = (const T*)g.src1 + (size_t)n * g.D * dpl1;
     const bf16_t* nb = NOISE ? g.noise + (size_t)n * ND * nplane : nullptr;
-    for (int col = tid; col < ncols; col += 256) {
+    const StageSplit sp = stage_split(ncols, g.HD, tid);
+    for (int col = sp.col0; col < ncols; col += sp.cstride) {
         const int e = ctab[2 * col], hoff = ctab[2 * col + 1];
         const int hh = e & 1023, hw = (e >> 10) & 1023, cg = e >> 20;
         const int c = chunk * g.CK + cg * 8;
@@ -233,13 +224,13 @@ __device__ __forceinline__ void stage_halo_tile(const GatherIn& g, char* halo, c
                 sf[j] = (f32x2){scs[g.CK + cg * 8 + 2 * j], scs[g.CK + cg * 8 + 2 * j + 1]};
             }
         }
-        for (int hd0 = 0; hd0 < g.HD; hd0 += UB) {
+        for (int hd0 = sp.hd_lo; hd0 < sp.hd_hi; hd0 += UB) {
             Raw8<T> raw[UB];
             Raw8<bf16_t> nz[NOISE ? UB : 1];
             bool ok[UB], nok[UB];
 #pragma unroll
             for (int k = 0; k < UB; ++k) {
-                const int hd = hd0 + k < g.HD ? hd0 + k : g.HD - 1;
+                const int hd = hd0 + k < sp.hd_hi ? hd0 + k : sp.hd_hi - 1;
                 int rd = pd0 + hd;
                 const int qd = rd + g.npad;
                 const bool dvalid = resolve_pos(rd, g.D, g.pad_mode);          // wave-uniform
@@ -255,7 +246,7 @@ __device__ __forceinline__ void stage_halo_tile(const GatherIn& g, char* halo, c
             }
 #pragma unroll
             for (int k = 0; k < UB; ++k) {
-                if (hd0 + k < g.HD) {
+                if (hd0 + k < sp.hd_hi) {
                     T* dst = (T*)(halo + (size_t)(hd0 + k) * plane + hoff);
                     if (plain) {
                         Raw8<T> r = raw[k];

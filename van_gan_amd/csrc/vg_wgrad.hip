@@ -37,7 +37,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* base0, const char* base1) 
 }
 
 template <typename T, int RMAX, int Q, bool NOISE>
-__global__ __launch_bounds__(256) void wgrad_kernel(const GatherIn g, const WgradK p) {
+__global__ __launch_bounds__(256, (RMAX * Q >= 16 ? 2 : 3)) void wgrad_kernel(const GatherIn g, const WgradK p) {
     constexpr bool F32 = sizeof(T) == 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -104,36 +104,38 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const GatherIn g, const Wgra
         }
         stage_resolve_axes(g, rtab, oh0, ow0, tid);
         __syncthreads();
-        if (!(g.dbg & 1) || tile == (int)blockIdx.x) stage_halo_tile<T, NOISE, 2>(g, halo, scs, utab, rtab, n, od0, cib, tid);
-        if (!(g.dbg & 2) || tile == (int)blockIdx.x)
-        // ---- stage dY tile [BM][16*Q] (zero outside the grid / beyond Cout).  Straight-line: out-of-range units load a
-        // clamped address and are zeroed afterwards, so the four loads of a batch are in flight together ----
-        for (int u0 = tid; u0 < BM * gcol; u0 += 256 * 4) {
-            Raw8<T> raw[4]; float y1[4]; bool ok[4];
+        // ---- dY tile [BM][16*Q] (zero outside the grid / beyond Cout): its loads are issued first and stay in flight
+        // while the halo tile is staged.  Straight-line: out-of-range units load a clamped address and are zeroed ----
+        Raw8<T> yraw[4]; float y1[4]; bool yok[4];
+        const bool dy_on = !(g.dbg & 2) || tile == (int)blockIdx.x;
+        if (dy_on) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const int u = min(u0 + k * 256, BM * gcol - 1);
+                const int u = min(tid + k * 256, BM * gcol - 1);
                 const int m = u >> gcol_l, cg = u & (gcol - 1);
                 const int w = m & TWm, h = (m >> g.twl) & THm, d = m >> (g.twl + g.thl);
                 const int od = od0 + d, oh = oh0 + h, ow = ow0 + w;
                 const int c = cob * p.COB + cg * 8;
-                ok[k] = od < p.OD && oh < p.OH && ow < p.OW && c < p.Cout;
-                const size_t vox = ok[k] ? ((size_t)(n * p.OD + od) * p.OH + oh) * p.OW + ow : 0;
-                if (p.Cout == 1) y1[k] = p.dy_f32 ? ((const float*)p.dy)[vox] : bf2f(((const bf16_t*)p.dy)[vox]);
-                else raw_load(raw[k], (const T*)p.dy + vox * p.Cout + (ok[k] ? c : 0));
+                yok[k] = od < p.OD && oh < p.OH && ow < p.OW && c < p.Cout;
+                const size_t vox = yok[k] ? ((size_t)(n * p.OD + od) * p.OH + oh) * p.OW + ow : 0;
+                if (p.Cout == 1) y1[k] = p.dy_f32 ? ld_global((const float*)p.dy + vox) : ld_global((const bf16_t*)p.dy + vox);
+                else raw_load(yraw[k], (const T*)p.dy + vox * p.Cout + (yok[k] ? c : 0));
             }
+        }
+        if (!(g.dbg & 1) || tile == (int)blockIdx.x) stage_halo_tile<T, NOISE, (RMAX * Q > 4 ? 2 : 4)>(g, halo, scs, utab, rtab, n, od0, cib, tid);
+        if (dy_on) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const int u = u0 + k * 256;
+                const int u = tid + k * 256;
                 if (u < BM * gcol) {
                     const int m = u >> gcol_l, cg = u & (gcol - 1);
                     T* dst = (T*)(dyt + (size_t)m * p.DYS) + cg * 8;
                     if (p.Cout == 1) {
-                        const float v[8] = {ok[k] ? y1[k] : 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        const float v[8] = {yok[k] ? y1[k] : 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                         store8<T>(dst, v);
                     } else {
-                        raw_mask(raw[k], ok[k]);
-                        *(Raw8<T>*)dst = raw[k];
+                        raw_mask(yraw[k], yok[k]);
+                        *(Raw8<T>*)dst = yraw[k];
                     }
                 }
             }
@@ -163,36 +165,64 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const GatherIn g, const Wgra
                 for (int q = 0; q < Q; ++q) b[q] = *(const float*)(y0 + q * 64);
 #pragma unroll
                 for (int j = 0; j < RMAX; ++j) {
-                    if (wave + 4 * j < nrows) {
-                        const float a = *(const float*)(halo + r0 + aoff[j]);
+                    const float a = *(const float*)(halo + r0 + aoff[j]);
 #pragma unroll
-                        for (int q = 0; q < Q; ++q) acc[j][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[q], acc[j][q], 0, 0, 0);
-                    }
+                    for (int q = 0; q < Q; ++q) acc[j][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[q], acc[j][q], 0, 0, 0);
                 }
             }
         } else {
-            // ---- K loop over voxels, 32 per MFMA ----
-            for (int s = 0; s < BM / 32; ++s) {
+            // ---- K loop over voxels, 32 per MFMA.  Rows are processed in chunks of RC; the operand fragments of the
+            // next chunk (or of the next K-step: its dY fragments too) are fetched before the MFMAs of the current one.
+            // No MFMA or fetch is conditional: rows beyond nrows re-read row 0 and are dropped at the slab write ----
+            constexpr int RC = RMAX <= 8 ? RMAX : 6;
+            static_assert(RMAX % RC == 0, "rows per wave must be a multiple of the chunk");
+            constexpr int NCH = RMAX / RC;
+            const int nks = BM / 32;
+            auto kaddr = [&](int ks, int& r0, int& r1, const char*& y0, const char*& y1) {
                 // this lane supplies the address of voxel row m0 (and m0+4) for the transposed block reads
-                const int m0 = s * 32 + 8 * lg + (li >> 2);
+                const int m0 = ks * 32 + 8 * lg + (li >> 2);
                 const int m1 = m0 + 4;
                 const int w0 = m0 & TWm, h0 = (m0 >> g.twl) & THm, d0 = m0 >> (g.twl + g.thl);
                 const int w1 = m1 & TWm, h1 = (m1 >> g.twl) & THm, d1 = m1 >> (g.twl + g.thl);
-                const int r0 = ((d0 * g.istr * g.HH + h0 * g.istr) * g.HW + w0 * g.istr) * g.RS + 8 * (li & 3);
-                const int r1 = ((d1 * g.istr * g.HH + h1 * g.istr) * g.HW + w1 * g.istr) * g.RS + 8 * (li & 3);
-                const char* y0 = dyt + (size_t)m0 * p.DYS + 8 * (li & 3);
-                const char* y1 = dyt + (size_t)m1 * p.DYS + 8 * (li & 3);
-                bf16x8 b[Q];
+                r0 = ((d0 * g.istr * g.HH + h0 * g.istr) * g.HW + w0 * g.istr) * g.RS + 8 * (li & 3);
+                r1 = ((d1 * g.istr * g.HH + h1 * g.istr) * g.HW + w1 * g.istr) * g.RS + 8 * (li & 3);
+                y0 = dyt + (size_t)m0 * p.DYS + 8 * (li & 3);
+                y1 = dyt + (size_t)m1 * p.DYS + 8 * (li & 3);
+            };
+            int r0, r1; const char *y0, *y1;
+            kaddr(0, r0, r1, y0, y1);
+            bf16x8 bc[Q], bn[Q], ac[RC], an[RC];
 #pragma unroll
-                for (int q = 0; q < Q; ++q) b[q] = tr_frag(y0 + q * 32, y1 + q * 32);          // B[k=voxel][co]
+            for (int q = 0; q < Q; ++q) bc[q] = tr_frag(y0 + q * 32, y1 + q * 32);              // B[k=voxel][co]
 #pragma unroll
-                for (int j = 0; j < RMAX; ++j) {
-                    if (wave + 4 * j < nrows) {
-                        const bf16x8 a = tr_frag(halo + r0 + aoff[j], halo + r1 + aoff[j]);  // A[ci][k=voxel]
+            for (int j = 0; j < RC; ++j) ac[j] = tr_frag(halo + r0 + aoff[j], halo + r1 + aoff[j]);   // A[ci][k=voxel]
+            for (int ks = 0; ks < nks; ++ks) {
+                int r0n, r1n; const char *y0n, *y1n;
+                kaddr(min(ks + 1, nks - 1), r0n, r1n, y0n, y1n);
 #pragma unroll
-                        for (int q = 0; q < Q; ++q) acc[j][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[q], acc[j][q], 0, 0, 0);
+                for (int c = 0; c < NCH; ++c) {
+                    if (c + 1 < NCH) {
+#pragma unroll
+                        for (int j = 0; j < RC; ++j) an[j] = tr_frag(halo + r0 + aoff[(c + 1) * RC + j], halo + r1 + aoff[(c + 1) * RC + j]);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < Q; ++q) bn[q] = tr_frag(y0n + q * 32, y1n + q * 32);
+#pragma unroll
+                        for (int j = 0; j < RC; ++j) an[j] = tr_frag(halo + r0n + aoff[j], halo + r1n + aoff[j]);
                     }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < RC; ++j)
+#pragma unroll
+                        for (int q = 0; q < Q; ++q)
+                            acc[c * RC + j][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ac[j], bc[q], acc[c * RC + j][q], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < RC; ++j) ac[j] = an[j];
                 }
+#pragma unroll
+                for (int q = 0; q < Q; ++q) bc[q] = bn[q];
+                r0 = r0n; r1 = r1n;
             }
         }
         VG_WSTAMP(3);
@@ -322,13 +352,23 @@ extern "C" int vg_conv3d_wgrad(const vg_conv_desc* d, const void* dy, int dy_f32
     if (bx > 8 && scratch && (int64_t)bx * k.dw_elems * 4 <= scratch_bytes) k.part = scratch;
     const dim3 grid(bx, by, 1);
     hipStream_t s = (hipStream_t)stream;
+    // rows per wave actually needed: small slabs (27 taps x 16 channels = 7 rows per wave) take the kernel variant with
+    // few accumulators (3 workgroups per CU instead of 2)
+    const int rw = (k.tpg * rows_per_tap + 3) / 4;
     if (d->f32) {
         if (Q == 1) launch_wgrad<float, 24, 1>(g, k, grid, lds, s);
         else if (Q == 2) launch_wgrad<float, 12, 2>(g, k, grid, lds, s);
         else launch_wgrad<float, 6, 4>(g, k, grid, lds, s);
+    } else if (Q == 1) {
+        if (rw <= 2) launch_wgrad<bf16_t, 2, 1>(g, k, grid, lds, s);
+        else if (rw <= 8) launch_wgrad<bf16_t, 8, 1>(g, k, grid, lds, s);
+        else launch_wgrad<bf16_t, 24, 1>(g, k, grid, lds, s);
+    } else if (Q == 2) {
+        if (rw <= 2) launch_wgrad<bf16_t, 2, 2>(g, k, grid, lds, s);
+        else if (rw <= 8) launch_wgrad<bf16_t, 8, 2>(g, k, grid, lds, s);
+        else launch_wgrad<bf16_t, 12, 2>(g, k, grid, lds, s);
     } else {
-        if (Q == 1) launch_wgrad<bf16_t, 24, 1>(g, k, grid, lds, s);
-        else if (Q == 2) launch_wgrad<bf16_t, 12, 2>(g, k, grid, lds, s);
+        if (rw <= 2) launch_wgrad<bf16_t, 2, 4>(g, k, grid, lds, s);
         else launch_wgrad<bf16_t, 6, 4>(g, k, grid, lds, s);
     }
     if (k.part) {
