@@ -100,6 +100,9 @@ int vg_conv3d(const vg_conv_desc* d, vg_stream_t stream);
 
 /* bytes of dynamic LDS the chosen tile needs, or <0 */
 int vg_conv3d_lds_bytes(const vg_conv_desc* d);
+/* the launch plan vg_conv3d would use for this descriptor: plan[0] = channel panel BN, plan[1] = voxels per tile,
+   plan[2] = LDS bytes, plan[3] = workgroups; lets the host compare channel-chunk sizes (CK) before packing weights */
+int vg_conv3d_plan(const vg_conv_desc* d, int32_t* plan4);
 
 /* Pack fp32 Keras DHWIO weights [T][Cin][Cout] to the bf16 layout vg_conv3d reads.
  * transpose=0: rows = Cout, contraction = Cin (forward); transpose=1: rows = Cin, contraction =

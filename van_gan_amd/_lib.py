@@ -54,6 +54,7 @@ _SIGS = {
     'vg_set_stamp_buffer': ([c_void_p], c_int),
     'vg_conv3d': ([C.POINTER(ConvDesc), c_void_p], c_int),
     'vg_conv3d_lds_bytes': ([C.POINTER(ConvDesc)], c_int),
+    'vg_conv3d_plan': ([C.POINTER(ConvDesc), C.POINTER(C.c_int32)], c_int),
     'vg_pack_weights': ([c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p], c_int),
     'vg_pack_weights_multi': ([c_void_p, c_int, c_void_p], c_int),
     'vg_packed_ktot': ([c_int, c_int, c_int], c_int),

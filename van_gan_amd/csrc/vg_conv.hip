@@ -53,13 +53,14 @@ template <typename T> using glb_ptr = const __attribute__((address_space(1))) T*
 // accumulators between AGPRs and VGPRs around every group).
 template <typename T, int MW, typename WP>
 __device__ __forceinline__ void conv_mfma_chunk(f32x4 (&acc)[MW], WP w, const char* halo, const int (&rowbase)[MW],
-                                                const int* tapoff, const int* koff, int ksteps, int ntaps, int CK, int lane) {
+                                                const int* tapoff, const int* koff, int ksteps, int ntaps, int CK, int CS, int lane) {
     if constexpr (sizeof(T) == 4) {
         // exact-parity mode: f32 operands, v_mfma_f32_16x16x4_f32 (k = 4 consecutive channels of one tap)
         int tap = 0, ch0 = 0;
         const int nk4 = (ntaps * CK) >> 2;
         for (int s = 0; s < nk4; ++s) {
-            const int off = tapoff[tap] + (ch0 + (lane >> 4)) * 4;
+            const int chn = ch0 + (lane >> 4);
+            const int off = tapoff[tap] + (chn >> 3) * CS + (chn & 7) * 4;
             float b[MW];
 #pragma unroll
             for (int i = 0; i < MW; ++i) b[i] = *(const float*)(halo + rowbase[i] + off);
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(256, ((BN / 16) * MSUB >= 8 ? 2 : VG_CONV_WAVES)) v
     const int TWm = (1 << g.twl) - 1, THm = (1 << g.thl) - 1;
 
     char* halo = smem;
-    const int hbytes = g.HD * g.HH * g.HW * g.RS;
+    const int hbytes = g.planar ? (g.CK >> 3) * g.PSB : g.HD * g.HHp * g.HWp * g.VS;
     int* tapoff = (int*)(smem + hbytes);
     float* scs = (float*)(smem + hbytes + 256);
     float* stat = scs + 2 * g.CK;
@@ -145,13 +146,13 @@ __global__ __launch_bounds__(256, ((BN / 16) * MSUB >= 8 ? 2 : VG_CONV_WAVES)) v
     wlds = (char*)(((size_t)wlds + 15) & ~(size_t)15);
 
     if (tid < g.ntaps)
-        tapoff[tid] = (((g.td[tid] - g.tmin_d) * g.HH + (g.th[tid] - g.tmin_h)) * g.HW + (g.tw[tid] - g.tmin_w)) * g.RS;
+        tapoff[tid] = (((g.td[tid] - g.tmin_d) * g.HHp + (g.th[tid] - g.tmin_h)) * g.HWp + halo_pos_w(g, g.tw[tid] - g.tmin_w)) * g.VS;
     if (tid < BN * 2) stat[tid] = 0.f;
     build_column_table(g, utab, tid);
     for (int i = tid; i < ksteps * 4; i += 256) {
         int G = i; if (G >= ngroups) G = ngroups - 1;                       // padded K: weights are zero there
         const int tp = G / gpc, cgq = G - tp * gpc;
-        koff[i] = (((g.td[tp] - g.tmin_d) * g.HH + (g.th[tp] - g.tmin_h)) * g.HW + (g.tw[tp] - g.tmin_w)) * g.RS + cgq * 16;
+        koff[i] = (((g.td[tp] - g.tmin_d) * g.HHp + (g.th[tp] - g.tmin_h)) * g.HWp + halo_pos_w(g, g.tw[tp] - g.tmin_w)) * g.VS + cgq * g.CS;
     }
     if (WL) {               // weight panel -> LDS, 16 B per thread per step
         const int per_row = (p.Ktot * (int)sizeof(T)) >> 4;
@@ -167,7 +168,8 @@ __global__ __launch_bounds__(256, ((BN / 16) * MSUB >= 8 ? 2 : VG_CONV_WAVES)) v
     for (int i = 0; i < MW; ++i) {
         const int m = (wave_m * MW + i) * 16 + (lane & 15);
         const int w = m & TWm, h = (m >> g.twl) & THm, d = m >> (g.twl + g.thl);
-        rowbase[i] = ((d * g.istr * g.HH + h * g.istr) * g.HW + w * g.istr) * g.RS;
+        // W step is one unit for either stride: stride-2 gathers read the de-interleaved image (halo_pos_w)
+        rowbase[i] = ((d * g.istr * g.HHp + h * g.istr) * g.HWp + w) * g.VS;
     }
     // weight fragment source: LDS panel or global (L2) rows -- kept as two address-space-typed pointers (a pointer
     // selected between the two becomes generic and every fragment fetch a flat_load)
@@ -223,8 +225,8 @@ __global__ __launch_bounds__(256, ((BN / 16) * MSUB >= 8 ? 2 : VG_CONV_WAVES)) v
             if (chunk == 0) VG_STAMP(2);
             const size_t kbase = (size_t)chunk * p.kc_pad;
             if (g.dbg & 4) continue;
-            if constexpr (WL) conv_mfma_chunk<T, MW>(acc, wrow_l + kbase, halo, rowbase, tapoff, koff, ksteps, g.ntaps, g.CK, lane);
-            else conv_mfma_chunk<T, MW>(acc, wrow_g + kbase, halo, rowbase, tapoff, koff, ksteps, g.ntaps, g.CK, lane);
+            if constexpr (WL) conv_mfma_chunk<T, MW>(acc, wrow_l + kbase, halo, rowbase, tapoff, koff, ksteps, g.ntaps, g.CK, g.CS, lane);
+            else conv_mfma_chunk<T, MW>(acc, wrow_g + kbase, halo, rowbase, tapoff, koff, ksteps, g.ntaps, g.CK, g.CS, lane);
         }
         VG_STAMP(3);
         if (g.dbg & 8) continue;
@@ -415,6 +417,17 @@ static int fill_conv(const vg_conv_desc* d, GatherIn& g, ConvOut& k, int& BN, in
     k.wp = d->wpacked;
     k.bias = d->bias; k.res = d->res; k.rs = d->res_scale; k.rb = d->res_shift; k.tanh_out = d->tanh_out;
     k.out = d->out; k.out_f32 = (d->out_f32 || d->f32) ? 1 : 0; k.accumulate = d->accumulate; k.sums = d->out_sums;
+    return VG_OK;
+}
+
+extern "C" int vg_conv3d_plan(const vg_conv_desc* d, int32_t* plan4) {
+    vg_begin();
+    if (!plan4) return VG_EINVAL;
+    GatherIn g; ConvOut k; int BN, MSUB, lds;
+    int rc = fill_conv(d, g, k, BN, MSUB, lds);
+    if (rc != VG_OK) return rc;
+    plan4[0] = BN; plan4[1] = 64 * MSUB; plan4[2] = lds;
+    plan4[3] = g.tiles_d * g.tiles_h * g.tiles_w * ((d->Cout + BN - 1) / BN) * d->N;
     return VG_OK;
 }
 

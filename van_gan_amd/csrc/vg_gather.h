@@ -13,7 +13,13 @@ struct GatherIn {
     const bf16_t* noise; int npad;
     int istr, pad_mode, ntaps;
     int8_t td[VG_MAX_TAPS], th[VG_MAX_TAPS], tw[VG_MAX_TAPS];
-    int tmin_d, tmin_h, tmin_w, HD, HH, HW, RS, CK;
+    int tmin_d, tmin_h, tmin_w, HD, HH, HW, CK;
+    int HHp, HWp, US, PSB;   // LDS halo image, pitches HHp/HWp in voxels, unit = 8 channels = US bytes.  Two forms, both
+    int VS, CS, planar;      // addressed as voxel * VS + channel_group * CS:  planar [group][HD][HHp][HWp] (VS = US,
+                             // CS = PSB: bank-conflict-free fragment reads, voxel-fastest staging) for thin chunks, and
+                             // row-major [HD][HHp][HWp][CK + pad] (VS = row bytes, CS = US: full-line global loads) for wide ones
+    int HWh;                 // istr 2: W positions are stored de-interleaved (even columns, then odd columns from HWh on) so
+                             // that the stride-2 voxels of a sub-tile are consecutive units; 0 for istr 1
     int tdl, thl, twl, tiles_d, tiles_h, tiles_w;
     int f32;        // storage type of multi-channel tensors / LDS tile: 0 bf16, 1 f32
     int dbg;        // development ablation flags (VG_DEBUG env): 1 skip halo staging, 2 skip dY staging, 4 skip MFMA
@@ -52,16 +58,21 @@ __device__ __forceinline__ void stage_scale_shift(const GatherIn& g, float* scs,
 //   ctab: LDS ints [2 * ncols]: {hh | hw<<10 | cg<<20, byte offset of the column inside one halo D-plane}; built once.
 //   rtab: LDS ints [3][HH + HW]: element offsets (or -1) along H and W for src0, src1 and the noise tensor; per tile.
 // ------------------------------------------------------------------------------------------------------------------
+// storage column of halo column hw
+__host__ __device__ __forceinline__ int halo_pos_w(const GatherIn& g, int hw) { return g.HWh ? (hw >> 1) + (hw & 1) * g.HWh : hw; }
 __host__ __device__ __forceinline__ int stage_ncols(const GatherIn& g) { return g.HH * g.HW * (g.Cin == 1 ? 1 : (g.CK >> 3)); }
 
 __device__ __forceinline__ void build_column_table(const GatherIn& g, int* ctab, int tid) {
     const int gpc = g.Cin == 1 ? 1 : (g.CK >> 3);
     const int ncols = g.HH * g.HW * gpc;
+    const int nv = g.HH * g.HW;
     for (int col = tid; col < ncols; col += 256) {
-        const int v = col / gpc, cg = col - v * gpc;
+        // planar: voxel-fastest, 8 consecutive lanes write 8 consecutive units of one plane (conflict-free ds_write_b128);
+        // row-major: channel-group-fastest, consecutive lanes read one voxel's contiguous channels
+        const int cg = g.planar ? col / nv : col % gpc, v = g.planar ? col - cg * nv : col / gpc;
         const int hh = v / g.HW, hw = v - hh * g.HW;
         ctab[2 * col] = hh | (hw << 10) | (cg << 20);
-        ctab[2 * col + 1] = v * g.RS + cg * 16 * (g.f32 ? 2 : 1);
+        ctab[2 * col + 1] = cg * g.CS + (hh * g.HWp + halo_pos_w(g, hw)) * g.VS;
     }
 }
 
@@ -124,7 +135,7 @@ __device__ __forceinline__ void stage_halo_c1(const GatherIn& g, char* halo, con
                                               int n, int pd0, int tid) {
     const int L = g.HH + g.HW;
     const int ncols = g.HH * g.HW;
-    const int plane = g.HH * g.HW * g.RS;
+    const int plane = g.HHp * g.HWp * g.VS;
     const float slope = g.act == VG_ACT_RELU ? 0.f : (g.act == VG_ACT_LRELU ? VG_LRELU : 1.f);
     const int ND = g.D + 2 * g.npad;
     const int nplane = (g.H + 2 * g.npad) * (g.W + 2 * g.npad);
@@ -168,7 +179,7 @@ __device__ __forceinline__ void stage_halo_c1(const GatherIn& g, char* halo, con
                     const float z8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                     T* row = (T*)(halo + (size_t)(hd0 + k) * plane + hoff);
                     store8<T>(row, v);
-                    for (int b = 1; b < ngrp; ++b) store8<T>(row + 8 * b, z8);
+                    for (int b = 1; b < ngrp; ++b) store8<T>((T*)((char*)row + (size_t)b * g.CS), z8);
                 }
             }
         }
@@ -180,7 +191,7 @@ __device__ __forceinline__ void stage_halo_tile(const GatherIn& g, char* halo, c
                                                 int n, int od0, int chunk, int tid) {
     const int L = g.HH + g.HW;
     const int ncols = stage_ncols(g);
-    const int plane = g.HH * g.HW * g.RS;                      // bytes of one halo D-plane
+    const int plane = g.HHp * g.HWp * g.VS;                    // bytes of one D-plane of the halo image
     const int pd0 = od0 * g.istr + g.tmin_d;
     const float slope = g.act == VG_ACT_RELU ? 0.f : (g.act == VG_ACT_LRELU ? VG_LRELU : 1.f);
     const bool zero_mode = g.pad_mode != VG_PAD_REFLECT;
@@ -275,7 +286,24 @@ __device__ __forceinline__ void stage_halo_tile(const GatherIn& g, char* halo, c
 }
 
 // ---- host: validate the input side of a descriptor and derive the tile geometry for BM voxels ----
-static inline int fill_gather(const vg_conv_desc* d, GatherIn& g, int CK, int BM) {
+// padded pitches of the LDS halo image: the 16 voxels of an MFMA sub-tile (TW x 16/TW rows [x planes]) must fall into 16
+// different 16-byte bank groups, i.e. be distinct modulo 16 units
+// Padding is taken only while it costs <= 25 % of the image (thin tiles on small grids keep a 2-way conflict instead of a
+// 2-3x larger LDS footprint, which would cost a resident workgroup); strided gathers (istr 2) cannot be made conflict-free
+// by pitch alone and are not padded.
+static inline void pad_pitches(int hh, int hw, int tw, int th, int istr, int& hhp, int& hwp) {
+    const int hw0 = istr == 2 ? 2 * ((hw + 1) / 2) : hw;          // de-interleaved rows hold two halves of ceil(hw/2)
+    hhp = hh; hwp = hw0;
+    if (tw >= 16) return;
+    int x = hw0; while (((istr * x) % (2 * tw)) != tw) ++x;       // rows of a sub-tile land tw units apart (odd multiples)
+    int y = hh;
+    if (tw * th < 16) { while (((istr * y * x) % (2 * tw * th)) != tw * th) ++y; }
+    if ((long)x * y * 4 <= (long)hw0 * hh * 5) { hwp = x; hhp = y; }
+}
+// skew: extra bytes on the plane stride (0: consecutive planes share banks -- right for the forward kernel whose lane
+// groups mix two planes over disjoint voxel sets; 64: the weight-gradient kernel's transposed reads take both planes of
+// the same 8 voxels)
+static inline int fill_gather(const vg_conv_desc* d, GatherIn& g, int CK, int BM, int skew = 0) {
     if (!d || !d->src0) return VG_EINVAL;
     g.f32 = d->f32 ? 1 : 0;
     { static int dbg = -1; if (dbg < 0) { const char* e = getenv("VG_DEBUG"); dbg = e ? atoi(e) : 0; } g.dbg = dbg; }
@@ -303,7 +331,9 @@ static inline int fill_gather(const vg_conv_desc* d, GatherIn& g, int CK, int BM
         for (int a = 0; a < 3; ++a) { if (v[a] < mn[a]) mn[a] = v[a]; if (v[a] > mx[a]) mx[a] = v[a]; }
     }
     g.tmin_d = mn[0]; g.tmin_h = mn[1]; g.tmin_w = mn[2];
-    g.RS = CK * (d->f32 ? 4 : 2) + 16;
+    g.US = d->f32 ? 32 : 16;
+    { static int pl = -2; if (pl == -2) { const char* e = getenv("VG_PLANAR"); pl = e ? atoi(e) : -1; }
+      g.planar = pl >= 0 ? pl : (CK <= 48 && d->istr == 1); }
     // tile shape: powers of two with product BM that minimise the halo volume (staging work and L2 traffic scale with
     // it); the innermost extent stays >= 8 voxels where the grid allows so that rows remain long contiguous runs
     int TW = 1, TH = 1, TD = 1;
@@ -315,7 +345,10 @@ static inline int fill_gather(const vg_conv_desc* d, GatherIn& g, int CK, int BM
             if (tw < 8 && tw < capw) continue;
             for (int th = 1; th <= caph && tw * th <= BM; th <<= 1) {
                 const int td = BM / (tw * th);
-                long vol = (long)((td - 1) * d->istr + ex[0]) * ((th - 1) * d->istr + ex[1]) * ((tw - 1) * d->istr + ex[2]);
+                const int hw_ = (tw - 1) * d->istr + ex[2], hh_ = (th - 1) * d->istr + ex[1];
+                int hwp_ = d->istr == 2 ? 2 * ((hw_ + 1) / 2) : hw_, hhp_ = hh_;
+                if (g.planar) pad_pitches(hh_, hw_, tw, th, d->istr, hhp_, hwp_);
+                long vol = (long)((td - 1) * d->istr + ex[0]) * hhp_ * hwp_;       // LDS image incl. pitch padding
                 if (td > capd) vol *= 4;          // overhang in D wastes whole planes: only when nothing else fits
                 if (best < 0 || vol < best || (vol == best && tw > TW)) { best = vol; TW = tw; TH = th; TD = td; }
             }
@@ -326,8 +359,14 @@ static inline int fill_gather(const vg_conv_desc* d, GatherIn& g, int CK, int BM
     g.HD = (TD - 1) * d->istr + (mx[0] - mn[0]) + 1;
     g.HH = (TH - 1) * d->istr + (mx[1] - mn[1]) + 1;
     g.HW = (TW - 1) * d->istr + (mx[2] - mn[2]) + 1;
+    g.HWh = d->istr == 2 ? (g.HW + 1) / 2 : 0;
+    g.HHp = g.HH; g.HWp = g.HWh ? 2 * g.HWh : g.HW;
+    if (g.planar) pad_pitches(g.HH, g.HW, TW, TH, d->istr, g.HHp, g.HWp);
+    g.PSB = ((g.HD * g.HHp * g.HWp * g.US + 255) & ~255) + skew;
+    if (g.planar) { g.VS = g.US; g.CS = g.PSB; }
+    else { g.VS = CK * (d->f32 ? 4 : 2) + 16; g.CS = g.US; }
     return VG_OK;
 }
-static inline int halo_bytes(const GatherIn& g) { return g.HD * g.HH * g.HW * g.RS; }
+static inline int halo_bytes(const GatherIn& g) { return g.planar ? (g.CK >> 3) * g.PSB : g.HD * g.HHp * g.HWp * g.VS; }
 // LDS ints of the staging tables (column table + per-tile axis tables)
 static inline int stage_table_ints(const GatherIn& g) { return 2 * stage_ncols(g) + 3 * (g.HH + g.HW); }

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256, (RMAX * Q >= 16 ? 2 : 3)) void wgrad_kernel(co
 
     const int BM = 1 << (g.tdl + g.thl + g.twl);
     char* halo = smem;
-    const int hbytes = g.HD * g.HH * g.HW * g.RS;
+    const int hbytes = g.planar ? (g.CK >> 3) * g.PSB : g.HD * g.HHp * g.HWp * g.VS;
     char* dyt = smem + hbytes;
     const int dybytes = BM * p.DYS;
     int* tapoff = (int*)(dyt + dybytes);
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256, (RMAX * Q >= 16 ? 2 : 3)) void wgrad_kernel(co
     int* rtab = utab + 2 * stage_ncols(g);
 
     if (tid < g.ntaps)
-        tapoff[tid] = (((g.td[tid] - g.tmin_d) * g.HH + (g.th[tid] - g.tmin_h)) * g.HW + (g.tw[tid] - g.tmin_w)) * g.RS;
+        tapoff[tid] = (((g.td[tid] - g.tmin_d) * g.HHp + (g.th[tid] - g.tmin_h)) * g.HWp + halo_pos_w(g, g.tw[tid] - g.tmin_w)) * g.VS;
     if (tid < VG_MAX_TAPS) tapsrc[tid] = p.tap_src[tid];
     build_column_table(g, utab, tid);
     __syncthreads();
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256, (RMAX * Q >= 16 ? 2 : 3)) void wgrad_kernel(co
     for (int j = 0; j < RMAX; ++j) {
         const int r = wave + 4 * j;
         const int rr = r < nrows ? r : 0;
-        aoff[j] = tapoff[tap0 + rr / tci] + (rr % tci) * 16 * (int)sizeof(T);
+        aoff[j] = tapoff[tap0 + rr / tci] + (rr % tci) * 2 * g.CS;          // a 16-channel row block = two 8-channel groups
     }
     f32x4 acc[RMAX][Q];
 #pragma unroll
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256, (RMAX * Q >= 16 ? 2 : 3)) void wgrad_kernel(co
             for (int s = 0; s < BM / 4; ++s) {
                 const int m0 = s * 4 + lg;
                 const int w0 = m0 & TWm, h0 = (m0 >> g.twl) & THm, d0 = m0 >> (g.twl + g.thl);
-                const int r0 = ((d0 * g.istr * g.HH + h0 * g.istr) * g.HW + w0 * g.istr) * g.RS + li * 4;
+                const int r0 = ((d0 * g.istr * g.HHp + h0 * g.istr) * g.HWp + w0) * g.VS + (li >> 3) * g.CS + (li & 7) * 4;
                 const char* y0 = dyt + (size_t)m0 * p.DYS + li * 4;
                 float b[Q];
 #pragma unroll
@@ -184,8 +184,8 @@ __global__ __launch_bounds__(256, (RMAX * Q >= 16 ? 2 : 3)) void wgrad_kernel(co
                 const int m1 = m0 + 4;
                 const int w0 = m0 & TWm, h0 = (m0 >> g.twl) & THm, d0 = m0 >> (g.twl + g.thl);
                 const int w1 = m1 & TWm, h1 = (m1 >> g.twl) & THm, d1 = m1 >> (g.twl + g.thl);
-                r0 = ((d0 * g.istr * g.HH + h0 * g.istr) * g.HW + w0 * g.istr) * g.RS + 8 * (li & 3);
-                r1 = ((d1 * g.istr * g.HH + h1 * g.istr) * g.HW + w1 * g.istr) * g.RS + 8 * (li & 3);
+                r0 = ((d0 * g.istr * g.HHp + h0 * g.istr) * g.HWp + w0) * g.VS + ((li & 3) >> 1) * g.CS + 8 * (li & 1);
+                r1 = ((d1 * g.istr * g.HHp + h1 * g.istr) * g.HWp + w1) * g.VS + ((li & 3) >> 1) * g.CS + 8 * (li & 1);
                 y0 = dyt + (size_t)m0 * p.DYS + 8 * (li & 3);
                 y1 = dyt + (size_t)m1 * p.DYS + 8 * (li & 3);
             };
@@ -320,7 +320,7 @@ extern "C" int vg_conv3d_wgrad(const vg_conv_desc* d, const void* dy, int dy_f32
         for (int bm = 128; bm >= 64 && !best_bm; bm -= 64)
             for (int c = 64; c >= 16; c -= 16) {
                 if (Cinp % c) continue;
-                int rc = fill_gather(d, g, c, bm);
+                int rc = fill_gather(d, g, c, bm, d->f32 ? 0 : 64);
                 if (rc != VG_OK) return rc;
                 const int lds = halo_bytes(g) + bm * (COB * esz + 16) + 512 + 2 * c * 4 + stage_table_ints(g) * 4;
                 if (lds <= limit) { best_bm = bm; best_cib = c; best_lds = lds; break; }
@@ -328,7 +328,7 @@ extern "C" int vg_conv3d_wgrad(const vg_conv_desc* d, const void* dy, int dy_f32
     }
     if (!best_bm) return VG_ELDS;
     const int CIB = best_cib, lds = best_lds;
-    int rc = fill_gather(d, g, CIB, best_bm);
+    int rc = fill_gather(d, g, CIB, best_bm, d->f32 ? 0 : 64);
     if (rc != VG_OK) return rc;
     k.DYS = COB * esz + 16;
     k.dy = dy; k.dy_f32 = dy_f32; k.Cout = d->Cout; k.OD = d->OD; k.OH = d->OH; k.OW = d->OW;

@@ -215,16 +215,21 @@ class ConvLayer:
         d.BD, d.BH, d.BW = iters
         d.Cout = rows
         d.f32 = self.f32
-        best = None
+        # plan of every feasible chunk size; prefer the biggest tile (voxels x channel panel: fewer halo voxels staged
+        # per output and more MFMAs per barrier), then two resident workgroups per CU (<= 80 KiB), then the largest
+        # chunk (every further chunk is another staging pass per tile).  Measured on D.down0 (64->128, k4 s2, 64^3):
+        # CK 32 / 128-voxel tile 0.128 ms, CK 16 / 128 voxels 0.196 ms, CK 64 / 64 voxels 0.247 ms.
+        best, best_key = None, None
+        plan = (C.c_int32 * 4)()
         for ck in _ck_candidates(C_):
             d.CK = ck
-            lds = lib.vg_conv3d_lds_bytes(C.byref(d))
-            if lds < 0:
+            if lib.vg_conv3d_plan(C.byref(d), plan) != 0:
                 continue
-            if lds <= 80 * 1024:
-                return ck
-            if best is None:
-                best = ck
+            key = (plan[0] * plan[1], 1 if plan[2] <= 80 * 1024 else 0, ck)
+            if ck < 32 and best is not None and best_key[0] >= key[0]:
+                continue                       # do not trade chunk size below 32 channels for occupancy alone
+            if best_key is None or key > best_key:
+                best, best_key = ck, key
         if best is None:
             raise _lib.VgError('no LDS-feasible tile for %s' % self.name)
         return best
