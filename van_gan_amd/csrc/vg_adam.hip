@@ -12,43 +12,89 @@ __device__ __forceinline__ int find_seg(const int64_t* off, int T, int64_t i) {
     return lo;
 }
 
-// every block covers a contiguous span of 256*ELEMS elements; spans may straddle tensors
-#define ADAM_ELEMS 8
-__global__ __launch_bounds__(256) void sqnorm_kernel(const float* g, const int64_t* off, int T, int64_t total, float scale, float* norms) {
-    const int64_t base = ((int64_t)blockIdx.x * 256 + threadIdx.x) * ADAM_ELEMS;
-    if (base >= total) return;
-    int seg = find_seg(off, T, base);
-    float s = 0.f;
-    for (int e = 0; e < ADAM_ELEMS; ++e) {
-        const int64_t i = base + e;
-        if (i >= total) break;
-        if (i >= off[seg + 1]) { atomicAdd(&norms[seg], s); s = 0.f; while (i >= off[seg + 1]) ++seg; }
-        const float v = g[i] * scale; s += v * v;
-    }
-    // wave-level combine when the whole wave sits in one segment
-    const int seg0 = __shfl(seg, 0);
-    const int64_t first = __shfl(base, 0);
-    const bool uniform = __all(seg == seg0) && find_seg(off, T, first) == seg0;
-    if (uniform) { s = wave_sum(s); if ((threadIdx.x & 63) == 0) atomicAdd(&norms[seg0], s); }
-    else if (s != 0.f) atomicAdd(&norms[seg], s);
+// Every block owns a contiguous span of ADAM_SPAN elements of the flat buffer.  A span inside one tensor (all but ~one per
+// tensor) is streamed with 16-byte loads/stores, consecutive lanes on consecutive float4s; a span that straddles tensors
+// walks its tensors one after the other.  Per (block, tensor) there is ONE norm atomic.
+#define ADAM_SPAN 4096
+typedef const __attribute__((address_space(1))) f32x4* gp_f32x4;
+
+__device__ __forceinline__ float block_sum(float s, float* red) {
+    s = wave_sum(s);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
 }
+
+__global__ __launch_bounds__(256) void sqnorm_kernel(const float* g, const int64_t* off, int T, int64_t total, float scale, float* norms) {
+    __shared__ float red[4];
+    const int tid = threadIdx.x;
+    const int64_t b0 = (int64_t)blockIdx.x * ADAM_SPAN;
+    const int64_t b1 = b0 + ADAM_SPAN < total ? b0 + ADAM_SPAN : total;
+    int seg = find_seg(off, T, b0);
+    if (off[seg + 1] >= b1 && b1 - b0 == ADAM_SPAN) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < ADAM_SPAN / 1024; ++j) {
+            const f32x4 v = *(gp_f32x4)(uintptr_t)(g + b0 + (int64_t)(j * 256 + tid) * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float x = v[e] * scale; s += x * x; }
+        }
+        s = block_sum(s, red);
+        if (tid == 0) atomicAdd(&norms[seg], s);
+        return;
+    }
+    for (; seg < T && off[seg] < b1; ++seg) {                      // block-uniform loop over the tensors of the span
+        const int64_t lo = off[seg] > b0 ? off[seg] : b0, hi = off[seg + 1] < b1 ? off[seg + 1] : b1;
+        float s = 0.f;
+        for (int64_t i = lo + tid; i < hi; i += 256) { const float x = g[i] * scale; s += x * x; }
+        s = block_sum(s, red);
+        if (tid == 0 && hi > lo) atomicAdd(&norms[seg], s);
+    }
+}
+
+__device__ __forceinline__ void adam_elem(float& w, float g, float& m, float& v, float f, float lr_t, float b1, float b2, float eps) {
+    const float gi = g * f;
+    m = b1 * m + (1.f - b1) * gi;
+    v = b2 * v + (1.f - b2) * gi * gi;
+    w -= lr_t * m / (sqrtf(v) + eps);
+}
+
 __global__ __launch_bounds__(256) void adam_kernel(float* w, const float* g, float* m, float* v, const int64_t* off, int T,
                                                    int64_t total, const float* norms, float lr_t, float b1, float b2, float eps,
                                                    float clip, float scale) {
-    const int64_t base = ((int64_t)blockIdx.x * 256 + threadIdx.x) * ADAM_ELEMS;
-    if (base >= total) return;
-    int seg = find_seg(off, T, base);
-    float nrm = sqrtf(norms[seg]);
-    float f = (clip > 0.f && nrm > clip) ? clip / nrm : 1.f;
-    for (int e = 0; e < ADAM_ELEMS; ++e) {
-        const int64_t i = base + e;
-        if (i >= total) break;
-        if (i >= off[seg + 1]) { while (i >= off[seg + 1]) ++seg; nrm = sqrtf(norms[seg]); f = (clip > 0.f && nrm > clip) ? clip / nrm : 1.f; }
-        const float gi = g[i] * scale * f;
-        const float mi = b1 * m[i] + (1.f - b1) * gi;
-        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
-        m[i] = mi; v[i] = vi;
-        w[i] -= lr_t * mi / (sqrtf(vi) + eps);
+    const int tid = threadIdx.x;
+    const int64_t s0 = (int64_t)blockIdx.x * ADAM_SPAN;
+    const int64_t s1 = s0 + ADAM_SPAN < total ? s0 + ADAM_SPAN : total;
+    int seg = find_seg(off, T, s0);
+    if (off[seg + 1] >= s1 && s1 - s0 == ADAM_SPAN) {
+        const float nrm = sqrtf(norms[seg]);
+        const float f = ((clip > 0.f && nrm > clip) ? clip / nrm : 1.f);
+        f32x4 gv[ADAM_SPAN / 1024], mv[ADAM_SPAN / 1024], vv[ADAM_SPAN / 1024], wv[ADAM_SPAN / 1024];
+#pragma unroll
+        for (int j = 0; j < ADAM_SPAN / 1024; ++j) {
+            const int64_t i = s0 + (int64_t)(j * 256 + tid) * 4;
+            gv[j] = *(gp_f32x4)(uintptr_t)(g + i); mv[j] = *(gp_f32x4)(uintptr_t)(m + i);
+            vv[j] = *(gp_f32x4)(uintptr_t)(v + i); wv[j] = *(gp_f32x4)(uintptr_t)(w + i);
+        }
+#pragma unroll
+        for (int j = 0; j < ADAM_SPAN / 1024; ++j) {
+            const int64_t i = s0 + (int64_t)(j * 256 + tid) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float we = wv[j][e], me = mv[j][e], ve = vv[j][e];
+                adam_elem(we, gv[j][e] * scale, me, ve, f, lr_t, b1, b2, eps);
+                wv[j][e] = we; mv[j][e] = me; vv[j][e] = ve;
+            }
+            *(f32x4*)(m + i) = mv[j]; *(f32x4*)(v + i) = vv[j]; *(f32x4*)(w + i) = wv[j];
+        }
+        return;
+    }
+    for (; seg < T && off[seg] < s1; ++seg) {
+        const int64_t lo = off[seg] > s0 ? off[seg] : s0, hi = off[seg + 1] < s1 ? off[seg + 1] : s1;
+        const float nrm = sqrtf(norms[seg]);
+        const float f = ((clip > 0.f && nrm > clip) ? clip / nrm : 1.f);
+        for (int64_t i = lo + tid; i < hi; i += 256) adam_elem(w[i], g[i] * scale, m[i], v[i], f, lr_t, b1, b2, eps);
     }
 }
 extern "C" int vg_adam_clip(float* w, const float* g, float* m, float* v, const int64_t* seg_off_dev, int T, int64_t total,
@@ -58,7 +104,7 @@ extern "C" int vg_adam_clip(float* w, const float* g, float* m, float* v, const 
     if (!w || !g || !m || !v || !seg_off_dev || !norms || T < 1 || total < 1) return VG_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     if (hipMemsetAsync(norms, 0, T * sizeof(float), s) != hipSuccess) return VG_ELAUNCH;
-    const int blocks = (int)((total + 256 * ADAM_ELEMS - 1) / (256 * ADAM_ELEMS));
+    const int blocks = (int)((total + ADAM_SPAN - 1) / ADAM_SPAN);
     hipLaunchKernelGGL(sqnorm_kernel, dim3(blocks), dim3(256), 0, s, g, seg_off_dev, T, total, grad_scale, norms);
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, s, w, g, m, v, seg_off_dev, T, total, norms, lr_t, beta1, beta2, eps,
                        clipnorm, grad_scale);

@@ -501,30 +501,61 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, int Cin, int Co
     }
 }
 
-__global__ void pack_weights_multi_kernel(const vg_pack_item* __restrict__ items) {
+// One launch repacks every operand of a network.  blockIdx.y = item.  Forward operands ([Cout rows][K]) transpose the
+// DHWIO kernel, so they go through a 64x64 LDS tile: reads run along Cout (contiguous in w), writes along K (contiguous in
+// the packed row); data-gradient operands ([Cin rows][K = (tap, co)]) are contiguous on both sides already.
+__global__ __launch_bounds__(256) void pack_weights_multi_kernel(const vg_pack_item* __restrict__ items) {
+    __shared__ float tile[64][65];
     const vg_pack_item it = items[blockIdx.y];
     const int C = it.transpose ? it.Cout : it.Cin, NR = it.transpose ? it.Cin : it.Cout;
     const int nchunks = (C + it.CK - 1) / it.CK;
     const int kc_pad = ((it.ntaps * it.CK + 31) / 32) * 32;
     const int Ktot = nchunks * kc_pad;
     const int rows_pad = ((NR + 63) / 64) * 64;
-    const size_t total = (size_t)rows_pad * Ktot;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int row = (int)(i / Ktot), k = (int)(i % Ktot);
-        const int chunk = k / kc_pad, kl = k % kc_pad;
-        const int tap = kl / it.CK, ch = chunk * it.CK + kl % it.CK;
-        float v = 0.f;
-        if (row < NR && tap < it.ntaps && ch < C) {
-            const int ts = it.tap_idx[tap];
-            v = it.transpose ? it.w[((size_t)ts * it.Cin + row) * it.Cout + ch] : it.w[((size_t)ts * it.Cin + ch) * it.Cout + row];
+    const int tid = threadIdx.x;
+    if (it.transpose) {
+        for (int row = blockIdx.x; row < rows_pad; row += gridDim.x)
+            for (int k = tid; k < Ktot; k += 256) {
+                const int chunk = k / kc_pad, kl = k - chunk * kc_pad;
+                const int tap = kl / it.CK, ch = chunk * it.CK + (kl - tap * it.CK);
+                float v = 0.f;
+                if (row < NR && tap < it.ntaps && ch < C) v = it.w[((size_t)it.tap_idx[tap] * it.Cin + row) * it.Cout + ch];
+                const size_t o = (size_t)row * Ktot + k;
+                if (it.out_f32) ((float*)it.out)[o] = v; else ((bf16_t*)it.out)[o] = f2bf(v);
+            }
+        return;
+    }
+    const int tk = (Ktot + 63) >> 6, tr = rows_pad >> 6;
+    for (int t = blockIdx.x; t < tk * tr; t += gridDim.x) {
+        const int r0 = (t / tk) << 6, k0 = (t % tk) << 6;
+#pragma unroll 4
+        for (int j = 0; j < 16; ++j) {
+            const int kk = j * 4 + (tid >> 6), rr = tid & 63;
+            const int k = k0 + kk, row = r0 + rr;
+            float v = 0.f;
+            if (k < Ktot) {
+                const int chunk = k / kc_pad, kl = k - chunk * kc_pad;
+                const int tap = kl / it.CK, ch = chunk * it.CK + (kl - tap * it.CK);
+                if (row < NR && tap < it.ntaps && ch < C) v = it.w[((size_t)it.tap_idx[tap] * it.Cin + ch) * it.Cout + row];
+            }
+            tile[kk][rr] = v;
         }
-        if (it.out_f32) ((float*)it.out)[i] = v; else ((bf16_t*)it.out)[i] = f2bf(v);
+        __syncthreads();
+#pragma unroll 4
+        for (int j = 0; j < 16; ++j) {
+            const int rr = j * 4 + (tid >> 6), kk = tid & 63;
+            if (k0 + kk < Ktot) {
+                const size_t o = (size_t)(r0 + rr) * Ktot + k0 + kk;
+                if (it.out_f32) ((float*)it.out)[o] = tile[kk][rr]; else ((bf16_t*)it.out)[o] = f2bf(tile[kk][rr]);
+            }
+        }
+        __syncthreads();
     }
 }
 extern "C" int vg_pack_weights_multi(const vg_pack_item* items_dev, int n, vg_stream_t stream) {
     vg_begin();
     if (!items_dev || n < 1) return VG_EINVAL;
-    hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(48, n), dim3(256), 0, (hipStream_t)stream, items_dev);
+    hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(128, n), dim3(256), 0, (hipStream_t)stream, items_dev);
     return vg_check_launch();
 }
 
