@@ -7,6 +7,7 @@ differences are fp32 accumulation order (~1e-6 relative) plus one bf16 rounding 
 1e-4 relative (L2) for fp32 outputs/gradients unless stated otherwise.
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -366,3 +367,14 @@ def test_rng_statistics():
     ops.dropout_mask(m, 0.2, 99, 0)
     keep = float((m > 0).float().mean())
     assert abs(keep - 0.8) < 0.01 and abs(float(m.max()) - 1.25) < 1e-6
+
+
+@pytest.mark.gpu
+def test_conv_lds_dma_staging_subprocess():
+    """The optional LDS-DMA (global_load_lds) staging path of conv_kernel is selected per process by VG_CONV_DMA=1:
+    run the forward/data-gradient conv cases again in a child process with it enabled."""
+    import subprocess, sys
+    env = dict(os.environ, VG_CONV_DMA='1', VG_NO_REBUILD='1')
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-x', '-m', 'gpu',
+                        '-k', 'test_conv_forward_dgrad_wgrad'], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

@@ -28,6 +28,7 @@ struct ConvOut {
     const float* bias; const void* res; const float* rs; const float* rb; int tanh_out;
     void* out; int out_f32, accumulate; float* sums;
     int w_lds;          // 1: the BN x Ktot weight panel of this workgroup is copied to LDS once (row stride WRS bytes)
+    int dma;            // 1: LDS-DMA double-buffered staging (planar bf16 image, weights in LDS)
     int WRS;
 };
 
@@ -113,31 +114,136 @@ __device__ __forceinline__ void conv_mfma_chunk(f32x4 (&acc)[MW], WP w, const ch
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// LDS-DMA staging (planar bf16 images, multi-channel sources without noise).  The halo tile of the NEXT stage is copied
+// global -> LDS by global_load_lds_dwordx4 while the MFMAs and the epilogue of the current stage run: no VGPR, no wait
+// until the next stage starts.  One wave-instruction fills 64 consecutive 16-byte units (one piece of a D-slice of one
+// channel-group plane; slices are padded to whole pieces), each lane supplying its own source address: reflection, zero
+// padding (-> a zero page), the virtual concat and the nearest upsample are all in that address.  The on-read transform
+// act(x*scale+shift) then runs LDS -> LDS when the stage is consumed.
+//   cq  : LDS ints [SU]      static: hh | hw << 10 of image column q, or -1 for pitch/piece padding
+//   tcol: LDS ints [2][SU]   per tile: byte offset of column q inside one D-plane of src0 / src1, or -1
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(16))) unsigned int vg_zero16[4];
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+
+__device__ __forceinline__ void dma_build_cq(const GatherIn& g, int* cq, int tid) {
+    const int SU = g.DS >> 4;
+    for (int q = tid; q < SU; q += 256) {
+        const int hh = q / g.HWp, hw = q - hh * g.HWp;
+        cq[q] = (hh < g.HH && hw < g.HW) ? (hh | (hw << 10)) : -1;
+    }
+}
+__device__ __forceinline__ void dma_build_tcol(const GatherIn& g, const int* cq, int* tcol, int oh0, int ow0, int tid) {
+    const int SU = g.DS >> 4;
+    const int ph0 = oh0 * g.istr + g.tmin_h, pw0 = ow0 * g.istr + g.tmin_w;
+    const int sh = g.shift0, Ws0 = g.W >> sh;
+    for (int q = tid; q < SU; q += 256) {
+        const int e = cq[q];
+        int o0 = -1, o1 = -1;
+        if (e >= 0) {
+            int ph = ph0 + (e & 1023), pw = pw0 + (e >> 10);
+            const bool ok = resolve_pos(ph, g.H, g.pad_mode) & resolve_pos(pw, g.W, g.pad_mode);
+            if (ok) { o0 = (((ph >> sh) * Ws0 + (pw >> sh)) * g.c0) * 2; o1 = ((ph * g.W + pw) * g.c1) * 2; }
+        }
+        tcol[q] = o0; tcol[SU + q] = o1;
+    }
+}
+// issue the copies of one stage (tile origin od0, channel chunk `chunk`) into the image at hb
+__device__ __forceinline__ void dma_issue(const GatherIn& g, char* hb, const int* tcol, int n, int od0, int chunk, int wave, int lane) {
+    const int SU = g.DS >> 4, J = SU >> 6, gpc = g.CK >> 3;
+    const int nitems = gpc * g.HD * J;
+    const int sh = g.shift0;
+    const size_t pl0 = (size_t)(g.H >> sh) * (g.W >> sh) * g.c0 * 2, pl1 = (size_t)g.H * g.W * g.c1 * 2;     // bytes per source D-plane
+    const char* zp = (const char*)vg_zero16;
+    // items (cg, hd, j) in j-fastest order, wave w takes items w, w+4, ...: decoded incrementally (no divisions)
+    int j = wave % J, t2 = wave / J; int hd = t2 % g.HD, cg = t2 / g.HD;
+    const int dj = 4 % J, dhd = (4 / J) % g.HD, dcg = (4 / J) / g.HD;
+    for (int it = wave; it < nitems; it += 4) {
+        const int c = chunk * g.CK + cg * 8;
+        int rd = od0 * g.istr + g.tmin_d + hd;
+        const bool dvalid = resolve_pos(rd, g.D, g.pad_mode) && c < g.Cin;
+        const bool from0 = c < g.c0;
+        const char* base = from0 ? (const char*)g.src0 + ((size_t)n * (g.D >> sh) + (rd >> sh)) * pl0 + (size_t)c * 2
+                                 : (const char*)g.src1 + ((size_t)n * g.D + rd) * pl1 + (size_t)(c - g.c0) * 2;
+        const int toff = tcol[(from0 ? 0 : SU) + j * 64 + lane];
+        const char* src = (dvalid && toff >= 0) ? base + toff : zp;
+        char* dst = hb + (size_t)cg * g.PSB + (size_t)hd * g.DS + j * 1024;
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(uintptr_t)src, (lds_void_t*)dst, 16, 0, 0);
+        j += dj; if (j >= J) { j -= J; ++hd; }
+        hd += dhd; if (hd >= g.HD) { hd -= g.HD; ++cg; }
+        cg += dcg;
+    }
+}
+// in-place on-read transform of a landed stage: y = act(x*scale+shift), 0 where the source position is padding
+__device__ __forceinline__ void dma_transform(const GatherIn& g, char* hb, const int* tcol, const float* scs, int od0, int chunk,
+                                              int wave, int lane) {
+    if (!g.in_scale && g.act == VG_ACT_NONE) return;                // data-gradient operand: pure copy, zero page did the padding
+    const int SU = g.DS >> 4, J = SU >> 6, gpc = g.CK >> 3;
+    const int nitems = gpc * g.HD * J;
+    const float slope = g.act == VG_ACT_RELU ? 0.f : (g.act == VG_ACT_LRELU ? VG_LRELU : 1.f);
+    const bool zero_mode = g.pad_mode != VG_PAD_REFLECT;
+    int j = wave % J, t2 = wave / J; int hd = t2 % g.HD, cg = t2 / g.HD;
+    const int dj = 4 % J, dhd = (4 / J) % g.HD, dcg = (4 / J) / g.HD;
+    for (int it = wave; it < nitems; it += 4, j += dj, hd += (j >= J ? 1 : 0) + dhd, j -= (j >= J ? J : 0), cg += (hd >= g.HD ? 1 : 0) + dcg, hd -= (hd >= g.HD ? g.HD : 0)) {
+        const int c = chunk * g.CK + cg * 8;
+        if (c >= g.Cin) continue;                                   // channel padding stays zero
+        int rd = od0 * g.istr + g.tmin_d + hd;
+        const bool dvalid = resolve_pos(rd, g.D, g.pad_mode);
+        bf16x8* u = (bf16x8*)(hb + (size_t)cg * g.PSB + (size_t)hd * g.DS + j * 1024) + lane;
+        if (zero_mode && !dvalid) continue;                         // whole slice came from the zero page
+        f32x2 sc[4], sf[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            sc[e] = (f32x2){scs[cg * 8 + 2 * e], scs[cg * 8 + 2 * e + 1]};
+            sf[e] = (f32x2){scs[g.CK + cg * 8 + 2 * e], scs[g.CK + cg * 8 + 2 * e + 1]};
+        }
+        const bf16x8 raw = *u;
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = bf2f((bf16_t)raw[e]);
+        stage_affine_act(x, sc, sf, slope);
+        if (zero_mode) {
+            const bool ok = tcol[(c < g.c0 ? 0 : SU) + j * 64 + lane] >= 0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = ok ? x[e] : 0.f;
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (short)f2bf(x[e]);
+        *u = o;
+    }
+}
+
 // Persistent workgroup: blockIdx.z = sample, blockIdx.y = BN-channel panel, blockIdx.x walks the output tiles of the
 // sample.  Per workgroup ONCE: tap offsets, the (halo voxel, channel group) unit table, the weight panel (if it fits in
 // LDS); per tile: stage halo (batched global loads), MFMA loop, epilogue; InstanceNorm statistics are carried in
 // registers across tiles and flushed once.
-template <typename T, int BN, int MSUB, bool NOISE, bool WL>
+template <typename T, int BN, int MSUB, bool NOISE, bool WL, bool DMA>
 __global__ __launch_bounds__(256, ((BN / 16) * MSUB >= 8 ? 2 : VG_CONV_WAVES)) void conv_kernel(const GatherIn g, const ConvOut p) {
     constexpr bool F32 = sizeof(T) == 4;
     // wave decomposition: WN waves along the channel panel (one 16-channel sub-tile each, so a weight fragment is
     // fetched by exactly one wave: L1 delivers 64 B/clk, LDS 256 B/clk), WM waves along the voxels
     constexpr int WN = BN / 16, WM = 4 / WN, MW = MSUB * WN;     // MW voxel sub-tiles per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wave_n = wave % WN, wave_m = wave / WN;
     const int n = blockIdx.z, ntile = blockIdx.y;
     const int TWm = (1 << g.twl) - 1, THm = (1 << g.thl) - 1;
 
     char* halo = smem;
-    const int hbytes = g.planar ? (g.CK >> 3) * g.PSB : g.HD * g.HHp * g.HWp * g.VS;
-    int* tapoff = (int*)(smem + hbytes);
-    float* scs = (float*)(smem + hbytes + 256);
-    float* stat = scs + 2 * g.CK;
+    const int hbytes = g.planar ? (g.CK >> 3) * g.PSB : g.HD * g.DS;
+    const int nhalo = DMA ? 2 : 1;                   // LDS-DMA staging double-buffers the image
+    int* tapoff = (int*)(smem + nhalo * hbytes);
+    float* scs = (float*)(smem + nhalo * hbytes + 256);
+    float* stat = scs + (DMA ? 4 : 2) * g.CK;        // DMA: two scale/shift buffers (next chunk is prepared ahead)
     int* utab = (int*)(stat + BN * 2);
     const int ncols = stage_ncols(g);
-    const int nunits = 2 * ncols + 3 * (g.HH + g.HW);               // column table + per-tile axis tables
+    const int SU = g.DS >> 4;                        // DMA: units per D-slice (multiple of 64)
+    const int nunits = DMA ? 5 * SU : 2 * ncols + 3 * (g.HH + g.HW);     // staging tables (see conv_lds_bytes)
     int* rtab = utab + 2 * ncols;
+    int* cq = utab; int* tcolb = utab + SU;          // DMA: static column table, tcol[2 tiles][2 sources][SU]
     const int gpc = g.CK >> 3;
     const int ngroups = g.ntaps * gpc;
     const int ksteps = (ngroups + 3) >> 2;
@@ -146,13 +252,13 @@ __global__ __launch_bounds__(256, ((BN / 16) * MSUB >= 8 ? 2 : VG_CONV_WAVES)) v
     wlds = (char*)(((size_t)wlds + 15) & ~(size_t)15);
 
     if (tid < g.ntaps)
-        tapoff[tid] = (((g.td[tid] - g.tmin_d) * g.HHp + (g.th[tid] - g.tmin_h)) * g.HWp + halo_pos_w(g, g.tw[tid] - g.tmin_w)) * g.VS;
+        tapoff[tid] = (g.td[tid] - g.tmin_d) * g.DS + ((g.th[tid] - g.tmin_h) * g.HWp + halo_pos_w(g, g.tw[tid] - g.tmin_w)) * g.VS;
     if (tid < BN * 2) stat[tid] = 0.f;
-    build_column_table(g, utab, tid);
+    if constexpr (DMA) dma_build_cq(g, cq, tid); else build_column_table(g, utab, tid);
     for (int i = tid; i < ksteps * 4; i += 256) {
         int G = i; if (G >= ngroups) G = ngroups - 1;                       // padded K: weights are zero there
         const int tp = G / gpc, cgq = G - tp * gpc;
-        koff[i] = (((g.td[tp] - g.tmin_d) * g.HHp + (g.th[tp] - g.tmin_h)) * g.HWp + halo_pos_w(g, g.tw[tp] - g.tmin_w)) * g.VS + cgq * g.CS;
+        koff[i] = (g.td[tp] - g.tmin_d) * g.DS + ((g.th[tp] - g.tmin_h) * g.HWp + halo_pos_w(g, g.tw[tp] - g.tmin_w)) * g.VS + cgq * g.CS;
     }
     if (WL) {               // weight panel -> LDS, 16 B per thread per step
         const int per_row = (p.Ktot * (int)sizeof(T)) >> 4;
@@ -169,7 +275,7 @@ __global__ __launch_bounds__(256, ((BN / 16) * MSUB >= 8 ? 2 : VG_CONV_WAVES)) v
         const int m = (wave_m * MW + i) * 16 + (lane & 15);
         const int w = m & TWm, h = (m >> g.twl) & THm, d = m >> (g.twl + g.thl);
         // W step is one unit for either stride: stride-2 gathers read the de-interleaved image (halo_pos_w)
-        rowbase[i] = ((d * g.istr * g.HHp + h * g.istr) * g.HWp + w) * g.VS;
+        rowbase[i] = d * g.istr * g.DS + (h * g.istr * g.HWp + w) * g.VS;
     }
     // weight fragment source: LDS panel or global (L2) rows -- kept as two address-space-typed pointers (a pointer
     // selected between the two becomes generic and every fragment fetch a flat_load)
@@ -203,30 +309,67 @@ __global__ __launch_bounds__(256, ((BN / 16) * MSUB >= 8 ? 2 : VG_CONV_WAVES)) v
 
     const int tiles_per_n = g.tiles_d * g.tiles_h * g.tiles_w;
     int it = -1;
-    for (int tile = blockIdx.x; tile < tiles_per_n; tile += gridDim.x) {
-        ++it;
-        VG_STAMP(0);
+    int sidx = 0;                                    // DMA: running stage index (tile visit x channel chunk)
+    auto tile_origin = [&](int tile, int& od0, int& oh0, int& ow0) {
         int t = tile;
         const int tw_i = t % g.tiles_w; t /= g.tiles_w;
         const int th_i = t % g.tiles_h; const int td_i = t / g.tiles_h;
-        const int od0 = td_i << g.tdl, oh0 = th_i << g.thl, ow0 = tw_i << g.twl;
+        od0 = td_i << g.tdl; oh0 = th_i << g.thl; ow0 = tw_i << g.twl;
+    };
+    if constexpr (DMA) {
+        // prologue: tables and copies of the first stage
+        if ((int)blockIdx.x < tiles_per_n) {
+            int od0, oh0, ow0; tile_origin(blockIdx.x, od0, oh0, ow0);
+            dma_build_tcol(g, cq, tcolb, oh0, ow0, tid);
+            if (p.nchunks > 1) stage_scale_shift(g, scs, n, 0, tid);
+            __syncthreads();
+            dma_issue(g, halo, tcolb, n, od0, 0, wave, lane);
+        }
+    }
+    for (int tile = blockIdx.x; tile < tiles_per_n; tile += gridDim.x) {
+        ++it;
+        VG_STAMP(0);
+        int od0, oh0, ow0; tile_origin(tile, od0, oh0, ow0);
         f32x4 acc[MW];
 #pragma unroll
         for (int i = 0; i < MW; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
         for (int chunk = 0; chunk < p.nchunks; ++chunk) {
-            __syncthreads();                       // previous readers of the halo tile are done
-            if (p.nchunks > 1) stage_scale_shift(g, scs, n, chunk, tid);
-            if (chunk == 0) stage_resolve_axes(g, rtab, oh0, ow0, tid);
-            if (p.nchunks > 1 || chunk == 0) __syncthreads();
-            if (!(g.dbg & 1)) stage_halo_tile<T, NOISE, (NOISE ? 4 : 6)>(g, halo, scs, utab, rtab, n, od0, chunk, tid);
-            if (chunk == 0) VG_STAMP(1);
-            __syncthreads();
-            if (chunk == 0) VG_STAMP(2);
+            char* hb = halo;
+            if constexpr (DMA) {
+                hb = halo + (sidx & 1) * hbytes;
+                int* tc = tcolb + (it & 1) * 2 * SU;
+                const float* sc_cur = scs + (p.nchunks > 1 ? (sidx & 1) * 2 * g.CK : 0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this stage's copies have landed (this wave's share)
+                __syncthreads();                                         // ... everyone's; previous stage fully consumed
+                // identity of the next stage; its tables / scale-shift go to the other buffers while this stage is transformed
+                const bool next_same = chunk + 1 < p.nchunks;
+                const int ntile2 = next_same ? tile : tile + (int)gridDim.x;
+                const bool has_next = ntile2 < tiles_per_n;
+                int nd0 = od0, nh0 = oh0, nw0 = ow0;
+                if (has_next && !next_same) { tile_origin(ntile2, nd0, nh0, nw0); dma_build_tcol(g, cq, tcolb + ((it + 1) & 1) * 2 * SU, nh0, nw0, tid); }
+                if (has_next && p.nchunks > 1) stage_scale_shift(g, scs + ((sidx + 1) & 1) * 2 * g.CK, n, next_same ? chunk + 1 : 0, tid);
+                if (!(g.dbg & 1)) dma_transform(g, hb, tc, sc_cur, od0, chunk, wave, lane);
+                if (chunk == 0) VG_STAMP(1);
+                __syncthreads();
+                if (chunk == 0) VG_STAMP(2);
+                if (has_next)
+                    dma_issue(g, halo + ((sidx + 1) & 1) * hbytes, tcolb + ((next_same ? it : it + 1) & 1) * 2 * SU, n, nd0, next_same ? chunk + 1 : 0, wave, lane);
+                ++sidx;
+            } else {
+                __syncthreads();                       // previous readers of the halo tile are done
+                if (p.nchunks > 1) stage_scale_shift(g, scs, n, chunk, tid);
+                if (chunk == 0) stage_resolve_axes(g, rtab, oh0, ow0, tid);
+                if (p.nchunks > 1 || chunk == 0) __syncthreads();
+                if (!(g.dbg & 1)) stage_halo_tile<T, NOISE, (NOISE ? 4 : 6)>(g, halo, scs, utab, rtab, n, od0, chunk, tid);
+                if (chunk == 0) VG_STAMP(1);
+                __syncthreads();
+                if (chunk == 0) VG_STAMP(2);
+            }
             const size_t kbase = (size_t)chunk * p.kc_pad;
             if (g.dbg & 4) continue;
-            if constexpr (WL) conv_mfma_chunk<T, MW>(acc, wrow_l + kbase, halo, rowbase, tapoff, koff, ksteps, g.ntaps, g.CK, g.CS, lane);
-            else conv_mfma_chunk<T, MW>(acc, wrow_g + kbase, halo, rowbase, tapoff, koff, ksteps, g.ntaps, g.CK, g.CS, lane);
+            if constexpr (WL) conv_mfma_chunk<T, MW>(acc, wrow_l + kbase, hb, rowbase, tapoff, koff, ksteps, g.ntaps, g.CK, g.CS, lane);
+            else conv_mfma_chunk<T, MW>(acc, wrow_g + kbase, hb, rowbase, tapoff, koff, ksteps, g.ntaps, g.CK, g.CS, lane);
         }
         VG_STAMP(3);
         if (g.dbg & 8) continue;
@@ -359,10 +502,10 @@ __global__ __launch_bounds__(256, ((BN / 16) * MSUB >= 8 ? 2 : VG_CONV_WAVES)) v
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-static int conv_lds_bytes(const GatherIn& g, int BN, int CK, int wbytes) {
-    const int nunits = stage_table_ints(g);
+static int conv_lds_bytes(const GatherIn& g, int BN, int CK, int wbytes, int dma = 0) {
+    const int nunits = dma ? 5 * (g.DS >> 4) : stage_table_ints(g);
     const int ksteps = (g.ntaps * (CK >> 3) + 3) >> 2;
-    return halo_bytes(g) + 256 + 2 * CK * 4 + BN * 2 * 4 + nunits * 4 + ksteps * 16 + 16 + wbytes;
+    return (dma ? 2 : 1) * halo_bytes(g) + 256 + (dma ? 4 : 2) * CK * 4 + BN * 2 * 4 + nunits * 4 + ksteps * 16 + 16 + wbytes;
 }
 
 static int fill_conv(const vg_conv_desc* d, GatherIn& g, ConvOut& k, int& BN, int& MSUB, int& lds) {
@@ -380,8 +523,10 @@ static int fill_conv(const vg_conv_desc* d, GatherIn& g, ConvOut& k, int& BN, in
     // Tile choice.  Efficiency wants a wide channel panel (BN) and a big voxel tile (MSUB*64: fewer halo voxels per
     // output voxel, more MFMAs per staged byte); the chip wants >= ~2 workgroups per CU.  Small grids (16^3, 8^3 levels)
     // therefore take narrow panels / small tiles.  Within a class, prefer <= 80 KiB of LDS (two workgroups per CU).
-    static int force_msub = -1, no_wlds = -1, force_bn = -1;
+    static int force_msub = -1, no_wlds = -1, force_bn = -1, use_dma = 0, max_ms16 = 8;
     if (force_msub < 0) {
+        const char* e5 = getenv("VG_CONV_MS16"); max_ms16 = e5 ? atoi(e5) : 8;
+        const char* e4 = getenv("VG_CONV_DMA"); use_dma = e4 ? atoi(e4) : 0;    // measured neutral (51.5 vs 51.7 ms/step): these kernels are issue-bound, not latency-bound
         const char* e = getenv("VG_CONV_MSUB"); force_msub = e ? atoi(e) : 0;
         const char* e2 = getenv("VG_CONV_NOWLDS"); no_wlds = e2 ? atoi(e2) : 0;
         const char* e3 = getenv("VG_CONV_BN"); force_bn = e3 ? atoi(e3) : 0;
@@ -389,11 +534,14 @@ static int fill_conv(const vg_conv_desc* d, GatherIn& g, ConvOut& k, int& BN, in
     const int bn_max = d->Cout <= 16 ? 16 : (d->Cout <= 32 ? 32 : 64);
     int found = 0, rc = VG_ELDS;
     long best_score = -1;
-    int best_bn = 0, best_ms = 0, best_wl = 0, best_lds = 0;
+    int best_bn = 0, best_ms = 0, best_wl = 0, best_lds = 0, best_dma = 0;
+    // LDS-DMA staging: bf16 planar image of a multi-channel, noise-free source, weights resident in LDS
+    const bool dma_ok = use_dma && !d->f32 && Cin != 1 && !d->noise && d->istr == 1 && d->CK <= 48;
     for (int bn = bn_max; bn >= 16; bn >>= 1) {
         if (force_bn && bn != force_bn && bn != bn_max) continue;
-        for (int ms = (bn <= 32 ? 4 : 2); ms >= 1; ms >>= 1) {
+        for (int ms = (bn == 16 ? max_ms16 : (bn == 32 ? 4 : 2)); ms >= 1; ms >>= 1) {
             if (force_msub && ms != force_msub) continue;
+            if (ms == 8 && d->f32) continue;
             rc = fill_gather(d, g, d->CK, 64 * ms);
             if (rc != VG_OK) return rc;
             const long wgs = (long)g.tiles_d * g.tiles_h * g.tiles_w * ((d->Cout + bn - 1) / bn) * d->N;
@@ -402,15 +550,23 @@ static int fill_conv(const vg_conv_desc* d, GatherIn& g, ConvOut& k, int& BN, in
             int need = conv_lds_bytes(g, bn, d->CK, wl ? wbytes : 0);
             if (need > 80 * 1024 && wl) { const int n2 = conv_lds_bytes(g, bn, d->CK, 0); if (n2 <= 80 * 1024 || need > VG_LDS_LIMIT) { wl = 0; need = n2; } }
             if (need > VG_LDS_LIMIT) continue;
+            if (ms == 8 && need > 80 * 1024) continue;     // the 512-voxel tile only pays while two workgroups stay resident
+            int dma = 0;
+            if (dma_ok && wl) {
+                GatherIn g2; rc = fill_gather(d, g2, d->CK, 64 * ms, 0, 1);
+                if (rc != VG_OK) return rc;
+                const int need2 = conv_lds_bytes(g2, bn, d->CK, wbytes, 1);
+                if (g2.planar && need2 <= 80 * 1024) { dma = 1; need = need2; }
+            }
             // score: reaching 512 workgroups dominates, then work per workgroup-tile (bn*ms), then small LDS
             const long fill = wgs >= 512 ? 512 : wgs;
             const long score = fill * 100000 + (long)bn * ms * 100 + (need <= 80 * 1024 ? 50 : 0);
-            if (score > best_score) { best_score = score; best_bn = bn; best_ms = ms; best_wl = wl; best_lds = need; found = 1; }
+            if (score > best_score) { best_score = score; best_bn = bn; best_ms = ms; best_wl = wl; best_lds = need; best_dma = dma; found = 1; }
         }
     }
-    if (found) { BN = best_bn; MSUB = best_ms; k.w_lds = best_wl; lds = best_lds; }
+    if (found) { BN = best_bn; MSUB = best_ms; k.w_lds = best_wl; k.dma = best_dma; lds = best_lds; }
     if (!found) return VG_ELDS;
-    rc = fill_gather(d, g, d->CK, 64 * MSUB);
+    rc = fill_gather(d, g, d->CK, 64 * MSUB, 0, k.dma);
     if (rc != VG_OK) return rc;
     k.OD = d->OD; k.OH = d->OH; k.OW = d->OW; k.ostr = d->ostr; k.ood = d->ooff_d; k.ooh = d->ooff_h; k.oow = d->ooff_w;
     k.BD = d->BD; k.BH = d->BH; k.BW = d->BW; k.Cout = d->Cout;
@@ -438,26 +594,35 @@ extern "C" int vg_conv3d_lds_bytes(const vg_conv_desc* d) {
     return rc == VG_OK ? lds : rc;
 }
 
-template <typename T, int BN, int MSUB, bool NOISE, bool WL>
+template <typename T, int BN, int MSUB, bool NOISE, bool WL, bool DMA>
 static int launch_conv3(const GatherIn& g, const ConvOut& k, int lds, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_kernel<T, BN, MSUB, NOISE, WL>, hipFuncAttributeMaxDynamicSharedMemorySize, VG_LDS_LIMIT);
+        (void)hipFuncSetAttribute((const void*)conv_kernel<T, BN, MSUB, NOISE, WL, DMA>, hipFuncAttributeMaxDynamicSharedMemorySize, VG_LDS_LIMIT);
         attr_set = true;
     }
-    static int wg_target = -1;
-    if (wg_target < 0) { const char* e = getenv("VG_CONV_WGS"); wg_target = e ? atoi(e) : 2048; }
+    // persistent grid = what is resident at once (register cap: 3 workgroups per CU, 2 for the 8-sub-tile variants; LDS):
+    // every further workgroup would repeat the per-workgroup prologue (weight panel, tables) for fewer tiles each
+    static int wg_env = -1;
+    if (wg_env < 0) { const char* e = getenv("VG_CONV_WGS"); wg_env = e ? atoi(e) : 0; }
+    int per_cu = ((BN / 16) * MSUB >= 8) ? 2 : VG_CONV_WAVES;
+    if (lds > 0 && VG_LDS_LIMIT / lds < per_cu) per_cu = VG_LDS_LIMIT / lds;
+    if (per_cu < 1) per_cu = 1;
+    const int wg_target = wg_env > 0 ? wg_env : 256 * per_cu;
     const int tiles = g.tiles_d * g.tiles_h * g.tiles_w;
     const int ny = (k.Cout + BN - 1) / BN;
     int bx = wg_target / (ny * g.N); if (bx < 1) bx = 1; if (bx > tiles) bx = tiles;
     dim3 grid(bx, ny, g.N);
-    hipLaunchKernelGGL((conv_kernel<T, BN, MSUB, NOISE, WL>), grid, dim3(256), lds, s, g, k);
+    hipLaunchKernelGGL((conv_kernel<T, BN, MSUB, NOISE, WL, DMA>), grid, dim3(256), lds, s, g, k);
     return vg_check_launch();
 }
 template <typename T, int BN, int MSUB, bool NOISE>
 static int launch_conv2(const GatherIn& g, const ConvOut& k, int lds, hipStream_t s) {
-    if constexpr (sizeof(T) == 2) { if (k.w_lds) return launch_conv3<T, BN, MSUB, NOISE, true>(g, k, lds, s); }
-    return launch_conv3<T, BN, MSUB, NOISE, false>(g, k, lds, s);
+    if constexpr (sizeof(T) == 2) {
+        if constexpr (!NOISE) { if (k.w_lds && k.dma) return launch_conv3<T, BN, MSUB, NOISE, true, true>(g, k, lds, s); }
+        if (k.w_lds) return launch_conv3<T, BN, MSUB, NOISE, true, false>(g, k, lds, s);
+    }
+    return launch_conv3<T, BN, MSUB, NOISE, false, false>(g, k, lds, s);
 }
 template <typename T, int BN, int MSUB>
 static int launch_conv(const GatherIn& g, const ConvOut& k, int lds, hipStream_t s) {
@@ -465,6 +630,7 @@ static int launch_conv(const GatherIn& g, const ConvOut& k, int lds, hipStream_t
 }
 template <typename T>
 static int dispatch_conv(const GatherIn& g, const ConvOut& k, int BN, int MSUB, int lds, hipStream_t s) {
+    if (BN == 16 && MSUB == 8) { if constexpr (sizeof(T) == 2) return launch_conv<T, 16, 8>(g, k, lds, s); else return VG_EINVAL; }
     if (BN == 16) return MSUB == 4 ? launch_conv<T, 16, 4>(g, k, lds, s) : (MSUB == 2 ? launch_conv<T, 16, 2>(g, k, lds, s) : launch_conv<T, 16, 1>(g, k, lds, s));
     if (BN == 32) return MSUB == 4 ? launch_conv<T, 32, 4>(g, k, lds, s) : (MSUB == 2 ? launch_conv<T, 32, 2>(g, k, lds, s) : launch_conv<T, 32, 1>(g, k, lds, s));
     return MSUB == 2 ? launch_conv<T, 64, 2>(g, k, lds, s) : launch_conv<T, 64, 1>(g, k, lds, s);

@@ -15,6 +15,7 @@ struct GatherIn {
     int8_t td[VG_MAX_TAPS], th[VG_MAX_TAPS], tw[VG_MAX_TAPS];
     int tmin_d, tmin_h, tmin_w, HD, HH, HW, CK;
     int HHp, HWp, US, PSB;   // LDS halo image, pitches HHp/HWp in voxels, unit = 8 channels = US bytes.  Two forms, both
+    int DS;                  // bytes of one D-slice of the image (HHp*HWp*VS, rounded to 64 units for LDS-DMA staging)
     int VS, CS, planar;      // addressed as voxel * VS + channel_group * CS:  planar [group][HD][HHp][HWp] (VS = US,
                              // CS = PSB: bank-conflict-free fragment reads, voxel-fastest staging) for thin chunks, and
                              // row-major [HD][HHp][HWp][CK + pad] (VS = row bytes, CS = US: full-line global loads) for wide ones
@@ -135,7 +136,7 @@ __device__ __forceinline__ void stage_halo_c1(const GatherIn& g, char* halo, con
                                               int n, int pd0, int tid) {
     const int L = g.HH + g.HW;
     const int ncols = g.HH * g.HW;
-    const int plane = g.HHp * g.HWp * g.VS;
+    const int plane = g.DS;
     const float slope = g.act == VG_ACT_RELU ? 0.f : (g.act == VG_ACT_LRELU ? VG_LRELU : 1.f);
     const int ND = g.D + 2 * g.npad;
     const int nplane = (g.H + 2 * g.npad) * (g.W + 2 * g.npad);
@@ -191,7 +192,7 @@ __device__ __forceinline__ void stage_halo_tile(const GatherIn& g, char* halo, c
                                                 int n, int od0, int chunk, int tid) {
     const int L = g.HH + g.HW;
     const int ncols = stage_ncols(g);
-    const int plane = g.HHp * g.HWp * g.VS;                    // bytes of one D-plane of the halo image
+    const int plane = g.DS;                                    // bytes of one D-slice of the halo image
     const int pd0 = od0 * g.istr + g.tmin_d;
     const float slope = g.act == VG_ACT_RELU ? 0.f : (g.act == VG_ACT_LRELU ? VG_LRELU : 1.f);
     const bool zero_mode = g.pad_mode != VG_PAD_REFLECT;
@@ -303,7 +304,7 @@ static inline void pad_pitches(int hh, int hw, int tw, int th, int istr, int& hh
 // skew: extra bytes on the plane stride (0: consecutive planes share banks -- right for the forward kernel whose lane
 // groups mix two planes over disjoint voxel sets; 64: the weight-gradient kernel's transposed reads take both planes of
 // the same 8 voxels)
-static inline int fill_gather(const vg_conv_desc* d, GatherIn& g, int CK, int BM, int skew = 0) {
+static inline int fill_gather(const vg_conv_desc* d, GatherIn& g, int CK, int BM, int skew = 0, int dma = 0) {
     if (!d || !d->src0) return VG_EINVAL;
     g.f32 = d->f32 ? 1 : 0;
     { static int dbg = -1; if (dbg < 0) { const char* e = getenv("VG_DEBUG"); dbg = e ? atoi(e) : 0; } g.dbg = dbg; }
@@ -362,11 +363,13 @@ static inline int fill_gather(const vg_conv_desc* d, GatherIn& g, int CK, int BM
     g.HWh = d->istr == 2 ? (g.HW + 1) / 2 : 0;
     g.HHp = g.HH; g.HWp = g.HWh ? 2 * g.HWh : g.HW;
     if (g.planar) pad_pitches(g.HH, g.HW, TW, TH, d->istr, g.HHp, g.HWp);
-    g.PSB = ((g.HD * g.HHp * g.HWp * g.US + 255) & ~255) + skew;
-    if (g.planar) { g.VS = g.US; g.CS = g.PSB; }
-    else { g.VS = CK * (d->f32 ? 4 : 2) + 16; g.CS = g.US; }
+    if (g.planar) {
+        g.VS = g.US; g.DS = g.HHp * g.HWp * g.US;
+        if (dma) g.DS = (g.DS + 1023) & ~1023;          // whole 64-unit pieces per D-slice (one LDS-DMA wave-instruction each)
+        g.PSB = ((g.HD * g.DS + 255) & ~255) + skew; g.CS = g.PSB;
+    } else { g.VS = CK * (d->f32 ? 4 : 2) + 16; g.CS = g.US; g.DS = g.HHp * g.HWp * g.VS; g.PSB = 0; }
     return VG_OK;
 }
-static inline int halo_bytes(const GatherIn& g) { return g.planar ? (g.CK >> 3) * g.PSB : g.HD * g.HHp * g.HWp * g.VS; }
+static inline int halo_bytes(const GatherIn& g) { return g.planar ? (g.CK >> 3) * g.PSB : g.HD * g.DS; }
 // LDS ints of the staging tables (column table + per-tile axis tables)
 static inline int stage_table_ints(const GatherIn& g) { return 2 * stage_ncols(g) + 3 * (g.HH + g.HW); }

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256, (RMAX * Q >= 16 ? 2 : 3)) void wgrad_kernel(co
 
     const int BM = 1 << (g.tdl + g.thl + g.twl);
     char* halo = smem;
-    const int hbytes = g.planar ? (g.CK >> 3) * g.PSB : g.HD * g.HHp * g.HWp * g.VS;
+    const int hbytes = g.planar ? (g.CK >> 3) * g.PSB : g.HD * g.DS;
     char* dyt = smem + hbytes;
     const int dybytes = BM * p.DYS;
     int* tapoff = (int*)(dyt + dybytes);
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256, (RMAX * Q >= 16 ? 2 : 3)) void wgrad_kernel(co
     int* rtab = utab + 2 * stage_ncols(g);
 
     if (tid < g.ntaps)
-        tapoff[tid] = (((g.td[tid] - g.tmin_d) * g.HHp + (g.th[tid] - g.tmin_h)) * g.HWp + halo_pos_w(g, g.tw[tid] - g.tmin_w)) * g.VS;
+        tapoff[tid] = (g.td[tid] - g.tmin_d) * g.DS + ((g.th[tid] - g.tmin_h) * g.HWp + halo_pos_w(g, g.tw[tid] - g.tmin_w)) * g.VS;
     if (tid < VG_MAX_TAPS) tapsrc[tid] = p.tap_src[tid];
     build_column_table(g, utab, tid);
     __syncthreads();
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256, (RMAX * Q >= 16 ? 2 : 3)) void wgrad_kernel(co
             for (int s = 0; s < BM / 4; ++s) {
                 const int m0 = s * 4 + lg;
                 const int w0 = m0 & TWm, h0 = (m0 >> g.twl) & THm, d0 = m0 >> (g.twl + g.thl);
-                const int r0 = ((d0 * g.istr * g.HHp + h0 * g.istr) * g.HWp + w0) * g.VS + (li >> 3) * g.CS + (li & 7) * 4;
+                const int r0 = d0 * g.istr * g.DS + (h0 * g.istr * g.HWp + w0) * g.VS + (li >> 3) * g.CS + (li & 7) * 4;
                 const char* y0 = dyt + (size_t)m0 * p.DYS + li * 4;
                 float b[Q];
 #pragma unroll
@@ -184,8 +184,8 @@ __global__ __launch_bounds__(256, (RMAX * Q >= 16 ? 2 : 3)) void wgrad_kernel(co
                 const int m1 = m0 + 4;
                 const int w0 = m0 & TWm, h0 = (m0 >> g.twl) & THm, d0 = m0 >> (g.twl + g.thl);
                 const int w1 = m1 & TWm, h1 = (m1 >> g.twl) & THm, d1 = m1 >> (g.twl + g.thl);
-                r0 = ((d0 * g.istr * g.HHp + h0 * g.istr) * g.HWp + w0) * g.VS + ((li & 3) >> 1) * g.CS + 8 * (li & 1);
-                r1 = ((d1 * g.istr * g.HHp + h1 * g.istr) * g.HWp + w1) * g.VS + ((li & 3) >> 1) * g.CS + 8 * (li & 1);
+                r0 = d0 * g.istr * g.DS + (h0 * g.istr * g.HWp + w0) * g.VS + ((li & 3) >> 1) * g.CS + 8 * (li & 1);
+                r1 = d1 * g.istr * g.DS + (h1 * g.istr * g.HWp + w1) * g.VS + ((li & 3) >> 1) * g.CS + 8 * (li & 1);
                 y0 = dyt + (size_t)m0 * p.DYS + 8 * (li & 3);
                 y1 = dyt + (size_t)m1 * p.DYS + 8 * (li & 3);
             };
@@ -313,13 +313,16 @@ extern "C" int vg_conv3d_wgrad(const vg_conv_desc* d, const void* dy, int dy_f32
     const int RMAX = Q == 1 ? 24 : (Q == 2 ? 12 : 6);
     const int esz = d->f32 ? 4 : 2;
     GatherIn g; WgradK k;
+    static int max_bm = -1;
+    if (max_bm < 0) { const char* e = getenv("VG_WGRAD_BM"); max_bm = e ? atoi(e) : 256; }
     // candidate (BM, CIB) in order of preference: large tile + all channels, LDS <= 80 KiB so that two workgroups fit a CU
     int best_bm = 0, best_cib = 0, best_lds = 0;
     for (int pass = 0; pass < 2 && !best_bm; ++pass) {
         const int limit = pass == 0 ? 80 * 1024 : VG_LDS_LIMIT;
-        for (int bm = 128; bm >= 64 && !best_bm; bm -= 64)
+        for (int bm = 256; bm >= 64 && !best_bm; bm = bm == 256 ? 128 : bm - 64)
             for (int c = 64; c >= 16; c -= 16) {
                 if (Cinp % c) continue;
+                if (bm == 256 && (Q > 2 || max_bm < 256)) continue;     // dY tile staging holds <= 4 units per thread
                 int rc = fill_gather(d, g, c, bm, d->f32 ? 0 : 64);
                 if (rc != VG_OK) return rc;
                 const int lds = halo_bytes(g) + bm * (COB * esz + 16) + 512 + 2 * c * 4 + stage_table_ints(g) * 4;
@@ -342,8 +345,15 @@ extern "C" int vg_conv3d_wgrad(const vg_conv_desc* d, const void* dy, int dy_f32
     k.dw = dw; k.db = db;
     k.total_tiles = d->N * g.tiles_d * g.tiles_h * g.tiles_w;
     const int by = k.ntg * k.ncib * k.ncob;
-    static int wg_target = -1;
-    if (wg_target < 0) { const char* e = getenv("VG_WGRAD_WGS"); wg_target = e ? atoi(e) : 512; }
+    // persistent grid = resident capacity (2 workgroups per CU for the big-slab variants, 3 for the small ones; LDS)
+    static int wg_env = -1;
+    if (wg_env < 0) { const char* e = getenv("VG_WGRAD_WGS"); wg_env = e ? atoi(e) : 0; }
+    const int rw_ = (k.tpg * rows_per_tap + 3) / 4;
+    const int rmax_sel = d->f32 ? RMAX : (rw_ <= 2 ? 2 : (rw_ <= 8 && Q <= 2 ? 8 : RMAX));
+    int per_cu = (rmax_sel * Q >= 16) ? 2 : 3;
+    if (VG_LDS_LIMIT / lds < per_cu) per_cu = VG_LDS_LIMIT / lds;
+    if (per_cu < 1) per_cu = 1;
+    const int wg_target = wg_env > 0 ? wg_env : 256 * per_cu;
     int bx = wg_target / by; if (bx < 1) bx = 1; if (bx > k.total_tiles) bx = k.total_tiles;
     // many workgroups per dW element: float atomics on a few-KB dW serialise (measured 0.7 ms on a 27 KB dW from 1024
     // workgroups), so each workgroup column stores its slab to a private partial buffer that a second kernel sums
