@@ -94,6 +94,16 @@ typedef struct {
     float* out_sums;         /* [VG_STRIPES][N][Cout][2] += (sum, sum of squares) of the stored values, or NULL */
     int32_t f32;             /* exact-parity mode: every "bf16" buffer of this call (multi-channel sources, res, out,
                                 packed weights, and dy/dgrad operands) is float32 and the MFMA is the f32 16x16x4 form */
+    /* Fused output-parity classes (data gradient of a strided Conv3D, vangan.py:426-438 via tf.GradientTape): with
+       nclass > 1 ONE launch stages each dY halo tile once and produces the outputs of all classes.  Class c uses the
+       taps tap_*[cls_tap0[c] .. cls_tap0[c+1]), its own packed weights cls_w[c] (packed with those taps and CK), the
+       output offset cls_ooff[c] (replaces ooff_*) and cls_iters[c] outputs per axis (replaces OD/OH/OW, which must
+       hold the per-axis maximum).  Requires c_src0 + c_src1 <= CK (one channel chunk).  nclass 0 or 1: fields unused. */
+    int32_t nclass;
+    int32_t cls_tap0[9];
+    const void* cls_w[8];
+    int32_t cls_ooff[8][3];
+    int32_t cls_iters[8][3];
 } vg_conv_desc;
 
 int vg_conv3d(const vg_conv_desc* d, vg_stream_t stream);

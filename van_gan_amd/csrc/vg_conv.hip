@@ -31,6 +31,16 @@ struct ConvOut {
     int dma;            // 1: LDS-DMA double-buffered staging (planar bf16 image, weights in LDS)
     int WRS;
 };
+// output-parity classes fused into one launch (data gradient of a strided conv): a separate kernel argument that only the
+// multi-class kernel variants read
+struct ConvCls {
+    int ncls;
+    int tap0[9];                    // taps of class c: [tap0[c], tap0[c+1])
+    const void* wp[8];              // packed weights of class c, ktot[c] elements per row
+    int ktot[8], woff[8];           // ... and the byte offset of its panel inside the LDS weight area
+    int ks0[9];                     // first K-step of class c in the koff table
+    int off[8][3], it[8][3];        // output offset / number of outputs per axis of class c
+};
 
 // 4 consecutive channels as stored (epilogue operands)
 template <typename T> struct Vec4;
@@ -220,8 +230,9 @@ __device__ __forceinline__ void dma_transform(const GatherIn& g, char* hb, const
 // sample.  Per workgroup ONCE: tap offsets, the (halo voxel, channel group) unit table, the weight panel (if it fits in
 // LDS); per tile: stage halo (batched global loads), MFMA loop, epilogue; InstanceNorm statistics are carried in
 // registers across tiles and flushed once.
-template <typename T, int BN, int MSUB, bool NOISE, bool WL, bool DMA>
-__global__ __launch_bounds__(256, ((BN / 16) * MSUB >= 8 ? 2 : VG_CONV_WAVES)) void conv_kernel(const GatherIn g, const ConvOut p) {
+template <typename T, int BN, int MSUB, bool NOISE, bool WL, bool DMA, bool MC>
+__global__ __launch_bounds__(256, ((BN / 16) * MSUB >= 8 ? 2 : VG_CONV_WAVES)) void conv_kernel(const GatherIn g, const ConvOut p, const ConvCls q) {
+    static_assert(!(MC && DMA), "fused classes use the synchronous staging path");
     constexpr bool F32 = sizeof(T) == 4;
     // wave decomposition: WN waves along the channel panel (one 16-channel sub-tile each, so a weight fragment is
     // fetched by exactly one wave: L1 delivers 64 B/clk, LDS 256 B/clk), WM waves along the voxels
@@ -246,7 +257,7 @@ __global__ __launch_bounds__(256, ((BN / 16) * MSUB >= 8 ? 2 : VG_CONV_WAVES)) v
     int* cq = utab; int* tcolb = utab + SU;          // DMA: static column table, tcol[2 tiles][2 sources][SU]
     const int gpc = g.CK >> 3;
     const int ngroups = g.ntaps * gpc;
-    const int ksteps = (ngroups + 3) >> 2;
+    const int ksteps = MC ? q.ks0[q.ncls] : (ngroups + 3) >> 2;      // MC: K-steps of all classes, each padded to whole steps
     int* koff = utab + nunits;                       // byte offset of the B fragment of (K-step, lane>>4) inside the halo tile
     char* wlds = (char*)(koff + ksteps * 4);
     wlds = (char*)(((size_t)wlds + 15) & ~(size_t)15);
@@ -256,16 +267,29 @@ __global__ __launch_bounds__(256, ((BN / 16) * MSUB >= 8 ? 2 : VG_CONV_WAVES)) v
     if (tid < BN * 2) stat[tid] = 0.f;
     if constexpr (DMA) dma_build_cq(g, cq, tid); else build_column_table(g, utab, tid);
     for (int i = tid; i < ksteps * 4; i += 256) {
-        int G = i; if (G >= ngroups) G = ngroups - 1;                       // padded K: weights are zero there
-        const int tp = G / gpc, cgq = G - tp * gpc;
+        int tp, cgq;
+        if constexpr (MC) {
+            int cls = 0; while (cls + 1 < q.ncls && (i >> 2) >= q.ks0[cls + 1]) ++cls;
+            const int ng = (q.tap0[cls + 1] - q.tap0[cls]) * gpc;
+            int G = i - q.ks0[cls] * 4; if (G >= ng) G = ng - 1;                // padded K: weights are zero there
+            tp = q.tap0[cls] + G / gpc; cgq = G % gpc;
+        } else {
+            int G = i; if (G >= ngroups) G = ngroups - 1;                       // padded K: weights are zero there
+            tp = G / gpc; cgq = G - tp * gpc;
+        }
         koff[i] = (g.td[tp] - g.tmin_d) * g.DS + ((g.th[tp] - g.tmin_h) * g.HWp + halo_pos_w(g, g.tw[tp] - g.tmin_w)) * g.VS + cgq * g.CS;
     }
-    if (WL) {               // weight panel -> LDS, 16 B per thread per step
-        const int per_row = (p.Ktot * (int)sizeof(T)) >> 4;
-        for (int u = tid; u < BN * per_row; u += 256) {
-            const int r = u / per_row, c = u - r * per_row;
-            *(f32x4*)(wlds + (size_t)r * p.WRS + c * 16) =
-                *(const f32x4*)((const char*)p.wp + ((size_t)(ntile * BN + r) * p.Ktot) * sizeof(T) + c * 16);
+    if (WL) {               // weight panel(s) -> LDS, 16 B per thread per step
+        const int npan = MC ? q.ncls : 1;
+        for (int cls = 0; cls < npan; ++cls) {
+            const int ktot = MC ? q.ktot[cls] : p.Ktot;
+            const char* src = (const char*)(MC ? q.wp[cls] : p.wp);
+            char* dstp = wlds + (MC ? q.woff[cls] : 0);
+            const int per_row = (ktot * (int)sizeof(T)) >> 4, wrs = ktot * (int)sizeof(T) + 16;
+            for (int u = tid; u < BN * per_row; u += 256) {
+                const int r = u / per_row, c = u - r * per_row;
+                *(f32x4*)(dstp + (size_t)r * wrs + c * 16) = *(const f32x4*)(src + ((size_t)(ntile * BN + r) * ktot) * sizeof(T) + c * 16);
+            }
         }
     }
 
@@ -331,6 +355,37 @@ __global__ __launch_bounds__(256, ((BN / 16) * MSUB >= 8 ? 2 : VG_CONV_WAVES)) v
         VG_STAMP(0);
         int od0, oh0, ow0; tile_origin(tile, od0, oh0, ow0);
         f32x4 acc[MW];
+        if constexpr (MC) {
+            // fused output-parity classes: the dY halo tile is staged once; every class runs its own taps / weights /
+            // accumulators over it and writes its own output sub-lattice
+            __syncthreads();                       // previous readers of the halo tile are done
+            stage_resolve_axes(g, rtab, oh0, ow0, tid);
+            __syncthreads();
+            if (!(g.dbg & 1)) stage_halo_tile<T, NOISE, (NOISE ? 4 : 6)>(g, halo, scs, utab, rtab, n, od0, 0, tid);
+            VG_STAMP(1);
+            __syncthreads();
+            VG_STAMP(2);
+            for (int cls = 0; cls < q.ncls; ++cls) {
+#pragma unroll
+                for (int i = 0; i < MW; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (!(g.dbg & 4)) {
+                    const int ktot = q.ktot[cls];
+                    const int ks = q.ks0[cls + 1] - q.ks0[cls], nt = q.tap0[cls + 1] - q.tap0[cls];
+                    if constexpr (WL) {
+                        const lds_ptr<T> w = (lds_ptr<T>)(wlds + q.woff[cls] + (size_t)(wave_n * 16 + (lane & 15)) * (ktot * (int)sizeof(T) + 16)) + (F32 ? 1 : 8) * (lane >> 4);
+                        conv_mfma_chunk<T, MW>(acc, w, halo, rowbase, tapoff + q.tap0[cls], koff + q.ks0[cls] * 4, ks, nt, g.CK, g.CS, lane);
+                    } else {
+                        const glb_ptr<T> w = (glb_ptr<T>)q.wp[cls] + (size_t)(ntile * BN + wave_n * 16 + (lane & 15)) * ktot + (F32 ? 1 : 8) * (lane >> 4);
+                        conv_mfma_chunk<T, MW>(acc, w, halo, rowbase, tapoff + q.tap0[cls], koff + q.ks0[cls] * 4, ks, nt, g.CK, g.CS, lane);
+                    }
+                }
+                if (!(g.dbg & 8)) {
+                    const int c_od = q.off[cls][0], c_oh = q.off[cls][1], c_ow = q.off[cls][2];
+                    const int c_OD = q.it[cls][0], c_OH = q.it[cls][1], c_OW = q.it[cls][2];
+#include "vg_conv_epilogue.inc"
+                }
+            }
+        } else {
 #pragma unroll
         for (int i = 0; i < MW; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -372,109 +427,10 @@ __global__ __launch_bounds__(256, ((BN / 16) * MSUB >= 8 ? 2 : VG_CONV_WAVES)) v
             else conv_mfma_chunk<T, MW>(acc, wrow_g + kbase, hb, rowbase, tapoff, koff, ksteps, g.ntaps, g.CK, g.CS, lane);
         }
         VG_STAMP(3);
-        if (g.dbg & 8) continue;
-        // ---- epilogue: lane holds out channels co0..co0+3 of voxel (lane&15) of each of the wave's sub-tiles ----
-        if (vec_epi) {
-            // tile base (wave-uniform, 64-bit) + per-lane constant offset: no per-voxel index math; residual / accumulate
-            // operands of all sub-tiles are fetched up front as 4-channel vectors
-            const size_t tbase = (((size_t)(n * p.BD + od0 * p.ostr + p.ood) * p.BH + oh0 * p.ostr + p.ooh) * p.BW + ow0 * p.ostr + p.oow) * p.Cout;
-            const int remd = p.OD - od0, remh = p.OH - oh0, remw = p.OW - ow0;
-            const bool cok = co0 < p.Cout;
-            bool inr[MW];
-#pragma unroll
-            for (int i = 0; i < MW; ++i)
-                inr[i] = cok && (dhw[i] & 1023) < remd && ((dhw[i] >> 10) & 1023) < remh && (dhw[i] >> 20) < remw;
-            float add[MW][4];
-#pragma unroll
-            for (int i = 0; i < MW; ++i) { add[i][0] = e_bias[0]; add[i][1] = e_bias[1]; add[i][2] = e_bias[2]; add[i][3] = e_bias[3]; }
-            if (p.res) {
-                const T* rp = (const T*)p.res + tbase;
-                Vec4<T> rv[MW];
-#pragma unroll
-                for (int i = 0; i < MW; ++i) vec4_load(rv[i], rp + (inr[i] ? ooff[i] : 0));
-#pragma unroll
-                for (int i = 0; i < MW; ++i) {
-                    float x[4]; vec4_unpack(rv[i], x);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) add[i][r] += x[r] * e_rs[r] + e_rb[r];
-                }
-            }
-            if (p.accumulate) {
-                if (p.out_f32) {
-                    const float* op = (const float*)p.out + tbase;
-                    Vec4<float> ov[MW];
-#pragma unroll
-                    for (int i = 0; i < MW; ++i) vec4_load(ov[i], op + (inr[i] ? ooff[i] : 0));
-#pragma unroll
-                    for (int i = 0; i < MW; ++i) { float x[4]; vec4_unpack(ov[i], x); for (int r = 0; r < 4; ++r) add[i][r] += x[r]; }
-                } else {
-                    const bf16_t* op = (const bf16_t*)p.out + tbase;
-                    Vec4<bf16_t> ov[MW];
-#pragma unroll
-                    for (int i = 0; i < MW; ++i) vec4_load(ov[i], op + (inr[i] ? ooff[i] : 0));
-#pragma unroll
-                    for (int i = 0; i < MW; ++i) { float x[4]; vec4_unpack(ov[i], x); for (int r = 0; r < 4; ++r) add[i][r] += x[r]; }
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < MW; ++i) {
-                if (inr[i]) {
-                    float v[4];
-                    if (p.tanh_out && !p.accumulate) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = tanhf(acc[i][r] + add[i][r]);
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = acc[i][r] + add[i][r];
-                    }
-                    if (p.out_f32) {
-                        *(f32x4*)((float*)p.out + tbase + ooff[i]) = (f32x4){v[0], v[1], v[2], v[3]};
-                    } else {
-                        const bf16x4 pk = {(short)f2bf(v[0]), (short)f2bf(v[1]), (short)f2bf(v[2]), (short)f2bf(v[3])};
-                        *(bf16x4*)((bf16_t*)p.out + tbase + ooff[i]) = pk;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = bf2f((bf16_t)pk[r]);
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { s1[r] += v[r]; s2[r] += v[r] * v[r]; }
-                }
-            }
-        } else
-#pragma unroll
-        for (int i = 0; i < MW; ++i) {
-            const int m = (wave_m * MW + i) * 16 + (lane & 15);
-            const int w = m & TWm, h = (m >> g.twl) & THm, d = m >> (g.twl + g.thl);
-            const int od = od0 + d, oh = oh0 + h, ow = ow0 + w;
-            const bool inr = od < p.OD && oh < p.OH && ow < p.OW;
-            if (!inr || co0 >= p.Cout) continue;
-            const size_t vox = ((size_t)(n * p.BD + od * p.ostr + p.ood) * p.BH + oh * p.ostr + p.ooh) * p.BW + ow * p.ostr + p.oow;
-            const size_t idx = vox * p.Cout + co0;
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int co = co0 + r;
-                float y = acc[i][r];
-                if (co < p.Cout) {
-                    y += e_bias[r];
-                    if (p.res) y += ld1<T>((const T*)p.res + idx + r) * e_rs[r] + e_rb[r];
-                    if (p.tanh_out) y = tanhf(y);
-                    if (p.accumulate) y += p.out_f32 ? ((float*)p.out)[idx + r] : bf2f(((bf16_t*)p.out)[idx + r]);
-                    if (!p.out_f32) y = bfround(y);
-                    s1[r] += y; s2[r] += y * y;
-                }
-                v[r] = y;
-            }
-            if (p.out_f32) {
-                float* o = (float*)p.out + idx;
-                if (co0 + 3 < p.Cout) { *(f32x4*)o = (f32x4){v[0], v[1], v[2], v[3]}; }
-                else { for (int r = 0; r < 4; ++r) if (co0 + r < p.Cout) o[r] = v[r]; }
-            } else {
-                bf16_t* o = (bf16_t*)p.out + idx;
-                if (co0 + 3 < p.Cout) {
-                    bf16x4 pk = {(short)f2bf(v[0]), (short)f2bf(v[1]), (short)f2bf(v[2]), (short)f2bf(v[3])};
-                    *(bf16x4*)o = pk;
-                } else { for (int r = 0; r < 4; ++r) if (co0 + r < p.Cout) o[r] = f2bf(v[r]); }
-            }
+        if (!(g.dbg & 8)) {
+            const int c_od = p.ood, c_oh = p.ooh, c_ow = p.oow, c_OD = p.OD, c_OH = p.OH, c_OW = p.OW;
+#include "vg_conv_epilogue.inc"
+        }
         }
         VG_STAMP(4);
     }
@@ -502,13 +458,13 @@ __global__ __launch_bounds__(256, ((BN / 16) * MSUB >= 8 ? 2 : VG_CONV_WAVES)) v
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-static int conv_lds_bytes(const GatherIn& g, int BN, int CK, int wbytes, int dma = 0) {
+static int conv_lds_bytes(const GatherIn& g, int BN, int CK, int wbytes, int dma = 0, int ksteps_total = 0) {
     const int nunits = dma ? 5 * (g.DS >> 4) : stage_table_ints(g);
-    const int ksteps = (g.ntaps * (CK >> 3) + 3) >> 2;
+    const int ksteps = ksteps_total > 0 ? ksteps_total : (g.ntaps * (CK >> 3) + 3) >> 2;
     return (dma ? 2 : 1) * halo_bytes(g) + 256 + (dma ? 4 : 2) * CK * 4 + BN * 2 * 4 + nunits * 4 + ksteps * 16 + 16 + wbytes;
 }
 
-static int fill_conv(const vg_conv_desc* d, GatherIn& g, ConvOut& k, int& BN, int& MSUB, int& lds) {
+static int fill_conv(const vg_conv_desc* d, GatherIn& g, ConvOut& k, ConvCls& q, int& BN, int& MSUB, int& lds) {
     if (!d || !d->out || !d->wpacked) return VG_EINVAL;
     if (d->Cout < 1 || (d->Cout != 1 && (d->Cout % 4))) return VG_EINVAL;
     if (d->ostr < 1 || d->ostr > 2) return VG_EINVAL;
@@ -520,6 +476,34 @@ static int fill_conv(const vg_conv_desc* d, GatherIn& g, ConvOut& k, int& BN, in
     k.Ktot = k.nchunks * k.kc_pad;
     const int esz = d->f32 ? 4 : 2;
     k.WRS = k.Ktot * esz + 16;
+    // output-parity classes
+    const int gpc_ = d->CK >> 3;
+    q.ncls = d->nclass > 1 ? d->nclass : 1;
+    if (q.ncls > 8) return VG_EINVAL;
+    int wrow_bytes = 0;                 // LDS bytes of one row of every class panel
+    if (q.ncls == 1) {
+        q.tap0[0] = 0; q.tap0[1] = d->ntaps; q.wp[0] = d->wpacked; q.ktot[0] = k.Ktot; q.woff[0] = 0;
+        q.ks0[0] = 0; q.ks0[1] = (d->ntaps * gpc_ + 3) >> 2;
+        q.off[0][0] = d->ooff_d; q.off[0][1] = d->ooff_h; q.off[0][2] = d->ooff_w;
+        q.it[0][0] = d->OD; q.it[0][1] = d->OH; q.it[0][2] = d->OW;
+        wrow_bytes = k.WRS;
+    } else {
+        if (k.nchunks != 1 || d->cls_tap0[0] != 0 || d->cls_tap0[q.ncls] != d->ntaps) return VG_EINVAL;
+        if (d->f32 || d->noise) return VG_EINVAL;              // fused classes: bf16, noise-free sources only
+        q.ks0[0] = 0;
+        for (int c = 0; c < q.ncls; ++c) {
+            const int nt = d->cls_tap0[c + 1] - d->cls_tap0[c];
+            if (nt < 1 || !d->cls_w[c]) return VG_EINVAL;
+            q.tap0[c] = d->cls_tap0[c]; q.wp[c] = d->cls_w[c];
+            q.ktot[c] = ((nt * d->CK + 31) / 32) * 32;
+            q.ks0[c + 1] = q.ks0[c] + ((nt * gpc_ + 3) >> 2);
+            for (int a = 0; a < 3; ++a) { q.off[c][a] = d->cls_ooff[c][a]; q.it[c][a] = d->cls_iters[c][a]; }
+            if (d->cls_iters[c][0] > d->OD || d->cls_iters[c][1] > d->OH || d->cls_iters[c][2] > d->OW) return VG_EINVAL;
+            wrow_bytes += q.ktot[c] * esz + 16;
+        }
+        q.tap0[q.ncls] = d->ntaps;
+    }
+    const int ksteps_total = q.ks0[q.ncls];
     // Tile choice.  Efficiency wants a wide channel panel (BN) and a big voxel tile (MSUB*64: fewer halo voxels per
     // output voxel, more MFMAs per staged byte); the chip wants >= ~2 workgroups per CU.  Small grids (16^3, 8^3 levels)
     // therefore take narrow panels / small tiles.  Within a class, prefer <= 80 KiB of LDS (two workgroups per CU).
@@ -536,7 +520,7 @@ static int fill_conv(const vg_conv_desc* d, GatherIn& g, ConvOut& k, int& BN, in
     long best_score = -1;
     int best_bn = 0, best_ms = 0, best_wl = 0, best_lds = 0, best_dma = 0;
     // LDS-DMA staging: bf16 planar image of a multi-channel, noise-free source, weights resident in LDS
-    const bool dma_ok = use_dma && !d->f32 && Cin != 1 && !d->noise && d->istr == 1 && d->CK <= 48;
+    const bool dma_ok = use_dma && !d->f32 && Cin != 1 && !d->noise && d->istr == 1 && d->CK <= 48 && q.ncls == 1;
     for (int bn = bn_max; bn >= 16; bn >>= 1) {
         if (force_bn && bn != force_bn && bn != bn_max) continue;
         for (int ms = (bn == 16 ? max_ms16 : (bn == 32 ? 4 : 2)); ms >= 1; ms >>= 1) {
@@ -545,17 +529,17 @@ static int fill_conv(const vg_conv_desc* d, GatherIn& g, ConvOut& k, int& BN, in
             rc = fill_gather(d, g, d->CK, 64 * ms);
             if (rc != VG_OK) return rc;
             const long wgs = (long)g.tiles_d * g.tiles_h * g.tiles_w * ((d->Cout + bn - 1) / bn) * d->N;
-            const int wbytes = bn * k.WRS;
+            const int wbytes = bn * wrow_bytes;
             int wl = (wbytes <= 56 * 1024 && !no_wlds && !d->f32) ? 1 : 0;       // exact-parity mode reads weights from L2
-            int need = conv_lds_bytes(g, bn, d->CK, wl ? wbytes : 0);
-            if (need > 80 * 1024 && wl) { const int n2 = conv_lds_bytes(g, bn, d->CK, 0); if (n2 <= 80 * 1024 || need > VG_LDS_LIMIT) { wl = 0; need = n2; } }
+            int need = conv_lds_bytes(g, bn, d->CK, wl ? wbytes : 0, 0, ksteps_total);
+            if (need > 80 * 1024 && wl) { const int n2 = conv_lds_bytes(g, bn, d->CK, 0, 0, ksteps_total); if (n2 <= 80 * 1024 || need > VG_LDS_LIMIT) { wl = 0; need = n2; } }
             if (need > VG_LDS_LIMIT) continue;
             if (ms == 8 && need > 80 * 1024) continue;     // the 512-voxel tile only pays while two workgroups stay resident
             int dma = 0;
             if (dma_ok && wl) {
                 GatherIn g2; rc = fill_gather(d, g2, d->CK, 64 * ms, 0, 1);
                 if (rc != VG_OK) return rc;
-                const int need2 = conv_lds_bytes(g2, bn, d->CK, wbytes, 1);
+                const int need2 = conv_lds_bytes(g2, bn, d->CK, wbytes, 1, ksteps_total);
                 if (g2.planar && need2 <= 80 * 1024) { dma = 1; need = need2; }
             }
             // score: reaching 512 workgroups dominates, then work per workgroup-tile (bn*ms), then small LDS
@@ -568,6 +552,7 @@ static int fill_conv(const vg_conv_desc* d, GatherIn& g, ConvOut& k, int& BN, in
     if (!found) return VG_ELDS;
     rc = fill_gather(d, g, d->CK, 64 * MSUB, 0, k.dma);
     if (rc != VG_OK) return rc;
+    if (q.ncls > 1) { int off = 0; for (int c = 0; c < q.ncls; ++c) { q.woff[c] = off; off += BN * (q.ktot[c] * esz + 16); } }
     k.OD = d->OD; k.OH = d->OH; k.OW = d->OW; k.ostr = d->ostr; k.ood = d->ooff_d; k.ooh = d->ooff_h; k.oow = d->ooff_w;
     k.BD = d->BD; k.BH = d->BH; k.BW = d->BW; k.Cout = d->Cout;
     k.wp = d->wpacked;
@@ -579,8 +564,8 @@ static int fill_conv(const vg_conv_desc* d, GatherIn& g, ConvOut& k, int& BN, in
 extern "C" int vg_conv3d_plan(const vg_conv_desc* d, int32_t* plan4) {
     vg_begin();
     if (!plan4) return VG_EINVAL;
-    GatherIn g; ConvOut k; int BN, MSUB, lds;
-    int rc = fill_conv(d, g, k, BN, MSUB, lds);
+    GatherIn g; ConvOut k; ConvCls q; int BN, MSUB, lds;
+    int rc = fill_conv(d, g, k, q, BN, MSUB, lds);
     if (rc != VG_OK) return rc;
     plan4[0] = BN; plan4[1] = 64 * MSUB; plan4[2] = lds;
     plan4[3] = g.tiles_d * g.tiles_h * g.tiles_w * ((d->Cout + BN - 1) / BN) * d->N;
@@ -589,16 +574,16 @@ extern "C" int vg_conv3d_plan(const vg_conv_desc* d, int32_t* plan4) {
 
 extern "C" int vg_conv3d_lds_bytes(const vg_conv_desc* d) {
     vg_begin();
-    GatherIn g; ConvOut k; int BN, MSUB, lds;
-    int rc = fill_conv(d, g, k, BN, MSUB, lds);
+    GatherIn g; ConvOut k; ConvCls q; int BN, MSUB, lds;
+    int rc = fill_conv(d, g, k, q, BN, MSUB, lds);
     return rc == VG_OK ? lds : rc;
 }
 
-template <typename T, int BN, int MSUB, bool NOISE, bool WL, bool DMA>
-static int launch_conv3(const GatherIn& g, const ConvOut& k, int lds, hipStream_t s) {
+template <typename T, int BN, int MSUB, bool NOISE, bool WL, bool DMA, bool MC>
+static int launch_conv3(const GatherIn& g, const ConvOut& k, const ConvCls& q, int lds, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_kernel<T, BN, MSUB, NOISE, WL, DMA>, hipFuncAttributeMaxDynamicSharedMemorySize, VG_LDS_LIMIT);
+        (void)hipFuncSetAttribute((const void*)conv_kernel<T, BN, MSUB, NOISE, WL, DMA, MC>, hipFuncAttributeMaxDynamicSharedMemorySize, VG_LDS_LIMIT);
         attr_set = true;
     }
     // persistent grid = what is resident at once (register cap: 3 workgroups per CU, 2 for the 8-sub-tile variants; LDS):
@@ -613,36 +598,39 @@ static int launch_conv3(const GatherIn& g, const ConvOut& k, int lds, hipStream_
     const int ny = (k.Cout + BN - 1) / BN;
     int bx = wg_target / (ny * g.N); if (bx < 1) bx = 1; if (bx > tiles) bx = tiles;
     dim3 grid(bx, ny, g.N);
-    hipLaunchKernelGGL((conv_kernel<T, BN, MSUB, NOISE, WL, DMA>), grid, dim3(256), lds, s, g, k);
+    hipLaunchKernelGGL((conv_kernel<T, BN, MSUB, NOISE, WL, DMA, MC>), grid, dim3(256), lds, s, g, k, q);
     return vg_check_launch();
 }
 template <typename T, int BN, int MSUB, bool NOISE>
-static int launch_conv2(const GatherIn& g, const ConvOut& k, int lds, hipStream_t s) {
-    if constexpr (sizeof(T) == 2) {
-        if constexpr (!NOISE) { if (k.w_lds && k.dma) return launch_conv3<T, BN, MSUB, NOISE, true, true>(g, k, lds, s); }
-        if (k.w_lds) return launch_conv3<T, BN, MSUB, NOISE, true, false>(g, k, lds, s);
+static int launch_conv2(const GatherIn& g, const ConvOut& k, const ConvCls& q, int lds, hipStream_t s) {
+    if constexpr (sizeof(T) == 2 && !NOISE) {
+        if (q.ncls > 1) return k.w_lds ? launch_conv3<T, BN, MSUB, NOISE, true, false, true>(g, k, q, lds, s)
+                                       : launch_conv3<T, BN, MSUB, NOISE, false, false, true>(g, k, q, lds, s);
+        if (k.w_lds && k.dma) return launch_conv3<T, BN, MSUB, NOISE, true, true, false>(g, k, q, lds, s);
     }
-    return launch_conv3<T, BN, MSUB, NOISE, false, false>(g, k, lds, s);
+    if (q.ncls > 1) return VG_EINVAL;                     // fused classes: bf16, noise-free sources only
+    if constexpr (sizeof(T) == 2) { if (k.w_lds) return launch_conv3<T, BN, MSUB, NOISE, true, false, false>(g, k, q, lds, s); }
+    return launch_conv3<T, BN, MSUB, NOISE, false, false, false>(g, k, q, lds, s);
 }
 template <typename T, int BN, int MSUB>
-static int launch_conv(const GatherIn& g, const ConvOut& k, int lds, hipStream_t s) {
-    return g.noise ? launch_conv2<T, BN, MSUB, true>(g, k, lds, s) : launch_conv2<T, BN, MSUB, false>(g, k, lds, s);
+static int launch_conv(const GatherIn& g, const ConvOut& k, const ConvCls& q, int lds, hipStream_t s) {
+    return g.noise ? launch_conv2<T, BN, MSUB, true>(g, k, q, lds, s) : launch_conv2<T, BN, MSUB, false>(g, k, q, lds, s);
 }
 template <typename T>
-static int dispatch_conv(const GatherIn& g, const ConvOut& k, int BN, int MSUB, int lds, hipStream_t s) {
-    if (BN == 16 && MSUB == 8) { if constexpr (sizeof(T) == 2) return launch_conv<T, 16, 8>(g, k, lds, s); else return VG_EINVAL; }
-    if (BN == 16) return MSUB == 4 ? launch_conv<T, 16, 4>(g, k, lds, s) : (MSUB == 2 ? launch_conv<T, 16, 2>(g, k, lds, s) : launch_conv<T, 16, 1>(g, k, lds, s));
-    if (BN == 32) return MSUB == 4 ? launch_conv<T, 32, 4>(g, k, lds, s) : (MSUB == 2 ? launch_conv<T, 32, 2>(g, k, lds, s) : launch_conv<T, 32, 1>(g, k, lds, s));
-    return MSUB == 2 ? launch_conv<T, 64, 2>(g, k, lds, s) : launch_conv<T, 64, 1>(g, k, lds, s);
+static int dispatch_conv(const GatherIn& g, const ConvOut& k, const ConvCls& q, int BN, int MSUB, int lds, hipStream_t s) {
+    if (BN == 16 && MSUB == 8) { if constexpr (sizeof(T) == 2) return launch_conv<T, 16, 8>(g, k, q, lds, s); else return VG_EINVAL; }
+    if (BN == 16) return MSUB == 4 ? launch_conv<T, 16, 4>(g, k, q, lds, s) : (MSUB == 2 ? launch_conv<T, 16, 2>(g, k, q, lds, s) : launch_conv<T, 16, 1>(g, k, q, lds, s));
+    if (BN == 32) return MSUB == 4 ? launch_conv<T, 32, 4>(g, k, q, lds, s) : (MSUB == 2 ? launch_conv<T, 32, 2>(g, k, q, lds, s) : launch_conv<T, 32, 1>(g, k, q, lds, s));
+    return MSUB == 2 ? launch_conv<T, 64, 2>(g, k, q, lds, s) : launch_conv<T, 64, 1>(g, k, q, lds, s);
 }
 
 extern "C" int vg_conv3d(const vg_conv_desc* d, vg_stream_t stream) {
     vg_begin();
-    GatherIn g; ConvOut k; int BN, MSUB, lds;
-    int rc = fill_conv(d, g, k, BN, MSUB, lds);
+    GatherIn g; ConvOut k; ConvCls q; int BN, MSUB, lds;
+    int rc = fill_conv(d, g, k, q, BN, MSUB, lds);
     if (rc != VG_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
-    return d->f32 ? dispatch_conv<float>(g, k, BN, MSUB, lds, s) : dispatch_conv<bf16_t>(g, k, BN, MSUB, lds, s);
+    return d->f32 ? dispatch_conv<float>(g, k, q, BN, MSUB, lds, s) : dispatch_conv<bf16_t>(g, k, q, BN, MSUB, lds, s);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -197,12 +197,21 @@ class ConvLayer:
                             for (b, ob) in th:
                                 for (c, oc) in tw:
                                     taps.append((oa, ob, oc)); idx.append((a * k + b) * k + c)
-                        ck = self._pick_ck(cout, taps, 1, self.out_dims, (nd, nh, nw), cin)
-                        ktot = check(lib.vg_packed_ktot(len(taps), cout, ck), 'vg_packed_ktot')
-                        self.d_classes.append(dict(
-                            off=(pd, ph, pw), iters=(nd, nh, nw), taps=taps, ck=ck, ktot=ktot,
-                            idx=torch.tensor(idx, dtype=torch.int32, device=dev),
-                            wp=torch.zeros(lib.vg_packed_rows(cin), ktot, dtype=dtype, device=dev)))
+                        self.d_classes.append(dict(off=(pd, ph, pw), iters=(nd, nh, nw), taps=taps, idx_list=idx))
+            # strided convs: ONE fused launch computes all output-parity classes from a dY halo tile staged once, when
+            # dY fits one channel chunk (<= 64 channels) and the plan is LDS-feasible; else one launch per class
+            self.d_fused = False
+            if len(self.d_classes) > 1 and cout <= 64 and not self.f32 and sum(len(c['taps']) for c in self.d_classes) <= _lib.VG_MAX_TAPS:
+                ck_f = -(-cout // 16) * 16
+                for c in self.d_classes:
+                    c['ck'] = ck_f
+                self.d_fused = self._fused_desc(None, 1, None, False, probe=True) is not None
+            for c in self.d_classes:
+                if not self.d_fused:
+                    c['ck'] = self._pick_ck(cout, c['taps'], 1, self.out_dims, c['iters'], cin)
+                c['ktot'] = check(lib.vg_packed_ktot(len(c['taps']), cout, c['ck']), 'vg_packed_ktot')
+                c['idx'] = torch.tensor(c['idx_list'], dtype=torch.int32, device=dev)
+                c['wp'] = torch.zeros(lib.vg_packed_rows(cin), c['ktot'], dtype=dtype, device=dev)
 
     def _pick_ck(self, C_, taps, istr, in_dims, iters, rows) -> int:
         d = ConvDesc()
@@ -289,9 +298,53 @@ class ConvLayer:
         if e0 is not None:
             PROF.end('conv_wgrad', 2.0 * src.N * math.prod(self.out_dims) * self.cout * self.cin * self.k ** 3, e0)
 
+    def _fused_desc(self, dy, N, out, accumulate, probe=False):
+        """Descriptor of the fused all-classes data gradient (probe=True: dummy pointers, returns None if infeasible)."""
+        d = ConvDesc()
+        dummy = 1 << 20
+        d.src0, d.src1 = (dummy if probe else _p(dy)), None
+        d.c_src0, d.c_src1, d.src0_shift = self.cout, 0, 0
+        d.src_f32 = 0 if probe else int(dy.dtype == torch.float32 and self.cout == 1)
+        d.N = N
+        d.D, d.H, d.W = self.out_dims
+        d.act, d.istr, d.pad_mode = ACT_NONE, 1, PAD_ZERO
+        taps = [t for c in self.d_classes for t in c['taps']]
+        _set_taps(d, taps)
+        d.OD, d.OH, d.OW = [max(c['iters'][a] for c in self.d_classes) for a in range(3)]
+        d.ostr = self.stride
+        d.ooff_d, d.ooff_h, d.ooff_w = self.d_classes[0]['off']
+        d.BD, d.BH, d.BW = self.buf_dims
+        d.Cout, d.CK = self.cin, self.d_classes[0]['ck']
+        d.f32 = self.f32
+        d.nclass = len(self.d_classes)
+        t0 = 0
+        for i, c in enumerate(self.d_classes):
+            d.cls_tap0[i] = t0
+            t0 += len(c['taps'])
+            d.cls_w[i] = dummy if probe else c['wp'].data_ptr()
+            for a in range(3):
+                d.cls_ooff[i][a] = c['off'][a]
+                d.cls_iters[i][a] = c['iters'][a]
+        d.cls_tap0[len(self.d_classes)] = t0
+        d.wpacked = d.cls_w[0]
+        if probe:
+            d.out = dummy
+            plan = (C.c_int32 * 4)()
+            return d if lib.vg_conv3d_plan(C.byref(d), plan) == 0 else None
+        d.out, d.out_f32, d.accumulate = _p(out), int(out.dtype == torch.float32), int(accumulate)
+        return d
+
     def dgrad(self, dy: torch.Tensor, N: int, out: torch.Tensor, accumulate: bool):
         """d/d input: writes the reflect-PADDED grid for 'reflect' convs (fold it with actnorm_bwd), the plain
         input grid for 'same' convs.  out: [N, *buf_dims, cin] bf16 (or f32 when cin==1)."""
+        if self.d_fused:
+            d = self._fused_desc(dy, N, out, accumulate)
+            e0 = PROF.begin() if PROF is not None else None
+            check(lib.vg_conv3d(C.byref(d), stream()), 'vg_conv3d(dgrad, fused classes) ' + self.name)
+            if e0 is not None:
+                PROF.end('conv_dgrad', sum(2.0 * N * math.prod(c['iters']) * self.cin * self.cout * len(c['taps'])
+                                           for c in self.d_classes), e0)
+            return
         for c in self.d_classes:
             d = ConvDesc()
             d.src0, d.src1 = _p(dy), None
