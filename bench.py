@@ -37,6 +37,7 @@ def synth_on_device(B, dims, seed, device):
 def cpu_baseline(budget_s=12.0):
     import torch
     from oracle import vangan_oracle as O
+    torch.set_num_threads(min(16, torch.get_num_threads()))   # 32^3 tensors: more threads only add synchronisation
     dims, B = (32, 32, 32), 1
     P = O.make_models(0)
     rI, rS = O.synth_volumes(B, *dims, seed=1234)
@@ -155,8 +156,20 @@ def main():
         tot_ms = sum(v['ms'] for v in summ.values())
         n = sum(v['launches'] for v in summ.values())
         ach = tot_fl / (tot_ms * 1e-3) / 1e12
+        # HBM traffic of the same kernel family: rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) cannot run inside this
+        # process, so the per-launch figure comes from the committed summary of those passes on this command
+        traffic, traffic_src = None, None
+        try:
+            with open(os.path.join(ROOT, 'profiles', 'r01_hbm_pmc.json')) as f:
+                pm = json.load(f)
+            if args.size == 128 and B == 1:
+                traffic, traffic_src = pm['hbm_bytes_per_launch'], 'profiles/r01_hbm_pmc.json'
+        except (OSError, KeyError, ValueError):
+            pass
+        alg_bytes = sum(v.get('bytes', 0.0) for v in summ.values())
         roof = {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS,
-                'traffic': None,
+                'traffic': traffic, 'traffic_unit': 'HBM bytes per launch (read + write), PMC', 'traffic_source': traffic_src,
+                'algorithmic_bytes_per_launch': alg_bytes / n,
                 'kernel': 'conv_kernel<bf16,*> + wgrad_kernel<bf16,*> (all gather-convolution launches of one step)',
                 'launches_per_step': n, 'avg_launch_ms': tot_ms / n, 'kernel_ms_per_step': tot_ms,
                 'algorithmic_gflop_per_step': tot_fl / 1e9,

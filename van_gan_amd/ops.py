@@ -36,18 +36,18 @@ class KernelProfile:
         e.record()
         return e
 
-    def end(self, kind: str, flops: float, e0):
+    def end(self, kind: str, flops: float, e0, nbytes: float = 0.0):
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        r = self.rows.setdefault(kind, [0, 0.0, []])
-        r[0] += 1; r[1] += flops; r[2].append((e0, e1))
+        r = self.rows.setdefault(kind, [0, 0.0, [], 0.0])
+        r[0] += 1; r[1] += flops; r[2].append((e0, e1)); r[3] += nbytes
 
     def summary(self):
         torch.cuda.synchronize()
         out = {}
-        for k, (n, fl, evs) in self.rows.items():
+        for k, (n, fl, evs, nb) in self.rows.items():
             ms = sum(a.elapsed_time(b) for a, b in evs)
-            out[k] = dict(launches=n, flops=fl, ms=ms)
+            out[k] = dict(launches=n, flops=fl, ms=ms, bytes=nb)
         return out
 
 
@@ -285,7 +285,9 @@ class ConvLayer:
         e0 = PROF.begin() if PROF is not None else None
         check(lib.vg_conv3d(C.byref(d), stream()), 'vg_conv3d ' + self.name)
         if e0 is not None:
-            PROF.end('conv_fwd', 2.0 * src.N * math.prod(self.out_dims) * self.cout * self.cin * self.k ** 3, e0)
+            esz = 4 if self.f32 else 2
+            PROF.end('conv_fwd', 2.0 * src.N * math.prod(self.out_dims) * self.cout * self.cin * self.k ** 3, e0,
+                     src.N * esz * (math.prod(self.in_dims) * self.cin + math.prod(self.out_dims) * self.cout))
 
     def wgrad(self, src: Src, dy: torch.Tensor):
         d = self._fwd_desc(src)
@@ -296,7 +298,9 @@ class ConvLayer:
         check(lib.vg_conv3d_wgrad(C.byref(d), _p(dy), int(dy.dtype == torch.float32), self.f_idx_host, self.k ** 3,
                                   _p(self.gw), _p(self.gb), _p(sc), sc.numel() * 4, stream()), 'vg_conv3d_wgrad ' + self.name)
         if e0 is not None:
-            PROF.end('conv_wgrad', 2.0 * src.N * math.prod(self.out_dims) * self.cout * self.cin * self.k ** 3, e0)
+            esz = 4 if self.f32 else 2
+            PROF.end('conv_wgrad', 2.0 * src.N * math.prod(self.out_dims) * self.cout * self.cin * self.k ** 3, e0,
+                     src.N * esz * (math.prod(self.in_dims) * self.cin + math.prod(self.out_dims) * self.cout))
 
     def _fused_desc(self, dy, N, out, accumulate, probe=False):
         """Descriptor of the fused all-classes data gradient (probe=True: dummy pointers, returns None if infeasible)."""
@@ -343,7 +347,8 @@ class ConvLayer:
             check(lib.vg_conv3d(C.byref(d), stream()), 'vg_conv3d(dgrad, fused classes) ' + self.name)
             if e0 is not None:
                 PROF.end('conv_dgrad', sum(2.0 * N * math.prod(c['iters']) * self.cin * self.cout * len(c['taps'])
-                                           for c in self.d_classes), e0)
+                                           for c in self.d_classes), e0,
+                         N * 2 * (math.prod(self.out_dims) * self.cout + math.prod(self.buf_dims) * self.cin))
             return
         for c in self.d_classes:
             d = ConvDesc()
@@ -363,7 +368,9 @@ class ConvLayer:
             e0 = PROF.begin() if PROF is not None else None
             check(lib.vg_conv3d(C.byref(d), stream()), 'vg_conv3d(dgrad) ' + self.name)
             if e0 is not None:      # algorithmic FLOPs of this parity class: its taps only
-                PROF.end('conv_dgrad', 2.0 * N * math.prod(c['iters']) * self.cin * self.cout * len(c['taps']), e0)
+                PROF.end('conv_dgrad', 2.0 * N * math.prod(c['iters']) * self.cin * self.cout * len(c['taps']), e0,
+                         N * (4 if self.f32 else 2) * (math.prod(self.out_dims) * self.cout * len(c['taps']) / self.k ** 3
+                                                       + math.prod(c['iters']) * self.cin))
 
 
 class PackTable:
