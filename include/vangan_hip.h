@@ -170,6 +170,8 @@ typedef struct {
     void* dx; int32_t dx_f32; int32_t accumulate;
     int32_t dx_cstride, dx_coff;              /* dx channel stride / offset (write into a slice) */
     int32_t f32;                              /* exact-parity mode: g, x, x1 and dx are float32 */
+    float* dgamma;                            /* optional [C]: the statistics pass itself adds d/d gamma and d/d beta of the */
+    float* dbeta;                             /* InstanceNorm (summed over samples) instead of a separate vg_in_param_grads */
 } vg_actnorm_bwd_desc;
 int vg_actnorm_bwd_stats(const vg_actnorm_bwd_desc* d, vg_stream_t stream);
 int vg_actnorm_bwd_apply(const vg_actnorm_bwd_desc* d, vg_stream_t stream);

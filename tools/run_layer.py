@@ -11,6 +11,7 @@ cases = {'stem': (3, 16, 16, 1, 'reflect', 128, None), 'dec0': (3, 48, 16, 1, 'r
          'enc1': (3, 32, 32, 1, 'reflect', 64, None), 'down2': (4, 256, 512, 1, 'same', 16, None)}
 name = sys.argv[1] if len(sys.argv) > 1 else 'stem'
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+mode = sys.argv[3] if len(sys.argv) > 3 else 'fwd'
 k, cin, cout, stride, pad, S, cat = cases[name]
 dims = (S,) * 3
 st = ParamStore([('c.w', (k, k, k, cin, cout), 'x'), ('c.b', (cout,), 'x')], dev)
@@ -26,7 +27,11 @@ else:
     src = Src(torch.randn(N, *dims, cin, device=dev).to(torch.bfloat16), (N,) + dims, cin, scale=sc, shift=sh, act=ops.ACT_RELU)
 out = torch.zeros(N, *lay.out_dims, cout, dtype=torch.bfloat16, device=dev)
 sums = torch.zeros(8, N, cout, 2, device=dev)
+dy = torch.randn(N, *lay.out_dims, cout, device=dev).to(torch.bfloat16)
 for _ in range(reps):
-    lay.forward(src, out, sums=sums)
+    if mode == 'fwd':
+        lay.forward(src, out, sums=sums)
+    else:
+        lay.wgrad(src, dy)
 torch.cuda.synchronize()
 print('done', name)

@@ -252,7 +252,9 @@ __global__ __launch_bounds__(256, ((BN / 16) * MSUB >= 8 ? 2 : VG_CONV_WAVES)) v
     int* utab = (int*)(stat + BN * 2);
     const int ncols = stage_ncols(g);
     const int SU = g.DS >> 4;                        // DMA: units per D-slice (multiple of 64)
-    const int nunits = DMA ? 5 * SU : 2 * ncols + 3 * (g.HH + g.HW);     // staging tables (see conv_lds_bytes)
+    const int RTN = 3 * (g.HH + g.HW);               // one buffer of per-tile axis tables; two buffers: the tables of tile t+1
+                                                     // are resolved while tile t is staged (no barrier, off the critical path)
+    const int nunits = DMA ? 5 * SU : 2 * ncols + 2 * RTN;               // staging tables (see conv_lds_bytes)
     int* rtab = utab + 2 * ncols;
     int* cq = utab; int* tcolb = utab + SU;          // DMA: static column table, tcol[2 tiles][2 sources][SU]
     const int gpc = g.CK >> 3;
@@ -329,6 +331,14 @@ __global__ __launch_bounds__(256, ((BN / 16) * MSUB >= 8 ? 2 : VG_CONV_WAVES)) v
     }
     const bool vec_epi = (p.Cout & 3) == 0 && !(p.tanh_out && p.accumulate);   // every lane owns 4 whole channels: vector loads/stores
     if (p.nchunks == 1) stage_scale_shift(g, scs, n, 0, tid);
+    if constexpr (!DMA) {
+        if ((int)blockIdx.x < g.tiles_d * g.tiles_h * g.tiles_w) {
+            int t = blockIdx.x;
+            const int tw_i = t % g.tiles_w; t /= g.tiles_w;
+            const int th_i = t % g.tiles_h;
+            stage_resolve_axes(g, rtab, th_i << g.thl, tw_i << g.twl, tid);
+        }
+    }
     __syncthreads();
 
     const int tiles_per_n = g.tiles_d * g.tiles_h * g.tiles_w;
@@ -350,18 +360,30 @@ __global__ __launch_bounds__(256, ((BN / 16) * MSUB >= 8 ? 2 : VG_CONV_WAVES)) v
             dma_issue(g, halo, tcolb, n, od0, 0, wave, lane);
         }
     }
+    // tile coordinates advance incrementally by the grid stride (decomposed once): the per-tile divisions by run-time tile
+    // counts were ~300 scalar instructions of the ~500-instruction empty tile iteration
+    int gs_w, gs_h, gs_d;
+    { int t = gridDim.x; gs_w = t % g.tiles_w; t /= g.tiles_w; gs_h = t % g.tiles_h; gs_d = t / g.tiles_h; }
+    int ti_w, ti_h, ti_d;
+    { int t = blockIdx.x; ti_w = t % g.tiles_w; t /= g.tiles_w; ti_h = t % g.tiles_h; ti_d = t / g.tiles_h; }
     for (int tile = blockIdx.x; tile < tiles_per_n; tile += gridDim.x) {
         ++it;
         VG_STAMP(0);
-        int od0, oh0, ow0; tile_origin(tile, od0, oh0, ow0);
+        const int od0 = ti_d << g.tdl, oh0 = ti_h << g.thl, ow0 = ti_w << g.twl;
+        // coordinates of the next tile of this workgroup (valid if tile + gridDim.x < tiles_per_n)
+        ti_w += gs_w; if (ti_w >= g.tiles_w) { ti_w -= g.tiles_w; ++ti_h; }
+        ti_h += gs_h; if (ti_h >= g.tiles_h) { ti_h -= g.tiles_h; ++ti_d; }
+        ti_d += gs_d;
+        const int nx_d0 = ti_d << g.tdl, nx_h0 = ti_h << g.thl, nx_w0 = ti_w << g.twl;
         f32x4 acc[MW];
         if constexpr (MC) {
             // fused output-parity classes: the dY halo tile is staged once; every class runs its own taps / weights /
             // accumulators over it and writes its own output sub-lattice
-            __syncthreads();                       // previous readers of the halo tile are done
-            stage_resolve_axes(g, rtab, oh0, ow0, tid);
-            __syncthreads();
-            if (!(g.dbg & 1)) stage_halo_tile<T, NOISE, (NOISE ? 4 : 6)>(g, halo, scs, utab, rtab, n, od0, 0, tid);
+            __syncthreads();                       // previous readers of the halo tile are done; this tile's axis tables visible
+            if (!(g.dbg & 1)) stage_halo_tile<T, NOISE, (NOISE ? 4 : 6)>(g, halo, scs, utab, rtab + (it & 1) * RTN, n, od0, 0, tid);
+            if (tile + (int)gridDim.x < tiles_per_n) {
+                stage_resolve_axes(g, rtab + ((it + 1) & 1) * RTN, nx_h0, nx_w0, tid);
+            }
             VG_STAMP(1);
             __syncthreads();
             VG_STAMP(2);
@@ -402,7 +424,7 @@ __global__ __launch_bounds__(256, ((BN / 16) * MSUB >= 8 ? 2 : VG_CONV_WAVES)) v
                 const int ntile2 = next_same ? tile : tile + (int)gridDim.x;
                 const bool has_next = ntile2 < tiles_per_n;
                 int nd0 = od0, nh0 = oh0, nw0 = ow0;
-                if (has_next && !next_same) { tile_origin(ntile2, nd0, nh0, nw0); dma_build_tcol(g, cq, tcolb + ((it + 1) & 1) * 2 * SU, nh0, nw0, tid); }
+                if (has_next && !next_same) { nd0 = nx_d0; nh0 = nx_h0; nw0 = nx_w0; dma_build_tcol(g, cq, tcolb + ((it + 1) & 1) * 2 * SU, nh0, nw0, tid); }
                 if (has_next && p.nchunks > 1) stage_scale_shift(g, scs + ((sidx + 1) & 1) * 2 * g.CK, n, next_same ? chunk + 1 : 0, tid);
                 if (!(g.dbg & 1)) dma_transform(g, hb, tc, sc_cur, od0, chunk, wave, lane);
                 if (chunk == 0) VG_STAMP(1);
@@ -412,11 +434,12 @@ __global__ __launch_bounds__(256, ((BN / 16) * MSUB >= 8 ? 2 : VG_CONV_WAVES)) v
                     dma_issue(g, halo + ((sidx + 1) & 1) * hbytes, tcolb + ((next_same ? it : it + 1) & 1) * 2 * SU, n, nd0, next_same ? chunk + 1 : 0, wave, lane);
                 ++sidx;
             } else {
-                __syncthreads();                       // previous readers of the halo tile are done
-                if (p.nchunks > 1) stage_scale_shift(g, scs, n, chunk, tid);
-                if (chunk == 0) stage_resolve_axes(g, rtab, oh0, ow0, tid);
-                if (p.nchunks > 1 || chunk == 0) __syncthreads();
-                if (!(g.dbg & 1)) stage_halo_tile<T, NOISE, (NOISE ? 4 : 6)>(g, halo, scs, utab, rtab, n, od0, chunk, tid);
+                __syncthreads();                       // previous readers of the halo tile are done; this tile's axis tables visible
+                if (p.nchunks > 1) { stage_scale_shift(g, scs, n, chunk, tid); __syncthreads(); }
+                if (!(g.dbg & 1)) stage_halo_tile<T, NOISE, (NOISE ? 4 : 6)>(g, halo, scs, utab, rtab + (it & 1) * RTN, n, od0, chunk, tid);
+                if (chunk == 0 && tile + (int)gridDim.x < tiles_per_n) {       // axis tables of the next tile, other buffer
+                    stage_resolve_axes(g, rtab + ((it + 1) & 1) * RTN, nx_h0, nx_w0, tid);
+                }
                 if (chunk == 0) VG_STAMP(1);
                 __syncthreads();
                 if (chunk == 0) VG_STAMP(2);

@@ -240,12 +240,16 @@ __global__ __launch_bounds__(256) void actnorm_stats_kernel(const ANB p) {
 
 // stripe 0 += stripes 1..7, which are then cleared (a later sum over all stripes stays correct): the apply pass and the
 // parameter-gradient kernel read 2 values per channel instead of 16
-__global__ void anb_fold_stripes_kernel(float* red, int total) {
+__global__ void anb_fold_stripes_kernel(float* red, int total, int C, float* dgamma, float* dbeta) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     float a = red[i];
     for (int t = 1; t < VG_STRIPES; ++t) { a += red[(size_t)t * total + i]; red[(size_t)t * total + i] = 0.f; }
     red[i] = a;
+    if (dgamma) {            // i = (n*C + c)*2 + moment: sum(dn) is d/d beta, sum(dn*xhat) is d/d gamma
+        const int c = (i >> 1) % C;
+        atomicAdd((i & 1) ? &dgamma[c] : &dbeta[c], a);
+    }
 }
 
 template <typename T, int VEC>
@@ -347,7 +351,8 @@ extern "C" int vg_actnorm_bwd_stats(const vg_actnorm_bwd_desc* d, vg_stream_t st
         else hipLaunchKernelGGL((actnorm_stats_kernel<bf16_t, 8>), anb_grid(p, true), dim3(256), 0, (hipStream_t)stream, p);
     }
     const int total = p.N * p.C * 2;
-    hipLaunchKernelGGL(anb_fold_stripes_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, p.red, total);
+    hipLaunchKernelGGL(anb_fold_stripes_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, p.red, total, p.C,
+                       d->dgamma && d->dbeta ? d->dgamma : nullptr, d->dbeta);
     return vg_check_launch();
 }
 extern "C" int vg_actnorm_bwd_apply(const vg_actnorm_bwd_desc* d, vg_stream_t stream) {

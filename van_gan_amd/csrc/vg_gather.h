@@ -81,10 +81,10 @@ __device__ __forceinline__ void stage_resolve_axes(const GatherIn& g, int* rtab,
     const int L = g.HH + g.HW;
     const int ph0 = oh0 * g.istr + g.tmin_h, pw0 = ow0 * g.istr + g.tmin_w;
     const int cs0 = g.Cin == 1 ? 1 : g.c0;
-    for (int set = 0; set < 3; ++set) {
-        if (set == 1 && g.c1 == 0) continue;
-        if (set == 2 && !g.noise) continue;
-        for (int j = tid; j < L; j += 256) {
+    // wave s resolves table s (src0, src1, noise): the three small jobs run side by side, off wave 0's critical path
+    const int set = tid >> 6;
+    if (set < 3 && !(set == 1 && g.c1 == 0) && !(set == 2 && !g.noise)) {
+        for (int j = tid & 63; j < L; j += 64) {
             const bool isH = j < g.HH;
             int p = isH ? ph0 + j : pw0 + j - g.HH;
             const int q = p + g.npad;
@@ -372,4 +372,4 @@ static inline int fill_gather(const vg_conv_desc* d, GatherIn& g, int CK, int BM
 }
 static inline int halo_bytes(const GatherIn& g) { return g.planar ? (g.CK >> 3) * g.PSB : g.HD * g.DS; }
 // LDS ints of the staging tables (column table + per-tile axis tables)
-static inline int stage_table_ints(const GatherIn& g) { return 2 * stage_ncols(g) + 3 * (g.HH + g.HW); }
+static inline int stage_table_ints(const GatherIn& g) { return 2 * stage_ncols(g) + 6 * (g.HH + g.HW); }   // column table + two axis-table buffers

@@ -26,6 +26,9 @@ struct WgradK {
     float* part; int dw_elems;              // per-workgroup-column partial slabs (no atomics) or NULL
 };
 
+#ifndef VG_WGRAD_2W
+#define VG_WGRAD_2W 16     // accumulator fragments per wave from which the register cap is 2 waves per SIMD
+#endif
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 #define VG_WSTAMP(slot) do { if (g.stamps && tid == 0 && it < 8) g.stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 64 + it * 8 + (slot)] = __builtin_readcyclecounter(); } while (0)
 
@@ -37,7 +40,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* base0, const char* base1) 
 }
 
 template <typename T, int RMAX, int Q, bool NOISE>
-__global__ __launch_bounds__(256, (RMAX * Q >= 16 ? 2 : 3)) void wgrad_kernel(const GatherIn g, const WgradK p) {
+__global__ __launch_bounds__(256, (RMAX * Q >= VG_WGRAD_2W ? 2 : 3)) void wgrad_kernel(const GatherIn g, const WgradK p) {
     constexpr bool F32 = sizeof(T) == 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -61,11 +64,32 @@ __global__ __launch_bounds__(256, (RMAX * Q >= 16 ? 2 : 3)) void wgrad_kernel(co
     float* scs = (float*)((char*)tapoff + 512);
     int* utab = (int*)(scs + 2 * g.CK);
     int* rtab = utab + 2 * stage_ncols(g);
+    const int RTN = 3 * (g.HH + g.HW);               // two axis-table buffers: tile t+1 is resolved while tile t is staged
+    int* ktab = rtab + 2 * RTN;                      // [BM/32][64 lanes]{r0, r1}: halo byte offsets of the transposed reads
 
     if (tid < g.ntaps)
         tapoff[tid] = (g.td[tid] - g.tmin_d) * g.DS + ((g.th[tid] - g.tmin_h) * g.HWp + halo_pos_w(g, g.tw[tid] - g.tmin_w)) * g.VS;
     if (tid < VG_MAX_TAPS) tapsrc[tid] = p.tap_src[tid];
     build_column_table(g, utab, tid);
+    if ((int)blockIdx.x < p.total_tiles) {           // axis tables of the first tile
+        int t2 = blockIdx.x % (g.tiles_d * g.tiles_h * g.tiles_w);
+        const int fw_i = t2 % g.tiles_w; t2 /= g.tiles_w;
+        const int fh_i = t2 % g.tiles_h;
+        stage_resolve_axes(g, rtab, fh_i << g.thl, fw_i << g.twl, tid);
+    }
+    if constexpr (!F32) {
+        const int TWm_ = (1 << g.twl) - 1, THm_ = (1 << g.thl) - 1;
+        for (int e = tid; e < (BM / 32) * 64; e += 256) {
+            // lane (lg2, li2) of K-step ks supplies voxel row m0 (and m0 + 4) for the transposed block reads
+            const int ks = e >> 6, l2 = e & 63, lg2 = l2 >> 4, li2 = l2 & 15;
+            const int m0 = ks * 32 + 8 * lg2 + (li2 >> 2), m1 = m0 + 4;
+            const int w0 = m0 & TWm_, h0 = (m0 >> g.twl) & THm_, d0 = m0 >> (g.twl + g.thl);
+            const int w1 = m1 & TWm_, h1 = (m1 >> g.twl) & THm_, d1 = m1 >> (g.twl + g.thl);
+            const int lo = ((li2 & 3) >> 1) * g.CS + 8 * (li2 & 1);
+            ktab[2 * e] = d0 * g.istr * g.DS + (h0 * g.istr * g.HWp + w0) * g.VS + lo;
+            ktab[2 * e + 1] = d1 * g.istr * g.DS + (h1 * g.istr * g.HWp + w1) * g.VS + lo;
+        }
+    }
     __syncthreads();
 
     // rows of this wave: r = wave + 4*j -> (tap, ci16); byte offset of the row's P fragment inside the halo tile
@@ -90,20 +114,27 @@ __global__ __launch_bounds__(256, (RMAX * Q >= 16 ? 2 : 3)) void wgrad_kernel(co
     const bool do_db = p.db && cib == 0 && tg == 0;
 
     int it = -1;
+    // (sample, tile) coordinates advance incrementally by the grid stride: no per-tile divisions
+    int gs_w, gs_h, gs_d, gs_n;
+    { int t = gridDim.x; gs_w = t % g.tiles_w; t /= g.tiles_w; gs_h = t % g.tiles_h; t /= g.tiles_h; gs_d = t % g.tiles_d; gs_n = t / g.tiles_d; }
+    int ti_w, ti_h, ti_d, ti_n;
+    { int t = blockIdx.x; ti_w = t % g.tiles_w; t /= g.tiles_w; ti_h = t % g.tiles_h; t /= g.tiles_h; ti_d = t % g.tiles_d; ti_n = t / g.tiles_d; }
     for (int tile = blockIdx.x; tile < p.total_tiles; tile += gridDim.x) {
         ++it;
         VG_WSTAMP(0);
-        const int n = tile / tiles_per_n; int t = tile - n * tiles_per_n;
-        const int tw_i = t % g.tiles_w; t /= g.tiles_w;
-        const int th_i = t % g.tiles_h; const int td_i = t / g.tiles_h;
-        const int od0 = td_i << g.tdl, oh0 = th_i << g.thl, ow0 = tw_i << g.twl;
-        __syncthreads();
+        const int n = ti_n;
+        const int od0 = ti_d << g.tdl, oh0 = ti_h << g.thl, ow0 = ti_w << g.twl;
+        ti_w += gs_w; if (ti_w >= g.tiles_w) { ti_w -= g.tiles_w; ++ti_h; }
+        ti_h += gs_h; if (ti_h >= g.tiles_h) { ti_h -= g.tiles_h; ++ti_d; }
+        ti_d += gs_d; if (ti_d >= g.tiles_d) { ti_d -= g.tiles_d; ++ti_n; }
+        ti_n += gs_n;
+        __syncthreads();                       // previous tile consumed; this tile's axis tables (built during it) visible
         if (n != cur_n) {                      // block-uniform: the on-read affine depends on the sample only
             stage_scale_shift(g, scs, n, cib, tid);
             cur_n = n;
+            __syncthreads();
         }
-        stage_resolve_axes(g, rtab, oh0, ow0, tid);
-        __syncthreads();
+        int* rt = rtab + (it & 1) * RTN;
         // ---- dY tile [BM][16*Q] (zero outside the grid / beyond Cout): its loads are issued first and stay in flight
         // while the halo tile is staged.  Straight-line: out-of-range units load a clamped address and are zeroed ----
         Raw8<T> yraw[4]; float y1[4]; bool yok[4];
@@ -122,7 +153,10 @@ __global__ __launch_bounds__(256, (RMAX * Q >= 16 ? 2 : 3)) void wgrad_kernel(co
                 else raw_load(yraw[k], (const T*)p.dy + vox * p.Cout + (yok[k] ? c : 0));
             }
         }
-        if (!(g.dbg & 1) || tile == (int)blockIdx.x) stage_halo_tile<T, NOISE, (RMAX * Q > 4 ? 2 : 4)>(g, halo, scs, utab, rtab, n, od0, cib, tid);
+        if (!(g.dbg & 1) || tile == (int)blockIdx.x) stage_halo_tile<T, NOISE, (RMAX * Q > 4 ? 2 : 4)>(g, halo, scs, utab, rt, n, od0, cib, tid);
+        if (tile + (int)gridDim.x < p.total_tiles) {      // axis tables of the next tile into the other buffer
+            stage_resolve_axes(g, rtab + ((it + 1) & 1) * RTN, ti_h << g.thl, ti_w << g.twl, tid);
+        }
         if (dy_on) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -177,52 +211,50 @@ __global__ __launch_bounds__(256, (RMAX * Q >= 16 ? 2 : 3)) void wgrad_kernel(co
             constexpr int RC = RMAX <= 8 ? RMAX : 6;
             static_assert(RMAX % RC == 0, "rows per wave must be a multiple of the chunk");
             constexpr int NCH = RMAX / RC;
-            const int nks = BM / 32;
-            auto kaddr = [&](int ks, int& r0, int& r1, const char*& y0, const char*& y1) {
-                // this lane supplies the address of voxel row m0 (and m0+4) for the transposed block reads
-                const int m0 = ks * 32 + 8 * lg + (li >> 2);
-                const int m1 = m0 + 4;
-                const int w0 = m0 & TWm, h0 = (m0 >> g.twl) & THm, d0 = m0 >> (g.twl + g.thl);
-                const int w1 = m1 & TWm, h1 = (m1 >> g.twl) & THm, d1 = m1 >> (g.twl + g.thl);
-                r0 = d0 * g.istr * g.DS + (h0 * g.istr * g.HWp + w0) * g.VS + ((li & 3) >> 1) * g.CS + 8 * (li & 1);
-                r1 = d1 * g.istr * g.DS + (h1 * g.istr * g.HWp + w1) * g.VS + ((li & 3) >> 1) * g.CS + 8 * (li & 1);
-                y0 = dyt + (size_t)m0 * p.DYS + 8 * (li & 3);
-                y1 = dyt + (size_t)m1 * p.DYS + 8 * (li & 3);
-            };
-            int r0, r1; const char *y0, *y1;
-            kaddr(0, r0, r1, y0, y1);
-            bf16x8 bc[Q], bn[Q], ac[RC], an[RC];
+            const int nks = BM / 32;                                   // even (BM is 64, 128 or 256)
+            // per-lane halo offsets of K-step ks come from the table built once per workgroup (kaddr_fill); the dY
+            // offsets advance by 32 rows per K-step.  Two register sets per operand, selected by compile-time parity, so
+            // the software pipeline needs no register moves.
+            const int2* kt = (const int2*)ktab + lane;
+            const char* ybase = dyt + (size_t)(8 * lg + (li >> 2)) * p.DYS + 8 * (li & 3);
+            const int ystep = 32 * p.DYS, y4 = 4 * p.DYS;
+            bf16x8 A[2][RC], B[2][Q];
+            {
+                const int2 r = kt[0];
 #pragma unroll
-            for (int q = 0; q < Q; ++q) bc[q] = tr_frag(y0 + q * 32, y1 + q * 32);              // B[k=voxel][co]
+                for (int q = 0; q < Q; ++q) B[0][q] = tr_frag(ybase + q * 32, ybase + y4 + q * 32);          // B[k=voxel][co]
 #pragma unroll
-            for (int j = 0; j < RC; ++j) ac[j] = tr_frag(halo + r0 + aoff[j], halo + r1 + aoff[j]);   // A[ci][k=voxel]
-            for (int ks = 0; ks < nks; ++ks) {
-                int r0n, r1n; const char *y0n, *y1n;
-                kaddr(min(ks + 1, nks - 1), r0n, r1n, y0n, y1n);
+                for (int j = 0; j < RC; ++j) A[0][j] = tr_frag(halo + r.x + aoff[j], halo + r.y + aoff[j]);   // A[ci][k=voxel]
+            }
+            for (int ks = 0; ks < nks; ks += 2) {
 #pragma unroll
-                for (int c = 0; c < NCH; ++c) {
-                    if (c + 1 < NCH) {
+                for (int u = 0; u < 2; ++u) {
+                    const int2 rc = kt[(ks + u) * 64];
+                    const int kn = min(ks + u + 1, nks - 1);
+                    const int2 rn = kt[kn * 64];
+                    const char* yn = ybase + (size_t)kn * ystep;
 #pragma unroll
-                        for (int j = 0; j < RC; ++j) an[j] = tr_frag(halo + r0 + aoff[(c + 1) * RC + j], halo + r1 + aoff[(c + 1) * RC + j]);
-                    } else {
+                    for (int c = 0; c < NCH; ++c) {
+                        constexpr int dummy = 0; (void)dummy;
+                        const int s = (u * NCH + c) & 1;
+                        if (c + 1 < NCH) {
 #pragma unroll
-                        for (int q = 0; q < Q; ++q) bn[q] = tr_frag(y0n + q * 32, y1n + q * 32);
+                            for (int j = 0; j < RC; ++j) A[s ^ 1][j] = tr_frag(halo + rc.x + aoff[(c + 1) * RC + j], halo + rc.y + aoff[(c + 1) * RC + j]);
+                        } else {
 #pragma unroll
-                        for (int j = 0; j < RC; ++j) an[j] = tr_frag(halo + r0n + aoff[j], halo + r1n + aoff[j]);
+                            for (int q = 0; q < Q; ++q) B[u ^ 1][q] = tr_frag(yn + q * 32, yn + y4 + q * 32);
+#pragma unroll
+                            for (int j = 0; j < RC; ++j) A[s ^ 1][j] = tr_frag(halo + rn.x + aoff[j], halo + rn.y + aoff[j]);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int j = 0; j < RC; ++j)
+#pragma unroll
+                            for (int q = 0; q < Q; ++q)
+                                acc[c * RC + j][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[s][j], B[u][q], acc[c * RC + j][q], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int j = 0; j < RC; ++j)
-#pragma unroll
-                        for (int q = 0; q < Q; ++q)
-                            acc[c * RC + j][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ac[j], bc[q], acc[c * RC + j][q], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int j = 0; j < RC; ++j) ac[j] = an[j];
                 }
-#pragma unroll
-                for (int q = 0; q < Q; ++q) bc[q] = bn[q];
-                r0 = r0n; r1 = r1n;
             }
         }
         VG_WSTAMP(3);
@@ -325,7 +357,7 @@ extern "C" int vg_conv3d_wgrad(const vg_conv_desc* d, const void* dy, int dy_f32
                 if (bm == 256 && (Q > 2 || max_bm < 256)) continue;     // dY tile staging holds <= 4 units per thread
                 int rc = fill_gather(d, g, c, bm, d->f32 ? 0 : 64);
                 if (rc != VG_OK) return rc;
-                const int lds = halo_bytes(g) + bm * (COB * esz + 16) + 512 + 2 * c * 4 + stage_table_ints(g) * 4;
+                const int lds = halo_bytes(g) + bm * (COB * esz + 16) + 512 + 2 * c * 4 + stage_table_ints(g) * 4 + (bm / 32) * 512;
                 if (lds <= limit) { best_bm = bm; best_cib = c; best_lds = lds; break; }
             }
     }
@@ -350,7 +382,7 @@ extern "C" int vg_conv3d_wgrad(const vg_conv_desc* d, const void* dy, int dy_f32
     if (wg_env < 0) { const char* e = getenv("VG_WGRAD_WGS"); wg_env = e ? atoi(e) : 0; }
     const int rw_ = (k.tpg * rows_per_tap + 3) / 4;
     const int rmax_sel = d->f32 ? RMAX : (rw_ <= 2 ? 2 : (rw_ <= 8 && Q <= 2 ? 8 : RMAX));
-    int per_cu = (rmax_sel * Q >= 16) ? 2 : 3;
+    int per_cu = (rmax_sel * Q >= VG_WGRAD_2W) ? 2 : 3;
     if (VG_LDS_LIMIT / lds < per_cu) per_cu = VG_LDS_LIMIT / lds;
     if (per_cu < 1) per_cu = 1;
     const int wg_target = wg_env > 0 ? wg_env : 256 * per_cu;

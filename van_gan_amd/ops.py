@@ -52,6 +52,26 @@ class KernelProfile:
 
 
 PROF: Optional[KernelProfile] = None
+
+# Weight-gradient launches go to a second HIP stream: within a layer the weight gradient (needs dY and the stored input)
+# and the data-gradient chain (dY -> dX -> IN backward -> next layer) are independent, and on the small deep layers either
+# alone leaves most CUs idle.  The side stream waits for the producer of dY; the main stream waits for the side stream
+# before arena memory is recycled (Arena.release) and before the gradients are consumed (side_join).
+SIDE: Optional[torch.cuda.Stream] = None
+_side_dirty = False
+
+
+def side_enable(device, on: bool = True):
+    global SIDE
+    SIDE = torch.cuda.Stream(device=device) if on else None
+
+
+def side_join():
+    """Main stream waits for every weight-gradient launch issued so far."""
+    global _side_dirty
+    if SIDE is not None and _side_dirty:
+        torch.cuda.current_stream().wait_stream(SIDE)
+        _side_dirty = False
 WGRAD_SCRATCH = {}     # device -> fp32 scratch for the partial-slab weight-gradient reduction (256 MB)
 
 
@@ -98,6 +118,7 @@ class Arena:
         return self.off
 
     def release(self, mark: int):
+        side_join()                 # weight gradients on the side stream may still read the buffers being recycled
         self.off = mark
 
 
@@ -290,6 +311,16 @@ class ConvLayer:
                      src.N * esz * (math.prod(self.in_dims) * self.cin + math.prod(self.out_dims) * self.cout))
 
     def wgrad(self, src: Src, dy: torch.Tensor):
+        global _side_dirty
+        if SIDE is not None and PROF is None:
+            SIDE.wait_stream(torch.cuda.current_stream())       # dY (and everything before it) is ready
+            with torch.cuda.stream(SIDE):
+                self._wgrad(src, dy)
+            _side_dirty = True
+        else:
+            self._wgrad(src, dy)
+
+    def _wgrad(self, src: Src, dy: torch.Tensor):
         d = self._fwd_desc(src)
         e0 = PROF.begin() if PROF is not None else None
         sc = WGRAD_SCRATCH.get(dy.device)
@@ -415,11 +446,10 @@ def actnorm_bwd(g, g_padded, x, dims, C_, dx, *, scale=None, shift=None, mult=No
     d.dx, d.dx_f32, d.accumulate = _p(dx), int(dx.dtype == torch.float32), int(accumulate)
     d.dx_cstride, d.dx_coff = dx_cstride, dx_coff
     d.f32 = int(g.dtype == torch.float32)
+    d.dgamma, d.dbeta = _p(dgamma), _p(dbeta)      # parameter gradients come out of the statistics pass
     s = stream()
     if norm:
         check(lib.vg_actnorm_bwd_stats(C.byref(d), s), 'vg_actnorm_bwd_stats')
-        if dgamma is not None:
-            check(lib.vg_in_param_grads(_p(red), dims[0], C_, _p(dgamma), _p(dbeta), s), 'vg_in_param_grads')
     check(lib.vg_actnorm_bwd_apply(C.byref(d), s), 'vg_actnorm_bwd_apply')
 
 

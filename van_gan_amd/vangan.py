@@ -68,6 +68,7 @@ class VanGan:
         if arena_bytes is None:
             arena_bytes = int(batch_size * S * 5200 * (2 if precision == 'fp32' else 1)) + (512 << 20)
         self.arena = Arena(arena_bytes, self.device)
+        ops.side_enable(self.device, os.environ.get('VG_SIDE_STREAM', '1') != '0')     # weight gradients on a second stream
         self.sync = GradSync({k: s.g for k, s in self.stores.items()}, self.pg, {k: s.w for k, s in self.stores.items()})
         self.checkpoint_dir = None
         if output_dir is not None:
@@ -231,6 +232,7 @@ class VanGan:
 
     # ------------------------------------------------------------------------------------------------
     def _start_allreduce(self, names):
+        ops.side_join()                     # the weight gradients of these networks were issued on the side stream
         self.sync.start(names)
 
     def _finish_allreduce(self):
