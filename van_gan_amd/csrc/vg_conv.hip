@@ -288,9 +288,21 @@ __global__ __launch_bounds__(256, ((BN / 16) * MSUB >= 8 ? 2 : VG_CONV_WAVES)) v
             const char* src = (const char*)(MC ? q.wp[cls] : p.wp);
             char* dstp = wlds + (MC ? q.woff[cls] : 0);
             const int per_row = (ktot * (int)sizeof(T)) >> 4, wrs = ktot * (int)sizeof(T) + 16;
-            for (int u = tid; u < BN * per_row; u += 256) {
-                const int r = u / per_row, c = u - r * per_row;
-                *(f32x4*)(dstp + (size_t)r * wrs + c * 16) = *(const f32x4*)(src + ((size_t)(ntile * BN + r) * ktot) * sizeof(T) + c * 16);
+            // four loads in flight per thread: a load -> store loop with an unknown trip count is not pipelined by the
+            // compiler and cost one L2 round trip per 16 bytes (several microseconds of every launch's prologue)
+            for (int u0 = tid; u0 < BN * per_row; u0 += 1024) {
+                f32x4 v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int u = min(u0 + k * 256, BN * per_row - 1);
+                    const int r = u / per_row, c = u - r * per_row;
+                    v[k] = *(const __attribute__((address_space(1))) f32x4*)(uintptr_t)(src + ((size_t)(ntile * BN + r) * ktot) * sizeof(T) + c * 16);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int u = u0 + k * 256;
+                    if (u < BN * per_row) { const int r = u / per_row, c = u - r * per_row; *(f32x4*)(dstp + (size_t)r * wrs + c * 16) = v[k]; }
+                }
             }
         }
     }

@@ -279,48 +279,74 @@ extern "C" int vg_ssim_bwd(const float* t, const float* p, const float* part, in
 // (3,3,1), (3,1,3), (1,3,3) for soft_erode (19-voxel union), raster order for the 27-voxel soft_dilate.
 // TP: the gradient of each pooling goes to the FIRST candidate attaining the extremum.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void erode_at(const float* img, int D, int H, int W, int d, int h, int w, float& best, int& boff) {
-    best = INFINITY; boff = 0;
-#define VG_ER(a, b, c)                                                                                   \
-    { const int dd = d + (a), hh = h + (b), ww = w + (c);                                                 \
-      if (dd >= 0 && dd < D && hh >= 0 && hh < H && ww >= 0 && ww < W) {                                  \
-          const int off = ((a) * H + (b)) * W + (c); const float v = img[off];                           \
-          if (v < best) { best = v; boff = off; } } }
-    for (int a = -1; a <= 1; ++a) for (int b = -1; b <= 1; ++b) VG_ER(a, b, 0)
-    for (int a = -1; a <= 1; ++a) for (int c = -1; c <= 1; ++c) VG_ER(a, 0, c)
-    for (int b = -1; b <= 1; ++b) for (int c = -1; c <= 1; ++c) VG_ER(0, b, c)
-#undef VG_ER
-}
-__device__ __forceinline__ void dilate_at(const float* img, int D, int H, int W, int d, int h, int w, float& best, int& boff) {
-    best = -INFINITY; boff = 0;
-    for (int a = -1; a <= 1; ++a) { const int dd = d + a; if (dd < 0 || dd >= D) continue;
-        for (int b = -1; b <= 1; ++b) { const int hh = h + b; if (hh < 0 || hh >= H) continue;
-            for (int c = -1; c <= 1; ++c) { const int ww = w + c; if (ww < 0 || ww >= W) continue;
-                const int off = (a * H + b) * W + c; const float v = img[off];
-                if (v > best) { best = v; boff = off; } } } }
-}
-#define VG_VOX(i, W, H, D, w, h, d, b)                                                                     \
-    const int w = (int)((i) % (W)); int64_t r_ = (i) / (W); const int h = (int)(r_ % (H)); r_ /= (H);        \
-    const int d = (int)(r_ % (D)); const int b = (int)(r_ / (D)); (void)b;
-
-__global__ void erode_kernel(const float* in, int B, int D, int H, int W, float* out) {
-    const int64_t total = (int64_t)B * D * H * W;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        VG_VOX(i, W, H, D, w, h, d, b)
-        float v; int o; erode_at(in + i, D, H, W, d, h, w, v, o);
-        out[i] = v;
+// Forward soft-skeleton steps, LDS-tiled.  A block computes a 32 x 8 x 8 (W x H x D) tile: the 34 x 10 x 10 halo goes to
+// LDS once (outside the volume: +inf for the erosion, -inf for the dilation = "neighbour skipped"), then a thread walks
+// one (h, w) column along D with a sliding window of per-slice partial results -- 9 LDS reads and ~12 min/max per
+// output instead of 19/27 bounds-checked global loads.  Values only (min/max are order-independent), so the result is
+// bitwise the same as the scan; the backward kernels keep the first-candidate scan because they need the argmin/argmax.
+//   ERODE : out = min over the 19-voxel neighbourhood (3x3x3 minus the 8 corners) of `in`
+//   !ERODE: dil = max over 3x3x3 of `in` (= img_{j+1}); delta = relu(imgj - dil);
+//           out = prev ? prev + relu(delta - prev*delta) : delta            (clDice_func.py:8-31)
+#define SK_TW 32
+#define SK_TH 8
+#define SK_TD 8
+template <bool ERODE>
+__global__ __launch_bounds__(256) void skel_tile_kernel(const float* __restrict__ in, const float* __restrict__ imgj,
+                                                        const float* __restrict__ prev, int D, int H, int W, float* __restrict__ out) {
+    __shared__ float t[SK_TD + 2][SK_TH + 2][SK_TW + 2];
+    const int tid = threadIdx.x;
+    const int tiles_w = (W + SK_TW - 1) / SK_TW, tiles_h = (H + SK_TH - 1) / SK_TH;
+    int bt = blockIdx.x;
+    const int tw = bt % tiles_w; bt /= tiles_w;
+    const int th = bt % tiles_h; const int td = bt / tiles_h;
+    const int w0 = tw * SK_TW, h0 = th * SK_TH, d0 = td * SK_TD;
+    const size_t vol = (size_t)blockIdx.y * D * H * W;
+    const float fill = ERODE ? INFINITY : -INFINITY;
+    constexpr int NH = (SK_TD + 2) * (SK_TH + 2) * (SK_TW + 2);
+    for (int i = tid; i < NH; i += 256) {
+        const int x = i % (SK_TW + 2); const int r = i / (SK_TW + 2);
+        const int y = r % (SK_TH + 2), z = r / (SK_TH + 2);
+        const int gw = w0 + x - 1, gh = h0 + y - 1, gd = d0 + z - 1;
+        float v = fill;
+        if (gw >= 0 && gw < W && gh >= 0 && gh < H && gd >= 0 && gd < D) v = in[vol + ((size_t)gd * H + gh) * W + gw];
+        (&t[0][0][0])[i] = v;
+    }
+    __syncthreads();
+    const int tx = tid & (SK_TW - 1), ty = tid >> 5;
+    const int gw = w0 + tx, gh = h0 + ty;
+    float p9[3], p5[3];                       // per-slice partials of slices s-2, s-1, s (ring)
+#pragma unroll
+    for (int sl = 0; sl < SK_TD + 2; ++sl) {
+        const float a00 = t[sl][ty][tx], a01 = t[sl][ty][tx + 1], a02 = t[sl][ty][tx + 2];
+        const float a10 = t[sl][ty + 1][tx], a11 = t[sl][ty + 1][tx + 1], a12 = t[sl][ty + 1][tx + 2];
+        const float a20 = t[sl][ty + 2][tx], a21 = t[sl][ty + 2][tx + 1], a22 = t[sl][ty + 2][tx + 2];
+        float plus, full;
+        if (ERODE) {
+            plus = fminf(fminf(fminf(a01, a21), fminf(a10, a12)), a11);
+            full = fminf(plus, fminf(fminf(a00, a02), fminf(a20, a22)));
+        } else {
+            plus = fmaxf(fmaxf(fmaxf(a01, a21), fmaxf(a10, a12)), a11);
+            full = fmaxf(plus, fmaxf(fmaxf(a00, a02), fmaxf(a20, a22)));
+        }
+        p9[sl % 3] = full; p5[sl % 3] = plus;
+        if (sl >= 2) {
+            const int gd = d0 + sl - 2;           // output slice (centre = slice sl-1 of the halo)
+            const int c = (sl - 1) % 3, lo = (sl - 2) % 3, hi = sl % 3;
+            const float nb = ERODE ? fminf(p9[c], fminf(p5[lo], p5[hi])) : fmaxf(p9[c], fmaxf(p9[lo], p9[hi]));
+            if (gw < W && gh < H && gd < D) {
+                const size_t o = vol + ((size_t)gd * H + gh) * W + gw;
+                if (ERODE) out[o] = nb;
+                else {
+                    const float delta = fmaxf(imgj[o] - nb, 0.f);
+                    if (prev) { const float sp = prev[o]; out[o] = sp + fmaxf(delta - sp * delta, 0.f); }
+                    else out[o] = delta;
+                }
+            }
+        }
     }
 }
-// step j: delta = relu(img_j - dilate(img_{j+1})); j==0: skel = delta, else skel = prev + relu(delta - prev*delta)
-__global__ void skel_update_kernel(const float* imgj, const float* imgj1, const float* prev, int B, int D, int H, int W, float* skel) {
-    const int64_t total = (int64_t)B * D * H * W;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        VG_VOX(i, W, H, D, w, h, d, b)
-        float dil; int o; dilate_at(imgj1 + i, D, H, W, d, h, w, dil, o);
-        const float delta = fmaxf(imgj[i] - dil, 0.f);
-        if (prev) { const float s = prev[i]; skel[i] = s + fmaxf(delta - s * delta, 0.f); }
-        else skel[i] = delta;
-    }
+static dim3 skel_grid(int B, int D, int H, int W) {
+    return dim3(((W + SK_TW - 1) / SK_TW) * ((H + SK_TH - 1) / SK_TH) * ((D + SK_TD - 1) / SK_TD), B);
 }
 extern "C" int vg_soft_skel_fwd(const float* img, int B, int D, int H, int W, int iters, float* imgs, float* skels,
                                 vg_stream_t stream) {
@@ -330,45 +356,111 @@ extern "C" int vg_soft_skel_fwd(const float* img, int B, int D, int H, int W, in
     const int64_t n = (int64_t)B * D * H * W;
     const int blocks = lblocks(n);
     if (hipMemcpyAsync(imgs, img, n * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return VG_ELAUNCH;
+    (void)blocks;
+    const dim3 grid = skel_grid(B, D, H, W);
     for (int j = 0; j <= iters; ++j)
-        hipLaunchKernelGGL(erode_kernel, dim3(blocks), dim3(256), 0, s, imgs + j * n, B, D, H, W, imgs + (j + 1) * n);
+        hipLaunchKernelGGL(skel_tile_kernel<true>, grid, dim3(256), 0, s, imgs + j * n, (const float*)nullptr, (const float*)nullptr,
+                           D, H, W, imgs + (j + 1) * n);
     for (int j = 0; j <= iters; ++j)
-        hipLaunchKernelGGL(skel_update_kernel, dim3(blocks), dim3(256), 0, s, imgs + j * n, imgs + (j + 1) * n,
-                           j ? skels + (j - 1) * n : (const float*)nullptr, B, D, H, W, skels + j * n);
+        hipLaunchKernelGGL(skel_tile_kernel<false>, grid, dim3(256), 0, s, imgs + (j + 1) * n, imgs + j * n,
+                           j ? skels + (j - 1) * n : (const float*)nullptr, D, H, W, skels + j * n);
     return vg_check_launch();
 }
 
+// ---- backward steps, LDS-tiled like the forward ones.  The pooling gradients go to the FIRST arg-min / arg-max in the
+// reference's scan order (ties: TP, tf max_pool3d / -max_pool3d(-x) gradients), so the candidates are visited in exactly
+// that order; outside the volume the tile holds +-inf, which a strict comparison never selects.
+__device__ __forceinline__ void sk_load_tile(float (&t)[SK_TD + 2][SK_TH + 2][SK_TW + 2], const float* __restrict__ in, size_t vol,
+                                             int w0, int h0, int d0, int D, int H, int W, float fill, int tid) {
+    constexpr int NH = (SK_TD + 2) * (SK_TH + 2) * (SK_TW + 2);
+    for (int i = tid; i < NH; i += 256) {
+        const int x = i % (SK_TW + 2); const int r = i / (SK_TW + 2);
+        const int y = r % (SK_TH + 2), z = r / (SK_TH + 2);
+        const int gw = w0 + x - 1, gh = h0 + y - 1, gd = d0 + z - 1;
+        float v = fill;
+        if (gw >= 0 && gw < W && gh >= 0 && gh < H && gd >= 0 && gd < D) v = in[vol + ((size_t)gd * H + gh) * W + gw];
+        (&t[0][0][0])[i] = v;
+    }
+}
+#define SK_TILE_ORIGIN()                                                                                    \
+    const int tiles_w = (W + SK_TW - 1) / SK_TW, tiles_h = (H + SK_TH - 1) / SK_TH;                           \
+    int bt_ = blockIdx.x; const int tw_ = bt_ % tiles_w; bt_ /= tiles_w;                                      \
+    const int th_ = bt_ % tiles_h, td_ = bt_ / tiles_h;                                                       \
+    const int w0 = tw_ * SK_TW, h0 = th_ * SK_TH, d0 = td_ * SK_TD;                                           \
+    const size_t vol = (size_t)blockIdx.y * D * H * W;                                                        \
+    const int tx = tid & (SK_TW - 1), ty = tid >> 5; const int gw = w0 + tx, gh = h0 + ty;
+
 // backward step j, part 1: local gradients of the skeleton update
-__global__ void skel_bwd_local_kernel(const float* imgj, const float* imgj1, const float* prev, int B, int D, int H, int W,
-                                      float* gs, float* dimgj, float* dimgj1) {
-    const int64_t total = (int64_t)B * D * H * W;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        VG_VOX(i, W, H, D, w, h, d, b)
-        float dil; int o; dilate_at(imgj1 + i, D, H, W, d, h, w, dil, o);
+__global__ __launch_bounds__(256) void skel_bwd_local_kernel(const float* __restrict__ imgj, const float* __restrict__ imgj1,
+                                                             const float* __restrict__ prev, int D, int H, int W,
+                                                             float* gs, float* dimgj, float* dimgj1) {
+    __shared__ float t[SK_TD + 2][SK_TH + 2][SK_TW + 2];
+    const int tid = threadIdx.x;
+    SK_TILE_ORIGIN()
+    sk_load_tile(t, imgj1, vol, w0, h0, d0, D, H, W, -INFINITY, tid);
+    __syncthreads();
+    if (gw >= W || gh >= H) return;
+    for (int z = 0; z < SK_TD; ++z) {
+        const int gd = d0 + z;
+        if (gd >= D) break;
+        const size_t i = vol + ((size_t)gd * H + gh) * W + gw;
+        // dilation value and first arg-max, scan order a (D), b (H), c (W) ascending
+        float dil = -INFINITY; int o = 0;
+#pragma unroll
+        for (int a = -1; a <= 1; ++a)
+#pragma unroll
+            for (int b = -1; b <= 1; ++b)
+#pragma unroll
+                for (int c = -1; c <= 1; ++c) {
+                    const float v = t[z + 1 + a][ty + 1 + b][tx + 1 + c];
+                    if (v > dil) { dil = v; o = (a * H + b) * W + c; }
+                }
         const float raw = imgj[i] - dil;
         const float delta = fmaxf(raw, 0.f);
         const float g = gs[i];
         float ddelta;
         if (prev) {
-            const float s = prev[i];
-            const float u = delta - s * delta;
+            const float sp = prev[i];
+            const float u = delta - sp * delta;
             const float dr = u > 0.f ? g : 0.f;
-            ddelta = dr * (1.f - s);
+            ddelta = dr * (1.f - sp);
             gs[i] = g - dr * delta;             // d skel_{j-1}
         } else ddelta = g;
         const float e = raw > 0.f ? ddelta : 0.f;
-        if (e != 0.f) { dimgj[i] += e; atomicAdd(&dimgj1[i + o], -e); }
+        if (e != 0.f) { dimgj[i] += e; atomicAdd(&dimgj1[(int64_t)i + o], -e); }
     }
 }
 // part 2: d img_j += erode^T(d img_{j+1})
-__global__ void erode_bwd_kernel(const float* imgj, const float* dimgj1, int B, int D, int H, int W, float* dimgj) {
-    const int64_t total = (int64_t)B * D * H * W;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+__global__ __launch_bounds__(256) void erode_bwd_kernel(const float* __restrict__ imgj, const float* __restrict__ dimgj1,
+                                                        int D, int H, int W, float* dimgj) {
+    __shared__ float t[SK_TD + 2][SK_TH + 2][SK_TW + 2];
+    const int tid = threadIdx.x;
+    SK_TILE_ORIGIN()
+    sk_load_tile(t, imgj, vol, w0, h0, d0, D, H, W, INFINITY, tid);
+    __syncthreads();
+    if (gw >= W || gh >= H) return;
+    for (int z = 0; z < SK_TD; ++z) {
+        const int gd = d0 + z;
+        if (gd >= D) break;
+        const size_t i = vol + ((size_t)gd * H + gh) * W + gw;
         const float g = dimgj1[i];
         if (g == 0.f) continue;
-        VG_VOX(i, W, H, D, w, h, d, b)
-        float v; int o; erode_at(imgj + i, D, H, W, d, h, w, v, o);
-        atomicAdd(&dimgj[i + o], g);
+        float best = INFINITY; int o = 0;
+#define SK_ER(a, b, c) { const float v = t[z + 1 + (a)][ty + 1 + (b)][tx + 1 + (c)]; if (v < best) { best = v; o = ((a) * H + (b)) * W + (c); } }
+#pragma unroll
+        for (int a = -1; a <= 1; ++a)
+#pragma unroll
+            for (int b = -1; b <= 1; ++b) SK_ER(a, b, 0)
+#pragma unroll
+        for (int a = -1; a <= 1; ++a)
+#pragma unroll
+            for (int c = -1; c <= 1; ++c) SK_ER(a, 0, c)
+#pragma unroll
+        for (int b = -1; b <= 1; ++b)
+#pragma unroll
+            for (int c = -1; c <= 1; ++c) SK_ER(0, b, c)
+#undef SK_ER
+        atomicAdd(&dimgj[(int64_t)i + o], g);
     }
 }
 extern "C" int vg_soft_skel_bwd(const float* imgs, const float* skels, const float* gskel, int B, int D, int H, int W,
@@ -378,13 +470,15 @@ extern "C" int vg_soft_skel_bwd(const float* imgs, const float* skels, const flo
     hipStream_t s = (hipStream_t)stream;
     const int64_t n = (int64_t)B * D * H * W;
     const int blocks = lblocks(n);
+    (void)blocks;
+    const dim3 grid = skel_grid(B, D, H, W);
     float* gs = work; float* bufA = work + n; float* bufB = work + 2 * n;     // bufA = d img_{j+1}, bufB = d img_j
     if (hipMemcpyAsync(gs, gskel, n * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return VG_ELAUNCH;
     if (hipMemsetAsync(bufA, 0, 2 * n * sizeof(float), s) != hipSuccess) return VG_ELAUNCH;
     for (int j = iters; j >= 0; --j) {
-        hipLaunchKernelGGL(skel_bwd_local_kernel, dim3(blocks), dim3(256), 0, s, imgs + j * n, imgs + (j + 1) * n,
-                           j ? skels + (j - 1) * n : (const float*)nullptr, B, D, H, W, gs, bufB, bufA);
-        hipLaunchKernelGGL(erode_bwd_kernel, dim3(blocks), dim3(256), 0, s, imgs + j * n, bufA, B, D, H, W, bufB);
+        hipLaunchKernelGGL(skel_bwd_local_kernel, grid, dim3(256), 0, s, imgs + j * n, imgs + (j + 1) * n,
+                           j ? skels + (j - 1) * n : (const float*)nullptr, D, H, W, gs, bufB, bufA);
+        hipLaunchKernelGGL(erode_bwd_kernel, grid, dim3(256), 0, s, imgs + j * n, bufA, D, H, W, bufB);
         if (j > 0) {
             if (hipMemsetAsync(bufA, 0, n * sizeof(float), s) != hipSuccess) return VG_ELAUNCH;
             float* t = bufA; bufA = bufB; bufB = t;
