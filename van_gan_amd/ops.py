@@ -312,7 +312,7 @@ class ConvLayer:
 
     def wgrad(self, src: Src, dy: torch.Tensor):
         global _side_dirty
-        if SIDE is not None and PROF is None:
+        if SIDE is not None and PROF is None:       # the per-launch timing pass serialises (attributable kernel durations)
             SIDE.wait_stream(torch.cuda.current_stream())       # dY (and everything before it) is ready
             with torch.cuda.stream(SIDE):
                 self._wgrad(src, dy)
