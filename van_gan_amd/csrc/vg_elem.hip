@@ -151,16 +151,28 @@ __device__ __forceinline__ void anb_walk(const ANB& p, int n, int c, int vl, con
                 const bool dhb = dk == 1 || dk == p.D - 2 || hk == 1 || hk == p.H - 2;
                 const bool wb = wk == 1 || wk == p.W - 2;
                 if (dhb) {
-                    // reflected copies: every combination of {own, mirrored} per axis except the all-own one (already loaded)
-                    int qd[3], qh[3], qw[3], nd = 0, nh = 0, nw = 0;
-                    qd[nd++] = dk + 1; if (dk == 1) qd[nd++] = 0; if (dk == p.D - 2) qd[nd++] = p.D + 1;
-                    qh[nh++] = hk + 1; if (hk == 1) qh[nh++] = 0; if (hk == p.H - 2) qh[nh++] = p.H + 1;
-                    qw[nw++] = wk + 1; if (wk == 1) qw[nw++] = 0; if (wk == p.W - 2) qw[nw++] = p.W + 1;
-                    for (int a = 0; a < nd; ++a)
-                        for (int b = 0; b < nh; ++b)
-                            for (int e = 0; e < nw; ++e) {
+                    // reflected copies: every combination of {own, mirrored} per axis except the all-own one (already
+                    // loaded).  An axis has at most one mirrored plane here (index 1 -> padded 0, index n-2 -> padded n+1;
+                    // both only when n == 3, which the descriptor check excludes for padded grids... handled: second below)
+                    const int md = dk == 1 ? 0 : (dk == p.D - 2 ? p.D + 1 : -1);
+                    const int mh = hk == 1 ? 0 : (hk == p.H - 2 ? p.H + 1 : -1);
+                    const int mw = wk == 1 ? 0 : (wk == p.W - 2 ? p.W + 1 : -1);
+                    // n == 3: index 1 is next to both faces -> second mirror
+                    const int md2 = (dk == 1 && dk == p.D - 2) ? p.D + 1 : -1;
+                    const int mh2 = (hk == 1 && hk == p.H - 2) ? p.H + 1 : -1;
+                    const int mw2 = (wk == 1 && wk == p.W - 2) ? p.W + 1 : -1;
+#pragma unroll
+                    for (int a = 0; a < 3; ++a)
+#pragma unroll
+                        for (int b = 0; b < 3; ++b)
+#pragma unroll
+                            for (int e = 0; e < 3; ++e) {
                                 if ((a | b | e) == 0) continue;
-                                const size_t idx = ((size_t)(qd[a] * PH + qh[b]) * PW + qw[e]) * p.C;
+                                const int qd = a == 0 ? dk + 1 : (a == 1 ? md : md2);
+                                const int qh = b == 0 ? hk + 1 : (b == 1 ? mh : mh2);
+                                const int qw = e == 0 ? wk + 1 : (e == 1 ? mw : mw2);
+                                if ((qd | qh | qw) < 0) continue;
+                                const size_t idx = ((size_t)(qd * PH + qh) * PW + qw) * p.C;
                                 if (VEC == 8) {
                                     float r[8]; load8<T>(gp + idx, r);
 #pragma unroll
