@@ -94,6 +94,37 @@ __device__ __forceinline__ void conv_mfma_chunk(f32x4 (&acc)[MW], WP w, const ch
         const int kg = lane >> 4;
         const int last = ksteps - 1;
         const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+        if constexpr (!__is_same(WP, lds_ptr<T>)) {
+            // weights straight from L2 (panels too big for LDS: the wide layers): a ring of four fragments, i.e. the
+            // fetch for K-step s+4 is issued when step s has been multiplied -- one step of MFMAs (64-128 cycles) does not
+            // cover an L2 round trip.  Halo fragments ping-pong between two sets as in the LDS-weight loop below.
+            bf16x8 a[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a[u] = wfrag(min(u, last));
+            bf16x8 bb[2][MW];
+            {
+                const int o0 = koff[kg];
+#pragma unroll
+                for (int i = 0; i < MW; ++i) bb[0][i] = *(const bf16x8*)(halo + rowbase[i] + o0);
+            }
+            int on1 = koff[min(1, last) * 4 + kg];
+            for (int s = 0; s < ksteps; s += 4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int on2 = koff[min(s + u + 2, last) * 4 + kg];
+#pragma unroll
+                    for (int i = 0; i < MW; ++i) bb[(u + 1) & 1][i] = *(const bf16x8*)(halo + rowbase[i] + on1);
+                    if (s + u >= ksteps) a[u] = zero8;                 // phantom steps of the last group add zero
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < MW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u], bb[u & 1][i], acc[i], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    a[u] = wfrag(min(s + u + 4, last));
+                    on1 = on2;
+                }
+            }
+            return;
+        }
         bf16x8 a0 = wfrag(0), a1;
         bf16x8 b0[MW], b1[MW];
         {
