@@ -77,6 +77,9 @@ CONV_CASES = [
     (4, 32, 64, 1, 'same', (4, 4, 4)),
     (3, 64, 1, 1, 'same', (4, 4, 4)),
     (3, 96, 32, 1, 'reflect', (4, 4, 8)),
+    # wide layers big enough for the 32x32x16-MFMA flavour (conv32_kernel): 128-wide panel forward, 64-wide data gradient
+    (3, 64, 128, 1, 'reflect', (16, 16, 32)),
+    (4, 64, 128, 2, 'reflect', (32, 32, 32)),
 ]
 
 

@@ -521,6 +521,202 @@ __global__ __launch_bounds__(256, ((BN / 16) * MSUB >= 8 ? 2 : VG_CONV_WAVES)) v
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// conv32_kernel: the wide-layer flavour (Cin >= 64, Cout a multiple of 64; bf16; weights from L2).  Same staging, tables and
+// persistent-tile structure as conv_kernel, but v_mfma_f32_32x32x16_bf16: a wave owns 32 output channels x 32-voxel
+// sub-tiles, so one A fragment (32 weight rows x 16 k) and one B fragment (16 k x 32 voxels) feed twice the MACs of the
+// 16x16x32 form -- half the LDS traffic and ~40 % fewer instructions per MAC -- and the channel panel is 128 (4 waves along
+// the channels) or 64 wide, which halves how often the same input tile is re-staged for another panel.  PMC/ablation on
+// D.down0/1/2 before: MFMA phase 40-70 % of the time at 10-19 % MFMA utilisation, staging up to 40 %.
+//   acc layout (32x32): lane l holds voxel (l & 31), channels 8*j + 4*(l >> 5) + r  for j = 0..3, r = 0..3  (acc[4*j + r])
+// ------------------------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+template <int BN, int MSUB, bool NOISE>
+__global__ __launch_bounds__(256, 2) void conv32_kernel(const GatherIn g, const ConvOut p) {
+    typedef bf16_t T;
+    constexpr int WN = BN / 32, WM = 4 / WN;            // waves along the channel panel / along the voxels
+    constexpr int NSUB = (64 * MSUB) / 32;              // 32-voxel sub-tiles per tile
+    static_assert(NSUB % WM == 0, "sub-tiles must divide over the voxel waves");
+    constexpr int MW = NSUB / WM;                       // sub-tiles per wave
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_n = wave % WN, wave_m = wave / WN;
+    const int n = blockIdx.z, ntile = blockIdx.y;
+    const int TWm = (1 << g.twl) - 1, THm = (1 << g.thl) - 1;
+    const int lv = lane & 31, lk = lane >> 5;
+
+    char* halo = smem;
+    const int hbytes = g.planar ? (g.CK >> 3) * g.PSB : g.HD * g.DS;
+    int* tapoff = (int*)(smem + hbytes);
+    float* scs = (float*)(smem + hbytes + 256);
+    float* stat = scs + 2 * g.CK;
+    int* utab = (int*)(stat + BN * 2);
+    const int ncols = stage_ncols(g);
+    const int RTN = 3 * (g.HH + g.HW);
+    int* rtab = utab + 2 * ncols;
+    const int c16 = g.CK >> 4;                           // 16-channel K-steps per tap
+    const int ksteps = g.ntaps * c16;
+    int* koff = rtab + 2 * RTN;                          // [K-step][k-group 0/1]: byte offset of the B fragment in the halo image
+
+    if (tid < g.ntaps)
+        tapoff[tid] = (g.td[tid] - g.tmin_d) * g.DS + ((g.th[tid] - g.tmin_h) * g.HWp + halo_pos_w(g, g.tw[tid] - g.tmin_w)) * g.VS;
+    if (tid < BN * 2) stat[tid] = 0.f;
+    build_column_table(g, utab, tid);
+    for (int i = tid; i < ksteps * 2; i += 256) {
+        const int st = i >> 1, kg = i & 1;
+        const int tp = st / c16, cgq = (st - tp * c16) * 2 + kg;
+        koff[i] = (g.td[tp] - g.tmin_d) * g.DS + ((g.th[tp] - g.tmin_h) * g.HWp + halo_pos_w(g, g.tw[tp] - g.tmin_w)) * g.VS + cgq * g.CS;
+    }
+    int rowbase[MW], ooff[MW], dhw[MW];
+    const int co_lane = ntile * BN + wave_n * 32 + 4 * lk;        // first channel of this lane's group 0 (groups are 8 apart)
+#pragma unroll
+    for (int i = 0; i < MW; ++i) {
+        const int m = (wave_m * MW + i) * 32 + lv;
+        const int w = m & TWm, h = (m >> g.twl) & THm, d = m >> (g.twl + g.thl);
+        rowbase[i] = d * g.istr * g.DS + (h * g.istr * g.HWp + w) * g.VS;
+        ooff[i] = ((d * p.ostr * p.BH + h * p.ostr) * p.BW + w * p.ostr) * p.Cout + co_lane;
+        dhw[i] = d | (h << 10) | (w << 20);
+    }
+    const glb_ptr<T> wrow = (glb_ptr<T>)p.wp + (size_t)(ntile * BN + wave_n * 32 + lv) * p.Ktot + 8 * lk;
+    float s1[16], s2[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
+    if (p.nchunks == 1) stage_scale_shift(g, scs, n, 0, tid);
+    const int tiles_per_n = g.tiles_d * g.tiles_h * g.tiles_w;
+    if ((int)blockIdx.x < tiles_per_n) {
+        int t = blockIdx.x;
+        const int tw_i = t % g.tiles_w; t /= g.tiles_w;
+        const int th_i = t % g.tiles_h;
+        stage_resolve_axes(g, rtab, th_i << g.thl, tw_i << g.twl, tid);
+    }
+    __syncthreads();
+
+    int gs_w, gs_h, gs_d;
+    { int t = gridDim.x; gs_w = t % g.tiles_w; t /= g.tiles_w; gs_h = t % g.tiles_h; gs_d = t / g.tiles_h; }
+    int ti_w, ti_h, ti_d;
+    { int t = blockIdx.x; ti_w = t % g.tiles_w; t /= g.tiles_w; ti_h = t % g.tiles_h; ti_d = t / g.tiles_h; }
+    typedef const __attribute__((address_space(1))) bf16x8 glb_frag;
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    int it = -1;
+    for (int tile = blockIdx.x; tile < tiles_per_n; tile += gridDim.x) {
+        ++it;
+        const int od0 = ti_d << g.tdl, oh0 = ti_h << g.thl, ow0 = ti_w << g.twl;
+        ti_w += gs_w; if (ti_w >= g.tiles_w) { ti_w -= g.tiles_w; ++ti_h; }
+        ti_h += gs_h; if (ti_h >= g.tiles_h) { ti_h -= g.tiles_h; ++ti_d; }
+        ti_d += gs_d;
+        f32x16 acc[MW];
+#pragma unroll
+        for (int i = 0; i < MW; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+        for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+            __syncthreads();                       // previous readers of the halo tile are done; this tile's axis tables visible
+            if (p.nchunks > 1) { stage_scale_shift(g, scs, n, chunk, tid); __syncthreads(); }
+            stage_halo_tile<T, NOISE, 4>(g, halo, scs, utab, rtab + (it & 1) * RTN, n, od0, chunk, tid);
+            if (chunk == 0 && tile + (int)gridDim.x < tiles_per_n)
+                stage_resolve_axes(g, rtab + ((it + 1) & 1) * RTN, ti_h << g.thl, ti_w << g.twl, tid);
+            __syncthreads();
+            // ---- K loop: ring of RD weight fragments (L2 latency), halo fragments ping-pong ----
+            const glb_ptr<T> w = wrow + (size_t)chunk * p.kc_pad;
+            const int last = ksteps - 1;
+            constexpr int RD = 8;                  // weight-fragment ring depth: one workgroup per CU has no other wave to hide L2 latency
+            bf16x8 a[RD];
+#pragma unroll
+            for (int u = 0; u < RD; ++u) a[u] = *(glb_frag*)(w + min(u, last) * 16);
+            bf16x8 bb[2][MW];
+            {
+                const int o0 = koff[lk];
+#pragma unroll
+                for (int i = 0; i < MW; ++i) bb[0][i] = *(const bf16x8*)(halo + rowbase[i] + o0);
+            }
+            int on1 = koff[min(1, last) * 2 + lk];
+            for (int s = 0; s < ksteps; s += RD) {
+#pragma unroll
+                for (int u = 0; u < RD; ++u) {
+                    const int on2 = koff[min(s + u + 2, last) * 2 + lk];
+#pragma unroll
+                    for (int i = 0; i < MW; ++i) bb[(u + 1) & 1][i] = *(const bf16x8*)(halo + rowbase[i] + on1);
+                    if (s + u >= ksteps) a[u] = zero8;                 // phantom steps of the last group add zero
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < MW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u], bb[u & 1][i], acc[i], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    a[u] = *(glb_frag*)(w + min(s + u + RD, last) * 16);
+                    on1 = on2;
+                }
+            }
+        }
+        // ---- epilogue: four groups of 4 consecutive channels per lane and sub-tile ----
+        const size_t tbase = (((size_t)(n * p.BD + od0 * p.ostr + p.ood) * p.BH + oh0 * p.ostr + p.ooh) * p.BW + ow0 * p.ostr + p.oow) * p.Cout;
+        const int remd = p.OD - od0, remh = p.OH - oh0, remw = p.OW - ow0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int co = co_lane + 8 * j;
+            if (co >= p.Cout) continue;
+            float bias4[4] = {0.f, 0.f, 0.f, 0.f}, rs4[4], rb4[4];
+            if (p.bias) { const f32x4 b4 = *(const __attribute__((address_space(1))) f32x4*)(uintptr_t)(p.bias + co); bias4[0] = b4[0]; bias4[1] = b4[1]; bias4[2] = b4[2]; bias4[3] = b4[3]; }
+            if (p.res) {
+                const f32x4 r4 = *(const __attribute__((address_space(1))) f32x4*)(uintptr_t)(p.rs + n * p.Cout + co);
+                const f32x4 q4 = *(const __attribute__((address_space(1))) f32x4*)(uintptr_t)(p.rb + n * p.Cout + co);
+                for (int r = 0; r < 4; ++r) { rs4[r] = r4[r]; rb4[r] = q4[r]; }
+            }
+#pragma unroll
+            for (int i = 0; i < MW; ++i) {
+                const bool inr = (dhw[i] & 1023) < remd && ((dhw[i] >> 10) & 1023) < remh && (dhw[i] >> 20) < remw;
+                if (!inr) continue;
+                const size_t o = tbase + ooff[i] + 8 * j;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = acc[i][4 * j + r] + bias4[r];
+                if (p.res) {
+                    Vec4<T> rv; vec4_load(rv, (const T*)p.res + o);
+                    float x[4]; vec4_unpack(rv, x);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += x[r] * rs4[r] + rb4[r];
+                }
+                if (p.accumulate) {
+                    float x[4];
+                    if (p.out_f32) { Vec4<float> ov; vec4_load(ov, (const float*)p.out + o); vec4_unpack(ov, x); }
+                    else { Vec4<bf16_t> ov; vec4_load(ov, (const bf16_t*)p.out + o); vec4_unpack(ov, x); }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += x[r];
+                }
+                if (p.out_f32) {
+                    *(f32x4*)((float*)p.out + o) = (f32x4){v[0], v[1], v[2], v[3]};
+                } else {
+                    const bf16x4 pk = {(short)f2bf(v[0]), (short)f2bf(v[1]), (short)f2bf(v[2]), (short)f2bf(v[3])};
+                    *(bf16x4*)((bf16_t*)p.out + o) = pk;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = bf2f((bf16_t)pk[r]);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { s1[4 * j + r] += v[r]; s2[4 * j + r] += v[r] * v[r]; }
+            }
+        }
+    }
+    if (p.sums) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float a = s1[r], b = s2[r];
+#pragma unroll
+            for (int o = 1; o < 32; o <<= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+            if (lv == 0) {
+                const int cl = wave_n * 32 + 8 * (r >> 2) + 4 * lk + (r & 3);
+                atomicAdd(&stat[cl * 2], a);
+                atomicAdd(&stat[cl * 2 + 1], b);
+            }
+        }
+        __syncthreads();
+        if (tid < BN * 2) {
+            const int co = ntile * BN + (tid >> 1);
+            const int stripe = blockIdx.x & (VG_STRIPES - 1);
+            if (co < p.Cout) atomicAdd(&p.sums[(((size_t)stripe * gridDim.z + n) * p.Cout + co) * 2 + (tid & 1)], stat[tid]);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -627,12 +823,67 @@ static int fill_conv(const vg_conv_desc* d, GatherIn& g, ConvOut& k, ConvCls& q,
     return VG_OK;
 }
 
+// ---- wide-layer flavour (conv32_kernel): eligibility and tile plan ----
+static int plan_conv32(const vg_conv_desc* d, const ConvOut& k, const ConvCls& q, GatherIn& g, int& BN, int& MSUB, int& lds) {
+    static int use32 = -1;
+    if (use32 < 0) { const char* e = getenv("VG_CONV32"); use32 = e ? atoi(e) : 1; }
+    const int Cin = d->c_src0 + d->c_src1;
+    if (!use32 || d->f32 || q.ncls != 1 || (d->Cout % 64) || Cin < 64 || Cin == 1 || d->tanh_out || (d->CK % 16)) return VG_EINVAL;
+    if ((long)d->OD * d->OH * d->OW * d->N * (d->Cout / 64) < 256 * 64) return VG_EINVAL;     // too small to fill the chip with 64-wide panels
+    BN = (d->Cout % 128 == 0) ? 128 : 64;
+    const int ksteps = d->ntaps * (d->CK >> 4);
+    long best = -1; int best_ms = 0, best_lds = 0;
+    for (int ms = (BN == 128 ? 2 : 4); ms >= (BN == 128 ? 1 : 2); ms >>= 1) {
+        int rc = fill_gather(d, g, d->CK, 64 * ms);
+        if (rc != VG_OK) return rc;
+        const int need = halo_bytes(g) + 256 + 2 * d->CK * 4 + BN * 2 * 4 + stage_table_ints(g) * 4 + ksteps * 8 + 16;
+        if (need > VG_LDS_LIMIT) continue;
+        const long wgs = (long)g.tiles_d * g.tiles_h * g.tiles_w * (d->Cout / BN) * d->N;
+        // every tile streams its BN x K weight panel from L2 (64 B/clk per CU): 64 voxels per tile give exactly the
+        // 64 FLOP/B that the MFMA rate needs, 128 voxels give headroom -- so one workgroup per CU with the big tile beats
+        // two with the small one
+        const long fill = wgs >= 256 ? 256 : wgs;
+        const long score = fill * 1000 + ms * 10 + (need <= 80 * 1024 ? 5 : 0);
+        if (score > best) { best = score; best_ms = ms; best_lds = need; }
+    }
+    if (best < 0) return VG_ELDS;
+    MSUB = best_ms; lds = best_lds;
+    (void)k;
+    return fill_gather(d, g, d->CK, 64 * MSUB);
+}
+template <int BN, int MSUB, bool NOISE>
+static int launch_conv32b(const GatherIn& g, const ConvOut& k, int lds, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)conv32_kernel<BN, MSUB, NOISE>, hipFuncAttributeMaxDynamicSharedMemorySize, VG_LDS_LIMIT);
+        attr_set = true;
+    }
+    int per_cu = 2;
+    if (lds > 0 && VG_LDS_LIMIT / lds < per_cu) per_cu = VG_LDS_LIMIT / lds;
+    if (per_cu < 1) per_cu = 1;
+    const int tiles = g.tiles_d * g.tiles_h * g.tiles_w;
+    const int ny = k.Cout / BN;
+    int bx = 256 * per_cu / (ny * g.N); if (bx < 1) bx = 1; if (bx > tiles) bx = tiles;
+    hipLaunchKernelGGL((conv32_kernel<BN, MSUB, NOISE>), dim3(bx, ny, g.N), dim3(256), lds, s, g, k);
+    return vg_check_launch();
+}
+static int launch_conv32(const GatherIn& g, const ConvOut& k, int BN, int MSUB, int lds, hipStream_t s) {
+    const bool nz = g.noise != nullptr;
+    if (BN == 128) {
+        if (MSUB == 2) return nz ? launch_conv32b<128, 2, true>(g, k, lds, s) : launch_conv32b<128, 2, false>(g, k, lds, s);
+        return nz ? launch_conv32b<128, 1, true>(g, k, lds, s) : launch_conv32b<128, 1, false>(g, k, lds, s);
+    }
+    if (MSUB == 4) return nz ? launch_conv32b<64, 4, true>(g, k, lds, s) : launch_conv32b<64, 4, false>(g, k, lds, s);
+    return nz ? launch_conv32b<64, 2, true>(g, k, lds, s) : launch_conv32b<64, 2, false>(g, k, lds, s);
+}
+
 extern "C" int vg_conv3d_plan(const vg_conv_desc* d, int32_t* plan4) {
     vg_begin();
     if (!plan4) return VG_EINVAL;
     GatherIn g; ConvOut k; ConvCls q; int BN, MSUB, lds;
     int rc = fill_conv(d, g, k, q, BN, MSUB, lds);
     if (rc != VG_OK) return rc;
+    { GatherIn g2; int bn2, ms2, lds2; if (plan_conv32(d, k, q, g2, bn2, ms2, lds2) == VG_OK) { g = g2; BN = bn2; MSUB = ms2; lds = lds2; } }
     plan4[0] = BN; plan4[1] = 64 * MSUB; plan4[2] = lds;
     plan4[3] = g.tiles_d * g.tiles_h * g.tiles_w * ((d->Cout + BN - 1) / BN) * d->N;
     return VG_OK;
@@ -642,6 +893,7 @@ extern "C" int vg_conv3d_lds_bytes(const vg_conv_desc* d) {
     vg_begin();
     GatherIn g; ConvOut k; ConvCls q; int BN, MSUB, lds;
     int rc = fill_conv(d, g, k, q, BN, MSUB, lds);
+    if (rc == VG_OK) { GatherIn g2; int bn2, ms2, lds2; if (plan_conv32(d, k, q, g2, bn2, ms2, lds2) == VG_OK) lds = lds2; }
     return rc == VG_OK ? lds : rc;
 }
 
@@ -696,6 +948,7 @@ extern "C" int vg_conv3d(const vg_conv_desc* d, vg_stream_t stream) {
     int rc = fill_conv(d, g, k, q, BN, MSUB, lds);
     if (rc != VG_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
+    { GatherIn g2; int bn2, ms2, lds2; if (plan_conv32(d, k, q, g2, bn2, ms2, lds2) == VG_OK) return launch_conv32(g2, k, bn2, ms2, lds2, s); }
     return d->f32 ? dispatch_conv<float>(g, k, q, BN, MSUB, lds, s) : dispatch_conv<bf16_t>(g, k, q, BN, MSUB, lds, s);
 }
 
