@@ -68,10 +68,9 @@ def side_enable(device, on: bool = True):
 
 def side_join():
     """Main stream waits for every weight-gradient launch issued so far."""
-    global _side_dirty
-    if SIDE is not None and _side_dirty:
+    # unconditional: with two backward lanes each lane's stream has to wait for itself (an event record + wait is cheap)
+    if SIDE is not None:
         torch.cuda.current_stream().wait_stream(SIDE)
-        _side_dirty = False
 WGRAD_SCRATCH = {}     # device -> fp32 scratch for the partial-slab weight-gradient reduction (256 MB)
 
 

@@ -69,6 +69,12 @@ class VanGan:
             arena_bytes = int(batch_size * S * 5200 * (2 if precision == 'fp32' else 1)) + (512 << 20)
         self.arena = Arena(arena_bytes, self.device)
         ops.side_enable(self.device, os.environ.get('VG_SIDE_STREAM', '1') != '0')     # weight gradients on a second stream
+        # forward lanes: the I->S->I chain (G_IS(real_I), G_SI(fake_S), D_S, cycle losses on cycled_I) and the S->I->S chain
+        # are independent until the backward sweeps, so they run on two streams and fill each other's low-occupancy
+        # 8^3/16^3 layers
+        self._lane_b = torch.cuda.Stream(device=self.device) if os.environ.get('VG_LANES', '1') != '0' else None
+        # second workspace for lane B's backward temporaries (bump allocators cannot interleave mark/release)
+        self.arena_b = Arena(arena_bytes // 2, self.device) if self._lane_b is not None else None
         self.sync = GradSync({k: s.g for k, s in self.stores.items()}, self.pg, {k: s.w for k, s in self.stores.items()})
         self.checkpoint_dir = None
         if output_dir is not None:
@@ -125,37 +131,47 @@ class VanGan:
         bufS[:B].copy_(real_S); bufI[:B].copy_(real_I)
         rI, rS, fake_S, fake_I = bufI[:B], bufS[:B], bufS[B:], bufI[B:]
         cyc_S, cyc_I = ar.alloc(vol, f32), ar.alloc(vol, f32)
-        c1 = self.gen_IS.forward(ar, rI, fake_S)                     # vangan.py:295
-        c2 = self.gen_SI.forward(ar, rS, fake_I)                     # :297
-        c3 = self.gen_IS.forward(ar, fake_I, cyc_S)                  # :300
-        c4 = self.gen_SI.forward(ar, fake_S, cyc_I)                  # :305
+        import contextlib
+        main = torch.cuda.current_stream()
+        lane_b = self._lane_b if ops.PROF is None else None        # the per-launch timing pass stays serial
+        if lane_b is not None:
+            lane_b.wait_stream(main)                                 # inputs copied, arena reset
+        def laneB():
+            return torch.cuda.stream(lane_b) if lane_b is not None else contextlib.nullcontext()
+        c1 = self.gen_IS.forward(ar, rI, fake_S)                     # vangan.py:295   (lane A)
+        with laneB():
+            c2 = self.gen_SI.forward(ar, rS, fake_I)                 # :297            (lane B)
+        c4 = self.gen_SI.forward(ar, fake_S, cyc_I)                  # :305            (lane A)
+        with laneB():
+            c3 = self.gen_IS.forward(ar, fake_I, cyc_S)              # :300            (lane B)
 
-        # ---- cycle / segmentation losses on cycled_S (loss_functions.py:185-190, 211-226) ----
-        mmS, mmcS = ar.alloc((B, 4), f32), ar.alloc((B, 4), f32)
-        nS, ncS = ar.alloc(vol, f32), ar.alloc(vol, f32)
-        ops.minmax(rS, B, S, mmS); ops.minmax_apply(rS, mmS, B, S, nS)
-        ops.minmax(cyc_S, B, S, mmcS); ops.minmax_apply(cyc_S, mmcS, B, S, ncS)
-        g_ncS = ar.alloc(vol, f32) if do_backward else None
-        ops.bce(nS, ncS, acc[0:1], self.lambda_cycle / (B * S * gbs), g_ncS, accumulate=False)
+        # ---- cycle / segmentation losses on cycled_S (loss_functions.py:185-190, 211-226): lane B ----
         it = self.skel_iters
         dims4 = (B, D, H, W)
-        imgs_p, skels_p = ar.alloc((it + 2,) + vol, f32), ar.alloc((it + 1,) + vol, f32)
-        imgs_t, skels_t = ar.alloc((it + 2,) + vol, f32), ar.alloc((it + 1,) + vol, f32)
-        ops.soft_skel_fwd(ncS, dims4, it, imgs_p, skels_p)
-        ops.soft_skel_fwd(nS, dims4, it, imgs_t, skels_t)
-        skel_p, skel_t = skels_p[it], skels_t[it]
-        sums = ar.alloc((9,), f32, zero=True)
-        coef = ar.alloc((8,), f32, zero=True)
-        ops.dot_sums(skel_p, nS, sums[0:3]); ops.dot_sums(skel_t, ncS, sums[3:6]); ops.dot_sums(nS, ncS, sums[6:9])
-        ops.cldice_coef(sums, self.lambda_topology / self.n_devices, 0.5, coef)
-        if do_backward:
-            gskel = ar.alloc(vol, f32)
-            ops.cldice_grads(nS, skel_t, coef, gskel, g_ncS, accumulate=True)
-            work = ar.alloc((3,) + vol, f32)
-            ops.soft_skel_bwd(imgs_p, skels_p, gskel, dims4, it, work, g_ncS)
-            g_cS = ar.alloc(vol, f32)
-            tmp2 = ar.alloc((B, 2), f32, zero=True)
-            ops.minmax_bwd(cyc_S, ncS, g_ncS, mmcS, B, S, tmp2, g_cS)
+        with laneB():
+            mmS, mmcS = ar.alloc((B, 4), f32), ar.alloc((B, 4), f32)
+            nS, ncS = ar.alloc(vol, f32), ar.alloc(vol, f32)
+            ops.minmax(rS, B, S, mmS); ops.minmax_apply(rS, mmS, B, S, nS)
+            ops.minmax(cyc_S, B, S, mmcS); ops.minmax_apply(cyc_S, mmcS, B, S, ncS)
+            g_ncS = ar.alloc(vol, f32) if do_backward else None
+            ops.bce(nS, ncS, acc[0:1], self.lambda_cycle / (B * S * gbs), g_ncS, accumulate=False)
+            imgs_p, skels_p = ar.alloc((it + 2,) + vol, f32), ar.alloc((it + 1,) + vol, f32)
+            imgs_t, skels_t = ar.alloc((it + 2,) + vol, f32), ar.alloc((it + 1,) + vol, f32)
+            ops.soft_skel_fwd(ncS, dims4, it, imgs_p, skels_p)
+            ops.soft_skel_fwd(nS, dims4, it, imgs_t, skels_t)
+            skel_p, skel_t = skels_p[it], skels_t[it]
+            sums = ar.alloc((9,), f32, zero=True)
+            coef = ar.alloc((8,), f32, zero=True)
+            ops.dot_sums(skel_p, nS, sums[0:3]); ops.dot_sums(skel_t, ncS, sums[3:6]); ops.dot_sums(nS, ncS, sums[6:9])
+            ops.cldice_coef(sums, self.lambda_topology / self.n_devices, 0.5, coef)
+            if do_backward:
+                gskel = ar.alloc(vol, f32)
+                ops.cldice_grads(nS, skel_t, coef, gskel, g_ncS, accumulate=True)
+                work = ar.alloc((3,) + vol, f32)
+                ops.soft_skel_bwd(imgs_p, skels_p, gskel, dims4, it, work, g_ncS)
+                g_cS = ar.alloc(vol, f32)
+                tmp2 = ar.alloc((B, 2), f32, zero=True)
+                ops.minmax_bwd(cyc_S, ncS, g_ncS, mmcS, B, S, tmp2, g_cS)
 
         # ---- cycle MSE + SSIM reconstruction on cycled_I (loss_functions.py:179-180, 193-208) ----
         g_cI = ar.alloc(vol, f32) if do_backward else None
@@ -180,39 +196,58 @@ class VanGan:
         logS, logI = ar.alloc((2 * B,) + ld + (1,), f32), ar.alloc((2 * B,) + ld + (1,), f32)
         if training and noise is None:
             nzS, dpS = self._make_noise(self.disc_S, 2 * B, ar)
-            nzI, dpI = self._make_noise(self.disc_I, 2 * B, ar)
+            with laneB():
+                nzI, dpI = self._make_noise(self.disc_I, 2 * B, ar)
         else:
             noise, drop = noise or {}, drop or {}
             nzS, dpS, nzI, dpI = noise.get('S'), drop.get('S'), noise.get('I'), drop.get('I')
-        dS = self.disc_S.forward(ar, bufS, logS, nzS, dpS)
-        dI = self.disc_I.forward(ar, bufI, logI, nzI, dpI)
+        dS = self.disc_S.forward(ar, bufS, logS, nzS, dpS)                                  # lane A: needs fake_S
         gd = 1.0 / (nps * gbs)
         gS_D, gI_D = (ar.alloc(logS.shape, f32), ar.alloc(logI.shape, f32)) if do_backward else (None, None)
         gS_G, gI_G = (ar.alloc(logS[B:].shape, f32), ar.alloc(logI[B:].shape, f32)) if do_backward else (None, None)
         ops.mse_const(logS[B:], 1.0, acc[3:4], gd, gS_G)                                  # gen_IS_loss
-        ops.mse_const(logI[B:], 1.0, acc[4:5], gd, gI_G)                                  # gen_SI_loss
         ops.mse_const(logS[:B], 1.0, acc[5:6], 0.5 * gd, None if gS_D is None else gS_D[:B])
         ops.mse_const(logS[B:], 0.0, acc[6:7], 0.5 * gd, None if gS_D is None else gS_D[B:])
-        ops.mse_const(logI[:B], 1.0, acc[7:8], 0.5 * gd, None if gI_D is None else gI_D[:B])
-        ops.mse_const(logI[B:], 0.0, acc[8:9], 0.5 * gd, None if gI_D is None else gI_D[B:])
+        with laneB():
+            dI = self.disc_I.forward(ar, bufI, logI, nzI, dpI)                              # lane B: needs fake_I
+            ops.mse_const(logI[B:], 1.0, acc[4:5], gd, gI_G)                              # gen_SI_loss
+            ops.mse_const(logI[:B], 1.0, acc[7:8], 0.5 * gd, None if gI_D is None else gI_D[:B])
+            ops.mse_const(logI[B:], 0.0, acc[8:9], 0.5 * gd, None if gI_D is None else gI_D[B:])
+        if lane_b is not None:
+            main.wait_stream(lane_b)                                                        # lanes join before the backward sweeps
 
         if do_backward:
             for st in self.stores.values():
                 st.g.zero_()
-            # discriminator sweeps: D loss over [real;fake] (weights) and generator loss through the fake half
+            # Backward lanes: lane A = D_S sweeps + both gen_IS applications, lane B = D_I sweeps + both gen_SI applications
+            # (total_loss_I only reaches gen_IS, total_loss_S only gen_SI; each lane accumulates into its own networks'
+            # gradient buffers).  Per network: D loss over [real;fake] (weights), generator loss through the fake half.
             g_fS, g_fI = ar.alloc(vol, f32), ar.alloc(vol, f32)
-            self.disc_I.backward(ar, dI, gI_D, 0, 2 * B, wgrad=True)
+            arB = ar
+            if lane_b is not None:
+                arB = self.arena_b
+                arB.reset()
+                lane_b.wait_stream(main)
             self.disc_S.backward(ar, dS, gS_D, 0, 2 * B, wgrad=True)
-            self._start_allreduce(['disc_I', 'disc_S'])
+            self._start_allreduce(['disc_S'])
             self.disc_S.backward(ar, dS, gS_G, B, 2 * B, wgrad=False, dx=g_fS)
-            self.disc_I.backward(ar, dI, gI_G, B, 2 * B, wgrad=False, dx=g_fI)
+            with laneB():
+                self.disc_I.backward(arB, dI, gI_D, 0, 2 * B, wgrad=True)
+                self._start_allreduce(['disc_I'])
+                self.disc_I.backward(arB, dI, gI_G, B, 2 * B, wgrad=False, dx=g_fI)
             mk = ar.mark()
             self.gen_IS.backward(ar, c1, g_fS); ar.release(mk)        # adversarial application
+            with laneB():
+                mkb = arB.mark()
+                self.gen_SI.backward(arB, c2, g_fI); arB.release(mkb)
             self.gen_IS.backward(ar, c3, g_cS); ar.release(mk)        # cycle application
             self._start_allreduce(['gen_IS'])
-            self.gen_SI.backward(ar, c2, g_fI); ar.release(mk)
-            self.gen_SI.backward(ar, c4, g_cI); ar.release(mk)
-            self._start_allreduce(['gen_SI'])
+            with laneB():
+                self.gen_SI.backward(arB, c4, g_cI); arB.release(mkb)
+                self._start_allreduce(['gen_SI'])
+            if lane_b is not None:
+                main.wait_stream(lane_b)
+            ops.side_join()
         self._acc, self._coef = acc, coef
         self._aux = dict(fake_S=fake_S, fake_I=fake_I, cycled_S=cyc_S, cycled_I=cyc_I, logits_S=logS, logits_I=logI)
         return B, S, nps
