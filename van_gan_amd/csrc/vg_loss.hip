@@ -544,8 +544,8 @@ __global__ void overlap_add_kernel(const float* win, int kx, int ky, int kz, int
         const int z = (int)(i % cz); int64_t r = i / cz; const int y = (int)(r % cy); const int x = (int)(r / cy);
         const float v = win[((size_t)(x + px) * ky + (y + py)) * kz + (z + pz)];
         const size_t o = ((size_t)(x0 + px + x) * Y + (y0 + py + y)) * Z + (z0 + pz + z);
-        pred[o] += v;                 // windows of one call are added by successive launches on one stream: no race
-        cnt[o] += 1.f;
+        atomicAdd(&pred[o], v);       // overlapping windows may be in flight on two streams (inference lanes)
+        atomicAdd(&cnt[o], 1.f);
     }
 }
 extern "C" int vg_overlap_add(const float* win, int kx, int ky, int kz, int px, int py, int pz, int x0, int y0, int z0,

@@ -60,28 +60,39 @@ def stitch_subvolumes(engine, gen: str, img: torch.Tensor, subvol_size: Sequence
     cnt = torch.zeros(X, Y, Z, device=dev)
     origins = [(a, b, c) for a in window_origins(X, kx, stride[0]) for b in window_origins(Y, ky, stride[1])
                for c in window_origins(Z, kz, stride[2])]
-    ar = engine.arena
     S = kx * ky * kz
-    for i0 in range(0, len(origins), window_batch):
+    # two lanes: consecutive window batches alternate between two streams, each with its own workspace, so that the
+    # low-occupancy deep layers of one batch overlap the full-resolution layers of the other
+    main = torch.cuda.current_stream()
+    lane_b = getattr(engine, '_lane_b', None)
+    lanes = [(main, engine.arena)]
+    if lane_b is not None and getattr(engine, 'arena_b', None) is not None:
+        lane_b.wait_stream(main)                             # v, pred, cnt are ready
+        lanes.append((lane_b, engine.arena_b))
+    for bi, i0 in enumerate(range(0, len(origins), window_batch)):
         chunk = origins[i0:i0 + window_batch]
         B = len(chunk)
-        ar.reset()
-        xin = ar.alloc((B, kx, ky, kz, 1), torch.float32)
-        yout = ar.alloc((B, kx, ky, kz, 1), torch.float32)
-        for b, (a, bb, c) in enumerate(chunk):
-            xin[b, ..., 0].copy_(v[a:a + kx, bb:bb + ky, c:c + kz])
-        if process_img:                # process_imaging_otf with axis=None (main.py:169-177): per-window min-max to [-1,1]
-            mm = ar.alloc((B, 4), torch.float32)
-            tmp = ar.alloc((B, kx, ky, kz, 1), torch.float32)
-            ops.minmax(xin, B, S, mm)
-            ops.minmax_apply(xin, mm, B, S, tmp)
-            ones = ar.alloc((B, kx, ky, kz, 1), torch.float32)
-            ones.fill_(1.0)                                  # memset-style fill (plumbing)
-            ops.axpby(tmp, 2.0, ones, -1.0, xin)             # 2*n - 1
-        net.forward(ar, xin, yout)
-        for b, (a, bb, c) in enumerate(chunk):
-            check(lib.vg_overlap_add(_p(yout[b]), kx, ky, kz, px, py, pz, a, bb, c, X, Y, Z, _p(pred), _p(cnt), stream()),
-                  'vg_overlap_add')
+        strm, ar = lanes[bi % len(lanes)]
+        with torch.cuda.stream(strm):
+            ar.reset()
+            xin = ar.alloc((B, kx, ky, kz, 1), torch.float32)
+            yout = ar.alloc((B, kx, ky, kz, 1), torch.float32)
+            for b, (a, bb, c) in enumerate(chunk):
+                xin[b, ..., 0].copy_(v[a:a + kx, bb:bb + ky, c:c + kz])
+            if process_img:            # process_imaging_otf with axis=None (main.py:169-177): per-window min-max to [-1,1]
+                mm = ar.alloc((B, 4), torch.float32)
+                tmp = ar.alloc((B, kx, ky, kz, 1), torch.float32)
+                ops.minmax(xin, B, S, mm)
+                ops.minmax_apply(xin, mm, B, S, tmp)
+                ones = ar.alloc((B, kx, ky, kz, 1), torch.float32)
+                ones.fill_(1.0)                              # memset-style fill (plumbing)
+                ops.axpby(tmp, 2.0, ones, -1.0, xin)         # 2*n - 1
+            net.forward(ar, xin, yout)
+            for b, (a, bb, c) in enumerate(chunk):
+                check(lib.vg_overlap_add(_p(yout[b]), kx, ky, kz, px, py, pz, a, bb, c, X, Y, Z, _p(pred), _p(cnt), stream()),
+                      'vg_overlap_add')
+    if len(lanes) > 1:
+        main.wait_stream(lane_b)
     out = torch.zeros(ox, oy, oz, device=dev)
     check(lib.vg_divide_crop(_p(pred), _p(cnt), X, Y, Z, sx, sy, sz, ox, oy, oz, _p(out), stream()), 'vg_divide_crop')
     mm = torch.zeros(1, 4, device=dev)
