@@ -16,7 +16,9 @@ def timeit(fn, iters=5):
     return e0.elapsed_time(e1) / iters
 
 dev = torch.device('cuda:0')
-for (S, Cc, padded) in ((128, 16, True), (128, 48, True), (64, 32, True), (128, 16, False)):
+import sys
+Ws = [int(a) for a in sys.argv[1:]] or [0]
+for (S, Cc, padded) in [(128, 16, True), (128, 48, True), (64, 32, True), (128, 16, False)] + [(w, 16, True) for w in Ws if w]:
     N = 1
     dims = (N, S, S, S)
     gshape = (N, S + 2, S + 2, S + 2, Cc) if padded else (N, S, S, S, Cc)

@@ -340,10 +340,13 @@ static dim3 anb_grid(const ANB& p, bool stats = false) {
     int bx = (S + p.vpb - 1) / p.vpb;
     static int cap_total = -1, cap_stats = -1;
     if (cap_total < 0) {
-        const char* e = getenv("VG_ANB_GRID_CAP"); cap_total = e ? atoi(e) : 2048;
-        const char* e2 = getenv("VG_ANB_STATS_CAP"); cap_stats = e2 ? atoi(e2) : 1024;
+        const char* e = getenv("VG_ANB_GRID_CAP"); cap_total = e ? atoi(e) : 2047;
+        const char* e2 = getenv("VG_ANB_STATS_CAP"); cap_stats = e2 ? atoi(e2) : 1023;
     }
-    // whole launch resident at once (8 blocks per CU): one block more than that runs alone afterwards and doubles the time
+    // whole launch resident at once (8 blocks per CU): one block more than that runs alone afterwards and doubles the time.
+    // The caps are odd on purpose: the UB voxels a thread has in flight are gridDim.x*vpb voxels apart, and with a
+    // power-of-two grid on a power-of-two volume that is a power-of-two byte stride -- every in-flight load of the chip
+    // then falls on the same HBM channels (measured at 128^3 x 16: stats 0.061 -> 0.046 ms, apply 0.053 -> 0.043 ms)
     int cap = (stats ? cap_stats : cap_total) / (p.N > 0 ? p.N : 1);
     if (cap < 1) cap = 1;
     if (bx > cap) bx = cap;
