@@ -440,7 +440,7 @@ extern "C" int vg_concat_bwd(const void* g, int N, int D, int H, int W, int Cu, 
     vg_begin();
     if (!g || !dlow || !dskip || (Cu % 8) || (Cs % 8) || Cu < 8 || Cs < 8 || ((D | H | W) & 1)) return VG_EINVAL;
     const size_t total = (size_t)N * (D / 2) * (H / 2) * (W / 2) * (Cu / 8) + (size_t)N * D * H * W * (Cs / 8);
-    int blocks = (int)((total + 255) / 256); if (blocks > 8192) blocks = 8192;
+    int blocks = (int)((total + 255) / 256); if (blocks > 8191) blocks = 8191;
     if (f32) hipLaunchKernelGGL(concat_bwd_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)g, N, D, H, W, Cu,
                                 Cs, (float*)dlow, (float*)dskip);
     else hipLaunchKernelGGL(concat_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)g, N, D, H, W, Cu,

@@ -4,7 +4,7 @@
 // soft skeleton (clDice_func.py:8-149) fwd/bwd.
 #include "vg_common.h"
 
-static inline int lblocks(int64_t n, int per = 256) { int64_t b = (n + per - 1) / per; return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b)); }
+static inline int lblocks(int64_t n, int per = 256) { int64_t b = (n + per - 1) / per; return (int)(b > 4095 ? 4095 : (b < 1 ? 1 : b)); }   // odd cap: no power-of-two grid stride (HBM channel aliasing)
 
 __device__ __forceinline__ float block_sum(float v, float* sm) {
     v = wave_sum(v);
