@@ -71,7 +71,7 @@ def side_join():
     # unconditional: with two backward lanes each lane's stream has to wait for itself (an event record + wait is cheap)
     if SIDE is not None:
         torch.cuda.current_stream().wait_stream(SIDE)
-WGRAD_SCRATCH = {}     # device -> fp32 scratch for the partial-slab weight-gradient reduction (256 MB)
+WGRAD_SCRATCH = {}     # (device, stream) -> fp32 scratch for the partial-slab weight-gradient reduction (256 MB)
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -322,9 +322,12 @@ class ConvLayer:
     def _wgrad(self, src: Src, dy: torch.Tensor):
         d = self._fwd_desc(src)
         e0 = PROF.begin() if PROF is not None else None
-        sc = WGRAD_SCRATCH.get(dy.device)
+        # one partial-slab scratch per (device, stream): launches on one stream reuse it in order, the two lanes of the
+        # engine issue weight gradients concurrently and must not share it
+        key = (dy.device, stream())
+        sc = WGRAD_SCRATCH.get(key)
         if sc is None:
-            sc = WGRAD_SCRATCH[dy.device] = torch.empty(64 << 20, dtype=torch.float32, device=dy.device)
+            sc = WGRAD_SCRATCH[key] = torch.empty(64 << 20, dtype=torch.float32, device=dy.device)
         check(lib.vg_conv3d_wgrad(C.byref(d), _p(dy), int(dy.dtype == torch.float32), self.f_idx_host, self.k ** 3,
                                   _p(self.gw), _p(self.gb), _p(sc), sc.numel() * 4, stream()), 'vg_conv3d_wgrad ' + self.name)
         if e0 is not None:
