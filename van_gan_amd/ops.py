@@ -57,20 +57,33 @@ PROF: Optional[KernelProfile] = None
 # and the data-gradient chain (dY -> dX -> IN backward -> next layer) are independent, and on the small deep layers either
 # alone leaves most CUs idle.  The side stream waits for the producer of dY; the main stream waits for the side stream
 # before arena memory is recycled (Arena.release) and before the gradients are consumed (side_join).
-SIDE: Optional[torch.cuda.Stream] = None
-_side_dirty = False
+SIDE: Optional[torch.cuda.Stream] = None      # not None: weight-gradient side streams enabled (one per issuing stream)
+_SIDE_OF = {}                                  # issuing stream handle -> its side stream
 
 
 def side_enable(device, on: bool = True):
     global SIDE
     SIDE = torch.cuda.Stream(device=device) if on else None
+    _SIDE_OF.clear()
+
+
+def _side_of_current() -> torch.cuda.Stream:
+    cur = torch.cuda.current_stream()
+    sd = _SIDE_OF.get(cur.cuda_stream)
+    if sd is None:
+        sd = _SIDE_OF[cur.cuda_stream] = torch.cuda.Stream(device=cur.device)
+    return sd
 
 
 def side_join():
-    """Main stream waits for every weight-gradient launch issued so far."""
-    # unconditional: with two backward lanes each lane's stream has to wait for itself (an event record + wait is cheap)
+    """The current stream waits for every weight-gradient launch it handed to its side stream."""
     if SIDE is not None:
-        torch.cuda.current_stream().wait_stream(SIDE)
+        cur = torch.cuda.current_stream()
+        sd = _SIDE_OF.get(cur.cuda_stream)
+        if sd is not None:
+            cur.wait_stream(sd)
+
+
 WGRAD_SCRATCH = {}     # (device, stream) -> fp32 scratch for the partial-slab weight-gradient reduction (256 MB)
 
 
@@ -310,12 +323,11 @@ class ConvLayer:
                      src.N * esz * (math.prod(self.in_dims) * self.cin + math.prod(self.out_dims) * self.cout))
 
     def wgrad(self, src: Src, dy: torch.Tensor):
-        global _side_dirty
         if SIDE is not None and PROF is None:       # the per-launch timing pass serialises (attributable kernel durations)
-            SIDE.wait_stream(torch.cuda.current_stream())       # dY (and everything before it) is ready
-            with torch.cuda.stream(SIDE):
+            sd = _side_of_current()
+            sd.wait_stream(torch.cuda.current_stream())         # dY (and everything before it) is ready
+            with torch.cuda.stream(sd):
                 self._wgrad(src, dy)
-            _side_dirty = True
         else:
             self._wgrad(src, dy)
 

@@ -68,8 +68,9 @@ class VanGan:
         if arena_bytes is None:
             arena_bytes = int(batch_size * S * 5200 * (2 if precision == 'fp32' else 1)) + (512 << 20)
         self.arena = Arena(arena_bytes, self.device)
-        ops.side_enable(self.device, os.environ.get('VG_SIDE_STREAM', '0') != '0')     # weight gradients on their own stream: opt-in,
-        # it gained 1 ms on a single-lane schedule but costs 2 ms next to the two lanes below (38.2 vs 40.1 ms/step)
+        # weight gradients go to a side stream of the stream that issues them (one per lane): within a layer they are
+        # independent of the data-gradient chain.  36.9 vs 37.6 ms/step; a single side stream shared by both lanes cost 2 ms.
+        ops.side_enable(self.device, os.environ.get('VG_SIDE_STREAM', '1') != '0')
         # forward lanes: the I->S->I chain (G_IS(real_I), G_SI(fake_S), D_S, cycle losses on cycled_I) and the S->I->S chain
         # are independent until the backward sweeps, so they run on two streams and fill each other's low-occupancy
         # 8^3/16^3 layers
