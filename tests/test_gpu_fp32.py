@@ -96,3 +96,55 @@ def test_train_step_fp32_32_b1():
 
 def test_train_step_fp32_32_b2():
     _engine_fp32((32, 32, 32), 2)
+
+
+def test_stream_schedule_does_not_change_gradients():
+    """The engine's schedule (two lanes + per-lane weight-gradient side streams, van_gan_amd/vangan.py) must only reorder
+    independent work.  Same weights and inputs with the lanes on and off: every loss and every gradient buffer has to
+    agree to fp32 reordering noise (a shared scratch buffer between lanes once showed up here as rel 0.3-1.4 on
+    single tensors)."""
+    import os
+    from van_gan_amd import VanGan
+    dev = _dev()
+    dims, B = (32, 32, 32), 2
+    P = {k: perturb(v, 40 + i) for i, (k, v) in enumerate(O.make_models(0).items())}
+    rI, rS = O.synth_volumes(B, *dims, seed=4321)
+    outs = []
+    for lanes in ('1', '0', '0'):
+        old = {k: os.environ.get(k) for k in ('VG_LANES', 'VG_SIDE_STREAM')}
+        os.environ['VG_LANES'], os.environ['VG_SIDE_STREAM'] = lanes, lanes
+        try:
+            eng = VanGan(dims, batch_size=B, n_devices=1, device='cuda:0', seed=0, layer_noise=0.0, dropout_rate=0.0,
+                         precision='fp32')
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        eng.load_weights(P)
+        res = None
+        for _ in range(3):                      # a race needs a few tries to show
+            res = eng.train_step(rI.to(dev), rS.to(dev), noise={}, drop={}, apply=False)
+        outs.append((res, eng.export_grads()))
+    (r1, g1), (r0, g0), (r0b, g0b) = outs
+
+    def worst(ga, gb):
+        # whole-network relative L2 (biases in front of an InstanceNorm have an analytically zero gradient: their
+        # per-tensor relative error is pure noise)
+        w, where = 0.0, None
+        for net in gb:
+            num = sum(float((ga[net][n].double() - gb[net][n].double()).pow(2).sum()) for n in gb[net])
+            den = sum(float(gb[net][n].double().pow(2).sum()) for n in gb[net])
+            e = (num / (den + 1e-300)) ** 0.5
+            if e > w:
+                w, where = e, net
+        return w, where
+    floor, wf = worst(g0b, g0)                  # serial vs serial: float-atomic ordering alone
+    got, wg = worst(g1, g0)
+    print('schedule test: serial-vs-serial worst network rel L2 %.2e (%s); lanes-vs-serial %.2e (%s)' % (floor, wf, got, wg))
+    for k in O.RESULT_KEYS:
+        assert abs(r1[k] - r0[k]) <= 1e-4 * abs(r0[k]) + 1e-6, k
+    # reordered float atomics alone move a network's gradient by the floor printed above; the scratch race moved single
+    # large tensors by 0.3-1.4 (whole-network > 1e-1)
+    assert got <= max(20.0 * floor, 1e-2), (got, wg, floor)
