@@ -255,6 +255,20 @@ int vg_adam_clip(float* w, const float* g, float* m, float* v, const int64_t* se
 int vg_randn_bf16(void* out, int64_t n, float std, uint64_t seed, uint64_t offset, vg_stream_t stream);
 int vg_dropout_mask(float* out, int64_t n, float rate, uint64_t seed, uint64_t offset, vg_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Training data pipeline on resident volumes (DatasetGen.process_imaging_domain / process_seg_domain /
+ * random_spatial_augmentation, dataset.py:205-251).  vol: fp32 [X][Y][Z][C]; out: fp32 [px][py][pz][C].
+ * vg_crop_augment: out = rot90_k( flip_up_down?( flip_left_right?( vol[x0:x0+px, y0:y0+py, z0:z0+pz] ))) with the
+ *   tf.image semantics the reference gets on 4-D tensors: X is a batch axis, "height" = Y, "width" = Z, i.e.
+ *   flip_left_right reverses Z, flip_up_down reverses Y, rot90 turns the (Y,Z) plane counter-clockwise k times
+ *   (k is taken modulo 4; odd k needs py == pz).  The random draws stay with the caller.
+ * vg_crop_max: out[0] = max over the crop box (the seg-domain rejection test reduce_max(arr) < 0.8, dataset.py:242).
+ * --------------------------------------------------------------------------------------------- */
+int vg_crop_augment(const float* vol, int X, int Y, int Z, int C, int x0, int y0, int z0, int px, int py, int pz,
+                    int flip_lr, int flip_ud, int rot_k, float* out, vg_stream_t stream);
+int vg_crop_max(const float* vol, int X, int Y, int Z, int C, int x0, int y0, int z0, int px, int py, int pz,
+                float* out, vg_stream_t stream);
+
 /* f32 <-> bf16 copies */
 int vg_f32_to_bf16(const float* x, void* y, int64_t n, vg_stream_t stream);
 int vg_bf16_to_f32(const void* x, float* y, int64_t n, vg_stream_t stream);

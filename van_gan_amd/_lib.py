@@ -59,6 +59,8 @@ _SIGS = {
     'vg_conv3d_plan': ([C.POINTER(ConvDesc), C.POINTER(C.c_int32)], c_int),
     'vg_pack_weights': ([c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p], c_int),
     'vg_pack_weights_multi': ([c_void_p, c_int, c_void_p], c_int),
+    'vg_crop_augment': ([c_void_p] + [c_int] * 13 + [c_void_p, c_void_p], c_int),
+    'vg_crop_max': ([c_void_p] + [c_int] * 10 + [c_void_p, c_void_p], c_int),
     'vg_packed_ktot': ([c_int, c_int, c_int], c_int),
     'vg_packed_rows': ([c_int], c_int),
     'vg_conv3d_wgrad': ([C.POINTER(ConvDesc), c_void_p, c_int, C.POINTER(c_int), c_int, c_void_p, c_void_p, c_void_p, c_i64,

@@ -554,3 +554,74 @@ extern "C" const char* vg_status_string(int code) {
 }
 extern "C" int vg_version(void) {
     vg_begin(); return 1; }
+
+// ------------------------------------------------------------------------------------------------
+// Training data pipeline on resident volumes (dataset.py:205-251): crop + flips + rot90 as ONE gather.
+// out[a][i][j][c] (a along X, i along Y = "height", j along Z = "width"):
+//   rot90 k (counter-clockwise, tf.image.rot90): k=1: r[i][j] = f[j][P-1-i]; k=2: r[i][j] = f[P-1-i][Q-1-j];
+//   k=3: r[i][j] = f[P-1-j][i]   (P x Q = rows x cols of f; odd k needs P == Q)
+//   f = flip_up_down?(flip_left_right?(crop)): f[i][j] = crop[ud ? P-1-i : i][lr ? Q-1-j : j]
+// ------------------------------------------------------------------------------------------------
+__global__ void crop_augment_kernel(const float* __restrict__ vol, int Y, int Z, int C, int x0, int y0, int z0,
+                                    int px, int py, int pz, int lr, int ud, int k, float* __restrict__ out) {
+    const int64_t total = (int64_t)px * py * pz * C;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C); int64_t r = e / C;
+        const int j = (int)(r % pz); r /= pz;
+        const int i = (int)(r % py); const int a = (int)(r / py);
+        int fi, fj;                                    // position in f (after the flips, before the rotation)
+        if (k == 0) { fi = i; fj = j; }
+        else if (k == 1) { fi = j; fj = pz - 1 - i; }
+        else if (k == 2) { fi = py - 1 - i; fj = pz - 1 - j; }
+        else { fi = py - 1 - j; fj = i; }
+        const int ci = ud ? py - 1 - fi : fi, cj = lr ? pz - 1 - fj : fj;
+        out[e] = vol[(((int64_t)(x0 + a) * Y + (y0 + ci)) * Z + (z0 + cj)) * C + c];
+    }
+}
+extern "C" int vg_crop_augment(const float* vol, int X, int Y, int Z, int C, int x0, int y0, int z0, int px, int py, int pz,
+                               int flip_lr, int flip_ud, int rot_k, float* out, vg_stream_t stream) {
+    vg_begin();
+    if (!vol || !out || C < 1 || px < 1 || py < 1 || pz < 1) return VG_EINVAL;
+    if (x0 < 0 || y0 < 0 || z0 < 0 || x0 + px > X || y0 + py > Y || z0 + pz > Z) return VG_EINVAL;
+    const int k = ((rot_k % 4) + 4) % 4;
+    if ((k & 1) && py != pz) return VG_EINVAL;
+    const int64_t total = (int64_t)px * py * pz * C;
+    int64_t b = (total + 255) / 256; if (b > 8191) b = 8191;
+    hipLaunchKernelGGL(crop_augment_kernel, dim3((int)b), dim3(256), 0, (hipStream_t)stream, vol, Y, Z, C, x0, y0, z0, px, py, pz,
+                       flip_lr ? 1 : 0, flip_ud ? 1 : 0, k, out);
+    return vg_check_launch();
+}
+__global__ void crop_max_kernel(const float* __restrict__ vol, int Y, int Z, int C, int x0, int y0, int z0, int px, int py, int pz,
+                                float* out) {
+    __shared__ float red[4];
+    const int64_t total = (int64_t)px * py * pz * C;
+    float m = -INFINITY;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C); int64_t r = e / C;
+        const int j = (int)(r % pz); r /= pz;
+        const int i = (int)(r % py); const int a = (int)(r / py);
+        m = fmaxf(m, vol[(((int64_t)(x0 + a) * Y + (y0 + i)) * Z + (z0 + j)) * C + c]);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        // float max through the integer atomics (values may be negative): order-preserving key
+        int* io = (int*)out;
+        int old = *io, assumed;
+        do { assumed = old; if (__int_as_float(assumed) >= m) break; old = atomicCAS(io, assumed, __float_as_int(m)); } while (old != assumed);
+    }
+}
+extern "C" int vg_crop_max(const float* vol, int X, int Y, int Z, int C, int x0, int y0, int z0, int px, int py, int pz,
+                           float* out, vg_stream_t stream) {
+    vg_begin();
+    if (!vol || !out || C < 1 || px < 1 || py < 1 || pz < 1) return VG_EINVAL;
+    if (x0 < 0 || y0 < 0 || z0 < 0 || x0 + px > X || y0 + py > Y || z0 + pz > Z) return VG_EINVAL;
+    if (hipMemsetD32Async((hipDeviceptr_t)out, (int)0xFF800000u, 1, (hipStream_t)stream) != hipSuccess) return VG_ELAUNCH;   // -inf
+    const int64_t total = (int64_t)px * py * pz * C;
+    int64_t b = (total + 1023) / 1024; if (b > 1023) b = 1023; if (b < 1) b = 1;
+    hipLaunchKernelGGL(crop_max_kernel, dim3((int)b), dim3(256), 0, (hipStream_t)stream, vol, Y, Z, C, x0, y0, z0, px, py, pz, out);
+    return vg_check_launch();
+}

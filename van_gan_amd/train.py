@@ -1,0 +1,96 @@
+"""Epoch loop around VanGan.train_step: host mirror of the reference's `train()` (vangan.py:510-551), the epoch loop of
+main.py:214-236 and the scalar part of GanMonitor (custom_callback.py:326-424, :426-445).  SURVEY section 8 row (f)3.
+
+Nothing here touches the device: the monitor writes two host scalars (`VanGan.lr`, `VanGan.layer_noise`) that the step
+reads when it enqueues Adam and the discriminator noise, the loop pulls batches from `data.DataPipeline` (which keeps the
+volumes and produces the batches in HBM)."""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+from . import data
+
+
+class GanMonitor:
+    """Schedules only (plots / TensorBoard of the reference's GanMonitor are out of scope)."""
+
+    def __init__(self, EPOCHS: int, INITIATE_LR_DECAY: int, INITIAL_LR: float, train_steps: int, NO_NOISE: int,
+                 init_noise: Optional[float] = None):
+        self.EPOCHS, self.INITIATE_LR_DECAY, self.INITIAL_LR = EPOCHS, INITIATE_LR_DECAY, INITIAL_LR
+        self.train_steps, self.NO_NOISE = train_steps, NO_NOISE
+        self.init_noise = init_noise
+        self.resume_epoch: Optional[int] = None
+
+    def set_learning_rate(self, model, epoch: int, step_in_epoch: int = 0):
+        """custom_callback.py:326-397.  The reference installs a PolynomialDecay object once and lets the optimizer's
+        iteration counter drive it; here the same value is written before every step."""
+        if getattr(model, 'checkpoint_loaded', False) and epoch > self.INITIATE_LR_DECAY:
+            model.checkpoint_loaded = False
+            self.resume_epoch = epoch
+        if self.resume_epoch is not None:
+            start = self.INITIAL_LR / (self.EPOCHS - self.INITIATE_LR_DECAY) * (self.EPOCHS - self.resume_epoch)
+            decay_steps = (self.EPOCHS - self.INITIATE_LR_DECAY - self.resume_epoch) * self.train_steps
+            if decay_steps <= 0:
+                raise ValueError('reference schedule undefined: decay_steps <= 0 (resumed past EPOCHS - INITIATE_LR_DECAY)')
+            step = min((epoch - self.resume_epoch) * self.train_steps + step_in_epoch, decay_steps)
+            model.lr = start * (1.0 - step / decay_steps)
+        else:
+            model.lr = data.learning_rate(self.INITIAL_LR, epoch, step_in_epoch, self.EPOCHS, self.INITIATE_LR_DECAY,
+                                          self.train_steps)
+        return model.lr
+
+    def updateDiscriminatorNoise(self, model, epoch: int):
+        if self.init_noise is None:
+            self.init_noise = model.layer_noise                    # custom_callback.py:441 passes model.layer_noise
+        model.layer_noise = data.discriminator_noise(self.init_noise, epoch, self.NO_NOISE)
+        return model.layer_noise
+
+    def on_epoch_start(self, model, epoch: int):
+        """custom_callback.py:426-445."""
+        self.set_learning_rate(model, epoch, 0)
+        self.updateDiscriminatorNoise(model, epoch)
+
+
+def train(ds, gan, epoch: int, steps: Optional[int] = None, training: bool = True,
+          monitor: Optional[GanMonitor] = None) -> Dict[str, List[float]]:
+    """vangan.py:510-551: `steps` batches through distributed_train_step / distributed_test_step, results appended per
+    key.  `ds` is an iterable of (real_I, real_S) or an object with next_batch()."""
+    results: Dict[str, List[float]] = {}
+    it = iter(ds) if hasattr(ds, '__iter__') else None
+    cntr = 0
+    while steps is None or cntr < steps:
+        if it is not None:
+            try:
+                x, y = next(it)
+            except StopIteration:
+                break
+        else:
+            x, y = ds.next_batch()
+        if training:
+            if monitor is not None:
+                monitor.set_learning_rate(gan, epoch, cntr)
+            result = gan.distributed_train_step(x, y)
+        else:
+            result = gan.distributed_test_step(x, y)
+        cntr += 1
+        for k, v in result.items():
+            results.setdefault(k, []).append(v)
+    return results
+
+
+def fit(gan, train_ds, monitor: GanMonitor, val_ds=None, val_steps: int = 0, start_epoch: int = 0,
+        checkpoint_period: int = 2, save: bool = True):
+    """main.py:214-236 without the plots: per epoch the monitor's schedules, train_steps training steps, val_steps
+    validation steps, a checkpoint when epoch % PERIOD == 1 or at the last epoch."""
+    history = []
+    for epoch in range(start_epoch, monitor.EPOCHS):
+        gan.current_epoch = epoch
+        monitor.on_epoch_start(gan, epoch)
+        tr = train(train_ds, gan, epoch, monitor.train_steps, True, monitor)
+        va = train(val_ds, gan, epoch, val_steps, False) if val_ds is not None and val_steps else {}
+        if save and (epoch % checkpoint_period == 1 or epoch == monitor.EPOCHS - 1):
+            gan.save_checkpoint(epoch=epoch)
+        history.append({'epoch': epoch, 'lr': gan.lr, 'noise': gan.layer_noise,
+                        'train': {k: sum(v) / len(v) for k, v in tr.items()},
+                        'val': {k: sum(v) / len(v) for k, v in va.items()}})
+    return history

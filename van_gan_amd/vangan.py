@@ -51,6 +51,7 @@ class VanGan:
         self.dropout_rate = dropout_rate
         self.skel_iters = skel_iters
         self.current_epoch = 0
+        self.checkpoint_loaded = False            # vangan.py:77 (set by the caller after load_checkpoint; read by GanMonitor)
         self.pg = process_group
         self.seed = seed
         self.rng_offset = 0
