@@ -80,6 +80,12 @@ CONV_CASES = [
     # wide layers big enough for the 32x32x16-MFMA flavour (conv32_kernel): 128-wide panel forward, 64-wide data gradient
     (3, 64, 128, 1, 'reflect', (16, 16, 32)),
     (4, 64, 128, 2, 'reflect', (32, 32, 32)),
+    # strided layers whose dY needs several channel chunks: class-parallel data gradient (one launch, workgroup -> (class,
+    # tile)); classes of 1/2/4/8 taps (k3), ragged class extents (odd dims), the 32x32x16 flavour (D.down1-like)
+    (3, 64, 128, 2, 'reflect', (8, 8, 16)),
+    (3, 128, 256, 2, 'reflect', (4, 8, 8)),
+    (3, 16, 128, 2, 'reflect', (5, 7, 9)),
+    (4, 128, 256, 2, 'reflect', (16, 16, 16)),
 ]
 
 

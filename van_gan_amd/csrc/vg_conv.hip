@@ -35,6 +35,7 @@ struct ConvOut {
 // multi-class kernel variants read
 struct ConvCls {
     int ncls;
+    int par;                        // 1: class-parallel launch (blockIdx.x = walker * ncls + class; any number of channel chunks)
     int tap0[9];                    // taps of class c: [tap0[c], tap0[c+1])
     const void* wp[8];              // packed weights of class c, ktot[c] elements per row
     int ktot[8], woff[8];           // ... and the byte offset of its panel inside the LDS weight area
@@ -261,7 +262,10 @@ __device__ __forceinline__ void dma_transform(const GatherIn& g, char* hb, const
 // sample.  Per workgroup ONCE: tap offsets, the (halo voxel, channel group) unit table, the weight panel (if it fits in
 // LDS); per tile: stage halo (batched global loads), MFMA loop, epilogue; InstanceNorm statistics are carried in
 // registers across tiles and flushed once.
-template <typename T, int BN, int MSUB, bool NOISE, bool WL, bool DMA, bool MC>
+// MC: 0 = one class (plain launch); 1 = all output-parity classes looped over one staged halo tile (single channel chunk);
+// 2 = class-parallel: the workgroup serves the ONE class blockIdx.x % ncls (own taps / weights / output sub-lattice) and
+// walks the tiles with the remaining part of blockIdx.x -- the launch carries ncls times the workgroups of a per-class launch
+template <typename T, int BN, int MSUB, bool NOISE, bool WL, bool DMA, int MC>
 __global__ __launch_bounds__(256, ((BN / 16) * MSUB >= 8 ? 2 : VG_CONV_WAVES)) void conv_kernel(const GatherIn g, const ConvOut p, const ConvCls q) {
     static_assert(!(MC && DMA), "fused classes use the synchronous staging path");
     constexpr bool F32 = sizeof(T) == 4;
@@ -273,6 +277,19 @@ __global__ __launch_bounds__(256, ((BN / 16) * MSUB >= 8 ? 2 : VG_CONV_WAVES)) v
     const int wave_n = wave % WN, wave_m = wave / WN;
     const int n = blockIdx.z, ntile = blockIdx.y;
     const int TWm = (1 << g.twl) - 1, THm = (1 << g.thl) - 1;
+    int bx = blockIdx.x, gx = gridDim.x, t0 = 0, nt = g.ntaps;
+    int Ktot = p.Ktot, kc_pad = p.kc_pad, WRS = p.WRS;
+    const void* wsrc = p.wp;
+    int c_od = p.ood, c_oh = p.ooh, c_ow = p.oow, c_OD = p.OD, c_OH = p.OH, c_OW = p.OW;
+    if constexpr (MC == 2) {
+        const int cls = __builtin_amdgcn_readfirstlane(bx % q.ncls);
+        bx /= q.ncls; gx /= q.ncls;
+        t0 = q.tap0[cls]; nt = q.tap0[cls + 1] - t0;
+        Ktot = q.ktot[cls]; kc_pad = Ktot / p.nchunks; WRS = Ktot * (int)sizeof(T) + 16;
+        wsrc = q.wp[cls];
+        c_od = q.off[cls][0]; c_oh = q.off[cls][1]; c_ow = q.off[cls][2];
+        c_OD = q.it[cls][0]; c_OH = q.it[cls][1]; c_OW = q.it[cls][2];
+    }
 
     char* halo = smem;
     const int hbytes = g.planar ? (g.CK >> 3) * g.PSB : g.HD * g.DS;
@@ -289,35 +306,35 @@ __global__ __launch_bounds__(256, ((BN / 16) * MSUB >= 8 ? 2 : VG_CONV_WAVES)) v
     int* rtab = utab + 2 * ncols;
     int* cq = utab; int* tcolb = utab + SU;          // DMA: static column table, tcol[2 tiles][2 sources][SU]
     const int gpc = g.CK >> 3;
-    const int ngroups = g.ntaps * gpc;
-    const int ksteps = MC ? q.ks0[q.ncls] : (ngroups + 3) >> 2;      // MC: K-steps of all classes, each padded to whole steps
+    const int ngroups = nt * gpc;
+    const int ksteps = MC == 1 ? q.ks0[q.ncls] : (ngroups + 3) >> 2;      // MC: K-steps of all classes, each padded to whole steps
     int* koff = utab + nunits;                       // byte offset of the B fragment of (K-step, lane>>4) inside the halo tile
     char* wlds = (char*)(koff + ksteps * 4);
     wlds = (char*)(((size_t)wlds + 15) & ~(size_t)15);
 
-    if (tid < g.ntaps)
-        tapoff[tid] = (g.td[tid] - g.tmin_d) * g.DS + ((g.th[tid] - g.tmin_h) * g.HWp + halo_pos_w(g, g.tw[tid] - g.tmin_w)) * g.VS;
+    if (tid < (MC == 1 ? g.ntaps : nt))
+        tapoff[tid] = (g.td[t0 + tid] - g.tmin_d) * g.DS + ((g.th[t0 + tid] - g.tmin_h) * g.HWp + halo_pos_w(g, g.tw[t0 + tid] - g.tmin_w)) * g.VS;
     if (tid < BN * 2) stat[tid] = 0.f;
     if constexpr (DMA) dma_build_cq(g, cq, tid); else build_column_table(g, utab, tid);
     for (int i = tid; i < ksteps * 4; i += 256) {
         int tp, cgq;
-        if constexpr (MC) {
+        if constexpr (MC == 1) {
             int cls = 0; while (cls + 1 < q.ncls && (i >> 2) >= q.ks0[cls + 1]) ++cls;
             const int ng = (q.tap0[cls + 1] - q.tap0[cls]) * gpc;
             int G = i - q.ks0[cls] * 4; if (G >= ng) G = ng - 1;                // padded K: weights are zero there
             tp = q.tap0[cls] + G / gpc; cgq = G % gpc;
         } else {
             int G = i; if (G >= ngroups) G = ngroups - 1;                       // padded K: weights are zero there
-            tp = G / gpc; cgq = G - tp * gpc;
+            tp = G / gpc; cgq = G - tp * gpc; tp += t0;
         }
         koff[i] = (g.td[tp] - g.tmin_d) * g.DS + ((g.th[tp] - g.tmin_h) * g.HWp + halo_pos_w(g, g.tw[tp] - g.tmin_w)) * g.VS + cgq * g.CS;
     }
     if (WL) {               // weight panel(s) -> LDS, 16 B per thread per step
-        const int npan = MC ? q.ncls : 1;
+        const int npan = MC == 1 ? q.ncls : 1;
         for (int cls = 0; cls < npan; ++cls) {
-            const int ktot = MC ? q.ktot[cls] : p.Ktot;
-            const char* src = (const char*)(MC ? q.wp[cls] : p.wp);
-            char* dstp = wlds + (MC ? q.woff[cls] : 0);
+            const int ktot = MC == 1 ? q.ktot[cls] : Ktot;
+            const char* src = (const char*)(MC == 1 ? q.wp[cls] : wsrc);
+            char* dstp = wlds + (MC == 1 ? q.woff[cls] : 0);
             const int per_row = (ktot * (int)sizeof(T)) >> 4, wrs = ktot * (int)sizeof(T) + 16;
             // four loads in flight per thread: a load -> store loop with an unknown trip count is not pipelined by the
             // compiler and cost one L2 round trip per 16 bytes (several microseconds of every launch's prologue)
@@ -348,8 +365,8 @@ __global__ __launch_bounds__(256, ((BN / 16) * MSUB >= 8 ? 2 : VG_CONV_WAVES)) v
     }
     // weight fragment source: LDS panel or global (L2) rows -- kept as two address-space-typed pointers (a pointer
     // selected between the two becomes generic and every fragment fetch a flat_load)
-    const lds_ptr<T> wrow_l = (lds_ptr<T>)(wlds + (size_t)(wave_n * 16 + (lane & 15)) * p.WRS) + (F32 ? 1 : 8) * (lane >> 4);
-    const glb_ptr<T> wrow_g = (glb_ptr<T>)p.wp + (size_t)(ntile * BN + wave_n * 16 + (lane & 15)) * p.Ktot + (F32 ? 1 : 8) * (lane >> 4);
+    const lds_ptr<T> wrow_l = (lds_ptr<T>)(wlds + (size_t)(wave_n * 16 + (lane & 15)) * WRS) + (F32 ? 1 : 8) * (lane >> 4);
+    const glb_ptr<T> wrow_g = (glb_ptr<T>)wsrc + (size_t)(ntile * BN + wave_n * 16 + (lane & 15)) * Ktot + (F32 ? 1 : 8) * (lane >> 4);
     float s1[4], s2[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
@@ -375,8 +392,8 @@ __global__ __launch_bounds__(256, ((BN / 16) * MSUB >= 8 ? 2 : VG_CONV_WAVES)) v
     const bool vec_epi = (p.Cout & 3) == 0 && !(p.tanh_out && p.accumulate);   // every lane owns 4 whole channels: vector loads/stores
     if (p.nchunks == 1) stage_scale_shift(g, scs, n, 0, tid);
     if constexpr (!DMA) {
-        if ((int)blockIdx.x < g.tiles_d * g.tiles_h * g.tiles_w) {
-            int t = blockIdx.x;
+        if (bx < g.tiles_d * g.tiles_h * g.tiles_w) {
+            int t = bx;
             const int tw_i = t % g.tiles_w; t /= g.tiles_w;
             const int th_i = t % g.tiles_h;
             stage_resolve_axes(g, rtab, th_i << g.thl, tw_i << g.twl, tid);
@@ -395,8 +412,8 @@ __global__ __launch_bounds__(256, ((BN / 16) * MSUB >= 8 ? 2 : VG_CONV_WAVES)) v
     };
     if constexpr (DMA) {
         // prologue: tables and copies of the first stage
-        if ((int)blockIdx.x < tiles_per_n) {
-            int od0, oh0, ow0; tile_origin(blockIdx.x, od0, oh0, ow0);
+        if (bx < tiles_per_n) {
+            int od0, oh0, ow0; tile_origin(bx, od0, oh0, ow0);
             dma_build_tcol(g, cq, tcolb, oh0, ow0, tid);
             if (p.nchunks > 1) stage_scale_shift(g, scs, n, 0, tid);
             __syncthreads();
@@ -406,10 +423,10 @@ __global__ __launch_bounds__(256, ((BN / 16) * MSUB >= 8 ? 2 : VG_CONV_WAVES)) v
     // tile coordinates advance incrementally by the grid stride (decomposed once): the per-tile divisions by run-time tile
     // counts were ~300 scalar instructions of the ~500-instruction empty tile iteration
     int gs_w, gs_h, gs_d;
-    { int t = gridDim.x; gs_w = t % g.tiles_w; t /= g.tiles_w; gs_h = t % g.tiles_h; gs_d = t / g.tiles_h; }
+    { int t = gx; gs_w = t % g.tiles_w; t /= g.tiles_w; gs_h = t % g.tiles_h; gs_d = t / g.tiles_h; }
     int ti_w, ti_h, ti_d;
-    { int t = blockIdx.x; ti_w = t % g.tiles_w; t /= g.tiles_w; ti_h = t % g.tiles_h; ti_d = t / g.tiles_h; }
-    for (int tile = blockIdx.x; tile < tiles_per_n; tile += gridDim.x) {
+    { int t = bx; ti_w = t % g.tiles_w; t /= g.tiles_w; ti_h = t % g.tiles_h; ti_d = t / g.tiles_h; }
+    for (int tile = bx; tile < tiles_per_n; tile += gx) {
         ++it;
         VG_STAMP(0);
         const int od0 = ti_d << g.tdl, oh0 = ti_h << g.thl, ow0 = ti_w << g.twl;
@@ -419,12 +436,12 @@ __global__ __launch_bounds__(256, ((BN / 16) * MSUB >= 8 ? 2 : VG_CONV_WAVES)) v
         ti_d += gs_d;
         const int nx_d0 = ti_d << g.tdl, nx_h0 = ti_h << g.thl, nx_w0 = ti_w << g.twl;
         f32x4 acc[MW];
-        if constexpr (MC) {
+        if constexpr (MC == 1) {
             // fused output-parity classes: the dY halo tile is staged once; every class runs its own taps / weights /
             // accumulators over it and writes its own output sub-lattice
             __syncthreads();                       // previous readers of the halo tile are done; this tile's axis tables visible
             if (!(g.dbg & 1)) stage_halo_tile<T, NOISE, (NOISE ? 4 : 6)>(g, halo, scs, utab, rtab + (it & 1) * RTN, n, od0, 0, tid);
-            if (tile + (int)gridDim.x < tiles_per_n) {
+            if (tile + gx < tiles_per_n) {
                 stage_resolve_axes(g, rtab + ((it + 1) & 1) * RTN, nx_h0, nx_w0, tid);
             }
             VG_STAMP(1);
@@ -445,8 +462,8 @@ __global__ __launch_bounds__(256, ((BN / 16) * MSUB >= 8 ? 2 : VG_CONV_WAVES)) v
                     }
                 }
                 if (!(g.dbg & 8)) {
-                    const int c_od = q.off[cls][0], c_oh = q.off[cls][1], c_ow = q.off[cls][2];
-                    const int c_OD = q.it[cls][0], c_OH = q.it[cls][1], c_OW = q.it[cls][2];
+                    c_od = q.off[cls][0]; c_oh = q.off[cls][1]; c_ow = q.off[cls][2];
+                    c_OD = q.it[cls][0]; c_OH = q.it[cls][1]; c_OW = q.it[cls][2];
 #include "vg_conv_epilogue.inc"
                 }
             }
@@ -464,7 +481,7 @@ __global__ __launch_bounds__(256, ((BN / 16) * MSUB >= 8 ? 2 : VG_CONV_WAVES)) v
                 __syncthreads();                                         // ... everyone's; previous stage fully consumed
                 // identity of the next stage; its tables / scale-shift go to the other buffers while this stage is transformed
                 const bool next_same = chunk + 1 < p.nchunks;
-                const int ntile2 = next_same ? tile : tile + (int)gridDim.x;
+                const int ntile2 = next_same ? tile : tile + gx;
                 const bool has_next = ntile2 < tiles_per_n;
                 int nd0 = od0, nh0 = oh0, nw0 = ow0;
                 if (has_next && !next_same) { nd0 = nx_d0; nh0 = nx_h0; nw0 = nx_w0; dma_build_tcol(g, cq, tcolb + ((it + 1) & 1) * 2 * SU, nh0, nw0, tid); }
@@ -480,21 +497,20 @@ __global__ __launch_bounds__(256, ((BN / 16) * MSUB >= 8 ? 2 : VG_CONV_WAVES)) v
                 __syncthreads();                       // previous readers of the halo tile are done; this tile's axis tables visible
                 if (p.nchunks > 1) { stage_scale_shift(g, scs, n, chunk, tid); __syncthreads(); }
                 if (!(g.dbg & 1)) stage_halo_tile<T, NOISE, (NOISE ? 4 : 6)>(g, halo, scs, utab, rtab + (it & 1) * RTN, n, od0, chunk, tid);
-                if (chunk == 0 && tile + (int)gridDim.x < tiles_per_n) {       // axis tables of the next tile, other buffer
+                if (chunk == 0 && tile + gx < tiles_per_n) {       // axis tables of the next tile, other buffer
                     stage_resolve_axes(g, rtab + ((it + 1) & 1) * RTN, nx_h0, nx_w0, tid);
                 }
                 if (chunk == 0) VG_STAMP(1);
                 __syncthreads();
                 if (chunk == 0) VG_STAMP(2);
             }
-            const size_t kbase = (size_t)chunk * p.kc_pad;
+            const size_t kbase = (size_t)chunk * kc_pad;
             if (g.dbg & 4) continue;
-            if constexpr (WL) conv_mfma_chunk<T, MW>(acc, wrow_l + kbase, hb, rowbase, tapoff, koff, ksteps, g.ntaps, g.CK, g.CS, lane);
-            else conv_mfma_chunk<T, MW>(acc, wrow_g + kbase, hb, rowbase, tapoff, koff, ksteps, g.ntaps, g.CK, g.CS, lane);
+            if constexpr (WL) conv_mfma_chunk<T, MW>(acc, wrow_l + kbase, hb, rowbase, tapoff, koff, ksteps, nt, g.CK, g.CS, lane);
+            else conv_mfma_chunk<T, MW>(acc, wrow_g + kbase, hb, rowbase, tapoff, koff, ksteps, nt, g.CK, g.CS, lane);
         }
         VG_STAMP(3);
         if (!(g.dbg & 8)) {
-            const int c_od = p.ood, c_oh = p.ooh, c_ow = p.oow, c_OD = p.OD, c_OH = p.OH, c_OW = p.OW;
 #include "vg_conv_epilogue.inc"
         }
         }
@@ -532,8 +548,9 @@ __global__ __launch_bounds__(256, ((BN / 16) * MSUB >= 8 ? 2 : VG_CONV_WAVES)) v
 // ------------------------------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-template <int BN, int MSUB, bool NOISE>
-__global__ __launch_bounds__(256, 2) void conv32_kernel(const GatherIn g, const ConvOut p) {
+// CP: class-parallel launch of the output-parity classes of a strided data gradient (see conv_kernel, MC == 2)
+template <int BN, int MSUB, bool NOISE, bool CP>
+__global__ __launch_bounds__(256, 2) void conv32_kernel(const GatherIn g, const ConvOut p, const ConvCls q) {
     typedef bf16_t T;
     constexpr int WN = BN / 32, WM = 4 / WN;            // waves along the channel panel / along the voxels
     constexpr int NSUB = (64 * MSUB) / 32;              // 32-voxel sub-tiles per tile
@@ -545,6 +562,19 @@ __global__ __launch_bounds__(256, 2) void conv32_kernel(const GatherIn g, const 
     const int n = blockIdx.z, ntile = blockIdx.y;
     const int TWm = (1 << g.twl) - 1, THm = (1 << g.thl) - 1;
     const int lv = lane & 31, lk = lane >> 5;
+    int bx = blockIdx.x, gx = gridDim.x, t0 = 0, nt = g.ntaps;
+    int Ktot = p.Ktot, kc_pad = p.kc_pad;
+    const void* wsrc = p.wp;
+    int c_od = p.ood, c_oh = p.ooh, c_ow = p.oow, c_OD = p.OD, c_OH = p.OH, c_OW = p.OW;
+    if constexpr (CP) {
+        const int cls = __builtin_amdgcn_readfirstlane(bx % q.ncls);
+        bx /= q.ncls; gx /= q.ncls;
+        t0 = q.tap0[cls]; nt = q.tap0[cls + 1] - t0;
+        Ktot = q.ktot[cls]; kc_pad = Ktot / p.nchunks;
+        wsrc = q.wp[cls];
+        c_od = q.off[cls][0]; c_oh = q.off[cls][1]; c_ow = q.off[cls][2];
+        c_OD = q.it[cls][0]; c_OH = q.it[cls][1]; c_OW = q.it[cls][2];
+    }
 
     char* halo = smem;
     const int hbytes = g.planar ? (g.CK >> 3) * g.PSB : g.HD * g.DS;
@@ -556,16 +586,16 @@ __global__ __launch_bounds__(256, 2) void conv32_kernel(const GatherIn g, const 
     const int RTN = 3 * (g.HH + g.HW);
     int* rtab = utab + 2 * ncols;
     const int c16 = g.CK >> 4;                           // 16-channel K-steps per tap
-    const int ksteps = g.ntaps * c16;
+    const int ksteps = nt * c16;
     int* koff = rtab + 2 * RTN;                          // [K-step][k-group 0/1]: byte offset of the B fragment in the halo image
 
-    if (tid < g.ntaps)
-        tapoff[tid] = (g.td[tid] - g.tmin_d) * g.DS + ((g.th[tid] - g.tmin_h) * g.HWp + halo_pos_w(g, g.tw[tid] - g.tmin_w)) * g.VS;
+    if (tid < nt)
+        tapoff[tid] = (g.td[t0 + tid] - g.tmin_d) * g.DS + ((g.th[t0 + tid] - g.tmin_h) * g.HWp + halo_pos_w(g, g.tw[t0 + tid] - g.tmin_w)) * g.VS;
     if (tid < BN * 2) stat[tid] = 0.f;
     build_column_table(g, utab, tid);
     for (int i = tid; i < ksteps * 2; i += 256) {
         const int st = i >> 1, kg = i & 1;
-        const int tp = st / c16, cgq = (st - tp * c16) * 2 + kg;
+        const int tq = st / c16, cgq = (st - tq * c16) * 2 + kg, tp = t0 + tq;
         koff[i] = (g.td[tp] - g.tmin_d) * g.DS + ((g.th[tp] - g.tmin_h) * g.HWp + halo_pos_w(g, g.tw[tp] - g.tmin_w)) * g.VS + cgq * g.CS;
     }
     int rowbase[MW], ooff[MW], dhw[MW];
@@ -578,14 +608,14 @@ __global__ __launch_bounds__(256, 2) void conv32_kernel(const GatherIn g, const 
         ooff[i] = ((d * p.ostr * p.BH + h * p.ostr) * p.BW + w * p.ostr) * p.Cout + co_lane;
         dhw[i] = d | (h << 10) | (w << 20);
     }
-    const glb_ptr<T> wrow = (glb_ptr<T>)p.wp + (size_t)(ntile * BN + wave_n * 32 + lv) * p.Ktot + 8 * lk;
+    const glb_ptr<T> wrow = (glb_ptr<T>)wsrc + (size_t)(ntile * BN + wave_n * 32 + lv) * Ktot + 8 * lk;
     float s1[16], s2[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
     if (p.nchunks == 1) stage_scale_shift(g, scs, n, 0, tid);
     const int tiles_per_n = g.tiles_d * g.tiles_h * g.tiles_w;
-    if ((int)blockIdx.x < tiles_per_n) {
-        int t = blockIdx.x;
+    if (bx < tiles_per_n) {
+        int t = bx;
         const int tw_i = t % g.tiles_w; t /= g.tiles_w;
         const int th_i = t % g.tiles_h;
         stage_resolve_axes(g, rtab, th_i << g.thl, tw_i << g.twl, tid);
@@ -593,13 +623,13 @@ __global__ __launch_bounds__(256, 2) void conv32_kernel(const GatherIn g, const 
     __syncthreads();
 
     int gs_w, gs_h, gs_d;
-    { int t = gridDim.x; gs_w = t % g.tiles_w; t /= g.tiles_w; gs_h = t % g.tiles_h; gs_d = t / g.tiles_h; }
+    { int t = gx; gs_w = t % g.tiles_w; t /= g.tiles_w; gs_h = t % g.tiles_h; gs_d = t / g.tiles_h; }
     int ti_w, ti_h, ti_d;
-    { int t = blockIdx.x; ti_w = t % g.tiles_w; t /= g.tiles_w; ti_h = t % g.tiles_h; ti_d = t / g.tiles_h; }
+    { int t = bx; ti_w = t % g.tiles_w; t /= g.tiles_w; ti_h = t % g.tiles_h; ti_d = t / g.tiles_h; }
     typedef const __attribute__((address_space(1))) bf16x8 glb_frag;
     const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
     int it = -1;
-    for (int tile = blockIdx.x; tile < tiles_per_n; tile += gridDim.x) {
+    for (int tile = bx; tile < tiles_per_n; tile += gx) {
         ++it;
         const int od0 = ti_d << g.tdl, oh0 = ti_h << g.thl, ow0 = ti_w << g.twl;
         ti_w += gs_w; if (ti_w >= g.tiles_w) { ti_w -= g.tiles_w; ++ti_h; }
@@ -615,11 +645,11 @@ __global__ __launch_bounds__(256, 2) void conv32_kernel(const GatherIn g, const 
             __syncthreads();                       // previous readers of the halo tile are done; this tile's axis tables visible
             if (p.nchunks > 1) { stage_scale_shift(g, scs, n, chunk, tid); __syncthreads(); }
             stage_halo_tile<T, NOISE, 4>(g, halo, scs, utab, rtab + (it & 1) * RTN, n, od0, chunk, tid);
-            if (chunk == 0 && tile + (int)gridDim.x < tiles_per_n)
+            if (chunk == 0 && tile + gx < tiles_per_n)
                 stage_resolve_axes(g, rtab + ((it + 1) & 1) * RTN, ti_h << g.thl, ti_w << g.twl, tid);
             __syncthreads();
             // ---- K loop: ring of RD weight fragments (L2 latency), halo fragments ping-pong ----
-            const glb_ptr<T> w = wrow + (size_t)chunk * p.kc_pad;
+            const glb_ptr<T> w = wrow + (size_t)chunk * kc_pad;
             const int last = ksteps - 1;
             constexpr int RD = 8;                  // weight-fragment ring depth: one workgroup per CU has no other wave to hide L2 latency
             bf16x8 a[RD];
@@ -649,8 +679,8 @@ __global__ __launch_bounds__(256, 2) void conv32_kernel(const GatherIn g, const 
             }
         }
         // ---- epilogue: four groups of 4 consecutive channels per lane and sub-tile ----
-        const size_t tbase = (((size_t)(n * p.BD + od0 * p.ostr + p.ood) * p.BH + oh0 * p.ostr + p.ooh) * p.BW + ow0 * p.ostr + p.oow) * p.Cout;
-        const int remd = p.OD - od0, remh = p.OH - oh0, remw = p.OW - ow0;
+        const size_t tbase = (((size_t)(n * p.BD + od0 * p.ostr + c_od) * p.BH + oh0 * p.ostr + c_oh) * p.BW + ow0 * p.ostr + c_ow) * p.Cout;
+        const int remd = c_OD - od0, remh = c_OH - oh0, remw = c_OW - ow0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int co = co_lane + 8 * j;
@@ -742,8 +772,27 @@ static int fill_conv(const vg_conv_desc* d, GatherIn& g, ConvOut& k, ConvCls& q,
     const int gpc_ = d->CK >> 3;
     q.ncls = d->nclass > 1 ? d->nclass : 1;
     if (q.ncls > 8) return VG_EINVAL;
+    // several channel chunks (or fp32 / noise sources): the classes cannot share one staged halo tile and its accumulators;
+    // they run class-parallel instead -- one launch, workgroup -> (class, tile walker)
+    q.par = (q.ncls > 1 && (k.nchunks != 1 || d->f32 || d->noise)) ? 1 : 0;
     int wrow_bytes = 0;                 // LDS bytes of one row of every class panel
-    if (q.ncls == 1) {
+    int ksteps_par = 0;
+    if (q.par) {
+        if (d->cls_tap0[0] != 0 || d->cls_tap0[q.ncls] != d->ntaps) return VG_EINVAL;
+        for (int c = 0; c < q.ncls; ++c) {
+            const int nt = d->cls_tap0[c + 1] - d->cls_tap0[c];
+            if (nt < 1 || !d->cls_w[c]) return VG_EINVAL;
+            q.tap0[c] = d->cls_tap0[c]; q.wp[c] = d->cls_w[c];
+            q.ktot[c] = k.nchunks * (((nt * d->CK + 31) / 32) * 32);
+            q.woff[c] = 0; q.ks0[c] = 0;
+            for (int a = 0; a < 3; ++a) { q.off[c][a] = d->cls_ooff[c][a]; q.it[c][a] = d->cls_iters[c][a]; }
+            if (d->cls_iters[c][0] > d->OD || d->cls_iters[c][1] > d->OH || d->cls_iters[c][2] > d->OW) return VG_EINVAL;
+            const int rb = q.ktot[c] * esz + 16, ks = (nt * gpc_ + 3) >> 2;
+            if (rb > wrow_bytes) wrow_bytes = rb;
+            if (ks > ksteps_par) ksteps_par = ks;
+        }
+        q.tap0[q.ncls] = d->ntaps; q.ks0[q.ncls] = ksteps_par;
+    } else if (q.ncls == 1) {
         q.tap0[0] = 0; q.tap0[1] = d->ntaps; q.wp[0] = d->wpacked; q.ktot[0] = k.Ktot; q.woff[0] = 0;
         q.ks0[0] = 0; q.ks0[1] = (d->ntaps * gpc_ + 3) >> 2;
         q.off[0][0] = d->ooff_d; q.off[0][1] = d->ooff_h; q.off[0][2] = d->ooff_w;
@@ -790,7 +839,7 @@ static int fill_conv(const vg_conv_desc* d, GatherIn& g, ConvOut& k, ConvCls& q,
             if (ms == 8 && d->f32) continue;
             rc = fill_gather(d, g, d->CK, 64 * ms);
             if (rc != VG_OK) return rc;
-            const long wgs = (long)g.tiles_d * g.tiles_h * g.tiles_w * ((d->Cout + bn - 1) / bn) * d->N;
+            const long wgs = (long)g.tiles_d * g.tiles_h * g.tiles_w * ((d->Cout + bn - 1) / bn) * d->N * (q.par ? q.ncls : 1);
             const int wbytes = bn * wrow_bytes;
             int wl = (wbytes <= 56 * 1024 && !no_wlds && !d->f32) ? 1 : 0;       // exact-parity mode reads weights from L2
             int need = conv_lds_bytes(g, bn, d->CK, wl ? wbytes : 0, 0, ksteps_total);
@@ -814,7 +863,7 @@ static int fill_conv(const vg_conv_desc* d, GatherIn& g, ConvOut& k, ConvCls& q,
     if (!found) return VG_ELDS;
     rc = fill_gather(d, g, d->CK, 64 * MSUB, 0, k.dma);
     if (rc != VG_OK) return rc;
-    if (q.ncls > 1) { int off = 0; for (int c = 0; c < q.ncls; ++c) { q.woff[c] = off; off += BN * (q.ktot[c] * esz + 16); } }
+    if (q.ncls > 1 && !q.par) { int off = 0; for (int c = 0; c < q.ncls; ++c) { q.woff[c] = off; off += BN * (q.ktot[c] * esz + 16); } }
     k.OD = d->OD; k.OH = d->OH; k.OW = d->OW; k.ostr = d->ostr; k.ood = d->ooff_d; k.ooh = d->ooff_h; k.oow = d->ooff_w;
     k.BD = d->BD; k.BH = d->BH; k.BW = d->BW; k.Cout = d->Cout;
     k.wp = d->wpacked;
@@ -828,17 +877,20 @@ static int plan_conv32(const vg_conv_desc* d, const ConvOut& k, const ConvCls& q
     static int use32 = -1;
     if (use32 < 0) { const char* e = getenv("VG_CONV32"); use32 = e ? atoi(e) : 1; }
     const int Cin = d->c_src0 + d->c_src1;
-    if (!use32 || d->f32 || q.ncls != 1 || (d->Cout % 64) || Cin < 64 || Cin == 1 || d->tanh_out || (d->CK % 16)) return VG_EINVAL;
-    if ((long)d->OD * d->OH * d->OW * d->N * (d->Cout / 64) < 256 * 64) return VG_EINVAL;     // too small to fill the chip with 64-wide panels
+    if (!use32 || d->f32 || (q.ncls != 1 && !q.par) || (d->Cout % 64) || Cin < 64 || Cin == 1 || d->tanh_out || (d->CK % 16)) return VG_EINVAL;
+    const int ncp = q.par ? q.ncls : 1;
+    if ((long)d->OD * d->OH * d->OW * d->N * (d->Cout / 64) * ncp < 256 * 64) return VG_EINVAL;     // too small to fill the chip with 64-wide panels
     BN = (d->Cout % 128 == 0) ? 128 : 64;
-    const int ksteps = d->ntaps * (d->CK >> 4);
+    int tmax = d->ntaps;
+    if (q.par) { tmax = 0; for (int c = 0; c < q.ncls; ++c) tmax = std::max(tmax, q.tap0[c + 1] - q.tap0[c]); }
+    const int ksteps = tmax * (d->CK >> 4);
     long best = -1; int best_ms = 0, best_lds = 0;
     for (int ms = (BN == 128 ? 2 : 4); ms >= (BN == 128 ? 1 : 2); ms >>= 1) {
         int rc = fill_gather(d, g, d->CK, 64 * ms);
         if (rc != VG_OK) return rc;
         const int need = halo_bytes(g) + 256 + 2 * d->CK * 4 + BN * 2 * 4 + stage_table_ints(g) * 4 + ksteps * 8 + 16;
         if (need > VG_LDS_LIMIT) continue;
-        const long wgs = (long)g.tiles_d * g.tiles_h * g.tiles_w * (d->Cout / BN) * d->N;
+        const long wgs = (long)g.tiles_d * g.tiles_h * g.tiles_w * (d->Cout / BN) * d->N * ncp;
         // every tile streams its BN x K weight panel from L2 (64 B/clk per CU): 64 voxels per tile give exactly the
         // 64 FLOP/B that the MFMA rate needs, 128 voxels give headroom -- so one workgroup per CU with the big tile beats
         // two with the small one
@@ -851,11 +903,11 @@ static int plan_conv32(const vg_conv_desc* d, const ConvOut& k, const ConvCls& q
     (void)k;
     return fill_gather(d, g, d->CK, 64 * MSUB);
 }
-template <int BN, int MSUB, bool NOISE>
-static int launch_conv32b(const GatherIn& g, const ConvOut& k, int lds, hipStream_t s) {
+template <int BN, int MSUB, bool NOISE, bool CP>
+static int launch_conv32b(const GatherIn& g, const ConvOut& k, const ConvCls& q, int lds, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv32_kernel<BN, MSUB, NOISE>, hipFuncAttributeMaxDynamicSharedMemorySize, VG_LDS_LIMIT);
+        (void)hipFuncSetAttribute((const void*)conv32_kernel<BN, MSUB, NOISE, CP>, hipFuncAttributeMaxDynamicSharedMemorySize, VG_LDS_LIMIT);
         attr_set = true;
     }
     int per_cu = 2;
@@ -863,18 +915,24 @@ static int launch_conv32b(const GatherIn& g, const ConvOut& k, int lds, hipStrea
     if (per_cu < 1) per_cu = 1;
     const int tiles = g.tiles_d * g.tiles_h * g.tiles_w;
     const int ny = k.Cout / BN;
-    int bx = 256 * per_cu / (ny * g.N); if (bx < 1) bx = 1; if (bx > tiles) bx = tiles;
-    hipLaunchKernelGGL((conv32_kernel<BN, MSUB, NOISE>), dim3(bx, ny, g.N), dim3(256), lds, s, g, k);
+    const int ncp = CP ? q.ncls : 1;
+    int bx = 256 * per_cu / (ny * g.N * ncp); if (bx < 1) bx = 1; if (bx > tiles) bx = tiles;
+    hipLaunchKernelGGL((conv32_kernel<BN, MSUB, NOISE, CP>), dim3(bx * ncp, ny, g.N), dim3(256), lds, s, g, k, q);
     return vg_check_launch();
 }
-static int launch_conv32(const GatherIn& g, const ConvOut& k, int BN, int MSUB, int lds, hipStream_t s) {
+static int launch_conv32(const GatherIn& g, const ConvOut& k, const ConvCls& q, int BN, int MSUB, int lds, hipStream_t s) {
     const bool nz = g.noise != nullptr;
-    if (BN == 128) {
-        if (MSUB == 2) return nz ? launch_conv32b<128, 2, true>(g, k, lds, s) : launch_conv32b<128, 2, false>(g, k, lds, s);
-        return nz ? launch_conv32b<128, 1, true>(g, k, lds, s) : launch_conv32b<128, 1, false>(g, k, lds, s);
+    if (q.par) {                                  // data gradients: noise-free sources
+        if (nz) return VG_EINVAL;
+        if (BN == 128) return MSUB == 2 ? launch_conv32b<128, 2, false, true>(g, k, q, lds, s) : launch_conv32b<128, 1, false, true>(g, k, q, lds, s);
+        return MSUB == 4 ? launch_conv32b<64, 4, false, true>(g, k, q, lds, s) : launch_conv32b<64, 2, false, true>(g, k, q, lds, s);
     }
-    if (MSUB == 4) return nz ? launch_conv32b<64, 4, true>(g, k, lds, s) : launch_conv32b<64, 4, false>(g, k, lds, s);
-    return nz ? launch_conv32b<64, 2, true>(g, k, lds, s) : launch_conv32b<64, 2, false>(g, k, lds, s);
+    if (BN == 128) {
+        if (MSUB == 2) return nz ? launch_conv32b<128, 2, true, false>(g, k, q, lds, s) : launch_conv32b<128, 2, false, false>(g, k, q, lds, s);
+        return nz ? launch_conv32b<128, 1, true, false>(g, k, q, lds, s) : launch_conv32b<128, 1, false, false>(g, k, q, lds, s);
+    }
+    if (MSUB == 4) return nz ? launch_conv32b<64, 4, true, false>(g, k, q, lds, s) : launch_conv32b<64, 4, false, false>(g, k, q, lds, s);
+    return nz ? launch_conv32b<64, 2, true, false>(g, k, q, lds, s) : launch_conv32b<64, 2, false, false>(g, k, q, lds, s);
 }
 
 extern "C" int vg_conv3d_plan(const vg_conv_desc* d, int32_t* plan4) {
@@ -897,7 +955,7 @@ extern "C" int vg_conv3d_lds_bytes(const vg_conv_desc* d) {
     return rc == VG_OK ? lds : rc;
 }
 
-template <typename T, int BN, int MSUB, bool NOISE, bool WL, bool DMA, bool MC>
+template <typename T, int BN, int MSUB, bool NOISE, bool WL, bool DMA, int MC>
 static int launch_conv3(const GatherIn& g, const ConvOut& k, const ConvCls& q, int lds, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
@@ -914,21 +972,28 @@ static int launch_conv3(const GatherIn& g, const ConvOut& k, const ConvCls& q, i
     const int wg_target = wg_env > 0 ? wg_env : 256 * per_cu;
     const int tiles = g.tiles_d * g.tiles_h * g.tiles_w;
     const int ny = (k.Cout + BN - 1) / BN;
-    int bx = wg_target / (ny * g.N); if (bx < 1) bx = 1; if (bx > tiles) bx = tiles;
-    dim3 grid(bx, ny, g.N);
+    const int ncp = MC == 2 ? q.ncls : 1;
+    int bx = wg_target / (ny * g.N * ncp); if (bx < 1) bx = 1; if (bx > tiles) bx = tiles;
+    dim3 grid(bx * ncp, ny, g.N);
     hipLaunchKernelGGL((conv_kernel<T, BN, MSUB, NOISE, WL, DMA, MC>), grid, dim3(256), lds, s, g, k, q);
     return vg_check_launch();
 }
 template <typename T, int BN, int MSUB, bool NOISE>
 static int launch_conv2(const GatherIn& g, const ConvOut& k, const ConvCls& q, int lds, hipStream_t s) {
-    if constexpr (sizeof(T) == 2 && !NOISE) {
-        if (q.ncls > 1) return k.w_lds ? launch_conv3<T, BN, MSUB, NOISE, true, false, true>(g, k, q, lds, s)
-                                       : launch_conv3<T, BN, MSUB, NOISE, false, false, true>(g, k, q, lds, s);
-        if (k.w_lds && k.dma) return launch_conv3<T, BN, MSUB, NOISE, true, true, false>(g, k, q, lds, s);
+    if constexpr (!NOISE) {
+        if (q.par) {                                      // class-parallel data gradient (noise-free sources)
+            if constexpr (sizeof(T) == 2) { if (k.w_lds) return launch_conv3<T, BN, MSUB, NOISE, true, false, 2>(g, k, q, lds, s); }
+            return launch_conv3<T, BN, MSUB, NOISE, false, false, 2>(g, k, q, lds, s);
+        }
     }
-    if (q.ncls > 1) return VG_EINVAL;                     // fused classes: bf16, noise-free sources only
-    if constexpr (sizeof(T) == 2) { if (k.w_lds) return launch_conv3<T, BN, MSUB, NOISE, true, false, false>(g, k, q, lds, s); }
-    return launch_conv3<T, BN, MSUB, NOISE, false, false, false>(g, k, q, lds, s);
+    if constexpr (sizeof(T) == 2 && !NOISE) {
+        if (q.ncls > 1) return k.w_lds ? launch_conv3<T, BN, MSUB, NOISE, true, false, 1>(g, k, q, lds, s)
+                                       : launch_conv3<T, BN, MSUB, NOISE, false, false, 1>(g, k, q, lds, s);
+        if (k.w_lds && k.dma) return launch_conv3<T, BN, MSUB, NOISE, true, true, 0>(g, k, q, lds, s);
+    }
+    if (q.ncls > 1) return VG_EINVAL;                     // several classes: noise-free sources only
+    if constexpr (sizeof(T) == 2) { if (k.w_lds) return launch_conv3<T, BN, MSUB, NOISE, true, false, 0>(g, k, q, lds, s); }
+    return launch_conv3<T, BN, MSUB, NOISE, false, false, 0>(g, k, q, lds, s);
 }
 template <typename T, int BN, int MSUB>
 static int launch_conv(const GatherIn& g, const ConvOut& k, const ConvCls& q, int lds, hipStream_t s) {
@@ -948,7 +1013,7 @@ extern "C" int vg_conv3d(const vg_conv_desc* d, vg_stream_t stream) {
     int rc = fill_conv(d, g, k, q, BN, MSUB, lds);
     if (rc != VG_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
-    { GatherIn g2; int bn2, ms2, lds2; if (plan_conv32(d, k, q, g2, bn2, ms2, lds2) == VG_OK) return launch_conv32(g2, k, bn2, ms2, lds2, s); }
+    { GatherIn g2; int bn2, ms2, lds2; if (plan_conv32(d, k, q, g2, bn2, ms2, lds2) == VG_OK) return launch_conv32(g2, k, q, bn2, ms2, lds2, s); }
     return d->f32 ? dispatch_conv<float>(g, k, q, BN, MSUB, lds, s) : dispatch_conv<bf16_t>(g, k, q, BN, MSUB, lds, s);
 }
 

@@ -4,6 +4,7 @@ the data path is done by torch."""
 from __future__ import annotations
 
 import ctypes as C
+import os
 import math
 from typing import List, Optional, Sequence, Tuple
 
@@ -239,6 +240,27 @@ class ConvLayer:
                 for c in self.d_classes:
                     c['ck'] = ck_f
                 self.d_fused = self._fused_desc(None, 1, None, False, probe=True) is not None
+            # otherwise (several channel chunks of dY, or exact-parity mode): still ONE launch, class-parallel -- every
+            # workgroup serves one class, so the launch carries all classes' tiles at once (8 launches of 8-64 workgroups
+            # each left most of the chip idle on enc3/enc4/D.down1).  All classes share the chunk size.
+            if (not self.d_fused and len(self.d_classes) > 1 and os.environ.get('VG_CLS_PAR', '1') != '0'
+                    and sum(len(c['taps']) for c in self.d_classes) <= _lib.VG_MAX_TAPS):
+                best, best_key = None, None
+                for ck in _ck_candidates(cout):
+                    for c in self.d_classes:
+                        c['ck'] = ck
+                    if self._fused_desc(None, 1, None, False, probe=True) is None:
+                        continue
+                    plan = self._last_plan
+                    key = (plan[0] * plan[1], 1 if plan[2] <= 80 * 1024 else 0, ck)
+                    if ck < 32 and best is not None and best_key[0] >= key[0]:
+                        continue
+                    if best_key is None or key > best_key:
+                        best, best_key = ck, key
+                if best is not None:
+                    for c in self.d_classes:
+                        c['ck'] = best
+                    self.d_fused = True
             for c in self.d_classes:
                 if not self.d_fused:
                     c['ck'] = self._pick_ck(cout, c['taps'], 1, self.out_dims, c['iters'], cin)
@@ -379,7 +401,9 @@ class ConvLayer:
         if probe:
             d.out = dummy
             plan = (C.c_int32 * 4)()
-            return d if lib.vg_conv3d_plan(C.byref(d), plan) == 0 else None
+            ok = lib.vg_conv3d_plan(C.byref(d), plan) == 0
+            self._last_plan = tuple(plan)
+            return d if ok else None
         d.out, d.out_f32, d.accumulate = _p(out), int(out.dtype == torch.float32), int(accumulate)
         return d
 
