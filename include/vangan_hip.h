@@ -120,12 +120,14 @@ int vg_conv3d_plan(const vg_conv_desc* d, int32_t* plan4);
 int vg_pack_weights(const float* w, int T, int Cin, int Cout, const int32_t* tap_idx_dev, int ntaps,
                     int transpose, int CK, void* out, int out_f32, vg_stream_t stream);
 /* Table-driven repack of every packed operand of a network in ONE launch: items_dev is a device array of n
- * vg_pack_item (all pointers device pointers). */
+ * vg_pack_item (all pointers device pointers).  Item i is served by the nblk >= 1 blocks starting at blk0 of a 1-D grid of
+ * total_blocks = sum(nblk) blocks (the caller sizes nblk in proportion to the operand, the ranges must tile the grid). */
 typedef struct {
     const float* w; const int32_t* tap_idx; void* out;
     int32_t Cin, Cout, ntaps, transpose, CK, out_f32;
+    int32_t blk0, nblk;
 } vg_pack_item;
-int vg_pack_weights_multi(const vg_pack_item* items_dev, int n, vg_stream_t stream);
+int vg_pack_weights_multi(const vg_pack_item* items_dev, int n, int total_blocks, vg_stream_t stream);
 int vg_packed_ktot(int ntaps, int C, int CK);
 int vg_packed_rows(int N);
 

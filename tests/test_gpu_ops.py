@@ -387,3 +387,28 @@ def test_conv_lds_dma_staging_subprocess():
     r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-x', '-m', 'gpu',
                         '-k', 'test_conv_forward_dgrad_wgrad'], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize('net', ['gen', 'disc'])
+def test_table_repack_equals_per_layer_pack(net):
+    """vg_pack_weights_multi (one launch, blocks shared out by operand size) writes exactly what the per-operand
+    vg_pack_weights writes, for every forward and data-gradient operand of a network."""
+    from van_gan_amd.nets import ParamStore, PatchGAN, ResUNet, disc_param_specs, gen_param_specs
+    dev = _dev()
+    st = ParamStore(gen_param_specs() if net == 'gen' else disc_param_specs(), dev)
+    st.w.copy_(torch.randn(st.w.shape, generator=torch.Generator().manual_seed(3)).to(dev))
+    m = ResUNet(st, (32, 32, 32)) if net == 'gen' else PatchGAN(st, (32, 32, 32))
+    m.pack()
+    torch.cuda.synchronize()
+    got = [[it[2].clone() for it in l.pack_items()] for l in m.L.values()]
+    for l in m.L.values():
+        for it in l.pack_items():
+            it[2].fill_(7.0)
+        l.pack()
+    torch.cuda.synchronize()
+    n = 0
+    for l, g in zip(m.L.values(), got):
+        for it, a in zip(l.pack_items(), g):
+            assert torch.equal(it[2], a), l.name
+            n += 1
+    assert n >= (30 if net == 'gen' else 5)

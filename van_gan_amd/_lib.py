@@ -36,7 +36,7 @@ class ConvDesc(C.Structure):
 
 class PackItem(C.Structure):
     _fields_ = [('w', c_void_p), ('tap_idx', c_void_p), ('out', c_void_p), ('Cin', c_int), ('Cout', c_int), ('ntaps', c_int),
-                ('transpose', c_int), ('CK', c_int), ('out_f32', c_int)]
+                ('transpose', c_int), ('CK', c_int), ('out_f32', c_int), ('blk0', c_int), ('nblk', c_int)]
 
 
 class ActNormBwdDesc(C.Structure):
@@ -58,7 +58,7 @@ _SIGS = {
     'vg_conv3d_lds_bytes': ([C.POINTER(ConvDesc)], c_int),
     'vg_conv3d_plan': ([C.POINTER(ConvDesc), C.POINTER(C.c_int32)], c_int),
     'vg_pack_weights': ([c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p], c_int),
-    'vg_pack_weights_multi': ([c_void_p, c_int, c_void_p], c_int),
+    'vg_pack_weights_multi': ([c_void_p, c_int, c_int, c_void_p], c_int),
     'vg_crop_augment': ([c_void_p] + [c_int] * 13 + [c_void_p, c_void_p], c_int),
     'vg_crop_max': ([c_void_p] + [c_int] * 10 + [c_void_p, c_void_p], c_int),
     'vg_packed_ktot': ([c_int, c_int, c_int], c_int),

@@ -1039,21 +1039,34 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, int Cin, int Co
     }
 }
 
-// One launch repacks every operand of a network.  blockIdx.y = item.  Forward operands ([Cout rows][K]) transpose the
-// DHWIO kernel, so they go through a 64x64 LDS tile: reads run along Cout (contiguous in w), writes along K (contiguous in
-// the packed row); data-gradient operands ([Cin rows][K = (tap, co)]) are contiguous on both sides already.
-__global__ __launch_bounds__(256) void pack_weights_multi_kernel(const vg_pack_item* __restrict__ items) {
+// One launch repacks every operand of a network.  The host gives item i the blocks [blk0, blk0 + nblk) of a 1-D grid in
+// proportion to its size (the first version gave every item 128 blocks: the two 8.4 M-element operands of D.down2 then ran
+// on half the chip long after the ~90 small items had finished: 0.9 ms per step for 0.5 GB of traffic).  Forward
+// operands ([Cout rows][K]) transpose the DHWIO kernel, so they go through a 64x64 LDS tile: reads run along Cout
+// (contiguous in w), writes along K (contiguous in the packed row); data-gradient operands ([Cin rows][K = (tap, co)])
+// are contiguous on both sides already.
+__global__ __launch_bounds__(256) void pack_weights_multi_kernel(const vg_pack_item* __restrict__ items, int n) {
     __shared__ float tile[64][65];
-    const vg_pack_item it = items[blockIdx.y];
+    __shared__ int sel;
+    const int tid = threadIdx.x;
+    for (int t = tid; t < n; t += 256) {
+        const int b0 = items[t].blk0;
+        if ((int)blockIdx.x >= b0 && (int)blockIdx.x < b0 + items[t].nblk) sel = t;
+    }
+    __syncthreads();
+    const vg_pack_item it = items[sel];
+    const int bx = blockIdx.x - it.blk0, gx = it.nblk;
     const int C = it.transpose ? it.Cout : it.Cin, NR = it.transpose ? it.Cin : it.Cout;
     const int nchunks = (C + it.CK - 1) / it.CK;
     const int kc_pad = ((it.ntaps * it.CK + 31) / 32) * 32;
     const int Ktot = nchunks * kc_pad;
     const int rows_pad = ((NR + 63) / 64) * 64;
-    const int tid = threadIdx.x;
     if (it.transpose) {
-        for (int row = blockIdx.x; row < rows_pad; row += gridDim.x)
-            for (int k = tid; k < Ktot; k += 256) {
+        // a block takes whole rows while there are enough of them, else (few long rows) a slice of every row
+        const int kspl = rows_pad >= gx ? 1 : (gx + rows_pad - 1) / rows_pad;
+        const int rb = bx / kspl, ks = bx - rb * kspl, nrb = (gx + kspl - 1) / kspl;
+        for (int row = rb; row < rows_pad; row += nrb)
+            for (int k = ks * 256 + tid; k < Ktot; k += 256 * kspl) {
                 const int chunk = k / kc_pad, kl = k - chunk * kc_pad;
                 const int tap = kl / it.CK, ch = chunk * it.CK + (kl - tap * it.CK);
                 float v = 0.f;
@@ -1064,7 +1077,7 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const vg_pack_i
         return;
     }
     const int tk = (Ktot + 63) >> 6, tr = rows_pad >> 6;
-    for (int t = blockIdx.x; t < tk * tr; t += gridDim.x) {
+    for (int t = bx; t < tk * tr; t += gx) {
         const int r0 = (t / tk) << 6, k0 = (t % tk) << 6;
 #pragma unroll 4
         for (int j = 0; j < 16; ++j) {
@@ -1090,10 +1103,10 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const vg_pack_i
         __syncthreads();
     }
 }
-extern "C" int vg_pack_weights_multi(const vg_pack_item* items_dev, int n, vg_stream_t stream) {
+extern "C" int vg_pack_weights_multi(const vg_pack_item* items_dev, int n, int total_blocks, vg_stream_t stream) {
     vg_begin();
-    if (!items_dev || n < 1) return VG_EINVAL;
-    hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(128, n), dim3(256), 0, (hipStream_t)stream, items_dev);
+    if (!items_dev || n < 1 || total_blocks < n) return VG_EINVAL;
+    hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, items_dev, n);
     return vg_check_launch();
 }
 

@@ -448,16 +448,21 @@ class PackTable:
     def __init__(self, layers, device):
         items = [it for l in layers for it in l.pack_items()]
         arr = (_lib.PackItem * len(items))()
+        blk = 0
+        per_block = int(os.environ.get('VG_PACK_ELEMS', 8192))     # packed elements per block: big operands get many blocks
         for a, (w, idx, out, cin, cout, ntaps, tr, ck, f32) in zip(arr, items):
             a.w, a.tap_idx, a.out = w.data_ptr(), idx.data_ptr(), out.data_ptr()
             a.Cin, a.Cout, a.ntaps, a.transpose, a.CK, a.out_f32 = cin, cout, ntaps, tr, ck, f32
+            a.blk0, a.nblk = blk, max(1, min(4096, -(-out.numel() // per_block)))
+            blk += a.nblk
+        self.total_blocks = blk
         raw = bytes(arr)
         self.keep = items
         self.n = len(items)
         self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
 
     def run(self):
-        check(lib.vg_pack_weights_multi(_p(self.table), self.n, stream()), 'vg_pack_weights_multi')
+        check(lib.vg_pack_weights_multi(_p(self.table), self.n, self.total_blocks, stream()), 'vg_pack_weights_multi')
 
 
 # ------------------------------------------------------------------------------------------------------
