@@ -98,12 +98,21 @@ typedef struct {
        nclass > 1 ONE launch stages each dY halo tile once and produces the outputs of all classes.  Class c uses the
        taps tap_*[cls_tap0[c] .. cls_tap0[c+1]), its own packed weights cls_w[c] (packed with those taps and CK), the
        output offset cls_ooff[c] (replaces ooff_*) and cls_iters[c] outputs per axis (replaces OD/OH/OW, which must
-       hold the per-axis maximum).  Requires c_src0 + c_src1 <= CK (one channel chunk).  nclass 0 or 1: fields unused. */
+       hold the per-axis maximum).  With one channel chunk (c_src0 + c_src1 <= CK, bf16, no noise) the classes share the
+       staged tile; otherwise the launch is class-parallel (workgroup -> one class), any number of chunks, all classes
+       packed with the same CK.  nclass 0 or 1: fields unused. */
     int32_t nclass;
     int32_t cls_tap0[9];
     const void* cls_w[8];
     int32_t cls_ooff[8][3];
     int32_t cls_iters[8][3];
+    /* W-packed single-channel source (the Conv3D layers that read a 1-channel volume: resunet_model.py:44-60 stem,
+       discriminator.py:50-60 first conv).  wpack = k > 1: the k taps along W become k pseudo-channels, the descriptor lists
+       only the k*k (d, h) taps (tap_w = 0), wpack_wmin is the W offset of the first tap (-pad_before).  The packed weights
+       are the same DHWIO kernel read as [k*k taps][k channels][Cout] (vg_pack_weights with ntaps = k*k, Cin = k), and
+       vg_conv3d_wgrad returns dw in that layout, i.e. the unchanged DHWIO tensor (T_total = k*k).  0: off. */
+    int32_t wpack;
+    int32_t wpack_wmin;
 } vg_conv_desc;
 
 int vg_conv3d(const vg_conv_desc* d, vg_stream_t stream);

@@ -86,6 +86,10 @@ CONV_CASES = [
     (3, 128, 256, 2, 'reflect', (4, 8, 8)),
     (3, 16, 128, 2, 'reflect', (5, 7, 9)),
     (4, 128, 256, 2, 'reflect', (16, 16, 16)),
+    # single-channel sources run W-packed (k taps along W -> k pseudo-channels); besides the stem / D.conv0 shapes above:
+    # zero padding, ragged extents, stride 2 with 'same' padding
+    (3, 1, 16, 1, 'same', (6, 10, 12)),
+    (4, 1, 32, 2, 'same', (7, 9, 11)),
 ]
 
 

@@ -265,7 +265,7 @@ __device__ __forceinline__ void dma_transform(const GatherIn& g, char* hb, const
 // MC: 0 = one class (plain launch); 1 = all output-parity classes looped over one staged halo tile (single channel chunk);
 // 2 = class-parallel: the workgroup serves the ONE class blockIdx.x % ncls (own taps / weights / output sub-lattice) and
 // walks the tiles with the remaining part of blockIdx.x -- the launch carries ncls times the workgroups of a per-class launch
-template <typename T, int BN, int MSUB, bool NOISE, bool WL, bool DMA, int MC>
+template <typename T, int BN, int MSUB, bool NOISE, bool WL, bool DMA, int MC, bool C1>
 __global__ __launch_bounds__(256, ((BN / 16) * MSUB >= 8 ? 2 : VG_CONV_WAVES)) void conv_kernel(const GatherIn g, const ConvOut p, const ConvCls q) {
     static_assert(!(MC && DMA), "fused classes use the synchronous staging path");
     constexpr bool F32 = sizeof(T) == 4;
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256, ((BN / 16) * MSUB >= 8 ? 2 : VG_CONV_WAVES)) v
     int* utab = (int*)(stat + BN * 2);
     const int ncols = stage_ncols(g);
     const int SU = g.DS >> 4;                        // DMA: units per D-slice (multiple of 64)
-    const int RTN = 3 * (g.HH + g.HW);               // one buffer of per-tile axis tables; two buffers: the tables of tile t+1
+    const int RTN = 3 * stage_axis_len<(C1 ? 1 : 3)>(g);               // one buffer of per-tile axis tables; two buffers: the tables of tile t+1
                                                      // are resolved while tile t is staged (no barrier, off the critical path)
     const int nunits = DMA ? 5 * SU : 2 * ncols + 2 * RTN;               // staging tables (see conv_lds_bytes)
     int* rtab = utab + 2 * ncols;
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(256, ((BN / 16) * MSUB >= 8 ? 2 : VG_CONV_WAVES)) v
             int t = bx;
             const int tw_i = t % g.tiles_w; t /= g.tiles_w;
             const int th_i = t % g.tiles_h;
-            stage_resolve_axes(g, rtab, th_i << g.thl, tw_i << g.twl, tid);
+            stage_resolve_axes<(C1 ? 1 : 3)>(g, rtab, th_i << g.thl, tw_i << g.twl, tid);
         }
     }
     __syncthreads();
@@ -440,9 +440,9 @@ __global__ __launch_bounds__(256, ((BN / 16) * MSUB >= 8 ? 2 : VG_CONV_WAVES)) v
             // fused output-parity classes: the dY halo tile is staged once; every class runs its own taps / weights /
             // accumulators over it and writes its own output sub-lattice
             __syncthreads();                       // previous readers of the halo tile are done; this tile's axis tables visible
-            if (!(g.dbg & 1)) stage_halo_tile<T, NOISE, (NOISE ? 4 : 6)>(g, halo, scs, utab, rtab + (it & 1) * RTN, n, od0, 0, tid);
+            if (!(g.dbg & 1)) stage_halo_tile<T, NOISE, (NOISE ? 4 : 6), (C1 ? 1 : 3)>(g, halo, scs, utab, rtab + (it & 1) * RTN, n, od0, 0, tid);
             if (tile + gx < tiles_per_n) {
-                stage_resolve_axes(g, rtab + ((it + 1) & 1) * RTN, nx_h0, nx_w0, tid);
+                stage_resolve_axes<(C1 ? 1 : 3)>(g, rtab + ((it + 1) & 1) * RTN, nx_h0, nx_w0, tid);
             }
             VG_STAMP(1);
             __syncthreads();
@@ -496,9 +496,9 @@ __global__ __launch_bounds__(256, ((BN / 16) * MSUB >= 8 ? 2 : VG_CONV_WAVES)) v
             } else {
                 __syncthreads();                       // previous readers of the halo tile are done; this tile's axis tables visible
                 if (p.nchunks > 1) { stage_scale_shift(g, scs, n, chunk, tid); __syncthreads(); }
-                if (!(g.dbg & 1)) stage_halo_tile<T, NOISE, (NOISE ? 4 : 6)>(g, halo, scs, utab, rtab + (it & 1) * RTN, n, od0, chunk, tid);
+                if (!(g.dbg & 1)) stage_halo_tile<T, NOISE, (NOISE ? 4 : 6), (C1 ? 1 : 3)>(g, halo, scs, utab, rtab + (it & 1) * RTN, n, od0, chunk, tid);
                 if (chunk == 0 && tile + gx < tiles_per_n) {       // axis tables of the next tile, other buffer
-                    stage_resolve_axes(g, rtab + ((it + 1) & 1) * RTN, nx_h0, nx_w0, tid);
+                    stage_resolve_axes<(C1 ? 1 : 3)>(g, rtab + ((it + 1) & 1) * RTN, nx_h0, nx_w0, tid);
                 }
                 if (chunk == 0) VG_STAMP(1);
                 __syncthreads();
@@ -583,7 +583,7 @@ __global__ __launch_bounds__(256, 2) void conv32_kernel(const GatherIn g, const 
     float* stat = scs + 2 * g.CK;
     int* utab = (int*)(stat + BN * 2);
     const int ncols = stage_ncols(g);
-    const int RTN = 3 * (g.HH + g.HW);
+    const int RTN = 3 * stage_axis_len<3>(g);
     int* rtab = utab + 2 * ncols;
     const int c16 = g.CK >> 4;                           // 16-channel K-steps per tap
     const int ksteps = nt * c16;
@@ -618,7 +618,7 @@ __global__ __launch_bounds__(256, 2) void conv32_kernel(const GatherIn g, const 
         int t = bx;
         const int tw_i = t % g.tiles_w; t /= g.tiles_w;
         const int th_i = t % g.tiles_h;
-        stage_resolve_axes(g, rtab, th_i << g.thl, tw_i << g.twl, tid);
+        stage_resolve_axes<3>(g, rtab, th_i << g.thl, tw_i << g.twl, tid);
     }
     __syncthreads();
 
@@ -644,9 +644,9 @@ __global__ __launch_bounds__(256, 2) void conv32_kernel(const GatherIn g, const 
         for (int chunk = 0; chunk < p.nchunks; ++chunk) {
             __syncthreads();                       // previous readers of the halo tile are done; this tile's axis tables visible
             if (p.nchunks > 1) { stage_scale_shift(g, scs, n, chunk, tid); __syncthreads(); }
-            stage_halo_tile<T, NOISE, 4>(g, halo, scs, utab, rtab + (it & 1) * RTN, n, od0, chunk, tid);
+            stage_halo_tile<T, NOISE, 4, 3>(g, halo, scs, utab, rtab + (it & 1) * RTN, n, od0, chunk, tid);
             if (chunk == 0 && tile + gx < tiles_per_n)
-                stage_resolve_axes(g, rtab + ((it + 1) & 1) * RTN, ti_h << g.thl, ti_w << g.twl, tid);
+                stage_resolve_axes<3>(g, rtab + ((it + 1) & 1) * RTN, ti_h << g.thl, ti_w << g.twl, tid);
             __syncthreads();
             // ---- K loop: ring of RD weight fragments (L2 latency), halo fragments ping-pong ----
             const glb_ptr<T> w = wrow + (size_t)chunk * kc_pad;
@@ -955,11 +955,11 @@ extern "C" int vg_conv3d_lds_bytes(const vg_conv_desc* d) {
     return rc == VG_OK ? lds : rc;
 }
 
-template <typename T, int BN, int MSUB, bool NOISE, bool WL, bool DMA, int MC>
+template <typename T, int BN, int MSUB, bool NOISE, bool WL, bool DMA, int MC, bool C1 = false>
 static int launch_conv3(const GatherIn& g, const ConvOut& k, const ConvCls& q, int lds, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_kernel<T, BN, MSUB, NOISE, WL, DMA, MC>, hipFuncAttributeMaxDynamicSharedMemorySize, VG_LDS_LIMIT);
+        (void)hipFuncSetAttribute((const void*)conv_kernel<T, BN, MSUB, NOISE, WL, DMA, MC, C1>, hipFuncAttributeMaxDynamicSharedMemorySize, VG_LDS_LIMIT);
         attr_set = true;
     }
     // persistent grid = what is resident at once (register cap: 3 workgroups per CU, 2 for the 8-sub-tile variants; LDS):
@@ -975,11 +975,16 @@ static int launch_conv3(const GatherIn& g, const ConvOut& k, const ConvCls& q, i
     const int ncp = MC == 2 ? q.ncls : 1;
     int bx = wg_target / (ny * g.N * ncp); if (bx < 1) bx = 1; if (bx > tiles) bx = tiles;
     dim3 grid(bx * ncp, ny, g.N);
-    hipLaunchKernelGGL((conv_kernel<T, BN, MSUB, NOISE, WL, DMA, MC>), grid, dim3(256), lds, s, g, k, q);
+    hipLaunchKernelGGL((conv_kernel<T, BN, MSUB, NOISE, WL, DMA, MC, C1>), grid, dim3(256), lds, s, g, k, q);
     return vg_check_launch();
 }
 template <typename T, int BN, int MSUB, bool NOISE>
 static int launch_conv2(const GatherIn& g, const ConvOut& k, const ConvCls& q, int lds, hipStream_t s) {
+    if (g.Cin == 1) {                                     // single-channel source: its staging path is a kernel variant of its own
+        if (q.ncls > 1) return VG_EINVAL;
+        if constexpr (sizeof(T) == 2) { if (k.w_lds) return launch_conv3<T, BN, MSUB, NOISE, true, false, 0, true>(g, k, q, lds, s); }
+        return launch_conv3<T, BN, MSUB, NOISE, false, false, 0, true>(g, k, q, lds, s);
+    }
     if constexpr (!NOISE) {
         if (q.par) {                                      // class-parallel data gradient (noise-free sources)
             if constexpr (sizeof(T) == 2) { if (k.w_lds) return launch_conv3<T, BN, MSUB, NOISE, true, false, 2>(g, k, q, lds, s); }

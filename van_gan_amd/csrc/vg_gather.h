@@ -23,6 +23,12 @@ struct GatherIn {
                              // that the stride-2 voxels of a sub-tile are consecutive units; 0 for istr 1
     int tdl, thl, twl, tiles_d, tiles_h, tiles_w;
     int f32;        // storage type of multi-channel tensors / LDS tile: 0 bf16, 1 f32
+    // W-packed single-channel source (Cin == 1, k > 1): the kernel sees the pseudo-input P[d][h][ow][j] = x[d][h][ow*istr + wmin + j],
+    // j < wpack = k, i.e. a k-channel source convolved with the k*k (d, h) taps only -- K shrinks from 16 padded channels
+    // per tap to 16 per (d, h) tap PAIR OF k taps, and the DHWIO kernel [k][k][k][1][Cout] is, unchanged in memory, the
+    // [k*k taps][k channels][Cout] kernel of that pseudo-convolution.  The halo image has no W halo (HW = tile width, unit
+    // W step for either stride); HWx is the true input W extent of a tile (axis-table length), Cw the weight-side Cin.
+    int wpack, HWx, wmin, Cw;
     int dbg;        // development ablation flags (VG_DEBUG env): 1 skip halo staging, 2 skip dY staging, 4 skip MFMA
     unsigned long long* stamps;   // diagnostic build only (vg_set_stamp_buffer): s_memtime stamps per phase, else NULL
 };
@@ -62,6 +68,11 @@ __device__ __forceinline__ void stage_scale_shift(const GatherIn& g, float* scs,
 // storage column of halo column hw
 __host__ __device__ __forceinline__ int halo_pos_w(const GatherIn& g, int hw) { return g.HWh ? (hw >> 1) + (hw & 1) * g.HWh : hw; }
 __host__ __device__ __forceinline__ int stage_ncols(const GatherIn& g) { return g.HH * g.HW * (g.Cin == 1 ? 1 : (g.CK >> 3)); }
+// length of the per-tile axis tables (H entries, then W entries)
+// (C1 = 0: the kernel variant never sees a single-channel source -- the W-packed form is compiled out; the hot multi-channel
+// kernels are instruction-issue bound and every extra scalar field they touch shows up in their run time)
+template <int C1 = 2>
+__host__ __device__ __forceinline__ int stage_axis_len(const GatherIn& g) { return g.HH + ((C1 != 0 && C1 != 3 && g.wpack) ? g.HWx : g.HW); }
 
 __device__ __forceinline__ void build_column_table(const GatherIn& g, int* ctab, int tid) {
     const int gpc = g.Cin == 1 ? 1 : (g.CK >> 3);
@@ -77,9 +88,10 @@ __device__ __forceinline__ void build_column_table(const GatherIn& g, int* ctab,
     }
 }
 
+template <int C1 = 2>
 __device__ __forceinline__ void stage_resolve_axes(const GatherIn& g, int* rtab, int oh0, int ow0, int tid) {
-    const int L = g.HH + g.HW;
-    const int ph0 = oh0 * g.istr + g.tmin_h, pw0 = ow0 * g.istr + g.tmin_w;
+    const int L = stage_axis_len<C1>(g);
+    const int ph0 = oh0 * g.istr + g.tmin_h, pw0 = ow0 * g.istr + ((C1 != 0 && C1 != 3 && g.wpack) ? g.wmin : g.tmin_w);
     const int cs0 = g.Cin == 1 ? 1 : g.c0;
     // wave s resolves table s (src0, src1, noise): the three small jobs run side by side, off wave 0's critical path
     const int set = tid >> 6;
@@ -131,10 +143,10 @@ __device__ __forceinline__ StageSplit stage_split(int ncols, int HD, int tid) {
 }
 
 // single-channel source of element type S (the fp32 input volumes, bf16 logits/gradients)
-template <typename T, typename S, bool NOISE, int UB>
+template <typename T, typename S, bool NOISE, int UB, bool WP = true>
 __device__ __forceinline__ void stage_halo_c1(const GatherIn& g, char* halo, const float* scs, const int* ctab, const int* rtab,
                                               int n, int pd0, int tid) {
-    const int L = g.HH + g.HW;
+    const int L = stage_axis_len<(WP ? 2 : 0)>(g);
     const int ncols = g.HH * g.HW;
     const int plane = g.DS;
     const float slope = g.act == VG_ACT_RELU ? 0.f : (g.act == VG_ACT_LRELU ? VG_LRELU : 1.f);
@@ -146,6 +158,57 @@ __device__ __forceinline__ void stage_halo_c1(const GatherIn& g, char* halo, con
     const bf16_t* nbase = NOISE ? g.noise + (size_t)n * ND * nplane : nullptr;
     const int ngrp = g.CK >> 3;
     const StageSplit sp = stage_split(ncols, g.HD, tid);
+    if (WP && g.wpack) {
+        // W-packed: channel j of halo voxel (hd, hh, hw) is the source at W position hw*istr + j of the tile's input window
+        for (int col = sp.col0; col < ncols; col += sp.cstride) {
+            const int e = ctab[2 * col], hoff = ctab[2 * col + 1];
+            const int hh = e & 1023, hw = (e >> 10) & 1023;
+            const int oh = rtab[hh];
+            int ow[8], nw[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int wi = min(hw * g.istr + j, g.HWx - 1);
+                ow[j] = j < g.wpack ? rtab[g.HH + wi] : -1;
+                nw[j] = (NOISE && j < g.wpack) ? rtab[2 * L + g.HH + wi] : -1;
+            }
+            const int nh = NOISE ? rtab[2 * L + hh] : -1;
+            for (int hd = sp.hd_lo; hd < sp.hd_hi; ++hd) {
+                int rd = pd0 + hd;
+                const int qd = rd + g.npad;
+                const bool dvalid = resolve_pos(rd, g.D, g.pad_mode);
+                const bool nd = NOISE && dvalid && qd >= 0 && qd < ND && nh >= 0;
+                const S* srow = sbase + (dvalid ? rd * splane : 0) + (oh >= 0 ? oh : 0);
+                const bf16_t* nrow = NOISE ? nbase + (nd ? qd * nplane + nh : 0) : nullptr;
+                float xv[8], zv[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {                      // straight-line clamped loads, masked afterwards
+                    xv[j] = ld_global(srow + (ow[j] >= 0 ? ow[j] : 0));
+                    zv[j] = NOISE ? ld_global(nrow + (nw[j] >= 0 ? nw[j] : 0)) : 0.f;
+                }
+#pragma unroll
+                for (int j = 4; j < 8; ++j) { xv[j] = 0.f; zv[j] = 0.f; }
+                if (g.wpack > 4) {
+#pragma unroll
+                    for (int j = 4; j < 8; ++j) {
+                        xv[j] = ld_global(srow + (ow[j] >= 0 ? ow[j] : 0));
+                        zv[j] = NOISE ? ld_global(nrow + (nw[j] >= 0 ? nw[j] : 0)) : 0.f;
+                    }
+                }
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float y = xv[j] * sc0 + sf0;
+                    y = fmaxf(y, y * slope) + ((nd && nw[j] >= 0) ? zv[j] : 0.f);
+                    v[j] = (dvalid && oh >= 0 && ow[j] >= 0) ? y : 0.f;
+                }
+                const float z8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                T* row = (T*)(halo + (size_t)hd * plane + hoff);
+                store8<T>(row, v);
+                for (int b = 1; b < ngrp; ++b) store8<T>((T*)((char*)row + (size_t)b * g.CS), z8);
+            }
+        }
+        return;
+    }
     for (int col = sp.col0; col < ncols; col += sp.cstride) {
         const int e = ctab[2 * col], hoff = ctab[2 * col + 1];
         const int hh = e & 1023, hw = (e >> 10) & 1023;
@@ -187,10 +250,15 @@ __device__ __forceinline__ void stage_halo_c1(const GatherIn& g, char* halo, con
     }
 }
 
-template <typename T, bool NOISE, int UB = 4>
+// C1: 0 = the source is never single-channel (that path is compiled out), 1 = always single-channel, 2 = decided at run
+// time (weight-gradient kernel), 3 = decided at run time, W-packed form not supported.  The multi-channel conv_kernel
+// variants use 3 although they never see a single-channel source: they sit at their register cap, and both compiling the
+// path out (0) and the W-packed version of it (2) made the allocator spill 4 more VGPRs in the 8-sub-tile variants
+// (+17 % run time on the 16->16 layers at 128^3; -Rpass-analysis=kernel-resource-usage: 10 -> 14 spilled VGPRs).
+template <typename T, bool NOISE, int UB = 4, int C1 = 2>
 __device__ __forceinline__ void stage_halo_tile(const GatherIn& g, char* halo, const float* scs, const int* ctab, const int* rtab,
                                                 int n, int od0, int chunk, int tid) {
-    const int L = g.HH + g.HW;
+    const int L = stage_axis_len<C1>(g);
     const int ncols = stage_ncols(g);
     const int plane = g.DS;                                    // bytes of one D-slice of the halo image
     const int pd0 = od0 * g.istr + g.tmin_d;
@@ -199,11 +267,13 @@ __device__ __forceinline__ void stage_halo_tile(const GatherIn& g, char* halo, c
     const int ND = g.D + 2 * g.npad;
     const int nplane = (g.H + 2 * g.npad) * (g.W + 2 * g.npad) * g.Cin;       // noise elements per D-plane
 
-    if (g.Cin == 1) {
-        // single-channel source (fp32 or bf16 volume): one scalar per voxel -> channel 0 of an otherwise zero row
-        if (g.src_f32) stage_halo_c1<T, float, NOISE, UB>(g, halo, scs, ctab, rtab, n, pd0, tid);
-        else stage_halo_c1<T, bf16_t, NOISE, UB>(g, halo, scs, ctab, rtab, n, pd0, tid);
-        return;
+    if constexpr (C1 != 0) {
+        if (C1 == 1 || g.Cin == 1) {
+            // single-channel source (fp32 or bf16 volume): one scalar per voxel -> channel 0 of an otherwise zero row
+            if (g.src_f32) stage_halo_c1<T, float, NOISE, UB, C1 != 3>(g, halo, scs, ctab, rtab, n, pd0, tid);
+            else stage_halo_c1<T, bf16_t, NOISE, UB, C1 != 3>(g, halo, scs, ctab, rtab, n, pd0, tid);
+            return;
+        }
     }
 
     const bool plain = !g.in_scale && g.act == VG_ACT_NONE && !NOISE;     // data-gradient operand: pure copy
@@ -325,6 +395,11 @@ static inline int fill_gather(const vg_conv_desc* d, GatherIn& g, int CK, int BM
     g.in_scale = d->in_scale; g.in_shift = d->in_shift; g.act = d->act;
     g.noise = (const bf16_t*)d->noise; g.npad = d->noise ? d->noise_pad : 0;
     g.istr = d->istr; g.pad_mode = d->pad_mode; g.ntaps = d->ntaps; g.CK = CK;
+    g.wpack = d->wpack; g.wmin = d->wpack_wmin; g.Cw = d->wpack ? d->wpack : Cin; g.HWx = 0;
+    if (d->wpack) {
+        if (Cin != 1 || d->wpack < 2 || d->wpack > 8) return VG_EINVAL;
+        for (int i = 0; i < d->ntaps; ++i) if (d->tap_w[i] != 0) return VG_EINVAL;
+    }
     int mn[3] = {127, 127, 127}, mx[3] = {-128, -128, -128};
     for (int i = 0; i < d->ntaps; ++i) {
         g.td[i] = d->tap_d[i]; g.th[i] = d->tap_h[i]; g.tw[i] = d->tap_w[i];
@@ -346,8 +421,8 @@ static inline int fill_gather(const vg_conv_desc* d, GatherIn& g, int CK, int BM
             if (tw < 8 && tw < capw) continue;
             for (int th = 1; th <= caph && tw * th <= BM; th <<= 1) {
                 const int td = BM / (tw * th);
-                const int hw_ = (tw - 1) * d->istr + ex[2], hh_ = (th - 1) * d->istr + ex[1];
-                int hwp_ = d->istr == 2 ? 2 * ((hw_ + 1) / 2) : hw_, hhp_ = hh_;
+                const int hw_ = d->wpack ? tw : (tw - 1) * d->istr + ex[2], hh_ = (th - 1) * d->istr + ex[1];
+                int hwp_ = (d->istr == 2 && !d->wpack) ? 2 * ((hw_ + 1) / 2) : hw_, hhp_ = hh_;
                 if (g.planar) pad_pitches(hh_, hw_, tw, th, d->istr, hhp_, hwp_);
                 long vol = (long)((td - 1) * d->istr + ex[0]) * hhp_ * hwp_;       // LDS image incl. pitch padding
                 if (td > capd) vol *= 4;          // overhang in D wastes whole planes: only when nothing else fits
@@ -360,7 +435,8 @@ static inline int fill_gather(const vg_conv_desc* d, GatherIn& g, int CK, int BM
     g.HD = (TD - 1) * d->istr + (mx[0] - mn[0]) + 1;
     g.HH = (TH - 1) * d->istr + (mx[1] - mn[1]) + 1;
     g.HW = (TW - 1) * d->istr + (mx[2] - mn[2]) + 1;
-    g.HWh = d->istr == 2 ? (g.HW + 1) / 2 : 0;
+    if (d->wpack) { g.HWx = (TW - 1) * d->istr + d->wpack; g.HW = TW; }
+    g.HWh = (d->istr == 2 && !d->wpack) ? (g.HW + 1) / 2 : 0;
     g.HHp = g.HH; g.HWp = g.HWh ? 2 * g.HWh : g.HW;
     if (g.planar) pad_pitches(g.HH, g.HW, TW, TH, d->istr, g.HHp, g.HWp);
     if (g.planar) {
@@ -372,4 +448,4 @@ static inline int fill_gather(const vg_conv_desc* d, GatherIn& g, int CK, int BM
 }
 static inline int halo_bytes(const GatherIn& g) { return g.planar ? (g.CK >> 3) * g.PSB : g.HD * g.DS; }
 // LDS ints of the staging tables (column table + per-tile axis tables)
-static inline int stage_table_ints(const GatherIn& g) { return 2 * stage_ncols(g) + 6 * (g.HH + g.HW); }   // column table + two axis-table buffers
+static inline int stage_table_ints(const GatherIn& g) { return 2 * stage_ncols(g) + 6 * stage_axis_len(g); }   // column table + two axis-table buffers

@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256, (RMAX * Q >= VG_WGRAD_2W ? 2 : 3)) void wgrad_
     float* scs = (float*)((char*)tapoff + 512);
     int* utab = (int*)(scs + 2 * g.CK);
     int* rtab = utab + 2 * stage_ncols(g);
-    const int RTN = 3 * (g.HH + g.HW);               // two axis-table buffers: tile t+1 is resolved while tile t is staged
+    const int RTN = 3 * stage_axis_len(g);               // two axis-table buffers: tile t+1 is resolved while tile t is staged
     int* ktab = rtab + 2 * RTN;                      // [BM/32][64 lanes]{r0, r1}: halo byte offsets of the transposed reads
 
     if (tid < g.ntaps)
@@ -272,8 +272,8 @@ __global__ __launch_bounds__(256, (RMAX * Q >= VG_WGRAD_2W ? 2 : 3)) void wgrad_
             if (co >= p.Cout) continue;
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                if (ci0 + e < g.Cin) {
-                    const size_t i = ((size_t)tapsrc[tap] * g.Cin + ci0 + e) * p.Cout + co;
+                if (ci0 + e < g.Cw) {
+                    const size_t i = ((size_t)tapsrc[tap] * g.Cw + ci0 + e) * p.Cout + co;
                     if (p.part) p.part[(size_t)blockIdx.x * p.dw_elems + i] = acc[j][q][e];
                     else atomicAdd(&p.dw[i], acc[j][q][e]);
                 }
@@ -389,7 +389,7 @@ extern "C" int vg_conv3d_wgrad(const vg_conv_desc* d, const void* dy, int dy_f32
     int bx = wg_target / by; if (bx < 1) bx = 1; if (bx > k.total_tiles) bx = k.total_tiles;
     // many workgroups per dW element: float atomics on a few-KB dW serialise (measured 0.7 ms on a 27 KB dW from 1024
     // workgroups), so each workgroup column stores its slab to a private partial buffer that a second kernel sums
-    k.dw_elems = T_total * Cin * d->Cout;
+    k.dw_elems = T_total * (d->wpack ? d->wpack : Cin) * d->Cout;     // W-packed single-channel source: T_total = k*k taps of k pseudo-channels
     k.part = nullptr;
     if (bx > 8 && scratch && (int64_t)bx * k.dw_elems * 4 <= scratch_bytes) k.part = scratch;
     const dim3 grid(bx, by, 1);

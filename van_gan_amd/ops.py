@@ -201,11 +201,20 @@ class ConvLayer:
             self.pad_mode = PAD_ZERO
         T = k * k * k
         # ---- forward ----
-        self.f_taps = [(a - self.pb[0], b - self.pb[1], c - self.pb[2]) for a in range(k) for b in range(k) for c in range(k)]
+        # single-channel source with k > 1: W-packed (include/vangan_hip.h: wpack) -- the k taps along W become k
+        # pseudo-channels, k*k (d, h) taps remain; the DHWIO kernel is read as [k*k][k][cout] without moving a byte
+        self.wpack = k if (cin == 1 and 1 < k <= 8 and os.environ.get('VG_WPACK', '1') != '0') else 0
+        if self.wpack:
+            self.f_taps = [(a - self.pb[0], b - self.pb[1], 0) for a in range(k) for b in range(k)]
+            self.f_T, self.f_cin = k * k, k
+        else:
+            self.f_taps = [(a - self.pb[0], b - self.pb[1], c - self.pb[2]) for a in range(k) for b in range(k) for c in range(k)]
+            self.f_T, self.f_cin = T, cin
+        T = self.f_T
         self.f_idx_host = (C.c_int32 * T)(*range(T))
         self.f_idx = torch.arange(T, dtype=torch.int32, device=dev)
-        self.f_ck = self._pick_ck(cin, self.f_taps, stride, in_dims, self.out_dims, cout)
-        self.f_ktot = check(lib.vg_packed_ktot(T, cin, self.f_ck), 'vg_packed_ktot')
+        self.f_ck = self._pick_ck(cin, self.f_taps, stride, in_dims, self.out_dims, cout, wpack=self.wpack)
+        self.f_ktot = check(lib.vg_packed_ktot(T, self.f_cin, self.f_ck), 'vg_packed_ktot')
         self.f_wp = torch.zeros(lib.vg_packed_rows(cout), self.f_ktot, dtype=dtype, device=dev)
         # ---- data gradient: one class per output parity; buffer = padded grid for 'reflect' ----
         self.d_classes = []
@@ -268,8 +277,9 @@ class ConvLayer:
                 c['idx'] = torch.tensor(c['idx_list'], dtype=torch.int32, device=dev)
                 c['wp'] = torch.zeros(lib.vg_packed_rows(cin), c['ktot'], dtype=dtype, device=dev)
 
-    def _pick_ck(self, C_, taps, istr, in_dims, iters, rows) -> int:
+    def _pick_ck(self, C_, taps, istr, in_dims, iters, rows, wpack=0) -> int:
         d = ConvDesc()
+        d.wpack, d.wpack_wmin = wpack, -self.pb[2]
         d.src0 = d.out = d.wpacked = 1 << 20
         d.c_src0, d.c_src1, d.N = C_, 0, 1
         d.D, d.H, d.W = in_dims
@@ -300,26 +310,27 @@ class ConvLayer:
 
     def pack_items(self):
         """(w, tap_idx, out, Cin, Cout, ntaps, transpose, CK, f32) of every packed operand, for PackTable."""
-        T = self.k ** 3
-        items = [(self.w, self.f_idx, self.f_wp, self.cin, self.cout, T, 0, self.f_ck, self.f32)]
+        T = self.f_T
+        items = [(self.w, self.f_idx, self.f_wp, self.f_cin, self.cout, T, 0, self.f_ck, self.f32)]
         for c in self.d_classes:
             items.append((self.w, c['idx'], c['wp'], self.cin, self.cout, len(c['taps']), 1, c['ck'], self.f32))
         return items
 
     def pack(self):
         """fp32 master weights -> bf16 packed operands (after every optimizer step)."""
-        T = self.k ** 3
+        T = self.f_T
         s = stream()
-        check(lib.vg_pack_weights(_p(self.w), T, self.cin, self.cout, _p(self.f_idx), T, 0, self.f_ck, _p(self.f_wp),
+        check(lib.vg_pack_weights(_p(self.w), T, self.f_cin, self.cout, _p(self.f_idx), T, 0, self.f_ck, _p(self.f_wp),
                                   self.f32, s), 'pack')
         for c in self.d_classes:
-            check(lib.vg_pack_weights(_p(self.w), T, self.cin, self.cout, _p(c['idx']), len(c['taps']), 1, c['ck'],
+            check(lib.vg_pack_weights(_p(self.w), self.k ** 3, self.cin, self.cout, _p(c['idx']), len(c['taps']), 1, c['ck'],
                                       _p(c['wp']), self.f32, s), 'pack')
 
     def _fwd_desc(self, src: Src) -> ConvDesc:
         d = ConvDesc()
         src.fill(d)
         d.istr, d.pad_mode = self.stride, self.pad_mode
+        d.wpack, d.wpack_wmin = self.wpack, -self.pb[2]
         _set_taps(d, self.f_taps)
         d.OD, d.OH, d.OW = self.out_dims
         d.ostr, d.ooff_d, d.ooff_h, d.ooff_w = 1, 0, 0, 0
@@ -362,7 +373,7 @@ class ConvLayer:
         sc = WGRAD_SCRATCH.get(key)
         if sc is None:
             sc = WGRAD_SCRATCH[key] = torch.empty(64 << 20, dtype=torch.float32, device=dy.device)
-        check(lib.vg_conv3d_wgrad(C.byref(d), _p(dy), int(dy.dtype == torch.float32), self.f_idx_host, self.k ** 3,
+        check(lib.vg_conv3d_wgrad(C.byref(d), _p(dy), int(dy.dtype == torch.float32), self.f_idx_host, self.f_T,
                                   _p(self.gw), _p(self.gb), _p(sc), sc.numel() * 4, stream()), 'vg_conv3d_wgrad ' + self.name)
         if e0 is not None:
             esz = 4 if self.f32 else 2
