@@ -1,0 +1,96 @@
+"""The real engine under world_size 2 on ONE GPU (both ranks on cuda:0, gloo process group -- RCCL refuses two ranks on one
+device): exercises what the driver's multi-GPU runs do on the product path -- rank-0 weight broadcast, the four per-network
+gradient all-reduces issued from the two stream lanes onto the communication stream, Adam on the reduced buckets, SUM of the
+result dict -- and checks the data-parallel semantics of the reference (MirroredStrategy, vangan.py:426-438,472-490;
+loss_functions.py:7-22,226): every replica computes its losses on its LOCAL batch with the GLOBAL batch size in the
+denominators and lambda_topology / n_devices on the clDice term; gradients and result scalars are SUMMED.  (Note that this is
+NOT the same as one process with the two samples as a batch: the reference's reduce_mean(axis=None) terms -- cycle BCE, SSIM
+reconstruction -- average over the local batch before dividing by the global batch size, and clDice is a ratio of sums.)
+
+Expected values come from the same engine run as "rank r of 2" without a process group (n_devices=2, one sample, apply=False):
+gradients summed on the host, then one Adam step.  Exact-parity mode (fp32 storage), dropout/noise off.  Tolerances: only fp32
+summation orders differ (float atomics): losses rel 1e-4; updated weights: <= 0.2 % of the elements differ by more than 1e-4
+(Adam's first step is sign-like, so a ~0 gradient that flips sign moves a weight by 2*lr = 4e-4)."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DIMS = (32, 32, 32)
+
+WORKER = r'''
+import os, sys, torch
+import torch.distributed as dist
+sys.path.insert(0, %(root)r)
+from van_gan_amd.vangan import VanGan
+from oracle.vangan_oracle import synth_volumes
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+dist.init_process_group('gloo', rank=rank, world_size=world)
+eng = VanGan(%(dims)r, batch_size=1, n_devices=world, device='cuda:0', seed=rank * 17, layer_noise=0.0, dropout_rate=0.0,
+             process_group=dist.group.WORLD, precision='fp32')
+eng.broadcast_weights(0)
+rI, rS = synth_volumes(2, *%(dims)r, seed=5)
+res = None
+for _ in range(1):
+    res = eng.distributed_train_step(rI[rank:rank + 1].cuda(), rS[rank:rank + 1].cuda())
+torch.cuda.synchronize()
+torch.save({'w': {k: s.w.cpu() for k, s in eng.stores.items()}, 'res': res}, %(out)r %% rank)
+dist.destroy_process_group()
+'''
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def test_two_ranks_equal_one_process_with_batch_two(tmp_path):
+    from oracle.vangan_oracle import synth_volumes
+    from van_gan_amd.vangan import VanGan
+    out = str(tmp_path / 'rank%d.pt')
+    script = tmp_path / 'worker.py'
+    script.write_text(WORKER % dict(root=ROOT, dims=DIMS, out=out))
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            p.kill(); o, _ = p.communicate()
+        logs.append(o.decode()[-3000:])
+    assert all(p.returncode == 0 for p in procs), '\n'.join(logs)
+    a, b = torch.load(out % 0), torch.load(out % 1)
+    # every rank applied the same update
+    for k in a['w']:
+        assert torch.equal(a['w'][k], b['w'][k]), k
+    assert a['res'] == b['res']
+    # expectation: the same engine as "rank r of 2", no process group; gradients summed by hand
+    eng = VanGan(DIMS, batch_size=1, n_devices=2, device='cuda:0', seed=0, layer_noise=0.0, dropout_rate=0.0, precision='fp32')
+    rI, rS = synth_volumes(2, *DIMS, seed=5)
+    gsum, rsum = None, None
+    for r in range(2):
+        res = eng.train_step(rI[r:r + 1].cuda(), rS[r:r + 1].cuda(), apply=False)
+        g = {k: s.g.clone() for k, s in eng.stores.items()}
+        gsum = g if gsum is None else {k: gsum[k] + g[k] for k in g}
+        rsum = res if rsum is None else {k: rsum[k] + res[k] for k in res}
+    for k, s in eng.stores.items():
+        s.g.copy_(gsum[k])
+    eng._apply_adam()
+    torch.cuda.synchronize()
+    for k, v in rsum.items():
+        assert abs(a['res'][k] - v) <= 1e-4 * abs(v) + 1e-6, (k, a['res'][k], v)
+    bad = tot = 0
+    for k, s in eng.stores.items():
+        d = (s.w.cpu() - a['w'][k]).abs()
+        bad += int((d > 1e-4).sum()); tot += d.numel()
+    assert bad <= 2e-3 * tot, (bad, tot)
