@@ -90,6 +90,10 @@ CONV_CASES = [
     # zero padding, ragged extents, stride 2 with 'same' padding
     (3, 1, 16, 1, 'same', (6, 10, 12)),
     (4, 1, 32, 2, 'same', (7, 9, 11)),
+    # 1x1x1 with one channel on one side: the HBM-bound VALU kernels of vg_pointwise.hip (with (1, 16, 1) above: forward
+    # C->1 / 1->C with statistics, both weight gradients, both data gradients)
+    (1, 1, 16, 1, 'same', (8, 8, 16)),
+    (1, 32, 1, 1, 'same', (5, 6, 7)),
 ]
 
 

@@ -83,6 +83,10 @@ static inline int vg_check_launch() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? VG_OK : VG_ELAUNCH;
 }
+// vg_pointwise.hip: 1x1x1 convolutions with one channel on one side (HBM-bound VALU kernels).  Return VG_OK when the call
+// was served, 1 when the shape is not one of theirs (the caller continues on the MFMA path), < 0 on error.
+int vg_pointwise_conv(const vg_conv_desc* d, hipStream_t s);
+int vg_pointwise_wgrad(const vg_conv_desc* d, const void* dy, int dy_f32, int T_total, float* dw, float* db, hipStream_t s);
 static inline int ilog2_exact(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 static inline int pow2_ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

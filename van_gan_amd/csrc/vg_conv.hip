@@ -1014,6 +1014,10 @@ static int dispatch_conv(const GatherIn& g, const ConvOut& k, const ConvCls& q, 
 
 extern "C" int vg_conv3d(const vg_conv_desc* d, vg_stream_t stream) {
     vg_begin();
+    if (d && d->out && d->wpacked && d->src0) {           // 1x1x1 with a single channel on one side: HBM-bound VALU kernels
+        const int prc = vg_pointwise_conv(d, (hipStream_t)stream);
+        if (prc <= 0) return prc;
+    }
     GatherIn g; ConvOut k; ConvCls q; int BN, MSUB, lds;
     int rc = fill_conv(d, g, k, q, BN, MSUB, lds);
     if (rc != VG_OK) return rc;

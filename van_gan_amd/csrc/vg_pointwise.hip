@@ -1,0 +1,303 @@
+// vg_pointwise.hip -- the 1x1x1 convolutions with ONE channel on one side (gfx950), behind vg_conv3d / vg_conv3d_wgrad.
+//
+// resunet_model.py:240-249 output head  Conv3D(1, 1, activation='tanh')  (16 -> 1), its data gradient (1 -> 16) and weight
+// gradient, and the 1 -> 16 shortcut convolution of the stem (resunet_model.py:103-143 with a 1-channel input) have 16..32
+// FLOP per voxel: they are HBM-bound byte work.  On the MFMA path they used 1 of 16 rows or columns of every tile and ran at
+// ~3x their memory time (86 us for 75 MB at 128^3).  Here each is one pass: every byte read once, written once, 16-byte
+// accesses, reductions through LDS and one atomic per (block, value).
+//
+// Same arithmetic contract as the MFMA kernels: operands are the bf16 (or, in exact-parity mode, fp32) stored values and the
+// packed weights, on-read transform y = act(x * scale + shift) rounded to the storage type before the product (as the LDS
+// halo image is), dY rounded to the storage type, fp32 accumulation.
+#include "vg_common.h"
+#include <stdlib.h>
+
+namespace {
+
+struct PW {
+    const void* x; int x_f32;              // source: [N][S][C] of T, or single channel [N][S] of float / bf16
+    const float* scale; const float* shift; int act;
+    const void* w; int kc_pad, CK;         // packed weights (row-major [rows][Ktot])
+    const float* bias;
+    void* out; int out_f32, accumulate, tanh_out;
+    float* sums;                           // [VG_STRIPES][N][C][2] or NULL
+    const void* dy; int dy_f32;            // weight gradient
+    float* dw; float* db;
+    int N, C; int64_t S;
+};
+
+__device__ __forceinline__ float pw_slope(int act) { return act == VG_ACT_RELU ? 0.f : (act == VG_ACT_LRELU ? VG_LRELU : 1.f); }
+__device__ __forceinline__ float ld_single(const void* p, int f32, int64_t i) {
+    return f32 ? ld_global((const float*)p + i) : ld_global((const bf16_t*)p + i);
+}
+
+// ---- C -> 1 forward: one thread per voxel, UB voxels in flight -------------------------------------------------------
+template <typename T, int G>       // G = C / 8 channel groups
+__global__ __launch_bounds__(256) void pw_cto1_kernel(const PW p) {
+    const int n = blockIdx.y;
+    float wv[G * 8], sc[G * 8], sf[G * 8];
+#pragma unroll
+    for (int c = 0; c < G * 8; ++c) {
+        wv[c] = ld1<T>((const T*)p.w + (c / p.CK) * p.kc_pad + (c % p.CK));
+        sc[c] = p.scale ? p.scale[n * p.C + c] : 1.f;
+        sf[c] = p.scale ? p.shift[n * p.C + c] : 0.f;
+    }
+    const float slope = pw_slope(p.act), b = p.bias ? p.bias[0] : 0.f;
+    const T* xb = (const T*)p.x + (size_t)n * p.S * p.C;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    float s1 = 0.f, s2 = 0.f;
+    for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < p.S; v += 2 * stride) {
+        Raw8<T> r[2][G];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int64_t vv = v + k * stride < p.S ? v + k * stride : v;
+#pragma unroll
+            for (int g = 0; g < G; ++g) raw_load(r[k][g], xb + vv * p.C + g * 8);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (v + k * stride >= p.S) continue;
+            float a = b;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                float x[8]; raw_unpack(r[k][g], x);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float y = x[j] * sc[g * 8 + j] + sf[g * 8 + j];
+                    y = fmaxf(y, y * slope);
+                    a += rnd<T>(y) * wv[g * 8 + j];
+                }
+            }
+            const size_t o = (size_t)n * p.S + v + k * stride;
+            if (p.tanh_out && !p.accumulate) a = tanhf(a);
+            if (p.out_f32) { float* q = (float*)p.out + o; a = p.accumulate ? *q + a : a; *q = a; }
+            else { bf16_t* q = (bf16_t*)p.out + o; const bf16_t h = f2bf(p.accumulate ? bf2f(*q) + a : a); *q = h; a = bf2f(h); }
+            s1 += a; s2 += a * a;
+        }
+    }
+    if (p.sums) {                         // InstanceNorm statistics of the stored values
+        __shared__ float red[8];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+        if ((threadIdx.x & 63) == 0) { red[(threadIdx.x >> 6) * 2] = s1; red[(threadIdx.x >> 6) * 2 + 1] = s2; }
+        __syncthreads();
+        if (threadIdx.x < 2) {
+            const int stripe = blockIdx.x & (VG_STRIPES - 1);
+            atomicAdd(&p.sums[((size_t)stripe * gridDim.y + n) * 2 + threadIdx.x],
+                      red[threadIdx.x] + red[2 + threadIdx.x] + red[4 + threadIdx.x] + red[6 + threadIdx.x]);
+        }
+    }
+}
+
+// ---- 1 -> C forward / data gradient: thread = (voxel, 8-channel group) ------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void pw_1toc_kernel(const PW p) {
+    __shared__ float part[16 * 256];
+    const int n = blockIdx.y, tid = threadIdx.x;
+    const int gpc = p.C >> 3, vpb = 256 / gpc;
+    const int cg = tid % gpc, vl = tid / gpc;
+    const bool live = tid < gpc * vpb;
+    float wv[8], bv[8], s1[8], s2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        wv[j] = live ? ld1<T>((const T*)p.w + (size_t)(cg * 8 + j) * p.kc_pad) : 0.f;
+        bv[j] = (live && p.bias) ? p.bias[cg * 8 + j] : 0.f;
+        s1[j] = 0.f; s2[j] = 0.f;
+    }
+    const float sc = p.scale ? p.scale[n] : 1.f, sf = p.scale ? p.shift[n] : 0.f, slope = pw_slope(p.act);
+    const int64_t xoff = (int64_t)n * p.S;
+    T* ob = (T*)p.out + (size_t)n * p.S * p.C + cg * 8;
+    const int64_t stride = (int64_t)gridDim.x * vpb;
+    if (live)
+    for (int64_t v = (int64_t)blockIdx.x * vpb + vl; v < p.S; v += 4 * stride) {
+        float xs[4]; Raw8<T> old[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t vv = v + k * stride < p.S ? v + k * stride : v;
+            xs[k] = ld_single(p.x, p.x_f32, xoff + vv);
+            if (p.accumulate) raw_load(old[k], ob + vv * p.C);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (v + k * stride >= p.S) continue;
+            float y = xs[k] * sc + sf;
+            y = rnd<T>(fmaxf(y, y * slope));
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = y * wv[j] + bv[j];
+            if (p.accumulate) {
+                float q[8]; raw_unpack(old[k], q);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] += q[j];
+            }
+            store8<T>(ob + (v + k * stride) * p.C, o);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float r = rnd<T>(o[j]); s1[j] += r; s2[j] += r * r; }
+        }
+    }
+    if (!p.sums) return;
+    // block reduction (value-major LDS, fixed order), one atomic per (channel, moment) and block
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { part[(2 * j) * 256 + tid] = live ? s1[j] : 0.f; part[(2 * j + 1) * 256 + tid] = live ? s2[j] : 0.f; }
+    __syncthreads();
+    const int stripe = blockIdx.x & (VG_STRIPES - 1);
+    float* dst = p.sums + ((size_t)stripe * gridDim.y + n) * p.C * 2;
+    for (int o = tid; o < p.C * 2; o += 256) {
+        const int ch = o >> 1, mom = o & 1, g8 = ch >> 3, j = ch & 7;
+        const float* src = part + (2 * j + mom) * 256 + g8;
+        float a = 0.f;
+        for (int t = 0; t < vpb; ++t) a += src[t * gpc];
+        atomicAdd(&dst[o], a);
+    }
+}
+
+// ---- weight gradients: dW[c] = sum_v P[v,(c)] * dY[v,(c)], db = sum dY; one side single-channel ------------------------
+// MULTI_X: true = C -> 1 layer (x has C channels, dY one), false = 1 -> C layer (x one channel, dY C channels)
+template <typename T, bool MULTI_X>
+__global__ __launch_bounds__(256) void pw_wgrad_kernel(const PW p) {
+    __shared__ float part[16 * 256];
+    const int n = blockIdx.y, tid = threadIdx.x;
+    const int gpc = p.C >> 3, vpb = 256 / gpc;
+    const int cg = tid % gpc, vl = tid / gpc;
+    const bool live = tid < gpc * vpb;
+    float a[8], bsum[8], sc[8], sf[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        a[j] = 0.f; bsum[j] = 0.f;
+        const int ci = MULTI_X ? n * p.C + cg * 8 + j : n;
+        sc[j] = (p.scale && live) ? p.scale[ci] : 1.f; sf[j] = (p.scale && live) ? p.shift[ci] : 0.f;
+    }
+    const float slope = pw_slope(p.act);
+    const T* mb = (const T*)(MULTI_X ? p.x : p.dy) + (size_t)n * p.S * p.C + cg * 8;       // the multi-channel operand
+    const void* sb = MULTI_X ? p.dy : p.x;                                                  // the single-channel operand
+    const int sb_f32 = MULTI_X ? p.dy_f32 : p.x_f32;
+    const int64_t soff = (int64_t)n * p.S;
+    const int64_t stride = (int64_t)gridDim.x * vpb;
+    if (live)
+    for (int64_t v = (int64_t)blockIdx.x * vpb + vl; v < p.S; v += 4 * stride) {
+        Raw8<T> m[4]; float sv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t vv = v + k * stride < p.S ? v + k * stride : v;
+            raw_load(m[k], mb + vv * p.C);
+            sv[k] = ld_single(sb, sb_f32, soff + vv);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (v + k * stride >= p.S) continue;
+            float q[8]; raw_unpack(m[k], q);
+            if (MULTI_X) {
+                const float g = rnd<T>(sv[k]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { float y = q[j] * sc[j] + sf[j]; y = rnd<T>(fmaxf(y, y * slope)); a[j] += y * g; }
+                bsum[0] += g;
+            } else {
+                float y = sv[k] * sc[0] + sf[0]; y = rnd<T>(fmaxf(y, y * slope));
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { a[j] += y * q[j]; bsum[j] += q[j]; }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { part[(2 * j) * 256 + tid] = live ? a[j] : 0.f; part[(2 * j + 1) * 256 + tid] = live ? bsum[j] : 0.f; }
+    __syncthreads();
+    for (int o = tid; o < p.C * 2; o += 256) {
+        const int ch = o >> 1, mom = o & 1, g8 = ch >> 3, j = ch & 7;
+        const float* src = part + (2 * j + mom) * 256 + g8;
+        float s = 0.f;
+        for (int t = 0; t < vpb; ++t) s += src[t * gpc];
+        if (mom == 0) atomicAdd(&p.dw[ch], s);
+        else if (p.db) {
+            if (!MULTI_X) atomicAdd(&p.db[ch], s);
+            else if (ch == 0) {
+                // C -> 1: the bias gradient is the sum of dY; every channel group of the block counted its own voxels' dY in
+                // slot j = 0, so summing group 0's column alone covers each voxel once
+                atomicAdd(&p.db[0], s);
+            }
+        }
+    }
+}
+
+bool pw_enabled() {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("VG_PW"); on = e ? atoi(e) : 1; }
+    return on != 0;
+}
+// common shape test: one centre tap, unit strides, whole grid, plain single source
+bool pw_shape_ok(const vg_conv_desc* d) {
+    if (!pw_enabled() || d->ntaps != 1 || d->tap_d[0] || d->tap_h[0] || d->tap_w[0]) return false;
+    if (d->istr != 1 || d->src1 || d->c_src1 || d->src0_shift || d->noise || d->wpack || d->nclass > 1) return false;
+    if (d->OD != d->D || d->OH != d->H || d->OW != d->W) return false;
+    return true;
+}
+int pw_blocks(int64_t work_items, int N) {
+    int64_t b = (work_items + 255) / 256;
+    const int64_t cap = 2047 / (N > 0 ? N : 1);          // odd cap: see anb_grid (HBM channel aliasing of power-of-two strides)
+    if (b > cap) b = cap;
+    return b < 1 ? 1 : (int)b;
+}
+
+}  // namespace
+
+// returns VG_OK when the launch was done here, 1 when the shape is not one of the pointwise cases (caller continues), < 0 on error
+int vg_pointwise_conv(const vg_conv_desc* d, hipStream_t s) {
+    if (!pw_shape_ok(d) || d->res) return 1;
+    if (d->ostr != 1 || d->ooff_d || d->ooff_h || d->ooff_w || d->BD != d->OD || d->BH != d->OH || d->BW != d->OW) return 1;
+    const int Cin = d->c_src0;
+    PW p = {};
+    p.x = d->src0; p.x_f32 = d->src_f32; p.scale = d->in_scale; p.shift = d->in_shift; p.act = d->act;
+    p.w = d->wpacked; p.CK = d->CK; p.kc_pad = ((d->CK + 31) / 32) * 32;
+    p.bias = d->bias; p.out = d->out; p.out_f32 = (d->out_f32 || d->f32) ? 1 : 0; p.accumulate = d->accumulate; p.tanh_out = d->tanh_out;
+    p.sums = d->out_sums; p.N = d->N; p.S = (int64_t)d->D * d->H * d->W;
+    if (d->Cout == 1 && Cin >= 8 && Cin <= 32 && (Cin % 8) == 0) {
+        p.C = Cin;
+        const dim3 grid(pw_blocks((p.S + 1) / 2, d->N), d->N);
+#define PW_CTO1(T)                                                                                                      \
+        switch (Cin / 8) {                                                                                              \
+            case 1: hipLaunchKernelGGL((pw_cto1_kernel<T, 1>), grid, dim3(256), 0, s, p); break;                        \
+            case 2: hipLaunchKernelGGL((pw_cto1_kernel<T, 2>), grid, dim3(256), 0, s, p); break;                        \
+            case 3: hipLaunchKernelGGL((pw_cto1_kernel<T, 3>), grid, dim3(256), 0, s, p); break;                        \
+            default: hipLaunchKernelGGL((pw_cto1_kernel<T, 4>), grid, dim3(256), 0, s, p); break;                       \
+        }
+        if (d->f32) { PW_CTO1(float) } else { PW_CTO1(bf16_t) }
+#undef PW_CTO1
+        return vg_check_launch();
+    }
+    if (Cin == 1 && d->Cout >= 8 && d->Cout <= 256 && (d->Cout % 8) == 0 && !d->tanh_out && !(d->out_f32 && !d->f32)) {
+        p.C = d->Cout;
+        p.kc_pad = ((d->CK + 31) / 32) * 32;                 // one tap, one chunk: row stride of the packed operand
+        const int vpb = 256 / (p.C >> 3);
+        const dim3 grid(pw_blocks((p.S + 3) / 4 * 256 / vpb / 1, d->N), d->N);
+        if (d->f32) hipLaunchKernelGGL((pw_1toc_kernel<float>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((pw_1toc_kernel<bf16_t>), grid, dim3(256), 0, s, p);
+        return vg_check_launch();
+    }
+    return 1;
+}
+
+int vg_pointwise_wgrad(const vg_conv_desc* d, const void* dy, int dy_f32, int T_total, float* dw, float* db, hipStream_t s) {
+    if (!pw_shape_ok(d) || T_total != 1) return 1;
+    const int Cin = d->c_src0;
+    PW p = {};
+    p.x = d->src0; p.x_f32 = d->src_f32; p.scale = d->in_scale; p.shift = d->in_shift; p.act = d->act;
+    p.dy = dy; p.dy_f32 = dy_f32; p.dw = dw; p.db = db; p.N = d->N; p.S = (int64_t)d->D * d->H * d->W;
+    const bool c_to_1 = d->Cout == 1 && Cin >= 8 && Cin <= 256 && (Cin % 8) == 0;
+    const bool one_to_c = Cin == 1 && d->Cout >= 8 && d->Cout <= 256 && (d->Cout % 8) == 0 && !(dy_f32 && !d->f32);
+    if (!c_to_1 && !one_to_c) return 1;
+    p.C = c_to_1 ? Cin : d->Cout;
+    const int vpb = 256 / (p.C >> 3);
+    // few blocks: every block ends with 2*C same-address atomics (the reason the MFMA weight gradient uses partial slabs)
+    int64_t b = (p.S + (int64_t)vpb * 16 - 1) / ((int64_t)vpb * 16);
+    const int64_t cap = 511 / d->N > 0 ? 511 / d->N : 1;
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    const dim3 grid((int)b, d->N);
+    if (c_to_1) {
+        if (d->f32) hipLaunchKernelGGL((pw_wgrad_kernel<float, true>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((pw_wgrad_kernel<bf16_t, true>), grid, dim3(256), 0, s, p);
+    } else {
+        if (d->f32) hipLaunchKernelGGL((pw_wgrad_kernel<float, false>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((pw_wgrad_kernel<bf16_t, false>), grid, dim3(256), 0, s, p);
+    }
+    return vg_check_launch();
+}

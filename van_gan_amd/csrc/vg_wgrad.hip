@@ -337,6 +337,10 @@ extern "C" int vg_conv3d_wgrad(const vg_conv_desc* d, const void* dy, int dy_f32
     if (!d || !dy || !dw || !tap_idx_host) return VG_EINVAL;
     if (d->Cout < 1 || (d->Cout != 1 && (d->Cout % 8))) return VG_EINVAL;
     if (dy_f32 && d->Cout != 1 && !d->f32) return VG_EINVAL;
+    if (d->src0 && tap_idx_host[0] == 0) {
+        const int prc = vg_pointwise_wgrad(d, dy, dy_f32, T_total, dw, db, (hipStream_t)stream);
+        if (prc <= 0) return prc;
+    }
     const int Cin = d->c_src0 + d->c_src1;
     const int Cinp = ((Cin + 15) / 16) * 16, Coutp = ((d->Cout + 15) / 16) * 16;
     const int COB = Coutp >= 64 ? 64 : (Coutp >= 32 ? 32 : 16);
