@@ -151,6 +151,58 @@ __global__ __launch_bounds__(256) void pw_1toc_kernel(const PW p) {
     }
 }
 
+// ---- Cin (8 or 16) -> C, plain source (the data gradient of a 1x1x1 shortcut convolution, decoder level 0: 16 -> 48 at 128^3,
+// accumulated into the concat gradient): thread = (voxel, 8-channel output group), its Cin x 8 weights live in registers
+template <typename T, int GI>
+__global__ __launch_bounds__(256) void pw_ctoc_kernel(const PW p, int Cin, int Ktot) {
+    const int n = blockIdx.y, tid = threadIdx.x;
+    const int gpc = p.C >> 3, vpb = 256 / gpc;
+    const int cg = tid % gpc, vl = tid / gpc;
+    if (tid >= gpc * vpb) return;
+    float wv[GI * 8][8], bv[8];
+#pragma unroll
+    for (int k = 0; k < GI * 8; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            wv[k][j] = ld1<T>((const T*)p.w + (size_t)(cg * 8 + j) * Ktot + (k / p.CK) * p.kc_pad + (k % p.CK));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bv[j] = p.bias ? p.bias[cg * 8 + j] : 0.f;
+    const T* xb = (const T*)p.x + (size_t)n * p.S * Cin;
+    T* ob = (T*)p.out + (size_t)n * p.S * p.C + cg * 8;
+    const int64_t stride = (int64_t)gridDim.x * vpb;
+    for (int64_t v = (int64_t)blockIdx.x * vpb + vl; v < p.S; v += 2 * stride) {
+        Raw8<T> xr[2][GI], old[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int64_t vv = v + k * stride < p.S ? v + k * stride : v;
+#pragma unroll
+            for (int g = 0; g < GI; ++g) raw_load(xr[k][g], xb + vv * Cin + g * 8);
+            if (p.accumulate) raw_load(old[k], ob + vv * p.C);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (v + k * stride >= p.S) continue;
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = bv[j];
+#pragma unroll
+            for (int g = 0; g < GI; ++g) {
+                float x[8]; raw_unpack(xr[k][g], x);
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] += x[e] * wv[g * 8 + e][j];
+            }
+            if (p.accumulate) {
+                float q[8]; raw_unpack(old[k], q);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] += q[j];
+            }
+            store8<T>(ob + (v + k * stride) * p.C, o);
+        }
+    }
+}
+
 // ---- weight gradients: dW[c] = sum_v P[v,(c)] * dY[v,(c)], db = sum dY; one side single-channel ------------------------
 // MULTI_X: true = C -> 1 layer (x has C channels, dY one), false = 1 -> C layer (x one channel, dY C channels)
 template <typename T, bool MULTI_X>
@@ -270,6 +322,22 @@ int vg_pointwise_conv(const vg_conv_desc* d, hipStream_t s) {
         const dim3 grid(pw_blocks((p.S + 3) / 4 * 256 / vpb / 1, d->N), d->N);
         if (d->f32) hipLaunchKernelGGL((pw_1toc_kernel<float>), grid, dim3(256), 0, s, p);
         else hipLaunchKernelGGL((pw_1toc_kernel<bf16_t>), grid, dim3(256), 0, s, p);
+        return vg_check_launch();
+    }
+    if ((Cin == 8 || Cin == 16) && d->Cout >= 16 && d->Cout <= 128 && (d->Cout % 8) == 0 && !d->in_scale && d->act == VG_ACT_NONE
+        && !d->tanh_out && !d->out_sums && !d->src_f32 && !(d->out_f32 && !d->f32)) {
+        p.C = d->Cout;
+        const int nchunks = (Cin + d->CK - 1) / d->CK;
+        const int Ktot = nchunks * p.kc_pad;
+        const int vpb = 256 / (p.C >> 3);
+        const dim3 grid(pw_blocks((p.S + 1) / 2 * (256 / vpb), d->N), d->N);
+        if (d->f32) {
+            if (Cin == 8) hipLaunchKernelGGL((pw_ctoc_kernel<float, 1>), grid, dim3(256), 0, s, p, Cin, Ktot);
+            else hipLaunchKernelGGL((pw_ctoc_kernel<float, 2>), grid, dim3(256), 0, s, p, Cin, Ktot);
+        } else {
+            if (Cin == 8) hipLaunchKernelGGL((pw_ctoc_kernel<bf16_t, 1>), grid, dim3(256), 0, s, p, Cin, Ktot);
+            else hipLaunchKernelGGL((pw_ctoc_kernel<bf16_t, 2>), grid, dim3(256), 0, s, p, Cin, Ktot);
+        }
         return vg_check_launch();
     }
     return 1;
