@@ -1,0 +1,38 @@
+"""MFMA-pipe utilisation of the gather-convolution family from one rocprofv3 PMC pass:
+    VG_LANES=0 VG_SIDE_STREAM=0 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace \
+        --output-format csv -d <dir> -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline
+usage: python tools/mfma_pmc.py <dir> <out.json>"""
+import csv
+import glob
+import json
+import sys
+
+
+def main():
+    d, out = sys.argv[1:3]
+    f = glob.glob(d + '/**/*counter_collection.csv', recursive=True)[0]
+    raw = {'other': {}, 'conv': {}, 'wgrad': {}}
+    for r in csv.DictReader(open(f)):
+        n = r['Kernel_Name']
+        fam = 'wgrad' if 'wgrad_kernel' in n else ('conv' if ('conv_kernel' in n or 'conv32_kernel' in n) else 'other')
+        raw[fam][r['Counter_Name']] = raw[fam].get(r['Counter_Name'], 0.0) + float(r['Counter_Value'])
+
+    def util(fams):
+        busy = sum(raw[k].get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) for k in fams)
+        act = sum(raw[k].get('GRBM_GUI_ACTIVE', 0.0) for k in fams)
+        return busy / (1024 * act / 8) if act else None
+
+    json.dump({
+        'command': 'VG_LANES=0 VG_SIDE_STREAM=0 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE '
+                   '--kernel-trace --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline   (tools/mfma_pmc.py)',
+        'note': 'sums over the dispatches of 2 train steps (128^3, batch 1). MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x '
+                'GRBM_GUI_ACTIVE / 8 XCDs): busy MFMA-pipe cycles over available SIMD cycles while the kernel family runs (includes the '
+                'zero-padded channels/taps the kernels multiply, so it sits above the algorithmic fraction of bench.py)',
+        'raw': raw,
+        'mfma_utilisation': {'conv_kernel+conv32_kernel': util(['conv']), 'wgrad_kernel': util(['wgrad']), 'conv family': util(['conv', 'wgrad'])},
+    }, open(out, 'w'), indent=1)
+    print(open(out).read()[-400:])
+
+
+if __name__ == '__main__':
+    main()
