@@ -855,7 +855,12 @@ static int fill_conv(const vg_conv_desc* d, GatherIn& g, ConvOut& k, ConvCls& q,
             }
             // score: reaching 512 workgroups dominates, then work per workgroup-tile (bn*ms), then small LDS
             const long fill = wgs >= 512 ? 512 : wgs;
-            const long score = fill * 100000 + (long)bn * ms * 100 + (need <= 80 * 1024 ? 50 : 0);
+            // (useful channels per panel, not the panel width: a 64-wide panel on 48 or 96 output channels multiplies zeros in a
+            // quarter of its MFMAs -- there the 32-wide panel with the twice larger voxel tile wins: 16->48 data gradient at 128^3
+            // 0.36 -> 0.32 ms)
+            const int ny_ = (d->Cout + bn - 1) / bn;
+            const long useful = (long)((d->Cout + ny_ - 1) / ny_) * ms;
+            const long score = fill * 100000 + useful * 100 + (need <= 80 * 1024 ? 50 : 0);
             if (score > best_score) { best_score = score; best_bn = bn; best_ms = ms; best_wl = wl; best_lds = need; best_dma = dma; found = 1; }
         }
     }
