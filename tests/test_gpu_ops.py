@@ -94,6 +94,8 @@ CONV_CASES = [
     # C->1 / 1->C with statistics, both weight gradients, both data gradients)
     (1, 1, 16, 1, 'same', (8, 8, 16)),
     (1, 32, 1, 1, 'same', (5, 6, 7)),
+    # 3x3x3 single-channel stem convolution on its VALU kernels: ragged W (quads of 4 voxels with a masked tail)
+    (3, 1, 16, 1, 'reflect', (5, 6, 10)),
 ]
 
 

@@ -270,6 +270,203 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const PW p) {
     }
 }
 
+// ---- single-channel source, 3x3x3 taps (the stem convolution 1 -> 16, resunet_model.py:44-60): 27 x 16 MACs per voxel are
+// VALU work next to 4 + 32 bytes of traffic.  A thread owns 4 consecutive voxels along W and 8 output channels; the 3x3x6
+// source window lives in registers, the weights come from LDS as broadcast reads shared by the 4 voxels.
+struct C1K3 {
+    const void* x; int x_f32; float sc, sf; int act, pad_mode;
+    int D, H, W, C, W4;                     // C = Cout, W4 = quads per row
+    int td0, th0, tw0;                      // offset of the first tap per axis (-pad_before)
+    const void* w; int Ktot, CK;            // packed [Cout][Ktot], k = tap * CK + j  (W-packed layout)
+    const float* bias; void* out; float* sums;
+    const void* dy; float* dw; float* db;
+    const float* scale; const float* shift;
+};
+__device__ __forceinline__ int c1_resolve(int p, int n, int reflect, bool& ok) {
+    ok = true;
+    if (reflect) { if (p < 0) p = -p; if (p >= n) p = 2 * n - 2 - p; return p < 0 ? 0 : (p >= n ? n - 1 : p); }
+    ok = p >= 0 && p < n;
+    return ok ? p : 0;
+}
+// loads the rows (a, b) x 6 columns of the source window of quad (d, h, w0): NA d-offsets starting at a0
+// S = element type of the single-channel source (a run-time switch here would put every load under a branch, and the compiler
+// drains vmcnt at each of them)
+template <typename T, typename S, int NA>
+__device__ __forceinline__ void c1_window(const C1K3& p, int n, int d, int h, int w0, int a0, float (&xv)[NA][3][6]) {
+    const bool refl = p.pad_mode == VG_PAD_REFLECT;
+    const float slope = pw_slope(p.act);
+    int cw[6]; bool okw[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) cw[i] = c1_resolve(w0 + p.tw0 + i, p.W, refl, okw[i]);
+    const int64_t base = (int64_t)n * p.D * p.H * p.W;
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+        bool okd; const int rd = c1_resolve(d + p.td0 + a0 + a, p.D, refl, okd);
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            bool okh; const int rh = c1_resolve(h + p.th0 + b, p.H, refl, okh);
+            const int64_t row = base + ((int64_t)rd * p.H + rh) * p.W;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) xv[a][b][i] = ld_global((const S*)p.x + row + cw[i]);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                float y = xv[a][b][i] * p.sc + p.sf;
+                y = rnd<T>(fmaxf(y, y * slope));
+                xv[a][b][i] = (okd && okh && okw[i]) ? y : 0.f;
+            }
+        }
+    }
+}
+
+template <typename T, typename S>
+__global__ __launch_bounds__(256, 3) void c1k3_fwd_kernel(C1K3 p) {
+    __shared__ float wl[27 * 32];                 // [tap(a,b)][j][co], Cout <= 32
+    __shared__ float part[16 * 256];
+    const int n = blockIdx.y, tid = threadIdx.x;
+    const int gpc = p.C >> 3, qpb = 256 / gpc;
+    const int cg = tid % gpc, ql = tid / gpc;
+    const bool live = tid < gpc * qpb;
+    if (p.scale) { p.sc = p.scale[n]; p.sf = p.shift[n]; }
+    for (int i = tid; i < 27 * p.C; i += 256) {
+        const int co = i % p.C, tj = i / p.C, t = tj / 3, j = tj - t * 3;
+        wl[i] = ld1<T>((const T*)p.w + (size_t)co * p.Ktot + t * p.CK + j);
+    }
+    __syncthreads();
+    float bv[8], s1[8], s2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { bv[j] = (live && p.bias) ? p.bias[cg * 8 + j] : 0.f; s1[j] = 0.f; s2[j] = 0.f; }
+    const int64_t nq = (int64_t)p.D * p.H * p.W4;
+    if (live)
+    for (int64_t q = (int64_t)blockIdx.x * qpb + ql; q < nq; q += (int64_t)gridDim.x * qpb) {
+        const int wq = (int)(q % p.W4); const int64_t r = q / p.W4;
+        const int h = (int)(r % p.H), d = (int)(r / p.H), w0 = wq * 4;
+        float acc[4][8];
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[v][j] = bv[j];
+        // one d-offset at a time (not unrolled): the fully unrolled form hoisted all 54 weight reads and 54 window loads and
+        // needed 256 VGPRs (one wave per SIMD) or, capped, 1 KB of scratch per lane
+#pragma unroll 1
+        for (int a = 0; a < 3; ++a) {
+            float xv[1][3][6];
+            c1_window<T, S, 1>(p, n, d, h, w0, a, xv);
+#pragma unroll
+            for (int b = 0; b < 3; ++b)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const float* wp = wl + ((a * 3 + b) * 3 + j) * p.C + cg * 8;
+                    const f32x4 w0v = *(const f32x4*)wp, w1v = *(const f32x4*)(wp + 4);
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const float x = xv[0][b][v + j];
+                        acc[v][0] += x * w0v[0]; acc[v][1] += x * w0v[1]; acc[v][2] += x * w0v[2]; acc[v][3] += x * w0v[3];
+                        acc[v][4] += x * w1v[0]; acc[v][5] += x * w1v[1]; acc[v][6] += x * w1v[2]; acc[v][7] += x * w1v[3];
+                    }
+                }
+        }
+        T* ob = (T*)p.out + (((size_t)n * p.D + d) * p.H + h) * p.W * p.C + cg * 8;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            if (w0 + v >= p.W) continue;
+            store8<T>(ob + (size_t)(w0 + v) * p.C, acc[v]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float rr = rnd<T>(acc[v][j]); s1[j] += rr; s2[j] += rr * rr; }
+        }
+    }
+    if (!p.sums) return;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { part[(2 * j) * 256 + tid] = live ? s1[j] : 0.f; part[(2 * j + 1) * 256 + tid] = live ? s2[j] : 0.f; }
+    __syncthreads();
+    const int stripe = blockIdx.x & (VG_STRIPES - 1);
+    float* dst = p.sums + ((size_t)stripe * gridDim.y + n) * p.C * 2;
+    for (int o = tid; o < p.C * 2; o += 256) {
+        const int ch = o >> 1, mom = o & 1, g8 = ch >> 3, j = ch & 7;
+        const float* src = part + (2 * j + mom) * 256 + g8;
+        float a = 0.f;
+        for (int t = 0; t < qpb; ++t) a += src[t * gpc];
+        atomicAdd(&dst[o], a);
+    }
+}
+
+// weight gradient: thread = (quad, 8-channel group, d-offset a): 3 x 3 x 8 accumulators dW[a][b][j][c] (+ bias gradient in the
+// a = 0 role), reduced over the block through LDS in chunks of 20 values, one atomic per (block, value)
+template <typename T, typename S>
+__global__ __launch_bounds__(256) void c1k3_wgrad_kernel(C1K3 p) {
+    __shared__ float part[20 * 256];
+    const int n = blockIdx.y, tid = threadIdx.x;
+    const int gpc = p.C >> 3, roles = 3 * gpc, qpb = 256 / roles;
+    const int role = tid % roles, cg = role % gpc, a = role / gpc, ql = tid / roles;
+    const bool live = tid < roles * qpb;
+    if (p.scale) { p.sc = p.scale[n]; p.sf = p.shift[n]; }
+    float acc[80];                                  // [b][j][c] = 72, then 8 bias sums
+#pragma unroll
+    for (int i = 0; i < 80; ++i) acc[i] = 0.f;
+    const int64_t nq = (int64_t)p.D * p.H * p.W4;
+    if (live)
+    for (int64_t q = (int64_t)blockIdx.x * qpb + ql; q < nq; q += (int64_t)gridDim.x * qpb) {
+        const int wq = (int)(q % p.W4); const int64_t r = q / p.W4;
+        const int h = (int)(r % p.H), d = (int)(r / p.H), w0 = wq * 4;
+        float xv[1][3][6];
+        c1_window<T, S, 1>(p, n, d, h, w0, a, xv);
+        const T* yb = (const T*)p.dy + (((size_t)n * p.D + d) * p.H + h) * p.W * p.C + cg * 8;
+        Raw8<T> yr[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) raw_load(yr[v], yb + (size_t)min(w0 + v, p.W - 1) * p.C);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            float g[8]; raw_unpack(yr[v], g);
+            const bool okv = w0 + v < p.W;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) g[c] = okv ? g[c] : 0.f;
+#pragma unroll
+            for (int b = 0; b < 3; ++b)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const float x = xv[0][b][v + j];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) acc[(b * 3 + j) * 8 + c] += x * g[c];
+                }
+            if (a == 0) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) acc[72 + c] += g[c];
+            }
+        }
+    }
+#pragma unroll
+    for (int chunk = 0; chunk < 4; ++chunk) {          // unrolled: the accumulators must stay in registers (static indices)
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 20; ++i) part[i * 256 + tid] = live ? acc[chunk * 20 + i] : 0.f;
+        __syncthreads();
+        // outputs of this chunk: (role, i) -> sum over the block's quads
+        for (int o = tid; o < roles * 20; o += 256) {
+            const int i = o / roles, ro = o - i * roles;
+            const float* src = part + i * 256 + ro;
+            float sacc = 0.f;
+            for (int t = 0; t < qpb; ++t) sacc += src[t * roles];
+            const int val = chunk * 20 + i, rcg = ro % gpc, ra = ro / gpc;
+            if (val < 72) {
+                const int b = val / 24, j = (val / 8) % 3, c = val & 7;
+                atomicAdd(&p.dw[(size_t)(((ra * 3 + b) * 3) + j) * p.C + rcg * 8 + c], sacc);
+            } else if (ra == 0 && p.db) atomicAdd(&p.db[rcg * 8 + (val - 72)], sacc);
+        }
+    }
+}
+
+bool c1k3_fill(const vg_conv_desc* d, C1K3& p) {
+    if (d->c_src0 != 1 || d->src1 || d->c_src1 || d->wpack != 3 || d->ntaps != 9 || d->istr != 1 || d->noise || d->nclass > 1) return false;
+    if (d->Cout < 8 || d->Cout > 32 || (d->Cout % 8)) return false;
+    if (d->OD != d->D || d->OH != d->H || d->OW != d->W) return false;
+    for (int t = 0; t < 9; ++t)
+        if (d->tap_d[t] != d->tap_d[0] + t / 3 || d->tap_h[t] != d->tap_h[0] + t % 3 || d->tap_w[t] != 0) return false;
+    p.x = d->src0; p.x_f32 = d->src_f32; p.sc = 1.f; p.sf = 0.f; p.scale = d->in_scale; p.shift = d->in_shift; p.act = d->act;
+    p.pad_mode = d->pad_mode; p.D = d->D; p.H = d->H; p.W = d->W; p.C = d->Cout; p.W4 = (d->W + 3) / 4;
+    p.td0 = d->tap_d[0]; p.th0 = d->tap_h[0]; p.tw0 = d->wpack_wmin;
+    p.CK = d->CK; p.Ktot = ((9 * d->CK + 31) / 32) * 32;
+    return true;
+}
+
 bool pw_enabled() {
     static int on = -1;
     if (on < 0) { const char* e = getenv("VG_PW"); on = e ? atoi(e) : 1; }
@@ -293,6 +490,26 @@ int pw_blocks(int64_t work_items, int N) {
 
 // returns VG_OK when the launch was done here, 1 when the shape is not one of the pointwise cases (caller continues), < 0 on error
 int vg_pointwise_conv(const vg_conv_desc* d, hipStream_t s) {
+    if (pw_enabled() && !d->res && !d->tanh_out && !d->accumulate && d->ostr == 1 && !d->ooff_d && !d->ooff_h && !d->ooff_w
+        && d->BD == d->OD && d->BH == d->OH && d->BW == d->OW && !(d->out_f32 && !d->f32)) {
+        C1K3 c;
+        if (c1k3_fill(d, c)) {
+            c.w = d->wpacked; c.bias = d->bias; c.out = d->out; c.sums = d->out_sums;
+            const int qpb = 256 / (c.C >> 3);
+            int64_t b = ((int64_t)c.D * c.H * c.W4 + qpb - 1) / qpb;
+            const int64_t cap = 2047 / d->N > 0 ? 2047 / d->N : 1;
+            if (b > cap) b = cap;
+            const dim3 grid((int)b, d->N);
+            if (d->f32) {
+                if (d->src_f32) hipLaunchKernelGGL((c1k3_fwd_kernel<float, float>), grid, dim3(256), 0, s, c);
+                else hipLaunchKernelGGL((c1k3_fwd_kernel<float, bf16_t>), grid, dim3(256), 0, s, c);
+            } else {
+                if (d->src_f32) hipLaunchKernelGGL((c1k3_fwd_kernel<bf16_t, float>), grid, dim3(256), 0, s, c);
+                else hipLaunchKernelGGL((c1k3_fwd_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, s, c);
+            }
+            return vg_check_launch();
+        }
+    }
     if (!pw_shape_ok(d) || d->res) return 1;
     if (d->ostr != 1 || d->ooff_d || d->ooff_h || d->ooff_w || d->BD != d->OD || d->BH != d->OH || d->BW != d->OW) return 1;
     const int Cin = d->c_src0;
@@ -344,6 +561,26 @@ int vg_pointwise_conv(const vg_conv_desc* d, hipStream_t s) {
 }
 
 int vg_pointwise_wgrad(const vg_conv_desc* d, const void* dy, int dy_f32, int T_total, float* dw, float* db, hipStream_t s) {
+    if (pw_enabled() && T_total == 9 && !(dy_f32 && !d->f32)) {
+        C1K3 c;
+        if (c1k3_fill(d, c)) {
+            c.dy = dy; c.dw = dw; c.db = db;
+            const int qpb = 256 / (3 * (c.C >> 3));
+            int64_t b = ((int64_t)c.D * c.H * c.W4 + (int64_t)qpb * 8 - 1) / ((int64_t)qpb * 8);
+            const int64_t cap = 767 / d->N > 0 ? 767 / d->N : 1;
+            if (b > cap) b = cap;
+            if (b < 1) b = 1;
+            const dim3 grid((int)b, d->N);
+            if (d->f32) {
+                if (d->src_f32) hipLaunchKernelGGL((c1k3_wgrad_kernel<float, float>), grid, dim3(256), 0, s, c);
+                else hipLaunchKernelGGL((c1k3_wgrad_kernel<float, bf16_t>), grid, dim3(256), 0, s, c);
+            } else {
+                if (d->src_f32) hipLaunchKernelGGL((c1k3_wgrad_kernel<bf16_t, float>), grid, dim3(256), 0, s, c);
+                else hipLaunchKernelGGL((c1k3_wgrad_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, s, c);
+            }
+            return vg_check_launch();
+        }
+    }
     if (!pw_shape_ok(d) || T_total != 1) return 1;
     const int Cin = d->c_src0;
     PW p = {};
