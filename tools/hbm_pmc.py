@@ -16,7 +16,7 @@ def sums(d, counter):
         if r['Counter_Name'] != counter:
             continue
         name = r['Kernel_Name']
-        fam = 'conv' if any(k in name for k in ('conv_kernel', 'conv32_kernel', 'wgrad_kernel', 'pw_cto', 'pw_1toc', 'pw_wgrad')) else 'other'
+        fam = 'conv' if any(k in name for k in ('conv_kernel', 'conv32_kernel', 'wgrad_kernel', 'pw_cto', 'pw_1toc', 'pw_wgrad', 'c1k3_')) else 'other'
         kb[fam] += float(r['Counter_Value'])
         n[fam] += 1
     return kb, n
