@@ -105,11 +105,19 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit('launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ...'
                              % (args.gpus, args.gpus))
+    # VG_BENCH_ONE_DEVICE=1 (development aid): every rank on cuda:0 over gloo, so that the N > 1 code path of this file can be
+    # exercised on a 1-GPU box (RCCL refuses two ranks on one device).  Never set by the driver.
+    one_dev = os.environ.get('VG_BENCH_ONE_DEVICE', '0') == '1'
+    if one_dev:
+        local = 0
     torch.cuda.set_device(local)
     device = 'cuda:%d' % local
     pg = None
     if world > 1:
-        dist.init_process_group('nccl', device_id=torch.device(device))
+        if one_dev:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=torch.device(device))
         pg = dist.group.WORLD
 
     from van_gan_amd import VanGan, ops
@@ -147,11 +155,14 @@ def main():
     mvox = steps_per_s * gbatch * S / 1e6
 
     roof = None
-    if rank == 0 and not args.no_roofline:
+    summ = None
+    if not args.no_roofline:
+        # EVERY rank runs the per-launch timing step: it contains the gradient all-reduces, which must be matched on all ranks
         ops.PROF = ops.KernelProfile()
         eng.train_step(rI, rS, sync=True)
         summ = ops.PROF.summary()
         ops.PROF = None
+    if rank == 0 and summ is not None:
         tot_fl = sum(v['flops'] for v in summ.values())
         tot_ms = sum(v['ms'] for v in summ.values())
         n = sum(v['launches'] for v in summ.values())
