@@ -94,3 +94,23 @@ def test_two_ranks_equal_one_process_with_batch_two(tmp_path):
         d = (s.w.cpu() - a['w'][k]).abs()
         bad += int((d > 1e-4).sum()); tot += d.numel()
     assert bad <= 2e-3 * tot, (bad, tot)
+
+
+def test_bench_two_ranks_completes():
+    """bench.py under torch.distributed.run with 2 ranks (both on cuda:0 over gloo, VG_BENCH_ONE_DEVICE=1): the driver's
+    multi-GPU contract -- barrier-bracketed timed steps, MAX over ranks, the per-launch timing step on EVERY rank (it contains
+    the all-reduces: on rank 0 alone it dead-locked), one JSON line from rank 0."""
+    import json
+    env = dict(os.environ, VG_BENCH_ONE_DEVICE='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+           '--size', '32']
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = r.stdout.decode()
+    assert r.returncode == 0, out[-3000:]
+    lines = [l for l in out.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, out[-3000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['steps'] == 2 and d['scaling'] == 'weak' and d['value'] > 0
+    assert d['roofline'] is not None and d['cpu_baseline'] is None
+    assert d['config']['parallelism'] == 'dp2'
