@@ -497,7 +497,7 @@ int vg_pointwise_conv(const vg_conv_desc* d, hipStream_t s) {
             c.w = d->wpacked; c.bias = d->bias; c.out = d->out; c.sums = d->out_sums;
             const int qpb = 256 / (c.C >> 3);
             int64_t b = ((int64_t)c.D * c.H * c.W4 + qpb - 1) / qpb;
-            const int64_t cap = 2047 / d->N > 0 ? 2047 / d->N : 1;
+            const int64_t cap = (2047 / d->N) > 0 ? (2047 / d->N) : 1;
             if (b > cap) b = cap;
             const dim3 grid((int)b, d->N);
             if (d->f32) {
@@ -536,7 +536,7 @@ int vg_pointwise_conv(const vg_conv_desc* d, hipStream_t s) {
         p.C = d->Cout;
         p.kc_pad = ((d->CK + 31) / 32) * 32;                 // one tap, one chunk: row stride of the packed operand
         const int vpb = 256 / (p.C >> 3);
-        const dim3 grid(pw_blocks((p.S + 3) / 4 * 256 / vpb / 1, d->N), d->N);
+        const dim3 grid(pw_blocks((p.S + 3) / 4 * (256 / vpb), d->N), d->N);
         if (d->f32) hipLaunchKernelGGL((pw_1toc_kernel<float>), grid, dim3(256), 0, s, p);
         else hipLaunchKernelGGL((pw_1toc_kernel<bf16_t>), grid, dim3(256), 0, s, p);
         return vg_check_launch();
@@ -567,7 +567,7 @@ int vg_pointwise_wgrad(const vg_conv_desc* d, const void* dy, int dy_f32, int T_
             c.dy = dy; c.dw = dw; c.db = db;
             const int qpb = 256 / (3 * (c.C >> 3));
             int64_t b = ((int64_t)c.D * c.H * c.W4 + (int64_t)qpb * 8 - 1) / ((int64_t)qpb * 8);
-            const int64_t cap = 767 / d->N > 0 ? 767 / d->N : 1;
+            const int64_t cap = (767 / d->N) > 0 ? (767 / d->N) : 1;
             if (b > cap) b = cap;
             if (b < 1) b = 1;
             const dim3 grid((int)b, d->N);
@@ -593,7 +593,7 @@ int vg_pointwise_wgrad(const vg_conv_desc* d, const void* dy, int dy_f32, int T_
     const int vpb = 256 / (p.C >> 3);
     // few blocks: every block ends with 2*C same-address atomics (the reason the MFMA weight gradient uses partial slabs)
     int64_t b = (p.S + (int64_t)vpb * 16 - 1) / ((int64_t)vpb * 16);
-    const int64_t cap = 511 / d->N > 0 ? 511 / d->N : 1;
+    const int64_t cap = (511 / d->N) > 0 ? (511 / d->N) : 1;
     if (b > cap) b = cap;
     if (b < 1) b = 1;
     const dim3 grid((int)b, d->N);
