@@ -837,6 +837,9 @@ static int fill_conv(const vg_conv_desc* d, GatherIn& g, ConvOut& k, ConvCls& q,
         for (int ms = (bn == 16 ? max_ms16 : (bn == 32 ? 4 : 2)); ms >= 1; ms >>= 1) {
             if (force_msub && ms != force_msub) continue;
             if (ms == 8 && d->f32) continue;
+            // fused classes keep a second set of per-class state live: their 8-sub-tile variants spill ~80 VGPRs (324 B of
+            // scratch per lane) and lose to the next smaller tile (enc1.cb1 data gradient at 128^3: 0.144 -> 0.084 ms)
+            if (q.ncls > 1 && !q.par && (bn / 16) * ms >= 8) continue;
             rc = fill_gather(d, g, d->CK, 64 * ms);
             if (rc != VG_OK) return rc;
             const long wgs = (long)g.tiles_d * g.tiles_h * g.tiles_w * ((d->Cout + bn - 1) / bn) * d->N * (q.par ? q.ncls : 1);
