@@ -86,8 +86,8 @@ def bench_infer(args, device):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--size', type=int, default=128)
     ap.add_argument('--batch', type=int, default=1, help='per-GPU batch')
     ap.add_argument('--no-cpu-baseline', action='store_true')
