@@ -52,6 +52,9 @@ __device__ __forceinline__ void vec4_load(Vec4<float>& r, const float* p) { r.v 
 __device__ __forceinline__ void vec4_unpack(const Vec4<bf16_t>& r, float* o) { for (int j = 0; j < 4; ++j) o[j] = bf2f((bf16_t)r.v[j]); }
 __device__ __forceinline__ void vec4_unpack(const Vec4<float>& r, float* o) { for (int j = 0; j < 4; ++j) o[j] = r.v[j]; }
 
+#ifndef VG_CONV_MW2
+#define VG_CONV_MW2 4      // sub-tiles per wave from which a variant is compiled for 2 waves per SIMD (256 VGPRs)
+#endif
 #ifndef VG_CONV_WAVES
 #define VG_CONV_WAVES 3      // waves per SIMD the register allocation must allow (3 workgroups per CU)
 #endif
@@ -266,7 +269,7 @@ __device__ __forceinline__ void dma_transform(const GatherIn& g, char* hb, const
 // 2 = class-parallel: the workgroup serves the ONE class blockIdx.x % ncls (own taps / weights / output sub-lattice) and
 // walks the tiles with the remaining part of blockIdx.x -- the launch carries ncls times the workgroups of a per-class launch
 template <typename T, int BN, int MSUB, bool NOISE, bool WL, bool DMA, int MC, bool C1>
-__global__ __launch_bounds__(256, ((BN / 16) * MSUB >= 8 ? 2 : VG_CONV_WAVES)) void conv_kernel(const GatherIn g, const ConvOut p, const ConvCls q) {
+__global__ __launch_bounds__(256, ((BN / 16) * MSUB >= VG_CONV_MW2 ? 2 : VG_CONV_WAVES)) void conv_kernel(const GatherIn g, const ConvOut p, const ConvCls q) {
     static_assert(!(MC && DMA), "fused classes use the synchronous staging path");
     constexpr bool F32 = sizeof(T) == 4;
     // wave decomposition: WN waves along the channel panel (one 16-channel sub-tile each, so a weight fragment is
@@ -974,7 +977,7 @@ static int launch_conv3(const GatherIn& g, const ConvOut& k, const ConvCls& q, i
     // every further workgroup would repeat the per-workgroup prologue (weight panel, tables) for fewer tiles each
     static int wg_env = -1;
     if (wg_env < 0) { const char* e = getenv("VG_CONV_WGS"); wg_env = e ? atoi(e) : 0; }
-    int per_cu = ((BN / 16) * MSUB >= 8) ? 2 : VG_CONV_WAVES;
+    int per_cu = ((BN / 16) * MSUB >= VG_CONV_MW2) ? 2 : VG_CONV_WAVES;
     if (lds > 0 && VG_LDS_LIMIT / lds < per_cu) per_cu = VG_LDS_LIMIT / lds;
     if (per_cu < 1) per_cu = 1;
     const int wg_target = wg_env > 0 ? wg_env : 256 * per_cu;
