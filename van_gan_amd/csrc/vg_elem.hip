@@ -340,10 +340,11 @@ static dim3 anb_grid(const ANB& p, bool stats = false) {
     int bx = (S + p.vpb - 1) / p.vpb;
     static int cap_total = -1, cap_stats = -1;
     if (cap_total < 0) {
-        const char* e = getenv("VG_ANB_GRID_CAP"); cap_total = e ? atoi(e) : 2047;
-        const char* e2 = getenv("VG_ANB_STATS_CAP"); cap_stats = e2 ? atoi(e2) : 1023;
+        const char* e = getenv("VG_ANB_GRID_CAP"); cap_total = e ? atoi(e) : 767;
+        const char* e2 = getenv("VG_ANB_STATS_CAP"); cap_stats = e2 ? atoi(e2) : 511;
     }
-    // whole launch resident at once (8 blocks per CU): one block more than that runs alone afterwards and doubles the time.
+    // whole launch resident at once (the 8-channel kernels hold ~150 VGPRs: 3 blocks per CU = 768 slots; re-swept at the end of
+    // round 1: 767 / 511 beat the earlier 2047 / 1023 by ~0.5 % of the step): one block more than that runs alone afterwards.
     // The caps are odd on purpose: the UB voxels a thread has in flight are gridDim.x*vpb voxels apart, and with a
     // power-of-two grid on a power-of-two volume that is a power-of-two byte stride -- every in-flight load of the chip
     // then falls on the same HBM channels (measured at 128^3 x 16: stats 0.061 -> 0.046 ms, apply 0.053 -> 0.043 ms)
