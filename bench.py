@@ -29,7 +29,7 @@ CONV_FLOP_PER_VOXEL = 2530548.0    # 12 F_G + 14 F_D per voxel-sample
 
 def synth_on_device(B, dims, seed, device):
     """SURVEY 8d synthetic volumes, generated once on the host (setup, untimed) and moved to HBM."""
-    from oracle.vangan_oracle import synth_volumes     # input generator shared with the tests
+    from van_gan_amd.synth import synth_volumes        # same generator family as the parity tests (tests/test_data_oracle.py)
     rI, rS = synth_volumes(B, *dims, seed=seed)
     return rI.to(device), rS.to(device)
 

@@ -44,6 +44,9 @@ const char* vg_status_string(int code);
 /* diagnostic builds only: device buffer receiving s_memtime stamps of the conv kernel phases (NULL = off) */
 int vg_set_stamp_buffer(void* dev_u64);
 int vg_version(void);
+/* sizeof() of the descriptor structs as THIS library was compiled (which: 0 vg_conv_desc, 1 vg_actnorm_bwd_desc,
+ * 2 vg_pack_item; else VG_EINVAL): a binding that mirrors the structs by hand checks its layout at load time. */
+int vg_abi_sizeof(int which);
 
 /* ---------------------------------------------------------------------------------------------
  * Gather-convolution (implicit GEMM on bf16 MFMA).  One descriptor covers

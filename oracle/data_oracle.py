@@ -69,15 +69,23 @@ def process_imaging_otf(batch):
     return 2.0 * (batch - mn) / (mx - mn) - 1.0
 
 
-def learning_rate(initial_lr, epoch, step_in_epoch, epochs, initiate_decay, train_steps):
+def learning_rate(initial_lr, epoch, step_in_epoch, epochs, initiate_decay, train_steps, schedule_step='global_iterations'):
     """set_learning_rate (custom_callback.py:326-365): constant until epoch == INITIATE_LR_DECAY, then Keras
-    PolynomialDecay(power=1, end=0) over (EPOCHS - INITIATE_LR_DECAY) * train_steps optimizer steps (TP: the schedule's
-    step is the optimizer iteration count since it was installed)."""
+    PolynomialDecay(power=1, end=0, cycle=False) over decay_steps = (EPOCHS - INITIATE_LR_DECAY) * train_steps:
+        lr(step) = initial * (1 - min(step, decay_steps) / decay_steps)
+    TP (tf.keras 2.10 optimizer_v2._decayed_lr, restated from memory: ``local_step = cast(self.iterations); lr_t =
+    lr_t(local_step)``): the schedule's step is the optimizer's GLOBAL iteration count, which already equals
+    INITIATE_LR_DECAY * train_steps when the schedule is installed -- with the reference defaults (200 / 100) that is
+    decay_steps, so the learning rate is 0 from epoch 100 on.  schedule_step='since_install' is the
+    linear decay the authors presumably intended; it is NOT what the reference computes."""
     if epoch < initiate_decay:
         return initial_lr
     decay_steps = (epochs - initiate_decay) * train_steps
-    step = min((epoch - initiate_decay) * train_steps + step_in_epoch, decay_steps)
-    return initial_lr * (1.0 - step / decay_steps)
+    if schedule_step == 'global_iterations':
+        it = epoch * train_steps + step_in_epoch
+    else:
+        it = (epoch - initiate_decay) * train_steps + step_in_epoch
+    return initial_lr * (1.0 - min(it, decay_steps) / decay_steps)
 
 
 def discriminator_noise(init_noise, epoch, no_noise_epoch):
@@ -87,15 +95,20 @@ def discriminator_noise(init_noise, epoch, no_noise_epoch):
     return max(init_noise * (1.0 - decay_rate), 0.0)
 
 
-def learning_rate_resumed(initial_lr, resume_epoch, epoch, step_in_epoch, epochs, initiate_decay, train_steps):
+def learning_rate_resumed(initial_lr, resume_epoch, epoch, step_in_epoch, epochs, initiate_decay, train_steps,
+                          schedule_step='global_iterations'):
     """set_learning_rate's second branch (custom_callback.py:365-397), taken once when a checkpoint was loaded at an epoch
     past INITIATE_LR_DECAY: the decay restarts from INITIAL_LR / (EPOCHS - INITIATE) * (EPOCHS - resume_epoch) and runs
     over (EPOCHS - INITIATE - resume_epoch) * train_steps steps -- the reference subtracts BOTH, so the window is shorter
     than the epochs left (and empty or negative for resume_epoch >= EPOCHS - INITIATE; TP: Keras' PolynomialDecay then
-    divides by a non-positive decay_steps, which this restatement refuses)."""
+    divides by a non-positive decay_steps, which this restatement refuses).  Step: as in learning_rate (TP: the restored
+    optimizer.iterations, i.e. the global count)."""
     start = initial_lr / (epochs - initiate_decay) * (epochs - resume_epoch)
     decay_steps = (epochs - initiate_decay - resume_epoch) * train_steps
     if decay_steps <= 0:
         raise ValueError('reference schedule undefined: decay_steps <= 0')
-    step = min((epoch - resume_epoch) * train_steps + step_in_epoch, decay_steps)
-    return start * (1.0 - step / decay_steps)
+    if schedule_step == 'global_iterations':
+        it = epoch * train_steps + step_in_epoch
+    else:
+        it = (epoch - resume_epoch) * train_steps + step_in_epoch
+    return start * (1.0 - min(it, decay_steps) / decay_steps)

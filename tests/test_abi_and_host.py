@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(_lib.lib, name), 'libvangan_hip.so does not export %s' % name
     assert set(_lib.EXPORTS) == declared, (set(_lib.EXPORTS) ^ declared)
-    assert _lib.lib.vg_version() == 1
+    assert _lib.lib.vg_version() == 2
     assert _lib.lib.vg_status_string(-2).decode().startswith('tile')
 
 

@@ -1,0 +1,85 @@
+"""Reference-shaped constructor (van_gan_amd/compat.py, vangan.py:20-245): argument translation and error behaviour on
+the CPU with an injected engine factory; one real step through it on the GPU."""
+import argparse
+
+import numpy as np
+import pytest
+import torch
+
+
+def _args(**over):
+    a = argparse.Namespace(N_DEVICES=4, INPUT_IMG_SIZE=(1, 512, 512, 140, 1), CHANNELS=1, GLOBAL_BATCH_SIZE=12, DIMENSIONS=3,
+                           SUBVOL_PATCH_SIZE=(128, 128, 128), train_steps=50, BATCH_SIZE=3, output_dir=None)
+    for k, v in over.items():
+        setattr(a, k, v)
+    return a
+
+
+class _FakeEngine:
+    def __init__(self, **kw):
+        self.kw = kw
+        self.device = 'cpu'
+        self.layer_noise, self.lr, self.current_epoch, self.checkpoint_loaded = 0.1, 2e-4, 0, False
+        self.gen_IS = self.gen_SI = self.disc_I = self.disc_S = object()
+        self.calls = []
+
+    def distributed_train_step(self, x, y):
+        self.calls.append((x, y))
+        return {'gen_IS_loss': 1.0}
+
+
+def test_reference_arguments_are_translated():
+    from van_gan_amd.compat import VanGan
+    g = VanGan(_args(), None, gen_i2s='resUnet', gen_s2i='resUnet', engine_factory=_FakeEngine)
+    kw = g.eng.kw
+    assert kw['subvol_patch_size'] == (128, 128, 128) and kw['batch_size'] == 3 and kw['global_batch_size'] == 12
+    assert kw['n_devices'] == 4 and kw['lambda_cycle'] == 10.0 and kw['lambda_topology'] == 5.0
+    assert g.subvol_patch_size == (128, 128, 128, 1) and g.train_steps == 50 and g.icritic == 1 and g.ncritic == 5
+    # GanMonitor writes these through the wrapper (custom_callback.py:343-365, 422-424)
+    g.layer_noise = 0.05; g.current_epoch = 7; g.checkpoint_loaded = True
+    assert g.eng.layer_noise == 0.05 and g.eng.current_epoch == 7 and g.eng.checkpoint_loaded is True
+    # numpy / tf-like inputs become fp32 torch tensors on the engine's device
+    x = np.zeros((1, 4, 4, 4, 1), np.float64)
+
+    class TfLike:
+        def numpy(self):
+            return x
+    g.distributed_train_step(x, TfLike())
+    a, b = g.eng.calls[0]
+    assert a.dtype == torch.float32 and b.dtype == torch.float32 and tuple(b.shape) == (1, 4, 4, 4, 1)
+
+
+def test_cpu_box_n_devices_zero_means_one_replica():
+    """main.py on a box without visible GPUs: N_DEVICES = len(GPUs) = 0 and GLOBAL_BATCH_SIZE = 0."""
+    from van_gan_amd.compat import engine_kwargs_from_args
+    kw = engine_kwargs_from_args(_args(N_DEVICES=0, GLOBAL_BATCH_SIZE=0, BATCH_SIZE=2), gen_i2s='resUnet', gen_s2i='resUnet')
+    assert kw['n_devices'] == 1 and kw['global_batch_size'] == 2
+
+
+def test_error_behaviour_follows_the_reference():
+    from van_gan_amd.compat import VanGan, engine_kwargs_from_args
+    with pytest.raises(ValueError, match='IS Generator type not recognised'):          # vangan.py:124
+        VanGan(_args(), None, gen_i2s='unet++', gen_s2i='resUnet', engine_factory=_FakeEngine)
+    with pytest.raises(ValueError, match='SI Generator type not recognised'):          # vangan.py:164
+        VanGan(_args(), None, gen_i2s='resUnet', gen_s2i='nope', engine_factory=_FakeEngine)
+    # the constructor defaults of the reference select 'resnet' (main.py overrides them): known, not built
+    with pytest.raises(NotImplementedError):
+        VanGan(_args(), None, engine_factory=_FakeEngine)
+    with pytest.raises(NotImplementedError):
+        engine_kwargs_from_args(_args(), gen_i2s='resUnet', gen_s2i='resUnet', wasserstein=True)
+    with pytest.raises(NotImplementedError):
+        engine_kwargs_from_args(_args(DIMENSIONS=2), gen_i2s='resUnet', gen_s2i='resUnet')
+
+
+@pytest.mark.gpu
+def test_real_engine_through_the_reference_constructor(tmp_path):
+    from van_gan_amd.compat import VanGan
+    from van_gan_amd.vangan import RESULT_KEYS
+    from van_gan_amd.synth import synth_volumes
+    a = _args(N_DEVICES=0, GLOBAL_BATCH_SIZE=0, BATCH_SIZE=1, SUBVOL_PATCH_SIZE=(32, 32, 32), output_dir=str(tmp_path))
+    g = VanGan(a, None, gen_i2s='resUnet', gen_s2i='resUnet')
+    rI, rS = synth_volumes(1, 32, 32, 32, seed=3)
+    res = g.distributed_train_step(rI.numpy(), rS.numpy())
+    assert list(res) == RESULT_KEYS and all(np.isfinite(v) for v in res.values())
+    g.save_checkpoint(0)
+    assert g.load_checkpoint(1)

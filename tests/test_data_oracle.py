@@ -70,10 +70,20 @@ def test_schedules_known_answers(mod):
     # defaults of the reference: EPOCHS 200, INITIATE_LR_DECAY 100, lr 2e-4
     assert lr(2e-4, 0, 0, 200, 100, 50) == 2e-4
     assert lr(2e-4, 99, 49, 200, 100, 50) == 2e-4
-    assert lr(2e-4, 100, 0, 200, 100, 50) == 2e-4
-    assert math.isclose(lr(2e-4, 150, 0, 200, 100, 50), 1e-4, rel_tol=1e-12)
-    assert math.isclose(lr(2e-4, 199, 49, 200, 100, 50), 2e-4 / 5000, rel_tol=1e-9)
-    assert lr(2e-4, 200, 0, 200, 100, 50) == 0.0
+    # reference-exact (default): Keras evaluates PolynomialDecay at the optimizer's global iteration count, which equals
+    # decay_steps at the swap when EPOCHS - INITIATE == INITIATE  =>  the rate is 0 from epoch 100 on
+    assert lr(2e-4, 100, 0, 200, 100, 50) == 0.0
+    assert lr(2e-4, 150, 7, 200, 100, 50) == 0.0
+    # ... and a partial decay when the decay window is longer than the constant phase: EPOCHS 10, INITIATE 2, 5 steps
+    assert math.isclose(lr(2e-4, 2, 0, 10, 2, 5), 2e-4 * (1 - 10 / 40), rel_tol=1e-12)
+    assert math.isclose(lr(2e-4, 5, 3, 10, 2, 5), 2e-4 * (1 - 28 / 40), rel_tol=1e-12)
+    assert lr(2e-4, 8, 0, 10, 2, 5) == 0.0
+    # 'since_install': the linear decay the authors presumably intended
+    si = dict(schedule_step='since_install')
+    assert lr(2e-4, 100, 0, 200, 100, 50, **si) == 2e-4
+    assert math.isclose(lr(2e-4, 150, 0, 200, 100, 50, **si), 1e-4, rel_tol=1e-12)
+    assert math.isclose(lr(2e-4, 199, 49, 200, 100, 50, **si), 2e-4 / 5000, rel_tol=1e-9)
+    assert lr(2e-4, 200, 0, 200, 100, 50, **si) == 0.0
     assert noise(0.9, 0, 100) == 0.9
     assert math.isclose(noise(0.9, 50, 100), 0.45)
     assert noise(0.9, 100, 100) == 0.0 and noise(0.9, 150, 100) == 0.0
@@ -105,11 +115,12 @@ class _FakeGan:
         self.saved.append(epoch)
 
 
-def test_fit_loop_applies_schedules_per_step_and_checkpoints():
+@pytest.mark.parametrize('mode', ['global_iterations', 'since_install'])
+def test_fit_loop_applies_schedules_per_step_and_checkpoints(mode):
     from van_gan_amd.train import GanMonitor, fit
     gan = _FakeGan()
     E, I, T = 6, 2, 3
-    mon = GanMonitor(EPOCHS=E, INITIATE_LR_DECAY=I, INITIAL_LR=2e-4, train_steps=T, NO_NOISE=4)
+    mon = GanMonitor(EPOCHS=E, INITIATE_LR_DECAY=I, INITIAL_LR=2e-4, train_steps=T, NO_NOISE=4, schedule_step=mode)
     batches = [(1.0, 2.0)] * 1000
     hist = fit(gan, batches, mon, val_ds=batches, val_steps=2)
     tr = [s for s in gan.seen if s[0] == 'train']
@@ -119,26 +130,42 @@ def test_fit_loop_applies_schedules_per_step_and_checkpoints():
         for step in range(T):
             _, ep, lr, nz = tr[k]; k += 1
             assert ep == epoch
-            assert lr == do.learning_rate(2e-4, epoch, step, E, I, T)
+            assert lr == do.learning_rate(2e-4, epoch, step, E, I, T, mode)
             assert nz == do.discriminator_noise(0.9, epoch, 4)
     assert gan.saved == [1, 3, 5]                       # epoch % 2 == 1 or the last epoch (main.py:230)
     assert hist[-1]['train']['gen_IS_loss'] == 1.0 and len(hist) == E
 
 
-def test_resumed_schedule_matches_oracle():
+@pytest.mark.parametrize('mode', ['global_iterations', 'since_install'])
+def test_resumed_schedule_matches_oracle(mode):
     from van_gan_amd.train import GanMonitor
     gan = _FakeGan()
     gan.checkpoint_loaded = True
     E, I, T, R = 20, 4, 5, 10
-    mon = GanMonitor(EPOCHS=E, INITIATE_LR_DECAY=I, INITIAL_LR=2e-4, train_steps=T, NO_NOISE=4)
+    mon = GanMonitor(EPOCHS=E, INITIATE_LR_DECAY=I, INITIAL_LR=2e-4, train_steps=T, NO_NOISE=4, schedule_step=mode)
     for epoch in range(R, R + 3):
         for step in range(T):
             got = mon.set_learning_rate(gan, epoch, step)
-            assert got == do.learning_rate_resumed(2e-4, R, epoch, step, E, I, T)
+            assert got == do.learning_rate_resumed(2e-4, R, epoch, step, E, I, T, mode)
     assert gan.checkpoint_loaded is False
-    assert math.isclose(do.learning_rate_resumed(2e-4, R, R, 0, E, I, T), 2e-4 / 16 * 10)
+    assert math.isclose(do.learning_rate_resumed(2e-4, R, R, 0, E, I, T, 'since_install'), 2e-4 / 16 * 10)
+    # global count: the restored optimizer.iterations (R * T = 50) already exceeds the 30-step window => 0
+    assert do.learning_rate_resumed(2e-4, R, R, 0, E, I, T) == 0.0
     with pytest.raises(ValueError):
         do.learning_rate_resumed(2e-4, 16, 16, 0, E, I, T)
     gan2 = _FakeGan(); gan2.checkpoint_loaded = True
     with pytest.raises(ValueError):
         GanMonitor(E, I, 2e-4, T, 4).set_learning_rate(gan2, 17, 0)
+
+
+def test_product_synth_generator_equals_the_oracles():
+    """bench.py / smoke inputs come from van_gan_amd.synth (the product must not import oracle/); the parity tests draw
+    theirs from the oracle's copy: same volumes, bit for bit."""
+    import torch
+    from oracle import vangan_oracle as O
+    from van_gan_amd.synth import synth_volumes
+    for B, dims, seed in ((1, (32, 32, 32), 1234), (2, (16, 32, 48), 7)):
+        a, b = synth_volumes(B, *dims, seed=seed), O.synth_volumes(B, *dims, seed=seed)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        assert a[0].shape == (B,) + dims + (1,) and float(a[0].min()) == -1.0 and float(a[0].max()) == 1.0
+        assert set(a[1].unique().tolist()) == {-1.0, 1.0}

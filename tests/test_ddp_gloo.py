@@ -45,7 +45,12 @@ def _worker(rank, world, port, out):
     sync = GradSync({k: s.g for k, s in stores.items()}, dist.group.WORLD, {k: s.w for k, s in stores.items()})
     sync.broadcast_weights(0)
     sync.start(['disc_I', 'disc_S']); sync.start(['gen_IS']); sync.start(['gen_SI'])
+    # per-bucket completion: a network's optimizer step waits for ITS bucket only
+    sync.finish(['disc_S'])
+    assert 'disc_S' not in sync.pending and {'disc_I', 'gen_IS', 'gen_SI'} <= set(sync.pending)
+    sync.finish(['gen_SI', 'never_started'])
     sync.finish()
+    assert not sync.pending
     red = sync.reduce_dict(res, O.RESULT_KEYS)
     # identical Adam update from the reduced buckets on every rank
     state = {}

@@ -107,9 +107,23 @@ def test_fit_end_to_end_small(tmp_path):
     for h in hist:
         assert all(math.isfinite(v) for v in h['train'].values()) and all(math.isfinite(v) for v in h['val'].values())
         assert h['noise'] == do.discriminator_noise(0.9, h['epoch'], 2)
-        assert h['lr'] == do.learning_rate(2e-4, h['epoch'], 1, 3, 1, 2)
+        assert h['lr'] == do.learning_rate(2e-4, h['epoch'], 1, 3, 1, 2)       # default: reference-exact global step
     w0 = {k: s.w.clone() for k, s in gan.stores.items()}
-    gan2 = VanGan(dims, batch_size=1, device='cuda:0', seed=99, output_dir=str(tmp_path))
+    # a resumed run: same seed (hence the same noise / dropout keys), state from the checkpoint of the last epoch
+    gan2 = VanGan(dims, batch_size=1, device='cuda:0', seed=1, layer_noise=0.9, output_dir=str(tmp_path))
+    assert not torch.equal(gan2.stores['gen_IS'].w, w0['gen_IS'])
     assert gan2.load_checkpoint(3, newpath=gan.checkpoint_dir)
     for k, s in gan2.stores.items():
         assert torch.equal(s.w, w0[k]) and s.step == gan.stores[k].step
+        assert torch.equal(s.m, gan.stores[k].m) and torch.equal(s.v, gan.stores[k].v), k       # Adam slots
+    assert gan2.rng_offset == gan.rng_offset > 0                  # the noise stream continues, it does not replay from 0
+    # the next step of the resumed engine is the next step of the original one (same weights, slots, noise draws, rate):
+    # only the order of float atomics differs between two runs
+    gan2.layer_noise, gan2.lr = gan.layer_noise, gan.lr
+    rI, rS = pipe.next_batch()
+    ra, rb = gan.train_step(rI, rS), gan2.train_step(rI, rS)
+    for k in ra:
+        assert abs(ra[k] - rb[k]) <= 2e-3 * abs(ra[k]) + 1e-6, (k, ra[k], rb[k])
+    with pytest.raises(ValueError):
+        VanGan(dims, batch_size=1, device='cuda:0').save_checkpoint(0)       # built without output_dir
+    assert VanGan(dims, batch_size=1, device='cuda:0').load_checkpoint(1) is False

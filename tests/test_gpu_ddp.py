@@ -31,16 +31,28 @@ sys.path.insert(0, %(root)r)
 from van_gan_amd.vangan import VanGan
 from oracle.vangan_oracle import synth_volumes
 rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
-dist.init_process_group('gloo', rank=rank, world_size=world)
-eng = VanGan(%(dims)r, batch_size=1, n_devices=world, device='cuda:0', seed=rank * 17, layer_noise=0.0, dropout_rate=0.0,
+backend = os.environ['VG_TEST_BACKEND']
+dev = 'cuda:%%d' %% (rank if backend == 'nccl' else 0)       # RCCL: one device per rank; gloo: both ranks on cuda:0
+torch.cuda.set_device(dev)
+if backend == 'nccl':
+    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(dev))
+else:
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+eng = VanGan(%(dims)r, batch_size=1, n_devices=world, device=dev, seed=rank * 17, layer_noise=0.0, dropout_rate=0.0,
              process_group=dist.group.WORLD, precision='fp32')
 eng.broadcast_weights(0)
 rI, rS = synth_volumes(2, *%(dims)r, seed=5)
 res = None
 for _ in range(1):
-    res = eng.distributed_train_step(rI[rank:rank + 1].cuda(), rS[rank:rank + 1].cuda())
+    res = eng.distributed_train_step(rI[rank:rank + 1].to(dev), rS[rank:rank + 1].to(dev))
 torch.cuda.synchronize()
-torch.save({'w': {k: s.w.cpu() for k, s in eng.stores.items()}, 'res': res}, %(out)r %% rank)
+# the stochastic layers of two replicas must not share a stream (discriminator.py:52,108 under MirroredStrategy): same seed on
+# both ranks here, different Philox keys
+eng2 = VanGan(%(dims)r, batch_size=1, n_devices=world, device=dev, seed=0, process_group=dist.group.WORLD)
+nz, dp = eng2._make_noise(eng2.disc_S, 2, eng2.arena)
+torch.cuda.synchronize()
+torch.save({'w': {k: s.w.cpu() for k, s in eng.stores.items()}, 'res': res, 'noise_key': eng2.noise_key,
+            'noise': nz['down2'].float().cpu(), 'drop': dp['down2'].cpu()}, %(out)r %% rank)
 dist.destroy_process_group()
 '''
 
@@ -49,7 +61,10 @@ def _free_port():
     s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def test_two_ranks_equal_one_process_with_batch_two(tmp_path):
+@pytest.mark.parametrize('backend', ['gloo', 'nccl'])
+def test_two_ranks_equal_one_process_with_batch_two(tmp_path, backend):
+    if backend == 'nccl' and torch.cuda.device_count() < 2:
+        pytest.skip('RCCL needs one device per rank: runs on boxes with >= 2 GPUs')
     from oracle.vangan_oracle import synth_volumes
     from van_gan_amd.vangan import VanGan
     out = str(tmp_path / 'rank%d.pt')
@@ -59,7 +74,7 @@ def test_two_ranks_equal_one_process_with_batch_two(tmp_path):
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY='0')
+                   HSA_ENABLE_IPC_MODE_LEGACY='0', VG_TEST_BACKEND=backend)
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     logs = []
     for p in procs:
@@ -74,6 +89,13 @@ def test_two_ranks_equal_one_process_with_batch_two(tmp_path):
     for k in a['w']:
         assert torch.equal(a['w'][k], b['w'][k]), k
     assert a['res'] == b['res']
+    # per-replica noise / dropout streams: different keys, uncorrelated draws of the expected spread
+    assert a['noise_key'] != b['noise_key']
+    na, nb = a['noise'].flatten(), b['noise'].flatten()
+    assert not torch.equal(na, nb)
+    corr = float((na * nb).mean() / (na.std() * nb.std()))
+    assert abs(corr) < 0.02 and abs(float(na.std()) - 0.1) < 5e-3, (corr, float(na.std()))
+    assert not torch.equal(a['drop'], b['drop'])
     # expectation: the same engine as "rank r of 2", no process group; gradients summed by hand
     eng = VanGan(DIMS, batch_size=1, n_devices=2, device='cuda:0', seed=0, layer_noise=0.0, dropout_rate=0.0, precision='fp32')
     rI, rS = synth_volumes(2, *DIMS, seed=5)

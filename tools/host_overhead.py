@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from van_gan_amd import VanGan
-from oracle.vangan_oracle import synth_volumes
+from van_gan_amd.synth import synth_volumes
 size = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 eng = VanGan((size,) * 3, batch_size=1, device='cuda:0')
 rI, rS = synth_volumes(1, size, size, size, seed=1)

@@ -53,6 +53,7 @@ class ActNormBwdDesc(C.Structure):
 
 _SIGS = {
     'vg_version': ([], c_int),
+    'vg_abi_sizeof': ([c_int], c_int),
     'vg_set_stamp_buffer': ([c_void_p], c_int),
     'vg_conv3d': ([C.POINTER(ConvDesc), c_void_p], c_int),
     'vg_conv3d_lds_bytes': ([C.POINTER(ConvDesc)], c_int),
@@ -100,13 +101,13 @@ EXPORTS = sorted(list(_SIGS.keys()) + ['vg_status_string'])
 
 
 def _load():
+    """Build if the sources changed, then dlopen.  A stale library is only accepted on explicit request (VG_NO_REBUILD=1, used
+    on the GPU box where the prebuilt .so travels with the snapshot): the descriptor structs are mirrored by hand in this
+    file, so a library built from other sources could corrupt memory instead of failing.  Either way the struct sizes the
+    library was compiled with are checked against the ctypes mirrors below."""
     path = _build.LIB
     if not os.path.exists(path) or (_build.needs_build() and os.environ.get('VG_NO_REBUILD') != '1'):
-        try:
-            _build.build()
-        except Exception:
-            if not os.path.exists(path):
-                raise
+        _build.build()                               # raises on failure: no silent fallback to an old binary
     lib = C.CDLL(path)
     for name, (args, ret) in _SIGS.items():
         fn = getattr(lib, name)
@@ -114,6 +115,11 @@ def _load():
         fn.restype = ret
     lib.vg_status_string.argtypes = [c_int]
     lib.vg_status_string.restype = C.c_char_p
+    for which, mirror in ((0, ConvDesc), (1, ActNormBwdDesc), (2, PackItem)):
+        got = lib.vg_abi_sizeof(which)
+        if got != C.sizeof(mirror):
+            raise ImportError('libvangan_hip.so ABI mismatch: sizeof(%s) is %d in the library, %d in van_gan_amd/_lib.py '
+                              '(stale build? remove %s and rebuild)' % (mirror.__name__, got, C.sizeof(mirror), path))
     return lib
 
 

@@ -42,12 +42,25 @@ def needs_build() -> bool:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
+    """Serialised by a file lock: under torch.distributed.run every rank imports the package at the same time."""
     if not force and not needs_build():
         return LIB
+    import fcntl
+    os.makedirs(os.path.join(HERE, 'build'), exist_ok=True)
+    with open(os.path.join(HERE, 'build', '.lock'), 'w') as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        try:
+            if not force and not needs_build():          # another rank built it while this one waited
+                return LIB
+            return _build_locked(verbose)
+        finally:
+            fcntl.flock(lk, fcntl.LOCK_UN)
+
+
+def _build_locked(verbose: bool) -> str:
     hipcc = _hipcc()
     objs = []
     procs = []
-    os.makedirs(os.path.join(HERE, 'build'), exist_ok=True)
     for s in SOURCES:
         o = os.path.join(HERE, 'build', s.replace('.hip', '.o'))
         objs.append(o)

@@ -1,0 +1,133 @@
+"""Reference-shaped constructor: ``VanGan(args, strategy, ..., gen_i2s=..., gen_s2i=...)`` as main.py:196-200 calls it
+(vangan.py:20-245), over the MI355X engine (``van_gan_amd.vangan.VanGan``).
+
+A maintainer of the reference swaps ``from vangan import VanGan`` for ``from van_gan_amd.compat import VanGan`` and keeps
+the rest of main.py: the dataset, ``train(ds, gan, ...)`` (vangan.py:510-550) and ``GanMonitor`` only touch the surface
+mirrored here.  What is read from ``args`` is exactly what the reference reads (vangan.py:37-58,80): ``N_DEVICES,
+INPUT_IMG_SIZE, CHANNELS, GLOBAL_BATCH_SIZE, DIMENSIONS, SUBVOL_PATCH_SIZE, train_steps, BATCH_SIZE, output_dir``.
+
+Differences that are deliberate and loud:
+  * only the default path is built: 3-D, single channel, ``gen_i2s == gen_s2i == 'resUnet'``, non-Wasserstein,
+    not semi-supervised.  Unknown generator names raise the reference's own ``ValueError`` (vangan.py:124,164); known but
+    unbuilt variants ('resnet', 'vnet', Wasserstein, 2-D) raise ``NotImplementedError`` naming SURVEY section 8(f)4;
+  * ``N_DEVICES == 0`` (what ``len(GPUs)`` gives on a box TensorFlow sees no GPU on, main.py:62-105) is read as 1: the
+    reference would divide by zero in cycle_seg_loss (loss_functions.py:226) and build with GLOBAL_BATCH_SIZE 0;
+  * ``strategy`` is accepted and ignored (None is fine): data parallelism is one process per GPU with a
+    ``torch.distributed`` process group (``process_group=``), not an in-process MirroredStrategy.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, Optional
+
+import numpy as np
+import torch
+
+KNOWN_GENERATORS = ('resnet', 'resUnet', 'vnet')       # vangan.py:88-124, 127-164
+
+
+def engine_kwargs_from_args(args, lambda_cycle=10.0, lambda_identity=5, lambda_reconstruction=5, lambda_topology=5,
+                            gen_i2s='resnet', gen_s2i='resnet', semi_supervised=False, wasserstein=False,
+                            ncritic=5, gp_weight=10.0) -> Dict:
+    """Validate the reference's constructor arguments and translate them into the engine's (pure host logic)."""
+    if gen_i2s not in KNOWN_GENERATORS:
+        raise ValueError('IS Generator type not recognised')          # vangan.py:124
+    if gen_s2i not in KNOWN_GENERATORS:
+        raise ValueError('SI Generator type not recognised')          # vangan.py:164
+    if gen_i2s != 'resUnet' or gen_s2i != 'resUnet':
+        raise NotImplementedError("only the default generators (gen_i2s='resUnet', gen_s2i='resUnet', main.py:196-200) are "
+                                  'built for MI355X; resnet / vnet are SURVEY section 8(f)4')
+    if wasserstein:
+        raise NotImplementedError('the WGAN-GP branch (vangan.py:355-378,400-423) is not built: SURVEY section 8(f)4')
+    if semi_supervised:
+        raise NotImplementedError('semi_supervised is never enabled by main.py and is not built')
+    if int(args.DIMENSIONS) != 3:
+        raise NotImplementedError('DIMENSIONS must be 3 (the 2-D branch of the reference is not on the hot path)')
+    if int(args.CHANNELS) != 1:
+        raise NotImplementedError('CHANNELS must be 1 (single-channel imaging and label volumes)')
+    patch = tuple(int(v) for v in args.SUBVOL_PATCH_SIZE)[:3]
+    if len(patch) != 3:
+        raise ValueError('SUBVOL_PATCH_SIZE must have three entries')
+    n_dev = int(args.N_DEVICES)
+    if n_dev < 0:
+        raise ValueError('N_DEVICES must be >= 0')
+    n_dev = max(n_dev, 1)                                             # 0 on a box without visible GPUs -> one replica
+    batch = int(args.BATCH_SIZE)
+    gbs = int(args.GLOBAL_BATCH_SIZE)
+    if gbs <= 0:
+        gbs = batch * n_dev                                           # N_DEVICES 0 made it 0 in main.py:70-71
+    return dict(subvol_patch_size=patch, batch_size=batch, global_batch_size=gbs, n_devices=n_dev,
+                lambda_cycle=float(lambda_cycle), lambda_reconstruction=float(lambda_reconstruction),
+                lambda_topology=float(lambda_topology), output_dir=getattr(args, 'output_dir', None))
+
+
+def to_device_volume(t, device) -> torch.Tensor:
+    """tf.Tensor / numpy array / torch tensor [B,D,H,W,1] -> fp32 torch tensor in HBM."""
+    if isinstance(t, torch.Tensor):
+        return t.to(device=device, dtype=torch.float32)
+    if hasattr(t, 'numpy') and not isinstance(t, np.ndarray):
+        t = t.numpy()
+    return torch.from_numpy(np.ascontiguousarray(t, dtype=np.float32)).to(device)
+
+
+class VanGan:
+    """vangan.py:20-550 surface used by main.py, train() and GanMonitor: constructor, train_step / test_step,
+    distributed_train_step / distributed_test_step, reduce_dict, save_checkpoint / load_checkpoint, gen_IS / gen_SI /
+    disc_I / disc_S, layer_noise, current_epoch, checkpoint_loaded, and the inert n-critic fields."""
+
+    def __init__(self, args, strategy=None, lambda_cycle=10.0, lambda_identity=5, lambda_reconstruction=5,
+                 lambda_topology=5, gen_i2s='resnet', gen_s2i='resnet', semi_supervised=False, wasserstein=False,
+                 ncritic=5, gp_weight=10.0, *, device: str = 'cuda:0', process_group=None, seed: int = 0,
+                 engine_factory: Optional[Callable] = None, **engine_kw):
+        kw = engine_kwargs_from_args(args, lambda_cycle, lambda_identity, lambda_reconstruction, lambda_topology, gen_i2s,
+                                     gen_s2i, semi_supervised, wasserstein, ncritic, gp_weight)
+        kw.update(engine_kw)
+        if engine_factory is None:
+            from .vangan import VanGan as engine_factory              # needs an MI355X; raises without one
+        self.strategy = strategy
+        self.n_devices, self.global_batch_size, self.batch_size = kw['n_devices'], kw['global_batch_size'], kw['batch_size']
+        self.img_size = getattr(args, 'INPUT_IMG_SIZE', None)
+        self.channels, self.dims = int(args.CHANNELS), int(args.DIMENSIONS)
+        self.subvol_patch_size = kw['subvol_patch_size'] + (self.channels,)
+        self.seg_subvol_patch_size = kw['subvol_patch_size'] + (1,)
+        self.train_steps = getattr(args, 'train_steps', None)
+        self.lambda_cycle, self.lambda_identity = lambda_cycle, lambda_identity
+        self.lambda_reconstruction, self.lambda_topology = lambda_reconstruction, lambda_topology
+        self.gen_i2s_typ, self.gen_s2i_typ = gen_i2s, gen_s2i
+        self.semi_supervised, self.wasserstein = semi_supervised, wasserstein
+        self.ncritic, self.icritic, self.initModel, self.updateGen, self.gp_weight = ncritic, 1, True, True, gp_weight
+        self.eng = engine_factory(device=device, process_group=process_group, seed=seed, **kw)
+        self.gen_IS, self.gen_SI = self.eng.gen_IS, self.eng.gen_SI
+        self.disc_I, self.disc_S = self.eng.disc_I, self.eng.disc_S
+        self.checkpoint_dir = getattr(self.eng, 'checkpoint_dir', None)
+
+    # scalars GanMonitor reads and writes (custom_callback.py:343-365,422-424,441-444) live on the engine
+    layer_noise = property(lambda self: self.eng.layer_noise, lambda self, v: setattr(self.eng, 'layer_noise', float(v)))
+    lr = property(lambda self: self.eng.lr, lambda self, v: setattr(self.eng, 'lr', float(v)))
+    current_epoch = property(lambda self: self.eng.current_epoch, lambda self, v: setattr(self.eng, 'current_epoch', int(v)))
+    checkpoint_loaded = property(lambda self: self.eng.checkpoint_loaded,
+                                 lambda self, v: setattr(self.eng, 'checkpoint_loaded', bool(v)))
+    stores = property(lambda self: getattr(self.eng, 'stores', None))
+
+    def _dev(self, t):
+        return to_device_volume(t, self.eng.device)
+
+    def train_step(self, real_I, real_S):
+        return self.eng.train_step(self._dev(real_I), self._dev(real_S))
+
+    def test_step(self, real_I, real_S):
+        return self.eng.test_step(self._dev(real_I), self._dev(real_S))
+
+    def distributed_train_step(self, x, y):
+        return self.eng.distributed_train_step(self._dev(x), self._dev(y))
+
+    def distributed_test_step(self, x, y):
+        return self.eng.distributed_test_step(self._dev(x), self._dev(y))
+
+    def reduce_dict(self, d):
+        return self.eng.reduce_dict(d)
+
+    def save_checkpoint(self, epoch):
+        return self.eng.save_checkpoint(epoch)
+
+    def load_checkpoint(self, epoch=None, expect_partial=False, newpath=None):
+        return self.eng.load_checkpoint(epoch, newpath)

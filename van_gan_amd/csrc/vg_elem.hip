@@ -554,7 +554,15 @@ extern "C" const char* vg_status_string(int code) {
     }
 }
 extern "C" int vg_version(void) {
-    vg_begin(); return 1; }
+    vg_begin(); return 2; }
+extern "C" int vg_abi_sizeof(int which) {
+    switch (which) {
+        case 0: return (int)sizeof(vg_conv_desc);
+        case 1: return (int)sizeof(vg_actnorm_bwd_desc);
+        case 2: return (int)sizeof(vg_pack_item);
+        default: return VG_EINVAL;
+    }
+}
 
 // ------------------------------------------------------------------------------------------------
 // Training data pipeline on resident volumes (dataset.py:205-251): crop + flips + rot90 as ONE gather.

@@ -349,14 +349,14 @@ extern "C" int vg_conv3d_wgrad(const vg_conv_desc* d, const void* dy, int dy_f32
     const int RMAX = Q == 1 ? 24 : (Q == 2 ? 12 : 6);
     const int esz = d->f32 ? 4 : 2;
     GatherIn g; WgradK k;
-    static int max_bm = -1;
-    if (max_bm < 0) { const char* e = getenv("VG_WGRAD_BM"); max_bm = e ? atoi(e) : 256; }
+    static int max_bm = -1, max_cib = 64;
+    if (max_bm < 0) { const char* e = getenv("VG_WGRAD_BM"); max_bm = e ? atoi(e) : 256; const char* e2 = getenv("VG_WGRAD_CIB"); max_cib = e2 ? atoi(e2) : 64; }
     // candidate (BM, CIB) in order of preference: large tile + all channels, LDS <= 80 KiB so that two workgroups fit a CU
     int best_bm = 0, best_cib = 0, best_lds = 0;
     for (int pass = 0; pass < 2 && !best_bm; ++pass) {
         const int limit = pass == 0 ? 80 * 1024 : VG_LDS_LIMIT;
         for (int bm = 256; bm >= 64 && !best_bm; bm = bm == 256 ? 128 : bm - 64)
-            for (int c = 64; c >= 16; c -= 16) {
+            for (int c = max_cib; c >= 16; c -= 16) {
                 if (Cinp % c) continue;
                 if (bm == 256 && (Q > 2 || max_bm < 256)) continue;     // dY tile staging holds <= 4 units per thread
                 int rc = fill_gather(d, g, c, bm, d->f32 ? 0 : 64);

@@ -123,12 +123,48 @@ _ONES = {}
 # ------------------------------------------------------------------------------------------------------
 # schedules (custom_callback.py:326-424): per-step scalars for VanGan.lr / VanGan.layer_noise
 # ------------------------------------------------------------------------------------------------------
-def learning_rate(initial_lr: float, epoch: int, step_in_epoch: int, epochs: int, initiate_decay: int, train_steps: int) -> float:
+def learning_rate(initial_lr: float, epoch: int, step_in_epoch: int, epochs: int, initiate_decay: int, train_steps: int,
+                  schedule_step: str = 'global_iterations', iterations: Optional[int] = None) -> float:
+    """set_learning_rate (custom_callback.py:326-365): constant until epoch INITIATE_LR_DECAY, then
+    PolynomialDecay(INITIAL_LR -> 0, decay_steps = (EPOCHS - INITIATE_LR_DECAY) * train_steps, power 1) assigned to
+    ``optimizer.lr``.
+
+    schedule_step selects the step the decay is evaluated at:
+      'global_iterations' (default, reference-exact): TP -- Keras optimizer_v2._decayed_lr calls the schedule with the
+          optimizer's own ``iterations``, which has counted every step since step 0.  With the reference defaults
+          (EPOCHS 200, INITIATE_LR_DECAY 100) iterations == decay_steps at the swap, so the rate is 0 for the whole second half.
+          ``iterations`` = optimizer steps taken so far (default: epoch * train_steps + step_in_epoch).
+      'since_install': the presumably intended linear decay -- steps counted from the epoch the schedule was installed."""
     if epoch < initiate_decay:
         return initial_lr
     decay_steps = (epochs - initiate_decay) * train_steps
-    step = min((epoch - initiate_decay) * train_steps + step_in_epoch, decay_steps)
+    if schedule_step == 'global_iterations':
+        it = epoch * train_steps + step_in_epoch if iterations is None else iterations
+    elif schedule_step == 'since_install':
+        it = (epoch - initiate_decay) * train_steps + step_in_epoch
+    else:
+        raise ValueError("schedule_step must be 'global_iterations' or 'since_install'")
+    step = min(it, decay_steps)
     return initial_lr * (1.0 - step / decay_steps)
+
+
+def learning_rate_resumed(initial_lr: float, resume_epoch: int, epoch: int, step_in_epoch: int, epochs: int,
+                          initiate_decay: int, train_steps: int, schedule_step: str = 'global_iterations',
+                          iterations: Optional[int] = None) -> float:
+    """set_learning_rate's resume branch (custom_callback.py:365-397): a new PolynomialDecay from
+    INITIAL_LR / (EPOCHS - INITIATE) * (EPOCHS - resume_epoch) over (EPOCHS - INITIATE - resume_epoch) * train_steps steps
+    (the reference subtracts both, kept as is; a non-positive window is refused)."""
+    start = initial_lr / (epochs - initiate_decay) * (epochs - resume_epoch)
+    decay_steps = (epochs - initiate_decay - resume_epoch) * train_steps
+    if decay_steps <= 0:
+        raise ValueError('reference schedule undefined: decay_steps <= 0 (resumed past EPOCHS - INITIATE_LR_DECAY)')
+    if schedule_step == 'global_iterations':
+        it = epoch * train_steps + step_in_epoch if iterations is None else iterations      # restored optimizer.iterations
+    elif schedule_step == 'since_install':
+        it = (epoch - resume_epoch) * train_steps + step_in_epoch
+    else:
+        raise ValueError("schedule_step must be 'global_iterations' or 'since_install'")
+    return start * (1.0 - min(it, decay_steps) / decay_steps)
 
 
 def discriminator_noise(init_noise: float, epoch: int, no_noise_epoch: int) -> float:

@@ -22,7 +22,8 @@ class GradSync:
         dev = next(iter(buckets.values())).device
         self.cuda = dev.type == 'cuda'
         self.stream = torch.cuda.Stream(device=dev) if (self.cuda and self.world > 1) else None
-        self.pending: List = []
+        self.pending: Dict[str, object] = {}        # bucket name -> CUDA event on the comm stream / async work handle
+        self.rank = dist.get_rank(process_group) if process_group is not None else 0
 
     def start(self, names: Iterable[str]):
         """Issue the all-reduce of these buckets; on GPU it runs on the side stream behind everything already queued
@@ -36,18 +37,27 @@ class GradSync:
             with torch.cuda.stream(self.stream):
                 for n in names:
                     dist.all_reduce(self.buckets[n], op=dist.ReduceOp.SUM, group=self.pg)
+                    done = torch.cuda.Event()
+                    done.record()
+                    self.pending[n] = done
         else:
             for n in names:
-                self.pending.append(dist.all_reduce(self.buckets[n], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+                self.pending[n] = dist.all_reduce(self.buckets[n], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
 
-    def finish(self):
+    def finish(self, names: Optional[Iterable[str]] = None):
+        """The current stream (GPU) / the host (CPU tensors) waits until the reduced buckets `names` (default: all that
+        are in flight) have landed.  Per bucket, so that a network's optimizer step can run as soon as ITS bucket is
+        there while the other networks' backward sweeps and all-reduces are still going."""
         if self.world == 1:
             return
-        if self.stream is not None:
-            torch.cuda.current_stream().wait_stream(self.stream)
-        for w in self.pending:
-            w.wait()
-        self.pending = []
+        for n in (list(self.pending) if names is None else list(names)):
+            h = self.pending.pop(n, None)
+            if h is None:
+                continue
+            if self.stream is not None:
+                torch.cuda.current_stream().wait_event(h)
+            else:
+                h.wait()
 
     def reduce_dict(self, d: Dict[str, float], keys: List[str]) -> Dict[str, float]:
         """vangan.py:472-473: strategy.reduce(SUM) of every result scalar."""

@@ -87,7 +87,7 @@ def stitch_subvolumes(engine, gen: str, img: torch.Tensor, subvol_size: Sequence
                 ones = ar.alloc((B, kx, ky, kz, 1), torch.float32)
                 ones.fill_(1.0)                              # memset-style fill (plumbing)
                 ops.axpby(tmp, 2.0, ones, -1.0, xin)         # 2*n - 1
-            net.forward(ar, xin, yout)
+            net.forward(ar, xin, yout, save=False)
             for b, (a, bb, c) in enumerate(chunk):
                 check(lib.vg_overlap_add(_p(yout[b]), kx, ky, kz, px, py, pz, a, bb, c, X, Y, Z, _p(pred), _p(cnt), stream()),
                       'vg_overlap_add')

@@ -207,9 +207,15 @@ class ResUNet:
         self._ptab.run()
 
     # ---------------------------------------------------------------------------------------------
-    def _block_fwd(self, ar: Arena, name: str, N: int, src_raw: Src, nrm_inputs, out_dims, co, ctx):
-        """residual_block (resunet_model.py:103-143): out = conv2(relu(IN(conv1(relu(IN(x)))))) + IN(short(x))."""
+    def _block_fwd(self, ar: Arena, name: str, N: int, src_raw: Src, nrm_inputs, out_dims, co, ctx, save: bool = True):
+        """residual_block (resunet_model.py:103-143): out = conv2(relu(IN(conv1(relu(IN(x)))))) + IN(short(x)).
+        save=False (inference): the block output is allocated first and everything else the block allocates (r, the
+        shortcut, the InstanceNorm scale/shift vectors) is handed back to the arena once the block's kernels are queued."""
         L, Nn = self.L, self.Nn
+        out = mk = None
+        if not save:
+            out = Act(ar, N, out_dims, co, dtype=self.dtype)
+            mk = ar.mark()
         n1 = Nn[name + '.cb1'].finalize(ar, *nrm_inputs)
         s1 = Src(src_raw.x0, (N,) + tuple(L[name + '.cb1'].in_dims), src_raw.c0, src_raw.x1, src_raw.c1, src_raw.shift0,
                  scale=n1['scale'], shift=n1['shift'], act=ACT_RELU)
@@ -220,13 +226,18 @@ class ResUNet:
         ns = Nn[name + '.short'].finalize(ar, sc)
         n2 = Nn[name + '.cb2'].finalize(ar, r)
         s2 = Src(r.data, (N,) + tuple(out_dims), co, scale=n2['scale'], shift=n2['shift'], act=ACT_RELU)
-        out = Act(ar, N, out_dims, co, dtype=self.dtype)
+        if out is None:
+            out = Act(ar, N, out_dims, co, dtype=self.dtype)
         L[name + '.cb2'].forward(s2, out.data, sums=out.sums, res=sc.data, res_scale=ns['scale'], res_shift=ns['shift'])
-        ctx[name] = dict(n1=n1, s1=s1, r=r, sc=sc, ns=ns, n2=n2, s2=s2, out=out, src_raw=src_raw)
+        if save:
+            ctx[name] = dict(n1=n1, s1=s1, r=r, sc=sc, ns=ns, n2=n2, s2=s2, out=out, src_raw=src_raw)
+        else:
+            ar.release(mk)                      # stream-ordered: later allocations are written by later kernels
         return out
 
     def forward(self, ar: Arena, x: torch.Tensor, y: torch.Tensor, save: bool = True) -> dict:
-        """x: fp32 [N,D,H,W,1]; y: fp32 [N,D,H,W,1] output buffer (tanh).  Returns the context for backward."""
+        """x: fp32 [N,D,H,W,1]; y: fp32 [N,D,H,W,1] output buffer (tanh).  Returns the context for backward
+        (save=True) or a stub (save=False: forward-only, block temporaries are recycled -- sliding-window inference)."""
         N = x.shape[0]
         f, lv, L, Nn = GEN_F, self.lv, self.L, self.Nn
         ctx = {'N': N, 'x': x, 'y': y}
@@ -244,8 +255,9 @@ class ResUNet:
         skips = [h]
         for e in range(1, 5):
             raw = Src(h.data, (N,) + lv[e - 1], f[e - 1])
-            h = self._block_fwd(ar, 'enc%d' % e, N, raw, (h,), lv[e], f[e], ctx)
-            ctx['enc%d' % e]['inp'] = (skips[-1],)
+            h = self._block_fwd(ar, 'enc%d' % e, N, raw, (h,), lv[e], f[e], ctx, save)
+            if save:
+                ctx['enc%d' % e]['inp'] = (skips[-1],)
             skips.append(h)
         nb1 = Nn['bridge.cb1'].finalize(ar, h)
         sb1 = Src(h.data, (N,) + lv[4], f[4], scale=nb1['scale'], shift=nb1['shift'], act=ACT_RELU)
@@ -261,8 +273,9 @@ class ResUNet:
             skip = skips[d]
             raw = Src(h.data, (N,) + lv[d], h.C, skip.data, skip.C, shift0=1)       # virtual upsample + concat
             low = h
-            h = self._block_fwd(ar, 'dec%d' % d, N, raw, (low, skip), lv[d], f[d], ctx)
-            ctx['dec%d' % d]['inp'] = (low, skip)
+            h = self._block_fwd(ar, 'dec%d' % d, N, raw, (low, skip), lv[d], f[d], ctx, save)
+            if save:
+                ctx['dec%d' % d]['inp'] = (low, skip)
         so = Src(h.data, (N,) + lv[0], f[0])
         L['out'].forward(so, y, tanh=True)
         ctx['out'] = dict(so=so, inp=h)

@@ -58,21 +58,26 @@ PROF: Optional[KernelProfile] = None
 # and the data-gradient chain (dY -> dX -> IN backward -> next layer) are independent, and on the small deep layers either
 # alone leaves most CUs idle.  The side stream waits for the producer of dY; the main stream waits for the side stream
 # before arena memory is recycled (Arena.release) and before the gradients are consumed (side_join).
-SIDE: Optional[torch.cuda.Stream] = None      # not None: weight-gradient side streams enabled (one per issuing stream)
-_SIDE_OF = {}                                  # issuing stream handle -> its side stream
+SIDE: Optional[bool] = None                   # truthy: weight-gradient side streams enabled (one per issuing stream)
+_SIDE_OF = {}                                  # (device index, issuing stream handle) -> its side stream.  The default stream
+#                                                has handle 0 on every device, hence the device index in the key; entries
+#                                                are never dropped, so several engines in one process share them safely
 
 
 def side_enable(device, on: bool = True):
     global SIDE
-    SIDE = torch.cuda.Stream(device=device) if on else None
-    _SIDE_OF.clear()
+    SIDE = True if on else None
+
+
+def _side_key(cur: torch.cuda.Stream):
+    return (cur.device.index, cur.cuda_stream)
 
 
 def _side_of_current() -> torch.cuda.Stream:
     cur = torch.cuda.current_stream()
-    sd = _SIDE_OF.get(cur.cuda_stream)
+    sd = _SIDE_OF.get(_side_key(cur))
     if sd is None:
-        sd = _SIDE_OF[cur.cuda_stream] = torch.cuda.Stream(device=cur.device)
+        sd = _SIDE_OF[_side_key(cur)] = torch.cuda.Stream(device=cur.device)
     return sd
 
 
@@ -80,7 +85,7 @@ def side_join():
     """The current stream waits for every weight-gradient launch it handed to its side stream."""
     if SIDE is not None:
         cur = torch.cuda.current_stream()
-        sd = _SIDE_OF.get(cur.cuda_stream)
+        sd = _SIDE_OF.get(_side_key(cur))
         if sd is not None:
             cur.wait_stream(sd)
 

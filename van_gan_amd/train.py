@@ -15,11 +15,23 @@ class GanMonitor:
     """Schedules only (plots / TensorBoard of the reference's GanMonitor are out of scope)."""
 
     def __init__(self, EPOCHS: int, INITIATE_LR_DECAY: int, INITIAL_LR: float, train_steps: int, NO_NOISE: int,
-                 init_noise: Optional[float] = None):
+                 init_noise: Optional[float] = None, schedule_step: str = 'global_iterations'):
+        """schedule_step: 'global_iterations' (default) evaluates the decay at the optimizer's iteration count as Keras
+        does -- reference-exact, and with the reference defaults the rate is 0 from epoch INITIATE_LR_DECAY on;
+        'since_install' is the linear decay the reference presumably intended (data.learning_rate)."""
+        if schedule_step not in ('global_iterations', 'since_install'):
+            raise ValueError("schedule_step must be 'global_iterations' or 'since_install'")
         self.EPOCHS, self.INITIATE_LR_DECAY, self.INITIAL_LR = EPOCHS, INITIATE_LR_DECAY, INITIAL_LR
         self.train_steps, self.NO_NOISE = train_steps, NO_NOISE
         self.init_noise = init_noise
+        self.schedule_step = schedule_step
         self.resume_epoch: Optional[int] = None
+
+    @staticmethod
+    def _iterations(model) -> Optional[int]:
+        """optimizer.iterations of the reference = Adam steps applied so far (all four optimizers step together)."""
+        stores = getattr(model, 'stores', None)
+        return None if not stores else int(next(iter(stores.values())).step)
 
     def set_learning_rate(self, model, epoch: int, step_in_epoch: int = 0):
         """custom_callback.py:326-397.  The reference installs a PolynomialDecay object once and lets the optimizer's
@@ -27,16 +39,13 @@ class GanMonitor:
         if getattr(model, 'checkpoint_loaded', False) and epoch > self.INITIATE_LR_DECAY:
             model.checkpoint_loaded = False
             self.resume_epoch = epoch
+        it = self._iterations(model)
         if self.resume_epoch is not None:
-            start = self.INITIAL_LR / (self.EPOCHS - self.INITIATE_LR_DECAY) * (self.EPOCHS - self.resume_epoch)
-            decay_steps = (self.EPOCHS - self.INITIATE_LR_DECAY - self.resume_epoch) * self.train_steps
-            if decay_steps <= 0:
-                raise ValueError('reference schedule undefined: decay_steps <= 0 (resumed past EPOCHS - INITIATE_LR_DECAY)')
-            step = min((epoch - self.resume_epoch) * self.train_steps + step_in_epoch, decay_steps)
-            model.lr = start * (1.0 - step / decay_steps)
+            model.lr = data.learning_rate_resumed(self.INITIAL_LR, self.resume_epoch, epoch, step_in_epoch, self.EPOCHS,
+                                                  self.INITIATE_LR_DECAY, self.train_steps, self.schedule_step, it)
         else:
             model.lr = data.learning_rate(self.INITIAL_LR, epoch, step_in_epoch, self.EPOCHS, self.INITIATE_LR_DECAY,
-                                          self.train_steps)
+                                          self.train_steps, self.schedule_step, it)
         return model.lr
 
     def updateDiscriminatorNoise(self, model, epoch: int):

@@ -54,7 +54,14 @@ class VanGan:
         self.checkpoint_loaded = False            # vangan.py:77 (set by the caller after load_checkpoint; read by GanMonitor)
         self.pg = process_group
         self.seed = seed
-        self.rng_offset = 0
+        # Philox keys of the discriminator noise / dropout streams.  `seed` controls the initialisation (identical on every
+        # replica, and rank 0 broadcasts anyway); the stochastic layers draw INDEPENDENT streams per replica, as the
+        # MirroredStrategy replicas of the reference do (discriminator.py:52,108): the rank is folded into the key.
+        import torch.distributed as _dist
+        self.rank = _dist.get_rank(process_group) if process_group is not None else 0
+        self.noise_key = seed + 7919 + self.rank * 1000003
+        self.drop_key = seed + 104729 + self.rank * 1000003
+        self.rng_offset = 0                       # Philox counter; persisted in the checkpoint
         self.stores: Dict[str, ParamStore] = {}
         for i, name in enumerate(NETS):
             st = ParamStore(gen_param_specs() if name.startswith('gen') else disc_param_specs(), self.device)
@@ -79,6 +86,9 @@ class VanGan:
         # second workspace for lane B's backward temporaries (bump allocators cannot interleave mark/release)
         self.arena_b = Arena(arena_bytes // 2, self.device) if self._lane_b is not None else None
         self.sync = GradSync({k: s.g for k, s in self.stores.items()}, self.pg, {k: s.w for k, s in self.stores.items()})
+        # optimizer stream: a network's clip + Adam + weight repack is queued here as soon as ITS backward sweeps are issued and
+        # waits only for ITS gradient bucket (all-reduce event), while the other networks' backward sweeps still run
+        self._opt = torch.cuda.Stream(device=self.device) if os.environ.get('VG_OPT_STREAM', '1') != '0' else None
         self.checkpoint_dir = None
         if output_dir is not None:
             self.checkpoint_dir = os.path.join(output_dir, 'checkpoints')
@@ -109,18 +119,18 @@ class VanGan:
         if self.layer_noise > 0:
             for k, shp in disc.noise_shapes(N).items():
                 t = ar.alloc(shp, torch.bfloat16)
-                ops.randn_bf16(t, self.layer_noise, self.seed + 7919, self.rng_offset)
+                ops.randn_bf16(t, self.layer_noise, self.noise_key, self.rng_offset)
                 self.rng_offset += (t.numel() + 3) // 4
                 noise[k] = t
         if self.dropout_rate > 0:
             for k, c in (('down0', 128), ('down1', 256), ('down2', 512)):
                 t = ar.alloc((N, c), torch.float32)
-                ops.dropout_mask(t, self.dropout_rate, self.seed + 104729, self.rng_offset)
+                ops.dropout_mask(t, self.dropout_rate, self.drop_key, self.rng_offset)
                 self.rng_offset += t.numel()
                 drop[k] = t
         return noise, drop
 
-    def _losses_and_backward(self, real_I, real_S, training: bool, noise, drop, do_backward: bool):
+    def _losses_and_backward(self, real_I, real_S, training: bool, noise, drop, do_backward: bool, apply: bool = False):
         ar = self.arena
         ar.reset()
         B = real_I.shape[0]
@@ -233,11 +243,15 @@ class VanGan:
                 lane_b.wait_stream(main)
             self.disc_S.backward(ar, dS, gS_D, 0, 2 * B, wgrad=True)
             self._start_allreduce(['disc_S'])
-            self.disc_S.backward(ar, dS, gS_G, B, 2 * B, wgrad=False, dx=g_fS)
+            self.disc_S.backward(ar, dS, gS_G, B, 2 * B, wgrad=False, dx=g_fS)       # still reads D_S's packed weights
+            if apply:
+                self._schedule_update('disc_S')
             with laneB():
                 self.disc_I.backward(arB, dI, gI_D, 0, 2 * B, wgrad=True)
                 self._start_allreduce(['disc_I'])
                 self.disc_I.backward(arB, dI, gI_G, B, 2 * B, wgrad=False, dx=g_fI)
+                if apply:
+                    self._schedule_update('disc_I')
             mk = ar.mark()
             self.gen_IS.backward(ar, c1, g_fS); ar.release(mk)        # adversarial application
             with laneB():
@@ -245,12 +259,18 @@ class VanGan:
                 self.gen_SI.backward(arB, c2, g_fI); arB.release(mkb)
             self.gen_IS.backward(ar, c3, g_cS); ar.release(mk)        # cycle application
             self._start_allreduce(['gen_IS'])
+            if apply:
+                self._schedule_update('gen_IS')
             with laneB():
                 self.gen_SI.backward(arB, c4, g_cI); arB.release(mkb)
                 self._start_allreduce(['gen_SI'])
+                if apply:
+                    self._schedule_update('gen_SI')
             if lane_b is not None:
                 main.wait_stream(lane_b)
             ops.side_join()
+            if apply and self._opt is not None:
+                main.wait_stream(self._opt)
         self._acc, self._coef = acc, coef
         self._aux = dict(fake_S=fake_S, fake_I=fake_I, cycled_S=cyc_S, cycled_I=cyc_I, logits_S=logS, logits_I=logI)
         return B, S, nps
@@ -276,24 +296,41 @@ class VanGan:
     def _finish_allreduce(self):
         self.sync.finish()
 
+    def _adam(self, name: str):
+        """a22: per-variable clip-by-norm + Adam on the (reduced) flat gradient bucket of one network, then its bf16 repack."""
+        st = self.stores[name]
+        st.step += 1
+        t = st.step
+        lr_t = self.lr * math.sqrt(1.0 - self.beta_2 ** t) / (1.0 - self.beta_1 ** t)
+        ops.adam_clip(st.w, st.g, st.m, st.v, st.seg_off, st.T, st.norms, lr_t, self.beta_1, self.beta_2,
+                      self.adam_eps, self.clipnorm, 1.0)
+        self.nets[name].pack()
+
+    def _schedule_update(self, name: str):
+        """Queue clip + Adam + repack of one network behind (a) everything the current lane has issued for it and (b) the
+        all-reduce of ITS bucket only -- on the optimizer stream, so the lane carries on with the next backward sweep.
+        Called after the last kernel that reads the network's packed weights in this step."""
+        if self._opt is None or ops.PROF is not None:          # serial mode (per-launch timing pass, VG_OPT_STREAM=0)
+            self.sync.finish([name])
+            self._adam(name)
+            return
+        ev = torch.cuda.Event()
+        ev.record()
+        self._opt.wait_event(ev)
+        with torch.cuda.stream(self._opt):
+            self.sync.finish([name])
+            self._adam(name)
+
     def _apply_adam(self):
         for name in NETS:
-            st = self.stores[name]
-            st.step += 1
-            t = st.step
-            lr_t = self.lr * math.sqrt(1.0 - self.beta_2 ** t) / (1.0 - self.beta_1 ** t)
-            ops.adam_clip(st.w, st.g, st.m, st.v, st.seg_off, st.T, st.norms, lr_t, self.beta_1, self.beta_2,
-                          self.adam_eps, self.clipnorm, 1.0)
-        self.repack()
+            self._adam(name)
 
     # ------------------------------------------------------------------------------------------------
     def train_step(self, real_I: torch.Tensor, real_S: torch.Tensor, noise=None, drop=None, apply: bool = True,
                    sync: bool = True):
         """vangan.py:380-440 (non-Wasserstein branch).  real_*: fp32 [B,D,H,W,1] on the device."""
-        B, S, nps = self._losses_and_backward(real_I, real_S, True, noise, drop, True)
-        self._finish_allreduce()
-        if apply:
-            self._apply_adam()
+        B, S, nps = self._losses_and_backward(real_I, real_S, True, noise, drop, True, apply=apply)
+        self._finish_allreduce()                 # apply=False (tests): the reduced gradients stay in the buckets
         return self._results(B, S, nps) if sync else None
 
     def test_step(self, real_I: torch.Tensor, real_S: torch.Tensor):
@@ -323,19 +360,34 @@ class VanGan:
 
     # ------------------------------------------------------------------------------------------------
     def save_checkpoint(self, epoch: int):
-        """vangan.py:247-250 (own format: the TF tensor-bundle format is not readable without TF)."""
+        """vangan.py:247-250 (own format: the TF tensor-bundle format is not readable without TF).  The replicas hold identical
+        weights and optimizer slots, so rank 0 writes (atomically: temp file + rename) and every rank meets at a barrier;
+        the Philox counter of the noise / dropout streams is saved per file too (each rank resumes its own key at the
+        common counter)."""
+        if self.checkpoint_dir is None:
+            raise ValueError('save_checkpoint needs the engine to be built with output_dir=...')
         path = os.path.join(self.checkpoint_dir, 'checkpoint_e%d.pt' % (epoch + 1))
-        torch.save({k: dict(w=s.w.cpu(), m=s.m.cpu(), v=s.v.cpu(), step=s.step) for k, s in self.stores.items()}, path)
+        if self.rank == 0:
+            torch.cuda.synchronize(self.device)
+            blob = {k: dict(w=s.w.cpu(), m=s.m.cpu(), v=s.v.cpu(), step=s.step) for k, s in self.stores.items()}
+            blob['_rng_offset'] = int(self.rng_offset)
+            tmp = path + '.tmp.%d' % os.getpid()
+            torch.save(blob, tmp)
+            os.replace(tmp, path)
+        if self.pg is not None:
+            import torch.distributed as dist
+            dist.barrier(group=self.pg)
         return path
 
     def load_checkpoint(self, epoch: int, newpath: Optional[str] = None) -> bool:
         d = newpath if newpath is not None else self.checkpoint_dir
-        path = os.path.join(d, 'checkpoint_e%d.pt' % epoch)
-        if not os.path.exists(path):
+        path = os.path.join(d, 'checkpoint_e%d.pt' % epoch) if d is not None else ''
+        if not d or not os.path.exists(path):
             print('Error: Checkpoint not found!')                  # vangan.py:267-268: prints, does not raise
             return False
         ck = torch.load(path, map_location='cpu')
         for k, s in self.stores.items():
             s.w.copy_(ck[k]['w']); s.m.copy_(ck[k]['m']); s.v.copy_(ck[k]['v']); s.step = ck[k]['step']
+        self.rng_offset = int(ck.get('_rng_offset', 0))
         self.repack()
         return True
