@@ -125,6 +125,15 @@ int vg_conv3d_lds_bytes(const vg_conv_desc* d);
 /* the launch plan vg_conv3d would use for this descriptor: plan[0] = channel panel BN, plan[1] = voxels per tile,
    plan[2] = LDS bytes, plan[3] = workgroups; lets the host compare channel-chunk sizes (CK) before packing weights */
 int vg_conv3d_plan(const vg_conv_desc* d, int32_t* plan4);
+/* Dry run of vg_conv3d: the whole dispatch runs, nothing is launched, and buf receives the name of the kernel variant the
+   call would launch, e.g. "conv<bf16,16,8,n0,wl1,dma0,mc0,c10>|walk1|ch0" (template arguments, then walk = a workgroup
+   visits more than one tile, ch = several channel chunks per tile) or "pw_cto1<bf16,2>".  The parity tests use it to prove
+   that every variant the BASELINE configurations run is compared with the oracle (tests/test_variant_coverage.py). */
+int vg_conv3d_variant(const vg_conv_desc* d, char* buf, int buflen);
+/* Host-side heuristic switches (forced tile shapes, persistent grid sizes, ...): key without the VG_ prefix of the
+   environment variable that sets the same switch, e.g. ("CONV_MSUB", 4).  reset != 0: back to environment / default.
+   Testing and tuning aid; the defaults are what the benchmarks run. */
+int vg_set_tuning(const char* key, int value, int reset);
 
 /* Pack fp32 Keras DHWIO weights [T][Cin][Cout] to the bf16 layout vg_conv3d reads.
  * transpose=0: rows = Cout, contraction = Cin (forward); transpose=1: rows = Cin, contraction =
@@ -151,6 +160,9 @@ int vg_packed_rows(int N);
  * --------------------------------------------------------------------------------------------- */
 int vg_conv3d_wgrad(const vg_conv_desc* d, const void* dy, int dy_f32, const int32_t* tap_idx_host,
                     int T_total, float* dw, float* db, float* scratch, int64_t scratch_bytes, vg_stream_t stream);
+/* dry run of vg_conv3d_wgrad (see vg_conv3d_variant): "wgrad<bf16,8,1,n0>|bm256|cib16|part1|walk1" */
+int vg_conv3d_wgrad_variant(const vg_conv_desc* d, int dy_f32, const int32_t* tap_idx_host, int T_total,
+                            int64_t scratch_bytes, char* buf, int buflen);
 /* scratch (optional, device): when many workgroups share one dW element their slabs are stored to
  * scratch[workgroup column][T_total*Cin*Cout] and summed in a fixed order by a second kernel instead of float atomics. */
 

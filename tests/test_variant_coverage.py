@@ -1,0 +1,46 @@
+"""CPU: every kernel variant that BASELINE configs 2, 3 and 4 run has a parity case on the GPU (tests/test_gpu_layers.py).
+
+The kernels pick a template instantiation per launch (channel panel, voxel tile, weights in LDS or L2, fused / class-parallel
+output-parity classes, single-channel staging, the 32x32x16 flavour, weight-gradient slab shapes ...), and the choice depends
+on the problem size -- so a parity suite made of small hand-picked shapes can be green while the kernels the benchmark
+times are never compared with the oracle.  Here the real schedules are walked in dry-run mode (tests/layer_recipes.py) and
+the variant of every convolution launch is collected through vg_conv3d_variant / vg_conv3d_wgrad_variant."""
+import pytest
+
+import layer_recipes as LR
+
+
+def test_every_variant_of_the_baseline_configs_has_a_gpu_parity_case():
+    reps = LR.representatives()
+    needed = LR.needed_variants()
+    assert len(needed) >= 60                       # sanity: the walk saw the whole step
+    missing = [kv for kv in needed if kv not in reps]
+    assert not missing, missing
+    # the GPU test is parametrised over exactly these representatives; each is a call of a real layer at its true shape
+    for kv in needed:
+        r = reps[kv]
+        assert r['config'] in LR.CONFIGS and r['recipe']['kind'] == kv[0]
+    # kinds of kernels that must be present: both MFMA flavours, fused and class-parallel strided data gradients, the
+    # single-channel staging variant, the pointwise kernels and the three weight-gradient slab families
+    names = ' '.join(v for _, v in needed)
+    for frag in ('conv<bf16,16,8', 'conv<bf16,32,4', 'conv32<128', 'conv32<64', 'mc1', 'mc2', 'cp1', 'c11', 'pw_cto1', 'pw_1toc',
+                 'c1k3_fwd', 'c1k3_wgrad', 'wgrad<bf16,24,1', 'wgrad<bf16,8,', 'wgrad<bf16,6,4', 'walk1', 'ch1', 'part1', 'n1'):
+        assert frag in names, frag
+
+
+def test_walk_is_complete():
+    """One generator application is 30 forward + 30 weight-gradient + 28 data-gradient calls (stem.conv1 / stem.short have
+    no data gradient), one discriminator 5 + 5 + 2 x 5 (the second sweep stops at the input volume)."""
+    recs = LR.all_records()['32^3 B1']
+    kinds = [k for k, _, _, _ in recs]
+    names = {n for _, n, _, _ in recs}
+    assert kinds.count('fwd') == 35 and kinds.count('wgrad') == 35
+    assert {'stem.conv1', 'dec0.cb1.conv', 'bridge.cb2.conv', 'out', 'conv0', 'down2'} <= names
+
+
+@pytest.mark.parametrize('cfg', LR.NEEDED)
+def test_variant_names_are_stable_within_a_config(cfg):
+    """The same call selects the same variant when asked twice (the dispatch has no hidden state)."""
+    dims, B = LR.CONFIGS[cfg]
+    a = LR.enumerate_config(dims, B)
+    assert [(k, n, v) for k, n, v, _ in a] == [(k, n, v) for k, n, v, _ in LR.all_records()[cfg]]

@@ -77,6 +77,16 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// ---- tuning knobs: vg_tune("CONV_BN", 0) reads the override set by vg_set_tuning, else the environment variable VG_CONV_BN
+// (once), else the default.  One registry for every host-side heuristic switch, so that tests can force kernel variants in
+// process (vg_set_tuning) and sweeps can use the environment.
+int vg_tune(const char* key, int dflt);
+// ---- dry run (vg_conv3d_variant / vg_conv3d_wgrad_variant): the dispatch code runs unchanged, and at the launch site the
+// name of the kernel variant it selected is recorded instead of launching.  Returns true when recording.
+bool vg_dry(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
+void vg_dry_begin(char* buf, int n);
+void vg_dry_end();
+
 // a sticky error left by an earlier, unrelated HIP call in this thread must not be blamed on our launch
 static inline void vg_begin() { (void)hipGetLastError(); }
 static inline int vg_check_launch() {

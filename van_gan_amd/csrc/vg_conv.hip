@@ -821,14 +821,9 @@ static int fill_conv(const vg_conv_desc* d, GatherIn& g, ConvOut& k, ConvCls& q,
     // Tile choice.  Efficiency wants a wide channel panel (BN) and a big voxel tile (MSUB*64: fewer halo voxels per
     // output voxel, more MFMAs per staged byte); the chip wants >= ~2 workgroups per CU.  Small grids (16^3, 8^3 levels)
     // therefore take narrow panels / small tiles.  Within a class, prefer <= 80 KiB of LDS (two workgroups per CU).
-    static int force_msub = -1, no_wlds = -1, force_bn = -1, use_dma = 0, max_ms16 = 8;
-    if (force_msub < 0) {
-        const char* e5 = getenv("VG_CONV_MS16"); max_ms16 = e5 ? atoi(e5) : 8;
-        const char* e4 = getenv("VG_CONV_DMA"); use_dma = e4 ? atoi(e4) : 0;    // measured neutral (51.5 vs 51.7 ms/step): these kernels are issue-bound, not latency-bound
-        const char* e = getenv("VG_CONV_MSUB"); force_msub = e ? atoi(e) : 0;
-        const char* e2 = getenv("VG_CONV_NOWLDS"); no_wlds = e2 ? atoi(e2) : 0;
-        const char* e3 = getenv("VG_CONV_BN"); force_bn = e3 ? atoi(e3) : 0;
-    }
+    const int max_ms16 = vg_tune("CONV_MS16", 8);
+    const int use_dma = vg_tune("CONV_DMA", 0);     // measured neutral (51.5 vs 51.7 ms/step): these kernels are issue-bound, not latency-bound
+    const int force_msub = vg_tune("CONV_MSUB", 0), no_wlds = vg_tune("CONV_NOWLDS", 0), force_bn = vg_tune("CONV_BN", 0);
     const int bn_max = d->Cout <= 16 ? 16 : (d->Cout <= 32 ? 32 : 64);
     int found = 0, rc = VG_ELDS;
     long best_score = -1;
@@ -885,8 +880,7 @@ static int fill_conv(const vg_conv_desc* d, GatherIn& g, ConvOut& k, ConvCls& q,
 
 // ---- wide-layer flavour (conv32_kernel): eligibility and tile plan ----
 static int plan_conv32(const vg_conv_desc* d, const ConvOut& k, const ConvCls& q, GatherIn& g, int& BN, int& MSUB, int& lds) {
-    static int use32 = -1;
-    if (use32 < 0) { const char* e = getenv("VG_CONV32"); use32 = e ? atoi(e) : 1; }
+    const int use32 = vg_tune("CONV32", 1);
     const int Cin = d->c_src0 + d->c_src1;
     if (!use32 || d->f32 || (q.ncls != 1 && !q.par) || (d->Cout % 64) || Cin < 64 || Cin == 1 || d->tanh_out || (d->CK % 16)) return VG_EINVAL;
     const int ncp = q.par ? q.ncls : 1;
@@ -928,6 +922,9 @@ static int launch_conv32b(const GatherIn& g, const ConvOut& k, const ConvCls& q,
     const int ny = k.Cout / BN;
     const int ncp = CP ? q.ncls : 1;
     int bx = 256 * per_cu / (ny * g.N * ncp); if (bx < 1) bx = 1; if (bx > tiles) bx = tiles;
+    // variant name for the coverage tests: template arguments + the two run-time regimes that change which code runs
+    // (walk: a workgroup visits more than one tile; ch: several channel chunks per tile)
+    if (vg_dry("conv32<%d,%d,n%d,cp%d>|walk%d|ch%d", BN, MSUB, (int)NOISE, (int)CP, tiles > bx ? 1 : 0, k.nchunks > 1 ? 1 : 0)) return VG_OK;
     hipLaunchKernelGGL((conv32_kernel<BN, MSUB, NOISE, CP>), dim3(bx * ncp, ny, g.N), dim3(256), lds, s, g, k, q);
     return vg_check_launch();
 }
@@ -958,6 +955,14 @@ extern "C" int vg_conv3d_plan(const vg_conv_desc* d, int32_t* plan4) {
     return VG_OK;
 }
 
+extern "C" int vg_conv3d_variant(const vg_conv_desc* d, char* buf, int buflen) {
+    if (!buf || buflen < 64) return VG_EINVAL;
+    vg_dry_begin(buf, buflen);
+    const int rc = vg_conv3d(d, nullptr);
+    vg_dry_end();
+    return rc;
+}
+
 extern "C" int vg_conv3d_lds_bytes(const vg_conv_desc* d) {
     vg_begin();
     GatherIn g; ConvOut k; ConvCls q; int BN, MSUB, lds;
@@ -975,8 +980,7 @@ static int launch_conv3(const GatherIn& g, const ConvOut& k, const ConvCls& q, i
     }
     // persistent grid = what is resident at once (register cap: 3 workgroups per CU, 2 for the 8-sub-tile variants; LDS):
     // every further workgroup would repeat the per-workgroup prologue (weight panel, tables) for fewer tiles each
-    static int wg_env = -1;
-    if (wg_env < 0) { const char* e = getenv("VG_CONV_WGS"); wg_env = e ? atoi(e) : 0; }
+    const int wg_env = vg_tune("CONV_WGS", 0);
     int per_cu = ((BN / 16) * MSUB >= VG_CONV_MW2) ? 2 : VG_CONV_WAVES;
     if (lds > 0 && VG_LDS_LIMIT / lds < per_cu) per_cu = VG_LDS_LIMIT / lds;
     if (per_cu < 1) per_cu = 1;
@@ -986,6 +990,8 @@ static int launch_conv3(const GatherIn& g, const ConvOut& k, const ConvCls& q, i
     const int ncp = MC == 2 ? q.ncls : 1;
     int bx = wg_target / (ny * g.N * ncp); if (bx < 1) bx = 1; if (bx > tiles) bx = tiles;
     dim3 grid(bx * ncp, ny, g.N);
+    if (vg_dry("conv<%s,%d,%d,n%d,wl%d,dma%d,mc%d,c1%d>|walk%d|ch%d", sizeof(T) == 4 ? "f32" : "bf16", BN, MSUB, (int)NOISE, (int)WL, (int)DMA,
+               MC, (int)C1, tiles > bx ? 1 : 0, k.nchunks > 1 ? 1 : 0)) return VG_OK;
     hipLaunchKernelGGL((conv_kernel<T, BN, MSUB, NOISE, WL, DMA, MC, C1>), grid, dim3(256), lds, s, g, k, q);
     return vg_check_launch();
 }

@@ -338,11 +338,7 @@ static int fill_anb(const vg_actnorm_bwd_desc* d, ANB& p, bool apply) {
 static dim3 anb_grid(const ANB& p, bool stats = false) {
     const int S = p.D * p.H * p.W;
     int bx = (S + p.vpb - 1) / p.vpb;
-    static int cap_total = -1, cap_stats = -1;
-    if (cap_total < 0) {
-        const char* e = getenv("VG_ANB_GRID_CAP"); cap_total = e ? atoi(e) : 767;
-        const char* e2 = getenv("VG_ANB_STATS_CAP"); cap_stats = e2 ? atoi(e2) : 511;
-    }
+    const int cap_total = vg_tune("ANB_GRID_CAP", 767), cap_stats = vg_tune("ANB_STATS_CAP", 511);
     // whole launch resident at once (the 8-channel kernels hold ~150 VGPRs: 3 blocks per CU = 768 slots; re-swept at the end of
     // round 1: 767 / 511 beat the earlier 2047 / 1023 by ~0.5 % of the step): one block more than that runs alone afterwards.
     // The caps are odd on purpose: the UB voxels a thread has in flight are gridDim.x*vpb voxels apart, and with a
@@ -553,6 +549,62 @@ extern "C" const char* vg_status_string(int code) {
         default: return "unknown status";
     }
 }
+// ------------------------------------------------------------------------------------------------
+// tuning registry and dry-run recorder (vg_common.h)
+// ------------------------------------------------------------------------------------------------
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <mutex>
+namespace {
+struct TuneEntry { char key[32]; int value; int state; };      // state: 0 unset, 1 from env/default (cached), 2 forced
+TuneEntry g_tune[64];
+int g_ntune = 0;
+std::mutex g_tune_mu;
+thread_local char* t_dry_buf = nullptr;
+thread_local int t_dry_len = 0;
+TuneEntry* tune_find(const char* key, bool create) {
+    for (int i = 0; i < g_ntune; ++i) if (!strcmp(g_tune[i].key, key)) return &g_tune[i];
+    if (!create || g_ntune >= 64 || strlen(key) >= sizeof(g_tune[0].key)) return nullptr;
+    TuneEntry* e = &g_tune[g_ntune++];
+    strcpy(e->key, key); e->value = 0; e->state = 0;
+    return e;
+}
+}
+int vg_tune(const char* key, int dflt) {
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    TuneEntry* e = tune_find(key, true);
+    if (!e) return dflt;
+    if (e->state == 0) {
+        char name[48]; snprintf(name, sizeof name, "VG_%s", key);
+        const char* v = getenv(name);
+        e->value = v ? atoi(v) : dflt; e->state = 1;
+    }
+    return e->value;
+}
+extern "C" int vg_set_tuning(const char* key, int value, int reset) {
+    if (!key) return VG_EINVAL;
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    TuneEntry* e = tune_find(key, true);
+    if (!e) return VG_EINVAL;
+    if (reset) e->state = 0; else { e->value = value; e->state = 2; }
+    return VG_OK;
+}
+bool vg_dry(const char* fmt, ...) {
+    if (!t_dry_buf) return false;
+    va_list ap; va_start(ap, fmt);
+    const int used = (int)strlen(t_dry_buf);
+    if (used < t_dry_len - 2) {
+        if (used) { t_dry_buf[used] = ';'; t_dry_buf[used + 1] = 0; }
+        const int u2 = (int)strlen(t_dry_buf);
+        vsnprintf(t_dry_buf + u2, t_dry_len - u2, fmt, ap);
+    }
+    va_end(ap);
+    return true;
+}
+void vg_dry_begin(char* buf, int n) { t_dry_buf = buf; t_dry_len = n; if (buf && n > 0) buf[0] = 0; }
+void vg_dry_end() { t_dry_buf = nullptr; t_dry_len = 0; }
+
 extern "C" int vg_version(void) {
     vg_begin(); return 2; }
 extern "C" int vg_abi_sizeof(int which) {

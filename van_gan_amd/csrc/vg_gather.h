@@ -377,7 +377,7 @@ static inline void pad_pitches(int hh, int hw, int tw, int th, int istr, int& hh
 static inline int fill_gather(const vg_conv_desc* d, GatherIn& g, int CK, int BM, int skew = 0, int dma = 0) {
     if (!d || !d->src0) return VG_EINVAL;
     g.f32 = d->f32 ? 1 : 0;
-    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("VG_DEBUG"); dbg = e ? atoi(e) : 0; } g.dbg = dbg; }
+    g.dbg = vg_tune("DEBUG", 0);
     g.stamps = g_vg_stamps;
     const int Cin = d->c_src0 + d->c_src1;
     if (Cin < 1 || d->ntaps < 1 || d->ntaps > VG_MAX_TAPS) return VG_EINVAL;
@@ -408,8 +408,7 @@ static inline int fill_gather(const vg_conv_desc* d, GatherIn& g, int CK, int BM
     }
     g.tmin_d = mn[0]; g.tmin_h = mn[1]; g.tmin_w = mn[2];
     g.US = d->f32 ? 32 : 16;
-    { static int pl = -2; if (pl == -2) { const char* e = getenv("VG_PLANAR"); pl = e ? atoi(e) : -1; }
-      g.planar = pl >= 0 ? pl : (CK <= 48 && d->istr == 1); }
+    { const int pl = vg_tune("PLANAR", -1); g.planar = pl >= 0 ? pl : (CK <= 48 && d->istr == 1); }
     // tile shape: powers of two with product BM that minimise the halo volume (staging work and L2 traffic scale with
     // it); the innermost extent stays >= 8 voxels where the grid allows so that rows remain long contiguous runs
     int TW = 1, TH = 1, TD = 1;

@@ -467,11 +467,7 @@ bool c1k3_fill(const vg_conv_desc* d, C1K3& p) {
     return true;
 }
 
-bool pw_enabled() {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("VG_PW"); on = e ? atoi(e) : 1; }
-    return on != 0;
-}
+bool pw_enabled() { return vg_tune("PW", 1) != 0; }
 // common shape test: one centre tap, unit strides, whole grid, plain single source
 bool pw_shape_ok(const vg_conv_desc* d) {
     if (!pw_enabled() || d->ntaps != 1 || d->tap_d[0] || d->tap_h[0] || d->tap_w[0]) return false;
@@ -500,6 +496,7 @@ int vg_pointwise_conv(const vg_conv_desc* d, hipStream_t s) {
             const int64_t cap = (2047 / d->N) > 0 ? (2047 / d->N) : 1;
             if (b > cap) b = cap;
             const dim3 grid((int)b, d->N);
+            if (vg_dry("c1k3_fwd<%s,%s>", d->f32 ? "f32" : "bf16", d->src_f32 ? "f32" : "bf16")) return VG_OK;
             if (d->f32) {
                 if (d->src_f32) hipLaunchKernelGGL((c1k3_fwd_kernel<float, float>), grid, dim3(256), 0, s, c);
                 else hipLaunchKernelGGL((c1k3_fwd_kernel<float, bf16_t>), grid, dim3(256), 0, s, c);
@@ -521,6 +518,7 @@ int vg_pointwise_conv(const vg_conv_desc* d, hipStream_t s) {
     if (d->Cout == 1 && Cin >= 8 && Cin <= 32 && (Cin % 8) == 0) {
         p.C = Cin;
         const dim3 grid(pw_blocks((p.S + 1) / 2, d->N), d->N);
+        if (vg_dry("pw_cto1<%s,%d>", d->f32 ? "f32" : "bf16", Cin / 8 > 4 ? 4 : Cin / 8)) return VG_OK;
 #define PW_CTO1(T)                                                                                                      \
         switch (Cin / 8) {                                                                                              \
             case 1: hipLaunchKernelGGL((pw_cto1_kernel<T, 1>), grid, dim3(256), 0, s, p); break;                        \
@@ -537,6 +535,7 @@ int vg_pointwise_conv(const vg_conv_desc* d, hipStream_t s) {
         p.kc_pad = ((d->CK + 31) / 32) * 32;                 // one tap, one chunk: row stride of the packed operand
         const int vpb = 256 / (p.C >> 3);
         const dim3 grid(pw_blocks((p.S + 3) / 4 * (256 / vpb), d->N), d->N);
+        if (vg_dry("pw_1toc<%s>", d->f32 ? "f32" : "bf16")) return VG_OK;
         if (d->f32) hipLaunchKernelGGL((pw_1toc_kernel<float>), grid, dim3(256), 0, s, p);
         else hipLaunchKernelGGL((pw_1toc_kernel<bf16_t>), grid, dim3(256), 0, s, p);
         return vg_check_launch();
@@ -548,6 +547,7 @@ int vg_pointwise_conv(const vg_conv_desc* d, hipStream_t s) {
         const int Ktot = nchunks * p.kc_pad;
         const int vpb = 256 / (p.C >> 3);
         const dim3 grid(pw_blocks((p.S + 1) / 2 * (256 / vpb), d->N), d->N);
+        if (vg_dry("pw_ctoc<%s,%d>", d->f32 ? "f32" : "bf16", Cin / 8)) return VG_OK;
         if (d->f32) {
             if (Cin == 8) hipLaunchKernelGGL((pw_ctoc_kernel<float, 1>), grid, dim3(256), 0, s, p, Cin, Ktot);
             else hipLaunchKernelGGL((pw_ctoc_kernel<float, 2>), grid, dim3(256), 0, s, p, Cin, Ktot);
@@ -571,6 +571,7 @@ int vg_pointwise_wgrad(const vg_conv_desc* d, const void* dy, int dy_f32, int T_
             if (b > cap) b = cap;
             if (b < 1) b = 1;
             const dim3 grid((int)b, d->N);
+            if (vg_dry("c1k3_wgrad<%s,%s>", d->f32 ? "f32" : "bf16", d->src_f32 ? "f32" : "bf16")) return VG_OK;
             if (d->f32) {
                 if (d->src_f32) hipLaunchKernelGGL((c1k3_wgrad_kernel<float, float>), grid, dim3(256), 0, s, c);
                 else hipLaunchKernelGGL((c1k3_wgrad_kernel<float, bf16_t>), grid, dim3(256), 0, s, c);
@@ -597,6 +598,7 @@ int vg_pointwise_wgrad(const vg_conv_desc* d, const void* dy, int dy_f32, int T_
     if (b > cap) b = cap;
     if (b < 1) b = 1;
     const dim3 grid((int)b, d->N);
+    if (vg_dry("pw_wgrad<%s,%s>", d->f32 ? "f32" : "bf16", c_to_1 ? "cto1" : "1toc")) return VG_OK;
     if (c_to_1) {
         if (d->f32) hipLaunchKernelGGL((pw_wgrad_kernel<float, true>), grid, dim3(256), 0, s, p);
         else hipLaunchKernelGGL((pw_wgrad_kernel<bf16_t, true>), grid, dim3(256), 0, s, p);

@@ -349,8 +349,7 @@ extern "C" int vg_conv3d_wgrad(const vg_conv_desc* d, const void* dy, int dy_f32
     const int RMAX = Q == 1 ? 24 : (Q == 2 ? 12 : 6);
     const int esz = d->f32 ? 4 : 2;
     GatherIn g; WgradK k;
-    static int max_bm = -1, max_cib = 64;
-    if (max_bm < 0) { const char* e = getenv("VG_WGRAD_BM"); max_bm = e ? atoi(e) : 256; const char* e2 = getenv("VG_WGRAD_CIB"); max_cib = e2 ? atoi(e2) : 64; }
+    const int max_bm = vg_tune("WGRAD_BM", 256), max_cib = vg_tune("WGRAD_CIB", 64);
     // candidate (BM, CIB) in order of preference: large tile + all channels, LDS <= 80 KiB so that two workgroups fit a CU
     int best_bm = 0, best_cib = 0, best_lds = 0;
     for (int pass = 0; pass < 2 && !best_bm; ++pass) {
@@ -382,8 +381,7 @@ extern "C" int vg_conv3d_wgrad(const vg_conv_desc* d, const void* dy, int dy_f32
     k.total_tiles = d->N * g.tiles_d * g.tiles_h * g.tiles_w;
     const int by = k.ntg * k.ncib * k.ncob;
     // persistent grid = resident capacity (2 workgroups per CU for the big-slab variants, 3 for the small ones; LDS)
-    static int wg_env = -1;
-    if (wg_env < 0) { const char* e = getenv("VG_WGRAD_WGS"); wg_env = e ? atoi(e) : 0; }
+    const int wg_env = vg_tune("WGRAD_WGS", 0);
     const int rw_ = (k.tpg * rows_per_tap + 3) / 4;
     const int rmax_sel = d->f32 ? RMAX : (rw_ <= 2 ? 2 : (rw_ <= 8 && Q <= 2 ? 8 : RMAX));
     int per_cu = (rmax_sel * Q >= VG_WGRAD_2W) ? 2 : 3;
@@ -401,6 +399,11 @@ extern "C" int vg_conv3d_wgrad(const vg_conv_desc* d, const void* dy, int dy_f32
     // rows per wave actually needed: small slabs (27 taps x 16 channels = 7 rows per wave) take the kernel variant with
     // few accumulators (3 workgroups per CU instead of 2)
     const int rw = (k.tpg * rows_per_tap + 3) / 4;
+    {
+        const int rsel = d->f32 ? RMAX : (rw <= 2 ? 2 : ((rw <= 8 && Q <= 2) ? 8 : RMAX));
+        if (vg_dry("wgrad<%s,%d,%d,n%d>|bm%d|cib%d|part%d|walk%d", d->f32 ? "f32" : "bf16", rsel, Q, g.noise ? 1 : 0, best_bm, CIB,
+                   k.part ? 1 : 0, k.total_tiles > bx ? 1 : 0)) return VG_OK;
+    }
     if (d->f32) {
         if (Q == 1) launch_wgrad<float, 24, 1>(g, k, grid, lds, s);
         else if (Q == 2) launch_wgrad<float, 12, 2>(g, k, grid, lds, s);
@@ -421,4 +424,15 @@ extern "C" int vg_conv3d_wgrad(const vg_conv_desc* d, const void* dy, int dy_f32
         hipLaunchKernelGGL(reduce_partials_kernel, dim3((k.dw_elems + 63) / 64), dim3(256), 0, s, k.part, bx, k.dw_elems, dw);
     }
     return vg_check_launch();
+}
+
+extern "C" int vg_conv3d_wgrad_variant(const vg_conv_desc* d, int dy_f32, const int32_t* tap_idx_host, int T_total,
+                                       int64_t scratch_bytes, char* buf, int buflen) {
+    if (!buf || buflen < 64) return VG_EINVAL;
+    vg_dry_begin(buf, buflen);
+    // dummy non-null operands: nothing is launched or dereferenced in a dry run
+    const int rc = vg_conv3d_wgrad(d, (const void*)(uintptr_t)0x1000, dy_f32, tap_idx_host, T_total, (float*)(uintptr_t)0x1000,
+                                   (float*)(uintptr_t)0x1000, scratch_bytes > 0 ? (float*)(uintptr_t)0x1000 : nullptr, scratch_bytes, nullptr);
+    vg_dry_end();
+    return rc;
 }

@@ -22,7 +22,62 @@ def _p(t: Optional[torch.Tensor]) -> Optional[int]:
 
 
 def stream() -> int:
+    if DRY is not None:
+        return 0
     return torch.cuda.current_stream().cuda_stream
+
+
+class DryRun:
+    """Context manager: every libvangan_hip.so call made through this module is replaced by a no-op, except that
+    vg_conv3d / vg_conv3d_wgrad run their complete host-side dispatch WITHOUT launching and report the kernel variant they
+    selected (vg_conv3d_variant / vg_conv3d_wgrad_variant).  Works on CPU tensors: the schedules of nets.py can be walked on
+    a box without a GPU to list the kernels a configuration would run (tests/test_variant_coverage.py).
+    records: [(kind, layer name, variant string)], kind in fwd / dgrad / wgrad."""
+
+    _PASS = ('vg_conv3d_plan', 'vg_packed_ktot', 'vg_packed_rows', 'vg_conv3d_lds_bytes', 'vg_status_string', 'vg_set_tuning')
+
+    def __init__(self):
+        self.records = []
+        self.tag = ('?', '?')
+        self.recipe = None          # how to rebuild the call that is being recorded (ConvLayer fills it in)
+        self.recipes = []           # parallel to records
+
+    def __getattr__(self, name):            # stands in for `lib`
+        real = _lib.lib
+        if name in self._PASS:
+            return getattr(real, name)
+        if name == 'vg_conv3d':
+            def conv(dref, _stream):
+                buf = C.create_string_buffer(512)
+                rc = real.vg_conv3d_variant(dref, buf, 512)
+                self.records.append(self.tag + (buf.value.decode(),)); self.recipes.append(self.recipe)
+                return rc
+            return conv
+        if name == 'vg_conv3d_wgrad':
+            def wgrad(dref, _dy, dy_f32, tap_idx, T, _gw, _gb, _sc, sc_bytes, _stream):
+                buf = C.create_string_buffer(512)
+                rc = real.vg_conv3d_wgrad_variant(dref, dy_f32, tap_idx, T, sc_bytes, buf, 512)
+                self.records.append(self.tag + (buf.value.decode(),)); self.recipes.append(self.recipe)
+                return rc
+            return wgrad
+        return lambda *a: 0
+
+    def variants(self):
+        return sorted({(k, v) for k, _, v in self.records})
+
+    def __enter__(self):
+        global DRY, lib
+        self._saved = lib
+        DRY, lib = self, self
+        return self
+
+    def __exit__(self, *exc):
+        global DRY, lib
+        DRY, lib = None, self._saved
+        return False
+
+
+DRY: Optional[DryRun] = None
 
 
 class KernelProfile:
@@ -91,6 +146,7 @@ def side_join():
 
 
 WGRAD_SCRATCH = {}     # (device, stream) -> fp32 scratch for the partial-slab weight-gradient reduction (256 MB)
+WGRAD_SCRATCH_ELEMS = 64 << 20
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -128,7 +184,7 @@ class Arena:
         self.off = start + nbytes
         self.peak = max(self.peak, self.off)
         t = self.buf[start:start + nbytes].view(dtype).view(*shape)
-        if zero:
+        if zero and DRY is None:
             t.zero_()
         return t
 
@@ -163,6 +219,11 @@ class Src:
     def C(self):
         return self.c0 + self.c1
 
+    def recipe(self) -> dict:
+        """Shape-level description (no data): enough to rebuild an equivalent operand with random contents."""
+        return dict(N=self.N, dims=(self.D, self.H, self.W), c0=self.c0, c1=self.c1, shift0=self.shift0, f32=bool(self.f32),
+                    affine=self.scale is not None, act=self.act, noise=self.noise is not None, noise_pad=self.noise_pad)
+
     def fill(self, d: ConvDesc):
         d.src0, d.src1 = _p(self.x0), _p(self.x1)
         d.c_src0, d.c_src1, d.src0_shift, d.src_f32 = self.c0, self.c1, self.shift0, int(self.f32)
@@ -190,6 +251,7 @@ class ConvLayer:
     def __init__(self, store, name: str, k: int, cin: int, cout: int, stride: int, pad: str, bias: bool,
                  in_dims: Tuple[int, int, int], need_dgrad: bool = True, dtype: torch.dtype = torch.bfloat16):
         self.dtype, self.f32 = dtype, int(dtype == torch.float32)
+        self.ctor = dict(k=k, cin=cin, cout=cout, stride=stride, pad=pad, bias=bias, in_dims=tuple(in_dims), need_dgrad=need_dgrad)
         self.name, self.k, self.cin, self.cout, self.stride, self.pad, self.has_bias = name, k, cin, cout, stride, pad, bias
         self.w, self.gw = store.param(name + '.w'), store.grad(name + '.w')
         self.b, self.gb = (store.param(name + '.b'), store.grad(name + '.b')) if bias else (None, None)
@@ -353,6 +415,10 @@ class ConvLayer:
         d.tanh_out = int(tanh)
         d.out, d.out_f32, d.accumulate = _p(out), int(out.dtype == torch.float32), 0
         d.out_sums = _p(sums)
+        if DRY is not None:
+            DRY.tag = ('fwd', self.name)
+            DRY.recipe = dict(kind='fwd', layer=self.ctor, src=src.recipe(), res=res is not None, tanh=bool(tanh),
+                              sums=sums is not None, out_f32=out.dtype == torch.float32)
         e0 = PROF.begin() if PROF is not None else None
         check(lib.vg_conv3d(C.byref(d), stream()), 'vg_conv3d ' + self.name)
         if e0 is not None:
@@ -371,13 +437,16 @@ class ConvLayer:
 
     def _wgrad(self, src: Src, dy: torch.Tensor):
         d = self._fwd_desc(src)
+        if DRY is not None:
+            DRY.tag = ('wgrad', self.name)
+            DRY.recipe = dict(kind='wgrad', layer=self.ctor, src=src.recipe(), dy_f32=dy.dtype == torch.float32)
         e0 = PROF.begin() if PROF is not None else None
         # one partial-slab scratch per (device, stream): launches on one stream reuse it in order, the two lanes of the
         # engine issue weight gradients concurrently and must not share it
         key = (dy.device, stream())
         sc = WGRAD_SCRATCH.get(key)
         if sc is None:
-            sc = WGRAD_SCRATCH[key] = torch.empty(64 << 20, dtype=torch.float32, device=dy.device)
+            sc = WGRAD_SCRATCH[key] = torch.empty(WGRAD_SCRATCH_ELEMS, dtype=torch.float32, device=dy.device)
         check(lib.vg_conv3d_wgrad(C.byref(d), _p(dy), int(dy.dtype == torch.float32), self.f_idx_host, self.f_T,
                                   _p(self.gw), _p(self.gb), _p(sc), sc.numel() * 4, stream()), 'vg_conv3d_wgrad ' + self.name)
         if e0 is not None:
@@ -426,6 +495,10 @@ class ConvLayer:
     def dgrad(self, dy: torch.Tensor, N: int, out: torch.Tensor, accumulate: bool):
         """d/d input: writes the reflect-PADDED grid for 'reflect' convs (fold it with actnorm_bwd), the plain
         input grid for 'same' convs.  out: [N, *buf_dims, cin] bf16 (or f32 when cin==1)."""
+        if DRY is not None:
+            DRY.tag = ('dgrad', self.name)
+            DRY.recipe = dict(kind='dgrad', layer=self.ctor, N=N, accumulate=bool(accumulate), dy_f32=dy.dtype == torch.float32,
+                              out_f32=out.dtype == torch.float32)
         if self.d_fused:
             d = self._fused_desc(dy, N, out, accumulate)
             e0 = PROF.begin() if PROF is not None else None
