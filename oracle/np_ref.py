@@ -242,3 +242,81 @@ def adam_first_step(w, g, lr=2e-4, b1=0.5, b2=0.9, eps=1e-7, clipnorm=100.0):
     m, v = (1 - b1) * g, (1 - b2) * g * g
     lr_t = lr * math.sqrt(1 - b2) / (1 - b1)
     return w - lr_t * m / (np.sqrt(v) + eps)
+
+
+# ------------------------------------------------------------------------------------------------------
+# Hand-derived BACKWARD of one residual block (resunet_model.py:103-143), closed forms in numpy: the second,
+# independent implementation of what torch autograd computes in oracle/vangan_oracle.py::_res_block.
+# ------------------------------------------------------------------------------------------------------
+def conv3d_backward(x, w, gy, stride=1, padding='valid'):
+    """-> (dx, dw, db) of conv3d above: explicit tap loop (dx scatters gy @ w^T back to the strided input slice)."""
+    kd, kh, kw, ci, co = w.shape
+    pads = [(0, 0)] * 3
+    if padding == 'same':
+        pads = [same_pads(x.shape[1 + a], (kd, kh, kw)[a], stride) for a in range(3)]
+    xp = np.pad(x, ((0, 0), pads[0], pads[1], pads[2], (0, 0)))
+    N, od, oh, ow, _ = gy.shape
+    dxp = np.zeros_like(xp, dtype=np.float64)
+    dw = np.zeros_like(w, dtype=np.float64)
+    for a in range(kd):
+        for b in range(kh):
+            for c in range(kw):
+                sl = (slice(None), slice(a, a + (od - 1) * stride + 1, stride), slice(b, b + (oh - 1) * stride + 1, stride),
+                      slice(c, c + (ow - 1) * stride + 1, stride), slice(None))
+                dw[a, b, c] = np.einsum('ndhwi,ndhwo->io', xp[sl], gy)
+                dxp[sl] += gy @ w[a, b, c].T
+    D, H, W = x.shape[1:4]
+    dx = dxp[:, pads[0][0]:pads[0][0] + D, pads[1][0]:pads[1][0] + H, pads[2][0]:pads[2][0] + W, :]
+    return dx, dw, gy.sum(axis=(0, 1, 2, 3))
+
+
+def reflect_pad1_backward(gp):
+    """Transpose of reflect_pad1: every padded position adds its gradient to the interior voxel it mirrors."""
+    g = gp.copy()
+    for ax in (1, 2, 3):
+        n = g.shape[ax] - 2
+        idx = np.arange(-1, n + 1)
+        idx = np.where(idx < 0, -idx, idx)
+        idx = np.where(idx >= n, 2 * n - 2 - idx, idx)
+        out = np.zeros(g.shape[:ax] + (n,) + g.shape[ax + 1:], dtype=np.float64)
+        np.add.at(out, (slice(None),) * ax + (idx,), g)
+        g = out
+    return g
+
+
+def instance_norm_backward(x, gamma, gy):
+    """-> (dx, dgamma, dbeta) of instance_norm above (biased variance, eps inside the square root):
+    dx = gamma*rstd * (gy - mean(gy) - xhat*mean(gy*xhat))."""
+    mu = x.mean(axis=(1, 2, 3), keepdims=True)
+    var = ((x - mu) ** 2).mean(axis=(1, 2, 3), keepdims=True)
+    rstd = 1.0 / np.sqrt(var + IN_EPS)
+    xh = (x - mu) * rstd
+    dgamma, dbeta = (gy * xh).sum(axis=(0, 1, 2, 3)), gy.sum(axis=(0, 1, 2, 3))
+    m1 = gy.mean(axis=(1, 2, 3), keepdims=True)
+    m2 = (gy * xh).mean(axis=(1, 2, 3), keepdims=True)
+    return gamma * rstd * (gy - m1 - xh * m2), dgamma, dbeta
+
+
+def _cb_backward(p, name, x, stride, gy):
+    n = instance_norm(x, p[name + '.in.gamma'], p[name + '.in.beta'])
+    a = relu(n)
+    gap, dw, db = conv3d_backward(reflect_pad1(a), p[name + '.conv.w'], gy, stride, 'valid')
+    gn = reflect_pad1_backward(gap) * (n > 0)
+    dx, dg, dbt = instance_norm_backward(x, p[name + '.in.gamma'], gn)
+    return dx, {name + '.conv.w': dw, name + '.conv.b': db, name + '.in.gamma': dg, name + '.in.beta': dbt}
+
+
+def res_block_backward(p, name, x, stride, gout):
+    """d(sum(out * gout)) / d(x, parameters) for out = _res(p, name, x, stride)."""
+    r = _cb(p, name + '.cb1', x, stride)
+    sc = conv3d(x, p[name + '.short.w'], p[name + '.short.b'], stride, 'same')
+    grads = {}
+    gr, g2 = _cb_backward(p, name + '.cb2', r, 1, gout)
+    grads.update(g2)
+    gsc, dg, dbt = instance_norm_backward(sc, p[name + '.short.in.gamma'], gout)
+    grads[name + '.short.in.gamma'], grads[name + '.short.in.beta'] = dg, dbt
+    dx_s, dw, db = conv3d_backward(x, p[name + '.short.w'], gsc, stride, 'same')
+    grads[name + '.short.w'], grads[name + '.short.b'] = dw, db
+    dx_1, g1 = _cb_backward(p, name + '.cb1', x, stride, gr)
+    grads.update(g1)
+    return dx_1 + dx_s, grads

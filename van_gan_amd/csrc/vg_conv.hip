@@ -16,148 +16,11 @@
 //     epilogue stores 8 B per lane, 512 B contiguous per 16-voxel subtile.
 //   epilogue: bias, residual*scale+shift, tanh, bf16 round, per-(n,c) sum / sum-of-squares of
 //   the stored values (for the next InstanceNorm), store or accumulate.
-#include "vg_gather.h"
+#include "vg_conv_common.h"
 
 unsigned long long* g_vg_stamps = nullptr;
 extern "C" int vg_set_stamp_buffer(void* p) { g_vg_stamps = (unsigned long long*)p; return VG_OK; }
 #define VG_STAMP(slot) do { if (g.stamps && tid == 0 && it < 8) g.stamps[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 64 + it * 8 + (slot)] = __builtin_readcyclecounter(); } while (0)
-
-struct ConvOut {
-    int OD, OH, OW, ostr, ood, ooh, oow, BD, BH, BW, Cout;
-    const void* wp; int Ktot, nchunks, kc_pad;
-    const float* bias; const void* res; const float* rs; const float* rb; int tanh_out;
-    void* out; int out_f32, accumulate; float* sums;
-    int w_lds;          // 1: the BN x Ktot weight panel of this workgroup is copied to LDS once (row stride WRS bytes)
-    int dma;            // 1: LDS-DMA double-buffered staging (planar bf16 image, weights in LDS)
-    int WRS;
-};
-// output-parity classes fused into one launch (data gradient of a strided conv): a separate kernel argument that only the
-// multi-class kernel variants read
-struct ConvCls {
-    int ncls;
-    int par;                        // 1: class-parallel launch (blockIdx.x = walker * ncls + class; any number of channel chunks)
-    int tap0[9];                    // taps of class c: [tap0[c], tap0[c+1])
-    const void* wp[8];              // packed weights of class c, ktot[c] elements per row
-    int ktot[8], woff[8];           // ... and the byte offset of its panel inside the LDS weight area
-    int ks0[9];                     // first K-step of class c in the koff table
-    int off[8][3], it[8][3];        // output offset / number of outputs per axis of class c
-};
-
-// 4 consecutive channels as stored (epilogue operands)
-template <typename T> struct Vec4;
-template <> struct Vec4<bf16_t> { bf16x4 v; };
-template <> struct Vec4<float> { f32x4 v; };
-__device__ __forceinline__ void vec4_load(Vec4<bf16_t>& r, const bf16_t* p) { r.v = *(const __attribute__((address_space(1))) bf16x4*)(uintptr_t)p; }
-__device__ __forceinline__ void vec4_load(Vec4<float>& r, const float* p) { r.v = *(const __attribute__((address_space(1))) f32x4*)(uintptr_t)p; }
-__device__ __forceinline__ void vec4_unpack(const Vec4<bf16_t>& r, float* o) { for (int j = 0; j < 4; ++j) o[j] = bf2f((bf16_t)r.v[j]); }
-__device__ __forceinline__ void vec4_unpack(const Vec4<float>& r, float* o) { for (int j = 0; j < 4; ++j) o[j] = r.v[j]; }
-
-#ifndef VG_CONV_MW2
-#define VG_CONV_MW2 4      // sub-tiles per wave from which a variant is compiled for 2 waves per SIMD (256 VGPRs)
-#endif
-#ifndef VG_CONV_WAVES
-#define VG_CONV_WAVES 3      // waves per SIMD the register allocation must allow (3 workgroups per CU)
-#endif
-template <typename T> using lds_ptr = const __attribute__((address_space(3))) T*;
-template <typename T> using glb_ptr = const __attribute__((address_space(1))) T*;
-
-// MFMA over the (tap, channel-group) pairs of one channel chunk.  w points at this lane's fragment of K-step 0 (LDS
-// panel or global row: WP carries the address space).  bf16: K-steps are processed KU at a time, all operand fetches of
-// a group issued before its first MFMA, the halo offsets of the NEXT group fetched meanwhile; the remainder steps run
-// one by one afterwards so that no MFMA sits under a condition (conditional MFMAs made the compiler shuttle the
-// accumulators between AGPRs and VGPRs around every group).
-template <typename T, int MW, typename WP>
-__device__ __forceinline__ void conv_mfma_chunk(f32x4 (&acc)[MW], WP w, const char* halo, const int (&rowbase)[MW],
-                                                const int* tapoff, const int* koff, int ksteps, int ntaps, int CK, int CS, int lane) {
-    if constexpr (sizeof(T) == 4) {
-        // exact-parity mode: f32 operands, v_mfma_f32_16x16x4_f32 (k = 4 consecutive channels of one tap)
-        int tap = 0, ch0 = 0;
-        const int nk4 = (ntaps * CK) >> 2;
-        for (int s = 0; s < nk4; ++s) {
-            const int chn = ch0 + (lane >> 4);
-            const int off = tapoff[tap] + (chn >> 3) * CS + (chn & 7) * 4;
-            float b[MW];
-#pragma unroll
-            for (int i = 0; i < MW; ++i) b[i] = *(const float*)(halo + rowbase[i] + off);
-            const float a = w[s * 4];
-#pragma unroll
-            for (int i = 0; i < MW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[i], acc[i], 0, 0, 0);
-            ch0 += 4;
-            if (ch0 >= CK) { ch0 = 0; ++tap; }
-        }
-    } else {
-        // explicit two-stage software pipeline: while the MFMAs of K-step s run, the operand fragments of step s+1 are
-        // already on their way from LDS (and the halo offset of step s+2 is being fetched); sched_barriers keep the
-        // compiler from sinking the prefetch below the MFMAs again to save registers.
-        typedef const __attribute__((address_space(3))) bf16x8 lds_frag;
-        typedef const __attribute__((address_space(1))) bf16x8 glb_frag;
-        auto wfrag = [&](int step) -> bf16x8 {
-            if constexpr (__is_same(WP, lds_ptr<T>)) return *(lds_frag*)(w + step * 32);
-            else return *(glb_frag*)(w + step * 32);
-        };
-        const int kg = lane >> 4;
-        const int last = ksteps - 1;
-        const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-        if constexpr (!__is_same(WP, lds_ptr<T>)) {
-            // weights straight from L2 (panels too big for LDS: the wide layers): a ring of four fragments, i.e. the
-            // fetch for K-step s+4 is issued when step s has been multiplied -- one step of MFMAs (64-128 cycles) does not
-            // cover an L2 round trip.  Halo fragments ping-pong between two sets as in the LDS-weight loop below.
-            bf16x8 a[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) a[u] = wfrag(min(u, last));
-            bf16x8 bb[2][MW];
-            {
-                const int o0 = koff[kg];
-#pragma unroll
-                for (int i = 0; i < MW; ++i) bb[0][i] = *(const bf16x8*)(halo + rowbase[i] + o0);
-            }
-            int on1 = koff[min(1, last) * 4 + kg];
-            for (int s = 0; s < ksteps; s += 4) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int on2 = koff[min(s + u + 2, last) * 4 + kg];
-#pragma unroll
-                    for (int i = 0; i < MW; ++i) bb[(u + 1) & 1][i] = *(const bf16x8*)(halo + rowbase[i] + on1);
-                    if (s + u >= ksteps) a[u] = zero8;                 // phantom steps of the last group add zero
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int i = 0; i < MW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u], bb[u & 1][i], acc[i], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    a[u] = wfrag(min(s + u + 4, last));
-                    on1 = on2;
-                }
-            }
-            return;
-        }
-        bf16x8 a0 = wfrag(0), a1;
-        bf16x8 b0[MW], b1[MW];
-        {
-            const int o0 = koff[kg];
-#pragma unroll
-            for (int i = 0; i < MW; ++i) b0[i] = *(const bf16x8*)(halo + rowbase[i] + o0);
-        }
-        int o1 = koff[min(1, last) * 4 + kg];
-        for (int s = 0; s < ksteps; s += 2) {
-            const int o2 = koff[min(s + 2, last) * 4 + kg];
-            a1 = wfrag(min(s + 1, last));
-#pragma unroll
-            for (int i = 0; i < MW; ++i) b1[i] = *(const bf16x8*)(halo + rowbase[i] + o1);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < MW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0[i], acc[i], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            o1 = koff[min(s + 3, last) * 4 + kg];
-            a0 = wfrag(min(s + 2, last));
-#pragma unroll
-            for (int i = 0; i < MW; ++i) b0[i] = *(const bf16x8*)(halo + rowbase[i] + o2);
-            if (s + 1 >= ksteps) a1 = zero8;                       // odd K-step count: the phantom step adds zero
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < MW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1[i], acc[i], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-}
 
 // ------------------------------------------------------------------------------------------------------------------
 // LDS-DMA staging (planar bf16 images, multi-channel sources without noise).  The halo tile of the NEXT stage is copied
@@ -827,7 +690,10 @@ static int fill_conv(const vg_conv_desc* d, GatherIn& g, ConvOut& k, ConvCls& q,
     const int bn_max = d->Cout <= 16 ? 16 : (d->Cout <= 32 ? 32 : 64);
     int found = 0, rc = VG_ELDS;
     long best_score = -1;
-    int best_bn = 0, best_ms = 0, best_wl = 0, best_lds = 0, best_dma = 0;
+    int best_bn = 0, best_ms = 0, best_wl = 0, best_lds = 0, best_dma = 0, best_pc = 0;
+    // producer/consumer flavour (vg_conv_pc.hip): bf16, one class or class-parallel classes, synchronous-staging sources
+    const int use_pc = vg_tune("CONV_PC", 0);
+    const bool pc_ok = use_pc && !d->f32 && (q.ncls == 1 || (q.par && !d->noise && Cin != 1));
     // LDS-DMA staging: bf16 planar image of a multi-channel, noise-free source, weights resident in LDS
     const bool dma_ok = use_dma && !d->f32 && Cin != 1 && !d->noise && d->istr == 1 && d->CK <= 48 && q.ncls == 1;
     for (int bn = bn_max; bn >= 16; bn >>= 1) {
@@ -845,10 +711,19 @@ static int fill_conv(const vg_conv_desc* d, GatherIn& g, ConvOut& k, ConvCls& q,
             int wl = (wbytes <= 56 * 1024 && !no_wlds && !d->f32) ? 1 : 0;       // exact-parity mode reads weights from L2
             int need = conv_lds_bytes(g, bn, d->CK, wl ? wbytes : 0, 0, ksteps_total);
             if (need > 80 * 1024 && wl) { const int n2 = conv_lds_bytes(g, bn, d->CK, 0, 0, ksteps_total); if (n2 <= 80 * 1024 || need > VG_LDS_LIMIT) { wl = 0; need = n2; } }
+            int pc = 0;
+            if (pc_ok) {
+                // two halo buffers; weights in LDS while everything fits (one 512-thread workgroup per CU is the design point
+                // of the 8-sub-tile variants, two for the smaller ones)
+                int wl2 = (wbytes <= 56 * 1024 && !no_wlds) ? 1 : 0;
+                int need2 = vg_conv_pc_lds_bytes(g, bn, d->CK, wl2 ? wbytes : 0, ksteps_total);
+                if (need2 > VG_LDS_LIMIT && wl2) { wl2 = 0; need2 = vg_conv_pc_lds_bytes(g, bn, d->CK, 0, ksteps_total); }
+                if (need2 <= VG_LDS_LIMIT) { pc = 1; wl = wl2; need = need2; }
+            }
             if (need > VG_LDS_LIMIT) continue;
-            if (ms == 8 && need > 80 * 1024) continue;     // the 512-voxel tile only pays while two workgroups stay resident
+            if (!pc && ms == 8 && need > 80 * 1024) continue;     // the 512-voxel tile only pays while two workgroups stay resident
             int dma = 0;
-            if (dma_ok && wl) {
+            if (dma_ok && wl && !pc) {
                 GatherIn g2; rc = fill_gather(d, g2, d->CK, 64 * ms, 0, 1);
                 if (rc != VG_OK) return rc;
                 const int need2 = conv_lds_bytes(g2, bn, d->CK, wbytes, 1, ksteps_total);
@@ -862,10 +737,10 @@ static int fill_conv(const vg_conv_desc* d, GatherIn& g, ConvOut& k, ConvCls& q,
             const int ny_ = (d->Cout + bn - 1) / bn;
             const long useful = (long)((d->Cout + ny_ - 1) / ny_) * ms;
             const long score = fill * 100000 + useful * 100 + (need <= 80 * 1024 ? 50 : 0);
-            if (score > best_score) { best_score = score; best_bn = bn; best_ms = ms; best_wl = wl; best_lds = need; best_dma = dma; found = 1; }
+            if (score > best_score) { best_score = score; best_bn = bn; best_ms = ms; best_wl = wl; best_lds = need; best_dma = dma; best_pc = pc; found = 1; }
         }
     }
-    if (found) { BN = best_bn; MSUB = best_ms; k.w_lds = best_wl; k.dma = best_dma; lds = best_lds; }
+    if (found) { BN = best_bn; MSUB = best_ms; k.w_lds = best_wl; k.dma = best_dma; k.pc = best_pc; lds = best_lds; }
     if (!found) return VG_ELDS;
     rc = fill_gather(d, g, d->CK, 64 * MSUB, 0, k.dma);
     if (rc != VG_OK) return rc;
@@ -1040,6 +915,7 @@ extern "C" int vg_conv3d(const vg_conv_desc* d, vg_stream_t stream) {
     if (rc != VG_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
     { GatherIn g2; int bn2, ms2, lds2; if (plan_conv32(d, k, q, g2, bn2, ms2, lds2) == VG_OK) return launch_conv32(g2, k, q, bn2, ms2, lds2, s); }
+    if (k.pc) return vg_launch_conv_pc(g, k, q, BN, MSUB, lds, s);
     return d->f32 ? dispatch_conv<float>(g, k, q, BN, MSUB, lds, s) : dispatch_conv<bf16_t>(g, k, q, BN, MSUB, lds, s);
 }
 
