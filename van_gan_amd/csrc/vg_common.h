@@ -121,6 +121,9 @@ __device__ __forceinline__ void raw_unpack(const Raw8<float>& r, float* o) {
 }
 
 
+// opaque use + redefinition: the value must exist at this point of the program (no sinking of its load below it)
+__device__ __forceinline__ void raw_pin(Raw8<bf16_t>& r) { asm volatile("" : "+v"(r.v)); }
+__device__ __forceinline__ void raw_pin(Raw8<float>& r) { asm volatile("" : "+v"(r.a), "+v"(r.b)); }
 __device__ __forceinline__ void raw_mask(Raw8<bf16_t>& r, bool keep) { if (!keep) r.v = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0}; }
 __device__ __forceinline__ void raw_mask(Raw8<float>& r, bool keep) { if (!keep) { r.a = (f32x4){0.f, 0.f, 0.f, 0.f}; r.b = r.a; } }
 

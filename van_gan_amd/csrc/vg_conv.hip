@@ -691,7 +691,11 @@ static int fill_conv(const vg_conv_desc* d, GatherIn& g, ConvOut& k, ConvCls& q,
     int found = 0, rc = VG_ELDS;
     long best_score = -1;
     int best_bn = 0, best_ms = 0, best_wl = 0, best_lds = 0, best_dma = 0, best_pc = 0;
-    // producer/consumer flavour (vg_conv_pc.hip): bf16, one class or class-parallel classes, synchronous-staging sources
+    // producer/consumer flavour (vg_conv_pc.hip): bf16, one class or class-parallel classes, synchronous-staging sources.
+    // OPT-IN (VG_CONV_PC=1): layer by layer it is 10-20 % faster on the thin 128^3 / 64^3 layers (dec0.cb1 forward 0.226 ->
+    // 0.197 ms, its data gradient 0.290 -> 0.250, dec1.cb1 0.093 -> 0.082), but its 100-130 KiB of LDS pin one workgroup per CU,
+    // and in the two-lane schedule of the train step the kernels of the other lane can no longer share the CU: 33.6 -> 34.4 ms
+    // per step.
     const int use_pc = vg_tune("CONV_PC", 0);
     const bool pc_ok = use_pc && !d->f32 && (q.ncls == 1 || (q.par && !d->noise && Cin != 1));
     // LDS-DMA staging: bf16 planar image of a multi-channel, noise-free source, weights resident in LDS
@@ -712,13 +716,21 @@ static int fill_conv(const vg_conv_desc* d, GatherIn& g, ConvOut& k, ConvCls& q,
             int need = conv_lds_bytes(g, bn, d->CK, wl ? wbytes : 0, 0, ksteps_total);
             if (need > 80 * 1024 && wl) { const int n2 = conv_lds_bytes(g, bn, d->CK, 0, 0, ksteps_total); if (n2 <= 80 * 1024 || need > VG_LDS_LIMIT) { wl = 0; need = n2; } }
             int pc = 0;
-            if (pc_ok) {
+            if (pc_ok && vg_conv_pc_mode(g) >= 0) {
                 // two halo buffers; weights in LDS while everything fits (one 512-thread workgroup per CU is the design point
-                // of the 8-sub-tile variants, two for the smaller ones)
+                // of the variants with >= 4 sub-tiles per wave, two for the smaller ones)
                 int wl2 = (wbytes <= 56 * 1024 && !no_wlds) ? 1 : 0;
                 int need2 = vg_conv_pc_lds_bytes(g, bn, d->CK, wl2 ? wbytes : 0, ksteps_total);
                 if (need2 > VG_LDS_LIMIT && wl2) { wl2 = 0; need2 = vg_conv_pc_lds_bytes(g, bn, d->CK, 0, ksteps_total); }
-                if (need2 <= VG_LDS_LIMIT) { pc = 1; wl = wl2; need = need2; }
+                // it only pays when a workgroup runs several stages: its prologue stages the first tile with the consumers idle
+                // (enc3.cb2 data gradient, 2 stages per workgroup: 0.051 -> 0.064 ms; bridge forward, 4 stages: 0.052 -> 0.041)
+                int pcu = ((bn / 16) * ms >= 4) ? 1 : 2;
+                if (need2 > 0 && VG_LDS_LIMIT / need2 < pcu) pcu = VG_LDS_LIMIT / need2;
+                const long tiles_n = (long)g.tiles_d * g.tiles_h * g.tiles_w;
+                const long per_x = (long)((d->Cout + bn - 1) / bn) * d->N * (q.par ? q.ncls : 1);
+                long bxp = pcu > 0 ? 256L * pcu / per_x : 0; if (bxp < 1) bxp = 1; if (bxp > tiles_n) bxp = tiles_n;
+                const long stages = ((tiles_n + bxp - 1) / bxp) * k.nchunks;
+                if (need2 <= VG_LDS_LIMIT && stages >= vg_tune("CONV_PC_MINSTAGES", 3)) { pc = 1; wl = wl2; need = need2; }
             }
             if (need > VG_LDS_LIMIT) continue;
             if (!pc && ms == 8 && need > 80 * 1024) continue;     // the 512-voxel tile only pays while two workgroups stay resident

@@ -144,5 +144,7 @@ __device__ __forceinline__ void conv_mfma_chunk(f32x4 (&acc)[MW], WP w, const ch
 
 // vg_conv_pc.hip: producer/consumer flavour (512-thread workgroups: 4 MFMA waves + 4 staging waves, double-buffered halo image)
 int vg_launch_conv_pc(const GatherIn& g, const ConvOut& k, const ConvCls& q, int BN, int MSUB, int lds, hipStream_t s);
+// staging mode (VG_STAGE_*) the producer/consumer flavour would use for this source, -1: not supported there
+int vg_conv_pc_mode(const GatherIn& g);
 // LDS bytes of the producer/consumer flavour for this geometry (host)
 int vg_conv_pc_lds_bytes(const GatherIn& g, int BN, int CK, int wbytes, int ksteps_total);

@@ -29,6 +29,7 @@ struct GatherIn {
     // [k*k taps][k channels][Cout] kernel of that pseudo-convolution.  The halo image has no W halo (HW = tile width, unit
     // W step for either stride); HWx is the true input W extent of a tile (axis-table length), Cw the weight-side Cin.
     int wpack, HWx, wmin, Cw;
+    int lean;       // >= 0: lean staging mode (VG_STAGE_*) of a multi-channel bf16 source; -1: original column staging
     int dbg;        // development ablation flags (VG_DEBUG env): 1 skip halo staging, 2 skip dY staging, 4 skip MFMA
     unsigned long long* stamps;   // diagnostic build only (vg_set_stamp_buffer): s_memtime stamps per phase, else NULL
 };
@@ -74,11 +75,12 @@ __host__ __device__ __forceinline__ int stage_ncols(const GatherIn& g) { return 
 template <int C1 = 2>
 __host__ __device__ __forceinline__ int stage_axis_len(const GatherIn& g) { return g.HH + ((C1 != 0 && C1 != 3 && g.wpack) ? g.HWx : g.HW); }
 
+template <int NT = 256>
 __device__ __forceinline__ void build_column_table(const GatherIn& g, int* ctab, int tid) {
     const int gpc = g.Cin == 1 ? 1 : (g.CK >> 3);
     const int ncols = g.HH * g.HW * gpc;
     const int nv = g.HH * g.HW;
-    for (int col = tid; col < ncols; col += 256) {
+    for (int col = tid; col < ncols; col += NT) {
         // planar: voxel-fastest, 8 consecutive lanes write 8 consecutive units of one plane (conflict-free ds_write_b128);
         // row-major: channel-group-fastest, consecutive lanes read one voxel's contiguous channels
         const int cg = g.planar ? col / nv : col % gpc, v = g.planar ? col - cg * nv : col / gpc;
@@ -130,10 +132,11 @@ __device__ __forceinline__ void stage_affine_act(float* x, const f32x2* sc, cons
 // Work split of a tile: few columns (thin tiles) are additionally split into D segments so that all 256 threads carry
 // loads; otherwise threads take whole columns round-robin.  Returns this thread's first column, column stride, and D range.
 struct StageSplit { int col0, cstride, hd_lo, hd_hi; };
+template <int NT = 256>
 __device__ __forceinline__ StageSplit stage_split(int ncols, int HD, int tid) {
-    StageSplit sp = {tid, 256, 0, HD};
-    if (ncols <= 128) {
-        int nseg = 256 / ncols; if (nseg > HD) nseg = HD;
+    StageSplit sp = {tid, NT, 0, HD};
+    if (ncols <= NT / 2) {
+        int nseg = NT / ncols; if (nseg > HD) nseg = HD;
         const int seglen = (HD + nseg - 1) / nseg;
         const int seg = tid / ncols;
         sp.col0 = seg < nseg ? tid - seg * ncols : ncols;         // surplus threads idle
@@ -356,6 +359,174 @@ __device__ __forceinline__ void stage_halo_tile(const GatherIn& g, char* halo, c
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// LEAN staging (multi-channel sources; used by the producer/consumer kernels).  Same column walk as stage_halo_tile, but
+//   * the D axis has a per-tile table too: rt[set][HH + HW + HD + VG_DPAD] holds BYTE offsets along H, W and D (or -1
+//     where the position is zero padding), so a unit's address is  column pointer + one LDS word  -- the first version
+//     resolved reflection / padding and multiplied out the plane offset per unit in vector ALU code (~35 of its ~70
+//     instructions per unit; the staging waves are VALU-issue bound, in-kernel stamps: 9.8 k cycles per 2000-unit tile);
+//     the D entries are repeated VG_DPAD times past the end so that a batch reads dt[hd0 + k] with immediate offsets;
+//   * the on-read transform is a template parameter (plain copy / affine + ReLU / affine + LeakyReLU [+ noise]): no
+//     run-time slope, no dead masking code in reflect mode (MASK = zero padding or a ragged last channel chunk).
+// ------------------------------------------------------------------------------------------------------------------
+#define VG_DPAD 16
+#define VG_STAGE_PLAIN 0      // no scale/shift, no activation (data-gradient operand, raw shortcut sources)
+#define VG_STAGE_RELU 1       // act(x * scale + shift), ReLU
+#define VG_STAGE_LRELU 2      // ... LeakyReLU(0.2)
+#define VG_STAGE_LRELU_NOISE 3
+#define VG_STAGE_LRELU_M 4    // the same two with masking (zero padding: D.down2 / D.out)
+#define VG_STAGE_LRELU_NOISE_M 5
+
+__host__ __device__ __forceinline__ int stage_axis_len3(const GatherIn& g) { return g.HH + g.HW + g.HD + VG_DPAD; }
+
+__device__ __forceinline__ void stage_resolve_axes3(const GatherIn& g, int* rt, int od0, int oh0, int ow0, int tid) {
+    const int L = stage_axis_len3(g);
+    const int esz = g.f32 ? 4 : 2;
+    const int pd0 = od0 * g.istr + g.tmin_d, ph0 = oh0 * g.istr + g.tmin_h, pw0 = ow0 * g.istr + g.tmin_w;
+    const int sh = g.shift0;
+    const int set = tid >> 6;            // wave s resolves table s (src0, src1, noise)
+    if (set < 3 && !(set == 1 && g.c1 == 0) && !(set == 2 && !g.noise)) {
+        for (int j = tid & 63; j < L; j += 64) {
+            const int axis = j < g.HH ? 1 : (j < g.HH + g.HW ? 2 : 0);                    // 1 H, 2 W, 0 D
+            int jj = axis == 1 ? j : (axis == 2 ? j - g.HH : j - g.HH - g.HW);
+            if (axis == 0 && jj >= g.HD) jj = g.HD - 1;                                 // padding entries repeat the last plane
+            const int n_ax = axis == 1 ? g.H : (axis == 2 ? g.W : g.D);
+            int p = (axis == 1 ? ph0 : (axis == 2 ? pw0 : pd0)) + jj;
+            const int q = p + g.npad;
+            bool valid = resolve_pos(p, n_ax, g.pad_mode);
+            long off;
+            if (set == 0) {
+                const int ps = p >> sh, Ws = g.W >> sh, Hs = g.H >> sh;
+                off = axis == 1 ? (long)ps * Ws * g.c0 : (axis == 2 ? (long)ps * g.c0 : (long)ps * Hs * Ws * g.c0);
+                off *= esz;
+            } else if (set == 1) {
+                off = axis == 1 ? (long)p * g.W * g.c1 : (axis == 2 ? (long)p * g.c1 : (long)p * g.H * g.W * g.c1);
+                off *= esz;
+            } else {
+                const int NW = g.W + 2 * g.npad, NH = g.H + 2 * g.npad;
+                valid = valid && q >= 0 && q < n_ax + 2 * g.npad;
+                off = axis == 1 ? (long)q * NW * g.Cin : (axis == 2 ? (long)q * g.Cin : (long)q * NH * NW * g.Cin);
+                off *= 2;
+            }
+            rt[set * L + j] = valid ? (int)off : -1;
+        }
+    }
+}
+
+// MODE >= 0: compile-time transform (producer/consumer kernels); MODE == -1: taken from g.lean at run time (wave-uniform
+// branches per unit: the scalar unit has slack, the vector ALU does not) -- NOISE then says whether the kernel variant
+// carries the noise operand at all.
+template <typename T, int MODE, int UB, int NT = 256, bool NOISE_RT = false>
+__device__ __forceinline__ void stage_halo_lean(const GatherIn& g, char* halo, const float* scs, const int* ctab, const int* rt,
+                                                int n, int chunk, int tid) {
+    const int mode = MODE >= 0 ? MODE : g.lean;
+    constexpr bool NOISE = MODE >= 0 ? (MODE == VG_STAGE_LRELU_NOISE || MODE == VG_STAGE_LRELU_NOISE_M) : NOISE_RT;
+    const bool noise_on = NOISE && (MODE >= 0 || mode == VG_STAGE_LRELU_NOISE || mode == VG_STAGE_LRELU_NOISE_M);
+    const bool MASK = mode == VG_STAGE_PLAIN || mode >= VG_STAGE_LRELU_M;    // zero padding / ragged last chunk possible
+    const bool plain = mode == VG_STAGE_PLAIN, relu = mode == VG_STAGE_RELU;
+    constexpr int esz = (int)sizeof(T);
+    const int L = stage_axis_len3(g);
+    const int ncols = stage_ncols(g);
+    const int plane = g.DS;
+    const int sh = g.shift0;
+    const char* b0 = (const char*)g.src0 + (size_t)n * (g.D >> sh) * (g.H >> sh) * (g.W >> sh) * g.c0 * esz;
+    const char* b1 = (const char*)g.src1 + (size_t)n * g.D * g.H * g.W * g.c1 * esz;
+    const char* nb = NOISE ? (const char*)g.noise + (size_t)n * (g.D + 2 * g.npad) * (g.H + 2 * g.npad) * (g.W + 2 * g.npad) * g.Cin * 2 : nullptr;
+    const StageSplit sp = stage_split<NT>(ncols, g.HD, tid);
+    for (int col = sp.col0; col < ncols; col += sp.cstride) {
+        const int e = ctab[2 * col], hoff = ctab[2 * col + 1];
+        const int hh = e & 1023, hw = (e >> 10) & 1023, cg = e >> 20;
+        const int c = chunk * g.CK + cg * 8;
+        const bool from0 = c < g.c0;
+        const int* rs = rt + (from0 ? 0 : L);
+        const int oh = rs[hh], ow = rs[g.HH + hw];
+        const bool cvalid = !MASK || (c < g.Cin && (oh | ow) >= 0);
+        const char* pc = (from0 ? b0 + (size_t)c * esz : b1 + (size_t)(c - g.c0) * esz) + (cvalid ? oh + ow : 0);
+        if (!cvalid) pc = b0;                                              // invalid columns read a dummy, then zero
+        const int* dt = rs + g.HH + g.HW + sp.hd_lo;
+        const char* pn = nullptr; const int* ndt = nullptr; bool nvalid = false;
+        if (NOISE) {
+            if (noise_on) {
+                const int nh = rt[2 * L + hh], nw = rt[2 * L + g.HH + hw];
+                nvalid = cvalid && (nh | nw) >= 0;
+                pn = nb + (nvalid ? nh + nw + c * 2 : 0);
+                ndt = rt + 2 * L + g.HH + g.HW + sp.hd_lo;
+            }
+        }
+        f32x2 sc[4], sf[4];
+        if (!plain) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                sc[j] = (f32x2){scs[cg * 8 + 2 * j], scs[cg * 8 + 2 * j + 1]};
+                sf[j] = (f32x2){scs[g.CK + cg * 8 + 2 * j], scs[g.CK + cg * 8 + 2 * j + 1]};
+            }
+        }
+        char* dcol = halo + hoff + (size_t)sp.hd_lo * plane;
+        const int nd = sp.hd_hi - sp.hd_lo;
+        for (int h0 = 0; h0 < nd; h0 += UB) {
+            Raw8<T> raw[UB];
+            Raw8<bf16_t> nz[NOISE ? UB : 1];
+            int od[UB], nod[NOISE ? UB : 1];
+#pragma unroll
+            for (int k = 0; k < UB; ++k) {                                  // entries past the segment are real table words
+                od[k] = dt[h0 + k];
+                if (g.dbg & 16) raw_mask(raw[k], false);       // ablation: no global loads
+                else raw_load(raw[k], (const T*)(pc + (unsigned)max(od[k], 0)));
+                if (NOISE) { if (noise_on) { nod[k] = ndt[h0 + k]; raw_load(nz[k], (const bf16_t*)(pn + (unsigned)max(nod[k], 0))); } }
+            }
+            // keep every load of the batch ahead of the first use: a load whose only use sits under `h0 + k < nd` is
+            // otherwise sunk into that branch by the compiler and waited for with vmcnt(0), which drains the whole batch
+#pragma unroll
+            for (int k = 0; k < UB; ++k) {
+                raw_pin(raw[k]);
+                if (NOISE) { if (noise_on) raw_pin(nz[k]); }
+            }
+#pragma unroll
+            for (int k = 0; k < UB; ++k) {
+                if (h0 + k < nd) {
+                    T* dst = (T*)(dcol + (size_t)(h0 + k) * plane);
+                    const bool ok = cvalid && od[k] >= 0;
+                    if (plain) {
+                        Raw8<T> r = raw[k];
+                        raw_mask(r, ok);
+                        *(Raw8<T>*)dst = r;
+                    } else {
+                        float x[8];
+                        raw_unpack(raw[k], x);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            f32x2 v = {x[2 * j], x[2 * j + 1]};
+                            v = v * sc[j] + sf[j];
+                            x[2 * j] = v[0]; x[2 * j + 1] = v[1];
+                        }
+                        if (relu) {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) x[j] = fmaxf(x[j], 0.f);
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) x[j] = fmaxf(x[j], x[j] * VG_LRELU);
+                        }
+                        if (NOISE) {
+                            if (noise_on) {
+                                float z[8];
+                                raw_unpack(nz[k], z);
+                                const bool nok = nvalid && nod[k] >= 0;
+#pragma unroll
+                                for (int j = 0; j < 8; ++j) x[j] += nok ? z[j] : 0.f;
+                            }
+                        }
+                        if (MASK) {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) x[j] = ok ? x[j] : 0.f;
+                        }
+                        store8<T>(dst, x);
+                    }
+                }
+            }
+        }
+    }
+}
+
 // ---- host: validate the input side of a descriptor and derive the tile geometry for BM voxels ----
 // padded pitches of the LDS halo image: the 16 voxels of an MFMA sub-tile (TW x 16/TW rows [x planes]) must fall into 16
 // different 16-byte bank groups, i.e. be distinct modulo 16 units
@@ -396,6 +567,16 @@ static inline int fill_gather(const vg_conv_desc* d, GatherIn& g, int CK, int BM
     g.noise = (const bf16_t*)d->noise; g.npad = d->noise ? d->noise_pad : 0;
     g.istr = d->istr; g.pad_mode = d->pad_mode; g.ntaps = d->ntaps; g.CK = CK;
     g.wpack = d->wpack; g.wmin = d->wpack_wmin; g.Cw = d->wpack ? d->wpack : Cin; g.HWx = 0;
+    {   // lean staging mode (see stage_halo_lean); LEAN=0 switches it off everywhere (A/B and fallback)
+        g.lean = -1;
+        const bool zero = d->pad_mode != VG_PAD_REFLECT || (Cin % CK) != 0;
+        if (Cin != 1 && !d->f32 && vg_tune("LEAN", 1)) {
+            if (!d->in_scale && d->act == VG_ACT_NONE && !d->noise) g.lean = VG_STAGE_PLAIN;
+            else if (d->in_scale && d->act == VG_ACT_RELU && !d->noise && !zero) g.lean = VG_STAGE_RELU;
+            else if (d->in_scale && d->act == VG_ACT_LRELU)
+                g.lean = d->noise ? (zero ? VG_STAGE_LRELU_NOISE_M : VG_STAGE_LRELU_NOISE) : (zero ? VG_STAGE_LRELU_M : VG_STAGE_LRELU);
+        }
+    }
     if (d->wpack) {
         if (Cin != 1 || d->wpack < 2 || d->wpack > 8) return VG_EINVAL;
         for (int i = 0; i < d->ntaps; ++i) if (d->tap_w[i] != 0) return VG_EINVAL;
@@ -448,3 +629,7 @@ static inline int fill_gather(const vg_conv_desc* d, GatherIn& g, int CK, int BM
 static inline int halo_bytes(const GatherIn& g) { return g.planar ? (g.CK >> 3) * g.PSB : g.HD * g.DS; }
 // LDS ints of the staging tables (column table + per-tile axis tables)
 static inline int stage_table_ints(const GatherIn& g) { return 2 * stage_ncols(g) + 6 * stage_axis_len(g); }   // column table + two axis-table buffers
+static inline int stage_table_ints3(const GatherIn& g) {            // axis tables incl. the D axis (lean staging)
+    const int a = stage_axis_len(g), b = stage_axis_len3(g);
+    return 2 * stage_ncols(g) + 6 * (a > b ? a : b);
+}
