@@ -24,6 +24,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PMC_SUMMARY = 'r02_hbm_pmc.json'   # tools/hbm_pmc.py output for the current kernels (stamped with their source hash)
 CONV_FLOP_PER_VOXEL = 2530548.0    # 12 F_G + 14 F_D per voxel-sample-step
 
 
@@ -92,6 +93,7 @@ def main():
     ap.add_argument('--batch', type=int, default=1, help='per-GPU batch')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--dump-kernels', default='', help='write the per-kernel-template table of the timing step (JSON) here')
     ap.add_argument('--infer', action='store_true', help='BASELINE config 5 instead: 256x256x128 sliding-window generator inference')
     args = ap.parse_args()
 
@@ -156,11 +158,13 @@ def main():
 
     roof = None
     summ = None
+    byvar = None
     if not args.no_roofline:
         # EVERY rank runs the per-launch timing step: it contains the gradient all-reduces, which must be matched on all ranks
         ops.PROF = ops.KernelProfile()
         eng.train_step(rI, rS, sync=True)
         summ = ops.PROF.summary()
+        byvar = ops.PROF.by_variant()
         ops.PROF = None
     if rank == 0 and summ is not None:
         tot_fl = sum(v['flops'] for v in summ.values())
@@ -169,12 +173,19 @@ def main():
         ach = tot_fl / (tot_ms * 1e-3) / 1e12
         # HBM traffic of the same kernel family: rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) cannot run inside this
         # process, so the per-launch figure comes from the committed summary of those passes on this command
+        # it is only quoted while it describes THIS build: the summary is stamped with the hash of the kernel sources it was
+        # measured on (van_gan_amd/build.py::_src_hash) and dropped (null) when the sources have changed since
         traffic, traffic_src = None, None
         try:
-            with open(os.path.join(ROOT, 'profiles', 'r01_hbm_pmc.json')) as f:
+            from van_gan_amd.build import _src_hash
+            with open(os.path.join(ROOT, 'profiles', PMC_SUMMARY)) as f:
                 pm = json.load(f)
-            if args.size == 128 and B == 1:
-                traffic, traffic_src = pm['hbm_bytes_per_launch'], 'profiles/r01_hbm_pmc.json'
+            if args.size == 128 and B == 1 and pm.get('csrc_hash') == _src_hash():
+                traffic = pm['hbm_bytes_per_launch']
+                traffic_src = 'profiles/%s (csrc %s)' % (PMC_SUMMARY, pm['csrc_hash'][:12])
+            elif args.size == 128 and B == 1:
+                traffic_src = 'stale: profiles/%s was measured on csrc %s, this build is %s' % (
+                    PMC_SUMMARY, str(pm.get('csrc_hash'))[:12], _src_hash()[:12])
         except (OSError, KeyError, ValueError):
             pass
         alg_bytes = sum(v.get('bytes', 0.0) for v in summ.values())
@@ -187,6 +198,19 @@ def main():
                 'by_kind': {k: {'launches': v['launches'], 'ms': round(v['ms'], 3),
                                 'tflops': (v['flops'] / (v['ms'] * 1e-3) / 1e12) if v['ms'] > 0 else None} for k, v in summ.items()},
                 'whole_step_conv_tflops': steps_per_s * gbatch / world * S * CONV_FLOP_PER_VOXEL / 1e12}
+        if byvar:
+            # the single kernel template with the most time in the step, by itself (the family figure above averages ~70
+            # templates): algorithmic FLOPs of ITS launches / ITS summed HIP-event durations
+            dom = byvar[0]
+            roof['dominant_kernel'] = {'kernel': dom['kernel'], 'kind': dom['kind'], 'launches_per_step': dom['launches'],
+                                       'ms_per_step': dom['ms'], 'avg_launch_ms': dom['ms'] / dom['launches'],
+                                       'achieved': dom['tflops'], 'frac': dom['tflops'] / PEAK_BF16_TFLOPS,
+                                       'algorithmic_bytes_per_launch': dom['algorithmic_bytes'] / dom['launches']}
+            roof['by_kernel'] = [{'kernel': r['kernel'], 'kind': r['kind'], 'launches': r['launches'], 'ms': round(r['ms'], 4),
+                                  'tflops': None if r['tflops'] is None else round(r['tflops'], 1)} for r in byvar[:12]]
+            if args.dump_kernels:
+                with open(args.dump_kernels, 'w') as f:
+                    json.dump(byvar, f, indent=1)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()

@@ -30,7 +30,11 @@ def main():
     launches = fn['conv'] / steps
     rd = fk['conv'] * 1024 * 2 / steps          # gfx950: 128-B read requests are counted as 64 B (guide: double it)
     wr = wk['conv'] * 1024 / steps
+    import os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'van_gan_amd'))
+    import build as _b                        # source hash of the kernels this run measured (bench.py drops a stale summary)
     json.dump({
+        'csrc_hash': _b._src_hash(),
         'command': 'rocprofv3 --pmc FETCH_SIZE (and, in a separate pass, WRITE_SIZE) --kernel-trace --output-format csv -- '
                    'python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline   (tools/hbm_pmc.py)',
         'note': 'sums over every conv_kernel/conv32_kernel/wgrad_kernel/pw_* dispatch of 2 train steps (128^3, batch 1); FETCH_SIZE in '

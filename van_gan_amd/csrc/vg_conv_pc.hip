@@ -303,7 +303,7 @@ static int launch_pc3(const GatherIn& g, const ConvOut& k, const ConvCls& q, int
 // staging mode of a multi-channel source, or -1 when the combination has no lean variant (the caller then stays on conv_kernel)
 int vg_conv_pc_mode(const GatherIn& g) {
     if (g.Cin == 1) return g.noise ? 1 : 0;
-    return g.lean;
+    return (g.lean >= 0 && g.lean != VG_STAGE_GENERIC) ? g.lean : -1;
 }
 template <int BN, int MSUB, bool WL>
 static int launch_pc2(const GatherIn& g, const ConvOut& k, const ConvCls& q, int lds, hipStream_t s) {

@@ -376,6 +376,7 @@ __device__ __forceinline__ void stage_halo_tile(const GatherIn& g, char* halo, c
 #define VG_STAGE_LRELU_NOISE 3
 #define VG_STAGE_LRELU_M 4    // the same two with masking (zero padding: D.down2 / D.out)
 #define VG_STAGE_LRELU_NOISE_M 5
+#define VG_STAGE_GENERIC 6    // run-time everything (scale/shift optional, any activation, noise if present, masked): rare combinations
 
 __host__ __device__ __forceinline__ int stage_axis_len3(const GatherIn& g) { return g.HH + g.HW + g.HD + VG_DPAD; }
 
@@ -421,9 +422,12 @@ __device__ __forceinline__ void stage_halo_lean(const GatherIn& g, char* halo, c
                                                 int n, int chunk, int tid) {
     const int mode = MODE >= 0 ? MODE : g.lean;
     constexpr bool NOISE = MODE >= 0 ? (MODE == VG_STAGE_LRELU_NOISE || MODE == VG_STAGE_LRELU_NOISE_M) : NOISE_RT;
-    const bool noise_on = NOISE && (MODE >= 0 || mode == VG_STAGE_LRELU_NOISE || mode == VG_STAGE_LRELU_NOISE_M);
+    const bool noise_on = NOISE && (MODE >= 0 || mode == VG_STAGE_LRELU_NOISE || mode == VG_STAGE_LRELU_NOISE_M ||
+                                    (mode == VG_STAGE_GENERIC && g.noise != nullptr));
     const bool MASK = mode == VG_STAGE_PLAIN || mode >= VG_STAGE_LRELU_M;    // zero padding / ragged last chunk possible
     const bool plain = mode == VG_STAGE_PLAIN, relu = mode == VG_STAGE_RELU;
+    const bool generic = MODE < 0 && mode == VG_STAGE_GENERIC;
+    const float gslope = g.act == VG_ACT_RELU ? 0.f : (g.act == VG_ACT_LRELU ? VG_LRELU : 1.f);
     constexpr int esz = (int)sizeof(T);
     const int L = stage_axis_len3(g);
     const int ncols = stage_ncols(g);
@@ -454,7 +458,7 @@ __device__ __forceinline__ void stage_halo_lean(const GatherIn& g, char* halo, c
             }
         }
         f32x2 sc[4], sf[4];
-        if (!plain) {
+        if (!plain) {                       // (scs holds 1 / 0 when the source has no scale / shift: stage_scale_shift)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 sc[j] = (f32x2){scs[cg * 8 + 2 * j], scs[cg * 8 + 2 * j + 1]};
@@ -502,6 +506,9 @@ __device__ __forceinline__ void stage_halo_lean(const GatherIn& g, char* halo, c
                         if (relu) {
 #pragma unroll
                             for (int j = 0; j < 8; ++j) x[j] = fmaxf(x[j], 0.f);
+                        } else if (generic) {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) x[j] = fmaxf(x[j], x[j] * gslope);
                         } else {
 #pragma unroll
                             for (int j = 0; j < 8; ++j) x[j] = fmaxf(x[j], x[j] * VG_LRELU);
@@ -526,6 +533,12 @@ __device__ __forceinline__ void stage_halo_lean(const GatherIn& g, char* halo, c
         }
     }
 }
+
+// (Measured and dropped: the lean routine inside conv_kernel / conv32_kernel / wgrad_kernel -- both as a second code path
+// and as the only path of the bf16 multi-channel instantiations.  Forward unchanged, data gradients 5-10 % faster, weight
+// gradients 10-30 % SLOWER (the noise-carrying ones spill), train step 33.6 -> 35.0 ms: those kernels sit at their register
+// caps and are bound by vector-instruction issue; a routine with fewer instructions does not help when the allocator
+// answers it with spills.  DESIGN 6.14.)
 
 // ---- host: validate the input side of a descriptor and derive the tile geometry for BM voxels ----
 // padded pitches of the LDS halo image: the 16 voxels of an MFMA sub-tile (TW x 16/TW rows [x planes]) must fall into 16
@@ -570,11 +583,12 @@ static inline int fill_gather(const vg_conv_desc* d, GatherIn& g, int CK, int BM
     {   // lean staging mode (see stage_halo_lean); LEAN=0 switches it off everywhere (A/B and fallback)
         g.lean = -1;
         const bool zero = d->pad_mode != VG_PAD_REFLECT || (Cin % CK) != 0;
-        if (Cin != 1 && !d->f32 && vg_tune("LEAN", 1)) {
+        if (Cin != 1 && !d->f32) {
             if (!d->in_scale && d->act == VG_ACT_NONE && !d->noise) g.lean = VG_STAGE_PLAIN;
             else if (d->in_scale && d->act == VG_ACT_RELU && !d->noise && !zero) g.lean = VG_STAGE_RELU;
             else if (d->in_scale && d->act == VG_ACT_LRELU)
                 g.lean = d->noise ? (zero ? VG_STAGE_LRELU_NOISE_M : VG_STAGE_LRELU_NOISE) : (zero ? VG_STAGE_LRELU_M : VG_STAGE_LRELU);
+            else g.lean = VG_STAGE_GENERIC;          // any other combination: affine (if given) + run-time activation + noise + mask
         }
     }
     if (d->wpack) {
@@ -593,6 +607,7 @@ static inline int fill_gather(const vg_conv_desc* d, GatherIn& g, int CK, int BM
     // tile shape: powers of two with product BM that minimise the halo volume (staging work and L2 traffic scale with
     // it); the innermost extent stays >= 8 voxels where the grid allows so that rows remain long contiguous runs
     int TW = 1, TH = 1, TD = 1;
+    const int w16 = vg_tune("TILE_W16", 1);
     {
         const int ex[3] = {mx[0] - mn[0] + 1, mx[1] - mn[1] + 1, mx[2] - mn[2] + 1};
         const int capd = pow2_ceil(d->OD), caph = pow2_ceil(d->OH), capw = pow2_ceil(d->OW) < 16 ? pow2_ceil(d->OW) : 16;
@@ -606,6 +621,11 @@ static inline int fill_gather(const vg_conv_desc* d, GatherIn& g, int CK, int BM
                 if (g.planar) pad_pitches(hh_, hw_, tw, th, d->istr, hhp_, hwp_);
                 long vol = (long)((td - 1) * d->istr + ex[0]) * hhp_ * hwp_;       // LDS image incl. pitch padding
                 if (td > capd) vol *= 4;          // overhang in D wastes whole planes: only when nothing else fits
+                // Planar images whose 16-voxel MFMA sub-tile spans two rows of 8 read with 2-way bank conflicts unless the row
+                // pitch was padded (PMC on the 16->16 layers at 128^3: 43 % of the LDS cycles were conflict cycles with the
+                // 10-unit pitch of the 8x8x8 tile).  A 16-wide tile has each sub-tile in ONE row -- consecutive 16-byte units,
+                // conflict-free at any pitch -- for 8 % more halo (18x10x6 vs 10x10x10): charge the conflicting shapes 25 %.
+                if (w16 && g.planar && skew == 0 && tw < 16 && hwp_ == hw_ && d->istr == 1) vol += vol / 4;
                 if (best < 0 || vol < best || (vol == best && tw > TW)) { best = vol; TW = tw; TH = th; TD = td; }
             }
         }

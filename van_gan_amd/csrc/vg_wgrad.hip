@@ -349,7 +349,12 @@ extern "C" int vg_conv3d_wgrad(const vg_conv_desc* d, const void* dy, int dy_f32
     const int RMAX = Q == 1 ? 24 : (Q == 2 ? 12 : 6);
     const int esz = d->f32 ? 4 : 2;
     GatherIn g; WgradK k;
-    const int max_bm = vg_tune("WGRAD_BM", 256), max_cib = vg_tune("WGRAD_CIB", 64);
+    int max_bm = vg_tune("WGRAD_BM", 256), max_cib = vg_tune("WGRAD_CIB", 64);
+    // 4x4x4 kernels (64 taps): 16-channel chunks.  A workgroup then owns (24 taps x 16 ci) x 64 co instead of (6 taps x 64 ci)
+    // x 64 co -- the same accumulators and MFMAs per tile, a quarter of the halo bytes staged for them, and the input is
+    // re-staged by ntg x ncob = 3 x 8 workgroup columns instead of 11 x 8 (D.down2: 0.351 -> 0.269 ms; HBM traffic of the
+    // noise-carrying weight gradients was 12.8x algorithmic, profiles/r02_roofline_by_kernel.json)
+    if (d->ntaps >= 64 && max_cib > 16 && vg_tune("WGRAD_CIB16_K4", 1)) max_cib = 16;
     // candidate (BM, CIB) in order of preference: large tile + all channels, LDS <= 80 KiB so that two workgroups fit a CU
     int best_bm = 0, best_cib = 0, best_lds = 0;
     for (int pass = 0; pass < 2 && !best_bm; ++pass) {

@@ -21,6 +21,13 @@ def _p(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
+def conv_variant(d) -> str:
+    """Name of the kernel variant vg_conv3d would launch for this descriptor (host-only dry run of the dispatch)."""
+    buf = C.create_string_buffer(512)
+    _lib.lib.vg_conv3d_variant(C.byref(d), buf, 512)
+    return buf.value.decode()
+
+
 def stream() -> int:
     if DRY is not None:
         return 0
@@ -85,18 +92,22 @@ class KernelProfile:
     stream), with the algorithmic FLOPs of every launch.  Used by bench.py for the roofline object."""
 
     def __init__(self):
-        self.rows = {}          # kind -> [launches, flops, [(ev0, ev1), ...]]
+        self.rows = {}          # kind -> [launches, flops, [(ev0, ev1), ...], bytes]
+        self.vrows = {}         # (kind, kernel variant) -> the same: the roofline of every kernel template by itself
 
     def begin(self):
         e = torch.cuda.Event(enable_timing=True)
         e.record()
         return e
 
-    def end(self, kind: str, flops: float, e0, nbytes: float = 0.0):
+    def end(self, kind: str, flops: float, e0, nbytes: float = 0.0, variant: Optional[str] = None):
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
         r = self.rows.setdefault(kind, [0, 0.0, [], 0.0])
         r[0] += 1; r[1] += flops; r[2].append((e0, e1)); r[3] += nbytes
+        if variant:
+            v = self.vrows.setdefault((kind, variant.split('|')[0]), [0, 0.0, [], 0.0])
+            v[0] += 1; v[1] += flops; v[2].append((e0, e1)); v[3] += nbytes
 
     def summary(self):
         torch.cuda.synchronize()
@@ -105,6 +116,16 @@ class KernelProfile:
             ms = sum(a.elapsed_time(b) for a, b in evs)
             out[k] = dict(launches=n, flops=fl, ms=ms, bytes=nb)
         return out
+
+    def by_variant(self):
+        """[{kind, kernel, launches, ms, gflop, tflops, bytes}] sorted by time: one row per kernel template."""
+        torch.cuda.synchronize()
+        rows = []
+        for (kind, var), (n, fl, evs, nb) in self.vrows.items():
+            ms = sum(a.elapsed_time(b) for a, b in evs)
+            rows.append(dict(kind=kind, kernel=var, launches=n, ms=ms, gflop=fl / 1e9, tflops=fl / (ms * 1e-3) / 1e12 if ms > 0 else None,
+                             algorithmic_bytes=nb))
+        return sorted(rows, key=lambda r: -r['ms'])
 
 
 PROF: Optional[KernelProfile] = None
@@ -424,7 +445,7 @@ class ConvLayer:
         if e0 is not None:
             esz = 4 if self.f32 else 2
             PROF.end('conv_fwd', 2.0 * src.N * math.prod(self.out_dims) * self.cout * self.cin * self.k ** 3, e0,
-                     src.N * esz * (math.prod(self.in_dims) * self.cin + math.prod(self.out_dims) * self.cout))
+                     src.N * esz * (math.prod(self.in_dims) * self.cin + math.prod(self.out_dims) * self.cout), conv_variant(d))
 
     def wgrad(self, src: Src, dy: torch.Tensor):
         if SIDE is not None and PROF is None:       # the per-launch timing pass serialises (attributable kernel durations)
@@ -451,8 +472,10 @@ class ConvLayer:
                                   _p(self.gw), _p(self.gb), _p(sc), sc.numel() * 4, stream()), 'vg_conv3d_wgrad ' + self.name)
         if e0 is not None:
             esz = 4 if self.f32 else 2
+            vb = C.create_string_buffer(512)
+            _lib.lib.vg_conv3d_wgrad_variant(C.byref(d), int(dy.dtype == torch.float32), self.f_idx_host, self.f_T, sc.numel() * 4, vb, 512)
             PROF.end('conv_wgrad', 2.0 * src.N * math.prod(self.out_dims) * self.cout * self.cin * self.k ** 3, e0,
-                     src.N * esz * (math.prod(self.in_dims) * self.cin + math.prod(self.out_dims) * self.cout))
+                     src.N * esz * (math.prod(self.in_dims) * self.cin + math.prod(self.out_dims) * self.cout), vb.value.decode())
 
     def _fused_desc(self, dy, N, out, accumulate, probe=False):
         """Descriptor of the fused all-classes data gradient (probe=True: dummy pointers, returns None if infeasible)."""
@@ -506,7 +529,7 @@ class ConvLayer:
             if e0 is not None:
                 PROF.end('conv_dgrad', sum(2.0 * N * math.prod(c['iters']) * self.cin * self.cout * len(c['taps'])
                                            for c in self.d_classes), e0,
-                         N * 2 * (math.prod(self.out_dims) * self.cout + math.prod(self.buf_dims) * self.cin))
+                         N * 2 * (math.prod(self.out_dims) * self.cout + math.prod(self.buf_dims) * self.cin), conv_variant(d))
             return
         for c in self.d_classes:
             d = ConvDesc()
@@ -528,7 +551,7 @@ class ConvLayer:
             if e0 is not None:      # algorithmic FLOPs of this parity class: its taps only
                 PROF.end('conv_dgrad', 2.0 * N * math.prod(c['iters']) * self.cin * self.cout * len(c['taps']), e0,
                          N * (4 if self.f32 else 2) * (math.prod(self.out_dims) * self.cout * len(c['taps']) / self.k ** 3
-                                                       + math.prod(c['iters']) * self.cin))
+                                                       + math.prod(c['iters']) * self.cin), conv_variant(d))
 
 
 class PackTable:
