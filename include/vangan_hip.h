@@ -198,6 +198,8 @@ typedef struct {
     int32_t f32;                              /* exact-parity mode: g, x, x1 and dx are float32 */
     float* dgamma;                            /* optional [C]: the statistics pass itself adds d/d gamma and d/d beta of the */
     float* dbeta;                             /* InstanceNorm (summed over samples) instead of a separate vg_in_param_grads */
+    int32_t* ticket;        /* optional: zero-initialised int; when given, the LAST workgroup of vg_actnorm_bwd_stats folds
+                               the striped sums (and the gamma/beta gradients) itself instead of a second launch */
 } vg_actnorm_bwd_desc;
 int vg_actnorm_bwd_stats(const vg_actnorm_bwd_desc* d, vg_stream_t stream);
 int vg_actnorm_bwd_apply(const vg_actnorm_bwd_desc* d, vg_stream_t stream);

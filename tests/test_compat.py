@@ -83,3 +83,16 @@ def test_real_engine_through_the_reference_constructor(tmp_path):
     assert list(res) == RESULT_KEYS and all(np.isfinite(v) for v in res.values())
     g.save_checkpoint(0)
     assert g.load_checkpoint(1)
+
+
+def test_unbuildable_reference_variants_raise_like_the_reference():
+    """ResUNet(upsample_mode='deconv') is a shape error in the reference itself (resunet_model.py:168-181: reflect pad + k2 s2
+    Conv3DTranspose gives 2(S+2) voxels, the skip tensor has 2S): the constructor raises, as Keras' concatenate does."""
+    from van_gan_amd.nets import ParamStore, ResUNet, gen_param_specs
+    st = ParamStore(gen_param_specs(), 'cpu')
+    with pytest.raises(ValueError, match='deconv'):
+        ResUNet(st, (32, 32, 32), upsample_mode='deconv')
+    with pytest.raises(ValueError):
+        ResUNet(st, (32, 32, 32), upsample_mode='bilinear')
+    with pytest.raises(ValueError):
+        ResUNet(st, (48, 40, 32))                       # spatial dims must be multiples of 16 (4 stride-2 stages)

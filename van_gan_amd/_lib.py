@@ -47,7 +47,7 @@ class ActNormBwdDesc(C.Structure):
         ('scale', c_void_p), ('shift', c_void_p), ('mult', c_void_p), ('act', c_int), ('norm', c_int),
         ('gamma', c_void_p), ('mean', c_void_p), ('rstd', c_void_p), ('red', c_void_p),
         ('dx', c_void_p), ('dx_f32', c_int), ('accumulate', c_int), ('dx_cstride', c_int), ('dx_coff', c_int),
-        ('f32', c_int), ('dgamma', c_void_p), ('dbeta', c_void_p),
+        ('f32', c_int), ('dgamma', c_void_p), ('dbeta', c_void_p), ('ticket', c_void_p),
     ]
 
 

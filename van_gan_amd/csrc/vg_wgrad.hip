@@ -346,7 +346,7 @@ extern "C" int vg_conv3d_wgrad(const vg_conv_desc* d, const void* dy, int dy_f32
     const int COB = Coutp >= 64 ? 64 : (Coutp >= 32 ? 32 : 16);
     if (Coutp % COB) return VG_EINVAL;
     const int Q = COB / 16;
-    const int RMAX = Q == 1 ? 24 : (Q == 2 ? 12 : 6);
+    int RMAX = Q == 1 ? 24 : (Q == 2 ? 12 : 6);
     const int esz = d->f32 ? 4 : 2;
     GatherIn g; WgradK k;
     int max_bm = vg_tune("WGRAD_BM", 256), max_cib = vg_tune("WGRAD_CIB", 64);
@@ -355,10 +355,16 @@ extern "C" int vg_conv3d_wgrad(const vg_conv_desc* d, const void* dy, int dy_f32
     // re-staged by ntg x ncob = 3 x 8 workgroup columns instead of 11 x 8 (D.down2: 0.351 -> 0.269 ms; HBM traffic of the
     // noise-carrying weight gradients was 12.8x algorithmic, profiles/r02_roofline_by_kernel.json)
     if (d->ntaps >= 64 && max_cib > 16 && vg_tune("WGRAD_CIB16_K4", 1)) max_cib = 16;
+    // 3x3x3 kernels with >= 32 output channels: 16-channel chunks as well, so that ONE workgroup column carries all 27 taps of
+    // its 16 input channels (27 rows: the <8,2> variant, or <7,4> below): the input halo is staged once per (ci chunk, co
+    // block) instead of once per tap group as well, and no row of MFMAs is spent on padding rows
+    // (sweep: dec1.cb1 0.155 -> 0.138 ms, dec3.cb1 0.076 -> 0.067, bridge 0.045 -> 0.039, enc3.cb2 0.054 -> 0.048)
+    const bool k3_all_taps = d->ntaps == 27 && Coutp >= 32 && !d->f32 && vg_tune("WGRAD_CIB16", 1);
+    if (k3_all_taps && max_cib > 16) max_cib = 16;
     // candidate (BM, CIB) in order of preference: large tile + all channels, LDS <= 80 KiB so that two workgroups fit a CU
     int best_bm = 0, best_cib = 0, best_lds = 0;
     for (int pass = 0; pass < 2 && !best_bm; ++pass) {
-        const int limit = pass == 0 ? 80 * 1024 : VG_LDS_LIMIT;
+        const int limit = pass == 0 ? vg_tune("WGRAD_LDS0", 80 * 1024) : VG_LDS_LIMIT;
         for (int bm = 256; bm >= 64 && !best_bm; bm = bm == 256 ? 128 : bm - 64)
             for (int c = max_cib; c >= 16; c -= 16) {
                 if (Cinp % c) continue;
@@ -377,6 +383,7 @@ extern "C" int vg_conv3d_wgrad(const vg_conv_desc* d, const void* dy, int dy_f32
     k.dy = dy; k.dy_f32 = dy_f32; k.Cout = d->Cout; k.OD = d->OD; k.OH = d->OH; k.OW = d->OW;
     k.CIB = CIB; k.COB = COB; k.ncib = Cinp / CIB; k.ncob = Coutp / COB;
     const int rows_per_tap = CIB / 16;
+    if (Q == 4 && k3_all_taps && CIB == 16) RMAX = 7;          // 28 rows >= 27 taps: the <7,4> variant
     k.tpg = (4 * RMAX) / rows_per_tap; if (k.tpg < 1) return VG_EINVAL;
     if (k.tpg > d->ntaps) k.tpg = d->ntaps;
     k.ntg = (d->ntaps + k.tpg - 1) / k.tpg;
@@ -388,7 +395,7 @@ extern "C" int vg_conv3d_wgrad(const vg_conv_desc* d, const void* dy, int dy_f32
     // persistent grid = resident capacity (2 workgroups per CU for the big-slab variants, 3 for the small ones; LDS)
     const int wg_env = vg_tune("WGRAD_WGS", 0);
     const int rw_ = (k.tpg * rows_per_tap + 3) / 4;
-    const int rmax_sel = d->f32 ? RMAX : (rw_ <= 2 ? 2 : (rw_ <= 8 && Q <= 2 ? 8 : RMAX));
+    const int rmax_sel = d->f32 ? RMAX : (rw_ <= 2 ? 2 : (rw_ <= 8 && Q <= 2 ? 8 : (Q == 4 && rw_ == 7 ? 7 : RMAX)));
     int per_cu = (rmax_sel * Q >= VG_WGRAD_2W) ? 2 : 3;
     if (VG_LDS_LIMIT / lds < per_cu) per_cu = VG_LDS_LIMIT / lds;
     if (per_cu < 1) per_cu = 1;
@@ -405,7 +412,7 @@ extern "C" int vg_conv3d_wgrad(const vg_conv_desc* d, const void* dy, int dy_f32
     // few accumulators (3 workgroups per CU instead of 2)
     const int rw = (k.tpg * rows_per_tap + 3) / 4;
     {
-        const int rsel = d->f32 ? RMAX : (rw <= 2 ? 2 : ((rw <= 8 && Q <= 2) ? 8 : RMAX));
+        const int rsel = d->f32 ? RMAX : (rw <= 2 ? 2 : ((rw <= 8 && Q <= 2) ? 8 : (Q == 4 && rw == 7 ? 7 : RMAX)));
         if (vg_dry("wgrad<%s,%d,%d,n%d>|bm%d|cib%d|part%d|walk%d", d->f32 ? "f32" : "bf16", rsel, Q, g.noise ? 1 : 0, best_bm, CIB,
                    k.part ? 1 : 0, k.total_tiles > bx ? 1 : 0)) return VG_OK;
     }
@@ -423,6 +430,7 @@ extern "C" int vg_conv3d_wgrad(const vg_conv_desc* d, const void* dy, int dy_f32
         else launch_wgrad<bf16_t, 12, 2>(g, k, grid, lds, s);
     } else {
         if (rw <= 2) launch_wgrad<bf16_t, 2, 4>(g, k, grid, lds, s);
+        else if (rw == 7) launch_wgrad<bf16_t, 7, 4>(g, k, grid, lds, s);
         else launch_wgrad<bf16_t, 6, 4>(g, k, grid, lds, s);
     }
     if (k.part) {

@@ -168,7 +168,18 @@ class Norm:
 # Generator
 # ======================================================================================================
 class ResUNet:
-    def __init__(self, store: ParamStore, dims: Tuple[int, int, int], dtype: torch.dtype = torch.bfloat16):
+    def __init__(self, store: ParamStore, dims: Tuple[int, int, int], dtype: torch.dtype = torch.bfloat16,
+                 upsample_mode: str = 'simple'):
+        # resunet_model.py:185-249 as vangan.py:112-122,151-162 configures it: upsample_mode='simple' (UpSampling3D).  The
+        # reference's other mode cannot be built by the reference itself: 'deconv' reflect-pads before its k2 s2
+        # Conv3DTranspose (resunet_model.py:168-174, padding='valid' is never overridden at :241), which yields 2(S+2) voxels
+        # per axis against the skip tensor's 2S, and Keras' concatenate raises on the mismatch -- so does this constructor.
+        if upsample_mode == 'deconv':
+            raise ValueError("upsample_mode='deconv': the reference builds ReflectionPadding3D + Conv3DTranspose(k2,s2,'valid') "
+                             'with 2(S+2) outputs per axis and concatenates it with a 2S skip tensor (resunet_model.py:168-181): '
+                             'a Concatenate shape error in Keras; only upsample_mode=\'simple\' is a working configuration')
+        if upsample_mode != 'simple':
+            raise ValueError("upsample_mode must be 'simple' (UpSampling3D(2), vangan.py:114,153)")
         self.dtype = dtype
         D, H, W = dims
         if any(n % 16 or n < 32 for n in dims):
@@ -285,7 +296,7 @@ class ResUNet:
     def _norm_bwd(self, ar, g, g_padded, src: Src, st, norm: Norm, dx, act, dx_cstride=0, accumulate=True):
         """(IN -> act) backward of the operand described by `src` with statistics `st`."""
         N = src.N
-        red = ar.alloc((ops.STRIPES, N, src.C, 2), torch.float32, zero=True)
+        red = ops.alloc_red(ar, N, src.C)
         ops.actnorm_bwd(g, g_padded, src.x0, (N, src.D, src.H, src.W), src.C, dx, scale=st['scale'], shift=st['shift'],
                         act=act, norm=True, gamma=norm.gamma, mean=st['mean'], rstd=st['rstd'], red=red,
                         accumulate=accumulate, x1=src.x1, c_x0=src.c0 if src.x1 is not None else 0, x0_shift=src.shift0,
@@ -470,7 +481,7 @@ class PatchGAN:
             lay.dgrad(g, N, dp, accumulate=False)
             st = ctx['sts'][li - 1]
             nrm = Nn[self.NAMES[li - 1]]
-            red = ar.alloc((ops.STRIPES, N, a.C, 2), torch.float32, zero=True)
+            red = ops.alloc_red(ar, N, a.C)
             dxa = ar.alloc((N,) + a.dims + (a.C,), self.dtype)
             ops.actnorm_bwd(dp, lay.pad == 'reflect', sl(a.data), (N,) + a.dims, a.C, dxa, scale=sl(st['scale']),
                             shift=sl(st['shift']), mult=sl(st['mult']), act=ACT_LRELU, norm=True, gamma=nrm.gamma,

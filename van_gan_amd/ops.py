@@ -586,10 +586,17 @@ def in_finalize(sums0, c0, count0, gamma, beta, N, scale, shift, mean=None, rstd
                              N, IN_EPS, _p(scale), _p(shift), _p(mean), _p(rstd), stream()), 'vg_in_finalize')
 
 
+def alloc_red(ar: 'Arena', N: int, C_: int) -> torch.Tensor:
+    """Striped reduction buffer of the InstanceNorm backward [STRIPES][N][C][2] followed by 4 words, the first of which is
+    the ticket of its last-workgroup fold (zero-initialised with the rest)."""
+    return ar.alloc((STRIPES * N * C_ * 2 + 4,), torch.float32, zero=True)
+
+
 def actnorm_bwd(g, g_padded, x, dims, C_, dx, *, scale=None, shift=None, mult=None, act=ACT_NONE, norm=False,
                 gamma=None, mean=None, rstd=None, red=None, accumulate=False, x1=None, c_x0=0, x0_shift=0,
                 dx_cstride=0, dx_coff=0, dgamma=None, dbeta=None):
-    """stats + apply (+ parameter gradients) of the (InstanceNorm -> act -> dropout) backward."""
+    """stats + apply (+ parameter gradients) of the (InstanceNorm -> act -> dropout) backward.  `red` from alloc_red()
+    (with ticket word: one launch fewer) or a plain zeroed [STRIPES, N, C, 2] tensor."""
     d = ActNormBwdDesc()
     d.g, d.g_padded = _p(g), int(g_padded)
     d.x, d.x_f32 = _p(x), int(x is not None and x.dtype == torch.float32)
@@ -602,6 +609,8 @@ def actnorm_bwd(g, g_padded, x, dims, C_, dx, *, scale=None, shift=None, mult=No
     d.dx_cstride, d.dx_coff = dx_cstride, dx_coff
     d.f32 = int(g.dtype == torch.float32)
     d.dgamma, d.dbeta = _p(dgamma), _p(dbeta)      # parameter gradients come out of the statistics pass
+    nred = STRIPES * dims[0] * C_ * 2
+    d.ticket = (red.data_ptr() + 4 * nred) if (red is not None and red.dim() == 1 and red.numel() == nred + 4) else None
     s = stream()
     if norm:
         check(lib.vg_actnorm_bwd_stats(C.byref(d), s), 'vg_actnorm_bwd_stats')
