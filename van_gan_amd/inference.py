@@ -33,6 +33,7 @@ def stitch_subvolumes(engine, gen: str, img: torch.Tensor, subvol_size: Sequence
     """img: [X,Y,Z,1] fp32 (host or device).  gen: 'gen_IS' or 'gen_SI'.  Returns 255*minmax(pred) as fp32 [X,Y,Z,1]
     on the device (custom_callback.py:202).  subvol_size is (kX,kY,kZ)."""
     dev = engine.device
+    ops.set_device(dev.index)
     net = engine.nets[gen]
     kx, ky, kz = subvol_size
     if tuple(net.dims) != (kx, ky, kz):

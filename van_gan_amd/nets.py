@@ -156,7 +156,8 @@ class Norm:
 
     def finalize(self, arena: Arena, a0: Act, a1: Optional[Act] = None, mult=None):
         N = a0.N
-        st = {k: arena.alloc((N, self.C), torch.float32) for k in ('scale', 'shift', 'mean', 'rstd')}
+        blk = arena.alloc((4, N, self.C), torch.float32)           # one allocation, four views
+        st = {'scale': blk[0], 'shift': blk[1], 'mean': blk[2], 'rstd': blk[3]}
         ops.in_finalize(a0.sums, a0.C, a0.count, self.gamma, self.beta, N, st['scale'], st['shift'], st['mean'],
                         st['rstd'], sums1=None if a1 is None else a1.sums, c1=0 if a1 is None else a1.C,
                         count1=1.0 if a1 is None else a1.count, mult=mult)

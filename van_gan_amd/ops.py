@@ -28,10 +28,34 @@ def conv_variant(d) -> str:
     return buf.value.decode()
 
 
+_DEV: Optional[int] = None          # device index of the engine (set_device): lets stream() take the fast path
+_STREAM_OBJ = {}                    # (device index, raw handle) -> torch.cuda.Stream object of that handle
+
+
+def set_device(index: int):
+    """The engine's device.  torch.cuda.current_stream() costs ~8 us of Python per call (device-index plumbing) and the step
+    asks for the current stream ~1300 times: with the index known, the raw handle comes from one C call instead."""
+    global _DEV
+    _DEV = int(index)
+
+
 def stream() -> int:
     if DRY is not None:
         return 0
+    if _DEV is not None:
+        return torch._C._cuda_getCurrentRawStream(_DEV)
     return torch.cuda.current_stream().cuda_stream
+
+
+def current_stream_obj() -> torch.cuda.Stream:
+    """torch.cuda.Stream object of the current stream, cached per raw handle."""
+    if _DEV is None:
+        return torch.cuda.current_stream()
+    key = (_DEV, torch._C._cuda_getCurrentRawStream(_DEV))
+    so = _STREAM_OBJ.get(key)
+    if so is None:
+        so = _STREAM_OBJ[key] = torch.cuda.current_stream()
+    return so
 
 
 class DryRun:
@@ -149,8 +173,7 @@ def _side_key(cur: torch.cuda.Stream):
     return (cur.device.index, cur.cuda_stream)
 
 
-def _side_of_current() -> torch.cuda.Stream:
-    cur = torch.cuda.current_stream()
+def _side_of(cur: torch.cuda.Stream) -> torch.cuda.Stream:
     sd = _SIDE_OF.get(_side_key(cur))
     if sd is None:
         sd = _SIDE_OF[_side_key(cur)] = torch.cuda.Stream(device=cur.device)
@@ -160,7 +183,7 @@ def _side_of_current() -> torch.cuda.Stream:
 def side_join():
     """The current stream waits for every weight-gradient launch it handed to its side stream."""
     if SIDE is not None:
-        cur = torch.cuda.current_stream()
+        cur = current_stream_obj()
         sd = _SIDE_OF.get(_side_key(cur))
         if sd is not None:
             cur.wait_stream(sd)
@@ -191,9 +214,11 @@ class Arena:
             self.zpool[:self.zoff].zero_()
         self.zoff = 0
 
+    _ESZ = {torch.float32: 4, torch.bfloat16: 2, torch.float16: 2, torch.int32: 4, torch.int64: 8, torch.uint8: 1, torch.float64: 8}
+
     def alloc(self, shape: Sequence[int], dtype: torch.dtype, zero: bool = False) -> torch.Tensor:
         n = int(math.prod(shape))
-        nbytes = n * torch.empty((), dtype=dtype).element_size()
+        nbytes = n * self._ESZ[dtype]
         if zero and nbytes <= 65536:
             zs = (self.zoff + 255) // 256 * 256
             if zs + nbytes <= self.ZPOOL:
@@ -415,16 +440,23 @@ class ConvLayer:
                                       _p(c['wp']), self.f32, s), 'pack')
 
     def _fwd_desc(self, src: Src) -> ConvDesc:
+        # the static part (taps, geometry, packed weights) is built once and block-copied: filling ~100 ctypes fields from
+        # Python cost ~9 us per call, 780 calls per train step
+        t = getattr(self, '_fwd_tmpl', None)
+        if t is None:
+            t = ConvDesc()
+            t.istr, t.pad_mode = self.stride, self.pad_mode
+            t.wpack, t.wpack_wmin = self.wpack, -self.pb[2]
+            _set_taps(t, self.f_taps)
+            t.OD, t.OH, t.OW = self.out_dims
+            t.ostr, t.ooff_d, t.ooff_h, t.ooff_w = 1, 0, 0, 0
+            t.BD, t.BH, t.BW = self.out_dims
+            t.Cout, t.wpacked, t.CK = self.cout, _p(self.f_wp), self.f_ck
+            t.f32 = self.f32
+            self._fwd_tmpl = t
         d = ConvDesc()
+        C.memmove(C.byref(d), C.byref(t), C.sizeof(ConvDesc))
         src.fill(d)
-        d.istr, d.pad_mode = self.stride, self.pad_mode
-        d.wpack, d.wpack_wmin = self.wpack, -self.pb[2]
-        _set_taps(d, self.f_taps)
-        d.OD, d.OH, d.OW = self.out_dims
-        d.ostr, d.ooff_d, d.ooff_h, d.ooff_w = 1, 0, 0, 0
-        d.BD, d.BH, d.BW = self.out_dims
-        d.Cout, d.wpacked, d.CK = self.cout, _p(self.f_wp), self.f_ck
-        d.f32 = self.f32
         return d
 
     def forward(self, src: Src, out: torch.Tensor, sums=None, res=None, res_scale=None, res_shift=None,
@@ -448,28 +480,29 @@ class ConvLayer:
                      src.N * esz * (math.prod(self.in_dims) * self.cin + math.prod(self.out_dims) * self.cout), conv_variant(d))
 
     def wgrad(self, src: Src, dy: torch.Tensor):
-        if SIDE is not None and PROF is None:       # the per-launch timing pass serialises (attributable kernel durations)
-            sd = _side_of_current()
-            sd.wait_stream(torch.cuda.current_stream())         # dY (and everything before it) is ready
-            with torch.cuda.stream(sd):
-                self._wgrad(src, dy)
-        else:
+        if SIDE is not None and PROF is None and DRY is None:   # the per-launch timing pass serialises (attributable durations)
+            cur = current_stream_obj()
+            sd = _side_of(cur)
+            sd.wait_stream(cur)                                  # dY (and everything before it) is ready
+            self._wgrad(src, dy, sd.cuda_stream)                 # launched on the side stream by handle: torch's current
+        else:                                                    # stream is not switched (the context manager cost ~10 us)
             self._wgrad(src, dy)
 
-    def _wgrad(self, src: Src, dy: torch.Tensor):
+    def _wgrad(self, src: Src, dy: torch.Tensor, on_stream: Optional[int] = None):
         d = self._fwd_desc(src)
+        s_ = stream() if on_stream is None else on_stream
         if DRY is not None:
             DRY.tag = ('wgrad', self.name)
             DRY.recipe = dict(kind='wgrad', layer=self.ctor, src=src.recipe(), dy_f32=dy.dtype == torch.float32)
         e0 = PROF.begin() if PROF is not None else None
         # one partial-slab scratch per (device, stream): launches on one stream reuse it in order, the two lanes of the
         # engine issue weight gradients concurrently and must not share it
-        key = (dy.device, stream())
+        key = (dy.device, s_)
         sc = WGRAD_SCRATCH.get(key)
         if sc is None:
             sc = WGRAD_SCRATCH[key] = torch.empty(WGRAD_SCRATCH_ELEMS, dtype=torch.float32, device=dy.device)
         check(lib.vg_conv3d_wgrad(C.byref(d), _p(dy), int(dy.dtype == torch.float32), self.f_idx_host, self.f_T,
-                                  _p(self.gw), _p(self.gb), _p(sc), sc.numel() * 4, stream()), 'vg_conv3d_wgrad ' + self.name)
+                                  _p(self.gw), _p(self.gb), _p(sc), sc.numel() * 4, s_), 'vg_conv3d_wgrad ' + self.name)
         if e0 is not None:
             esz = 4 if self.f32 else 2
             vb = C.create_string_buffer(512)
@@ -523,7 +556,14 @@ class ConvLayer:
             DRY.recipe = dict(kind='dgrad', layer=self.ctor, N=N, accumulate=bool(accumulate), dy_f32=dy.dtype == torch.float32,
                               out_f32=out.dtype == torch.float32)
         if self.d_fused:
-            d = self._fused_desc(dy, N, out, accumulate)
+            t = getattr(self, '_dg_tmpl', None)
+            if t is None:                            # static part once (taps / weights / offsets of every class), then block copies
+                t = self._dg_tmpl = self._fused_desc(dy, N, out, accumulate)
+            d = ConvDesc()
+            C.memmove(C.byref(d), C.byref(t), C.sizeof(ConvDesc))
+            d.src0, d.N = _p(dy), N
+            d.src_f32 = int(dy.dtype == torch.float32 and self.cout == 1)
+            d.out, d.out_f32, d.accumulate = _p(out), int(out.dtype == torch.float32), int(accumulate)
             e0 = PROF.begin() if PROF is not None else None
             check(lib.vg_conv3d(C.byref(d), stream()), 'vg_conv3d(dgrad, fused classes) ' + self.name)
             if e0 is not None:
@@ -532,19 +572,25 @@ class ConvLayer:
                          N * 2 * (math.prod(self.out_dims) * self.cout + math.prod(self.buf_dims) * self.cin), conv_variant(d))
             return
         for c in self.d_classes:
+            t = c.get('tmpl')
+            if t is None:
+                t = ConvDesc()
+                t.src1 = None
+                t.c_src0, t.c_src1, t.src0_shift = self.cout, 0, 0
+                t.D, t.H, t.W = self.out_dims
+                t.act, t.istr, t.pad_mode = ACT_NONE, 1, PAD_ZERO
+                _set_taps(t, c['taps'])
+                t.OD, t.OH, t.OW = c['iters']
+                t.ostr = self.stride
+                t.ooff_d, t.ooff_h, t.ooff_w = c['off']
+                t.BD, t.BH, t.BW = self.buf_dims
+                t.Cout, t.wpacked, t.CK = self.cin, _p(c['wp']), c['ck']
+                t.f32 = self.f32
+                c['tmpl'] = t
             d = ConvDesc()
-            d.src0, d.src1 = _p(dy), None
-            d.c_src0, d.c_src1, d.src0_shift, d.src_f32 = self.cout, 0, 0, int(dy.dtype == torch.float32 and self.cout == 1)
-            d.N = N
-            d.D, d.H, d.W = self.out_dims
-            d.act, d.istr, d.pad_mode = ACT_NONE, 1, PAD_ZERO
-            _set_taps(d, c['taps'])
-            d.OD, d.OH, d.OW = c['iters']
-            d.ostr = self.stride
-            d.ooff_d, d.ooff_h, d.ooff_w = c['off']
-            d.BD, d.BH, d.BW = self.buf_dims
-            d.Cout, d.wpacked, d.CK = self.cin, _p(c['wp']), c['ck']
-            d.f32 = self.f32
+            C.memmove(C.byref(d), C.byref(t), C.sizeof(ConvDesc))
+            d.src0, d.N = _p(dy), N
+            d.src_f32 = int(dy.dtype == torch.float32 and self.cout == 1)
             d.out, d.out_f32, d.accumulate = _p(out), int(out.dtype == torch.float32), int(accumulate)
             e0 = PROF.begin() if PROF is not None else None
             check(lib.vg_conv3d(C.byref(d), stream()), 'vg_conv3d(dgrad) ' + self.name)

@@ -40,6 +40,9 @@ class VanGan:
         self.dtype = torch.bfloat16 if precision == 'bf16' else torch.float32
         self.device = torch.device(device)
         torch.cuda.set_device(self.device)
+        if self.device.index is None:
+            self.device = torch.device('cuda', torch.cuda.current_device())
+        ops.set_device(self.device.index)
         self.dims = tuple(subvol_patch_size)
         self.batch_size = batch_size
         self.n_devices = n_devices
@@ -133,6 +136,7 @@ class VanGan:
     def _losses_and_backward(self, real_I, real_S, training: bool, noise, drop, do_backward: bool, apply: bool = False):
         ar = self.arena
         ar.reset()
+        ops.set_device(self.device.index)          # module-level fast path of ops.stream(): this engine's device
         B = real_I.shape[0]
         D, H, W = self.dims
         S = D * H * W
