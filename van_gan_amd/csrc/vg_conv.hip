@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256, ((BN / 16) * MSUB >= VG_CONV_MW2 ? 2 : VG_CONV
         ooff[i] = ((d * p.ostr * p.BH + h * p.ostr) * p.BW + w * p.ostr) * p.Cout + co0;
         dhw[i] = d | (h << 10) | (w << 20);
     }
-    const bool vec_epi = (p.Cout & 3) == 0 && !(p.tanh_out && p.accumulate);   // every lane owns 4 whole channels: vector loads/stores
+    const bool vec_epi = (p.Cout & 3) == 0 && !p.tanh_out;        // every lane owns 4 whole channels: vector loads/stores
     if (p.nchunks == 1) stage_scale_shift(g, scs, n, 0, tid);
     if constexpr (!DMA) {
         if (bx < g.tiles_d * g.tiles_h * g.tiles_w) {

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(128 * NCW, (NCW == 8 ? 4 : ((BN / 16) * MSUB >= 4 ?
         e_rs[r] = (!producer && p.res && co < p.Cout) ? p.rs[n * p.Cout + co] : 0.f;
         e_rb[r] = (!producer && p.res && co < p.Cout) ? p.rb[n * p.Cout + co] : 0.f;
     }
-    const bool vec_epi = (p.Cout & 3) == 0 && !(p.tanh_out && p.accumulate);
+    const bool vec_epi = (p.Cout & 3) == 0 && !p.tanh_out;        // every lane owns 4 whole channels
 
     // ---- prologue: stage 0 into buffer 0, tables of stage 1 ----
     // producer cursor: (pj, pc) = (local tile, chunk) of the stage it stages next; pcur / pnxt = coordinates of tile pj / pj + 1
