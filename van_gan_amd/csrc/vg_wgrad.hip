@@ -313,7 +313,9 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* part,
     }
     sm[w][lane] = s;
     __syncthreads();
-    if (w == 0 && i < n) dw[i] += sm[0][lane] + sm[1][lane] + sm[2][lane] + sm[3][lane];
+    // atomic: two applications of one network may run their backward sweeps concurrently (four-lane schedule) and both add into
+    // the network's gradient buffer; the SUM over this launch's slabs above stays in a fixed order
+    if (w == 0 && i < n) atomicAdd(&dw[i], sm[0][lane] + sm[1][lane] + sm[2][lane] + sm[3][lane]);
 }
 
 template <typename T, int RMAX, int Q, bool NOISE>
