@@ -928,6 +928,10 @@ extern "C" int vg_conv3d(const vg_conv_desc* d, vg_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     { GatherIn g2; int bn2, ms2, lds2; if (plan_conv32(d, k, q, g2, bn2, ms2, lds2) == VG_OK) return launch_conv32(g2, k, q, bn2, ms2, lds2, s); }
     if (k.pc) return vg_launch_conv_pc(g, k, q, BN, MSUB, lds, s);
+    if (!d->f32 && MSUB == 8 && BN == 16 && vg_conv_thin_ok(d, g, k, q)) {
+        const int trc = vg_launch_conv_thin(g, k, s);
+        if (trc <= 0) return trc;
+    }
     return d->f32 ? dispatch_conv<float>(g, k, q, BN, MSUB, lds, s) : dispatch_conv<bf16_t>(g, k, q, BN, MSUB, lds, s);
 }
 

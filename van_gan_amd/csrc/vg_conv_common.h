@@ -144,6 +144,9 @@ __device__ __forceinline__ void conv_mfma_chunk(f32x4 (&acc)[MW], WP w, const ch
 
 // vg_conv_pc.hip: producer/consumer flavour (512-thread workgroups: 4 MFMA waves + 4 staging waves, double-buffered halo image)
 int vg_launch_conv_pc(const GatherIn& g, const ConvOut& k, const ConvCls& q, int BN, int MSUB, int lds, hipStream_t s);
+// vg_conv_thin.hip: specialist for the 16-channel-chunk 3x3x3 stride-1 layers with a fixed 16x8x4 tile
+bool vg_conv_thin_ok(const vg_conv_desc* d, const GatherIn& g, const ConvOut& k, const ConvCls& q);
+int vg_launch_conv_thin(const GatherIn& g, const ConvOut& k, hipStream_t s);       // VG_OK, < 0 on error, 1: not one of its combinations
 // staging mode (VG_STAGE_*) the producer/consumer flavour would use for this source, -1: not supported there
 int vg_conv_pc_mode(const GatherIn& g);
 // LDS bytes of the producer/consumer flavour for this geometry (host)

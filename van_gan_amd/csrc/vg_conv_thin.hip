@@ -1,0 +1,277 @@
+// vg_conv_thin.hip -- specialist gather-convolution for the thin-channel 3x3x3 stride-1 layers of the two finest levels
+// (stem.cb, dec0.cb1/cb2 at full resolution and their data gradients: the largest single share of the train step).
+//
+// Why a specialist: PMC on conv_kernel<16,8> shows the SIMDs 59 % busy issuing ordinary vector instructions
+// (5 850 per 512-voxel tile) against 18 % for the matrix pipe -- the layer is bound by instruction count, and most of those
+// instructions exist only because the generic kernel keeps its geometry and its epilogue options in run-time variables.
+// Here the tile is FIXED at 16 (W) x 8 (H) x 4 (D) output voxels, 16 output channels per workgroup, 16 input channels per
+// chunk, 27 taps: halo image 18 x 10 x 6 voxels, planar [channel group 2][6][10][18] x 16 bytes.  Consequences:
+//   * a wave owns one D-plane of the tile = 8 sub-tiles of 16 consecutive voxels (one W row each): the B fragment of
+//     sub-tile j is at  lane_base[K-step] + j * 288 bytes -- an immediate of ds_read_b128; lane_base[14] lives in registers
+//     for the whole kernel, so the MFMA loop issues NO address arithmetic (the generic loop: 8 adds + a table read per K-step);
+//   * the weight fragment of K-step s is at  lane_row + chunk_base + s * 64 -- an immediate as well;
+//   * the loop is fully unrolled (14 K-steps) with the fragments of two K-steps ahead in flight;
+//   * the epilogue options are template flags (bias, residual, statistics), the arithmetic is packed f32, two sub-tiles are
+//     exchanged across the 16-lane rows with v_permlane16_swap so that every lane stores 16 contiguous bytes;
+//   * staging is the lean routine (vg_gather.h) with a compile-time transform, its 360 columns x 2 D-segments dealt out evenly.
+// Everything else (persistent workgroups, tables, InstanceNorm statistics carried in registers) follows conv_kernel.
+#include "vg_conv_common.h"
+#include <stdio.h>
+#include <type_traits>
+
+namespace {
+constexpr int TW = 16, TH = 8, TD = 4;                 // output tile
+constexpr int HW = 18, HH = 10, HD = 6;                // halo (3x3x3, stride 1)
+constexpr int UNIT = 16;                               // bytes of one 8-channel bf16 unit
+constexpr int ROWB = HW * UNIT;                        // 288: one halo row
+constexpr int DSB = HH * ROWB;                         // 2880: one halo D-plane
+constexpr int PSB = ((HD * DSB + 255) / 256) * 256;    // 17408: one channel-group plane (what fill_gather computes)
+constexpr int HALO = 2 * PSB;                          // two channel groups (16 channels)
+constexpr int KSTEPS = 14;                             // ceil(27 taps * 2 groups / 4)
+constexpr int KCPAD = 448;                             // packed K of one 16-channel chunk (27 * 16 rounded to 32)
+}
+
+__device__ __forceinline__ void lds_only_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// MODE: VG_STAGE_PLAIN (data-gradient operand, zero padded) or VG_STAGE_RELU (forward: IN affine + ReLU, reflect padded)
+template <int MODE, bool BIAS, bool RES, bool STATS>
+__global__ __launch_bounds__(256, 2) void conv_thin_kernel(const GatherIn g, const ConvOut p) {
+    typedef bf16_t T;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, kg = lane >> 4;
+    const int n = blockIdx.z, ntile = blockIdx.y;
+    // ---- LDS: [halo][scale/shift 2*16 floats][statistics 32 floats][tap offsets 32 ints][column table][axis tables x 2]
+    //           [weights of ONE 16-channel chunk: 16 rows x (448 + 8) bf16]
+    char* halo = smem;
+    float* scs = (float*)(smem + HALO);
+    float* stat = scs + 32;
+    int* tapb = (int*)(stat + 32);
+    int* utab = tapb + 32;
+    constexpr int NCOLS = HH * HW * 2;
+    int* rtab = utab + 2 * NCOLS;
+    const int RTN = 3 * stage_axis_len3(g);
+    char* wlds = (char*)(rtab + 2 * RTN);
+    wlds = (char*)(((size_t)wlds + 15) & ~(size_t)15);
+    const int Ktot = p.Ktot, nchunks = p.nchunks;
+    constexpr int WRS = KCPAD * 2 + 16;                  // LDS row stride of the chunk panel (16 bytes of padding: bank spread)
+
+    build_column_table(g, utab, tid);
+    if (tid < 32) stat[tid] = 0.f;
+    if (tid < 27) tapb[tid] = (g.td[tid] - g.tmin_d) * DSB + (g.th[tid] - g.tmin_h) * ROWB + (g.tw[tid] - g.tmin_w) * UNIT;
+    // the 16 x 448 weight panel of one chunk -> LDS: 16 rows x 56 units of 16 bytes, 3.5 per thread
+    auto load_weights = [&](int chunk) {
+        const char* src = (const char*)p.wp + ((size_t)(ntile * 16) * Ktot + (size_t)chunk * KCPAD) * 2;
+        f32x4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int u = min(tid + k * 256, 16 * 56 - 1);
+            const int r = u / 56, c = u - r * 56;
+            v[k] = *(const __attribute__((address_space(1))) f32x4*)(uintptr_t)(src + (size_t)r * Ktot * 2 + c * 16);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int u = tid + k * 256;
+            if (u < 16 * 56) { const int r = u / 56, c = u - r * 56; *(f32x4*)(wlds + r * WRS + c * 16) = v[k]; }
+        }
+    };
+    load_weights(0);
+    // ---- per-lane constants of the MFMA loop: B-fragment base of every K-step (tap and channel group of this lane's k-group)
+    const int wbase = li * WRS + kg * 16;                                // A fragment: row li of the panel, k-group kg
+    const int co0 = ntile * 16 + 4 * kg;                                 // this lane's 4 output channels
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x2 e_b[2] = {{0.f, 0.f}, {0.f, 0.f}}, e_rs[2], e_rb[2];
+    if (BIAS) { e_b[0] = (f32x2){p.bias[co0], p.bias[co0 + 1]}; e_b[1] = (f32x2){p.bias[co0 + 2], p.bias[co0 + 3]}; }
+    if (RES) {
+        e_rs[0] = (f32x2){p.rs[n * p.Cout + co0], p.rs[n * p.Cout + co0 + 1]}; e_rs[1] = (f32x2){p.rs[n * p.Cout + co0 + 2], p.rs[n * p.Cout + co0 + 3]};
+        e_rb[0] = (f32x2){p.rb[n * p.Cout + co0], p.rb[n * p.Cout + co0 + 1]}; e_rb[1] = (f32x2){p.rb[n * p.Cout + co0 + 2], p.rb[n * p.Cout + co0 + 3]};
+    }
+    // 16-byte stores: after the row swap an even k-group lane holds channels 8*(kg/2)..+7 of sub-tile j, an odd one of j+1
+    const int cst = ntile * 16 + 8 * (kg >> 1);
+    const int jodd = kg & 1;
+
+    const int tiles_per_n = g.tiles_d * g.tiles_h * g.tiles_w;
+    int gs_w, gs_h, gs_d;
+    { int t = gridDim.x; gs_w = t % g.tiles_w; t /= g.tiles_w; gs_h = t % g.tiles_h; gs_d = t / g.tiles_h; }
+    int ti_w, ti_h, ti_d;
+    { int t = blockIdx.x; ti_w = t % g.tiles_w; t /= g.tiles_w; ti_h = t % g.tiles_h; ti_d = t / g.tiles_h; }
+    if (nchunks == 1) stage_scale_shift(g, scs, n, 0, tid);
+    if ((int)blockIdx.x < tiles_per_n) stage_resolve_axes3(g, rtab, ti_d * TD, ti_h * TH, ti_w * TW, tid);
+    lds_only_barrier();
+    int boff[KSTEPS];
+    {
+        const int rowbase = wave * DSB + li * UNIT;                      // sub-tile 0 of this wave's plane, this lane's voxel
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            int G = 4 * s + kg; if (G > 53) G = 53;                       // padded K (weights are zero there)
+            boff[s] = rowbase + tapb[G >> 1] + (G & 1) * PSB;
+        }
+    }
+
+    typedef const __attribute__((address_space(3))) bf16x8 lds_frag;
+    int it = 0;
+    for (int tile = blockIdx.x; tile < tiles_per_n; tile += gridDim.x, ++it) {
+        const int od0 = ti_d * TD, oh0 = ti_h * TH, ow0 = ti_w * TW;
+        ti_w += gs_w; if (ti_w >= g.tiles_w) { ti_w -= g.tiles_w; ++ti_h; }
+        ti_h += gs_h; if (ti_h >= g.tiles_h) { ti_h -= g.tiles_h; ++ti_d; }
+        ti_d += gs_d;
+        f32x4 acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int chunk = 0; chunk < nchunks; ++chunk) {
+            if (it | chunk) lds_only_barrier();                            // previous readers of the halo image / weight panel are done
+            if (nchunks > 1) { stage_scale_shift(g, scs, n, chunk, tid); if (it | chunk) load_weights(chunk); lds_only_barrier(); }
+            stage_halo_lean<T, MODE, 3, 256, false, 2, HD>(g, halo, scs, utab, rtab + (it & 1) * RTN, n, chunk, tid);
+            if (chunk == 0 && tile + (int)gridDim.x < tiles_per_n)
+                stage_resolve_axes3(g, rtab + ((it + 1) & 1) * RTN, ti_d * TD, ti_h * TH, ti_w * TW, tid);
+            lds_only_barrier();
+            // ---- MFMA loop: 14 K-steps x 8 sub-tiles, every address an immediate, fragments of two K-steps ahead in flight
+            const char* wb = wlds + wbase;
+            bf16x8 a[3], b[3][8];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                a[u] = *(lds_frag*)(wb + u * 64);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) b[u][j] = *(lds_frag*)(halo + boff[u] + j * ROWB);
+            }
+#pragma unroll
+            for (int s = 0; s < KSTEPS; ++s) {
+                if (s + 2 < KSTEPS) {
+                    a[(s + 2) % 3] = *(lds_frag*)(wb + (s + 2) * 64);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) b[(s + 2) % 3][j] = *(lds_frag*)(halo + boff[s + 2] + j * ROWB);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s % 3], b[s % 3][j], acc[j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // ---- epilogue: wave = D-plane `wave` of the tile, sub-tile j = H row j, lane li = voxel W, lanes own 4 channels;
+        //      pairs of sub-tiles are exchanged across the 16-lane rows so that every lane stores 8 channels = 16 bytes.
+        //      Tiles that lie wholly inside the output (all of them for the forward layers, ~80 % for the data gradients
+        //      on the padded grid) take the predicate-free instance.
+        const int od = od0 + wave, ow = ow0 + li;
+        const size_t rowpitch = (size_t)p.BW * p.Cout;                                       // elements per output H row (ostr == 1)
+        const size_t obase = (((size_t)(n * p.BD + od + p.ood) * p.BH + oh0 + p.ooh) * p.BW + ow + p.oow) * p.Cout;
+        T* const optr = (T*)p.out + obase + cst;
+        const T* const rptr = RES ? (const T*)p.res + obase + co0 : nullptr;
+        const bool full = od0 + TD <= p.OD && oh0 + TH <= p.OH && ow0 + TW <= p.OW;
+        auto epilogue = [&](auto masked_tag) {
+            constexpr bool MASKED = decltype(masked_tag)::value;
+            const bool dw_ok = !MASKED || (od < p.OD && ow < p.OW);
+            const int nrow = MASKED ? p.OH - oh0 : TH;                                        // valid H rows of this tile
+            typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+            typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+#pragma unroll
+            for (int jp = 0; jp < 8; jp += 2) {
+                bf16x4 pk[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int j = jp + e;
+                    const bool ok = !MASKED || (dw_ok && j < nrow);
+                    f32x2 v0 = {acc[j][0], acc[j][1]}, v1 = {acc[j][2], acc[j][3]};
+                    if (BIAS) { v0 += e_b[0]; v1 += e_b[1]; }
+                    if (RES) {
+                        const bf16x4 r = *(const __attribute__((address_space(1))) bf16x4*)(uintptr_t)(ok ? rptr + j * rowpitch : rptr);
+                        const f32x2 r0 = {bf2f((bf16_t)r[0]), bf2f((bf16_t)r[1])}, r1 = {bf2f((bf16_t)r[2]), bf2f((bf16_t)r[3])};
+                        v0 += r0 * e_rs[0] + e_rb[0]; v1 += r1 * e_rs[1] + e_rb[1];
+                    }
+                    pk[e] = (bf16x4){(short)f2bf(v0[0]), (short)f2bf(v0[1]), (short)f2bf(v1[0]), (short)f2bf(v1[1])};
+                    if (STATS) {
+                        f32x2 q0 = {bf2f((bf16_t)pk[e][0]), bf2f((bf16_t)pk[e][1])}, q1 = {bf2f((bf16_t)pk[e][2]), bf2f((bf16_t)pk[e][3])};
+                        if (MASKED && !ok) { q0 = (f32x2){0.f, 0.f}; q1 = q0; }
+                        f32x2 a0 = {s1[0], s1[1]}, a1 = {s1[2], s1[3]}, c0 = {s2[0], s2[1]}, c1 = {s2[2], s2[3]};
+                        a0 += q0; a1 += q1; c0 += q0 * q0; c1 += q1 * q1;
+                        s1[0] = a0[0]; s1[1] = a0[1]; s1[2] = a1[0]; s1[3] = a1[1]; s2[0] = c0[0]; s2[1] = c0[1]; s2[2] = c1[0]; s2[3] = c1[1];
+                    }
+                }
+                // rows (16-lane groups) 1,3 of pk[0] <-> rows 0,2 of pk[1]: even rows end with sub-tile jp channels [4kg..4kg+7],
+                // odd rows with sub-tile jp+1 channels [4(kg-1)..4kg+3]
+                const u32x2 wa = __builtin_bit_cast(u32x2, pk[0]), wb2 = __builtin_bit_cast(u32x2, pk[1]);
+                const u32x2 x0 = __builtin_amdgcn_permlane16_swap(wa[0], wb2[0], false, false);
+                const u32x2 x1 = __builtin_amdgcn_permlane16_swap(wa[1], wb2[1], false, false);
+                const u32x4 outv = {x0[0], x1[0], x0[1], x1[1]};
+                const int j = jp + jodd;
+                if (!MASKED || (dw_ok && j < nrow)) *(u32x4*)(optr + j * rowpitch) = outv;
+            }
+        };
+        if (full) epilogue(std::false_type{}); else epilogue(std::true_type{});
+    }
+    if (STATS && p.sums) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float a = s1[r], b = s2[r];
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+            if (li == 0) { atomicAdd(&stat[(4 * kg + r) * 2], a); atomicAdd(&stat[(4 * kg + r) * 2 + 1], b); }
+        }
+        __syncthreads();
+        if (tid < 32) {
+            const int co = ntile * 16 + (tid >> 1);
+            const int stripe = blockIdx.x & (VG_STRIPES - 1);
+            if (co < p.Cout) atomicAdd(&p.sums[(((size_t)stripe * gridDim.z + n) * p.Cout + co) * 2 + (tid & 1)], stat[tid]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+int vg_conv_thin_lds_bytes(const GatherIn& g) {
+    return HALO + (32 + 32 + 32) * 4 + (2 * HH * HW * 2 + 6 * stage_axis_len3(g)) * 4 + 16 + 16 * (KCPAD * 2 + 16);
+}
+
+// Does this launch have the one shape the specialist serves?  (g from fill_gather for a 512-voxel tile)
+bool vg_conv_thin_ok(const vg_conv_desc* d, const GatherIn& g, const ConvOut& k, const ConvCls& q) {
+    if (!vg_tune("CONV_THIN", 1)) return false;
+    if (vg_tune("DEBUG_THIN", 0))
+        fprintf(stderr, "thin? f32 %d noise %p ncls %d istr %d ostr %d CK %d ntaps %d wpack %d Cin %d Cout %d tanh %d acc %d of32 %d lean %d planar %d HW %d HH %d HD %d HWp %d HHp %d DS %d PSB %d tile %d %d %d Ktot %d nch %d res %p bias %p\n",
+                d->f32, d->noise, q.ncls, d->istr, d->ostr, d->CK, d->ntaps, d->wpack, d->c_src0 + d->c_src1, d->Cout, d->tanh_out, d->accumulate,
+                d->out_f32, g.lean, g.planar, g.HW, g.HH, g.HD, g.HWp, g.HHp, g.DS, g.PSB, 1 << g.twl, 1 << g.thl, 1 << g.tdl, k.Ktot, k.nchunks, d->res, (const void*)d->bias);
+    if (d->f32 || d->noise || q.ncls != 1 || d->istr != 1 || d->ostr != 1 || d->CK != 16 || d->ntaps != 27 || d->wpack) return false;
+    if ((d->c_src0 + d->c_src1) % 16 || (d->Cout % 16) || d->tanh_out || d->accumulate || d->out_f32) return false;
+    if (g.lean != VG_STAGE_PLAIN && g.lean != VG_STAGE_RELU) return false;
+    if (!g.planar || g.HW != HW || g.HH != HH || g.HD != HD || g.HWp != HW || g.HHp != HH || g.DS != DSB || g.PSB != PSB) return false;
+    if ((1 << g.twl) != TW || (1 << g.thl) != TH || (1 << g.tdl) != TD) return false;
+    if (d->res && (d->bias == nullptr)) return false;                  // (instantiated combinations only)
+    if (k.Ktot != k.nchunks * KCPAD) return false;
+    for (int i = 0; i < 27; ++i)                                       // a full 3x3x3 stencil (any order)
+        if (d->tap_d[i] - g.tmin_d > 2 || d->tap_h[i] - g.tmin_h > 2 || d->tap_w[i] - g.tmin_w > 2) return false;
+    return true;
+}
+
+template <int MODE, bool BIAS, bool RES, bool STATS>
+static int launch_thin(const GatherIn& g, const ConvOut& k, int lds, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)conv_thin_kernel<MODE, BIAS, RES, STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, VG_LDS_LIMIT);
+        attr_set = true;
+    }
+    int per_cu = 2;
+    if (lds > 0 && VG_LDS_LIMIT / lds < per_cu) per_cu = VG_LDS_LIMIT / lds;
+    if (per_cu < 1) per_cu = 1;
+    const int tiles = g.tiles_d * g.tiles_h * g.tiles_w;
+    const int ny = k.Cout / 16;
+    const int wg = vg_tune("CONV_THIN_WGS", 0) > 0 ? vg_tune("CONV_THIN_WGS", 0) : 256 * per_cu;
+    int bx = wg / (ny * g.N); if (bx < 1) bx = 1; if (bx > tiles) bx = tiles;
+    if (vg_dry("conv_thin<m%d,b%d,r%d,s%d>|walk%d|ch%d", MODE, (int)BIAS, (int)RES, (int)STATS, tiles > bx ? 1 : 0, k.nchunks > 1 ? 1 : 0)) return VG_OK;
+    hipLaunchKernelGGL((conv_thin_kernel<MODE, BIAS, RES, STATS>), dim3(bx, ny, g.N), dim3(256), lds, s, g, k);
+    return vg_check_launch();
+}
+
+int vg_launch_conv_thin(const GatherIn& g, const ConvOut& k, hipStream_t s) {
+    const int lds = vg_conv_thin_lds_bytes(g);
+    if (lds > VG_LDS_LIMIT) return VG_ELDS;
+    const bool st = k.sums != nullptr;
+    if (g.lean == VG_STAGE_PLAIN) {
+        // data gradient (no bias / residual / statistics) and raw-source forward convolutions
+        if (k.bias == nullptr && k.res == nullptr && !st) return launch_thin<VG_STAGE_PLAIN, false, false, false>(g, k, lds, s);
+        if (k.bias != nullptr && k.res == nullptr) return st ? launch_thin<VG_STAGE_PLAIN, true, false, true>(g, k, lds, s)
+                                                             : launch_thin<VG_STAGE_PLAIN, true, false, false>(g, k, lds, s);
+        return 1;
+    }
+    if (k.bias == nullptr) return 1;
+    if (k.res != nullptr) return st ? launch_thin<VG_STAGE_RELU, true, true, true>(g, k, lds, s) : launch_thin<VG_STAGE_RELU, true, true, false>(g, k, lds, s);
+    return st ? launch_thin<VG_STAGE_RELU, true, false, true>(g, k, lds, s) : launch_thin<VG_STAGE_RELU, true, false, false>(g, k, lds, s);
+}

@@ -417,7 +417,10 @@ __device__ __forceinline__ void stage_resolve_axes3(const GatherIn& g, int* rt, 
 // MODE >= 0: compile-time transform (producer/consumer kernels); MODE == -1: taken from g.lean at run time (wave-uniform
 // branches per unit: the scalar unit has slack, the vector ALU does not) -- NOISE then says whether the kernel variant
 // carries the noise operand at all.
-template <typename T, int MODE, int UB, int NT = 256, bool NOISE_RT = false>
+// SEG > 0: the tile's columns are cut into SEG segments along D and the (column, segment) items dealt round-robin (for tiles
+// whose column count is not a multiple of the thread count: 360 columns x 2 segments over 256 threads is balanced, 360 whole
+// columns are not); SEG == 0: stage_split decides.
+template <typename T, int MODE, int UB, int NT = 256, bool NOISE_RT = false, int SEG = 0, int HDC = 0>
 __device__ __forceinline__ void stage_halo_lean(const GatherIn& g, char* halo, const float* scs, const int* ctab, const int* rt,
                                                 int n, int chunk, int tid) {
     const int mode = MODE >= 0 ? MODE : g.lean;
@@ -436,8 +439,17 @@ __device__ __forceinline__ void stage_halo_lean(const GatherIn& g, char* halo, c
     const char* b0 = (const char*)g.src0 + (size_t)n * (g.D >> sh) * (g.H >> sh) * (g.W >> sh) * g.c0 * esz;
     const char* b1 = (const char*)g.src1 + (size_t)n * g.D * g.H * g.W * g.c1 * esz;
     const char* nb = NOISE ? (const char*)g.noise + (size_t)n * (g.D + 2 * g.npad) * (g.H + 2 * g.npad) * (g.W + 2 * g.npad) * g.Cin * 2 : nullptr;
-    const StageSplit sp = stage_split<NT>(ncols, g.HD, tid);
-    for (int col = sp.col0; col < ncols; col += sp.cstride) {
+    StageSplit sp = stage_split<NT>(ncols, g.HD, tid);
+    const int HDv = HDC > 0 ? HDC : g.HD;                        // (compile-time halo depth where the kernel fixes its tile)
+    const int seglen = SEG > 0 ? (HDv + SEG - 1) / SEG : 0;
+    const int nitems = SEG > 0 ? ncols * SEG : ncols;
+    int sgi = SEG > 0 ? tid / ncols : 0, scol = SEG > 0 ? tid - sgi * ncols : 0;      // (segment, column) of the first item
+    for (int item = (SEG > 0 ? tid : sp.col0); item < nitems; item += (SEG > 0 ? NT : sp.cstride)) {
+        int col = item;
+        if (SEG > 0) {
+            col = scol; sp.hd_lo = sgi * seglen; sp.hd_hi = min(HDv, sp.hd_lo + seglen);
+            scol += NT; if (scol >= ncols) { scol -= ncols; ++sgi; }                 // next item of this thread (NT <= ncols)
+        }
         const int e = ctab[2 * col], hoff = ctab[2 * col + 1];
         const int hh = e & 1023, hw = (e >> 10) & 1023, cg = e >> 20;
         const int c = chunk * g.CK + cg * 8;
@@ -474,8 +486,7 @@ __device__ __forceinline__ void stage_halo_lean(const GatherIn& g, char* halo, c
 #pragma unroll
             for (int k = 0; k < UB; ++k) {                                  // entries past the segment are real table words
                 od[k] = dt[h0 + k];
-                if (g.dbg & 16) raw_mask(raw[k], false);       // ablation: no global loads
-                else raw_load(raw[k], (const T*)(pc + (unsigned)max(od[k], 0)));
+                raw_load(raw[k], (const T*)(pc + (unsigned)max(od[k], 0)));
                 if (NOISE) { if (noise_on) { nod[k] = ndt[h0 + k]; raw_load(nz[k], (const bf16_t*)(pn + (unsigned)max(nod[k], 0))); } }
             }
             // keep every load of the batch ahead of the first use: a load whose only use sits under `h0 + k < nd` is
@@ -626,7 +637,7 @@ static inline int fill_gather(const vg_conv_desc* d, GatherIn& g, int CK, int BM
                 // 10-unit pitch of the 8x8x8 tile).  A 16-wide tile has each sub-tile in ONE row -- consecutive 16-byte units,
                 // conflict-free at any pitch -- for 8 % more halo (18x10x6 vs 10x10x10): charge the conflicting shapes 25 %.
                 if (w16 && g.planar && skew == 0 && tw < 16 && hwp_ == hw_ && d->istr == 1) vol += vol / 4;
-                if (best < 0 || vol < best || (vol == best && tw > TW)) { best = vol; TW = tw; TH = th; TD = td; }
+                if (best < 0 || vol < best || (vol == best && (tw > TW || (tw == TW && th > TH)))) { best = vol; TW = tw; TH = th; TD = td; }   // ties: wider, then taller (D is the walked axis)
             }
         }
     }
