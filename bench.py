@@ -165,6 +165,7 @@ def main():
         eng.train_step(rI, rS, sync=True)
         summ = ops.PROF.summary()
         byvar = ops.PROF.by_variant()
+        bylayer = ops.PROF.by_layer()
         ops.PROF = None
     if rank == 0 and summ is not None:
         tot_fl = sum(v['flops'] for v in summ.values())
@@ -211,6 +212,10 @@ def main():
             if args.dump_kernels:
                 with open(args.dump_kernels, 'w') as f:
                     json.dump(byvar, f, indent=1)
+            if os.environ.get('VG_DUMP_LAYERS'):           # development aid: where the family's time goes, layer by layer
+                with open(os.environ['VG_DUMP_LAYERS'], 'w') as f:
+                    for r in bylayer:
+                        f.write('%-11s %-34s %-44s n %3d  %8.3f ms  %7.1f TF/s\n' % (r['kind'], r['layer'], r['kernel'], r['launches'], r['ms'], r['tflops'] or 0))
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()

@@ -36,7 +36,9 @@ def main():
     S = args.size
     # (name, k, cin, cout, stride, pad, level, concat split)
     L = [('stem.cb 16->16', 3, 16, 16, 1, 'reflect', 0, None), ('dec0.cb1 48->16', 3, 48, 16, 1, 'reflect', 0, (32, 16)),
-         ('dec0.short 48->16 k1', 1, 48, 16, 1, 'same', 0, (32, 16)), ('enc1.cb1 16->32 s2', 3, 16, 32, 2, 'reflect', 0, None),
+         ('dec0.short 48->16 k1', 1, 48, 16, 1, 'same', 0, (32, 16)), ('dec1.short 96->32 k1', 1, 96, 32, 1, 'same', 1, (64, 32)),
+         ('p.short 16->16 k1 64^3', 1, 16, 16, 1, 'same', 1, None), ('p.short 16->16 k1 32^3', 1, 16, 16, 1, 'same', 2, None),
+         ('enc1.short 16->32 k1s2', 1, 16, 32, 2, 'same', 0, None), ('enc2.short 32->64 k1s2', 1, 32, 64, 2, 'same', 1, None), ('enc1.cb1 16->32 s2', 3, 16, 32, 2, 'reflect', 0, None),
          ('enc1.cb2 32->32', 3, 32, 32, 1, 'reflect', 1, None), ('dec1.cb1 96->32', 3, 96, 32, 1, 'reflect', 1, (64, 32)),
          ('enc2.cb2 64->64', 3, 64, 64, 1, 'reflect', 2, None), ('dec2.cb1 192->64', 3, 192, 64, 1, 'reflect', 2, (128, 64)),
          ('enc3.cb2 128->128', 3, 128, 128, 1, 'reflect', 3, None), ('dec3.cb1 384->128', 3, 384, 128, 1, 'reflect', 3, (256, 128)),
@@ -56,17 +58,20 @@ def main():
         N = 1
         scale = torch.rand(N, cin, device=dev) + 0.5
         shift = torch.randn(N, cin, device=dev) * 0.1
+        raw = 'short' in name                 # the shortcut convolutions read the block input as stored (no IN / activation)
+        if raw:
+            scale = shift = None
         if cat:
             low = torch.randn(N, dims[0] // 2, dims[1] // 2, dims[2] // 2, cat[0], device=dev).to(torch.bfloat16)
             skip = torch.randn(N, *dims, cat[1], device=dev).to(torch.bfloat16)
-            src = Src(low, (N,) + dims, cat[0], skip, cat[1], shift0=1, scale=scale, shift=shift, act=ops.ACT_RELU)
+            src = Src(low, (N,) + dims, cat[0], skip, cat[1], shift0=1, scale=scale, shift=shift, act=ops.ACT_NONE if raw else ops.ACT_RELU)
         else:
             x = torch.randn(N, *dims, cin, device=dev).to(torch.bfloat16)
             nz = None
             if name.startswith('D.'):
                 npad = 1 if pad == 'reflect' else 0
                 nz = (torch.randn(N, *[d_ + 2 * npad for d_ in dims], cin, device=dev) * 0.1).to(torch.bfloat16)
-            src = Src(x, (N,) + dims, cin, scale=scale, shift=shift, act=ops.ACT_LRELU if nz is not None else ops.ACT_RELU,
+            src = Src(x, (N,) + dims, cin, scale=scale, shift=shift, act=ops.ACT_LRELU if nz is not None else (ops.ACT_NONE if raw else ops.ACT_RELU),
                       noise=nz, noise_pad=1 if pad == 'reflect' else 0)
         out = torch.zeros(N, *lay.out_dims, cout, dtype=torch.bfloat16, device=dev)
         sums = torch.zeros(8, N, cout, 2, device=dev)
@@ -74,7 +79,7 @@ def main():
         dp = torch.zeros(N, *lay.buf_dims, cin, dtype=torch.bfloat16, device=dev)
         flops = 2.0 * N * math.prod(lay.out_dims) * cout * cin * k ** 3
         res = []
-        for kind, fn in (('fwd', lambda: lay.forward(src, out, sums=None if os.environ.get('NOSUMS') else sums)), ('dgrad', lambda: lay.dgrad(dy, N, dp, False)),
+        for kind, fn in (('fwd', lambda: lay.forward(src, out, sums=None if os.environ.get('NOSUMS') else sums)), ('dgrad', lambda: lay.dgrad(dy, N, dp, raw)),
                          ('wgrad', lambda: lay.wgrad(src, dy))):
             if args.only and kind != args.only:
                 res.append('        -')

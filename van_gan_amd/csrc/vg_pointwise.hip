@@ -203,6 +203,199 @@ __global__ __launch_bounds__(256) void pw_ctoc_kernel(const PW p, int Cin, int K
     }
 }
 
+// ---- Cin -> Cout, both multi-channel, plain source (the 1x1x1 shortcut convolutions of the residual blocks,
+// resunet_model.py:103-143: decoder level 0 reads the virtual upsample + concat 48 -> 16 at 128^3, the encoders 16 -> 32 with
+// stride 2, ...; and their data gradients Cout -> Cin accumulated into the block-input gradient).  A few dozen FLOP per byte:
+// HBM-bound.  The generic gather kernels stage a halo image through LDS for ONE tap and ran these at 1.1-1.6 TB/s.
+// Here there is no LDS on the data path at all: with the voxel as the N index of v_mfma_f32_16x16x32_bf16, lane (kg, r) supplies
+// B[k = 8kg..8kg+7][n = r] = 8 consecutive channels of voxel r -- exactly one 16-byte global load from the [voxel][channel]
+// layout -- the weights A[m = co][k] sit in registers for the whole kernel, and the result D[m = 4kg..4kg+3][n = r] is 4
+// consecutive output channels of voxel r; two sub-tiles are exchanged with v_permlane16_swap so that every lane stores 16
+// contiguous bytes.  A wave handles MS sub-tiles of 16 consecutive output voxels per iteration (all their loads in flight
+// together); InstanceNorm statistics of the stored values are carried in registers.
+struct PWG {
+    const bf16_t* x0; const bf16_t* x1; int c0, c1, Cin, sh;
+    const bf16_t* w; int Ktot, CK, kc_pad;
+    const float* bias; bf16_t* out; float* sums;
+    int N, ID, IH, IW, OD, OH, OW, istr;
+    int BD, BH, BW, ostr, od0, oh0, ow0;
+    int Cout; int SO;
+    unsigned long long* stamps;          // diagnostic (vg_set_stamp_buffer): s_memrealtime at wave start / end, else NULL
+};
+}
+extern unsigned long long* g_vg_stamps;
+namespace {
+typedef __attribute__((ext_vector_type(2))) float pw_f32x2;
+typedef __attribute__((ext_vector_type(2))) unsigned pw_u32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned pw_u32x4;
+
+template <int KS, int NB, bool GEO, bool ACC, bool STATS>
+__global__ __launch_bounds__(256) void pw_gemm_kernel(const PWG p) {
+    constexpr int MS = (KS * NB <= 2) ? 4 : 2;
+    __shared__ float stat[NB * 32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, kg = lane >> 4;
+    const int n = blockIdx.y;
+    if (p.stamps && lane == 0) p.stamps[((size_t)blockIdx.x * 4 + wave) * 8] = __builtin_amdgcn_s_memrealtime();
+    bf16x8 wA[NB][KS];
+    pw_f32x2 e_b[NB][2];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int co = nb * 16 + r;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int c = ks * 32 + kg * 8;
+            wA[nb][ks] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+            if (co < p.Cout && c < p.Cin) wA[nb][ks] = *(const bf16x8*)(p.w + (size_t)co * p.Ktot + (c / p.CK) * p.kc_pad + (c % p.CK));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int cb = nb * 16 + kg * 4 + i;
+            e_b[nb][i >> 1][i & 1] = (p.bias && cb < p.Cout) ? p.bias[cb] : 0.f;
+        }
+    }
+    if (p.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (lane == 0) p.stamps[((size_t)blockIdx.x * 4 + wave) * 8 + 1] = __builtin_amdgcn_s_memrealtime(); }
+    float s1[NB][4], s2[NB][4];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { s1[nb][i] = 0.f; s2[nb][i] = 0.f; }
+    if (STATS) { if (tid < NB * 32) stat[tid] = 0.f; __syncthreads(); }
+    const int OHW = p.OH * p.OW;
+    const int ID2 = p.ID >> p.sh, IH2 = p.IH >> p.sh, IW2 = p.IW >> p.sh;
+    const int nwt = (p.SO + MS * 16 - 1) / (MS * 16);
+    const int jodd = kg & 1, chof = (kg & ~1) * 4;
+    for (int wt = blockIdx.x * 4 + wave; wt < nwt; wt += gridDim.x * 4) {
+        bf16x8 xb[MS][KS];
+        bool vok[MS], oks[MS / 2];
+        size_t i0s[MS], i1s[MS], ovs[MS / 2];           // ovs / oks: the sub-tile this lane STORES of each pair (jp + jodd)
+#pragma unroll
+        for (int jp = 0; jp < MS; jp += 2) {
+            size_t ovp[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int i = jp + e;
+                const int v = wt * (MS * 16) + i * 16 + r;
+                vok[i] = v < p.SO;
+                const int vc = vok[i] ? v : p.SO - 1;
+                if (GEO) {
+                    const int od = vc / OHW, rem = vc - od * OHW, oh = rem / p.OW, ow = rem - oh * p.OW;
+                    const int id = od * p.istr, ih = oh * p.istr, iw = ow * p.istr;
+                    i0s[i] = (((size_t)n * ID2 + (id >> p.sh)) * IH2 + (ih >> p.sh)) * IW2 + (iw >> p.sh);
+                    i1s[i] = (((size_t)n * p.ID + id) * p.IH + ih) * p.IW + iw;
+                    ovp[e] = (((size_t)n * p.BD + od * p.ostr + p.od0) * p.BH + oh * p.ostr + p.oh0) * p.BW + ow * p.ostr + p.ow0;
+                } else {
+                    i0s[i] = i1s[i] = ovp[e] = (size_t)n * p.SO + vc;
+                }
+            }
+            ovs[jp >> 1] = (jodd ? ovp[1] : ovp[0]) * p.Cout + chof;
+            oks[jp >> 1] = jodd ? vok[jp + 1] : vok[jp];
+        }
+        // accumulate mode: the old values are fetched together with the operands (out-of-range voxels were clamped to the last
+        // one: a valid address)
+        Raw8<bf16_t> oldv[ACC ? MS / 2 : 1][ACC ? NB : 1];
+        if (ACC) {
+#pragma unroll
+            for (int jh = 0; jh < MS / 2; ++jh)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) raw_load(oldv[jh][nb], p.out + ovs[jh] + (nb * 16 < p.Cout ? nb * 16 : 0));
+            if (p.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (lane == 0) p.stamps[((size_t)blockIdx.x * 4 + wave) * 8 + 3] = __builtin_amdgcn_s_memrealtime(); }
+        }
+#pragma unroll
+        for (int i = 0; i < MS; ++i)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                // lanes beyond Cin (K padding of the last step) re-read a valid channel group of their own voxel and are zeroed: a
+                // shared dummy address would send half of every wave of the launch to ONE cache line
+                const int c = ks * 32 + kg * 8;
+                const bool cok = c < p.Cin;
+                const int ce = cok ? c : c % p.Cin;
+                const bf16_t* q = ce < p.c0 ? p.x0 + i0s[i] * p.c0 + ce : p.x1 + i1s[i] * p.c1 + (ce - p.c0);
+                Raw8<bf16_t> t;
+                raw_load(t, q);
+                raw_mask(t, cok);
+                xb[i][ks] = t.v;
+            }
+        if (p.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (lane == 0) p.stamps[((size_t)blockIdx.x * 4 + wave) * 8 + 2] = __builtin_amdgcn_s_memrealtime(); }
+        f32x4 acc[MS][NB];
+#pragma unroll
+        for (int i = 0; i < MS; ++i)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                acc[i][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) acc[i][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wA[nb][ks], xb[i][ks], acc[i][nb], 0, 0, 0);
+            }
+        // ---- epilogue: sub-tiles (jp, jp+1) exchanged across the 16-lane rows: even rows end with sub-tile jp channels
+        // [4kg..4kg+7], odd rows with sub-tile jp+1 channels [4(kg-1)..4kg+3]
+#pragma unroll
+        for (int jp = 0; jp < MS; jp += 2) {
+            const bool ok = oks[jp >> 1];
+            const size_t ob = ovs[jp >> 1];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                if (nb * 16 >= p.Cout) continue;
+                bf16_t* optr = p.out + ob + nb * 16;
+                pw_u32x4 outv;
+                if (ACC) {
+                    // single rounding of (old + new): the exchange is done on the f32 values
+                    float o[8];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const pw_u32x2 x = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[jp][nb][i] + e_b[nb][i >> 1][i & 1]),
+                                                                            __float_as_uint(acc[jp + 1][nb][i] + e_b[nb][i >> 1][i & 1]), false, false);
+                        o[i] = __uint_as_float(x[0]); o[4 + i] = __uint_as_float(x[1]);
+                    }
+                    // the bias of the received half belongs to the neighbouring row's channels: e_b was added before the swap
+                    float q[8]; raw_unpack(oldv[ACC ? jp >> 1 : 0][ACC ? nb : 0], q);
+                    bf16x8 pk;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) pk[i] = (short)f2bf(o[i] + q[i]);
+                    outv = __builtin_bit_cast(pw_u32x4, pk);
+                } else {
+                    bf16x4 pk[2];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        pw_f32x2 v0 = {acc[jp + e][nb][0], acc[jp + e][nb][1]}, v1 = {acc[jp + e][nb][2], acc[jp + e][nb][3]};
+                        v0 += e_b[nb][0]; v1 += e_b[nb][1];
+                        pk[e] = (bf16x4){(short)f2bf(v0[0]), (short)f2bf(v0[1]), (short)f2bf(v1[0]), (short)f2bf(v1[1])};
+                        if (STATS) {
+                            const bool okv = vok[jp + e];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const float qv = okv ? bf2f((bf16_t)pk[e][i]) : 0.f;
+                                s1[nb][i] += qv; s2[nb][i] += qv * qv;
+                            }
+                        }
+                    }
+                    const pw_u32x2 wa = __builtin_bit_cast(pw_u32x2, pk[0]), wb = __builtin_bit_cast(pw_u32x2, pk[1]);
+                    const pw_u32x2 x0 = __builtin_amdgcn_permlane16_swap(wa[0], wb[0], false, false);
+                    const pw_u32x2 x1 = __builtin_amdgcn_permlane16_swap(wa[1], wb[1], false, false);
+                    outv = (pw_u32x4){x0[0], x1[0], x0[1], x1[1]};
+                }
+                if (ok) *(pw_u32x4*)optr = outv;
+            }
+        }
+    }
+    if (p.stamps && lane == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); p.stamps[((size_t)blockIdx.x * 4 + wave) * 8 + 7] = __builtin_amdgcn_s_memrealtime(); }
+    if (STATS && p.sums) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float a = s1[nb][i], b = s2[nb][i];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+                if (r == 0) { atomicAdd(&stat[(nb * 16 + 4 * kg + i) * 2], a); atomicAdd(&stat[(nb * 16 + 4 * kg + i) * 2 + 1], b); }
+            }
+        __syncthreads();
+        if (tid < NB * 32) {
+            const int co = tid >> 1;
+            const int stripe = blockIdx.x & (VG_STRIPES - 1);
+            if (co < p.Cout) atomicAdd(&p.sums[(((size_t)stripe * gridDim.y + n) * p.Cout + co) * 2 + (tid & 1)], stat[tid]);
+        }
+    }
+}
+
 // ---- weight gradients: dW[c] = sum_v P[v,(c)] * dY[v,(c)], db = sum dY; one side single-channel ------------------------
 // MULTI_X: true = C -> 1 layer (x has C channels, dY one), false = 1 -> C layer (x one channel, dY C channels)
 template <typename T, bool MULTI_X>
@@ -482,6 +675,58 @@ int pw_blocks(int64_t work_items, int N) {
     return b < 1 ? 1 : (int)b;
 }
 
+template <bool GEO, bool ACC, bool STATS>
+bool pwg_launch(int KS, int NB, dim3 grid, hipStream_t s, const PWG& p) {
+#define PWG_CASE(ks, nb) if (KS == ks && NB == nb) { hipLaunchKernelGGL((pw_gemm_kernel<ks, nb, GEO, ACC, STATS>), grid, dim3(256), 0, s, p); return true; }
+    PWG_CASE(1, 1) PWG_CASE(1, 2) PWG_CASE(1, 3) PWG_CASE(1, 4) PWG_CASE(1, 6) PWG_CASE(2, 1) PWG_CASE(2, 2) PWG_CASE(3, 2)
+    PWG_CASE(4, 4) PWG_CASE(6, 4) PWG_CASE(2, 8)
+#undef PWG_CASE
+    return false;
+}
+bool pwg_case_ok(int KS, int NB) {
+    static const int tab[][2] = {{1, 1}, {1, 2}, {1, 3}, {1, 4}, {1, 6}, {2, 1}, {2, 2}, {3, 2}, {4, 4}, {6, 4}, {2, 8}};
+    for (auto& t : tab) if (t[0] == KS && t[1] == NB) return true;
+    return false;
+}
+// the multi-channel 1x1x1 case: VG_OK when launched, 1 when the shape is not served
+int pw_gemm_conv(const vg_conv_desc* d, hipStream_t s) {
+    if (!pw_enabled() || !vg_tune("PW_GEMM", 1)) return 1;
+    if (d->ntaps != 1 || d->tap_d[0] || d->tap_h[0] || d->tap_w[0] || d->noise || d->wpack || d->nclass > 1) return 1;
+    if (d->f32 || d->src_f32 || d->out_f32 || d->in_scale || d->act != VG_ACT_NONE || d->res || d->tanh_out) return 1;
+    const int Cin = d->c_src0 + d->c_src1;
+    if (Cin < 8 || (Cin % 8) || (d->c_src1 && (d->c_src0 % 8)) || d->Cout < 16 || (d->Cout % 16) || (d->CK % 8)) return 1;
+    if (d->c_src1 && !d->src1) return 1;
+    if (d->src0_shift && ((d->D | d->H | d->W) & 1)) return 1;
+    if (d->istr < 1 || d->ostr < 1 || (d->OD - 1) * d->istr >= d->D || (d->OH - 1) * d->istr >= d->H || (d->OW - 1) * d->istr >= d->W) return 1;
+    if (d->accumulate && d->out_sums) return 1;
+    const int64_t SO = (int64_t)d->OD * d->OH * d->OW;
+    if (SO < 1 || SO > (1 << 30)) return 1;
+    const int KS = (Cin + 31) / 32, NB = d->Cout / 16;
+    if (!pwg_case_ok(KS, NB)) return 1;
+    const bool geo = d->src0_shift || d->istr != 1 || d->ostr != 1 || d->ooff_d || d->ooff_h || d->ooff_w || d->BD != d->OD || d->BH != d->OH
+                     || d->BW != d->OW || d->OD != d->D || d->OH != d->H || d->OW != d->W;
+    PWG p = {};
+    p.x0 = (const bf16_t*)d->src0; p.x1 = (const bf16_t*)(d->c_src1 ? d->src1 : d->src0); p.c0 = d->c_src0; p.c1 = d->c_src1 ? d->c_src1 : 1;
+    p.Cin = Cin; p.sh = d->src0_shift ? 1 : 0;
+    p.w = (const bf16_t*)d->wpacked; p.CK = d->CK; p.kc_pad = ((d->CK + 31) / 32) * 32; p.Ktot = ((Cin + d->CK - 1) / d->CK) * p.kc_pad;
+    p.bias = d->bias; p.out = (bf16_t*)d->out; p.sums = d->out_sums;
+    p.N = d->N; p.ID = d->D; p.IH = d->H; p.IW = d->W; p.OD = d->OD; p.OH = d->OH; p.OW = d->OW; p.istr = d->istr;
+    p.BD = d->BD; p.BH = d->BH; p.BW = d->BW; p.ostr = d->ostr; p.od0 = d->ooff_d; p.oh0 = d->ooff_h; p.ow0 = d->ooff_w;
+    p.Cout = d->Cout; p.SO = (int)SO; p.stamps = g_vg_stamps;
+    const int MS = (KS * NB <= 2) ? 4 : 2;
+    const int64_t nwt = (SO + MS * 16 - 1) / (MS * 16);
+    int64_t b = (nwt + 3) / 4;
+    const int capt = vg_tune("PW_GEMM_CAP", 2047);
+    const int64_t cap = (capt / d->N) > 0 ? (capt / d->N) : 1;
+    if (b > cap) b = cap;
+    const dim3 grid((int)b, d->N);
+    if (vg_dry("pw_gemm<%d,%d,g%d,a%d>", KS, NB, (geo || !d->accumulate) ? 1 : 0, d->accumulate ? 1 : 0)) return VG_OK;
+    bool ok;
+    if (!d->accumulate) ok = pwg_launch<true, false, true>(KS, NB, grid, s, p);
+    else ok = geo ? pwg_launch<true, true, false>(KS, NB, grid, s, p) : pwg_launch<false, true, false>(KS, NB, grid, s, p);
+    return ok ? vg_check_launch() : 1;
+}
+
 }  // namespace
 
 // returns VG_OK when the launch was done here, 1 when the shape is not one of the pointwise cases (caller continues), < 0 on error
@@ -507,6 +752,7 @@ int vg_pointwise_conv(const vg_conv_desc* d, hipStream_t s) {
             return vg_check_launch();
         }
     }
+    { const int grc = pw_gemm_conv(d, s); if (grc <= 0) return grc; }
     if (!pw_shape_ok(d) || d->res) return 1;
     if (d->ostr != 1 || d->ooff_d || d->ooff_h || d->ooff_w || d->BD != d->OD || d->BH != d->OH || d->BW != d->OW) return 1;
     const int Cin = d->c_src0;

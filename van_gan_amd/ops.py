@@ -118,13 +118,14 @@ class KernelProfile:
     def __init__(self):
         self.rows = {}          # kind -> [launches, flops, [(ev0, ev1), ...], bytes]
         self.vrows = {}         # (kind, kernel variant) -> the same: the roofline of every kernel template by itself
+        self.lrows = {}         # (kind, layer name, kernel variant) -> the same: where the step's time goes, layer by layer
 
     def begin(self):
         e = torch.cuda.Event(enable_timing=True)
         e.record()
         return e
 
-    def end(self, kind: str, flops: float, e0, nbytes: float = 0.0, variant: Optional[str] = None):
+    def end(self, kind: str, flops: float, e0, nbytes: float = 0.0, variant: Optional[str] = None, layer: Optional[str] = None):
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
         r = self.rows.setdefault(kind, [0, 0.0, [], 0.0])
@@ -132,6 +133,19 @@ class KernelProfile:
         if variant:
             v = self.vrows.setdefault((kind, variant.split('|')[0]), [0, 0.0, [], 0.0])
             v[0] += 1; v[1] += flops; v[2].append((e0, e1)); v[3] += nbytes
+            if layer:
+                v = self.lrows.setdefault((kind, layer, variant.split('|')[0]), [0, 0.0, [], 0.0])
+                v[0] += 1; v[1] += flops; v[2].append((e0, e1)); v[3] += nbytes
+
+    def by_layer(self):
+        """[{kind, layer, kernel, launches, ms, gflop, tflops}] sorted by time."""
+        torch.cuda.synchronize()
+        rows = []
+        for (kind, layer, var), (n, fl, evs, nb) in self.lrows.items():
+            ms = sum(a.elapsed_time(b) for a, b in evs)
+            rows.append(dict(kind=kind, layer=layer, kernel=var, launches=n, ms=ms, gflop=fl / 1e9,
+                             tflops=fl / (ms * 1e-3) / 1e12 if ms > 0 else None, algorithmic_bytes=nb))
+        return sorted(rows, key=lambda r: -r['ms'])
 
     def summary(self):
         torch.cuda.synchronize()
@@ -477,7 +491,7 @@ class ConvLayer:
         if e0 is not None:
             esz = 4 if self.f32 else 2
             PROF.end('conv_fwd', 2.0 * src.N * math.prod(self.out_dims) * self.cout * self.cin * self.k ** 3, e0,
-                     src.N * esz * (math.prod(self.in_dims) * self.cin + math.prod(self.out_dims) * self.cout), conv_variant(d))
+                     src.N * esz * (math.prod(self.in_dims) * self.cin + math.prod(self.out_dims) * self.cout), conv_variant(d), self.name)
 
     def wgrad(self, src: Src, dy: torch.Tensor):
         if SIDE is not None and PROF is None and DRY is None:   # the per-launch timing pass serialises (attributable durations)
@@ -508,7 +522,7 @@ class ConvLayer:
             vb = C.create_string_buffer(512)
             _lib.lib.vg_conv3d_wgrad_variant(C.byref(d), int(dy.dtype == torch.float32), self.f_idx_host, self.f_T, sc.numel() * 4, vb, 512)
             PROF.end('conv_wgrad', 2.0 * src.N * math.prod(self.out_dims) * self.cout * self.cin * self.k ** 3, e0,
-                     src.N * esz * (math.prod(self.in_dims) * self.cin + math.prod(self.out_dims) * self.cout), vb.value.decode())
+                     src.N * esz * (math.prod(self.in_dims) * self.cin + math.prod(self.out_dims) * self.cout), vb.value.decode(), self.name)
 
     def _fused_desc(self, dy, N, out, accumulate, probe=False):
         """Descriptor of the fused all-classes data gradient (probe=True: dummy pointers, returns None if infeasible)."""
@@ -569,7 +583,7 @@ class ConvLayer:
             if e0 is not None:
                 PROF.end('conv_dgrad', sum(2.0 * N * math.prod(c['iters']) * self.cin * self.cout * len(c['taps'])
                                            for c in self.d_classes), e0,
-                         N * 2 * (math.prod(self.out_dims) * self.cout + math.prod(self.buf_dims) * self.cin), conv_variant(d))
+                         N * 2 * (math.prod(self.out_dims) * self.cout + math.prod(self.buf_dims) * self.cin), conv_variant(d), self.name)
             return
         for c in self.d_classes:
             t = c.get('tmpl')
@@ -597,7 +611,7 @@ class ConvLayer:
             if e0 is not None:      # algorithmic FLOPs of this parity class: its taps only
                 PROF.end('conv_dgrad', 2.0 * N * math.prod(c['iters']) * self.cin * self.cout * len(c['taps']), e0,
                          N * (4 if self.f32 else 2) * (math.prod(self.out_dims) * self.cout * len(c['taps']) / self.k ** 3
-                                                       + math.prod(c['iters']) * self.cin), conv_variant(d))
+                                                       + math.prod(c['iters']) * self.cin), conv_variant(d), self.name)
 
 
 class PackTable:
