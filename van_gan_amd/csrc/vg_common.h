@@ -96,7 +96,10 @@ static inline int vg_check_launch() {
 // vg_pointwise.hip: 1x1x1 convolutions with one channel on one side (HBM-bound VALU kernels).  Return VG_OK when the call
 // was served, 1 when the shape is not one of theirs (the caller continues on the MFMA path), < 0 on error.
 int vg_pointwise_conv(const vg_conv_desc* d, hipStream_t s);
-int vg_pointwise_wgrad(const vg_conv_desc* d, const void* dy, int dy_f32, int T_total, float* dw, float* db, hipStream_t s);
+int vg_pointwise_wgrad(const vg_conv_desc* d, const void* dy, int dy_f32, int T_total, float* dw, float* db, float* scratch,
+                       int64_t scratch_bytes, hipStream_t s);
+// vg_wgrad.hip: dw[i] += sum_b part[b][i] in a fixed order (partial slabs written by weight-gradient workgroups)
+void vg_launch_reduce_partials(const float* part, int nb, int n, float* dw, hipStream_t s);
 static inline int ilog2_exact(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 static inline int pow2_ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

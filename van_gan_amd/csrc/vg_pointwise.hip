@@ -396,6 +396,119 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const PWG p) {
     }
 }
 
+// ---- weight gradient of the multi-channel 1x1x1 shortcut convolutions: dW[ci][co] = sum_v x[v][ci] * dY[v][co], db = sum dY.
+// 2 * Cin * Cout FLOP against 2 * (Cin + Cout) bytes per voxel: HBM-bound, and with K = voxels the MFMA operands would need
+// transposed (2-byte strided) global reads.  VALU instead: thread role = (8 input channels, 16 output channels) keeps its
+// 8 x 16 block of dW in registers (packed f32 FMAs), reads 16 bytes of x and 32 bytes of dY per voxel, walks the voxels with an
+// incrementally updated (d, h, w) (virtual upsample / concat / stride of the source), and the block's roles are reduced
+// through LDS into one partial slab per workgroup (summed in a fixed order by reduce_partials_kernel).
+struct PWW {
+    const bf16_t* x0; const bf16_t* x1; int c0, c1, Cin, sh;
+    const bf16_t* dy; int Cout;
+    int N, ID, IH, IW, OD, OH, OW, istr, SO;
+    int gin, roles, rp, vpb;             // rp = roles rounded up to a power of two (threads role >= roles idle), vpb = 256 / rp
+    float* dw; float* db; float* part; int dw_elems;
+};
+
+__global__ __launch_bounds__(256) void pw_wgrad_cc_kernel(const PWW p) {
+    __shared__ float red[4 * 64 * 16];
+    const int tid = threadIdx.x, n = blockIdx.y;
+    const int role = tid & (p.rp - 1), vl = tid / p.rp;
+    const bool live = role < p.roles;
+    const int rl = live ? role : 0;
+    const int cg = rl % p.gin, cob = rl / p.gin, c = cg * 8;
+    const bool from0 = c < p.c0;
+    const float bmask = cg == 0 ? 1.f : 0.f;
+    pw_f32x2 acc[8][8], bs[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        bs[i] = (pw_f32x2){0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = (pw_f32x2){0.f, 0.f};
+    }
+    const int ID2 = p.ID >> p.sh, IH2 = p.IH >> p.sh, IW2 = p.IW >> p.sh;
+    const int step = gridDim.x * p.vpb;
+    // (od, oh, ow) of this thread's first voxel and of the grid stride: advanced with carries, no per-voxel divisions
+    int v = blockIdx.x * p.vpb + vl;
+    const int OHW = p.OH * p.OW;
+    int od = v / OHW, oh = (v - od * OHW) / p.OW, ow = v - od * OHW - oh * p.OW;
+    const int sd = step / OHW, sh_ = (step - sd * OHW) / p.OW, sw = step - sd * OHW - sh_ * p.OW;
+    const bf16_t* xb = from0 ? p.x0 + c : p.x1 + (c - p.c0);
+    const int cs = from0 ? p.c0 : p.c1, shx = from0 ? p.sh : 0;
+    const int XD = from0 ? ID2 : p.ID, XH = from0 ? IH2 : p.IH, XW = from0 ? IW2 : p.IW;
+    const bf16_t* yb = p.dy + (size_t)n * p.SO * p.Cout + cob * 16;
+    if (live)
+    for (; v < p.SO; v += 2 * step) {
+        Raw8<bf16_t> xr[2], yr[2][2]; bool okv[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int vk = v + k * step;
+            okv[k] = vk < p.SO;
+            const int dq = okv[k] ? od : 0, hq = okv[k] ? oh : 0, wq = okv[k] ? ow : 0, vq = okv[k] ? vk : 0;
+            const size_t xi = (((size_t)n * XD + ((dq * p.istr) >> shx)) * XH + ((hq * p.istr) >> shx)) * XW + ((wq * p.istr) >> shx);
+            raw_load(xr[k], xb + xi * cs);
+            raw_load(yr[k][0], yb + (size_t)vq * p.Cout);
+            raw_load(yr[k][1], yb + (size_t)vq * p.Cout + 8);
+            ow += sw; if (ow >= p.OW) { ow -= p.OW; ++oh; }
+            oh += sh_; if (oh >= p.OH) { oh -= p.OH; ++od; }
+            od += sd;
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            float x[8], y[16];
+            raw_unpack(xr[k], x); raw_unpack(yr[k][0], y); raw_unpack(yr[k][1], y + 8);
+            pw_f32x2 y2[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) y2[j] = okv[k] ? (pw_f32x2){y[2 * j], y[2 * j + 1]} : (pw_f32x2){0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const pw_f32x2 xi2 = {x[i], x[i]};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[i][j] += xi2 * y2[j];
+            }
+            const pw_f32x2 bm = {bmask, bmask};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bs[j] += y2[j] * bm;
+        }
+    }
+    // ---- reduction.  Roles are dealt out modulo rp (a power of two): the lanes of a wave that share a role are rp apart and
+    // are summed with xor shuffles; one lane per (wave, role) then holds 144 values (8 rows of 16 + 16 bias sums), which go
+    // through LDS in 9 chunks of 16 and are added over the 4 waves into the workgroup's partial slab ----
+    for (int off = 32; off >= p.rp; off >>= 1) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            bs[j][0] += __shfl_xor(bs[j][0], off); bs[j][1] += __shfl_xor(bs[j][1], off);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { acc[i][j][0] += __shfl_xor(acc[i][j][0], off); acc[i][j][1] += __shfl_xor(acc[i][j][1], off); }
+        }
+    }
+    float* slab = p.part ? p.part + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * p.dw_elems : nullptr;
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int ch = 0; ch < 9; ++ch) {
+        __syncthreads();
+        if (lane < p.rp) {
+            float* dst = red + (size_t)(wave * p.rp + lane) * 16;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const pw_f32x2 val = ch < 8 ? acc[ch < 8 ? ch : 0][j] : bs[j];
+                dst[2 * j] = val[0]; dst[2 * j + 1] = val[1];
+            }
+        }
+        __syncthreads();
+        for (int o = tid; o < p.rp * 16; o += 256) {
+            const int ro = o >> 4, i = o & 15;
+            if (ro >= p.roles) continue;
+            const float sacc = red[o] + red[p.rp * 16 + o] + red[2 * p.rp * 16 + o] + red[3 * p.rp * 16 + o];
+            const int rcg = ro % p.gin, rcob = ro / p.gin, co = rcob * 16 + i;
+            if (ch < 8) {
+                const size_t idx = (size_t)(rcg * 8 + ch) * p.Cout + co;
+                if (slab) slab[idx] = sacc; else atomicAdd(&p.dw[idx], sacc);
+            } else if (rcg == 0 && p.db) atomicAdd(&p.db[co], sacc);
+        }
+    }
+}
+
 // ---- weight gradients: dW[c] = sum_v P[v,(c)] * dY[v,(c)], db = sum dY; one side single-channel ------------------------
 // MULTI_X: true = C -> 1 layer (x has C channels, dY one), false = 1 -> C layer (x one channel, dY C channels)
 template <typename T, bool MULTI_X>
@@ -727,6 +840,42 @@ int pw_gemm_conv(const vg_conv_desc* d, hipStream_t s) {
     return ok ? vg_check_launch() : 1;
 }
 
+int pw_wgrad_cc(const vg_conv_desc* d, const void* dy, int dy_f32, int T_total, float* dw, float* db, float* scratch,
+                int64_t scratch_bytes, hipStream_t s) {
+    if (!pw_enabled() || !vg_tune("PW_WGRAD_CC", 1)) return 1;
+    if (T_total != 1 || d->ntaps != 1 || d->tap_d[0] || d->tap_h[0] || d->tap_w[0] || d->noise || d->wpack || d->nclass > 1) return 1;
+    if (d->f32 || d->src_f32 || dy_f32 || d->in_scale || d->act != VG_ACT_NONE) return 1;
+    const int Cin = d->c_src0 + d->c_src1;
+    if (Cin < 8 || (Cin % 8) || (d->c_src1 && (d->c_src0 % 8)) || d->Cout < 16 || (d->Cout % 16)) return 1;
+    if (d->c_src1 && !d->src1) return 1;
+    if (d->src0_shift && ((d->D | d->H | d->W) & 1)) return 1;
+    if (d->istr < 1 || (d->OD - 1) * d->istr >= d->D || (d->OH - 1) * d->istr >= d->H || (d->OW - 1) * d->istr >= d->W) return 1;
+    const int64_t SO = (int64_t)d->OD * d->OH * d->OW;
+    if (SO < 1 || SO > (1 << 30)) return 1;
+    PWW p = {};
+    p.gin = Cin / 8; p.roles = p.gin * (d->Cout / 16);
+    // measured against the MFMA weight-gradient kernel (kernel + slab reduction, us): 6 roles (48 -> 16 at 128^3) 123 vs 164,
+    // 4 roles (16 -> 32 s2) 30 vs 41, 16 roles (32 -> 64 s2) 23 vs 29, but 24 roles (96 -> 32 at 64^3) 71 vs 55: the packed-f32
+    // FMAs (150 instructions per voxel and role, 4 cycles each on a 16-lane SIMD) become the bound as the channel product grows
+    if (p.roles > vg_tune("PW_WGRAD_ROLES", 16)) return 1;
+    p.rp = pow2_ceil(p.roles); p.vpb = 256 / p.rp;
+    p.x0 = (const bf16_t*)d->src0; p.x1 = (const bf16_t*)(d->c_src1 ? d->src1 : d->src0); p.c0 = d->c_src0; p.c1 = d->c_src1 ? d->c_src1 : 1;
+    p.Cin = Cin; p.sh = d->src0_shift ? 1 : 0; p.dy = (const bf16_t*)dy; p.Cout = d->Cout;
+    p.N = d->N; p.ID = d->D; p.IH = d->H; p.IW = d->W; p.OD = d->OD; p.OH = d->OH; p.OW = d->OW; p.istr = d->istr; p.SO = (int)SO;
+    p.dw = dw; p.db = db; p.dw_elems = Cin * d->Cout;
+    int64_t b = (SO + (int64_t)p.vpb * 8 - 1) / ((int64_t)p.vpb * 8);
+    const int capt = vg_tune("PW_WGRAD_CAP", 511);
+    const int64_t cap = (capt / d->N) > 0 ? (capt / d->N) : 1;
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    const int nslab = (int)b * d->N;
+    p.part = (nslab > 4 && scratch && (int64_t)nslab * p.dw_elems * 4 <= scratch_bytes) ? scratch : nullptr;
+    if (vg_dry("pw_wgrad_cc<r%d>|part%d", p.roles, p.part ? 1 : 0)) return VG_OK;
+    hipLaunchKernelGGL(pw_wgrad_cc_kernel, dim3((int)b, d->N), dim3(256), 0, s, p);
+    if (p.part) vg_launch_reduce_partials(p.part, nslab, p.dw_elems, dw, s);
+    return vg_check_launch();
+}
+
 }  // namespace
 
 // returns VG_OK when the launch was done here, 1 when the shape is not one of the pointwise cases (caller continues), < 0 on error
@@ -806,7 +955,8 @@ int vg_pointwise_conv(const vg_conv_desc* d, hipStream_t s) {
     return 1;
 }
 
-int vg_pointwise_wgrad(const vg_conv_desc* d, const void* dy, int dy_f32, int T_total, float* dw, float* db, hipStream_t s) {
+int vg_pointwise_wgrad(const vg_conv_desc* d, const void* dy, int dy_f32, int T_total, float* dw, float* db, float* scratch,
+                       int64_t scratch_bytes, hipStream_t s) {
     if (pw_enabled() && T_total == 9 && !(dy_f32 && !d->f32)) {
         C1K3 c;
         if (c1k3_fill(d, c)) {
@@ -828,6 +978,7 @@ int vg_pointwise_wgrad(const vg_conv_desc* d, const void* dy, int dy_f32, int T_
             return vg_check_launch();
         }
     }
+    { const int wrc = pw_wgrad_cc(d, dy, dy_f32, T_total, dw, db, scratch, scratch_bytes, s); if (wrc <= 0) return wrc; }
     if (!pw_shape_ok(d) || T_total != 1) return 1;
     const int Cin = d->c_src0;
     PW p = {};

@@ -318,6 +318,10 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* part,
     if (w == 0 && i < n) atomicAdd(&dw[i], sm[0][lane] + sm[1][lane] + sm[2][lane] + sm[3][lane]);
 }
 
+void vg_launch_reduce_partials(const float* part, int nb, int n, float* dw, hipStream_t s) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((n + 63) / 64), dim3(256), 0, s, part, nb, n, dw);
+}
+
 template <typename T, int RMAX, int Q, bool NOISE>
 static void launch_wgrad2(const GatherIn& g, const WgradK& k, dim3 grid, int lds, hipStream_t s) {
     static bool attr_set = false;
@@ -340,7 +344,7 @@ extern "C" int vg_conv3d_wgrad(const vg_conv_desc* d, const void* dy, int dy_f32
     if (d->Cout < 1 || (d->Cout != 1 && (d->Cout % 8))) return VG_EINVAL;
     if (dy_f32 && d->Cout != 1 && !d->f32) return VG_EINVAL;
     if (d->src0 && tap_idx_host[0] == 0) {
-        const int prc = vg_pointwise_wgrad(d, dy, dy_f32, T_total, dw, db, (hipStream_t)stream);
+        const int prc = vg_pointwise_wgrad(d, dy, dy_f32, T_total, dw, db, scratch, scratch_bytes, (hipStream_t)stream);
         if (prc <= 0) return prc;
     }
     const int Cin = d->c_src0 + d->c_src1;
