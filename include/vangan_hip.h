@@ -203,6 +203,8 @@ typedef struct {
 } vg_actnorm_bwd_desc;
 int vg_actnorm_bwd_stats(const vg_actnorm_bwd_desc* d, vg_stream_t stream);
 int vg_actnorm_bwd_apply(const vg_actnorm_bwd_desc* d, vg_stream_t stream);
+/* both passes in one call (statistics only when d->norm) */
+int vg_actnorm_bwd(const vg_actnorm_bwd_desc* d, vg_stream_t stream);
 /* dgamma[c] += sum_{stripes,n} red[.][n][c][1], dbeta[c] += sum red[.][n][c][0] */
 int vg_in_param_grads(const float* red, int N, int C, float* dgamma, float* dbeta, vg_stream_t stream);
 

@@ -73,6 +73,7 @@ _SIGS = {
                         c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], c_int),
     'vg_actnorm_bwd_stats': ([C.POINTER(ActNormBwdDesc), c_void_p], c_int),
     'vg_actnorm_bwd_apply': ([C.POINTER(ActNormBwdDesc), c_void_p], c_int),
+    'vg_actnorm_bwd': ([C.POINTER(ActNormBwdDesc), c_void_p], c_int),
     'vg_in_param_grads': ([c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p], c_int),
     'vg_concat_bwd': ([c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p], c_int),
     'vg_tanh_bwd': ([c_void_p, c_void_p, c_void_p, c_i64, c_void_p], c_int),

@@ -97,10 +97,8 @@ template <typename T> __device__ __forceinline__ void rawv_unpack(const RawV<T, 
 // kernels latency-bound at ~1 TB/s.  (d, h, w) advance incrementally (no per-voxel division).  The transpose of the
 // reflection pad only adds terms on the two planes next to each face: a rare divergent tail after the main loads.
 template <typename T, int VEC, int UB, typename F>
-__device__ __forceinline__ void anb_walk(const ANB& p, int n, int c, int vl, const ChanK<VEC>& ck, F&& consume) {
+__device__ __forceinline__ void anb_walk_from(const ANB& p, int n, int c, int v, const int stride, const ChanK<VEC>& ck, F&& consume) {
     const int S = p.D * p.H * p.W;
-    const int stride = gridDim.x * p.vpb;
-    int v = blockIdx.x * p.vpb + vl;
     if (v >= S) return;
     int w = v % p.W, t0 = v / p.W; int h = t0 % p.H, d = t0 / p.H;
     const int sw = stride % p.W, t1 = stride / p.W; const int sh_ = t1 % p.H, sd = t1 / p.H;
@@ -211,6 +209,11 @@ __device__ __forceinline__ void anb_walk(const ANB& p, int n, int c, int vl, con
             consume(vv[k], dn, xh);
         }
     }
+}
+
+template <typename T, int VEC, int UB, typename F>
+__device__ __forceinline__ void anb_walk(const ANB& p, int n, int c, int vl, const ChanK<VEC>& ck, F&& consume) {
+    anb_walk_from<T, VEC, UB>(p, n, c, (int)(blockIdx.x * p.vpb + vl), (int)(gridDim.x * p.vpb), ck, consume);
 }
 
 template <typename T, int VEC>
@@ -413,6 +416,14 @@ extern "C" int vg_actnorm_bwd_apply(const vg_actnorm_bwd_desc* d, vg_stream_t st
         else hipLaunchKernelGGL((actnorm_apply_kernel<bf16_t, 8>), anb_grid(p), dim3(256), 0, (hipStream_t)stream, p);
     }
     return vg_check_launch();
+}
+
+// statistics (when d->norm) + apply in one call.  (A single-launch form for small grids -- one workgroup per (sample, 8-channel
+// group) plane, no atomics or ticket -- was measured and dropped: at 16^3 x 128 it took 50 us against 23 us for the two launches,
+// because only C/8 = 16 workgroups carry the whole walk incl. its reflect-pad tails; at 8^3 x 256 and 16^3 x 512 it tied.)
+extern "C" int vg_actnorm_bwd(const vg_actnorm_bwd_desc* d, vg_stream_t stream) {
+    if (d && d->norm) { const int rc = vg_actnorm_bwd_stats(d, stream); if (rc != VG_OK) return rc; }
+    return vg_actnorm_bwd_apply(d, stream);
 }
 
 __global__ void in_param_grads_kernel(const float* red, int N, int C, float* dgamma, float* dbeta) {

@@ -671,10 +671,7 @@ def actnorm_bwd(g, g_padded, x, dims, C_, dx, *, scale=None, shift=None, mult=No
     d.dgamma, d.dbeta = _p(dgamma), _p(dbeta)      # parameter gradients come out of the statistics pass
     nred = STRIPES * dims[0] * C_ * 2
     d.ticket = (red.data_ptr() + 4 * nred) if (red is not None and red.dim() == 1 and red.numel() == nred + 4) else None
-    s = stream()
-    if norm:
-        check(lib.vg_actnorm_bwd_stats(C.byref(d), s), 'vg_actnorm_bwd_stats')
-    check(lib.vg_actnorm_bwd_apply(C.byref(d), s), 'vg_actnorm_bwd_apply')
+    check(lib.vg_actnorm_bwd(C.byref(d), stream()), 'vg_actnorm_bwd')       # statistics (when norm) + apply behind one C call
 
 
 def concat_bwd(g, dims, Cu, Cs, dlow, dskip):
