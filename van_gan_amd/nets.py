@@ -337,7 +337,7 @@ class ResUNet:
             self._norm_bwd(ar, dp1, True, s1, c['n1'], Nn[name + '.cb1'], dcat, ACT_RELU, accumulate=False)
             short.dgrad(d_sc, N, dcat, accumulate=True)
             ops.concat_bwd(dcat, (N,) + tuple(cb1.in_dims), low.C, skip.C, low.grad, skip.grad)
-        ar.release(mk)
+        ar.release(mk, defer=True)
 
     def backward(self, ar: Arena, ctx: dict, gy: torch.Tensor):
         """gy: fp32 [N,D,H,W,1] gradient w.r.t. the tanh output.  Adds parameter gradients into store.g."""
@@ -370,7 +370,7 @@ class ResUNet:
         dp = ar.alloc((N,) + cb1.buf_dims + (b['inp'].C,), self.dtype)
         cb1.dgrad(d_b1, N, dp, accumulate=False)
         self._norm_bwd(ar, dp, True, b['sb1'], b['nb1'], Nn['bridge.cb1'], b['inp'].grad, ACT_RELU, accumulate=True)
-        ar.release(mk)
+        ar.release(mk, defer=True)
         for e in (4, 3, 2, 1):
             self._block_bwd(ar, 'enc%d' % e, ctx['enc%d' % e], N)
         # stem
@@ -497,4 +497,4 @@ class PatchGAN:
             dp = ar.alloc((N,) + tuple(lay.buf_dims) + (1,), self.dtype)
             lay.dgrad(g, N, dp, accumulate=False)
             ops.actnorm_bwd(dp, True, None, (N,) + self.lv[0], 1, dx, act=ACT_NONE, norm=False, accumulate=False)
-        ar.release(mk)
+        ar.release(mk, defer=True)

@@ -172,6 +172,7 @@ PROF: Optional[KernelProfile] = None
 # and the data-gradient chain (dY -> dX -> IN backward -> next layer) are independent, and on the small deep layers either
 # alone leaves most CUs idle.  The side stream waits for the producer of dY; the main stream waits for the side stream
 # before arena memory is recycled (Arena.release) and before the gradients are consumed (side_join).
+LAZY_RELEASE = os.environ.get('VG_LAZY_RELEASE', '1') != '0'
 SIDE: Optional[bool] = None                   # truthy: weight-gradient side streams enabled (one per issuing stream)
 _SIDE_OF = {}                                  # (device index, issuing stream handle) -> its side stream.  The default stream
 #                                                has handle 0 on every device, hence the device index in the key; entries
@@ -251,7 +252,13 @@ class Arena:
     def mark(self) -> int:
         return self.off
 
-    def release(self, mark: int):
+    def release(self, mark: int, defer: bool = False):
+        """Hand the allocations since `mark` back.  defer=True (the backward sweeps): when weight-gradient launches may still be
+        reading them on a side stream, the memory is simply NOT recycled before the next reset() -- joining the side stream here
+        stalled the data-gradient chain behind every block's weight gradients (each lane idle 45 % of a step in the kernel trace);
+        the workspace is sized for it (a few GB more at 128^3, of 288)."""
+        if defer and LAZY_RELEASE and SIDE is not None and PROF is None and DRY is None:
+            return
         side_join()                 # weight gradients on the side stream may still read the buffers being recycled
         self.off = mark
 

@@ -77,7 +77,8 @@ class VanGan:
         self.nets = {'gen_IS': self.gen_IS, 'gen_SI': self.gen_SI, 'disc_I': self.disc_I, 'disc_S': self.disc_S}
         S = self.dims[0] * self.dims[1] * self.dims[2]
         if arena_bytes is None:
-            arena_bytes = int(batch_size * S * 5200 * (2 if precision == 'fp32' else 1)) + (512 << 20)
+            # bytes per voxel: measured peak of one train step with the deferred release of backward temporaries (ops.Arena.release)
+            arena_bytes = int(batch_size * S * (8000 if ops.LAZY_RELEASE else 5200) * (2 if precision == 'fp32' else 1)) + (512 << 20)
         self.arena = Arena(arena_bytes, self.device)
         # weight gradients go to a side stream of the stream that issues them (one per lane): within a layer they are
         # independent of the data-gradient chain.  36.9 vs 37.6 ms/step; a single side stream shared by both lanes cost 2 ms.
@@ -102,6 +103,7 @@ class VanGan:
         # optimizer stream: a network's clip + Adam + weight repack is queued here as soon as ITS backward sweeps are issued and
         # waits only for ITS gradient bucket (all-reduce event), while the other networks' backward sweeps still run
         self._opt = torch.cuda.Stream(device=self.device) if os.environ.get('VG_OPT_STREAM', '1') != '0' else None
+        self._tl = [] if os.environ.get('VG_TIMELINE') == '1' else None
         self.checkpoint_dir = None
         if output_dir is not None:
             self.checkpoint_dir = os.path.join(output_dir, 'checkpoints')
@@ -143,9 +145,27 @@ class VanGan:
                 drop[k] = t
         return noise, drop
 
+    def _mark(self, name: str):
+        """Development aid (VG_TIMELINE=1): an event on the current stream, printed by timeline() -- where the lanes wait for each
+        other, without a profiler's launch overhead."""
+        if self._tl is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self._tl.append((name, e))
+
+    def timeline(self):
+        torch.cuda.synchronize(self.device)
+        t0 = self._tl[0][1]
+        out = [(n, t0.elapsed_time(e)) for n, e in self._tl]
+        self._tl = []
+        return out
+
     def _losses_and_backward(self, real_I, real_S, training: bool, noise, drop, do_backward: bool, apply: bool = False):
         ar = self.arena
         ar.reset()
+        if self._tl is not None:
+            self._tl = []
+        self._mark('A start')
         ops.set_device(self.device.index)          # module-level fast path of ops.stream(): this engine's device
         B = real_I.shape[0]
         D, H, W = self.dims
@@ -166,11 +186,15 @@ class VanGan:
         def laneB():
             return torch.cuda.stream(lane_b) if lane_b is not None else contextlib.nullcontext()
         c1 = self.gen_IS.forward(ar, rI, fake_S)                     # vangan.py:295   (lane A)
+        self._mark('A G1 fwd')
         with laneB():
             c2 = self.gen_SI.forward(ar, rS, fake_I)                 # :297            (lane B)
+            self._mark('B G1 fwd')
         c4 = self.gen_SI.forward(ar, fake_S, cyc_I)                  # :305            (lane A)
+        self._mark('A G2 fwd')
         with laneB():
             c3 = self.gen_IS.forward(ar, fake_I, cyc_S)              # :300            (lane B)
+            self._mark('B G2 fwd')
 
         # ---- cycle / segmentation losses on cycled_S (loss_functions.py:185-190, 211-226): lane B ----
         it = self.skel_iters
@@ -199,6 +223,7 @@ class VanGan:
                 g_cS = ar.alloc(vol, f32)
                 tmp2 = ar.alloc((B, 2), f32, zero=True)
                 ops.minmax_bwd(cyc_S, ncS, g_ncS, mmcS, B, S, tmp2, g_cS)
+            self._mark('B clDice')
 
         # ---- cycle MSE + SSIM reconstruction on cycled_I (loss_functions.py:179-180, 193-208) ----
         g_cI = ar.alloc(vol, f32) if do_backward else None
@@ -216,6 +241,7 @@ class VanGan:
             tmp2b = ar.alloc((B, 2), f32, zero=True)
             ops.minmax_bwd(cyc_I, ncI, g_ncI, mmcI, B, S, tmp2b, g_tmp)
             ops.axpby(g_tmp, 1.0, None, 0.0, g_cI, accumulate=True)
+        self._mark('A cycle losses')
 
         # ---- discriminators on [real; fake] (vangan.py:315-319) and LSGAN losses (:329-332) ----
         ld = tuple(n // 8 for n in self.dims)
@@ -240,6 +266,8 @@ class VanGan:
             ops.mse_const(logI[B:], 1.0, acc[4:5], gd, gI_G)                              # gen_SI_loss
             ops.mse_const(logI[:B], 1.0, acc[7:8], 0.5 * gd, None if gI_D is None else gI_D[:B])
             ops.mse_const(logI[B:], 0.0, acc[8:9], 0.5 * gd, None if gI_D is None else gI_D[B:])
+            self._mark('B D fwd')
+        self._mark('A D fwd')
         if lane_b is not None:
             main.wait_stream(lane_b)                                                        # lanes join before the backward sweeps
 
@@ -272,21 +300,26 @@ class VanGan:
             self.disc_S.backward(ar, dS, gS_G, B, 2 * B, wgrad=False, dx=g_fS)       # still reads D_S's packed weights
             if apply:
                 self._schedule_update('disc_S')
+            self._mark('A D bwd')
             with laneB():
                 self.disc_I.backward(arB, dI, gI_D, 0, 2 * B, wgrad=True)
                 self._start_allreduce(['disc_I'])
                 self.disc_I.backward(arB, dI, gI_G, B, 2 * B, wgrad=False, dx=g_fI)
                 if apply:
                     self._schedule_update('disc_I')
+                self._mark('B D bwd')
             mk = ar.mark()
-            self.gen_IS.backward(ar, c1, g_fS); ar.release(mk)        # adversarial application
+            self.gen_IS.backward(ar, c1, g_fS); ar.release(mk, defer=True)        # adversarial application
+            self._mark('A G adv bwd')
             with laneB():
                 mkb = arB.mark()
-                self.gen_SI.backward(arB, c2, g_fI); arB.release(mkb)
+                self.gen_SI.backward(arB, c2, g_fI); arB.release(mkb, defer=True)
+                self._mark('B G adv bwd')
             if four:
                 main.wait_stream(self._lane_a2)
             else:
-                self.gen_IS.backward(ar, c3, g_cS); ar.release(mk)    # cycle application
+                self.gen_IS.backward(ar, c3, g_cS); ar.release(mk, defer=True)    # cycle application
+                self._mark('A G cyc bwd')
             self._start_allreduce(['gen_IS'])
             if apply:
                 self._schedule_update('gen_IS')
@@ -294,7 +327,8 @@ class VanGan:
                 if four:
                     lane_b.wait_stream(self._lane_b2)
                 else:
-                    self.gen_SI.backward(arB, c4, g_cI); arB.release(mkb)
+                    self.gen_SI.backward(arB, c4, g_cI); arB.release(mkb, defer=True)
+                    self._mark('B G cyc bwd')
                 self._start_allreduce(['gen_SI'])
                 if apply:
                     self._schedule_update('gen_SI')
@@ -303,6 +337,7 @@ class VanGan:
             ops.side_join()
             if apply and self._opt is not None:
                 main.wait_stream(self._opt)
+            self._mark('A all joined')
         self._acc, self._coef = acc, coef
         self._aux = dict(fake_S=fake_S, fake_I=fake_I, cycled_S=cyc_S, cycled_I=cyc_I, logits_S=logS, logits_I=logI)
         return B, S, nps
