@@ -60,6 +60,7 @@ int vg_abi_sizeof(int which);
  *     on dY with transposed packed weights, per output-parity class for stride 2.
  * out[n, o*ostr+ooff, co] (+)= sum_taps sum_ci f(src[n, bnd(o*istr + tap), ci]) * W[tap][ci][co]
  * --------------------------------------------------------------------------------------------- */
+struct vg_actnorm_bwd_desc_s;
 typedef struct {
     /* input: virtual concat of src0 (c_src0 channels) and src1 (c_src1 channels, may be 0) */
     const void* src0;
@@ -116,6 +117,11 @@ typedef struct {
        vg_conv3d_wgrad returns dw in that layout, i.e. the unchanged DHWIO tensor (T_total = k*k).  0: off. */
     int32_t wpack;
     int32_t wpack_wmin;
+    /* Optional (data-gradient launches): the STATISTICS pass of the IN backward that consumes this launch's output (g == out,
+       bf16, one launch covering the whole grid, no accumulate).  The 16-channel specialist accumulates sum dn and sum dn*xhat
+       in its epilogue -- the upstream gradient is not re-read from HBM -- other kernels are followed by vg_actnorm_bwd_stats.
+       Either way red[stripe 0] (and dgamma / dbeta) are final when the call returns; the caller then runs vg_actnorm_bwd_apply. */
+    const struct vg_actnorm_bwd_desc_s* bstat;
 } vg_conv_desc;
 
 int vg_conv3d(const vg_conv_desc* d, vg_stream_t stream);
@@ -183,7 +189,7 @@ int vg_in_finalize(const float* sums0, int c0, float count0, const float* sums1,
  * pass 2 (apply):  dx (+)= gamma*rstd*(dn - mean(dn) - xhat*mean(dn*xhat))      (norm=1)
  *                  dx (+)= dn                                                     (norm=0)
  * x is bf16 (x_f32=0) ; g is bf16; dx is bf16 unless dx_f32. */
-typedef struct {
+typedef struct vg_actnorm_bwd_desc_s {
     const void* g; int32_t g_padded;
     const void* x; int32_t x_f32;            /* forward input of the norm (channels [0,c_x0) when x1 is set) */
     const void* x1; int32_t c_x0; int32_t x0_shift;   /* virtual upsample+concat: x = [up(x), x1] */

@@ -247,11 +247,51 @@ def run_recipe(recipe, expect_variant, dev, seed=1, precision='bf16'):
         dp = prior.to(dev).clone()
     else:
         dp = torch.full((N,) + tuple(lay.buf_dims) + (L['cin'],), 7.0, dtype=odt, device=dev)       # must be overwritten everywhere
-    call = lambda: lay.dgrad(dys.to(dev), N, dp, accumulate=recipe['accumulate'])
+    bs = recipe.get('bstat')
+    bdesc = None
+    if bs:
+        # the IN backward that consumes this data gradient: its statistics ride on the launch (ConvLayer.dgrad(bstat=...))
+        from van_gan_amd import ops
+        Cc, dims_in = L['cin'], tuple(lay.in_dims)
+        c0 = bs['c_x0'] if bs['cat'] else Cc
+        sh = 1 if bs['cat'] else 0
+        bx0 = torch.randn(N, *[n >> sh for n in dims_in], c0, generator=g).to(torch.bfloat16)
+        bx1 = torch.randn(N, *dims_in, Cc - c0, generator=g).to(torch.bfloat16) if bs['cat'] else None
+        bsc, bsf = torch.rand(N, Cc, generator=g) + 0.5, torch.randn(N, Cc, generator=g) * 0.3
+        bmu, brs = torch.randn(N, Cc, generator=g) * 0.2, torch.rand(N, Cc, generator=g) + 0.5
+        red = torch.zeros(ops.STRIPES * N * Cc * 2 + 4, device=dev)
+        dgam, dbet = torch.zeros(Cc, device=dev), torch.zeros(Cc, device=dev)
+        dxo = torch.zeros(N, *dims_in, Cc, dtype=torch.bfloat16, device=dev)
+        tod = lambda t: None if t is None else t.to(dev)
+        bdesc = ops.actnorm_desc(dp, bs['pad'], tod(bx0), (N,) + dims_in, Cc, dxo, scale=tod(bsc), shift=tod(bsf), act=bs['act'], norm=True,
+                                 gamma=torch.ones(Cc, device=dev), mean=tod(bmu), rstd=tod(brs), red=red, accumulate=False, x1=tod(bx1),
+                                 c_x0=c0 if bs['cat'] else 0, x0_shift=sh, dgamma=dgam, dbeta=dbet)
+    done = []
+    call = lambda: done.append(lay.dgrad(dys.to(dev), N, dp, accumulate=recipe['accumulate'], bstat=bdesc))
     got_variants = dry_variants(call)
     assert expect_variant in got_variants and len(set(got_variants)) == 1, (got_variants, expect_variant)
     call()
     torch.cuda.synchronize()
+    if bs:
+        assert done[-1] is True
+        # reference statistics from the data gradient the kernel stored: transpose of the reflection pad, dn = g * act'(pre)
+        gp = O.to_ncdhw(dp.double().cpu())
+        a0 = torch.zeros(N, L['cin'], *lay.in_dims, dtype=torch.float64, requires_grad=True)
+        ((O.reflect_pad1(a0) if bs['pad'] else a0) * gp).sum().backward()
+        gf = O.to_ndhwc(a0.grad)
+        xf = bx0.double()
+        if bs['cat']:
+            xf = torch.cat([xf.repeat_interleave(2, 1).repeat_interleave(2, 2).repeat_interleave(2, 3), bx1.double()], dim=-1)
+        v = lambda t: t.double().view(N, 1, 1, 1, -1)
+        pre = xf * v(bsc) + v(bsf)
+        slope = 0.0 if bs['act'] == ops.ACT_RELU else (0.2 if bs['act'] == ops.ACT_LRELU else 1.0)
+        dn = gf * torch.where(pre > 0, torch.ones_like(pre), torch.full_like(pre, slope))
+        xh = (xf - v(bmu)) * v(brs)
+        ref_red = torch.stack([dn.sum(dim=(1, 2, 3)), (dn * xh).sum(dim=(1, 2, 3))], dim=-1)
+        got_red = red[:N * L['cin'] * 2].view(N, L['cin'], 2)
+        assert rel_l2(got_red, ref_red) < 2e-3, 'fused IN-backward statistics rel %.2e' % rel_l2(got_red, ref_red)
+        assert float(red[N * L['cin'] * 2:ops.STRIPES * N * L['cin'] * 2].abs().max()) == 0.0          # stripes folded and cleared
+        assert rel_l2(dbet, ref_red[..., 0].sum(0)) < 2e-3 and rel_l2(dgam, ref_red[..., 1].sum(0)) < 2e-3
     xin = torch.zeros(N, L['cin'], *lay.buf_dims, dtype=dt, requires_grad=True)
     (O.conv3d(xin, w_ref, None, stride, conv_pad) * dy_ref).sum().backward()
     ref = O.to_ndhwc(xin.grad)

@@ -30,7 +30,7 @@ class ConvDesc(C.Structure):
         ('res', c_void_p), ('res_scale', c_void_p), ('res_shift', c_void_p), ('tanh_out', c_int),
         ('out', c_void_p), ('out_f32', c_int), ('accumulate', c_int), ('out_sums', c_void_p), ('f32', c_int),
         ('nclass', c_int), ('cls_tap0', c_int * 9), ('cls_w', c_void_p * 8), ('cls_ooff', (c_int * 3) * 8),
-        ('cls_iters', (c_int * 3) * 8), ('wpack', c_int), ('wpack_wmin', c_int),
+        ('cls_iters', (c_int * 3) * 8), ('wpack', c_int), ('wpack_wmin', c_int), ('bstat', c_void_p),
     ]
 
 

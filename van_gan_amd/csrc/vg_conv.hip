@@ -762,6 +762,12 @@ static int fill_conv(const vg_conv_desc* d, GatherIn& g, ConvOut& k, ConvCls& q,
     k.wp = d->wpacked;
     k.bias = d->bias; k.res = d->res; k.rs = d->res_scale; k.rb = d->res_shift; k.tanh_out = d->tanh_out;
     k.out = d->out; k.out_f32 = (d->out_f32 || d->f32) ? 1 : 0; k.accumulate = d->accumulate; k.sums = d->out_sums;
+    k.bs_x0 = nullptr;
+    if (const vg_actnorm_bwd_desc* b = d->bstat) {       // validated by vg_conv3d
+        k.bs_x0 = b->x; k.bs_x1 = b->x1; k.bs_c0 = b->x1 ? b->c_x0 : b->C; k.bs_sh = b->x1 ? (b->x0_shift ? 1 : 0) : 0;
+        k.bs_act = b->act; k.bs_pad = b->g_padded ? 1 : 0; k.bs_D = b->D; k.bs_H = b->H; k.bs_W = b->W;
+        k.bs_sc = b->scale; k.bs_sf = b->shift; k.bs_mu = b->mean; k.bs_rs = b->rstd; k.bs_ml = b->mult;
+    }
     return VG_OK;
 }
 
@@ -916,8 +922,8 @@ static int dispatch_conv(const GatherIn& g, const ConvOut& k, const ConvCls& q, 
     return MSUB == 2 ? launch_conv<T, 64, 2>(g, k, q, lds, s) : launch_conv<T, 64, 1>(g, k, q, lds, s);
 }
 
-extern "C" int vg_conv3d(const vg_conv_desc* d, vg_stream_t stream) {
-    vg_begin();
+// did_stats: set when the launched kernel accumulated the IN-backward statistics of d->bstat itself (striped, unfolded)
+static int conv3d_impl(const vg_conv_desc* d, vg_stream_t stream, bool& did_stats) {
     if (d && d->out && d->wpacked && d->src0) {           // 1x1x1 with a single channel on one side: HBM-bound VALU kernels
         const int prc = vg_pointwise_conv(d, (hipStream_t)stream);
         if (prc <= 0) return prc;
@@ -929,10 +935,28 @@ extern "C" int vg_conv3d(const vg_conv_desc* d, vg_stream_t stream) {
     { GatherIn g2; int bn2, ms2, lds2; if (plan_conv32(d, k, q, g2, bn2, ms2, lds2) == VG_OK) return launch_conv32(g2, k, q, bn2, ms2, lds2, s); }
     if (k.pc) return vg_launch_conv_pc(g, k, q, BN, MSUB, lds, s);
     if (!d->f32 && MSUB == 8 && BN == 16 && vg_conv_thin_ok(d, g, k, q)) {
-        const int trc = vg_launch_conv_thin(g, k, s);
+        const int trc = vg_launch_conv_thin(g, k, s, d->bstat ? d->bstat->red : nullptr, did_stats);
         if (trc <= 0) return trc;
     }
     return d->f32 ? dispatch_conv<float>(g, k, q, BN, MSUB, lds, s) : dispatch_conv<bf16_t>(g, k, q, BN, MSUB, lds, s);
+}
+
+extern "C" int vg_conv3d(const vg_conv_desc* d, vg_stream_t stream) {
+    vg_begin();
+    if (!d) return VG_EINVAL;
+    const vg_actnorm_bwd_desc* b = d->bstat;
+    if (b) {
+        // the statistics are those of THIS launch's complete output: same tensor, same grid, plain bf16 stores
+        const int pd = b->g_padded ? 2 : 0;
+        if (b->g != d->out || !b->norm || !b->red || !b->x || !b->mean || !b->rstd || b->f32 || d->f32 || d->out_f32 || d->accumulate
+            || b->N != d->N || b->C != d->Cout || b->D + pd != d->BD || b->H + pd != d->BH || b->W + pd != d->BW)
+            return VG_EINVAL;
+    }
+    bool did_stats = false;
+    const int rc = conv3d_impl(d, stream, did_stats);
+    if (rc != VG_OK || !b || vg_dry_on()) return rc;
+    if (did_stats) { vg_launch_anb_fold(b->red, b->N, b->C, b->dgamma, b->dbeta, (hipStream_t)stream); return vg_check_launch(); }
+    return vg_actnorm_bwd_stats(b, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

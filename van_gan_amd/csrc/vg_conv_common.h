@@ -12,6 +12,10 @@ struct ConvOut {
     int dma;            // 1: LDS-DMA double-buffered staging (planar bf16 image, weights in LDS)
     int WRS;
     int pc;             // 1: producer/consumer flavour (vg_conv_pc.hip)
+    // IN-backward statistics of the output fused into the epilogue (conv_thin_kernel<..., BSTAT>; vg_conv_desc::bstat): the
+    // pre-norm tensor(s) of the layer whose gradient this launch produces and its per-(sample, channel) constants
+    const void* bs_x0; const void* bs_x1; int bs_c0, bs_sh, bs_act, bs_pad, bs_D, bs_H, bs_W;
+    const float* bs_sc; const float* bs_sf; const float* bs_mu; const float* bs_rs; const float* bs_ml;
 };
 // output-parity classes fused into one launch (data gradient of a strided conv): a separate kernel argument that only the
 // multi-class kernel variants read
@@ -146,7 +150,8 @@ __device__ __forceinline__ void conv_mfma_chunk(f32x4 (&acc)[MW], WP w, const ch
 int vg_launch_conv_pc(const GatherIn& g, const ConvOut& k, const ConvCls& q, int BN, int MSUB, int lds, hipStream_t s);
 // vg_conv_thin.hip: specialist for the 16-channel-chunk 3x3x3 stride-1 layers with a fixed 16x8x4 tile
 bool vg_conv_thin_ok(const vg_conv_desc* d, const GatherIn& g, const ConvOut& k, const ConvCls& q);
-int vg_launch_conv_thin(const GatherIn& g, const ConvOut& k, hipStream_t s);       // VG_OK, < 0 on error, 1: not one of its combinations
+// red != NULL: accumulate the IN-backward statistics (ConvOut::bs_*) into red in the epilogue when the instance exists (did_stats)
+int vg_launch_conv_thin(const GatherIn& g, const ConvOut& k, hipStream_t s, float* red, bool& did_stats);       // VG_OK, < 0 on error, 1: not one of its combinations
 // staging mode (VG_STAGE_*) the producer/consumer flavour would use for this source, -1: not supported there
 int vg_conv_pc_mode(const GatherIn& g);
 // LDS bytes of the producer/consumer flavour for this geometry (host)

@@ -34,7 +34,10 @@ constexpr int KCPAD = 448;                             // packed K of one 16-cha
 __device__ __forceinline__ void lds_only_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // MODE: VG_STAGE_PLAIN (data-gradient operand, zero padded) or VG_STAGE_RELU (forward: IN affine + ReLU, reflect padded)
-template <int MODE, bool BIAS, bool RES, bool STATS>
+// BSTAT (data gradient): the epilogue also accumulates the statistics of the IN backward that consumes this output --
+// sum dn and sum dn * xhat with dn = g * mult * act'(x * scale + shift) taken at the reflect-folded position of the pre-norm
+// tensor x -- into p.sums (same striped layout as the forward statistics), so that the statistics pass need not re-read g.
+template <int MODE, bool BIAS, bool RES, bool STATS, bool BSTAT = false>
 __global__ __launch_bounds__(256, 2) void conv_thin_kernel(const GatherIn g, const ConvOut p) {
     typedef bf16_t T;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -85,6 +88,16 @@ __global__ __launch_bounds__(256, 2) void conv_thin_kernel(const GatherIn g, con
     if (RES) {
         e_rs[0] = (f32x2){p.rs[n * p.Cout + co0], p.rs[n * p.Cout + co0 + 1]}; e_rs[1] = (f32x2){p.rs[n * p.Cout + co0 + 2], p.rs[n * p.Cout + co0 + 3]};
         e_rb[0] = (f32x2){p.rb[n * p.Cout + co0], p.rb[n * p.Cout + co0 + 1]}; e_rb[1] = (f32x2){p.rb[n * p.Cout + co0 + 2], p.rb[n * p.Cout + co0 + 3]};
+    }
+    // BSTAT: the source tensor of this workgroup's 16-channel panel (the per-channel constants are fetched in the epilogue:
+    // held across the MFMA loop they pushed this instance over its register cap)
+    const T* b_x = nullptr; int b_cs = 0, b_sh = 0; float b_slope = 1.f;
+    if (BSTAT) {
+        const bool lo = co0 < p.bs_c0;                                   // panel-uniform (bs_c0 is a multiple of 16)
+        b_sh = lo ? p.bs_sh : 0; b_cs = lo ? p.bs_c0 : p.Cout - p.bs_c0;
+        b_x = (lo ? (const T*)p.bs_x0 + co0 : (const T*)p.bs_x1 + (co0 - p.bs_c0))
+              + (size_t)n * (p.bs_D >> b_sh) * (p.bs_H >> b_sh) * (p.bs_W >> b_sh) * b_cs;
+        b_slope = p.bs_act == VG_ACT_RELU ? 0.f : (p.bs_act == VG_ACT_LRELU ? VG_LRELU : 1.f);
     }
     // 16-byte stores: after the row swap an even k-group lane holds channels 8*(kg/2)..+7 of sub-tile j, an odd one of j+1
     const int cst = ntile * 16 + 8 * (kg >> 1);
@@ -163,6 +176,28 @@ __global__ __launch_bounds__(256, 2) void conv_thin_kernel(const GatherIn g, con
             const int nrow = MASKED ? p.OH - oh0 : TH;                                        // valid H rows of this tile
             typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
             typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+            bf16x4 bx[BSTAT ? 8 : 1];
+            f32x2 b_sc[2], b_sf[2], b_rs[2], b_nm[2];
+            if (BSTAT) {
+                const int nc = n * p.Cout + co0;
+                typedef const __attribute__((address_space(1))) f32x4 gf4;
+                const f32x4 c_sc = *(gf4*)(uintptr_t)(p.bs_sc + nc), c_sf = *(gf4*)(uintptr_t)(p.bs_sf + nc), c_rs = *(gf4*)(uintptr_t)(p.bs_rs + nc),
+                            c_mu = *(gf4*)(uintptr_t)(p.bs_mu + nc);
+                b_sc[0] = (f32x2){c_sc[0], c_sc[1]}; b_sc[1] = (f32x2){c_sc[2], c_sc[3]}; b_sf[0] = (f32x2){c_sf[0], c_sf[1]}; b_sf[1] = (f32x2){c_sf[2], c_sf[3]};
+                b_rs[0] = (f32x2){c_rs[0], c_rs[1]}; b_rs[1] = (f32x2){c_rs[2], c_rs[3]};
+                b_nm[0] = (f32x2){-c_mu[0] * c_rs[0], -c_mu[1] * c_rs[1]}; b_nm[1] = (f32x2){-c_mu[2] * c_rs[2], -c_mu[3] * c_rs[3]};
+                // padded output coordinate -> interior coordinate -> transpose of the reflection pad (-1 -> 1, n -> n-2); rows of a
+                // masked tile that lie outside are clamped (their contribution is zeroed below).  All 8 loads are issued up front.
+                auto fold = [&](int q, int nn) { int i = q - p.bs_pad; i = i < 0 ? -i : i; i = i >= nn ? 2 * nn - 2 - i : i; return min(max(i, 0), nn - 1); };
+                const int XH = p.bs_H >> b_sh, XW = p.bs_W >> b_sh;
+                const int id = fold(od + p.ood, p.bs_D) >> b_sh, iw = fold(ow + p.oow, p.bs_W) >> b_sh;
+                const T* xcol = b_x + ((size_t)id * XH * XW + iw) * b_cs;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int ih = fold(oh0 + j + p.ooh, p.bs_H) >> b_sh;
+                    bx[j] = *(const __attribute__((address_space(1))) bf16x4*)(uintptr_t)(xcol + (size_t)ih * XW * b_cs);
+                }
+            }
 #pragma unroll
             for (int jp = 0; jp < 8; jp += 2) {
                 bf16x4 pk[2];
@@ -185,6 +220,20 @@ __global__ __launch_bounds__(256, 2) void conv_thin_kernel(const GatherIn g, con
                         a0 += q0; a1 += q1; c0 += q0 * q0; c1 += q1 * q1;
                         s1[0] = a0[0]; s1[1] = a0[1]; s1[2] = a1[0]; s1[3] = a1[1]; s2[0] = c0[0]; s2[1] = c0[1]; s2[2] = c1[0]; s2[3] = c1[1];
                     }
+                    if (BSTAT) {
+                        f32x2 q0 = {bf2f((bf16_t)pk[e][0]), bf2f((bf16_t)pk[e][1])}, q1 = {bf2f((bf16_t)pk[e][2]), bf2f((bf16_t)pk[e][3])};
+                        if (MASKED && !ok) { q0 = (f32x2){0.f, 0.f}; q1 = q0; }
+                        const bf16x4 xr = bx[BSTAT ? j : 0];
+                        const f32x2 x0 = {bf2f((bf16_t)xr[0]), bf2f((bf16_t)xr[1])}, x1 = {bf2f((bf16_t)xr[2]), bf2f((bf16_t)xr[3])};
+                        const f32x2 pre0 = x0 * b_sc[0] + b_sf[0], pre1 = x1 * b_sc[1] + b_sf[1];
+                        const f32x2 d0 = {pre0[0] > 0.f ? 1.f : b_slope, pre0[1] > 0.f ? 1.f : b_slope};     // TP: the activation gradient uses pre > 0
+                        const f32x2 d1 = {pre1[0] > 0.f ? 1.f : b_slope, pre1[1] > 0.f ? 1.f : b_slope};
+                        const f32x2 dn0 = q0 * d0, dn1 = q1 * d1;                                          // (no dropout multiplier on this path)
+                        const f32x2 xh0 = x0 * b_rs[0] + b_nm[0], xh1 = x1 * b_rs[1] + b_nm[1];
+                        f32x2 a0 = {s1[0], s1[1]}, a1 = {s1[2], s1[3]}, c0 = {s2[0], s2[1]}, c1 = {s2[2], s2[3]};
+                        a0 += dn0; a1 += dn1; c0 += dn0 * xh0; c1 += dn1 * xh1;
+                        s1[0] = a0[0]; s1[1] = a0[1]; s1[2] = a1[0]; s1[3] = a1[1]; s2[0] = c0[0]; s2[1] = c0[1]; s2[2] = c1[0]; s2[3] = c1[1];
+                    }
                 }
                 // rows (16-lane groups) 1,3 of pk[0] <-> rows 0,2 of pk[1]: even rows end with sub-tile jp channels [4kg..4kg+7],
                 // odd rows with sub-tile jp+1 channels [4(kg-1)..4kg+3]
@@ -198,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void conv_thin_kernel(const GatherIn g, con
         };
         if (full) epilogue(std::false_type{}); else epilogue(std::true_type{});
     }
-    if (STATS && p.sums) {
+    if ((STATS || BSTAT) && p.sums) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float a = s1[r], b = s2[r];
@@ -241,11 +290,11 @@ bool vg_conv_thin_ok(const vg_conv_desc* d, const GatherIn& g, const ConvOut& k,
     return true;
 }
 
-template <int MODE, bool BIAS, bool RES, bool STATS>
+template <int MODE, bool BIAS, bool RES, bool STATS, bool BSTAT = false>
 static int launch_thin(const GatherIn& g, const ConvOut& k, int lds, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_thin_kernel<MODE, BIAS, RES, STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, VG_LDS_LIMIT);
+        (void)hipFuncSetAttribute((const void*)conv_thin_kernel<MODE, BIAS, RES, STATS, BSTAT>, hipFuncAttributeMaxDynamicSharedMemorySize, VG_LDS_LIMIT);
         attr_set = true;
     }
     int per_cu = 2;
@@ -255,17 +304,25 @@ static int launch_thin(const GatherIn& g, const ConvOut& k, int lds, hipStream_t
     const int ny = k.Cout / 16;
     const int wg = vg_tune("CONV_THIN_WGS", 0) > 0 ? vg_tune("CONV_THIN_WGS", 0) : 256 * per_cu;
     int bx = wg / (ny * g.N); if (bx < 1) bx = 1; if (bx > tiles) bx = tiles;
-    if (vg_dry("conv_thin<m%d,b%d,r%d,s%d>|walk%d|ch%d", MODE, (int)BIAS, (int)RES, (int)STATS, tiles > bx ? 1 : 0, k.nchunks > 1 ? 1 : 0)) return VG_OK;
-    hipLaunchKernelGGL((conv_thin_kernel<MODE, BIAS, RES, STATS>), dim3(bx, ny, g.N), dim3(256), lds, s, g, k);
+    // bs1 / bs2: IN-backward statistics in the epilogue, of a plain / a virtually concatenated (half-resolution + skip) pre-norm tensor
+    if (vg_dry(BSTAT ? (k.bs_x1 ? "conv_thin<m%d,b%d,r%d,s%d,bs2>|walk%d|ch%d" : "conv_thin<m%d,b%d,r%d,s%d,bs1>|walk%d|ch%d") : "conv_thin<m%d,b%d,r%d,s%d>|walk%d|ch%d",
+               MODE, (int)BIAS, (int)RES, (int)STATS, tiles > bx ? 1 : 0, k.nchunks > 1 ? 1 : 0)) return VG_OK;
+    hipLaunchKernelGGL((conv_thin_kernel<MODE, BIAS, RES, STATS, BSTAT>), dim3(bx, ny, g.N), dim3(256), lds, s, g, k);
     return vg_check_launch();
 }
 
-int vg_launch_conv_thin(const GatherIn& g, const ConvOut& k, hipStream_t s) {
+int vg_launch_conv_thin(const GatherIn& g, const ConvOut& k, hipStream_t s, float* red, bool& did_stats) {
     const int lds = vg_conv_thin_lds_bytes(g);
     if (lds > VG_LDS_LIMIT) return VG_ELDS;
     const bool st = k.sums != nullptr;
     if (g.lean == VG_STAGE_PLAIN) {
         // data gradient (no bias / residual / statistics) and raw-source forward convolutions
+        if (red && k.bs_x0 && !k.bs_ml && k.bs_sc && k.bias == nullptr && k.res == nullptr && !st && (k.bs_c0 % 16) == 0 && (k.bs_c0 == k.Cout || k.bs_x1)
+            && k.OD == k.BD && k.OH == k.BH && k.OW == k.BW && !k.ood && !k.ooh && !k.oow && vg_tune("CONV_BSTAT", 1)) {
+            ConvOut k2 = k; k2.sums = red;                 // the IN-backward statistics take the place of the forward ones
+            did_stats = !vg_dry_on();
+            return launch_thin<VG_STAGE_PLAIN, false, false, false, true>(g, k2, lds, s);
+        }
         if (k.bias == nullptr && k.res == nullptr && !st) return launch_thin<VG_STAGE_PLAIN, false, false, false>(g, k, lds, s);
         if (k.bias != nullptr && k.res == nullptr) return st ? launch_thin<VG_STAGE_PLAIN, true, false, true>(g, k, lds, s)
                                                              : launch_thin<VG_STAGE_PLAIN, true, false, false>(g, k, lds, s);

@@ -385,6 +385,11 @@ static dim3 anb_grid(const ANB& p, bool stats = false) {
     return dim3(bx, p.N);
 }
 
+void vg_launch_anb_fold(float* red, int N, int C, float* dgamma, float* dbeta, hipStream_t s) {
+    const int total = N * C * 2;
+    hipLaunchKernelGGL(anb_fold_stripes_kernel, dim3((total + 255) / 256), dim3(256), 0, s, red, total, C, dgamma && dbeta ? dgamma : nullptr, dbeta);
+}
+
 extern "C" int vg_actnorm_bwd_stats(const vg_actnorm_bwd_desc* d, vg_stream_t stream) {
     vg_begin();
     ANB p; int rc = fill_anb(d, p, false);
@@ -649,6 +654,7 @@ bool vg_dry(const char* fmt, ...) {
 }
 void vg_dry_begin(char* buf, int n) { t_dry_buf = buf; t_dry_len = n; if (buf && n > 0) buf[0] = 0; }
 void vg_dry_end() { t_dry_buf = nullptr; t_dry_len = 0; }
+bool vg_dry_on() { return t_dry_buf != nullptr; }
 
 extern "C" int vg_version(void) {
     vg_begin(); return 2; }

@@ -294,14 +294,23 @@ class ResUNet:
         return ctx
 
     # ---------------------------------------------------------------------------------------------
-    def _norm_bwd(self, ar, g, g_padded, src: Src, st, norm: Norm, dx, act, dx_cstride=0, accumulate=True):
-        """(IN -> act) backward of the operand described by `src` with statistics `st`."""
+    def _norm_desc(self, ar, g, g_padded, src: Src, st, norm: Norm, dx, act, dx_cstride=0, accumulate=True):
+        """Descriptor of the (IN -> act) backward of the operand described by `src` with statistics `st` (ops.actnorm_desc)."""
         N = src.N
         red = ops.alloc_red(ar, N, src.C)
-        ops.actnorm_bwd(g, g_padded, src.x0, (N, src.D, src.H, src.W), src.C, dx, scale=st['scale'], shift=st['shift'],
-                        act=act, norm=True, gamma=norm.gamma, mean=st['mean'], rstd=st['rstd'], red=red,
-                        accumulate=accumulate, x1=src.x1, c_x0=src.c0 if src.x1 is not None else 0, x0_shift=src.shift0,
-                        dx_cstride=dx_cstride, dgamma=norm.dgamma, dbeta=norm.dbeta)
+        return ops.actnorm_desc(g, g_padded, src.x0, (N, src.D, src.H, src.W), src.C, dx, scale=st['scale'], shift=st['shift'],
+                                act=act, norm=True, gamma=norm.gamma, mean=st['mean'], rstd=st['rstd'], red=red,
+                                accumulate=accumulate, x1=src.x1, c_x0=src.c0 if src.x1 is not None else 0, x0_shift=src.shift0,
+                                dx_cstride=dx_cstride, dgamma=norm.dgamma, dbeta=norm.dbeta)
+
+    def _norm_bwd(self, ar, g, g_padded, src: Src, st, norm: Norm, dx, act, dx_cstride=0, accumulate=True):
+        ops.actnorm_run(self._norm_desc(ar, g, g_padded, src, st, norm, dx, act, dx_cstride, accumulate))
+
+    def _dgrad_norm_bwd(self, ar, lay, dy, N, dp, src: Src, st, norm: Norm, dx, act, accumulate):
+        """Data gradient of `lay` into the padded grid dp, then the (IN -> act) backward of its input operand `src` into dx; the
+        statistics pass rides on the data-gradient launch where the kernel carries it (ConvLayer.dgrad(bstat=...))."""
+        dsc = self._norm_desc(ar, dp, True, src, st, norm, dx, act, accumulate=accumulate)
+        ops.actnorm_run(dsc, stats_done=lay.dgrad(dy, N, dp, accumulate=False, bstat=dsc))
 
     def _block_bwd(self, ar: Arena, name: str, c: dict, N: int):
         """Backward of one residual block given the complete gradient of its output in c['out'].grad."""
@@ -317,24 +326,22 @@ class ResUNet:
         # conv2: weights + data gradient on the padded grid, folded through relu(IN(r))
         cb2.wgrad(c['s2'], d_out)
         dp = ar.alloc((N,) + cb2.buf_dims + (r.C,), self.dtype)
-        cb2.dgrad(d_out, N, dp, accumulate=False)
         d_r = ar.alloc(r.data.shape, self.dtype)
-        self._norm_bwd(ar, dp, True, c['s2'], c['n2'], Nn[name + '.cb2'], d_r, ACT_RELU, accumulate=False)
+        self._dgrad_norm_bwd(ar, cb2, d_out, N, dp, c['s2'], c['n2'], Nn[name + '.cb2'], d_r, ACT_RELU, accumulate=False)
         # conv1 and shortcut conv read the block input (possibly the virtual concat)
         s1, raw = c['s1'], c['src_raw']
         cb1.wgrad(s1, d_r)
         short.wgrad(raw, d_sc)
         dp1 = ar.alloc((N,) + cb1.buf_dims + (s1.C,), self.dtype)
-        cb1.dgrad(d_r, N, dp1, accumulate=False)
         inp = c['inp']
         if len(inp) == 1:            # encoder block: accumulate into the input's gradient
             gin = inp[0].alloc_grad(ar) if inp[0].grad is None else inp[0].grad
-            self._norm_bwd(ar, dp1, True, s1, c['n1'], Nn[name + '.cb1'], gin, ACT_RELU, accumulate=True)
+            self._dgrad_norm_bwd(ar, cb1, d_r, N, dp1, s1, c['n1'], Nn[name + '.cb1'], gin, ACT_RELU, accumulate=True)
             short.dgrad(d_sc, N, gin, accumulate=True)
         else:                        # decoder block: gradient of the virtual concat, then split / sum-pool
             low, skip = inp
             dcat = ar.alloc((N,) + tuple(cb1.in_dims) + (s1.C,), self.dtype)
-            self._norm_bwd(ar, dp1, True, s1, c['n1'], Nn[name + '.cb1'], dcat, ACT_RELU, accumulate=False)
+            self._dgrad_norm_bwd(ar, cb1, d_r, N, dp1, s1, c['n1'], Nn[name + '.cb1'], dcat, ACT_RELU, accumulate=False)
             short.dgrad(d_sc, N, dcat, accumulate=True)
             ops.concat_bwd(dcat, (N,) + tuple(cb1.in_dims), low.C, skip.C, low.grad, skip.grad)
         ar.release(mk, defer=True)
@@ -382,9 +389,8 @@ class ResUNet:
         cb = L['stem.cb']
         cb.wgrad(s['s1'], d_out)
         dp = ar.alloc((N,) + cb.buf_dims + (s['c1'].C,), self.dtype)
-        cb.dgrad(d_out, N, dp, accumulate=False)
         d_c1 = ar.alloc(s['c1'].data.shape, self.dtype)
-        self._norm_bwd(ar, dp, True, s['s1'], s['n1'], Nn['stem.cb'], d_c1, ACT_RELU, accumulate=False)
+        self._dgrad_norm_bwd(ar, cb, d_out, N, dp, s['s1'], s['n1'], Nn['stem.cb'], d_c1, ACT_RELU, accumulate=False)
         L['stem.conv1'].wgrad(s['sx'], d_c1)
         L['stem.short'].wgrad(s['sx'], d_sc)
 

@@ -173,6 +173,7 @@ PROF: Optional[KernelProfile] = None
 # alone leaves most CUs idle.  The side stream waits for the producer of dY; the main stream waits for the side stream
 # before arena memory is recycled (Arena.release) and before the gradients are consumed (side_join).
 LAZY_RELEASE = os.environ.get('VG_LAZY_RELEASE', '1') != '0'
+BSTAT = os.environ.get('VG_BSTAT', '1') != '0'       # IN-backward statistics with the data-gradient launch (ConvLayer.dgrad(bstat=...))
 SIDE: Optional[bool] = None                   # truthy: weight-gradient side streams enabled (one per issuing stream)
 _SIDE_OF = {}                                  # (device index, issuing stream handle) -> its side stream.  The default stream
 #                                                has handle 0 on every device, hence the device index in the key; entries
@@ -569,13 +570,22 @@ class ConvLayer:
         d.out, d.out_f32, d.accumulate = _p(out), int(out.dtype == torch.float32), int(accumulate)
         return d
 
-    def dgrad(self, dy: torch.Tensor, N: int, out: torch.Tensor, accumulate: bool):
+    def dgrad(self, dy: torch.Tensor, N: int, out: torch.Tensor, accumulate: bool, bstat=None) -> bool:
         """d/d input: writes the reflect-PADDED grid for 'reflect' convs (fold it with actnorm_bwd), the plain
-        input grid for 'same' convs.  out: [N, *buf_dims, cin] bf16 (or f32 when cin==1)."""
+        input grid for 'same' convs.  out: [N, *buf_dims, cin] bf16 (or f32 when cin==1).
+        bstat: the actnorm_desc() of the IN backward that consumes `out` (bstat.g is out): when the data gradient is ONE launch,
+        its statistics pass is done with it (in the kernel's epilogue where the kernel can, else right behind it) and True is
+        returned -- the caller then runs actnorm_run(bstat, stats_done=True)."""
+        # only where the 16-channel specialist (which carries the statistics in its epilogue) is the expected kernel: elsewhere the
+        # separate statistics launch stays where it was
+        use_bs = bstat is not None and BSTAT and not accumulate and not self.f32 and out.dtype == torch.bfloat16 and bstat.norm \
+            and len(self.d_classes) == 1 and self.stride == 1 and self.k == 3 and self.pad == 'reflect' \
+            and self.d_classes[0]['ck'] == 16 and self.cin % 16 == 0 and self.cout % 16 == 0 and not bstat.mult
         if DRY is not None:
             DRY.tag = ('dgrad', self.name)
             DRY.recipe = dict(kind='dgrad', layer=self.ctor, N=N, accumulate=bool(accumulate), dy_f32=dy.dtype == torch.float32,
-                              out_f32=out.dtype == torch.float32)
+                              out_f32=out.dtype == torch.float32, bstat=None if not use_bs else dict(
+                                  cat=bool(bstat.x1), c_x0=bstat.c_x0, act=bstat.act, pad=bool(bstat.g_padded)))
         if self.d_fused:
             t = getattr(self, '_dg_tmpl', None)
             if t is None:                            # static part once (taps / weights / offsets of every class), then block copies
@@ -585,13 +595,14 @@ class ConvLayer:
             d.src0, d.N = _p(dy), N
             d.src_f32 = int(dy.dtype == torch.float32 and self.cout == 1)
             d.out, d.out_f32, d.accumulate = _p(out), int(out.dtype == torch.float32), int(accumulate)
+            d.bstat = C.addressof(bstat) if use_bs else None
             e0 = PROF.begin() if PROF is not None else None
             check(lib.vg_conv3d(C.byref(d), stream()), 'vg_conv3d(dgrad, fused classes) ' + self.name)
             if e0 is not None:
                 PROF.end('conv_dgrad', sum(2.0 * N * math.prod(c['iters']) * self.cin * self.cout * len(c['taps'])
                                            for c in self.d_classes), e0,
                          N * 2 * (math.prod(self.out_dims) * self.cout + math.prod(self.buf_dims) * self.cin), conv_variant(d), self.name)
-            return
+            return use_bs
         for c in self.d_classes:
             t = c.get('tmpl')
             if t is None:
@@ -613,12 +624,14 @@ class ConvLayer:
             d.src0, d.N = _p(dy), N
             d.src_f32 = int(dy.dtype == torch.float32 and self.cout == 1)
             d.out, d.out_f32, d.accumulate = _p(out), int(out.dtype == torch.float32), int(accumulate)
+            d.bstat = C.addressof(bstat) if use_bs else None
             e0 = PROF.begin() if PROF is not None else None
             check(lib.vg_conv3d(C.byref(d), stream()), 'vg_conv3d(dgrad) ' + self.name)
             if e0 is not None:      # algorithmic FLOPs of this parity class: its taps only
                 PROF.end('conv_dgrad', 2.0 * N * math.prod(c['iters']) * self.cin * self.cout * len(c['taps']), e0,
                          N * (4 if self.f32 else 2) * (math.prod(self.out_dims) * self.cout * len(c['taps']) / self.k ** 3
                                                        + math.prod(c['iters']) * self.cin), conv_variant(d), self.name)
+        return use_bs
 
 
 class PackTable:
@@ -659,11 +672,12 @@ def alloc_red(ar: 'Arena', N: int, C_: int) -> torch.Tensor:
     return ar.alloc((STRIPES * N * C_ * 2 + 4,), torch.float32, zero=True)
 
 
-def actnorm_bwd(g, g_padded, x, dims, C_, dx, *, scale=None, shift=None, mult=None, act=ACT_NONE, norm=False,
-                gamma=None, mean=None, rstd=None, red=None, accumulate=False, x1=None, c_x0=0, x0_shift=0,
-                dx_cstride=0, dx_coff=0, dgamma=None, dbeta=None):
-    """stats + apply (+ parameter gradients) of the (InstanceNorm -> act -> dropout) backward.  `red` from alloc_red()
-    (with ticket word: one launch fewer) or a plain zeroed [STRIPES, N, C, 2] tensor."""
+def actnorm_desc(g, g_padded, x, dims, C_, dx, *, scale=None, shift=None, mult=None, act=ACT_NONE, norm=False,
+                 gamma=None, mean=None, rstd=None, red=None, accumulate=False, x1=None, c_x0=0, x0_shift=0,
+                 dx_cstride=0, dx_coff=0, dgamma=None, dbeta=None) -> ActNormBwdDesc:
+    """Descriptor of the (InstanceNorm -> act -> dropout) backward: statistics + apply (+ parameter gradients).  `red` from
+    alloc_red() (with ticket word: one launch fewer) or a plain zeroed [STRIPES, N, C, 2] tensor.  The tensors are kept
+    alive on the descriptor (it may be handed to ConvLayer.dgrad(bstat=...) before actnorm_run)."""
     d = ActNormBwdDesc()
     d.g, d.g_padded = _p(g), int(g_padded)
     d.x, d.x_f32 = _p(x), int(x is not None and x.dtype == torch.float32)
@@ -678,7 +692,21 @@ def actnorm_bwd(g, g_padded, x, dims, C_, dx, *, scale=None, shift=None, mult=No
     d.dgamma, d.dbeta = _p(dgamma), _p(dbeta)      # parameter gradients come out of the statistics pass
     nred = STRIPES * dims[0] * C_ * 2
     d.ticket = (red.data_ptr() + 4 * nred) if (red is not None and red.dim() == 1 and red.numel() == nred + 4) else None
-    check(lib.vg_actnorm_bwd(C.byref(d), stream()), 'vg_actnorm_bwd')       # statistics (when norm) + apply behind one C call
+    d._keep = (g, x, dx, scale, shift, mult, gamma, mean, rstd, red, x1, dgamma, dbeta)
+    return d
+
+
+def actnorm_run(d: ActNormBwdDesc, stats_done: bool = False):
+    """stats_done: the statistics were produced with the data gradient (ConvLayer.dgrad(bstat=d) returned True)."""
+    if stats_done:
+        check(lib.vg_actnorm_bwd_apply(C.byref(d), stream()), 'vg_actnorm_bwd_apply')
+    else:
+        check(lib.vg_actnorm_bwd(C.byref(d), stream()), 'vg_actnorm_bwd')       # statistics (when norm) + apply behind one C call
+
+
+def actnorm_bwd(g, g_padded, x, dims, C_, dx, **kw):
+    """stats + apply (+ parameter gradients) of the (InstanceNorm -> act -> dropout) backward (see actnorm_desc)."""
+    actnorm_run(actnorm_desc(g, g_padded, x, dims, C_, dx, **kw))
 
 
 def concat_bwd(g, dims, Cu, Cs, dlow, dskip):
