@@ -8,7 +8,7 @@ from van_gan_amd.nets import ParamStore
 from van_gan_amd.ops import ConvLayer, Src
 dev = torch.device('cuda:0')
 cases = {'stem': (3, 16, 16, 1, 'reflect', 128, None), 'dec0': (3, 48, 16, 1, 'reflect', 128, (32, 16)), 'enc2': (3, 64, 64, 1, 'reflect', 32, None),
-         'enc1': (3, 32, 32, 1, 'reflect', 64, None), 'down2': (4, 256, 512, 1, 'same', 16, None), 'down0': (4, 64, 128, 2, 'reflect', 64, None), 'down1': (4, 128, 256, 2, 'reflect', 32, None)}
+         'enc1': (3, 32, 32, 1, 'reflect', 64, None), 'down2': (4, 256, 512, 1, 'same', 16, None), 'down0': (4, 64, 128, 2, 'reflect', 64, None), 'bridge': (3, 256, 256, 1, 'reflect', 8, None), 'enc3': (3, 128, 128, 1, 'reflect', 16, None), 'down1': (4, 128, 256, 2, 'reflect', 32, None)}
 name = sys.argv[1] if len(sys.argv) > 1 else 'stem'
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 mode = sys.argv[3] if len(sys.argv) > 3 else 'fwd'

@@ -10,7 +10,8 @@ from van_gan_amd.nets import ParamStore
 from van_gan_amd.ops import ConvLayer, Src
 dev = torch.device('cuda:0')
 cases = {'stem': (3, 16, 16, 1, 'reflect', 128, None), 'dec0': (3, 48, 16, 1, 'reflect', 128, (32, 16)), 'enc2': (3, 64, 64, 1, 'reflect', 32, None),
-         'down2': (4, 256, 512, 1, 'same', 16, None)}
+         'down2': (4, 256, 512, 1, 'same', 16, None), 'bridge': (3, 256, 256, 1, 'reflect', 8, None), 'enc3': (3, 128, 128, 1, 'reflect', 16, None),
+         'dec3': (3, 384, 128, 1, 'reflect', 16, (256, 128))}
 for name in (sys.argv[1:] or list(cases)):
     k, cin, cout, stride, pad, S, cat = cases[name]
     dims = (S,) * 3

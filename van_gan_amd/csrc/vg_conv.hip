@@ -742,7 +742,8 @@ static int fill_conv(const vg_conv_desc* d, GatherIn& g, ConvOut& k, ConvCls& q,
                 if (g2.planar && need2 <= 80 * 1024) { dma = 1; need = need2; }
             }
             // score: reaching 512 workgroups dominates, then work per workgroup-tile (bn*ms), then small LDS
-            const long fill = wgs >= 512 ? 512 : wgs;
+            const long fill_t = vg_tune("CONV_FILL", 128);     // sweep of the 128^3 train step: 512 -> 31.5 ms, 256 -> 30.9, 128 -> 30.6, 64 -> 30.7 (the other lane and the side streams fill the chip)
+            const long fill = wgs >= fill_t ? fill_t : wgs;
             // (useful channels per panel, not the panel width: a 64-wide panel on 48 or 96 output channels multiplies zeros in a
             // quarter of its MFMAs -- there the 32-wide panel with the twice larger voxel tile wins: 16->48 data gradient at 128^3
             // 0.36 -> 0.32 ms)

@@ -405,7 +405,10 @@ extern "C" int vg_conv3d_wgrad(const vg_conv_desc* d, const void* dy, int dy_f32
     int per_cu = (rmax_sel * Q >= VG_WGRAD_2W) ? 2 : 3;
     if (VG_LDS_LIMIT / lds < per_cu) per_cu = VG_LDS_LIMIT / lds;
     if (per_cu < 1) per_cu = 1;
-    const int wg_target = wg_env > 0 ? wg_env : 256 * per_cu;
+    // 384 persistent workgroups (1.5 per CU), not the resident capacity (512 / 768): the weight gradients run on side streams next
+    // to the data-gradient chain of their lane and the other lane's kernels, and a launch that occupies every slot starves those
+    // (128^3 train step: 256 -> 30.44 ms, 320 -> 30.52, 384 -> 30.08..30.21, 448 -> 30.56, 512 -> 30.75, 640 -> 30.99)
+    const int wg_target = wg_env > 0 ? wg_env : (256 * per_cu < 384 ? 256 * per_cu : 384);
     int bx = wg_target / by; if (bx < 1) bx = 1; if (bx > k.total_tiles) bx = k.total_tiles;
     // many workgroups per dW element: float atomics on a few-KB dW serialise (measured 0.7 ms on a 27 KB dW from 1024
     // workgroups), so each workgroup column stores its slab to a private partial buffer that a second kernel sums
