@@ -793,7 +793,8 @@ static int plan_conv32(const vg_conv_desc* d, const ConvOut& k, const ConvCls& q
         // every tile streams its BN x K weight panel from L2 (64 B/clk per CU): 64 voxels per tile give exactly the
         // 64 FLOP/B that the MFMA rate needs, 128 voxels give headroom -- so one workgroup per CU with the big tile beats
         // two with the small one
-        const long fill = wgs >= 256 ? 256 : wgs;
+        const long fill32 = vg_tune("CONV32_FILL", 256);
+        const long fill = wgs >= fill32 ? fill32 : wgs;
         const long score = fill * 1000 + ms * 10 + (need <= 80 * 1024 ? 5 : 0);
         if (score > best) { best = score; best_ms = ms; best_lds = need; }
     }
