@@ -17,4 +17,7 @@ python3 tools/mfma_pmc.py $O/mfma $O/mfma_pmc.json > $O/mfma_pmc.log 2>&1
 python3 tools/roofline_by_kernel.py $O/bench_kernels.json $O/stats 8 $O/fetch $O/write 2 $O/roofline_by_kernel.json > $O/roofline_by_kernel.txt 2>&1
 cp $(find $O/stats -name '*kernel_stats.csv' | head -1) $O/kernel_stats.csv
 rm -rf $O/stats $O/fetch $O/write $O/mfma          # raw traces are large; the summaries above are what gets committed
+cp $O/roofline_by_kernel.json $R/profiles/${tag}_roofline_by_kernel.json; cp $O/roofline_by_kernel.txt $R/profiles/${tag}_roofline_by_kernel.txt
+cp $O/kernel_stats.csv $R/profiles/${tag}_bench128_kernel_stats.csv; cp $O/mfma_pmc.json $R/profiles/${tag}_mfma_pmc.json; cp $O/bench_line.json $R/profiles/${tag}_bench128_line.json
+cp $R/profiles/${tag}_*.* $O/ 2>/dev/null
 tail -3 $O/roofline_by_kernel.txt; cut -c1-300 $O/bench_line.json

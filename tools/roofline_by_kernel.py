@@ -32,12 +32,18 @@ def b(x):
 
 def variant_of(kernel_name: str):
     """rocprof kernel name -> the variant string of vg_conv3d_variant / vg_conv3d_wgrad_variant (without |walk|ch flags)."""
+    if 'pw_wgrad_cc_kernel' in kernel_name:
+        return 'pw_wgrad_cc'
     m = re.search(r'(\w+)_kernel<([^>]*)>', kernel_name)
     if not m:
         return None
     k, args = m.group(1), [a.strip() for a in m.group(2).split(',')]
     if k == 'conv' and len(args) == 8:
         return 'conv<%s,%s,%s,n%s,wl%s,dma%s,mc%s,c1%s>' % (tname(args[0]), args[1], args[2], b(args[3]), b(args[4]), b(args[5]), args[6], b(args[7]))
+    if k == 'conv_thin' and len(args) >= 4:
+        return 'conv_thin<m%s,b%s,r%s,s%s%s>' % (args[0], b(args[1]), b(args[2]), b(args[3]), ',bs' if len(args) > 4 and b(args[4]) == '1' else '')
+    if k == 'pw_gemm' and len(args) == 5:
+        return 'pw_gemm<%s,%s,g%s,a%s>' % (args[0], args[1], b(args[2]), b(args[3]))
     if k == 'conv32' and len(args) == 4:
         return 'conv32<%s,%s,n%s,cp%s>' % (args[0], args[1], b(args[2]), b(args[3]))
     if k == 'conv_pc' and len(args) == 8:
@@ -89,6 +95,7 @@ def main():
     # one template may serve several kinds (forward and data gradient): merge the bench rows per template
     merged = {}
     for r in bench:
+        r['kernel'] = re.sub(r',bs[12]>', ',bs>', re.sub(r'pw_wgrad_cc<r\d+>', 'pw_wgrad_cc', r['kernel']))
         e = merged.setdefault(r['kernel'], {'kinds': [], 'launches': 0, 'ms_events': 0.0, 'gflop': 0.0, 'alg_bytes': 0.0})
         e['kinds'].append(r['kind']); e['launches'] += r['launches']; e['ms_events'] += r['ms']; e['gflop'] += r['gflop']
         e['alg_bytes'] += r['algorithmic_bytes']
