@@ -185,10 +185,19 @@ class VanGan:
             lane_b.wait_stream(main)                                 # inputs copied, arena reset
         def laneB():
             return torch.cuda.stream(lane_b) if lane_b is not None else contextlib.nullcontext()
+        # Lane balance (timeline from HIP events, tools/timeline.py): lane B carries the clDice skeletons, so lane A used to idle
+        # 3.2 ms at the forward join.  Everything of the S-side losses that depends on real_S only (its min-max normalisation and
+        # the TARGET skeleton) and the forward of D_I (needs fake_I only) therefore run on lane A, behind events.
+        it = self.skel_iters
+        dims4 = (B, D, H, W)
+        mmS, nS = ar.alloc((B, 4), f32), ar.alloc(vol, f32)
+        ops.minmax(rS, B, S, mmS); ops.minmax_apply(rS, mmS, B, S, nS)                   # lane A, first thing: lane B needs nS at 5.8 ms
+        ev_nS = main.record_event() if lane_b is not None else None
         c1 = self.gen_IS.forward(ar, rI, fake_S)                     # vangan.py:295   (lane A)
         self._mark('A G1 fwd')
         with laneB():
             c2 = self.gen_SI.forward(ar, rS, fake_I)                 # :297            (lane B)
+            ev_fakeI = lane_b.record_event() if lane_b is not None else None
             self._mark('B G1 fwd')
         c4 = self.gen_SI.forward(ar, fake_S, cyc_I)                  # :305            (lane A)
         self._mark('A G2 fwd')
@@ -196,20 +205,23 @@ class VanGan:
             c3 = self.gen_IS.forward(ar, fake_I, cyc_S)              # :300            (lane B)
             self._mark('B G2 fwd')
 
-        # ---- cycle / segmentation losses on cycled_S (loss_functions.py:185-190, 211-226): lane B ----
-        it = self.skel_iters
-        dims4 = (B, D, H, W)
+        # ---- cycle / segmentation losses on cycled_S (loss_functions.py:185-190, 211-226): lane B; target skeleton: lane A ----
+        imgs_t, skels_t = ar.alloc((it + 2,) + vol, f32), ar.alloc((it + 1,) + vol, f32)
+        ops.soft_skel_fwd(nS, dims4, it, imgs_t, skels_t)                                # lane A
+        ev_skel_t = main.record_event() if lane_b is not None else None
+        self._mark('A target skeleton')
         with laneB():
-            mmS, mmcS = ar.alloc((B, 4), f32), ar.alloc((B, 4), f32)
-            nS, ncS = ar.alloc(vol, f32), ar.alloc(vol, f32)
-            ops.minmax(rS, B, S, mmS); ops.minmax_apply(rS, mmS, B, S, nS)
+            if lane_b is not None:
+                lane_b.wait_event(ev_nS)
+            mmcS = ar.alloc((B, 4), f32)
+            ncS = ar.alloc(vol, f32)
             ops.minmax(cyc_S, B, S, mmcS); ops.minmax_apply(cyc_S, mmcS, B, S, ncS)
             g_ncS = ar.alloc(vol, f32) if do_backward else None
             ops.bce(nS, ncS, acc[0:1], self.lambda_cycle / (B * S * gbs), g_ncS, accumulate=False)
             imgs_p, skels_p = ar.alloc((it + 2,) + vol, f32), ar.alloc((it + 1,) + vol, f32)
-            imgs_t, skels_t = ar.alloc((it + 2,) + vol, f32), ar.alloc((it + 1,) + vol, f32)
             ops.soft_skel_fwd(ncS, dims4, it, imgs_p, skels_p)
-            ops.soft_skel_fwd(nS, dims4, it, imgs_t, skels_t)
+            if lane_b is not None:
+                lane_b.wait_event(ev_skel_t)
             skel_p, skel_t = skels_p[it], skels_t[it]
             sums = ar.alloc((9,), f32, zero=True)
             coef = ar.alloc((8,), f32, zero=True)
@@ -249,8 +261,7 @@ class VanGan:
         logS, logI = ar.alloc((2 * B,) + ld + (1,), f32), ar.alloc((2 * B,) + ld + (1,), f32)
         if training and noise is None:
             nzS, dpS = self._make_noise(self.disc_S, 2 * B, ar)
-            with laneB():
-                nzI, dpI = self._make_noise(self.disc_I, 2 * B, ar)
+            nzI, dpI = self._make_noise(self.disc_I, 2 * B, ar)
         else:
             noise, drop = noise or {}, drop or {}
             nzS, dpS, nzI, dpI = noise.get('S'), drop.get('S'), noise.get('I'), drop.get('I')
@@ -261,12 +272,13 @@ class VanGan:
         ops.mse_const(logS[B:], 1.0, acc[3:4], gd, gS_G)                                  # gen_IS_loss
         ops.mse_const(logS[:B], 1.0, acc[5:6], 0.5 * gd, None if gS_D is None else gS_D[:B])
         ops.mse_const(logS[B:], 0.0, acc[6:7], 0.5 * gd, None if gS_D is None else gS_D[B:])
-        with laneB():
-            dI = self.disc_I.forward(ar, bufI, logI, nzI, dpI)                              # lane B: needs fake_I
-            ops.mse_const(logI[B:], 1.0, acc[4:5], gd, gI_G)                              # gen_SI_loss
-            ops.mse_const(logI[:B], 1.0, acc[7:8], 0.5 * gd, None if gI_D is None else gI_D[:B])
-            ops.mse_const(logI[B:], 0.0, acc[8:9], 0.5 * gd, None if gI_D is None else gI_D[B:])
-            self._mark('B D fwd')
+        self._mark('A D_S fwd')
+        if lane_b is not None:
+            main.wait_event(ev_fakeI)                                                       # fake_I comes from lane B's first generator
+        dI = self.disc_I.forward(ar, bufI, logI, nzI, dpI)                                  # lane A as well: lane B is the longer one
+        ops.mse_const(logI[B:], 1.0, acc[4:5], gd, gI_G)                                  # gen_SI_loss
+        ops.mse_const(logI[:B], 1.0, acc[7:8], 0.5 * gd, None if gI_D is None else gI_D[:B])
+        ops.mse_const(logI[B:], 0.0, acc[8:9], 0.5 * gd, None if gI_D is None else gI_D[B:])
         self._mark('A D fwd')
         if lane_b is not None:
             main.wait_stream(lane_b)                                                        # lanes join before the backward sweeps
@@ -301,6 +313,8 @@ class VanGan:
             if apply:
                 self._schedule_update('disc_S')
             self._mark('A D bwd')
+            # (Moving D_I's D-loss sweep to lane A, whose sweeps finish 3.7 ms before lane B's, was measured: the main lanes then end at
+            # 26.8 / 23.4 ms but lane A's weight-gradient side stream becomes the tail -- 29.9 vs 29.4 ms per step.)
             with laneB():
                 self.disc_I.backward(arB, dI, gI_D, 0, 2 * B, wgrad=True)
                 self._start_allreduce(['disc_I'])
