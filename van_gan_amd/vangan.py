@@ -22,6 +22,7 @@ from .ops import Arena
 
 RESULT_KEYS = ['total_IS_loss', 'total_SI_loss', 'D_I_loss', 'D_S_loss', 'gen_IS_loss', 'gen_SI_loss',
                'cycle_gen_SIS_loss', 'cycle_gen_ISI_loss', 'seg_loss', 'reconstruction_loss_I']
+_BFIRST = int(os.environ.get('VG_BFIRST', '0'))
 NETS = ['gen_IS', 'gen_SI', 'disc_I', 'disc_S']
 
 
@@ -307,45 +308,64 @@ class VanGan:
                 with torch.cuda.stream(self._lane_b2):
                     self.gen_SI.backward(self.arena_b2, c4, g_cI)
                     ops.side_join()
-            self.disc_S.backward(ar, dS, gS_D, 0, 2 * B, wgrad=True)
-            self._start_allreduce(['disc_S'])
-            self.disc_S.backward(ar, dS, gS_G, B, 2 * B, wgrad=False, dx=g_fS)       # still reads D_S's packed weights
-            if apply:
-                self._schedule_update('disc_S')
-            self._mark('A D bwd')
-            # (Moving D_I's D-loss sweep to lane A, whose sweeps finish 3.7 ms before lane B's, was measured: the main lanes then end at
-            # 26.8 / 23.4 ms but lane A's weight-gradient side stream becomes the tail -- 29.9 vs 29.4 ms per step.)
-            with laneB():
-                self.disc_I.backward(arB, dI, gI_D, 0, 2 * B, wgrad=True)
-                self._start_allreduce(['disc_I'])
-                self.disc_I.backward(arB, dI, gI_G, B, 2 * B, wgrad=False, dx=g_fI)
+            def a_disc():
+                self.disc_S.backward(ar, dS, gS_D, 0, 2 * B, wgrad=True)
+                self._start_allreduce(['disc_S'])
+                self.disc_S.backward(ar, dS, gS_G, B, 2 * B, wgrad=False, dx=g_fS)       # still reads D_S's packed weights
                 if apply:
-                    self._schedule_update('disc_I')
-                self._mark('B D bwd')
+                    self._schedule_update('disc_S')
+                self._mark('A D bwd')
+
+            def b_disc():
+                # (Moving D_I's D-loss sweep to lane A, whose sweeps finish 3.7 ms before lane B's, was measured: the main lanes then end
+                # at 26.8 / 23.4 ms but lane A's weight-gradient side stream becomes the tail -- 29.9 vs 29.4 ms per step.)
+                with laneB():
+                    self.disc_I.backward(arB, dI, gI_D, 0, 2 * B, wgrad=True)
+                    self._start_allreduce(['disc_I'])
+                    self.disc_I.backward(arB, dI, gI_G, B, 2 * B, wgrad=False, dx=g_fI)
+                    if apply:
+                        self._schedule_update('disc_I')
+                    self._mark('B D bwd')
+
             mk = ar.mark()
-            self.gen_IS.backward(ar, c1, g_fS); ar.release(mk, defer=True)        # adversarial application
-            self._mark('A G adv bwd')
-            with laneB():
-                mkb = arB.mark()
-                self.gen_SI.backward(arB, c2, g_fI); arB.release(mkb, defer=True)
-                self._mark('B G adv bwd')
-            if four:
-                main.wait_stream(self._lane_a2)
-            else:
-                self.gen_IS.backward(ar, c3, g_cS); ar.release(mk, defer=True)    # cycle application
-                self._mark('A G cyc bwd')
-            self._start_allreduce(['gen_IS'])
-            if apply:
-                self._schedule_update('gen_IS')
-            with laneB():
+            mkb = arB.mark()
+
+            def a_adv():
+                self.gen_IS.backward(ar, c1, g_fS); ar.release(mk, defer=True)        # adversarial application
+                self._mark('A G adv bwd')
+
+            def b_adv():
+                with laneB():
+                    self.gen_SI.backward(arB, c2, g_fI); arB.release(mkb, defer=True)
+                    self._mark('B G adv bwd')
+
+            def a_cyc():
                 if four:
-                    lane_b.wait_stream(self._lane_b2)
+                    main.wait_stream(self._lane_a2)
                 else:
-                    self.gen_SI.backward(arB, c4, g_cI); arB.release(mkb, defer=True)
-                    self._mark('B G cyc bwd')
-                self._start_allreduce(['gen_SI'])
+                    self.gen_IS.backward(ar, c3, g_cS); ar.release(mk, defer=True)    # cycle application
+                    self._mark('A G cyc bwd')
+                self._start_allreduce(['gen_IS'])
                 if apply:
-                    self._schedule_update('gen_SI')
+                    self._schedule_update('gen_IS')
+
+            def b_cyc():
+                with laneB():
+                    if four:
+                        lane_b.wait_stream(self._lane_b2)
+                    else:
+                        self.gen_SI.backward(arB, c4, g_cI); arB.release(mkb, defer=True)
+                        self._mark('B G cyc bwd')
+                    self._start_allreduce(['gen_SI'])
+                    if apply:
+                        self._schedule_update('gen_SI')
+
+            # host enqueue order per stage (bit i of VG_BFIRST: lane B's sweep of stage i is enqueued before lane A's)
+            for i, (fa, fb) in enumerate(((a_disc, b_disc), (a_adv, b_adv), (a_cyc, b_cyc))):
+                if (_BFIRST >> i) & 1:
+                    fb(); fa()
+                else:
+                    fa(); fb()
             if lane_b is not None:
                 main.wait_stream(lane_b)
             ops.side_join()
