@@ -315,6 +315,27 @@ def test_losses_vs_oracle():
     assert rel_l2(gp, pr.grad) < 1e-3
 
 
+def test_soft_skeleton_chain_kernel_is_bitwise_the_per_step_kernels():
+    """The single-launch skeleton chain (all steps of one soft_skel, running skeleton in registers) against the one-launch-per-step
+    kernels it replaces: every intermediate skeleton bit for bit, on a grid with ragged tiles."""
+    from van_gan_amd import ops
+    from van_gan_amd._lib import lib
+    dev = _dev()
+    B, D, H, W, it = 2, 11, 13, 37, 6
+    g = torch.Generator().manual_seed(17)
+    p = torch.rand(B, D, H, W, 1, generator=g).to(dev)
+    vol = (B, D, H, W, 1)
+    out = []
+    for chain in (1, 0):
+        lib.vg_set_tuning(b'SKEL_CHAIN', chain, 0)
+        imgs, skels = torch.zeros((it + 2,) + vol, device=dev), torch.full((it + 1,) + vol, 3.0, device=dev)
+        ops.soft_skel_fwd(p, (B, D, H, W), it, imgs, skels)
+        torch.cuda.synchronize()
+        out.append((imgs.cpu(), skels.cpu()))
+    lib.vg_set_tuning(b'SKEL_CHAIN', 0, 1)
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+
+
 def test_soft_skeleton_and_cldice():
     """soft_skel forward/backward and the Dice+clDice combination vs the oracle (continuous data: no ties)."""
     from van_gan_amd import ops
