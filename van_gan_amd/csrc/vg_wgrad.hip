@@ -26,6 +26,13 @@ struct WgradK {
     float* part; int dw_elems;              // per-workgroup-column partial slabs (no atomics) or NULL
 };
 
+// halo units a thread has in flight per staging batch (each a 16-byte load, plus one of the noise tensor)
+#ifndef VG_WGRAD_UB
+#define VG_WGRAD_UB (NOISE ? VG_WGRAD_UBN : (RMAX * Q > 4 ? 2 : 4))
+#endif
+#ifndef VG_WGRAD_UBN
+#define VG_WGRAD_UBN 4
+#endif
 #ifndef VG_WGRAD_2W
 #define VG_WGRAD_2W 16     // accumulator fragments per wave from which the register cap is 2 waves per SIMD
 #endif
@@ -153,7 +160,7 @@ __global__ __launch_bounds__(256, (RMAX * Q >= VG_WGRAD_2W ? 2 : 3)) void wgrad_
                 else raw_load(yraw[k], (const T*)p.dy + vox * p.Cout + (yok[k] ? c : 0));
             }
         }
-        if (!(g.dbg & 1) || tile == (int)blockIdx.x) stage_halo_tile<T, NOISE, (RMAX * Q > 4 ? 2 : 4)>(g, halo, scs, utab, rt, n, od0, cib, tid);
+        if (!(g.dbg & 1) || tile == (int)blockIdx.x) stage_halo_tile<T, NOISE, VG_WGRAD_UB>(g, halo, scs, utab, rt, n, od0, cib, tid);
         if (tile + (int)gridDim.x < p.total_tiles) {      // axis tables of the next tile into the other buffer
             stage_resolve_axes(g, rtab + ((it + 1) & 1) * RTN, ti_h << g.thl, ti_w << g.twl, tid);
         }
