@@ -120,7 +120,8 @@ typedef struct {
     /* Optional (data-gradient launches): the STATISTICS pass of the IN backward that consumes this launch's output (g == out,
        bf16, one launch covering the whole grid, no accumulate).  The 16-channel specialist accumulates sum dn and sum dn*xhat
        in its epilogue -- the upstream gradient is not re-read from HBM -- other kernels are followed by vg_actnorm_bwd_stats.
-       Either way red[stripe 0] (and dgamma / dbeta) are final when the call returns; the caller then runs vg_actnorm_bwd_apply. */
+       Either way the striped sums in red are complete when the call returns; the caller then runs vg_actnorm_bwd_apply (which adds
+       the stripes up and produces dgamma / dbeta). */
     const struct vg_actnorm_bwd_desc_s* bstat;
 } vg_conv_desc;
 
@@ -202,10 +203,9 @@ typedef struct vg_actnorm_bwd_desc_s {
     void* dx; int32_t dx_f32; int32_t accumulate;
     int32_t dx_cstride, dx_coff;              /* dx channel stride / offset (write into a slice) */
     int32_t f32;                              /* exact-parity mode: g, x, x1 and dx are float32 */
-    float* dgamma;                            /* optional [C]: the statistics pass itself adds d/d gamma and d/d beta of the */
-    float* dbeta;                             /* InstanceNorm (summed over samples) instead of a separate vg_in_param_grads */
-    int32_t* ticket;        /* optional: zero-initialised int; when given, the LAST workgroup of vg_actnorm_bwd_stats folds
-                               the striped sums (and the gamma/beta gradients) itself instead of a second launch */
+    float* dgamma;                            /* optional [C]: the APPLY pass adds d/d gamma and d/d beta of the InstanceNorm */
+    float* dbeta;                             /* (summed over samples and stripes) instead of a separate vg_in_param_grads */
+    int32_t* ticket;        /* unused (the stripes are added up by the apply pass); kept for layout stability */
 } vg_actnorm_bwd_desc;
 int vg_actnorm_bwd_stats(const vg_actnorm_bwd_desc* d, vg_stream_t stream);
 int vg_actnorm_bwd_apply(const vg_actnorm_bwd_desc* d, vg_stream_t stream);

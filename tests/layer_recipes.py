@@ -288,10 +288,13 @@ def run_recipe(recipe, expect_variant, dev, seed=1, precision='bf16'):
         dn = gf * torch.where(pre > 0, torch.ones_like(pre), torch.full_like(pre, slope))
         xh = (xf - v(bmu)) * v(brs)
         ref_red = torch.stack([dn.sum(dim=(1, 2, 3)), (dn * xh).sum(dim=(1, 2, 3))], dim=-1)
-        got_red = red[:N * L['cin'] * 2].view(N, L['cin'], 2)
+        got_red = red[:ops.STRIPES * N * L['cin'] * 2].view(ops.STRIPES, N, L['cin'], 2).sum(0)       # striped: the apply pass adds them up
         assert rel_l2(got_red, ref_red) < 2e-3, 'fused IN-backward statistics rel %.2e' % rel_l2(got_red, ref_red)
-        assert float(red[N * L['cin'] * 2:ops.STRIPES * N * L['cin'] * 2].abs().max()) == 0.0          # stripes folded and cleared
+        ops.actnorm_run(bdesc, stats_done=True)                                                     # apply: dx and the gamma / beta gradients
+        torch.cuda.synchronize()
         assert rel_l2(dbet, ref_red[..., 0].sum(0)) < 2e-3 and rel_l2(dgam, ref_red[..., 1].sum(0)) < 2e-3
+        ref_dx = v(brs) * (dn - ref_red[..., 0].view(N, 1, 1, 1, -1) / dn[0, ..., 0].numel() - xh * ref_red[..., 1].view(N, 1, 1, 1, -1) / dn[0, ..., 0].numel())
+        assert rel_l2(dxo, ref_dx) < 1e-2, 'IN backward after fused statistics rel %.2e' % rel_l2(dxo, ref_dx)
     xin = torch.zeros(N, L['cin'], *lay.buf_dims, dtype=dt, requires_grad=True)
     (O.conv3d(xin, w_ref, None, stride, conv_pad) * dy_ref).sum().backward()
     ref = O.to_ndhwc(xin.grad)

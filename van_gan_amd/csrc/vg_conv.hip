@@ -957,7 +957,7 @@ extern "C" int vg_conv3d(const vg_conv_desc* d, vg_stream_t stream) {
     bool did_stats = false;
     const int rc = conv3d_impl(d, stream, did_stats);
     if (rc != VG_OK || !b || vg_dry_on()) return rc;
-    if (did_stats) { vg_launch_anb_fold(b->red, b->N, b->C, b->dgamma, b->dbeta, (hipStream_t)stream); return vg_check_launch(); }
+    if (did_stats) return rc;                       // the epilogue left the striped sums in b->red; the apply pass adds them up
     return vg_actnorm_bwd_stats(b, stream);
 }
 

@@ -252,36 +252,6 @@ __global__ __launch_bounds__(256) void actnorm_stats_kernel(const ANB p) {
     const int stripe = blockIdx.x & (VG_STRIPES - 1);
     float* dst = p.red + ((size_t)stripe * p.N + n) * p.C * 2;
     for (int i = tid; i < p.C * 2; i += 256) atomicAdd(&dst[i], red[i]);
-    if (p.ticket) {
-        // The workgroup that draws the last ticket folds the stripes (what anb_fold_stripes_kernel does in a launch of its
-        // own: ~5 us each, 128 per train step).  Float atomics execute at the memory side and leave nothing in L1 / L2, so
-        // after every workgroup's atomics have been waited for (vmcnt) and released, plain loads behind an agent-scope
-        // acquire see the final sums (MI355X_MICROARCH.md, Global float atomics / inter-workgroup visibility).
-        __shared__ int is_last;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const int t = __hip_atomic_fetch_add(p.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            is_last = t == (int)(gridDim.x * gridDim.y) - 1;
-            if (is_last) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-        }
-        __syncthreads();
-        if (is_last) {
-            const int total = p.N * p.C * 2;
-            for (int i = tid; i < total; i += 256) {
-                float a = 0.f;
-                for (int t = 0; t < VG_STRIPES; ++t) {
-                    a += __hip_atomic_load(&p.red[(size_t)t * total + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (t) p.red[(size_t)t * total + i] = 0.f;
-                }
-                p.red[i] = a;
-                if (p.dgamma) { const int c = (i >> 1) % p.C; atomicAdd((i & 1) ? &p.dgamma[c] : &p.dbeta[c], a); }
-            }
-            if (tid == 0) *p.ticket = 0;
-        }
-    }
 }
 
 // stripe 0 += stripes 1..7, which are then cleared (a later sum over all stripes stays correct): the apply pass and the
@@ -307,16 +277,32 @@ __global__ __launch_bounds__(256) void actnorm_apply_kernel(const ANB p) {
     const int cg = tid % p.gpc, vl = tid / p.gpc;
     const int S = p.D * p.H * p.W;
     const int c = cg * VEC;
-    // coefficients of dx = k0*dn - k1 - k2*xhat; the striped sums were folded into stripe 0 after the statistics pass
+    // coefficients of dx = k0*dn - k1 - k2*xhat
     float k0[VEC], k1[VEC], k2[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) { k0[j] = 1.f; k1[j] = 0.f; k2[j] = 0.f; }
     if (p.norm) {
+        // the striped sums of the statistics pass (or of the data-gradient epilogue that carried it) are added up HERE, by every
+        // thread for its own channels -- a fold at the end of the statistics kernel (last-workgroup ticket: fence, returning
+        // atomic, acquire, fold loop) or a fold launch cost more than these 8 x 2 vector loads per thread
         const int nc = n * p.C + c;
+        const size_t total = (size_t)p.N * p.C * 2;
         float gm[VEC], rs[VEC], r[2 * VEC];
         ldvec(p.gamma + c, gm, VEC); ldvec(p.rstd + nc, rs, VEC);
-        ldvec(p.red + (size_t)nc * 2, r, VEC);
-        if (VEC == 8) ldvec(p.red + (size_t)nc * 2 + 8, r + 8, VEC); else r[1] = p.red[(size_t)nc * 2 + 1];
+#pragma unroll
+        for (int j = 0; j < 2 * VEC; ++j) r[j] = 0.f;
+#pragma unroll
+        for (int t = 0; t < VG_STRIPES; ++t) {
+            float q[2 * VEC];
+            ldvec(p.red + t * total + (size_t)nc * 2, q, VEC);
+            if (VEC == 8) ldvec(p.red + t * total + (size_t)nc * 2 + 8, q + 8, VEC); else q[1] = p.red[t * total + (size_t)nc * 2 + 1];
+#pragma unroll
+            for (int j = 0; j < 2 * VEC; ++j) r[j] += q[j];
+        }
+        if (p.dgamma && blockIdx.x == 0 && vl == 0) {          // sum(dn) is d/d beta, sum(dn * xhat) is d/d gamma (summed over samples)
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) { atomicAdd(&p.dbeta[c + j], r[2 * j]); atomicAdd(&p.dgamma[c + j], r[2 * j + 1]); }
+        }
         const float cnt = (float)S;
 #pragma unroll
         for (int j = 0; j < VEC; ++j) { const float gr = gm[j] * rs[j]; k0[j] = gr; k1[j] = gr * r[2 * j] / cnt; k2[j] = gr * r[2 * j + 1] / cnt; }
@@ -402,12 +388,7 @@ extern "C" int vg_actnorm_bwd_stats(const vg_actnorm_bwd_desc* d, vg_stream_t st
         if (p.C == 1) hipLaunchKernelGGL((actnorm_stats_kernel<bf16_t, 1>), anb_grid(p, true), dim3(256), 0, (hipStream_t)stream, p);
         else hipLaunchKernelGGL((actnorm_stats_kernel<bf16_t, 8>), anb_grid(p, true), dim3(256), 0, (hipStream_t)stream, p);
     }
-    if (!p.ticket) {          // no ticket word: the stripes are folded by a second launch
-        const int total = p.N * p.C * 2;
-        hipLaunchKernelGGL(anb_fold_stripes_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, p.red, total, p.C,
-                           d->dgamma && d->dbeta ? d->dgamma : nullptr, d->dbeta);
-    }
-    return vg_check_launch();
+    return vg_check_launch();          // red stays striped: the apply pass adds the stripes up (and the gamma / beta gradients)
 }
 extern "C" int vg_actnorm_bwd_apply(const vg_actnorm_bwd_desc* d, vg_stream_t stream) {
     vg_begin();
