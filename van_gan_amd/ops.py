@@ -173,6 +173,7 @@ PROF: Optional[KernelProfile] = None
 # alone leaves most CUs idle.  The side stream waits for the producer of dY; the main stream waits for the side stream
 # before arena memory is recycled (Arena.release) and before the gradients are consumed (side_join).
 LAZY_RELEASE = os.environ.get('VG_LAZY_RELEASE', '1') != '0'
+FORK_SHORT = os.environ.get('VG_FORK_SHORT', '1') != '0'   # forward shortcut branches on the lane's side stream
 BSTAT = os.environ.get('VG_BSTAT', '1') != '0'       # IN-backward statistics with the data-gradient launch (ConvLayer.dgrad(bstat=...))
 SIDE: Optional[bool] = None                   # truthy: weight-gradient side streams enabled (one per issuing stream)
 _SIDE_OF = {}                                  # (device index, issuing stream handle) -> its side stream.  The default stream
@@ -194,6 +195,34 @@ def _side_of(cur: torch.cuda.Stream) -> torch.cuda.Stream:
     if sd is None:
         sd = _SIDE_OF[_side_key(cur)] = torch.cuda.Stream(device=cur.device)
     return sd
+
+
+class fork_side:
+    """with fork_side() as f: ...launches...; f.join() -- the block runs on the current stream's side stream behind everything the
+    current stream has issued so far; join() makes the current stream wait for it.  Serial (a no-op) when side streams are off,
+    in the per-launch timing pass and in dry runs."""
+
+    def __init__(self):
+        self.on = SIDE is not None and PROF is None and DRY is None and FORK_SHORT
+        self.cur = self.sd = self.ctx = None
+
+    def __enter__(self):
+        if self.on:
+            self.cur = current_stream_obj()
+            self.sd = _side_of(self.cur)
+            self.sd.wait_stream(self.cur)
+            self.ctx = torch.cuda.stream(self.sd)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.ctx.__exit__(*exc)
+        return False
+
+    def join(self):
+        if self.on:
+            self.cur.wait_stream(self.sd)
 
 
 def side_join():
