@@ -11,22 +11,22 @@ rI, rS = synth_volumes(1, size, size, size, seed=1)
 rI, rS = rI.cuda(), rS.cuda()
 eng.train_step(rI, rS)
 rec = []
-_orig = ops.actnorm_bwd
-def wrapped(g, g_padded, x, dims, C_, dx, **kw):
+_orig = ops.actnorm_run
+def wrapped(d, stats_done=False):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(); r = _orig(g, g_padded, x, dims, C_, dx, **kw); e1.record()
-    key = (tuple(dims), C_, bool(g_padded), bool(kw.get('norm')), bool(kw.get('accumulate')), kw.get('x1') is not None, kw.get('dx_cstride', 0))
+    e0.record(); r = _orig(d, stats_done); e1.record()
+    key = ((d.N, d.D, d.H, d.W), d.C, bool(d.g_padded), bool(d.norm), bool(d.accumulate), bool(d.x1), 'apply only' if stats_done else 'stats+apply')
     rec.append((key, e0, e1)); return r
-ops.actnorm_bwd = wrapped
+ops.actnorm_run = wrapped
 import van_gan_amd.nets as nets
-nets.ops.actnorm_bwd = wrapped
+nets.ops.actnorm_run = wrapped
 eng.train_step(rI, rS)
 torch.cuda.synchronize()
 agg = collections.defaultdict(lambda: [0, 0.0])
 for key, e0, e1 in rec:
     agg[key][0] += 1; agg[key][1] += e0.elapsed_time(e1)
 tot = sum(v[1] for v in agg.values())
-print('total actnorm_bwd (stats+apply) %.2f ms in %d calls' % (tot, len(rec)))
+print('total IN backward (statistics where not carried by the data gradient, + apply) %.2f ms in %d calls' % (tot, len(rec)))
 for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:25]:
     N, D, H, W = k[0]
     gb = N * D * H * W * k[1] * (10 if k[3] else 6) / 1e9
