@@ -186,7 +186,8 @@ int vg_in_finalize(const float* sums0, int c0, float count0, const float* sums1,
 /* Backward of  a = mult * act(x*scale+shift)  [InstanceNorm -> activation -> dropout], with the
  * upstream gradient g read either plain ([N][D][H][W][C]) or folded from the reflect-padded grid
  * ([N][D+2][H+2][W+2][C], transpose of ReflectionPadding3D).
- * pass 1 (stats):  red[n][c][0] += sum dn,  red[n][c][1] += sum dn*xhat,   dn = g*mult*act'(.)
+ * pass 1 (stats):  red[stripe][n][c][0] += sum dn,  red[stripe][n][c][1] += sum dn*xhat,   dn = g*mult*act'(.)   (striped partial
+ *                  sums; the apply pass adds the stripes up and produces dgamma / dbeta)
  * pass 2 (apply):  dx (+)= gamma*rstd*(dn - mean(dn) - xhat*mean(dn*xhat))      (norm=1)
  *                  dx (+)= dn                                                     (norm=0)
  * x is bf16 (x_f32=0) ; g is bf16; dx is bf16 unless dx_f32. */
