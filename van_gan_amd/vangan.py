@@ -23,6 +23,7 @@ from .ops import Arena
 RESULT_KEYS = ['total_IS_loss', 'total_SI_loss', 'D_I_loss', 'D_S_loss', 'gen_IS_loss', 'gen_SI_loss',
                'cycle_gen_SIS_loss', 'cycle_gen_ISI_loss', 'seg_loss', 'reconstruction_loss_I']
 _BFIRST = int(os.environ.get('VG_BFIRST', '0'))
+_NOJOIN = os.environ.get('VG_NOJOIN', '1') != '0'
 NETS = ['gen_IS', 'gen_SI', 'disc_I', 'disc_S']
 
 
@@ -281,8 +282,15 @@ class VanGan:
         ops.mse_const(logI[:B], 1.0, acc[7:8], 0.5 * gd, None if gI_D is None else gI_D[:B])
         ops.mse_const(logI[B:], 0.0, acc[8:9], 0.5 * gd, None if gI_D is None else gI_D[B:])
         self._mark('A D fwd')
+        # No full join before the backward sweeps (VG_NOJOIN): lane A's discriminator sweeps and its adversarial generator sweep need
+        # nothing of lane B; only its cycle sweep (c3 ran on lane B, g_cS comes out of lane B's clDice) waits for lane B's forward.
+        nojoin = lane_b is not None and do_backward and self._lane_a2 is None and _NOJOIN
+        ev_bfwd = None
         if lane_b is not None:
-            main.wait_stream(lane_b)                                                        # lanes join before the backward sweeps
+            if nojoin:
+                ev_bfwd = lane_b.record_event()
+            else:
+                main.wait_stream(lane_b)                                                    # lanes join before the backward sweeps
 
         if do_backward:
             for st in self.stores.values():
@@ -340,6 +348,8 @@ class VanGan:
                     self._mark('B G adv bwd')
 
             def a_cyc():
+                if ev_bfwd is not None:
+                    main.wait_event(ev_bfwd)                                          # c3 and g_cS are lane B's
                 if four:
                     main.wait_stream(self._lane_a2)
                 else:
