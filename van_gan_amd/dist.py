@@ -25,15 +25,18 @@ class GradSync:
         self.pending: Dict[str, object] = {}        # bucket name -> CUDA event on the comm stream / async work handle
         self.rank = dist.get_rank(process_group) if process_group is not None else 0
 
-    def start(self, names: Iterable[str]):
+    def start(self, names: Iterable[str], also=None):
         """Issue the all-reduce of these buckets; on GPU it runs on the side stream behind everything already queued
-        on the current stream, so the remaining backward sweeps overlap with it."""
+        on the current stream (and behind the event `also`: the weight gradients a lane handed to ITS side stream), so the
+        remaining backward sweeps overlap with it."""
         if self.world == 1:
             return
         if self.stream is not None:
             ev = torch.cuda.Event()
             ev.record()
             self.stream.wait_event(ev)
+            if also is not None:
+                self.stream.wait_event(also)
             with torch.cuda.stream(self.stream):
                 for n in names:
                     dist.all_reduce(self.buckets[n], op=dist.ReduceOp.SUM, group=self.pg)

@@ -225,6 +225,14 @@ class fork_side:
             self.cur.wait_stream(self.sd)
 
 
+def side_event():
+    """An event behind everything the current stream has handed to its side stream so far (None: no side stream in use)."""
+    if SIDE is None:
+        return None
+    sd = _SIDE_OF.get(_side_key(current_stream_obj()))
+    return None if sd is None else sd.record_event()
+
+
 def side_join():
     """The current stream waits for every weight-gradient launch it handed to its side stream."""
     if SIDE is not None:

@@ -24,6 +24,7 @@ RESULT_KEYS = ['total_IS_loss', 'total_SI_loss', 'D_I_loss', 'D_S_loss', 'gen_IS
                'cycle_gen_SIS_loss', 'cycle_gen_ISI_loss', 'seg_loss', 'reconstruction_loss_I']
 _BFIRST = int(os.environ.get('VG_BFIRST', '0'))
 _NOJOIN = os.environ.get('VG_NOJOIN', '1') != '0'
+_LAZY_AR = os.environ.get('VG_LAZY_AR', '1') != '0'
 NETS = ['gen_IS', 'gen_SI', 'disc_I', 'disc_S']
 
 
@@ -106,6 +107,7 @@ class VanGan:
         # waits only for ITS gradient bucket (all-reduce event), while the other networks' backward sweeps still run
         self._opt = torch.cuda.Stream(device=self.device) if os.environ.get('VG_OPT_STREAM', '1') != '0' else None
         self._tl = [] if os.environ.get('VG_TIMELINE') == '1' else None
+        self._side_ev = {}
         self.checkpoint_dir = None
         if output_dir is not None:
             self.checkpoint_dir = os.path.join(output_dir, 'checkpoints')
@@ -318,7 +320,7 @@ class VanGan:
                     ops.side_join()
             def a_disc():
                 self.disc_S.backward(ar, dS, gS_D, 0, 2 * B, wgrad=True)
-                self._start_allreduce(['disc_S'])
+                self._start_allreduce(['disc_S'], lazy=apply)
                 self.disc_S.backward(ar, dS, gS_G, B, 2 * B, wgrad=False, dx=g_fS)       # still reads D_S's packed weights
                 if apply:
                     self._schedule_update('disc_S')
@@ -329,7 +331,7 @@ class VanGan:
                 # at 26.8 / 23.4 ms but lane A's weight-gradient side stream becomes the tail -- 29.9 vs 29.4 ms per step.)
                 with laneB():
                     self.disc_I.backward(arB, dI, gI_D, 0, 2 * B, wgrad=True)
-                    self._start_allreduce(['disc_I'])
+                    self._start_allreduce(['disc_I'], lazy=apply)
                     self.disc_I.backward(arB, dI, gI_G, B, 2 * B, wgrad=False, dx=g_fI)
                     if apply:
                         self._schedule_update('disc_I')
@@ -355,7 +357,7 @@ class VanGan:
                 else:
                     self.gen_IS.backward(ar, c3, g_cS); ar.release(mk, defer=True)    # cycle application
                     self._mark('A G cyc bwd')
-                self._start_allreduce(['gen_IS'])
+                self._start_allreduce(['gen_IS'], lazy=apply)
                 if apply:
                     self._schedule_update('gen_IS')
 
@@ -366,7 +368,7 @@ class VanGan:
                     else:
                         self.gen_SI.backward(arB, c4, g_cI); arB.release(mkb, defer=True)
                         self._mark('B G cyc bwd')
-                    self._start_allreduce(['gen_SI'])
+                    self._start_allreduce(['gen_SI'], lazy=apply)
                     if apply:
                         self._schedule_update('gen_SI')
 
@@ -377,6 +379,8 @@ class VanGan:
                 else:
                     fa(); fb()
             if lane_b is not None:
+                with laneB():
+                    ops.side_join()                 # lane B's weight gradients (its lane no longer waits for them on the way)
                 main.wait_stream(lane_b)
             ops.side_join()
             if apply and self._opt is not None:
@@ -400,7 +404,17 @@ class VanGan:
         return dict(zip(RESULT_KEYS, vals))
 
     # ------------------------------------------------------------------------------------------------
-    def _start_allreduce(self, names):
+    def _start_allreduce(self, names, lazy: bool = False):
+        """The gradient buckets `names` are complete once the current lane AND its weight-gradient side stream have run what was
+        issued so far.  lazy (an optimizer step follows on the optimizer stream): the lane itself does not wait for its side
+        stream -- the all-reduce stream and the optimizer stream do (it used to stall, e.g. between the two discriminator sweeps,
+        until the discriminator's weight gradients had finished)."""
+        if lazy and self._opt is not None and ops.PROF is None and _LAZY_AR:
+            ev = ops.side_event()
+            for n in names:
+                self._side_ev[n] = ev
+            self.sync.start(names, also=ev)
+            return
         ops.side_join()                     # the weight gradients of these networks were issued on the side stream
         self.sync.start(names)
 
@@ -428,6 +442,9 @@ class VanGan:
         ev = torch.cuda.Event()
         ev.record()
         self._opt.wait_event(ev)
+        sev = self._side_ev.pop(name, None)
+        if sev is not None:
+            self._opt.wait_event(sev)           # ... and the weight gradients of this network on the lane's side stream
         with torch.cuda.stream(self._opt):
             self.sync.finish([name])
             self._adam(name)
