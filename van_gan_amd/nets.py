@@ -353,8 +353,11 @@ class ResUNet:
             ops.concat_bwd(dcat, (N,) + tuple(cb1.in_dims), low.C, skip.C, low.grad, skip.grad)
         ar.release(mk, defer=True)
 
-    def backward(self, ar: Arena, ctx: dict, gy: torch.Tensor):
-        """gy: fp32 [N,D,H,W,1] gradient w.r.t. the tanh output.  Adds parameter gradients into store.g."""
+    def backward(self, ar: Arena, ctx: dict, gy: torch.Tensor, inline_from: int = -1):
+        """gy: fp32 [N,D,H,W,1] gradient w.r.t. the tanh output.  Adds parameter gradients into store.g.
+        inline_from (the LAST sweep of a lane): the weight gradients of encoder blocks <= inline_from and of the stem are launched on
+        the lane itself instead of its side stream -- at the end of a step the side stream is a couple of milliseconds behind the
+        lanes, which have nothing left to do."""
         N = ctx['N']
         L, Nn = self.L, self.Nn
         # gradient buffers of every tensor that has more than one consumer / is read across blocks
@@ -386,7 +389,11 @@ class ResUNet:
         self._norm_bwd(ar, dp, True, b['sb1'], b['nb1'], Nn['bridge.cb1'], b['inp'].grad, ACT_RELU, accumulate=True)
         ar.release(mk, defer=True)
         for e in (4, 3, 2, 1):
+            if e <= inline_from:
+                ops.WGRAD_INLINE = True          # (see backward(): the sweep's last weight gradients on the lane itself)
             self._block_bwd(ar, 'enc%d' % e, ctx['enc%d' % e], N)
+        if inline_from >= 0:
+            ops.WGRAD_INLINE = True
         # stem
         s = ctx['stem']
         d_out = s['out'].grad
@@ -400,6 +407,7 @@ class ResUNet:
         self._dgrad_norm_bwd(ar, cb, d_out, N, dp, s['s1'], s['n1'], Nn['stem.cb'], d_c1, ACT_RELU, accumulate=False)
         L['stem.conv1'].wgrad(s['sx'], d_c1)
         L['stem.short'].wgrad(s['sx'], d_sc)
+        ops.WGRAD_INLINE = False
 
 
 # ======================================================================================================

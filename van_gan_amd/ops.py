@@ -172,6 +172,7 @@ PROF: Optional[KernelProfile] = None
 # and the data-gradient chain (dY -> dX -> IN backward -> next layer) are independent, and on the small deep layers either
 # alone leaves most CUs idle.  The side stream waits for the producer of dY; the main stream waits for the side stream
 # before arena memory is recycled (Arena.release) and before the gradients are consumed (side_join).
+WGRAD_INLINE = False        # set by ResUNet.backward for the tail of a lane's last sweep
 LAZY_RELEASE = os.environ.get('VG_LAZY_RELEASE', '1') != '0'
 FORK_SHORT = os.environ.get('VG_FORK_SHORT', '1') != '0'   # forward shortcut branches on the lane's side stream
 BSTAT = os.environ.get('VG_BSTAT', '1') != '0'       # IN-backward statistics with the data-gradient launch (ConvLayer.dgrad(bstat=...))
@@ -539,7 +540,7 @@ class ConvLayer:
                      src.N * esz * (math.prod(self.in_dims) * self.cin + math.prod(self.out_dims) * self.cout), conv_variant(d), self.name)
 
     def wgrad(self, src: Src, dy: torch.Tensor):
-        if SIDE is not None and PROF is None and DRY is None:   # the per-launch timing pass serialises (attributable durations)
+        if SIDE is not None and PROF is None and DRY is None and not WGRAD_INLINE:   # the per-launch timing pass serialises (attributable durations)
             cur = current_stream_obj()
             sd = _side_of(cur)
             sd.wait_stream(cur)                                  # dY (and everything before it) is ready

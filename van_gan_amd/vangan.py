@@ -25,6 +25,7 @@ RESULT_KEYS = ['total_IS_loss', 'total_SI_loss', 'D_I_loss', 'D_S_loss', 'gen_IS
 _BFIRST = int(os.environ.get('VG_BFIRST', '0'))
 _NOJOIN = os.environ.get('VG_NOJOIN', '1') != '0'
 _LAZY_AR = os.environ.get('VG_LAZY_AR', '1') != '0'
+_INLINE = int(os.environ.get('VG_WGRAD_INLINE', '1'))      # sweep: off 28.28, stem 28.13, enc1 + stem 28.05, all encoder blocks 28.08 ms
 NETS = ['gen_IS', 'gen_SI', 'disc_I', 'disc_S']
 
 
@@ -355,7 +356,7 @@ class VanGan:
                 if four:
                     main.wait_stream(self._lane_a2)
                 else:
-                    self.gen_IS.backward(ar, c3, g_cS); ar.release(mk, defer=True)    # cycle application
+                    self.gen_IS.backward(ar, c3, g_cS, inline_from=_INLINE); ar.release(mk, defer=True)    # cycle application
                     self._mark('A G cyc bwd')
                 self._start_allreduce(['gen_IS'], lazy=apply)
                 if apply:
@@ -366,7 +367,7 @@ class VanGan:
                     if four:
                         lane_b.wait_stream(self._lane_b2)
                     else:
-                        self.gen_SI.backward(arB, c4, g_cI); arB.release(mkb, defer=True)
+                        self.gen_SI.backward(arB, c4, g_cI, inline_from=_INLINE); arB.release(mkb, defer=True)
                         self._mark('B G cyc bwd')
                     self._start_allreduce(['gen_SI'], lazy=apply)
                     if apply:
