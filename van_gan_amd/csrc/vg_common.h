@@ -87,8 +87,6 @@ bool vg_dry(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
 void vg_dry_begin(char* buf, int n);
 void vg_dry_end();
 
-// vg_elem.hip: stripe 0 += stripes 1.. of red[VG_STRIPES][N][C][2] (then cleared), dgamma / dbeta += the folded sums
-void vg_launch_anb_fold(float* red, int N, int C, float* dgamma, float* dbeta, hipStream_t s);
 bool vg_dry_on();
 // a sticky error left by an earlier, unrelated HIP call in this thread must not be blamed on our launch
 static inline void vg_begin() { (void)hipGetLastError(); }

@@ -16,7 +16,6 @@
 //   * staging is the lean routine (vg_gather.h) with a compile-time transform, its 360 columns x 2 D-segments dealt out evenly.
 // Everything else (persistent workgroups, tables, InstanceNorm statistics carried in registers) follows conv_kernel.
 #include "vg_conv_common.h"
-#include <stdio.h>
 #include <type_traits>
 
 namespace {
@@ -274,10 +273,6 @@ int vg_conv_thin_lds_bytes(const GatherIn& g) {
 // Does this launch have the one shape the specialist serves?  (g from fill_gather for a 512-voxel tile)
 bool vg_conv_thin_ok(const vg_conv_desc* d, const GatherIn& g, const ConvOut& k, const ConvCls& q) {
     if (!vg_tune("CONV_THIN", 1)) return false;
-    if (vg_tune("DEBUG_THIN", 0))
-        fprintf(stderr, "thin? f32 %d noise %p ncls %d istr %d ostr %d CK %d ntaps %d wpack %d Cin %d Cout %d tanh %d acc %d of32 %d lean %d planar %d HW %d HH %d HD %d HWp %d HHp %d DS %d PSB %d tile %d %d %d Ktot %d nch %d res %p bias %p\n",
-                d->f32, d->noise, q.ncls, d->istr, d->ostr, d->CK, d->ntaps, d->wpack, d->c_src0 + d->c_src1, d->Cout, d->tanh_out, d->accumulate,
-                d->out_f32, g.lean, g.planar, g.HW, g.HH, g.HD, g.HWp, g.HHp, g.DS, g.PSB, 1 << g.twl, 1 << g.thl, 1 << g.tdl, k.Ktot, k.nchunks, d->res, (const void*)d->bias);
     if (d->f32 || d->noise || q.ncls != 1 || d->istr != 1 || d->ostr != 1 || d->CK != 16 || d->ntaps != 27 || d->wpack) return false;
     if ((d->c_src0 + d->c_src1) % 16 || (d->Cout % 16) || d->tanh_out || d->accumulate || d->out_f32) return false;
     if (g.lean != VG_STAGE_PLAIN && g.lean != VG_STAGE_RELU) return false;

@@ -254,20 +254,6 @@ __global__ __launch_bounds__(256) void actnorm_stats_kernel(const ANB p) {
     for (int i = tid; i < p.C * 2; i += 256) atomicAdd(&dst[i], red[i]);
 }
 
-// stripe 0 += stripes 1..7, which are then cleared (a later sum over all stripes stays correct): the apply pass and the
-// parameter-gradient kernel read 2 values per channel instead of 16
-__global__ void anb_fold_stripes_kernel(float* red, int total, int C, float* dgamma, float* dbeta) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    float a = red[i];
-    for (int t = 1; t < VG_STRIPES; ++t) { a += red[(size_t)t * total + i]; red[(size_t)t * total + i] = 0.f; }
-    red[i] = a;
-    if (dgamma) {            // i = (n*C + c)*2 + moment: sum(dn) is d/d beta, sum(dn*xhat) is d/d gamma
-        const int c = (i >> 1) % C;
-        atomicAdd((i & 1) ? &dgamma[c] : &dbeta[c], a);
-    }
-}
-
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void actnorm_apply_kernel(const ANB p) {
     const int n = blockIdx.y;
@@ -369,11 +355,6 @@ static dim3 anb_grid(const ANB& p, bool stats = false) {
     if (cap < 1) cap = 1;
     if (bx > cap) bx = cap;
     return dim3(bx, p.N);
-}
-
-void vg_launch_anb_fold(float* red, int N, int C, float* dgamma, float* dbeta, hipStream_t s) {
-    const int total = N * C * 2;
-    hipLaunchKernelGGL(anb_fold_stripes_kernel, dim3((total + 255) / 256), dim3(256), 0, s, red, total, C, dgamma && dbeta ? dgamma : nullptr, dbeta);
 }
 
 extern "C" int vg_actnorm_bwd_stats(const vg_actnorm_bwd_desc* d, vg_stream_t stream) {
