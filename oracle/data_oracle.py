@@ -101,10 +101,12 @@ def learning_rate_resumed(initial_lr, resume_epoch, epoch, step_in_epoch, epochs
     past INITIATE_LR_DECAY: the decay restarts from INITIAL_LR / (EPOCHS - INITIATE) * (EPOCHS - resume_epoch) and runs
     over (EPOCHS - INITIATE - resume_epoch) * train_steps steps -- the reference subtracts BOTH, so the window is shorter
     than the epochs left (and empty or negative for resume_epoch >= EPOCHS - INITIATE; TP: Keras' PolynomialDecay then
-    divides by a non-positive decay_steps, which this restatement refuses).  Step: as in learning_rate (TP: the restored
+    divides by decay_steps: a negative window yields end_learning_rate = 0, an empty one 0/0, which this restatement refuses).  Step: as in learning_rate (TP: the restored
     optimizer.iterations, i.e. the global count)."""
     start = initial_lr / (epochs - initiate_decay) * (epochs - resume_epoch)
     decay_steps = (epochs - initiate_decay - resume_epoch) * train_steps
+    if decay_steps < 0 and schedule_step == 'global_iterations':
+        return 0.0          # TP: PolynomialDecay: min(step, decay_steps) / decay_steps = 1 for a negative window => end_learning_rate
     if decay_steps <= 0:
         raise ValueError('reference schedule undefined: decay_steps <= 0')
     if schedule_step == 'global_iterations':

@@ -24,16 +24,3 @@ def test_layer_variant_matches_oracle(kv):
     r = _REPS[kv]
     LR.run_recipe(r['recipe'], kv[1], torch.device('cuda:0'))
 
-
-def test_producer_consumer_flavour_subprocess():
-    """The opt-in producer/consumer flavour of the convolution (vg_conv_pc.hip, VG_CONV_PC=1) changes which kernels the
-    configurations select: run this file again in a child process with it enabled -- the parametrisation is re-derived there,
-    so every conv_pc variant the BASELINE configurations would run gets its true-shape parity case too."""
-    import os, subprocess, sys
-    if os.environ.get('VG_CONV_PC') == '1':
-        pytest.skip('already inside the child run')
-    env = dict(os.environ, VG_CONV_PC='1', VG_NO_REBUILD='1')
-    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-x', '-m', 'gpu'], env=env,
-                       capture_output=True, text=True, timeout=1800)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert 'conv_pc<' in r.stdout or ' passed' in r.stdout

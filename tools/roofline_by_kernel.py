@@ -46,8 +46,6 @@ def variant_of(kernel_name: str):
         return 'pw_gemm<%s,%s,g%s,a%s>' % (args[0], args[1], b(args[2]), b(args[3]))
     if k == 'conv32' and len(args) == 4:
         return 'conv32<%s,%s,n%s,cp%s>' % (args[0], args[1], b(args[2]), b(args[3]))
-    if k == 'conv_pc' and len(args) == 8:
-        return 'conv_pc<%s,%s,%s,m%s,wl%s,mc%s,c1%s,w%s>' % (tname(args[0]), args[1], args[2], args[3], b(args[4]), args[5], b(args[6]), args[7])
     if k == 'wgrad' and len(args) == 4:
         return 'wgrad<%s,%s,%s,n%s>' % (tname(args[0]), args[1], args[2], b(args[3]))
     if k in ('pw_cto1', 'pw_ctoc') and len(args) == 2:

@@ -688,16 +688,10 @@ static int fill_conv(const vg_conv_desc* d, GatherIn& g, ConvOut& k, ConvCls& q,
     const int use_dma = vg_tune("CONV_DMA", 0);     // measured neutral (51.5 vs 51.7 ms/step): these kernels are issue-bound, not latency-bound
     const int force_msub = vg_tune("CONV_MSUB", 0), no_wlds = vg_tune("CONV_NOWLDS", 0), force_bn = vg_tune("CONV_BN", 0);
     const int bn_max = d->Cout <= 16 ? 16 : (d->Cout <= 32 ? 32 : 64);
+    const long fill_t = vg_tune("CONV_FILL", 128);
     int found = 0, rc = VG_ELDS;
     long best_score = -1;
-    int best_bn = 0, best_ms = 0, best_wl = 0, best_lds = 0, best_dma = 0, best_pc = 0;
-    // producer/consumer flavour (vg_conv_pc.hip): bf16, one class or class-parallel classes, synchronous-staging sources.
-    // OPT-IN (VG_CONV_PC=1): layer by layer it is 10-20 % faster on the thin 128^3 / 64^3 layers (dec0.cb1 forward 0.226 ->
-    // 0.197 ms, its data gradient 0.290 -> 0.250, dec1.cb1 0.093 -> 0.082), but its 100-130 KiB of LDS pin one workgroup per CU,
-    // and in the two-lane schedule of the train step the kernels of the other lane can no longer share the CU: 33.6 -> 34.4 ms
-    // per step.
-    const int use_pc = vg_tune("CONV_PC", 0);
-    const bool pc_ok = use_pc && !d->f32 && (q.ncls == 1 || (q.par && !d->noise && Cin != 1));
+    int best_bn = 0, best_ms = 0, best_wl = 0, best_lds = 0, best_dma = 0;
     // LDS-DMA staging: bf16 planar image of a multi-channel, noise-free source, weights resident in LDS
     const bool dma_ok = use_dma && !d->f32 && Cin != 1 && !d->noise && d->istr == 1 && d->CK <= 48 && q.ncls == 1;
     for (int bn = bn_max; bn >= 16; bn >>= 1) {
@@ -715,34 +709,17 @@ static int fill_conv(const vg_conv_desc* d, GatherIn& g, ConvOut& k, ConvCls& q,
             int wl = (wbytes <= 56 * 1024 && !no_wlds && !d->f32) ? 1 : 0;       // exact-parity mode reads weights from L2
             int need = conv_lds_bytes(g, bn, d->CK, wl ? wbytes : 0, 0, ksteps_total);
             if (need > 80 * 1024 && wl) { const int n2 = conv_lds_bytes(g, bn, d->CK, 0, 0, ksteps_total); if (n2 <= 80 * 1024 || need > VG_LDS_LIMIT) { wl = 0; need = n2; } }
-            int pc = 0;
-            if (pc_ok && vg_conv_pc_mode(g) >= 0) {
-                // two halo buffers; weights in LDS while everything fits (one 512-thread workgroup per CU is the design point
-                // of the variants with >= 4 sub-tiles per wave, two for the smaller ones)
-                int wl2 = (wbytes <= 56 * 1024 && !no_wlds) ? 1 : 0;
-                int need2 = vg_conv_pc_lds_bytes(g, bn, d->CK, wl2 ? wbytes : 0, ksteps_total);
-                if (need2 > VG_LDS_LIMIT && wl2) { wl2 = 0; need2 = vg_conv_pc_lds_bytes(g, bn, d->CK, 0, ksteps_total); }
-                // it only pays when a workgroup runs several stages: its prologue stages the first tile with the consumers idle
-                // (enc3.cb2 data gradient, 2 stages per workgroup: 0.051 -> 0.064 ms; bridge forward, 4 stages: 0.052 -> 0.041)
-                int pcu = ((bn / 16) * ms >= 4) ? 1 : 2;
-                if (need2 > 0 && VG_LDS_LIMIT / need2 < pcu) pcu = VG_LDS_LIMIT / need2;
-                const long tiles_n = (long)g.tiles_d * g.tiles_h * g.tiles_w;
-                const long per_x = (long)((d->Cout + bn - 1) / bn) * d->N * (q.par ? q.ncls : 1);
-                long bxp = pcu > 0 ? 256L * pcu / per_x : 0; if (bxp < 1) bxp = 1; if (bxp > tiles_n) bxp = tiles_n;
-                const long stages = ((tiles_n + bxp - 1) / bxp) * k.nchunks;
-                if (need2 <= VG_LDS_LIMIT && stages >= vg_tune("CONV_PC_MINSTAGES", 3)) { pc = 1; wl = wl2; need = need2; }
-            }
             if (need > VG_LDS_LIMIT) continue;
-            if (!pc && ms == 8 && need > 80 * 1024) continue;     // the 512-voxel tile only pays while two workgroups stay resident
+            if (ms == 8 && need > 80 * 1024) continue;     // the 512-voxel tile only pays while two workgroups stay resident
             int dma = 0;
-            if (dma_ok && wl && !pc) {
+            if (dma_ok && wl) {
                 GatherIn g2; rc = fill_gather(d, g2, d->CK, 64 * ms, 0, 1);
                 if (rc != VG_OK) return rc;
                 const int need2 = conv_lds_bytes(g2, bn, d->CK, wbytes, 1, ksteps_total);
                 if (g2.planar && need2 <= 80 * 1024) { dma = 1; need = need2; }
             }
             // score: reaching 512 workgroups dominates, then work per workgroup-tile (bn*ms), then small LDS
-            const long fill_t = vg_tune("CONV_FILL", 128);     // sweep of the 128^3 train step: 512 -> 31.5 ms, 256 -> 30.9, 128 -> 30.6, 64 -> 30.7 (the other lane and the side streams fill the chip)
+            // sweep of the 128^3 train step: 512 -> 31.5 ms, 256 -> 30.9, 128 -> 30.6, 64 -> 30.7 (the other lane and the side streams fill the chip)
             const long fill = wgs >= fill_t ? fill_t : wgs;
             // (useful channels per panel, not the panel width: a 64-wide panel on 48 or 96 output channels multiplies zeros in a
             // quarter of its MFMAs -- there the 32-wide panel with the twice larger voxel tile wins: 16->48 data gradient at 128^3
@@ -750,10 +727,10 @@ static int fill_conv(const vg_conv_desc* d, GatherIn& g, ConvOut& k, ConvCls& q,
             const int ny_ = (d->Cout + bn - 1) / bn;
             const long useful = (long)((d->Cout + ny_ - 1) / ny_) * ms;
             const long score = fill * 100000 + useful * 100 + (need <= 80 * 1024 ? 50 : 0);
-            if (score > best_score) { best_score = score; best_bn = bn; best_ms = ms; best_wl = wl; best_lds = need; best_dma = dma; best_pc = pc; found = 1; }
+            if (score > best_score) { best_score = score; best_bn = bn; best_ms = ms; best_wl = wl; best_lds = need; best_dma = dma; found = 1; }
         }
     }
-    if (found) { BN = best_bn; MSUB = best_ms; k.w_lds = best_wl; k.dma = best_dma; k.pc = best_pc; lds = best_lds; }
+    if (found) { BN = best_bn; MSUB = best_ms; k.w_lds = best_wl; k.dma = best_dma; lds = best_lds; }
     if (!found) return VG_ELDS;
     rc = fill_gather(d, g, d->CK, 64 * MSUB, 0, k.dma);
     if (rc != VG_OK) return rc;
@@ -784,6 +761,7 @@ static int plan_conv32(const vg_conv_desc* d, const ConvOut& k, const ConvCls& q
     if (q.par) { tmax = 0; for (int c = 0; c < q.ncls; ++c) tmax = std::max(tmax, q.tap0[c + 1] - q.tap0[c]); }
     const int ksteps = tmax * (d->CK >> 4);
     long best = -1; int best_ms = 0, best_lds = 0;
+    const long fill32 = vg_tune("CONV32_FILL", 256);
     for (int ms = (BN == 128 ? 2 : 4); ms >= (BN == 128 ? 1 : 2); ms >>= 1) {
         int rc = fill_gather(d, g, d->CK, 64 * ms);
         if (rc != VG_OK) return rc;
@@ -793,7 +771,6 @@ static int plan_conv32(const vg_conv_desc* d, const ConvOut& k, const ConvCls& q
         // every tile streams its BN x K weight panel from L2 (64 B/clk per CU): 64 voxels per tile give exactly the
         // 64 FLOP/B that the MFMA rate needs, 128 voxels give headroom -- so one workgroup per CU with the big tile beats
         // two with the small one
-        const long fill32 = vg_tune("CONV32_FILL", 256);
         const long fill = wgs >= fill32 ? fill32 : wgs;
         const long score = fill * 1000 + ms * 10 + (need <= 80 * 1024 ? 5 : 0);
         if (score > best) { best = score; best_ms = ms; best_lds = need; }
@@ -935,7 +912,6 @@ static int conv3d_impl(const vg_conv_desc* d, vg_stream_t stream, bool& did_stat
     if (rc != VG_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
     { GatherIn g2; int bn2, ms2, lds2; if (plan_conv32(d, k, q, g2, bn2, ms2, lds2) == VG_OK) return launch_conv32(g2, k, q, bn2, ms2, lds2, s); }
-    if (k.pc) return vg_launch_conv_pc(g, k, q, BN, MSUB, lds, s);
     if (!d->f32 && MSUB == 8 && BN == 16 && vg_conv_thin_ok(d, g, k, q)) {
         const int trc = vg_launch_conv_thin(g, k, s, d->bstat ? d->bstat->red : nullptr, did_stats);
         if (trc <= 0) return trc;

@@ -1,5 +1,5 @@
-// vg_conv_common.h -- definitions shared by the two translation units of the gather-convolution: vg_conv.hip (conv_kernel,
-// conv32_kernel, host-side tile choice and dispatch) and vg_conv_pc.hip (the producer/consumer flavour conv_pc_kernel).
+// vg_conv_common.h -- definitions shared by the translation units of the gather-convolution: vg_conv.hip (conv_kernel,
+// conv32_kernel, host-side tile choice and dispatch) and vg_conv_thin.hip (the 16-channel specialist).
 #pragma once
 #include "vg_gather.h"
 
@@ -11,7 +11,6 @@ struct ConvOut {
     int w_lds;          // 1: the BN x Ktot weight panel of this workgroup is copied to LDS once (row stride WRS bytes)
     int dma;            // 1: LDS-DMA double-buffered staging (planar bf16 image, weights in LDS)
     int WRS;
-    int pc;             // 1: producer/consumer flavour (vg_conv_pc.hip)
     // IN-backward statistics of the output fused into the epilogue (conv_thin_kernel<..., BSTAT>; vg_conv_desc::bstat): the
     // pre-norm tensor(s) of the layer whose gradient this launch produces and its per-(sample, channel) constants
     const void* bs_x0; const void* bs_x1; int bs_c0, bs_sh, bs_act, bs_pad, bs_D, bs_H, bs_W;
@@ -146,13 +145,7 @@ __device__ __forceinline__ void conv_mfma_chunk(f32x4 (&acc)[MW], WP w, const ch
 }
 
 
-// vg_conv_pc.hip: producer/consumer flavour (512-thread workgroups: 4 MFMA waves + 4 staging waves, double-buffered halo image)
-int vg_launch_conv_pc(const GatherIn& g, const ConvOut& k, const ConvCls& q, int BN, int MSUB, int lds, hipStream_t s);
 // vg_conv_thin.hip: specialist for the 16-channel-chunk 3x3x3 stride-1 layers with a fixed 16x8x4 tile
 bool vg_conv_thin_ok(const vg_conv_desc* d, const GatherIn& g, const ConvOut& k, const ConvCls& q);
 // red != NULL: accumulate the IN-backward statistics (ConvOut::bs_*) into red in the epilogue when the instance exists (did_stats)
 int vg_launch_conv_thin(const GatherIn& g, const ConvOut& k, hipStream_t s, float* red, bool& did_stats);       // VG_OK, < 0 on error, 1: not one of its combinations
-// staging mode (VG_STAGE_*) the producer/consumer flavour would use for this source, -1: not supported there
-int vg_conv_pc_mode(const GatherIn& g);
-// LDS bytes of the producer/consumer flavour for this geometry (host)
-int vg_conv_pc_lds_bytes(const GatherIn& g, int BN, int CK, int wbytes, int ksteps_total);

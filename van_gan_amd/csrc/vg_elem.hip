@@ -596,6 +596,9 @@ int vg_tune(const char* key, int dflt) {
 }
 extern "C" int vg_set_tuning(const char* key, int value, int reset) {
     if (!key) return VG_EINVAL;
+#ifndef VG_ABLATE
+    if (!strcmp(key, "DEBUG")) return VG_EINVAL;        // phase ablations (silent no-store kernels) exist in diagnostic builds only
+#endif
     std::lock_guard<std::mutex> lk(g_tune_mu);
     TuneEntry* e = tune_find(key, true);
     if (!e) return VG_EINVAL;

@@ -30,7 +30,8 @@ struct GatherIn {
     // W step for either stride); HWx is the true input W extent of a tile (axis-table length), Cw the weight-side Cin.
     int wpack, HWx, wmin, Cw;
     int lean;       // >= 0: lean staging mode (VG_STAGE_*) of a multi-channel bf16 source; -1: original column staging
-    int dbg;        // development ablation flags (VG_DEBUG env): 1 skip halo staging, 2 skip dY staging, 4 skip MFMA
+    int dbg;        // development ablation flags (VG_DEBUG env, -DVG_ABLATE builds only; else 0): 1 skip halo staging, 2 skip dY staging,
+                    // 4 skip MFMA, 64 skip the epilogue's vector store
     unsigned long long* stamps;   // diagnostic build only (vg_set_stamp_buffer): s_memtime stamps per phase, else NULL
 };
 
@@ -572,7 +573,11 @@ static inline void pad_pitches(int hh, int hw, int tw, int th, int istr, int& hh
 static inline int fill_gather(const vg_conv_desc* d, GatherIn& g, int CK, int BM, int skew = 0, int dma = 0) {
     if (!d || !d->src0) return VG_EINVAL;
     g.f32 = d->f32 ? 1 : 0;
-    g.dbg = vg_tune("DEBUG", 0);
+#ifdef VG_ABLATE
+    g.dbg = vg_tune("DEBUG", 0);        // diagnostic builds only (-DVG_ABLATE): phase ablations skip staging / MFMA / stores
+#else
+    g.dbg = 0;
+#endif
     g.stamps = g_vg_stamps;
     const int Cin = d->c_src0 + d->c_src1;
     if (Cin < 1 || d->ntaps < 1 || d->ntaps > VG_MAX_TAPS) return VG_EINVAL;

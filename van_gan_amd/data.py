@@ -145,7 +145,12 @@ def learning_rate(initial_lr: float, epoch: int, step_in_epoch: int, epochs: int
     else:
         raise ValueError("schedule_step must be 'global_iterations' or 'since_install'")
     step = min(it, decay_steps)
-    return initial_lr * (1.0 - step / decay_steps)
+    lr = initial_lr * (1.0 - step / decay_steps)
+    if lr <= 0.0 and epoch < epochs - 1:
+        _warn_once('lr0', 'learning rate is 0 from epoch %d of %d on: the reference schedule evaluated at the optimizer\'s global '
+                   'iteration count (custom_callback.py:326-365) has used up its decay window; schedule_step=\'since_install\' '
+                   'gives the linear decay instead' % (epoch, epochs))
+    return lr
 
 
 def learning_rate_resumed(initial_lr: float, resume_epoch: int, epoch: int, step_in_epoch: int, epochs: int,
@@ -153,11 +158,16 @@ def learning_rate_resumed(initial_lr: float, resume_epoch: int, epoch: int, step
                           iterations: Optional[int] = None) -> float:
     """set_learning_rate's resume branch (custom_callback.py:365-397): a new PolynomialDecay from
     INITIAL_LR / (EPOCHS - INITIATE) * (EPOCHS - resume_epoch) over (EPOCHS - INITIATE - resume_epoch) * train_steps steps
-    (the reference subtracts both, kept as is; a non-positive window is refused)."""
+    (the reference subtracts both, kept as is; a NEGATIVE window gives 0 as TF's PolynomialDecay does, an empty one -- 0/0 in TF -- is refused)."""
     start = initial_lr / (epochs - initiate_decay) * (epochs - resume_epoch)
     decay_steps = (epochs - initiate_decay - resume_epoch) * train_steps
+    if decay_steps < 0 and schedule_step == 'global_iterations':
+        # TP: tf PolynomialDecay clamps the step to decay_steps (min(step, negative) / negative = 1) and returns end_learning_rate:
+        # the reference carries on with a rate of 0
+        _warn_once('lr0r', 'resumed past EPOCHS - INITIATE_LR_DECAY: the reference schedule yields a learning rate of 0')
+        return 0.0
     if decay_steps <= 0:
-        raise ValueError('reference schedule undefined: decay_steps <= 0 (resumed past EPOCHS - INITIATE_LR_DECAY)')
+        raise ValueError('schedule undefined: decay_steps <= 0 (resumed at or past EPOCHS - INITIATE_LR_DECAY; TF divides 0 by 0)')
     if schedule_step == 'global_iterations':
         it = epoch * train_steps + step_in_epoch if iterations is None else iterations      # restored optimizer.iterations
     elif schedule_step == 'since_install':
@@ -165,6 +175,16 @@ def learning_rate_resumed(initial_lr: float, resume_epoch: int, epoch: int, step
     else:
         raise ValueError("schedule_step must be 'global_iterations' or 'since_install'")
     return start * (1.0 - min(it, decay_steps) / decay_steps)
+
+
+_WARNED = set()
+
+
+def _warn_once(key: str, msg: str):
+    if key not in _WARNED:
+        _WARNED.add(key)
+        import warnings
+        warnings.warn(msg, RuntimeWarning, stacklevel=3)
 
 
 def discriminator_noise(init_noise: float, epoch: int, no_noise_epoch: int) -> float:

@@ -54,7 +54,7 @@ def current_stream_obj() -> torch.cuda.Stream:
     key = (_DEV, torch._C._cuda_getCurrentRawStream(_DEV))
     so = _STREAM_OBJ.get(key)
     if so is None:
-        so = _STREAM_OBJ[key] = torch.cuda.current_stream()
+        so = _STREAM_OBJ[key] = torch.cuda.current_stream(_DEV)
     return so
 
 
@@ -260,6 +260,7 @@ class Arena:
         self.off = 0
         self.zoff = 0
         self.peak = 0
+        self.lazy_ok = True         # False: this arena is shared by sweeps of both lanes (VG_LANES=0), so release() always recycles
         self.zpool.zero_()
 
     def reset(self):
@@ -296,7 +297,7 @@ class Arena:
         reading them on a side stream, the memory is simply NOT recycled before the next reset() -- joining the side stream here
         stalled the data-gradient chain behind every block's weight gradients (each lane idle 45 % of a step in the kernel trace);
         the workspace is sized for it (a few GB more at 128^3, of 288)."""
-        if defer and LAZY_RELEASE and SIDE is not None and PROF is None and DRY is None:
+        if defer and LAZY_RELEASE and self.lazy_ok and SIDE is not None and PROF is None and DRY is None:
             return
         side_join()                 # weight gradients on the side stream may still read the buffers being recycled
         self.off = mark

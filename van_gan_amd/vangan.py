@@ -93,16 +93,9 @@ class VanGan:
         self._lane_b = torch.cuda.Stream(device=self.device) if os.environ.get('VG_LANES', '1') != '0' else None
         # second workspace for lane B's backward temporaries (bump allocators cannot interleave mark/release)
         self.arena_b = Arena(arena_bytes // 2, self.device) if self._lane_b is not None else None
-        # backward, OPT-IN (VG_LANES4=1): the two applications of a generator (adversarial and cycle) are independent sweeps that
-        # only meet in the network's gradient buffer (atomic adds), so each lane can hand its cycle application to a second
-        # stream with its own workspace -- four sweeps in flight.  Measured SLOWER: 33.6 -> 35.0 ms per 128^3 step, 18.1 -> 20.2
-        # at 64^3 batch 2: the chip-filling kernels are bound by vector-instruction issue, a third and fourth resident kernel
-        # only takes issue slots and cache from them.  Two lanes is the optimum.
-        four = self._lane_b is not None and os.environ.get('VG_LANES4', '0') == '1'
-        self._lane_a2 = torch.cuda.Stream(device=self.device) if four else None
-        self._lane_b2 = torch.cuda.Stream(device=self.device) if four else None
-        self.arena_a2 = Arena(arena_bytes // 2, self.device) if four else None
-        self.arena_b2 = Arena(arena_bytes // 2, self.device) if four else None
+        # one arena for every backward sweep (VG_LANES=0): the workspace is sized for the two-lane layout, so backward temporaries
+        # are recycled there (joining release) instead of being kept until the next reset
+        self.arena.lazy_ok = self._lane_b is not None
         self.sync = GradSync({k: s.g for k, s in self.stores.items()}, self.pg, {k: s.w for k, s in self.stores.items()})
         # optimizer stream: a network's clip + Adam + weight repack is queued here as soon as ITS backward sweeps are issued and
         # waits only for ITS gradient bucket (all-reduce event), while the other networks' backward sweeps still run
@@ -117,10 +110,12 @@ class VanGan:
 
     # ------------------------------------------------------------------------------------------------
     def repack(self):
+        ops.set_device(self.device.index)
         for n in self.nets.values():
             n.pack()
 
     def load_weights(self, P: Dict[str, Dict[str, torch.Tensor]]):
+        ops.set_device(self.device.index)
         for k in NETS:
             self.stores[k].load({n: t.to(self.device) for n, t in P[k].items()})
         self.repack()
@@ -287,7 +282,7 @@ class VanGan:
         self._mark('A D fwd')
         # No full join before the backward sweeps (VG_NOJOIN): lane A's discriminator sweeps and its adversarial generator sweep need
         # nothing of lane B; only its cycle sweep (c3 ran on lane B, g_cS comes out of lane B's clDice) waits for lane B's forward.
-        nojoin = lane_b is not None and do_backward and self._lane_a2 is None and _NOJOIN
+        nojoin = lane_b is not None and do_backward and _NOJOIN
         ev_bfwd = None
         if lane_b is not None:
             if nojoin:
@@ -307,18 +302,6 @@ class VanGan:
                 arB = self.arena_b
                 arB.reset()
                 lane_b.wait_stream(main)
-            four = lane_b is not None and self._lane_a2 is not None
-            if four:
-                # cycle applications on their own streams (they need only g_cS / g_cI, ready since the lanes joined; gradient buffers zeroed on main)
-                for st_, arn in ((self._lane_a2, self.arena_a2), (self._lane_b2, self.arena_b2)):
-                    arn.reset()
-                    st_.wait_stream(main)
-                with torch.cuda.stream(self._lane_a2):
-                    self.gen_IS.backward(self.arena_a2, c3, g_cS)
-                    ops.side_join()
-                with torch.cuda.stream(self._lane_b2):
-                    self.gen_SI.backward(self.arena_b2, c4, g_cI)
-                    ops.side_join()
             def a_disc():
                 self.disc_S.backward(ar, dS, gS_D, 0, 2 * B, wgrad=True)
                 self._start_allreduce(['disc_S'], lazy=apply)
@@ -353,22 +336,16 @@ class VanGan:
             def a_cyc():
                 if ev_bfwd is not None:
                     main.wait_event(ev_bfwd)                                          # c3 and g_cS are lane B's
-                if four:
-                    main.wait_stream(self._lane_a2)
-                else:
-                    self.gen_IS.backward(ar, c3, g_cS, inline_from=_INLINE); ar.release(mk, defer=True)    # cycle application
-                    self._mark('A G cyc bwd')
+                self.gen_IS.backward(ar, c3, g_cS, inline_from=_INLINE); ar.release(mk, defer=True)    # cycle application
+                self._mark('A G cyc bwd')
                 self._start_allreduce(['gen_IS'], lazy=apply)
                 if apply:
                     self._schedule_update('gen_IS')
 
             def b_cyc():
                 with laneB():
-                    if four:
-                        lane_b.wait_stream(self._lane_b2)
-                    else:
-                        self.gen_SI.backward(arB, c4, g_cI, inline_from=_INLINE); arB.release(mkb, defer=True)
-                        self._mark('B G cyc bwd')
+                    self.gen_SI.backward(arB, c4, g_cI, inline_from=_INLINE); arB.release(mkb, defer=True)
+                    self._mark('B G cyc bwd')
                     self._start_allreduce(['gen_SI'], lazy=apply)
                     if apply:
                         self._schedule_update('gen_SI')
@@ -451,6 +428,7 @@ class VanGan:
             self._adam(name)
 
     def _apply_adam(self):
+        ops.set_device(self.device.index)
         for name in NETS:
             self._adam(name)
 
@@ -479,6 +457,7 @@ class VanGan:
         return self.sync.reduce_dict(d, RESULT_KEYS)
 
     def broadcast_weights(self, src: int = 0):
+        ops.set_device(self.device.index)
         self.sync.broadcast_weights(src)
         self.repack()
 
@@ -508,10 +487,11 @@ class VanGan:
             dist.barrier(group=self.pg)
         return path
 
-    def load_checkpoint(self, epoch: int, newpath: Optional[str] = None) -> bool:
+    def load_checkpoint(self, epoch: Optional[int], newpath: Optional[str] = None) -> bool:
+        ops.set_device(self.device.index)
         d = newpath if newpath is not None else self.checkpoint_dir
-        path = os.path.join(d, 'checkpoint_e%d.pt' % epoch) if d is not None else ''
-        if not d or not os.path.exists(path):
+        path = os.path.join(d, 'checkpoint_e%d.pt' % epoch) if (d is not None and epoch is not None) else ''
+        if not d or not path or not os.path.exists(path):
             print('Error: Checkpoint not found!')                  # vangan.py:267-268: prints, does not raise
             return False
         ck = torch.load(path, map_location='cpu')
