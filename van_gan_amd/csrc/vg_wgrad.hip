@@ -354,6 +354,10 @@ extern "C" int vg_conv3d_wgrad(const vg_conv_desc* d, const void* dy, int dy_f32
         const int prc = vg_pointwise_wgrad(d, dy, dy_f32, T_total, dw, db, scratch, scratch_bytes, (hipStream_t)stream);
         if (prc <= 0) return prc;
     }
+    {   // materialised operand + LDS-DMA staging (vg_wgrad_dma.hip) where the shape is one of its
+        const int drc = vg_wgrad_dma(d, dy, dy_f32, tap_idx_host, T_total, dw, db, scratch, scratch_bytes, (hipStream_t)stream);
+        if (drc <= 0) return drc;
+    }
     const int Cin = d->c_src0 + d->c_src1;
     const int Cinp = ((Cin + 15) / 16) * 16, Coutp = ((d->Cout + 15) / 16) * 16;
     const int COB = Coutp >= 64 ? 64 : (Coutp >= 32 ? 32 : 16);

@@ -1,0 +1,466 @@
+// vg_wgrad_dma.hip -- weight gradient of the gather-convolution from a MATERIALISED operand, staged by LDS-DMA (gfx950).
+//
+// dW[tap][ci][co] += sum_{n,o} P[n, o*istr + tap, ci] * dY[n,o,co]      (tf.GradientTape d/dW of Conv3D, vangan.py:426-438)
+//
+// vg_wgrad.hip transforms the operand P = noise + mask * act(IN(x)) on the fly, once per (tap group x output block) column,
+// with ~70 vector instructions per 16 bytes: its weight gradients are bound by vector-instruction issue (21 VALU per MFMA on
+// the discriminators' 4x4x4 layers, profiles/r02_pmc_down0_wgrad.txt).  Here P is written ONCE per layer by an elementwise
+// kernel (materialize_kernel: reflection / zero padding, virtual upsample + concat, InstanceNorm apply, activation, dropout
+// mask, noise all resolved there) in the layout this kernel wants:
+//     P[n][ci / 16][Dp][Hp][Wp'][16 channels]     bf16, padded grid, 16-channel planes; for stride-2 layers the W axis is
+//                                                 stored de-interleaved (even positions, then odd positions)
+// so that a workgroup's halo box of one plane is a set of long contiguous runs and the staging is nothing but
+// global_load_lds_dwordx4 (no VGPR, no transform, ~3 instructions per KiB), double-buffered against the MFMA loop.
+//
+// Workgroup = 512 threads (8 waves, 2 per SIMD), persistent over a strided set of output tiles.  It owns the slab
+// dW[all taps][PL planes of 16 ci][CO = 16*Q co]: wave w holds rows r = w, w+8, ... (row = (tap, plane)) x Q column blocks in
+// accumulators, so a halo tile is staged ONCE for all taps (the 4x4x4 layers re-staged it per tap group: 3.8-9.6x the
+// algorithmic HBM bytes, profiles/r02_roofline_by_kernel.txt).  GEMM view M = ci, N = co, K = voxels: K is the slow axis of
+// both operands in memory, the fragments come from ds_read_b64_tr_b16 (as in vg_wgrad.hip).  LDS images:
+//     A (halo): [plane][hd][hh][hw'][16 ch]  32 B per voxel; the 8 voxels a half-wave reads are consecutive along W
+//               (256 contiguous bytes = all 64 banks once; stride 2: de-interleaved W keeps them consecutive)
+//     B (dY)  : [voxel][CO ch] with the 32-byte blocks of a voxel XOR-swizzled by voxel bits (conflict-free transposed
+//               reads for CO = 32 / 64); the swizzle is applied on the DMA's per-lane SOURCE address, LDS stays linear.
+// K order inside a 32-voxel step: lane group lg reads voxels 4*lg..4*lg+3 and 16+4*lg..: any bijection is valid for a
+// contraction as long as both operands use it, and this one makes each half-wave read 8 consecutive voxels.
+#include "vg_gather.h"
+
+typedef __attribute__((address_space(3))) void lds_void_d;
+typedef const __attribute__((address_space(1))) void glb_void_d;
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_d;
+
+// ------------------------------------------------------------------------------------------------------------------
+// operand materialisation
+// ------------------------------------------------------------------------------------------------------------------
+struct MatK {
+    const void* src0; const void* src1; int c0, c1, shift0;
+    int N, D, H, W, Cin;
+    const float* in_scale; const float* in_shift; int act;
+    const bf16_t* noise; int npad;
+    int pad_mode;
+    int pmin_d, pmin_h, pmin_w;      // input position of padded index 0
+    int Dp, Hp, Wp;                  // padded extents (positions)
+    int deint, WE, Wps;              // W stored de-interleaved: WE even positions first; Wps = stored row length (voxels)
+    bf16_t* out;
+};
+
+__global__ __launch_bounds__(256) void materialize_kernel(const MatK p) {
+    const int tid = threadIdx.x;
+    int row = blockIdx.x;
+    const int hp = row % p.Hp; row /= p.Hp;
+    const int dp = row % p.Dp; const int n = row / p.Dp;
+    int pd = dp + p.pmin_d, ph = hp + p.pmin_h;
+    const int qd = pd + p.npad, qh = ph + p.npad;
+    const bool vd = resolve_pos(pd, p.D, p.pad_mode), vh = resolve_pos(ph, p.H, p.pad_mode);
+    const int npl = p.Cin >> 4;
+    const int units = npl * p.Wps * 2;
+    const int sh = p.shift0;
+    const float slope = p.act == VG_ACT_RELU ? 0.f : (p.act == VG_ACT_LRELU ? VG_LRELU : 1.f);
+    const int ND = p.D + 2 * p.npad, NH = p.H + 2 * p.npad, NW = p.W + 2 * p.npad;
+    const bool nrow = p.noise && vd && vh && qd >= 0 && qd < ND && qh >= 0 && qh < NH;
+    const size_t s0row = (((size_t)n * (p.D >> sh) + (pd >> sh)) * (p.H >> sh) + (ph >> sh)) * (p.W >> sh);
+    const size_t s1row = (((size_t)n * p.D + pd) * p.H + ph) * p.W;
+    const size_t nzrow = (((size_t)n * ND + (nrow ? qd : 0)) * NH + (nrow ? qh : 0)) * NW;
+    for (int u = tid; u < units; u += 256) {
+        const int plane = u / (p.Wps * 2), r = u - plane * p.Wps * 2;
+        const int ws = r >> 1, half = r & 1;
+        const int j = p.deint ? (ws < p.WE ? 2 * ws : 2 * (ws - p.WE) + 1) : ws;
+        int pw = j + p.pmin_w;
+        const int qw = pw + p.npad;
+        const bool vw = j < p.Wp && resolve_pos(pw, p.W, p.pad_mode);
+        const bool valid = vd && vh && vw;
+        const int c = plane * 16 + half * 8;
+        float x[8];
+        {
+            const bool from0 = c < p.c0;
+            const bf16_t* src = from0 ? (const bf16_t*)p.src0 + (s0row + (valid ? (pw >> sh) : 0)) * p.c0 + c
+                                      : (const bf16_t*)p.src1 + (s1row + (valid ? pw : 0)) * p.c1 + (c - p.c0);
+            if (!valid) src = (const bf16_t*)p.src0;
+            Raw8<bf16_t> raw; raw_load(raw, src);
+            raw_unpack(raw, x);
+        }
+        if (p.in_scale) {
+            const f32x4* sc = (const f32x4*)(p.in_scale + n * p.Cin + c);
+            const f32x4* sf = (const f32x4*)(p.in_shift + n * p.Cin + c);
+            const f32x4 s0 = sc[0], s1 = sc[1], f0 = sf[0], f1 = sf[1];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { x[e] = x[e] * s0[e] + f0[e]; x[4 + e] = x[4 + e] * s1[e] + f1[e]; }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = fmaxf(x[e], x[e] * slope);
+        if (p.noise) {
+            const bool nok = nrow && valid && qw >= 0 && qw < NW;
+            Raw8<bf16_t> nz; raw_load(nz, p.noise + (nzrow + (nok ? qw : 0)) * p.Cin + c);
+            float z[8]; raw_unpack(nz, z);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] += nok ? z[e] : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = valid ? x[e] : 0.f;
+        bf16_t* dst = p.out + ((((size_t)(n * npl + plane) * p.Dp + dp) * p.Hp + hp) * p.Wps + ws) * 16 + half * 8;
+        store8<bf16_t>(dst, x);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// weight gradient
+// ------------------------------------------------------------------------------------------------------------------
+#define VG_WD_MAXA 9          // A (halo) DMA pieces per wave and tile (8 waves x 9 KiB = 72 KiB of halo planes per buffer)
+#define VG_WD_MAXB 4          // B (dY) pieces per wave and tile (32 KiB)
+
+struct WgdK {
+    const char* P; const char* dy;
+    int N, OD, OH, OW, Cout, Cin;
+    int plane_bytes;                  // one P plane: Dp*Hp*Wps*32
+    int Hp, Wps, WEP;                 // P row geometry; WEP: voxel offset of the odd half of a row (de-interleaved), else 0
+    int istr, deint;
+    int ntaps; int tap_src[VG_MAX_TAPS]; int8_t td[VG_MAX_TAPS], th[VG_MAX_TAPS], tw[VG_MAX_TAPS];     // 0-based tap offsets
+    int PL, NPL, ncob, CO2;           // planes per workgroup, planes of P, output blocks, bytes of one dY row in LDS (CO * 2)
+    int tdl, thl, twl, tiles_d, tiles_h, tiles_w, total_tiles;
+    int HD, HH, HW, HWE;              // halo box (voxels); HWE: even part of a de-interleaved halo row
+    int imgp, nA, nB, bufb;           // 1-KiB pieces per plane image, A pieces, B pieces per tile; bytes per buffer
+    float* dw; float* db; float* part; int dw_elems;
+};
+
+// One LDS-DMA piece: 64 lanes x 16 bytes from sbase + voff (per lane) to LDS bytes [lds_addr, lds_addr + 1024).  Inline asm on
+// purpose: for the builtin hipcc tracks the copy as a pending LDS write and drains it (s_waitcnt vmcnt(0)) in front of the next
+// ds_read -- the copy of tile t+1 must stay in flight under the MFMA loop of tile t.  The kernel counts it itself (vmcnt(0)
+// at the top of the tile loop, where nothing else is outstanding).  M0 = LDS base of the piece, restored afterwards.
+__device__ __forceinline__ void glds16(const char* sbase, int voff, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+}
+
+__device__ __forceinline__ bf16x8 tr_frag_d(const char* base0, const char* base1) {
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4_d*)base0);
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4_d*)base1);
+    return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+template <int R, int Q>
+__global__ __launch_bounds__(512, 2) void wgrad_dma_kernel(const WgdK p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lg = lane >> 4, li = lane & 15;
+    const int cob = blockIdx.y % p.ncob, cib = blockIdx.y / p.ncob;
+    const int BM = 1 << (p.tdl + p.thl + p.twl);
+    const int nks = BM >> 5;
+    const int TWm = (1 << p.twl) - 1, THm = (1 << p.thl) - 1;
+    int* tapoff = (int*)(smem + 2 * p.bufb);
+    int2* ktab = (int2*)(tapoff + VG_MAX_TAPS);
+    const int CO = p.CO2 >> 1;
+    const int nrows = p.ntaps * p.PL;
+
+    // ---- per-lane DMA source offsets (the halo box has the same shape for every tile: P is padded, tiles divide the grid) ----
+    int aoffs[VG_WD_MAXA], boffs[VG_WD_MAXB];
+    {
+        const int nvox = p.HD * p.HH * p.HW;
+#pragma unroll
+        for (int k = 0; k < VG_WD_MAXA; ++k) {
+            const int piece = wave + 8 * k;
+            const int pl = piece / p.imgp, pk = piece - pl * p.imgp;
+            int iv = pk * 32 + (lane >> 1);
+            if (iv >= nvox) iv = 0;
+            const int hd = iv / (p.HH * p.HW), rem = iv - hd * (p.HH * p.HW);
+            const int hh = rem / p.HW, ws = rem - hh * p.HW;
+            const int gw = p.deint ? (ws < p.HWE ? ws : p.WEP + ws - p.HWE) : ws;
+            aoffs[k] = pl * p.plane_bytes + ((hd * p.Hp + hh) * p.Wps + gw) * 32 + (lane & 1) * 16;
+        }
+#pragma unroll
+        for (int k = 0; k < VG_WD_MAXB; ++k) {
+            const int byte = (wave + 8 * k) * 1024 + lane * 16;
+            int m = byte / p.CO2; const int s = (byte - m * p.CO2) >> 4;
+            if (m >= BM) m = 0;
+            const int f = p.CO2 == 128 ? (m >> 1) & 3 : (p.CO2 == 64 ? (m >> 2) & 1 : 0);
+            const int blk = (s >> 1) ^ f;
+            const int w = m & TWm, h = (m >> p.twl) & THm, d = m >> (p.twl + p.thl);
+            boffs[k] = (((d * p.OH + h) * p.OW + w) * p.Cout + cob * CO + blk * 16 + (s & 1) * 8) * 2;
+        }
+    }
+    const int tiles_per_n = p.tiles_d * p.tiles_h * p.tiles_w;
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_d*)smem;
+    auto issue = [&](int tile, int bufoff) {
+        int t = tile;
+        const int n = t / tiles_per_n; t -= n * tiles_per_n;
+        const int ti_w = t % p.tiles_w; t /= p.tiles_w;
+        const int ti_h = t % p.tiles_h; const int ti_d = t / p.tiles_h;
+        const int od0 = ti_d << p.tdl, oh0 = ti_h << p.thl, ow0 = ti_w << p.twl;
+        const char* abase = p.P + (size_t)(n * p.NPL + cib * p.PL) * p.plane_bytes
+                            + (size_t)((od0 * p.istr * p.Hp + oh0 * p.istr) * p.Wps + (p.deint ? ow0 : ow0 * p.istr)) * 32;
+        const char* bbase = p.dy + ((((size_t)n * p.OD + od0) * p.OH + oh0) * p.OW + ow0) * p.Cout * 2;
+#pragma unroll
+        for (int k = 0; k < VG_WD_MAXA; ++k) {
+            const int piece = wave + 8 * k;
+            if (piece < p.nA) glds16(abase, aoffs[k], lds0 + bufoff + piece * 1024);
+        }
+#pragma unroll
+        for (int k = 0; k < VG_WD_MAXB; ++k) {
+            const int piece = wave + 8 * k;
+            if (piece < p.nB) glds16(bbase, boffs[k], lds0 + bufoff + (p.nA + piece) * 1024);
+        }
+    };
+    if ((int)blockIdx.x < p.total_tiles) issue(blockIdx.x, 0);
+
+    // ---- tables: tap offsets inside the halo image, per-(K-step, lane) offsets of the transposed reads ----
+    if (tid < p.ntaps)
+        tapoff[tid] = ((p.td[tid] * p.HH + p.th[tid]) * p.HW + (p.deint ? (p.tw[tid] & 1) * p.HWE + (p.tw[tid] >> 1) : p.tw[tid])) * 32;
+    for (int e = tid; e < nks * 64; e += 512) {
+        const int ks = e >> 6, l2 = e & 63;
+        const int m0 = ks * 32 + 4 * (l2 >> 4) + ((l2 & 15) >> 2), m1 = m0 + 16;
+        const int w0 = m0 & TWm, h0 = (m0 >> p.twl) & THm, d0 = m0 >> (p.twl + p.thl);
+        const int w1 = m1 & TWm, h1 = (m1 >> p.twl) & THm, d1 = m1 >> (p.twl + p.thl);
+        const int lo = 8 * (l2 & 3);
+        const int ws = p.deint ? 1 : p.istr;
+        ktab[e] = make_int2(((d0 * p.istr * p.HH + h0 * p.istr) * p.HW + w0 * ws) * 32 + lo,
+                            ((d1 * p.istr * p.HH + h1 * p.istr) * p.HW + w1 * ws) * 32 + lo);
+    }
+    __syncthreads();
+
+    // rows of this wave: r = wave + 8*j -> (tap, plane); rows beyond the slab re-read row 0 and are dropped at the write
+    int aoff[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const int r = wave + 8 * j, rr = r < nrows ? r : 0;
+        aoff[j] = (rr % p.PL) * p.imgp * 1024 + tapoff[rr / p.PL];
+    }
+    f32x4 acc[R][Q];
+#pragma unroll
+    for (int j = 0; j < R; ++j)
+#pragma unroll
+        for (int q = 0; q < Q; ++q) acc[j][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // B fragments: voxel row m0 = 4*lg + (li >> 2) of the K-step, swizzled 32-byte block q ^ f(m0)
+    const int m0l = 4 * lg + (li >> 2);
+    const int fsw = p.CO2 == 128 ? (m0l >> 1) & 3 : (p.CO2 == 64 ? (m0l >> 2) & 1 : 0);
+    int yq[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) yq[q] = m0l * p.CO2 + 32 * (q ^ fsw) + 8 * (li & 3);
+    const int ystep = 32 * p.CO2, y16 = 16 * p.CO2;
+    const bool do_db = p.db && cib == 0;
+    float dbs[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dbs[e] = 0.f;
+    const int nslots = CO >> 3;                  // 16-byte slots per dY row
+    const int db_s = tid % nslots, db_v0 = tid / nslots, db_vs = 512 / nslots;
+
+    constexpr int RC = R <= 4 ? R : (R == 7 ? 7 : 4);
+    constexpr int NCH = (R + RC - 1) / RC;
+    int it = 0;
+    for (int tile = blockIdx.x; tile < p.total_tiles; tile += gridDim.x, ++it) {
+        char* hb = smem + (it & 1) * p.bufb;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of the tile has landed ...
+        __syncthreads();                                     // ... everybody's has; and the other buffer is no longer being read
+        if (tile + (int)gridDim.x < p.total_tiles) issue(tile + gridDim.x, ((it + 1) & 1) * p.bufb);
+        const char* yb = hb + p.nA * 1024;
+        if (do_db) {
+            for (int v = db_v0; v < BM; v += db_vs) {
+                const bf16x8 r = *(const bf16x8*)(yb + v * p.CO2 + db_s * 16);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dbs[e] += bf2f((bf16_t)r[e]);
+            }
+        }
+        // ---- K loop over the tile's voxels, 32 per step; rows in chunks of RC with the next chunk's (or next step's) operand
+        // fragments fetched before the MFMAs of the current one.  No MFMA or fetch is conditional. ----
+        const int2* kt = ktab + lane;
+        bf16x8 A[2][RC], B[2][Q];
+        {
+            const int2 r = kt[0];
+#pragma unroll
+            for (int q = 0; q < Q; ++q) B[0][q] = tr_frag_d(yb + yq[q], yb + yq[q] + y16);
+#pragma unroll
+            for (int j = 0; j < RC; ++j) A[0][j] = tr_frag_d(hb + r.x + aoff[j], hb + r.y + aoff[j]);
+        }
+        for (int ks = 0; ks < nks; ks += 2) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int2 rc = kt[(ks + u) * 64];
+                const int kn = min(ks + u + 1, nks - 1);
+                const int2 rn = kt[kn * 64];
+                const char* yn = yb + kn * ystep;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    const int s = (u * NCH + c) & 1;
+                    if (c + 1 < NCH) {
+#pragma unroll
+                        for (int j = 0; j < RC; ++j) {
+                            const int jj = (c + 1) * RC + j < R ? (c + 1) * RC + j : R - 1;
+                            A[s ^ 1][j] = tr_frag_d(hb + rc.x + aoff[jj], hb + rc.y + aoff[jj]);
+                        }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < Q; ++q) B[u ^ 1][q] = tr_frag_d(yn + yq[q], yn + yq[q] + y16);
+#pragma unroll
+                        for (int j = 0; j < RC; ++j) A[s ^ 1][j] = tr_frag_d(hb + rn.x + aoff[j], hb + rn.y + aoff[j]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < RC; ++j)
+                        if (c * RC + j < R) {
+#pragma unroll
+                            for (int q = 0; q < Q; ++q)
+                                acc[c * RC + j][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[s][j], B[u][q], acc[c * RC + j][q], 0, 0, 0);
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    }
+    // ---- the slab: lane holds dW rows ci = 4*lg + e, column co = li of every (row, column block) ----
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const int r = wave + 8 * j;
+        if (r >= nrows) continue;
+        const int tap = r / p.PL, ci0 = (cib * p.PL + r % p.PL) * 16 + 4 * lg;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int co = cob * CO + q * 16 + li;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const size_t i = ((size_t)p.tap_src[tap] * p.Cin + ci0 + e) * p.Cout + co;
+                if (p.part) p.part[(size_t)blockIdx.x * p.dw_elems + i] = acc[j][q][e];
+                else atomicAdd(&p.dw[i], acc[j][q][e]);
+            }
+        }
+    }
+    if (do_db) {        // block-reduce the bias partials in LDS, then one atomic per channel per workgroup
+        __syncthreads();
+        float* red = (float*)smem;
+        if (tid < CO) red[tid] = 0.f;
+        __syncthreads();
+        if (db_v0 < BM) {
+            const int fv = p.CO2 == 128 ? (db_v0 >> 1) & 3 : (p.CO2 == 64 ? (db_v0 >> 2) & 1 : 0);
+            const int ch = 16 * ((db_s >> 1) ^ fv) + 8 * (db_s & 1);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) atomicAdd(&red[ch + e], dbs[e]);
+        }
+        __syncthreads();
+        if (tid < CO) atomicAdd(&p.db[cob * CO + tid], red[tid]);
+    }
+}
+
+template <int R, int Q>
+static void launch_wd(const WgdK& k, dim3 grid, int lds, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)wgrad_dma_kernel<R, Q>, hipFuncAttributeMaxDynamicSharedMemorySize, VG_LDS_LIMIT);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((wgrad_dma_kernel<R, Q>), grid, dim3(512), lds, s, k);
+}
+
+// Serve vg_conv3d_wgrad through the materialised-operand path.  Returns VG_OK when served, 1 when the call is not one of its
+// shapes (the caller continues with wgrad_kernel), < 0 on error.
+int vg_wgrad_dma(const vg_conv_desc* d, const void* dy, int dy_f32, const int32_t* tap_idx_host, int T_total, float* dw, float* db,
+                 float* scratch, int64_t scratch_bytes, hipStream_t s) {
+    if (!vg_tune("WGRAD_DMA", 1)) return 1;
+    const int Cin = d->c_src0 + d->c_src1;
+    if (d->f32 || dy_f32 || d->src_f32 || d->wpack || Cin < 16 || (Cin % 16) || (d->Cout % 16) || d->ntaps < 8 || d->ntaps > VG_MAX_TAPS) return 1;
+    if (d->istr < 1 || d->istr > 2 || !scratch || T_total < 1) return 1;
+    if ((d->OW % 8) || d->OD < 2 || d->OH < 2) return 1;
+    if (d->c_src1 > 0 && ((d->c_src0 % 8) || (d->c_src1 % 8))) return 1;
+    // taps: extents and 0-based offsets
+    int mn[3] = {127, 127, 127}, mx[3] = {-128, -128, -128};
+    for (int i = 0; i < d->ntaps; ++i) {
+        const int v[3] = {d->tap_d[i], d->tap_h[i], d->tap_w[i]};
+        for (int a = 0; a < 3; ++a) { if (v[a] < mn[a]) mn[a] = v[a]; if (v[a] > mx[a]) mx[a] = v[a]; }
+    }
+    const int ex[3] = {mx[0] - mn[0] + 1, mx[1] - mn[1] + 1, mx[2] - mn[2] + 1};
+    if (d->pad_mode == VG_PAD_REFLECT) {         // one reflection only: the padded grid must stay within [-(n-1), 2n-2]
+        const int od[3] = {d->OD, d->OH, d->OW}, nn[3] = {d->D, d->H, d->W};
+        for (int a = 0; a < 3; ++a) if (mn[a] < -(nn[a] - 1) || (od[a] - 1) * d->istr + mx[a] > 2 * nn[a] - 2) return 1;
+    }
+    const int CO = d->Cout >= 64 ? 64 : d->Cout;
+    if (d->Cout % CO) return 1;
+    const int Q = CO / 16;
+    const int NPL = Cin / 16;
+    // rows per wave the instantiated variants offer for this Q; planes per workgroup: as many as the largest variant holds
+    static const int RQ4[] = {7, 8, 0}, RQ2[] = {4, 7, 12, 0}, RQ1[] = {4, 12, 0};
+    const int* ravail = Q == 4 ? RQ4 : (Q == 2 ? RQ2 : RQ1);
+    int rmax = 0; for (int i = 0; ravail[i]; ++i) rmax = ravail[i];
+    int PL = 0;
+    for (int pl = NPL; pl >= 1; --pl) if (NPL % pl == 0 && d->ntaps * pl <= 8 * rmax) { PL = pl; break; }
+    if (!PL) return 1;
+    const int deint = d->istr == 2 ? 1 : 0;
+    const int Dp = (d->OD - 1) * d->istr + ex[0], Hp = (d->OH - 1) * d->istr + ex[1], Wp = (d->OW - 1) * d->istr + ex[2];
+    const int WE = (Wp + 1) / 2, Wps = deint ? 2 * WE : Wp;
+    const int64_t plane_bytes = (int64_t)Dp * Hp * Wps * 32;
+    const int64_t p_bytes = ((plane_bytes * NPL * d->N + 255) / 256) * 256;
+    if (p_bytes >= (1LL << 31) || plane_bytes * PL >= (1LL << 30)) return 1;
+    // ---- tile: TW in {8, 16}, powers of two dividing the grid, two buffers within the LDS; the largest tile that still
+    // gives the chip >= 256 workgroups (columns x tiles), else the largest that fits ----
+    const int ncib = NPL / PL, ncob = d->Cout / CO;
+    const int columns = ncib * ncob;
+    int best[8] = {0}; bool have = false;
+    const int bm_cap = vg_tune("WGRAD_DMA_BM", 256);
+    for (int bm = 256; bm >= 64 && !have; bm >>= 1) {
+        if (bm > bm_cap) continue;
+        long bvol = -1;
+        for (int tw = 8; tw <= 16; tw <<= 1) {
+            if (d->OW % tw) continue;
+            for (int th = 1; th <= d->OH && tw * th <= bm; th <<= 1) {
+                if (d->OH % th) continue;
+                const int td = bm / (tw * th);
+                if (td > d->OD || (d->OD % td)) continue;
+                const int HD = (td - 1) * d->istr + ex[0], HH = (th - 1) * d->istr + ex[1], HW = (tw - 1) * d->istr + ex[2];
+                const int imgp = (HD * HH * HW * 32 + 1023) / 1024;
+                const int nA = PL * imgp, nB = bm * CO * 2 / 1024;
+                if (nA > 8 * VG_WD_MAXA || nB > 8 * VG_WD_MAXB || nB < 1) continue;
+                const int bufb = (nA + nB) * 1024;
+                const int lds = 2 * bufb + VG_MAX_TAPS * 4 + (bm / 32) * 512;
+                if (lds > VG_LDS_LIMIT) continue;
+                const long vol = (long)HD * HH * HW;
+                if (bvol < 0 || vol < bvol) { bvol = vol; best[0] = td; best[1] = th; best[2] = tw; best[3] = lds; }
+            }
+        }
+        if (bvol < 0) continue;
+        const long tiles = (long)d->N * (d->OD / best[0]) * (d->OH / best[1]) * (d->OW / best[2]);
+        if (tiles * columns >= 256 || bm == 64) have = true;
+        else { best[4] = best[0]; best[5] = best[1]; best[6] = best[2]; best[7] = best[3]; }     // remember: a smaller tile may not exist
+    }
+    if (!have) { if (!best[4]) return 1; best[0] = best[4]; best[1] = best[5]; best[2] = best[6]; best[3] = best[7]; }
+    const int TD = best[0], TH = best[1], TW = best[2], lds = best[3];
+    const int BM = TD * TH * TW;
+    WgdK k;
+    k.N = d->N; k.OD = d->OD; k.OH = d->OH; k.OW = d->OW; k.Cout = d->Cout; k.Cin = Cin;
+    k.plane_bytes = (int)plane_bytes; k.Hp = Hp; k.Wps = Wps; k.WEP = deint ? WE : 0; k.istr = d->istr; k.deint = deint;
+    k.ntaps = d->ntaps;
+    for (int i = 0; i < VG_MAX_TAPS; ++i) {
+        k.tap_src[i] = i < d->ntaps ? tap_idx_host[i] : 0;
+        k.td[i] = i < d->ntaps ? d->tap_d[i] - mn[0] : 0; k.th[i] = i < d->ntaps ? d->tap_h[i] - mn[1] : 0; k.tw[i] = i < d->ntaps ? d->tap_w[i] - mn[2] : 0;
+    }
+    k.PL = PL; k.NPL = NPL; k.ncob = ncob; k.CO2 = CO * 2;
+    k.tdl = ilog2_exact(TD); k.thl = ilog2_exact(TH); k.twl = ilog2_exact(TW);
+    k.tiles_d = d->OD / TD; k.tiles_h = d->OH / TH; k.tiles_w = d->OW / TW;
+    k.total_tiles = d->N * k.tiles_d * k.tiles_h * k.tiles_w;
+    k.HD = (TD - 1) * d->istr + ex[0]; k.HH = (TH - 1) * d->istr + ex[1]; k.HW = (TW - 1) * d->istr + ex[2];
+    k.HWE = deint ? (k.HW + 1) / 2 : 0;
+    k.imgp = (k.HD * k.HH * k.HW * 32 + 1023) / 1024; k.nA = PL * k.imgp; k.nB = BM * CO * 2 / 1024; k.bufb = (k.nA + k.nB) * 1024;
+    k.dw = dw; k.db = db; k.dw_elems = T_total * Cin * d->Cout;
+    // rows per wave: the smallest instantiated variant that holds the slab
+    const int rneed = (d->ntaps * PL + 7) / 8;
+    int Rsel = 0; for (int i = 0; ravail[i]; ++i) if (ravail[i] >= rneed) { Rsel = ravail[i]; break; }
+    if (!Rsel) return 1;
+    // persistent grid: one workgroup per CU (LDS); WGRAD_DMA_WGS workgroups in all, shared out over the columns
+    const int wg_target = vg_tune("WGRAD_DMA_WGS", 256);
+    int bx = wg_target / columns; if (bx < 1) bx = 1; if (bx > k.total_tiles) bx = k.total_tiles;
+    const int64_t part_bytes = bx > 1 ? (int64_t)bx * k.dw_elems * 4 : 0;
+    if (p_bytes + part_bytes > scratch_bytes) return 1;
+    k.P = (const char*)scratch; k.dy = (const char*)dy;
+    k.part = bx > 1 ? (float*)((char*)scratch + p_bytes) : nullptr;
+    if (vg_dry("wgrad_dma<%d,%d>|bm%d|pl%d|s%d|part%d|walk%d", Rsel, Q, BM, PL, d->istr, k.part ? 1 : 0, k.total_tiles > bx ? 1 : 0)) return VG_OK;
+    MatK m;
+    m.src0 = d->src0; m.src1 = d->src1; m.c0 = d->c_src0; m.c1 = d->c_src1; m.shift0 = d->src0_shift ? 1 : 0;
+    m.N = d->N; m.D = d->D; m.H = d->H; m.W = d->W; m.Cin = Cin;
+    m.in_scale = d->in_scale; m.in_shift = d->in_shift; m.act = d->act;
+    m.noise = (const bf16_t*)d->noise; m.npad = d->noise ? d->noise_pad : 0; m.pad_mode = d->pad_mode;
+    m.pmin_d = mn[0]; m.pmin_h = mn[1]; m.pmin_w = mn[2]; m.Dp = Dp; m.Hp = Hp; m.Wp = Wp;
+    m.deint = deint; m.WE = WE; m.Wps = Wps; m.out = (bf16_t*)scratch;
+    hipLaunchKernelGGL(materialize_kernel, dim3(d->N * Dp * Hp), dim3(256), 0, s, m);
+    const dim3 grid(bx, columns, 1);
+    if (Q == 4) { if (Rsel == 7) launch_wd<7, 4>(k, grid, lds, s); else launch_wd<8, 4>(k, grid, lds, s); }
+    else if (Q == 2) { if (Rsel == 4) launch_wd<4, 2>(k, grid, lds, s); else if (Rsel == 7) launch_wd<7, 2>(k, grid, lds, s); else launch_wd<12, 2>(k, grid, lds, s); }
+    else { if (Rsel == 4) launch_wd<4, 1>(k, grid, lds, s); else launch_wd<12, 1>(k, grid, lds, s); }
+    if (k.part) vg_launch_reduce_partials(k.part, bx, k.dw_elems, dw, s);
+    return vg_check_launch();
+}

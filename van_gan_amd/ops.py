@@ -243,8 +243,8 @@ def side_join():
             cur.wait_stream(sd)
 
 
-WGRAD_SCRATCH = {}     # (device, stream) -> fp32 scratch for the partial-slab weight-gradient reduction (256 MB)
-WGRAD_SCRATCH_ELEMS = 64 << 20
+WGRAD_SCRATCH = {}     # (device, stream) -> fp32 scratch of the weight gradients: materialised operand + partial slabs (384 MB)
+WGRAD_SCRATCH_ELEMS = 96 << 20
 
 
 # ------------------------------------------------------------------------------------------------------
