@@ -118,9 +118,16 @@ struct WgdK {
     int PL, NPL, ncob, CO2;           // planes per workgroup, planes of P, output blocks, bytes of one dY row in LDS (CO * 2)
     int tdl, thl, twl, tiles_d, tiles_h, tiles_w, total_tiles;
     int HD, HH, HW, HWE;              // halo box (voxels); HWE: even part of a de-interleaved halo row
-    int imgp, nA, nB, bufb;           // 1-KiB pieces per plane image, A pieces, B pieces per tile; bytes per buffer
+    int imgp, nA, nB, bufb, nbuf;     // 1-KiB pieces per plane image, A pieces, B pieces per tile; bytes per buffer; buffers (2..5)
     float* dw; float* db; float* part; int dw_elems;
+    unsigned m_imgp, m_hhw, m_hw, m_pl, m_tpn, m_tw, m_th, m_ncob;     // floor(2^32 / d) + 1 of the run-time divisors (fast_div)
+    int co2l;                         // log2(CO2)
+    unsigned long long* stamps;       // diagnostic (vg_set_stamp_buffer): per workgroup 8 words of phase cycle sums, else NULL
 };
+
+// n / d for 0 <= n < 2^32 / d by one multiply-high, m = floor(2^32 / d) + 1 from the host (the integer divisions of the
+// prologue -- 13 DMA pieces x 3 divisions x ~40 instructions -- were 6 us of every workgroup's life)
+__device__ __forceinline__ int fast_div(int n, unsigned m) { return m ? (int)__umulhi((unsigned)n, m) : n; }       // m == 0: d == 1
 
 // One LDS-DMA piece: 64 lanes x 16 bytes from sbase + voff (per lane) to LDS bytes [lds_addr, lds_addr + 1024).  Inline asm on
 // purpose: for the builtin hipcc tracks the copy as a pending LDS write and drains it (s_waitcnt vmcnt(0)) in front of the next
@@ -130,6 +137,20 @@ __device__ __forceinline__ void glds16(const char* sbase, int voff, unsigned lds
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+}
+
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate): all but this wave's n youngest copies
+// have landed.  n beyond the table waits for more than asked (a smaller count is always safe).
+#define VG_VMCNT_CASE(i) case i: asm volatile("s_waitcnt vmcnt(" #i ")" ::: "memory"); break;
+__device__ __forceinline__ void wait_vmcnt(int n) {
+    switch (n) {
+        VG_VMCNT_CASE(0) VG_VMCNT_CASE(1) VG_VMCNT_CASE(2) VG_VMCNT_CASE(3) VG_VMCNT_CASE(4) VG_VMCNT_CASE(5) VG_VMCNT_CASE(6) VG_VMCNT_CASE(7)
+        VG_VMCNT_CASE(8) VG_VMCNT_CASE(9) VG_VMCNT_CASE(10) VG_VMCNT_CASE(11) VG_VMCNT_CASE(12) VG_VMCNT_CASE(13) VG_VMCNT_CASE(14) VG_VMCNT_CASE(15)
+        VG_VMCNT_CASE(16) VG_VMCNT_CASE(17) VG_VMCNT_CASE(18) VG_VMCNT_CASE(19) VG_VMCNT_CASE(20) VG_VMCNT_CASE(21) VG_VMCNT_CASE(22) VG_VMCNT_CASE(23)
+        VG_VMCNT_CASE(24) VG_VMCNT_CASE(25) VG_VMCNT_CASE(26) VG_VMCNT_CASE(27) VG_VMCNT_CASE(28) VG_VMCNT_CASE(29) VG_VMCNT_CASE(30) VG_VMCNT_CASE(31)
+        VG_VMCNT_CASE(32) VG_VMCNT_CASE(33) VG_VMCNT_CASE(34) VG_VMCNT_CASE(35) VG_VMCNT_CASE(36) VG_VMCNT_CASE(37) VG_VMCNT_CASE(38) VG_VMCNT_CASE(39)
+        default: asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); break;
+    }
 }
 
 __device__ __forceinline__ bf16x8 tr_frag_d(const char* base0, const char* base1) {
@@ -144,14 +165,16 @@ __global__ __launch_bounds__(512, 2) void wgrad_dma_kernel(const WgdK p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lg = lane >> 4, li = lane & 15;
-    const int cob = blockIdx.y % p.ncob, cib = blockIdx.y / p.ncob;
+    const int cib = fast_div(blockIdx.y, p.m_ncob), cob = blockIdx.y - cib * p.ncob;
     const int BM = 1 << (p.tdl + p.thl + p.twl);
     const int nks = BM >> 5;
     const int TWm = (1 << p.twl) - 1, THm = (1 << p.thl) - 1;
-    int* tapoff = (int*)(smem + 2 * p.bufb);
-    int2* ktab = (int2*)(tapoff + VG_MAX_TAPS);
+    int* tapoff = (int*)(smem + p.nbuf * p.bufb);
     const int CO = p.CO2 >> 1;
     const int nrows = p.ntaps * p.PL;
+    const bool stamp = p.stamps != nullptr;
+    unsigned long long t_begin = 0, t_loop = 0, t_a = 0, s_wait = 0, s_issue = 0, s_k = 0;
+    if (stamp) t_begin = __builtin_readcyclecounter();
 
     // ---- per-lane DMA source offsets (the halo box has the same shape for every tile: P is padded, tiles divide the grid) ----
     int aoffs[VG_WD_MAXA], boffs[VG_WD_MAXB];
@@ -160,18 +183,18 @@ __global__ __launch_bounds__(512, 2) void wgrad_dma_kernel(const WgdK p) {
 #pragma unroll
         for (int k = 0; k < VG_WD_MAXA; ++k) {
             const int piece = wave + 8 * k;
-            const int pl = piece / p.imgp, pk = piece - pl * p.imgp;
+            const int pl = fast_div(piece, p.m_imgp), pk = piece - pl * p.imgp;
             int iv = pk * 32 + (lane >> 1);
             if (iv >= nvox) iv = 0;
-            const int hd = iv / (p.HH * p.HW), rem = iv - hd * (p.HH * p.HW);
-            const int hh = rem / p.HW, ws = rem - hh * p.HW;
+            const int hd = fast_div(iv, p.m_hhw), rem = iv - hd * (p.HH * p.HW);
+            const int hh = fast_div(rem, p.m_hw), ws = rem - hh * p.HW;
             const int gw = p.deint ? (ws < p.HWE ? ws : p.WEP + ws - p.HWE) : ws;
             aoffs[k] = pl * p.plane_bytes + ((hd * p.Hp + hh) * p.Wps + gw) * 32 + (lane & 1) * 16;
         }
 #pragma unroll
         for (int k = 0; k < VG_WD_MAXB; ++k) {
             const int byte = (wave + 8 * k) * 1024 + lane * 16;
-            int m = byte / p.CO2; const int s = (byte - m * p.CO2) >> 4;
+            int m = byte >> p.co2l; const int s = (byte - (m << p.co2l)) >> 4;
             if (m >= BM) m = 0;
             const int f = p.CO2 == 128 ? (m >> 1) & 3 : (p.CO2 == 64 ? (m >> 2) & 1 : 0);
             const int blk = (s >> 1) ^ f;
@@ -183,9 +206,9 @@ __global__ __launch_bounds__(512, 2) void wgrad_dma_kernel(const WgdK p) {
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_d*)smem;
     auto issue = [&](int tile, int bufoff) {
         int t = tile;
-        const int n = t / tiles_per_n; t -= n * tiles_per_n;
-        const int ti_w = t % p.tiles_w; t /= p.tiles_w;
-        const int ti_h = t % p.tiles_h; const int ti_d = t / p.tiles_h;
+        const int n = fast_div(t, p.m_tpn); t -= n * tiles_per_n;
+        const int t1 = fast_div(t, p.m_tw), ti_w = t - t1 * p.tiles_w;
+        const int ti_d = fast_div(t1, p.m_th), ti_h = t1 - ti_d * p.tiles_h;
         const int od0 = ti_d << p.tdl, oh0 = ti_h << p.thl, ow0 = ti_w << p.twl;
         const char* abase = p.P + (size_t)(n * p.NPL + cib * p.PL) * p.plane_bytes
                             + (size_t)((od0 * p.istr * p.Hp + oh0 * p.istr) * p.Wps + (p.deint ? ow0 : ow0 * p.istr)) * 32;
@@ -201,21 +224,14 @@ __global__ __launch_bounds__(512, 2) void wgrad_dma_kernel(const WgdK p) {
             if (piece < p.nB) glds16(bbase, boffs[k], lds0 + bufoff + (p.nA + piece) * 1024);
         }
     };
-    if ((int)blockIdx.x < p.total_tiles) issue(blockIdx.x, 0);
+    // this workgroup's tiles: blockIdx.x, + gridDim.x, ...; nbuf - 1 of them are kept in flight ahead of the one being multiplied
+    const int ntw = ((int)blockIdx.x < p.total_tiles) ? (p.total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+    const int n_w = (wave < p.nA ? (p.nA - wave + 7) >> 3 : 0) + (wave < p.nB ? (p.nB - wave + 7) >> 3 : 0);     // this wave's copies per tile
+    for (int j = 0; j < p.nbuf - 1 && j < ntw; ++j) issue(blockIdx.x + j * gridDim.x, j * p.bufb);
 
-    // ---- tables: tap offsets inside the halo image, per-(K-step, lane) offsets of the transposed reads ----
+    // ---- table: tap offsets inside the halo image ----
     if (tid < p.ntaps)
         tapoff[tid] = ((p.td[tid] * p.HH + p.th[tid]) * p.HW + (p.deint ? (p.tw[tid] & 1) * p.HWE + (p.tw[tid] >> 1) : p.tw[tid])) * 32;
-    for (int e = tid; e < nks * 64; e += 512) {
-        const int ks = e >> 6, l2 = e & 63;
-        const int m0 = ks * 32 + 4 * (l2 >> 4) + ((l2 & 15) >> 2), m1 = m0 + 16;
-        const int w0 = m0 & TWm, h0 = (m0 >> p.twl) & THm, d0 = m0 >> (p.twl + p.thl);
-        const int w1 = m1 & TWm, h1 = (m1 >> p.twl) & THm, d1 = m1 >> (p.twl + p.thl);
-        const int lo = 8 * (l2 & 3);
-        const int ws = p.deint ? 1 : p.istr;
-        ktab[e] = make_int2(((d0 * p.istr * p.HH + h0 * p.istr) * p.HW + w0 * ws) * 32 + lo,
-                            ((d1 * p.istr * p.HH + h1 * p.istr) * p.HW + w1 * ws) * 32 + lo);
-    }
     __syncthreads();
 
     // rows of this wave: r = wave + 8*j -> (tap, plane); rows beyond the slab re-read row 0 and are dropped at the write
@@ -223,7 +239,8 @@ __global__ __launch_bounds__(512, 2) void wgrad_dma_kernel(const WgdK p) {
 #pragma unroll
     for (int j = 0; j < R; ++j) {
         const int r = wave + 8 * j, rr = r < nrows ? r : 0;
-        aoff[j] = (rr % p.PL) * p.imgp * 1024 + tapoff[rr / p.PL];
+        const int tp = fast_div(rr, p.m_pl);
+        aoff[j] = (rr - tp * p.PL) * p.imgp * 1024 + tapoff[tp];
     }
     f32x4 acc[R][Q];
 #pragma unroll
@@ -237,6 +254,14 @@ __global__ __launch_bounds__(512, 2) void wgrad_dma_kernel(const WgdK p) {
 #pragma unroll
     for (int q = 0; q < Q; ++q) yq[q] = m0l * p.CO2 + 32 * (q ^ fsw) + 8 * (li & 3);
     const int ystep = 32 * p.CO2, y16 = 16 * p.CO2;
+    // A fragments: halo offset of a K-step's voxel = lane part (voxel m0l resp. m0l + 16 of the step: w, and the row inside the
+    // step's 32 / TW rows) + a wave-uniform part (the step's first row and plane: scalar arithmetic, no table, no LDS read in the
+    // dependent chain).  The host keeps TH >= 32 / TW, so lane row + step row never carries into the next plane.
+    const int rps_l = 5 - p.twl;                                   // log2 of the rows one K-step spans
+    const int wsx = p.deint ? 1 : p.istr;
+    const int lx = (((m0l >> p.twl) * p.istr) * p.HW + (m0l & TWm) * wsx) * 32 + 8 * (li & 3);
+    const int ly = ((((m0l + 16) >> p.twl) * p.istr) * p.HW + ((m0l + 16) & TWm) * wsx) * 32 + 8 * (li & 3);
+    auto soff = [&](int ks) { const int q32 = ks << rps_l; return (((q32 >> p.thl) * p.istr * p.HH + (q32 & THm) * p.istr) * p.HW) << 5; };
     const bool do_db = p.db && cib == 0;
     float dbs[8];
 #pragma unroll
@@ -244,14 +269,20 @@ __global__ __launch_bounds__(512, 2) void wgrad_dma_kernel(const WgdK p) {
     const int nslots = CO >> 3;                  // 16-byte slots per dY row
     const int db_s = tid % nslots, db_v0 = tid / nslots, db_vs = 512 / nslots;
 
-    constexpr int RC = R <= 4 ? R : (R == 7 ? 7 : 4);
+    constexpr int RC = R <= 4 ? R : 4;
     constexpr int NCH = (R + RC - 1) / RC;
-    int it = 0;
-    for (int tile = blockIdx.x; tile < p.total_tiles; tile += gridDim.x, ++it) {
-        char* hb = smem + (it & 1) * p.bufb;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of the tile has landed ...
-        __syncthreads();                                     // ... everybody's has; and the other buffer is no longer being read
-        if (tile + (int)gridDim.x < p.total_tiles) issue(tile + gridDim.x, ((it + 1) & 1) * p.bufb);
+    int cur = 0, nxt = p.nbuf - 1;                          // buffer of the tile being multiplied / of the next tile to request
+    if (stamp) t_loop = __builtin_readcyclecounter();
+    for (int it = 0; it < ntw; ++it) {
+        char* hb = smem + cur * p.bufb;
+        if (stamp) t_a = __builtin_readcyclecounter();
+        const int newer = min(p.nbuf - 2, ntw - 1 - it);         // tiles requested after this one
+        wait_vmcnt(newer * n_w);                             // this wave's share of the tile has landed ...
+        __syncthreads();                                     // ... everybody's has; and the buffer multiplied last is no longer being read
+        if (stamp) { const unsigned long long t = __builtin_readcyclecounter(); s_wait += t - t_a; t_a = t; }
+        if (it + p.nbuf - 1 < ntw) issue(blockIdx.x + (it + p.nbuf - 1) * gridDim.x, nxt * p.bufb);
+        if (stamp) { const unsigned long long t = __builtin_readcyclecounter(); s_issue += t - t_a; t_a = t; }
+        cur = cur + 1 == p.nbuf ? 0 : cur + 1; nxt = nxt + 1 == p.nbuf ? 0 : nxt + 1;
         const char* yb = hb + p.nA * 1024;
         if (do_db) {
             for (int v = db_v0; v < BM; v += db_vs) {
@@ -262,56 +293,59 @@ __global__ __launch_bounds__(512, 2) void wgrad_dma_kernel(const WgdK p) {
         }
         // ---- K loop over the tile's voxels, 32 per step; rows in chunks of RC with the next chunk's (or next step's) operand
         // fragments fetched before the MFMAs of the current one.  No MFMA or fetch is conditional. ----
-        const int2* kt = ktab + lane;
-        bf16x8 A[2][RC], B[2][Q];
         {
-            const int2 r = kt[0];
+            bf16x8 A[2][RC], B[2][Q];
+            {
 #pragma unroll
-            for (int q = 0; q < Q; ++q) B[0][q] = tr_frag_d(yb + yq[q], yb + yq[q] + y16);
+                for (int q = 0; q < Q; ++q) B[0][q] = tr_frag_d(yb + yq[q], yb + yq[q] + y16);
 #pragma unroll
-            for (int j = 0; j < RC; ++j) A[0][j] = tr_frag_d(hb + r.x + aoff[j], hb + r.y + aoff[j]);
-        }
-        for (int ks = 0; ks < nks; ks += 2) {
+                for (int j = 0; j < RC; ++j) A[0][j] = tr_frag_d(hb + lx + aoff[j], hb + ly + aoff[j]);
+            }
+            for (int ks = 0; ks < nks; ks += 2) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int2 rc = kt[(ks + u) * 64];
-                const int kn = min(ks + u + 1, nks - 1);
-                const int2 rn = kt[kn * 64];
-                const char* yn = yb + kn * ystep;
+                for (int u = 0; u < 2; ++u) {
+                    const int kn = min(ks + u + 1, nks - 1);
+                    const char* hc = hb + soff(ks + u);
+                    const char* hn = hb + soff(kn);
+                    const char* yn = yb + kn * ystep;
 #pragma unroll
-                for (int c = 0; c < NCH; ++c) {
-                    const int s = (u * NCH + c) & 1;
-                    if (c + 1 < NCH) {
+                    for (int c = 0; c < NCH; ++c) {
+                        const int s = (u * NCH + c) & 1;
+                        if (c + 1 < NCH) {
 #pragma unroll
-                        for (int j = 0; j < RC; ++j) {
-                            const int jj = (c + 1) * RC + j < R ? (c + 1) * RC + j : R - 1;
-                            A[s ^ 1][j] = tr_frag_d(hb + rc.x + aoff[jj], hb + rc.y + aoff[jj]);
+                            for (int j = 0; j < RC; ++j) {
+                                const int jj = (c + 1) * RC + j < R ? (c + 1) * RC + j : R - 1;
+                                A[s ^ 1][j] = tr_frag_d(hc + lx + aoff[jj], hc + ly + aoff[jj]);
+                            }
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < Q; ++q) B[u ^ 1][q] = tr_frag_d(yn + yq[q], yn + yq[q] + y16);
+#pragma unroll
+                            for (int j = 0; j < RC; ++j) A[s ^ 1][j] = tr_frag_d(hn + lx + aoff[j], hn + ly + aoff[j]);
                         }
-                    } else {
+                        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int q = 0; q < Q; ++q) B[u ^ 1][q] = tr_frag_d(yn + yq[q], yn + yq[q] + y16);
+                        for (int j = 0; j < RC; ++j)
+                            if (c * RC + j < R) {
 #pragma unroll
-                        for (int j = 0; j < RC; ++j) A[s ^ 1][j] = tr_frag_d(hb + rn.x + aoff[j], hb + rn.y + aoff[j]);
+                                for (int q = 0; q < Q; ++q)
+                                    acc[c * RC + j][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[s][j], B[u][q], acc[c * RC + j][q], 0, 0, 0);
+                            }
+                        __builtin_amdgcn_sched_barrier(0);
                     }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int j = 0; j < RC; ++j)
-                        if (c * RC + j < R) {
-#pragma unroll
-                            for (int q = 0; q < Q; ++q)
-                                acc[c * RC + j][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[s][j], B[u][q], acc[c * RC + j][q], 0, 0, 0);
-                        }
-                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
+        if (stamp) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); s_k += __builtin_readcyclecounter() - t_a; }
     }
+    unsigned long long t_slab = 0;
+    if (stamp) t_slab = __builtin_readcyclecounter();
     // ---- the slab: lane holds dW rows ci = 4*lg + e, column co = li of every (row, column block) ----
 #pragma unroll
     for (int j = 0; j < R; ++j) {
         const int r = wave + 8 * j;
         if (r >= nrows) continue;
-        const int tap = r / p.PL, ci0 = (cib * p.PL + r % p.PL) * 16 + 4 * lg;
+        const int tap = fast_div(r, p.m_pl), ci0 = (cib * p.PL + r - tap * p.PL) * 16 + 4 * lg;
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
             const int co = cob * CO + q * 16 + li;
@@ -336,6 +370,12 @@ __global__ __launch_bounds__(512, 2) void wgrad_dma_kernel(const WgdK p) {
         }
         __syncthreads();
         if (tid < CO) atomicAdd(&p.db[cob * CO + tid], red[tid]);
+    }
+    if (stamp && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned long long* o = p.stamps + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
+        o[0] = t_loop - t_begin; o[1] = s_wait; o[2] = s_issue; o[3] = s_k; o[4] = __builtin_readcyclecounter() - t_slab;
+        o[5] = __builtin_readcyclecounter() - t_begin; o[6] = ntw; o[7] = __builtin_amdgcn_s_memrealtime();
     }
 }
 
@@ -370,56 +410,93 @@ int vg_wgrad_dma(const vg_conv_desc* d, const void* dy, int dy_f32, const int32_
         const int od[3] = {d->OD, d->OH, d->OW}, nn[3] = {d->D, d->H, d->W};
         for (int a = 0; a < 3; ++a) if (mn[a] < -(nn[a] - 1) || (od[a] - 1) * d->istr + mx[a] > 2 * nn[a] - 2) return 1;
     }
-    const int CO = d->Cout >= 64 ? 64 : d->Cout;
-    if (d->Cout % CO) return 1;
-    const int Q = CO / 16;
     const int NPL = Cin / 16;
-    // rows per wave the instantiated variants offer for this Q; planes per workgroup: as many as the largest variant holds
-    static const int RQ4[] = {7, 8, 0}, RQ2[] = {4, 7, 12, 0}, RQ1[] = {4, 12, 0};
-    const int* ravail = Q == 4 ? RQ4 : (Q == 2 ? RQ2 : RQ1);
-    int rmax = 0; for (int i = 0; ravail[i]; ++i) rmax = ravail[i];
-    int PL = 0;
-    for (int pl = NPL; pl >= 1; --pl) if (NPL % pl == 0 && d->ntaps * pl <= 8 * rmax) { PL = pl; break; }
-    if (!PL) return 1;
     const int deint = d->istr == 2 ? 1 : 0;
     const int Dp = (d->OD - 1) * d->istr + ex[0], Hp = (d->OH - 1) * d->istr + ex[1], Wp = (d->OW - 1) * d->istr + ex[2];
     const int WE = (Wp + 1) / 2, Wps = deint ? 2 * WE : Wp;
     const int64_t plane_bytes = (int64_t)Dp * Hp * Wps * 32;
     const int64_t p_bytes = ((plane_bytes * NPL * d->N + 255) / 256) * 256;
-    if (p_bytes >= (1LL << 31) || plane_bytes * PL >= (1LL << 30)) return 1;
-    // ---- tile: TW in {8, 16}, powers of two dividing the grid, two buffers within the LDS; the largest tile that still
-    // gives the chip >= 256 workgroups (columns x tiles), else the largest that fits ----
-    const int ncib = NPL / PL, ncob = d->Cout / CO;
-    const int columns = ncib * ncob;
-    int best[8] = {0}; bool have = false;
-    const int bm_cap = vg_tune("WGRAD_DMA_BM", 256);
-    for (int bm = 256; bm >= 64 && !have; bm >>= 1) {
-        if (bm > bm_cap) continue;
-        long bvol = -1;
-        for (int tw = 8; tw <= 16; tw <<= 1) {
-            if (d->OW % tw) continue;
-            for (int th = 1; th <= d->OH && tw * th <= bm; th <<= 1) {
-                if (d->OH % th) continue;
-                const int td = bm / (tw * th);
-                if (td > d->OD || (d->OD % td)) continue;
-                const int HD = (td - 1) * d->istr + ex[0], HH = (th - 1) * d->istr + ex[1], HW = (tw - 1) * d->istr + ex[2];
-                const int imgp = (HD * HH * HW * 32 + 1023) / 1024;
-                const int nA = PL * imgp, nB = bm * CO * 2 / 1024;
-                if (nA > 8 * VG_WD_MAXA || nB > 8 * VG_WD_MAXB || nB < 1) continue;
-                const int bufb = (nA + nB) * 1024;
-                const int lds = 2 * bufb + VG_MAX_TAPS * 4 + (bm / 32) * 512;
-                if (lds > VG_LDS_LIMIT) continue;
-                const long vol = (long)HD * HH * HW;
-                if (bvol < 0 || vol < bvol) { bvol = vol; best[0] = td; best[1] = th; best[2] = tw; best[3] = lds; }
+    if (p_bytes >= (1LL << 31)) return 1;
+    const int64_t dw_elems = (int64_t)T_total * Cin * d->Cout;
+    // ---- plan: column block CO (16 * Q channels), planes per workgroup PL, tile, K split bx.  Every candidate (CO, PL) with an
+    // instantiated (rows per wave, Q) variant is priced with a small model of one workgroup's life (cycles): tile loop =
+    // max(MFMA issue, staging at the per-CU LDS-DMA rate) per tile + one DMA latency, the slab write, and -- for bx > 1 -- the
+    // partial slabs' round trip through HBM plus the reduce launch.  Small deep layers (8^3, 16^3: few voxels, megabytes of dW)
+    // come out with narrow columns and no K split (slab added to dW with atomics once), the big thin layers with wide slabs
+    // and 256 K slices.  WGRAD_DMA_CO / _PL / _BX / _BM override (sweeps: tools/sweep_wgrad.py).
+    struct Plan { int CO, PL, R, TD, TH, TW, lds, columns, tiles, bx, nbuf; double cost; };
+    Plan best; best.cost = -1;
+    const int f_co = vg_tune("WGRAD_DMA_CO", 0), f_pl = vg_tune("WGRAD_DMA_PL", 0), f_bx = vg_tune("WGRAD_DMA_BX", 0);
+    const int bm_cap = vg_tune("WGRAD_DMA_BM", 512), nbuf_cap = vg_tune("WGRAD_DMA_NBUF", 5), wg_target = vg_tune("WGRAD_DMA_WGS", 256);
+    static const int RQ4[] = {8, 0}, RQ2[] = {4, 8, 0}, RQ1[] = {4, 8, 12, 0};       // the instantiated (rows per wave, Q) variants
+    for (int CO = 64; CO >= 16; CO >>= 1) {
+        if (CO > d->Cout || (d->Cout % CO) || (f_co && CO != f_co)) continue;
+        const int Q = CO / 16;
+        const int* ravail = Q == 4 ? RQ4 : (Q == 2 ? RQ2 : RQ1);
+        for (int PL = NPL; PL >= 1; --PL) {
+            if ((NPL % PL) || (f_pl && PL != f_pl) || plane_bytes * PL >= (1LL << 30)) continue;
+            const int rneed = (d->ntaps * PL + 7) / 8;
+            int R = 0; for (int i = 0; ravail[i]; ++i) if (ravail[i] >= rneed) { R = ravail[i]; break; }
+            if (!R) continue;
+            const int columns = (NPL / PL) * (d->Cout / CO);
+            // thin slabs (<= 8 accumulator fragments per wave, <= 128 VGPRs): two workgroups per CU -- their MFMA phases are too
+            // short to cover an LDS round trip with two waves per SIMD
+            const int per_cu = 1;          // (two workgroups per CU for the thin slabs: measured slower, 132 vs 115 us on the 16->16 layers at 128^3)
+            const int lds_cap = VG_LDS_LIMIT / per_cu;
+            for (int bm = 512; bm >= 64; bm >>= 1) {
+                if (bm > bm_cap) continue;
+                // tile: TW in {8, 16}, powers of two dividing the grid, two buffers within the LDS, least halo volume
+                long bvol = -1; int t3[5] = {0, 0, 0, 0, 0}, bufb = 0;
+                for (int tw = 8; tw <= 16; tw <<= 1) {
+                    if (d->OW % tw) continue;
+                    for (int th = 1; th <= d->OH && tw * th <= bm; th <<= 1) {
+                        if ((d->OH % th) || tw * th < 32) continue;       // a K-step's 32 voxels stay inside one plane of the tile
+                        const int td = bm / (tw * th);
+                        if (td > d->OD || (d->OD % td)) continue;
+                        const int HD = (td - 1) * d->istr + ex[0], HH = (th - 1) * d->istr + ex[1], HW = (tw - 1) * d->istr + ex[2];
+                        const int imgp = (HD * HH * HW * 32 + 1023) / 1024;
+                        const int nA = PL * imgp, nB = bm * CO * 2 / 1024;
+                        if (nA > 8 * VG_WD_MAXA || nB > 8 * VG_WD_MAXB || nB < 1) continue;
+                        const int tabs = VG_MAX_TAPS * 4;
+                        if (2 * (nA + nB) * 1024 + tabs > lds_cap) continue;
+                        int nb_ = (lds_cap - tabs) / ((nA + nB) * 1024); if (nb_ > nbuf_cap) nb_ = nbuf_cap; if (nb_ < 2) nb_ = 2;
+                        const int lds = nb_ * (nA + nB) * 1024 + tabs;
+                        const long vol = (long)HD * HH * HW;
+                        if (bvol < 0 || vol < bvol) { bvol = vol; t3[0] = td; t3[1] = th; t3[2] = tw; t3[3] = lds; t3[4] = nb_; bufb = (nA + nB) * 1024; }
+                    }
+                }
+                if (bvol < 0) continue;
+                const int tiles = d->N * (d->OD / t3[0]) * (d->OH / t3[1]) * (d->OW / t3[2]);
+                static const int BXC[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192, 256, 0};
+                for (int ib = 0; ib < 17; ++ib) {
+                    int bxx = BXC[ib] ? BXC[ib] : wg_target * per_cu / columns;        // last candidate: exactly the target grid
+                    if (bxx < 1) bxx = 1;
+                    if (bxx > tiles) bxx = tiles;
+                    if (f_bx) bxx = f_bx < tiles ? f_bx : tiles;
+                    else if ((long)bxx * columns > (long)wg_target * per_cu && bxx > 1) continue;
+                    const int64_t part_bytes = bxx > 1 ? (int64_t)bxx * dw_elems * 4 : 0;
+                    if (p_bytes + part_bytes > scratch_bytes) { if (f_bx) break; continue; }
+                    const double ntile = (double)((tiles + bxx - 1) / bxx);
+                    const double rounds = (double)(((long)bxx * columns + 256 * per_cu - 1) / (256 * per_cu));          // workgroups beyond the CUs queue up
+                    const double mfma = (bm / 32) * R * Q * 16.0 * 2.0 * per_cu, stage = bufb / 14.0 * per_cu;
+                    // a copy takes ~4500 cycles to land: with nbuf - 1 tiles in flight a tile costs at least latency / (nbuf - 1)
+                    const double lat = 4500.0 / (t3[4] - 1);
+                    double per = mfma > stage ? mfma : stage; if (lat > per) per = lat;
+                    const double loop = ntile * per + 5000.0;
+                    const double slab = (double)dw_elems / columns * 4.0 / 16.0;                  // one workgroup's slab at ~16 B/clk
+                    double tail;
+                    if (bxx > 1) tail = ((double)(bxx + 1) * dw_elems * 4.0 + dw_elems * 4.0 * 3.0) / 2500.0 + 12000.0;   // partials back in, atomics out (bytes per clk, chip), reduce launch
+                    else tail = (double)dw_elems * 4.0 * 3.0 / 2500.0;                                                     // atomics: ~1/3 of the store rate
+                    const double cost = rounds * (loop + slab) + tail + 6000.0;
+                    if (best.cost < 0 || cost < best.cost) best = Plan{CO, PL, R, t3[0], t3[1], t3[2], t3[3], columns, tiles, bxx, t3[4], cost};
+                    if (f_bx) break;
+                }
             }
         }
-        if (bvol < 0) continue;
-        const long tiles = (long)d->N * (d->OD / best[0]) * (d->OH / best[1]) * (d->OW / best[2]);
-        if (tiles * columns >= 256 || bm == 64) have = true;
-        else { best[4] = best[0]; best[5] = best[1]; best[6] = best[2]; best[7] = best[3]; }     // remember: a smaller tile may not exist
     }
-    if (!have) { if (!best[4]) return 1; best[0] = best[4]; best[1] = best[5]; best[2] = best[6]; best[3] = best[7]; }
-    const int TD = best[0], TH = best[1], TW = best[2], lds = best[3];
+    if (best.cost < 0) return 1;
+    const int CO = best.CO, Q = CO / 16, PL = best.PL, Rsel = best.R;
+    const int TD = best.TD, TH = best.TH, TW = best.TW, lds = best.lds, columns = best.columns, ncob = d->Cout / CO;
     const int BM = TD * TH * TW;
     WgdK k;
     k.N = d->N; k.OD = d->OD; k.OH = d->OH; k.OW = d->OW; k.Cout = d->Cout; k.Cin = Cin;
@@ -435,20 +512,16 @@ int vg_wgrad_dma(const vg_conv_desc* d, const void* dy, int dy_f32, const int32_
     k.total_tiles = d->N * k.tiles_d * k.tiles_h * k.tiles_w;
     k.HD = (TD - 1) * d->istr + ex[0]; k.HH = (TH - 1) * d->istr + ex[1]; k.HW = (TW - 1) * d->istr + ex[2];
     k.HWE = deint ? (k.HW + 1) / 2 : 0;
-    k.imgp = (k.HD * k.HH * k.HW * 32 + 1023) / 1024; k.nA = PL * k.imgp; k.nB = BM * CO * 2 / 1024; k.bufb = (k.nA + k.nB) * 1024;
-    k.dw = dw; k.db = db; k.dw_elems = T_total * Cin * d->Cout;
-    // rows per wave: the smallest instantiated variant that holds the slab
-    const int rneed = (d->ntaps * PL + 7) / 8;
-    int Rsel = 0; for (int i = 0; ravail[i]; ++i) if (ravail[i] >= rneed) { Rsel = ravail[i]; break; }
-    if (!Rsel) return 1;
-    // persistent grid: one workgroup per CU (LDS); WGRAD_DMA_WGS workgroups in all, shared out over the columns
-    const int wg_target = vg_tune("WGRAD_DMA_WGS", 256);
-    int bx = wg_target / columns; if (bx < 1) bx = 1; if (bx > k.total_tiles) bx = k.total_tiles;
-    const int64_t part_bytes = bx > 1 ? (int64_t)bx * k.dw_elems * 4 : 0;
-    if (p_bytes + part_bytes > scratch_bytes) return 1;
+    k.imgp = (k.HD * k.HH * k.HW * 32 + 1023) / 1024; k.nA = PL * k.imgp; k.nB = BM * CO * 2 / 1024; k.bufb = (k.nA + k.nB) * 1024; k.nbuf = best.nbuf;
+    k.dw = dw; k.db = db; k.dw_elems = (int)dw_elems; k.stamps = g_vg_stamps;
+    auto magic = [](int dd) { return dd <= 1 ? 0u : (unsigned)((1ULL << 32) / (unsigned)dd + 1ULL); };
+    k.m_imgp = magic(k.imgp); k.m_hhw = magic(k.HH * k.HW); k.m_hw = magic(k.HW); k.m_pl = magic(PL);
+    k.m_tpn = magic(k.tiles_d * k.tiles_h * k.tiles_w); k.m_tw = magic(k.tiles_w); k.m_th = magic(k.tiles_h); k.m_ncob = magic(ncob);
+    k.co2l = ilog2_exact(CO * 2);
+    const int bx = best.bx;
     k.P = (const char*)scratch; k.dy = (const char*)dy;
     k.part = bx > 1 ? (float*)((char*)scratch + p_bytes) : nullptr;
-    if (vg_dry("wgrad_dma<%d,%d>|bm%d|pl%d|s%d|part%d|walk%d", Rsel, Q, BM, PL, d->istr, k.part ? 1 : 0, k.total_tiles > bx ? 1 : 0)) return VG_OK;
+    if (vg_dry("wgrad_dma<%d,%d>|bm%d|pl%d|s%d|nb%d|part%d|walk%d", Rsel, Q, BM, PL, d->istr, k.nbuf, k.part ? 1 : 0, k.total_tiles > bx ? 1 : 0)) return VG_OK;
     MatK m;
     m.src0 = d->src0; m.src1 = d->src1; m.c0 = d->c_src0; m.c1 = d->c_src1; m.shift0 = d->src0_shift ? 1 : 0;
     m.N = d->N; m.D = d->D; m.H = d->H; m.W = d->W; m.Cin = Cin;
@@ -458,9 +531,9 @@ int vg_wgrad_dma(const vg_conv_desc* d, const void* dy, int dy_f32, const int32_
     m.deint = deint; m.WE = WE; m.Wps = Wps; m.out = (bf16_t*)scratch;
     hipLaunchKernelGGL(materialize_kernel, dim3(d->N * Dp * Hp), dim3(256), 0, s, m);
     const dim3 grid(bx, columns, 1);
-    if (Q == 4) { if (Rsel == 7) launch_wd<7, 4>(k, grid, lds, s); else launch_wd<8, 4>(k, grid, lds, s); }
-    else if (Q == 2) { if (Rsel == 4) launch_wd<4, 2>(k, grid, lds, s); else if (Rsel == 7) launch_wd<7, 2>(k, grid, lds, s); else launch_wd<12, 2>(k, grid, lds, s); }
-    else { if (Rsel == 4) launch_wd<4, 1>(k, grid, lds, s); else launch_wd<12, 1>(k, grid, lds, s); }
+    if (Q == 4) launch_wd<8, 4>(k, grid, lds, s);
+    else if (Q == 2) { if (Rsel == 4) launch_wd<4, 2>(k, grid, lds, s); else launch_wd<8, 2>(k, grid, lds, s); }
+    else { if (Rsel == 4) launch_wd<4, 1>(k, grid, lds, s); else if (Rsel == 8) launch_wd<8, 1>(k, grid, lds, s); else launch_wd<12, 1>(k, grid, lds, s); }
     if (k.part) vg_launch_reduce_partials(k.part, bx, k.dw_elems, dw, s);
     return vg_check_launch();
 }
