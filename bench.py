@@ -84,6 +84,22 @@ def bench_infer(args, device):
                       'finite': bool(torch.isfinite(out).all())}))
 
 
+def _self_launch(args):
+    import socket
+    import subprocess
+    sk = socket.socket(); sk.bind(('127.0.0.1', 0)); port = sk.getsockname()[1]; sk.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    sys.stderr.write(r.stderr.decode(errors='replace')[-6000:])
+    for line in r.stdout.decode(errors='replace').splitlines():
+        if line.startswith('{"metric"'):
+            print(line)
+    if r.returncode != 0:
+        raise SystemExit(r.returncode)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -103,10 +119,11 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ...'
-                             % (args.gpus, args.gpus))
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N` (the reference's main.py:22 MirroredStrategy is single-command too): start the
+        # one-process-per-GPU job as a CHILD, before anything here has touched the GPU (never exec from a GPU process), and relay
+        # its JSON line and return code
+        return _self_launch(args)
     # VG_BENCH_ONE_DEVICE=1 (development aid): every rank on cuda:0 over gloo, so that the N > 1 code path of this file can be
     # exercised on a 1-GPU box (RCCL refuses two ranks on one device).  Never set by the driver.
     one_dev = os.environ.get('VG_BENCH_ONE_DEVICE', '0') == '1'

@@ -119,14 +119,15 @@ def test_two_ranks_equal_one_process_with_batch_two(tmp_path, backend):
 
 
 def test_bench_two_ranks_completes():
-    """bench.py under torch.distributed.run with 2 ranks (both on cuda:0 over gloo, VG_BENCH_ONE_DEVICE=1): the driver's
-    multi-GPU contract -- barrier-bracketed timed steps, MAX over ranks, the per-launch timing step on EVERY rank (it contains
-    the all-reduces: on rank 0 alone it dead-locked), one JSON line from rank 0."""
+    """Plain `python bench.py --gpus 2` (bench.py starts its own one-process-per-GPU job as a child process; both ranks on
+    cuda:0 over gloo here, VG_BENCH_ONE_DEVICE=1): the driver's multi-GPU contract -- barrier-bracketed timed steps, MAX over
+    ranks, the per-launch timing step on EVERY rank (it contains the all-reduces: on rank 0 alone it dead-locked), one JSON
+    line from rank 0, the child's return code relayed."""
     import json
     env = dict(os.environ, VG_BENCH_ONE_DEVICE='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
-           '--size', '32']
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--size', '32']
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     out = r.stdout.decode()
     assert r.returncode == 0, out[-3000:]

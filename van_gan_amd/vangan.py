@@ -102,6 +102,10 @@ class VanGan:
         self._opt = torch.cuda.Stream(device=self.device) if os.environ.get('VG_OPT_STREAM', '1') != '0' else None
         self._tl = [] if os.environ.get('VG_TIMELINE') == '1' else None
         self._side_ev = {}
+        # world > 1: the step does not end with a join of the optimizer stream -- the last buckets' all-reduce + Adam + repack run
+        # under the head of the NEXT step, whose consumers wait for the update event of the network they read (VG_XSTEP=0: join)
+        self._xstep = self.pg is not None and self._opt is not None and os.environ.get('VG_XSTEP', '1') != '0'
+        self._upd_ev = {}
         self.checkpoint_dir = None
         if output_dir is not None:
             self.checkpoint_dir = os.path.join(output_dir, 'checkpoints')
@@ -111,6 +115,7 @@ class VanGan:
     # ------------------------------------------------------------------------------------------------
     def repack(self):
         ops.set_device(self.device.index)
+        self._join_updates()
         for n in self.nets.values():
             n.pack()
 
@@ -121,9 +126,11 @@ class VanGan:
         self.repack()
 
     def export_weights(self):
+        self._join_updates()
         return {k: self.stores[k].export() for k in NETS}
 
     def export_grads(self):
+        self._join_updates()
         return {k: self.stores[k].export(self.stores[k].g) for k in NETS}
 
     # ------------------------------------------------------------------------------------------------
@@ -144,6 +151,21 @@ class VanGan:
                 self.rng_offset += t.numel()
                 drop[k] = t
         return noise, drop
+
+    def _join_updates(self):
+        """Cross-step mode: the current stream waits for every optimizer step still queued (consumers outside train_step)."""
+        if self._upd_ev and self._opt is not None:
+            torch.cuda.current_stream().wait_stream(self._opt)
+            self._upd_ev = {}
+
+    def _need(self, *names):
+        """The current stream is about to read the weights of these networks: wait for their pending update (cross-step mode)."""
+        if self._upd_ev:
+            cur = torch.cuda.current_stream()
+            for n in names:
+                ev = self._upd_ev.get(n)
+                if ev is not None:
+                    cur.wait_event(ev)
 
     def _mark(self, name: str):
         """Development aid (VG_TIMELINE=1): an event on the current stream, printed by timeline() -- where the lanes wait for each
@@ -193,15 +215,19 @@ class VanGan:
         mmS, nS = ar.alloc((B, 4), f32), ar.alloc(vol, f32)
         ops.minmax(rS, B, S, mmS); ops.minmax_apply(rS, mmS, B, S, nS)                   # lane A, first thing: lane B needs nS at 5.8 ms
         ev_nS = main.record_event() if lane_b is not None else None
+        self._need('gen_IS')
         c1 = self.gen_IS.forward(ar, rI, fake_S)                     # vangan.py:295   (lane A)
         self._mark('A G1 fwd')
         with laneB():
+            self._need('gen_SI')
             c2 = self.gen_SI.forward(ar, rS, fake_I)                 # :297            (lane B)
             ev_fakeI = lane_b.record_event() if lane_b is not None else None
             self._mark('B G1 fwd')
+        self._need('gen_SI')
         c4 = self.gen_SI.forward(ar, fake_S, cyc_I)                  # :305            (lane A)
         self._mark('A G2 fwd')
         with laneB():
+            self._need('gen_IS')
             c3 = self.gen_IS.forward(ar, fake_I, cyc_S)              # :300            (lane B)
             self._mark('B G2 fwd')
 
@@ -265,6 +291,7 @@ class VanGan:
         else:
             noise, drop = noise or {}, drop or {}
             nzS, dpS, nzI, dpI = noise.get('S'), drop.get('S'), noise.get('I'), drop.get('I')
+        self._need('disc_S', 'disc_I')
         dS = self.disc_S.forward(ar, bufS, logS, nzS, dpS)                                  # lane A: needs fake_S
         gd = 1.0 / (nps * gbs)
         gS_D, gI_D = (ar.alloc(logS.shape, f32), ar.alloc(logI.shape, f32)) if do_backward else (None, None)
@@ -290,6 +317,7 @@ class VanGan:
             else:
                 main.wait_stream(lane_b)                                                    # lanes join before the backward sweeps
 
+        self._upd_ev = {}                # every stream that reads weights in this step has queued its waits (main: all four networks)
         if do_backward:
             for st in self.stores.values():
                 st.g.zero_()
@@ -361,7 +389,7 @@ class VanGan:
                     ops.side_join()                 # lane B's weight gradients (its lane no longer waits for them on the way)
                 main.wait_stream(lane_b)
             ops.side_join()
-            if apply and self._opt is not None:
+            if apply and self._opt is not None and not (self._xstep and ops.PROF is None):
                 main.wait_stream(self._opt)
             self._mark('A all joined')
         self._acc, self._coef = acc, coef
@@ -426,6 +454,8 @@ class VanGan:
         with torch.cuda.stream(self._opt):
             self.sync.finish([name])
             self._adam(name)
+            if self._xstep:
+                self._upd_ev[name] = self._opt.record_event()
 
     def _apply_adam(self):
         ops.set_device(self.device.index)
@@ -464,6 +494,7 @@ class VanGan:
     def stitch_subvolumes(self, gen: str, img, subvol_size=None, **kw):
         """GanMonitor.stitch_subvolumes (custom_callback.py:47-223) on the GPU; see van_gan_amd/inference.py."""
         from .inference import stitch_subvolumes as _st
+        self._join_updates()
         return _st(self, gen, img, tuple(subvol_size) if subvol_size is not None else self.dims, **kw)
 
     # ------------------------------------------------------------------------------------------------
@@ -475,6 +506,7 @@ class VanGan:
         if self.checkpoint_dir is None:
             raise ValueError('save_checkpoint needs the engine to be built with output_dir=...')
         path = os.path.join(self.checkpoint_dir, 'checkpoint_e%d.pt' % (epoch + 1))
+        self._join_updates()
         if self.rank == 0:
             torch.cuda.synchronize(self.device)
             blob = {k: dict(w=s.w.cpu(), m=s.m.cpu(), v=s.v.cpu(), step=s.step) for k, s in self.stores.items()}
