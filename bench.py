@@ -59,29 +59,38 @@ def cpu_baseline(budget_s=12.0):
                       '32x32x32 batch 1, %d steps in %.1f s on %d host threads' % (n, el, torch.get_num_threads())}
 
 
-def bench_infer(args, device):
+def time_infer(eng, device, steps, warmup, precision):
     """Config 5: one 256x256x128 volume, 128^3 windows, stride 50, symmetric pad 0.1, 10 % border crop
-    (post_training.py:38-39; custom_callback.py:47-223): 50 windows, bf16 generator, overlap-add on the GPU."""
+    (post_training.py:38-39; custom_callback.py:47-223): 50 windows through the generator, overlap-add on the GPU.
+    precision 'fp16' (what BASELINE.json names: IEEE half storage, libvangan_hip_h.so) or None (the engine's bf16)."""
     import torch
-    from van_gan_amd import VanGan
-    eng = VanGan((128, 128, 128), batch_size=2, device=device, seed=0)
     vol = (torch.rand(256, 256, 128, 1, generator=torch.Generator().manual_seed(1)) * 2 - 1).to(device)
-    kw = dict(stride=(50, 50, 50), complete=True, padFactor=0.1, process_img=True, window_batch=2)
-    for _ in range(max(args.warmup, 1)):
-        eng.stitch_subvolumes('gen_IS', vol, (128, 128, 128), **kw)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
+    kw = dict(stride=(50, 50, 50), complete=True, padFactor=0.1, process_img=True, window_batch=2, precision=precision)
+    out = None
+    for _ in range(max(warmup, 1)):
         out = eng.stitch_subvolumes('gen_IS', vol, (128, 128, 128), **kw)
     torch.cuda.synchronize()
-    el = (time.perf_counter() - t0) / args.steps
-    print(json.dumps({'metric': 'sliding-window inference Mvoxels/s (256x256x128 volume, 50 windows of 128^3, bf16)',
-                      'value': 256 * 256 * 128 / el / 1e6, 'unit': 'Mvoxels/s', 'volumes_per_sec': 1.0 / el, 'n_gpus': 1,
-                      'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': el * 1e3, 'higher_is_better': True,
-                      'dtype': 'bf16', 'data': 'synthetic', 'windows': 50,
-                      'generator_tflops': 50 * 2 * 149.65e9 / el / 1e12,
-                      'config': {'workload': 'GanMonitor.stitch_subvolumes 256x256x128, 128^3 windows, stride 50, pad 0.1'},
-                      'finite': bool(torch.isfinite(out).all())}))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = eng.stitch_subvolumes('gen_IS', vol, (128, 128, 128), **kw)
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / steps
+    return {'workload': 'GanMonitor.stitch_subvolumes 256x256x128, 50 windows of 128^3, stride 50, pad 0.1 (BASELINE config 5)',
+            'dtype': precision or 'bf16', 'ms_per_volume': el * 1e3, 'volumes_per_sec': 1.0 / el, 'Mvoxels_per_sec': 256 * 256 * 128 / el / 1e6,
+            'generator_tflops': 50 * 2 * 149.65e9 / el / 1e12, 'windows': 50, 'steps': steps, 'finite': bool(torch.isfinite(out).all())}
+
+
+def bench_infer(args, device):
+    import torch  # noqa: F401
+    from van_gan_amd import VanGan
+    eng = VanGan((128, 128, 128), batch_size=2, device=device, seed=0)
+    r = time_infer(eng, device, args.steps, args.warmup, 'fp16')
+    rb = time_infer(eng, device, args.steps, args.warmup, None)
+    print(json.dumps({'metric': 'sliding-window inference Mvoxels/s (256x256x128 volume, 50 windows of 128^3, fp16)',
+                      'value': r['Mvoxels_per_sec'], 'unit': 'Mvoxels/s', 'volumes_per_sec': r['volumes_per_sec'], 'n_gpus': 1,
+                      'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': r['ms_per_volume'], 'higher_is_better': True,
+                      'dtype': 'fp16', 'data': 'synthetic', 'windows': 50, 'generator_tflops': r['generator_tflops'],
+                      'config': {'workload': r['workload']}, 'finite': r['finite'], 'bf16': rb}))
 
 
 def _self_launch(args):
@@ -111,6 +120,7 @@ def main():
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--dump-kernels', default='', help='write the per-kernel-template table of the timing step (JSON) here')
     ap.add_argument('--infer', action='store_true', help='BASELINE config 5 instead: 256x256x128 sliding-window generator inference')
+    ap.add_argument('--no-infer', action='store_true', help='skip the inference object (config 5) of the default N=1 line')
     args = ap.parse_args()
 
     import torch
@@ -173,6 +183,11 @@ def main():
     steps_per_s = args.steps / el
     mvox = steps_per_s * gbatch * S / 1e6
 
+    infer = None
+    if rank == 0 and world == 1 and args.size == 128 and not args.no_infer:
+        # BASELINE config 5 beside the headline: the same engine's gen_IS, fp16 storage (and the bf16 figure next to it)
+        infer = time_infer(eng, device, 3, 1, 'fp16')
+        infer['bf16_ms_per_volume'] = time_infer(eng, device, 3, 1, None)['ms_per_volume']
     roof = None
     summ = None
     byvar = None
@@ -250,7 +265,7 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
             'config': {'workload': 'VanGan.train_step, %dx%dx%d volumes, batch %d per GPU (global %d), clDice on, disc noise+dropout on'
                                    % (dims + (B, gbatch)), 'parallelism': 'dp%d' % world},
-            'losses': res, 'roofline': roof, 'cpu_baseline': cpu,
+            'losses': res, 'roofline': roof, 'cpu_baseline': cpu, 'inference': infer,
             'arena_peak_gb': eng.arena.peak / 1e9,
         }
         print(json.dumps(out))

@@ -44,6 +44,10 @@ const char* vg_status_string(int code);
 /* diagnostic builds only: device buffer receiving s_memtime stamps of the conv kernel phases (NULL = off) */
 int vg_set_stamp_buffer(void* dev_u64);
 int vg_version(void);
+/* The 16-bit storage format of THIS build: 0 = bfloat16 (libvangan_hip.so: training and inference), 1 = IEEE half precision
+ * (libvangan_hip_h.so: the same sources compiled with -DVG_FP16 -- the fp16 sliding-window inference of BASELINE config 5,
+ * post_training.py:38-39 / custom_callback.py:174-175).  Every "bf16" buffer of this header holds that format. */
+int vg_storage16(void);
 /* sizeof() of the descriptor structs as THIS library was compiled (which: 0 vg_conv_desc, 1 vg_actnorm_bwd_desc,
  * 2 vg_pack_item; else VG_EINVAL): a binding that mirrors the structs by hand checks its layout at load time. */
 int vg_abi_sizeof(int which);

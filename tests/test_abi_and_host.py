@@ -21,8 +21,14 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(_lib.lib, name), 'libvangan_hip.so does not export %s' % name
     assert set(_lib.EXPORTS) == declared, (set(_lib.EXPORTS) ^ declared)
-    assert _lib.lib.vg_version() == 2
+    assert _lib.lib.vg_version() == 3 and _lib.lib.vg_storage16() == 0
     assert _lib.lib.vg_status_string(-2).decode().startswith('tile')
+    # the fp16-storage build of the same sources (libvangan_hip_h.so): same export set, same descriptor layout, reports itself
+    h = _lib.lib_fp16()
+    for name in sorted(declared):
+        assert hasattr(h, name), 'libvangan_hip_h.so does not export %s' % name
+    assert h.vg_storage16() == 1 and h.vg_version() == 3
+    assert [h.vg_abi_sizeof(i) for i in range(3)] == [_lib.lib.vg_abi_sizeof(i) for i in range(3)]
 
 
 def test_descriptor_struct_layout_matches_header():

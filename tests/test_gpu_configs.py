@@ -136,3 +136,11 @@ def test_config5_sliding_window_full_size_product_precision():
     e32 = np.abs(got32 - ref32).max()
     print('stitch 256x128x128 fp32 mode: max abs err %.5f (0..255 scale)' % e32)
     assert e32 < 0.05
+    # fp16 storage (what BASELINE config 5 names): the product stitch with precision='fp16' on the same weights against the
+    # fp32-mode stitch of the same sub-volume -- fp16 keeps 11 significand bits, 8x finer than bf16
+    got16 = eng32.stitch_subvolumes('gen_IS', sub, k, window_batch=2, precision='fp16', **kw).cpu().numpy()
+    rel16 = float(np.linalg.norm(got16 - got32) / np.linalg.norm(got32))
+    print('stitch 256x128x128 fp16 vs fp32 mode: rel L2 %.3e, max abs %.4f (0..255 scale)' % (rel16, float(np.abs(got16 - got32).max())))
+    assert np.isfinite(got16).all() and rel16 < 1e-2
+    got16f = eng.stitch_subvolumes('gen_IS', vol, k, window_batch=2, precision='fp16', **kw).cpu().numpy()
+    assert got16f.shape == (256, 256, 128, 1) and np.isfinite(got16f).all() and got16f.min() == 0.0 and abs(got16f.max() - 255.0) < 1e-3

@@ -34,6 +34,39 @@ def test_stitch_subvolumes_matches_oracle(process_img):
     assert err < 0.05
 
 
+def test_fp16_generator_matches_oracle_with_fp16_storage_points():
+    """BASELINE config 5 names fp16: the generator's forward in libvangan_hip_h.so (IEEE half storage, fp32 accumulation) against
+    the oracle with every stored tensor and the weights rounded to fp16 at the same points (q hook); and against the unrounded
+    fp32 oracle, where fp16 (11 significand bits) must sit well below the bf16 path's 1.8e-2 noise floor."""
+    from van_gan_amd import VanGan
+    k = (32, 32, 32)
+    eng = VanGan(k, batch_size=2, device='cuda:0', seed=7)
+    P = eng.export_weights()['gen_IS']
+    x, _ = O.synth_volumes(2, *k, seed=21)
+    net = eng.fp16_generator('gen_IS')
+    ar = eng.arena
+    ar.reset()
+    y = ar.alloc((2,) + k + (1,), torch.float32)
+    xin = ar.alloc((2,) + k + (1,), torch.float32)
+    xin.copy_(x)
+    from van_gan_amd import ops
+    with ops.Fp16():
+        net.forward(ar, xin, y, save=False)
+    torch.cuda.synchronize()
+    assert net.L['stem.cb'].f_wp.dtype == torch.float16
+
+    def q16(t):
+        return t.half().float()
+    with torch.no_grad():
+        ref16 = O.resunet_forward(P, x, q=q16)
+        ref32 = O.resunet_forward(P, x)
+    got = y.cpu()
+    e16 = float((got - ref16).norm() / ref16.norm())
+    e32 = float((got - ref32).norm() / ref32.norm())
+    print('fp16 generator: rel L2 vs fp16-rounded oracle %.3e, vs fp32 oracle %.3e' % (e16, e32))
+    assert e16 < 5e-3 and e32 < 5e-3
+
+
 def test_window_origins_follow_reference_loop():
     from van_gan_amd.inference import window_origins
     # 256x256x128 volume, padFactor 0.1, stride 50 (post_training.py:38-39): 306x306x152 padded -> 5 x 5 x 2 windows

@@ -53,6 +53,7 @@ class ActNormBwdDesc(C.Structure):
 
 _SIGS = {
     'vg_version': ([], c_int),
+    'vg_storage16': ([], c_int),
     'vg_abi_sizeof': ([c_int], c_int),
     'vg_set_stamp_buffer': ([c_void_p], c_int),
     'vg_conv3d': ([C.POINTER(ConvDesc), c_void_p], c_int),
@@ -104,12 +105,12 @@ _SIGS = {
 EXPORTS = sorted(list(_SIGS.keys()) + ['vg_status_string'])
 
 
-def _load():
+def _load(path=None, storage16=0):
     """Build if the sources changed, then dlopen.  A stale library is only accepted on explicit request (VG_NO_REBUILD=1, used
     on the GPU box where the prebuilt .so travels with the snapshot): the descriptor structs are mirrored by hand in this
     file, so a library built from other sources could corrupt memory instead of failing.  Either way the struct sizes the
     library was compiled with are checked against the ctypes mirrors below."""
-    path = _build.LIB
+    path = _build.LIB if path is None else path
     if not os.path.exists(path) or (_build.needs_build() and os.environ.get('VG_NO_REBUILD') != '1'):
         _build.build()                               # raises on failure: no silent fallback to an old binary
     lib = C.CDLL(path)
@@ -124,10 +125,22 @@ def _load():
         if got != C.sizeof(mirror):
             raise ImportError('libvangan_hip.so ABI mismatch: sizeof(%s) is %d in the library, %d in van_gan_amd/_lib.py '
                               '(stale build? remove %s and rebuild)' % (mirror.__name__, got, C.sizeof(mirror), path))
+    if lib.vg_storage16() != storage16:
+        raise ImportError('%s stores %s in its 16-bit buffers, expected %s' % (path, ('bf16', 'fp16')[lib.vg_storage16()], ('bf16', 'fp16')[storage16]))
     return lib
 
 
 lib = _load()
+_lib_h = None
+
+
+def lib_fp16():
+    """libvangan_hip_h.so: the same entry points with IEEE half precision in every 16-bit buffer (inference only; loaded on
+    first use, RTLD_LOCAL: its symbols do not meet the bf16 library's)."""
+    global _lib_h
+    if _lib_h is None:
+        _lib_h = _load(_build.LIB_H, 1)
+    return _lib_h
 
 
 class VgError(RuntimeError):

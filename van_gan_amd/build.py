@@ -1,4 +1,6 @@
-"""Build libvangan_hip.so (gfx950 only) in-tree with hipcc.  No fallback: a missing compiler is an error."""
+"""Build libvangan_hip.so and libvangan_hip_h.so (gfx950 only) in-tree with hipcc.  No fallback: a missing compiler is an error.
+The second library is the SAME sources compiled with -DVG_FP16: its 16-bit buffers hold IEEE half precision instead of bfloat16
+(fp16 sliding-window inference, BASELINE config 5)."""
 from __future__ import annotations
 
 import os
@@ -9,6 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libvangan_hip.so')
+LIB_H = os.path.join(HERE, 'libvangan_hip_h.so')
 SOURCES = ['vg_conv.hip', 'vg_conv_thin.hip', 'vg_wgrad.hip', 'vg_wgrad_dma.hip', 'vg_pointwise.hip', 'vg_elem.hip', 'vg_loss.hip', 'vg_adam.hip']
 
 
@@ -35,7 +38,7 @@ def _src_hash() -> str:
 
 
 def needs_build() -> bool:
-    if not os.path.exists(LIB) or not os.path.exists(HASHFILE):
+    if not os.path.exists(LIB) or not os.path.exists(LIB_H) or not os.path.exists(HASHFILE):
         return True
     with open(HASHFILE) as f:
         return f.read().strip() != _src_hash()
@@ -59,25 +62,28 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 def _build_locked(verbose: bool) -> str:
     hipcc = _hipcc()
-    objs = []
     procs = []
-    for s in SOURCES:
-        o = os.path.join(HERE, 'build', s.replace('.hip', '.o'))
-        objs.append(o)
-        cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-c', os.path.join(CSRC, s), '-o', o]
-        if verbose:
-            print(' '.join(cmd))
-        procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    variants = (('', LIB, []), ('h_', LIB_H, ['-DVG_FP16']))
+    objs = {LIB: [], LIB_H: []}
+    for tag, lib, defs in variants:
+        for s in SOURCES:
+            o = os.path.join(HERE, 'build', tag + s.replace('.hip', '.o'))
+            objs[lib].append(o)
+            cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17'] + defs + ['-c', os.path.join(CSRC, s), '-o', o]
+            if verbose:
+                print(' '.join(cmd))
+            procs.append((tag + s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     for s, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError('hipcc failed on %s:\n%s' % (s, out.decode()))
-    tmp = LIB + '.tmp.%d' % os.getpid()
-    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', tmp] + objs
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
-    if r.returncode != 0:
-        raise RuntimeError('link failed:\n' + r.stdout.decode())
-    os.replace(tmp, LIB)          # atomic: a process that already mapped the old library keeps its inode
+    for _, lib, _ in variants:
+        tmp = lib + '.tmp.%d' % os.getpid()
+        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', tmp] + objs[lib]
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        if r.returncode != 0:
+            raise RuntimeError('link failed:\n' + r.stdout.decode())
+        os.replace(tmp, lib)          # atomic: a process that already mapped the old library keeps its inode
     with open(HASHFILE, 'w') as f:
         f.write(_src_hash())
     return LIB

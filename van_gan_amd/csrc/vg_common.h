@@ -12,11 +12,27 @@ typedef unsigned short bf16_t;
 #define VG_LDS_LIMIT 163840
 #define VG_LRELU 0.2f
 
+// The 16-bit storage format is a property of the BUILD: libvangan_hip.so stores bf16 (training and inference), the same sources
+// compiled with -DVG_FP16 give libvangan_hip_h.so, whose 16-bit buffers hold IEEE half precision (BASELINE config 5: fp16
+// sliding-window inference, post_training.py:38-39).  Only these two conversions and the MFMA opcode differ; "bf16" in type and
+// kernel names then reads "the build's 16-bit format".
+#ifdef VG_FP16
+typedef __attribute__((ext_vector_type(8))) _Float16 vg_h8;
+__device__ __forceinline__ float bf2f(bf16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(unsigned short, (_Float16)f); }      // v_cvt_f16_f32: RNE
+#define VG_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(vg_h8, a), __builtin_bit_cast(vg_h8, b), c, 0, 0, 0)
+#define VG_MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(vg_h8, a), __builtin_bit_cast(vg_h8, b), c, 0, 0, 0)
+#define VG_STORAGE16 "fp16"
+#else
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
 __device__ __forceinline__ bf16_t f2bf(float f) {
     __bf16 b = (__bf16)f;                       // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
     return __builtin_bit_cast(unsigned short, b);
 }
+#define VG_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+#define VG_MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#define VG_STORAGE16 "bf16"
+#endif
 __device__ __forceinline__ float bfround(float f) { return bf2f(f2bf(f)); }
 
 // ---- storage-type helpers: activations/gradients/weights are bf16 (product) or f32 (exact-parity mode) ----

@@ -537,7 +537,7 @@ __global__ __launch_bounds__(256, 2) void conv32_kernel(const GatherIn g, const 
                     if (s + u >= ksteps) a[u] = zero8;                 // phantom steps of the last group add zero
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int i = 0; i < MW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u], bb[u & 1][i], acc[i], 0, 0, 0);
+                    for (int i = 0; i < MW; ++i) acc[i] = VG_MFMA32(a[u], bb[u & 1][i], acc[i]);
                     __builtin_amdgcn_sched_barrier(0);
                     a[u] = *(glb_frag*)(w + min(s + u + RD, last) * 16);
                     on1 = on2;

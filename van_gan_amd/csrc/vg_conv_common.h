@@ -106,7 +106,7 @@ __device__ __forceinline__ void conv_mfma_chunk(f32x4 (&acc)[MW], WP w, const ch
                     if (s + u >= ksteps) a[u] = zero8;                 // phantom steps of the last group add zero
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int i = 0; i < MW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u], bb[u & 1][i], acc[i], 0, 0, 0);
+                    for (int i = 0; i < MW; ++i) acc[i] = VG_MFMA16(a[u], bb[u & 1][i], acc[i]);
                     __builtin_amdgcn_sched_barrier(0);
                     a[u] = wfrag(min(s + u + 4, last));
                     on1 = on2;
@@ -129,7 +129,7 @@ __device__ __forceinline__ void conv_mfma_chunk(f32x4 (&acc)[MW], WP w, const ch
             for (int i = 0; i < MW; ++i) b1[i] = *(const bf16x8*)(halo + rowbase[i] + o1);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < MW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0[i], acc[i], 0, 0, 0);
+            for (int i = 0; i < MW; ++i) acc[i] = VG_MFMA16(a0, b0[i], acc[i]);
             __builtin_amdgcn_sched_barrier(0);
             o1 = koff[min(s + 3, last) * 4 + kg];
             a0 = wfrag(min(s + 2, last));
@@ -138,7 +138,7 @@ __device__ __forceinline__ void conv_mfma_chunk(f32x4 (&acc)[MW], WP w, const ch
             if (s + 1 >= ksteps) a1 = zero8;                       // odd K-step count: the phantom step adds zero
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < MW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1[i], acc[i], 0, 0, 0);
+            for (int i = 0; i < MW; ++i) acc[i] = VG_MFMA16(a1, b1[i], acc[i]);
             __builtin_amdgcn_sched_barrier(0);
         }
     }

@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256, 2) void conv_thin_kernel(const GatherIn g, con
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s % 3], b[s % 3][j], acc[j], 0, 0, 0);
+                for (int j = 0; j < 8; ++j) acc[j] = VG_MFMA16(a[s % 3], b[s % 3][j], acc[j]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }

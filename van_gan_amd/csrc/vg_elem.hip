@@ -622,7 +622,14 @@ void vg_dry_end() { t_dry_buf = nullptr; t_dry_len = 0; }
 bool vg_dry_on() { return t_dry_buf != nullptr; }
 
 extern "C" int vg_version(void) {
-    vg_begin(); return 2; }
+    vg_begin(); return 3; }
+extern "C" int vg_storage16(void) {
+#ifdef VG_FP16
+    return 1;
+#else
+    return 0;
+#endif
+}
 extern "C" int vg_abi_sizeof(int which) {
     switch (which) {
         case 0: return (int)sizeof(vg_conv_desc);

@@ -323,7 +323,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const PWG p) {
             for (int nb = 0; nb < NB; ++nb) {
                 acc[i][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) acc[i][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wA[nb][ks], xb[i][ks], acc[i][nb], 0, 0, 0);
+                for (int ks = 0; ks < KS; ++ks) acc[i][nb] = VG_MFMA16(wA[nb][ks], xb[i][ks], acc[i][nb]);
             }
         // ---- epilogue: sub-tiles (jp, jp+1) exchanged across the 16-lane rows: even rows end with sub-tile jp channels
         // [4kg..4kg+7], odd rows with sub-tile jp+1 channels [4(kg-1)..4kg+3]

@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256, (RMAX * Q >= VG_WGRAD_2W ? 2 : 3)) void wgrad_
                         for (int j = 0; j < RC; ++j)
 #pragma unroll
                             for (int q = 0; q < Q; ++q)
-                                acc[c * RC + j][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[s][j], B[u][q], acc[c * RC + j][q], 0, 0, 0);
+                                acc[c * RC + j][q] = VG_MFMA16(A[s][j], B[u][q], acc[c * RC + j][q]);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }

@@ -329,7 +329,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_dma_kernel(const WgdK p) {
                             if (c * RC + j < R) {
 #pragma unroll
                                 for (int q = 0; q < Q; ++q)
-                                    acc[c * RC + j][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[s][j], B[u][q], acc[c * RC + j][q], 0, 0, 0);
+                                    acc[c * RC + j][q] = VG_MFMA16(A[s][j], B[u][q], acc[c * RC + j][q]);
                             }
                         __builtin_amdgcn_sched_barrier(0);
                     }

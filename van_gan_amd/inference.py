@@ -29,12 +29,19 @@ def window_origins(n: int, k: int, s: int):
 
 def stitch_subvolumes(engine, gen: str, img: torch.Tensor, subvol_size: Sequence[int], stride=(25, 25, 128), complete=True,
                       padFactor: float = 0.25, border_removal: bool = True, process_img: bool = False,
-                      window_batch: int = 4) -> torch.Tensor:
+                      window_batch: int = 4, precision: str = None) -> torch.Tensor:
     """img: [X,Y,Z,1] fp32 (host or device).  gen: 'gen_IS' or 'gen_SI'.  Returns 255*minmax(pred) as fp32 [X,Y,Z,1]
-    on the device (custom_callback.py:202).  subvol_size is (kX,kY,kZ)."""
+    on the device (custom_callback.py:202).  subvol_size is (kX,kY,kZ).
+    precision: None = the engine's training precision (bf16 / fp32 storage); 'fp16' = IEEE half-precision storage with fp32
+    accumulation (BASELINE config 5; the reference's inference runs whatever policy TF was given, post_training.py:38-39): the
+    generator's forward runs in libvangan_hip_h.so (van_gan_amd.ops.Fp16) on weights repacked to fp16 at the start of the call."""
+    import contextlib
     dev = engine.device
     ops.set_device(dev.index)
-    net = engine.nets[gen]
+    if precision not in (None, 'fp16', engine.precision):
+        raise ValueError("precision must be None, 'fp16' or the engine's own precision")
+    half = precision == 'fp16'
+    net = engine.fp16_generator(gen) if half else engine.nets[gen]
     kx, ky, kz = subvol_size
     if tuple(net.dims) != (kx, ky, kz):
         raise ValueError('generator was built for windows %s' % (net.dims,))
@@ -88,7 +95,8 @@ def stitch_subvolumes(engine, gen: str, img: torch.Tensor, subvol_size: Sequence
                 ones = ar.alloc((B, kx, ky, kz, 1), torch.float32)
                 ones.fill_(1.0)                              # memset-style fill (plumbing)
                 ops.axpby(tmp, 2.0, ones, -1.0, xin)         # 2*n - 1
-            net.forward(ar, xin, yout, save=False)
+            with (ops.Fp16() if half else contextlib.nullcontext()):
+                net.forward(ar, xin, yout, save=False)
             for b, (a, bb, c) in enumerate(chunk):
                 check(lib.vg_overlap_add(_p(yout[b]), kx, ky, kz, px, py, pz, a, bb, c, X, Y, Z, _p(pred), _p(cnt), stream()),
                       'vg_overlap_add')

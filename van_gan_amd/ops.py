@@ -111,6 +111,23 @@ class DryRun:
 DRY: Optional[DryRun] = None
 
 
+class Fp16:
+    """Context manager: every library call made through this module goes to libvangan_hip_h.so, the build whose 16-bit buffers
+    hold IEEE half precision (fp16 sliding-window inference, BASELINE config 5).  Tensors handed to the calls inside must be
+    torch.float16 where the bf16 path has torch.bfloat16."""
+
+    def __enter__(self):
+        global lib
+        self._saved = lib
+        lib = _lib.lib_fp16()
+        return self
+
+    def __exit__(self, *exc):
+        global lib
+        lib = self._saved
+        return False
+
+
 class KernelProfile:
     """Optional per-launch HIP-event timing of the MFMA kernels on the stream they are launched on (torch's current
     stream), with the algorithmic FLOPs of every launch.  Used by bench.py for the roofline object."""

@@ -106,6 +106,7 @@ class VanGan:
         # under the head of the NEXT step, whose consumers wait for the update event of the network they read (VG_XSTEP=0: join)
         self._xstep = self.pg is not None and self._opt is not None and os.environ.get('VG_XSTEP', '1') != '0'
         self._upd_ev = {}
+        self._fp16_nets = {}
         self.checkpoint_dir = None
         if output_dir is not None:
             self.checkpoint_dir = os.path.join(output_dir, 'checkpoints')
@@ -490,6 +491,20 @@ class VanGan:
         ops.set_device(self.device.index)
         self.sync.broadcast_weights(src)
         self.repack()
+
+    def fp16_generator(self, gen: str):
+        """The generator `gen` as an fp16-storage network over the SAME fp32 master weights (forward only; built on first use),
+        freshly repacked: 16-bit buffers of libvangan_hip_h.so hold IEEE half precision (include/vangan_hip.h: vg_storage16)."""
+        if gen not in ('gen_IS', 'gen_SI'):
+            raise ValueError('gen must be gen_IS or gen_SI')
+        ops.set_device(self.device.index)
+        self._join_updates()
+        with ops.Fp16():
+            net = self._fp16_nets.get(gen)
+            if net is None:
+                net = self._fp16_nets[gen] = ResUNet(self.stores[gen], self.dims, torch.float16)
+            net.pack()
+        return net
 
     def stitch_subvolumes(self, gen: str, img, subvol_size=None, **kw):
         """GanMonitor.stitch_subvolumes (custom_callback.py:47-223) on the GPU; see van_gan_amd/inference.py."""
