@@ -63,8 +63,13 @@ def test_fp16_generator_matches_oracle_with_fp16_storage_points():
     got = y.cpu()
     e16 = float((got - ref16).norm() / ref16.norm())
     e32 = float((got - ref32).norm() / ref32.norm())
-    print('fp16 generator: rel L2 vs fp16-rounded oracle %.3e, vs fp32 oracle %.3e' % (e16, e32))
-    assert e16 < 5e-3 and e32 < 5e-3
+    # the same forward on the engine's bf16 path: fp16 keeps three more significand bits and must come out clearly closer
+    yb = ar.alloc((2,) + k + (1,), torch.float32)
+    eng.gen_IS.forward(ar, xin, yb, save=False)
+    torch.cuda.synchronize()
+    eb = float((yb.cpu() - ref32).norm() / ref32.norm())
+    print('fp16 generator: rel L2 vs fp16-rounded oracle %.3e, vs fp32 oracle %.3e (bf16 path vs fp32 oracle: %.3e)' % (e16, e32, eb))
+    assert e16 < 1e-2 and e32 < 1e-2 and e32 < 0.6 * eb
 
 
 def test_window_origins_follow_reference_loop():

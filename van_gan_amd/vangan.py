@@ -25,7 +25,7 @@ RESULT_KEYS = ['total_IS_loss', 'total_SI_loss', 'D_I_loss', 'D_S_loss', 'gen_IS
 _BFIRST = int(os.environ.get('VG_BFIRST', '0'))
 _NOJOIN = os.environ.get('VG_NOJOIN', '1') != '0'
 _LAZY_AR = os.environ.get('VG_LAZY_AR', '1') != '0'
-_INLINE = int(os.environ.get('VG_WGRAD_INLINE', '1'))      # sweep: off 28.28, stem 28.13, enc1 + stem 28.05, all encoder blocks 28.08 ms
+_INLINE = int(os.environ.get('VG_WGRAD_INLINE', '3'))      # encoder blocks <= this and the stem; sweep with the DMA weight gradients: off 24.96, 1: 24.92, 2: 24.74, 3: 24.59, 4: 24.62 ms
 NETS = ['gen_IS', 'gen_SI', 'disc_I', 'disc_S']
 
 
