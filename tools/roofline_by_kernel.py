@@ -34,6 +34,10 @@ def variant_of(kernel_name: str):
     """rocprof kernel name -> the variant string of vg_conv3d_variant / vg_conv3d_wgrad_variant (without |walk|ch flags)."""
     if 'pw_wgrad_cc_kernel' in kernel_name:
         return 'pw_wgrad_cc'
+    if kernel_name.startswith('materialize_kernel'):          # the operand pass and the partial-slab sum of the DMA weight gradients:
+        return 'wgrad_dma:materialize'                        # rows of their own (time and HBM bytes; their FLOPs are the wgrad_dma rows')
+    if kernel_name.startswith('reduce_partials_kernel'):
+        return 'wgrad:reduce_partials'
     m = re.search(r'(\w+)_kernel<([^>]*)>', kernel_name)
     if not m:
         return None
@@ -46,6 +50,8 @@ def variant_of(kernel_name: str):
         return 'pw_gemm<%s,%s,g%s,a%s>' % (args[0], args[1], b(args[2]), b(args[3]))
     if k == 'conv32' and len(args) == 4:
         return 'conv32<%s,%s,n%s,cp%s>' % (args[0], args[1], b(args[2]), b(args[3]))
+    if k == 'wgrad_dma' and len(args) == 2:
+        return 'wgrad_dma<%s,%s>' % (args[0], args[1])
     if k == 'wgrad' and len(args) == 4:
         return 'wgrad<%s,%s,%s,n%s>' % (tname(args[0]), args[1], args[2], b(args[3]))
     if k in ('pw_cto1', 'pw_ctoc') and len(args) == 2:
@@ -97,6 +103,9 @@ def main():
         e = merged.setdefault(r['kernel'], {'kinds': [], 'launches': 0, 'ms_events': 0.0, 'gflop': 0.0, 'alg_bytes': 0.0})
         e['kinds'].append(r['kind']); e['launches'] += r['launches']; e['ms_events'] += r['ms']; e['gflop'] += r['gflop']
         e['alg_bytes'] += r['algorithmic_bytes']
+    for aux in ('wgrad_dma:materialize', 'wgrad:reduce_partials'):
+        if aux in stats:
+            merged[aux] = {'kinds': ['conv_wgrad (auxiliary pass)'], 'launches': int(stats[aux]['calls'] / ssteps), 'ms_events': 0.0, 'gflop': 0.0, 'alg_bytes': 0.0}
     rows = []
     for k, e in merged.items():
         st = stats.get(k)
