@@ -220,9 +220,11 @@ int vg_actnorm_bwd(const vg_actnorm_bwd_desc* d, vg_stream_t stream);
 int vg_in_param_grads(const float* red, int N, int C, float* dgamma, float* dbeta, vg_stream_t stream);
 
 /* Backward of the virtual upsample+concat (resunet_model.py:175-181): g is bf16 [N][D][H][W][Cu+Cs];
- * dlow[N][D/2][H/2][W/2][Cu] += sum of the 8 children, dskip[N][D][H][W][Cs] += g[..., Cu:]. */
+ * dlow[N][D/2][H/2][W/2][Cu] (+)= sum of the 8 children, dskip[N][D][H][W][Cs] (+)= g[..., Cu:].
+ * accumulate: bit 0 -- add to dlow (else overwrite), bit 1 -- add to dskip: the first writer of a gradient buffer overwrites,
+ * so the buffers need no memset. */
 int vg_concat_bwd(const void* g, int N, int D, int H, int W, int Cu, int Cs, void* dlow, void* dskip,
-                  int f32, vg_stream_t stream);
+                  int f32, int accumulate, vg_stream_t stream);
 
 /* d_pre = dy * (1 - y*y)   (tanh output activation, resunet_model.py:245), all fp32 */
 int vg_tanh_bwd(const float* dy, const float* y, float* dpre, int64_t n, vg_stream_t stream);

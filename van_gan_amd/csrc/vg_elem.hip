@@ -411,7 +411,7 @@ extern "C" int vg_in_param_grads(const float* red, int N, int C, float* dgamma, 
 // backward of UpSampling3D(2) + concatenate (resunet_model.py:175-181)
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ void concat_bwd_kernel(const T* g, int N, int D, int H, int W, int Cu, int Cs, T* dlow, T* dskip) {
+__global__ void concat_bwd_kernel(const T* g, int N, int D, int H, int W, int Cu, int Cs, T* dlow, T* dskip, int acc) {
     const int C = Cu + Cs;
     const int gu = Cu / 8, gs = Cs / 8;
     const size_t nlow = (size_t)N * (D / 2) * (H / 2) * (W / 2) * gu;
@@ -429,31 +429,36 @@ __global__ void concat_bwd_kernel(const T* g, int N, int D, int H, int W, int Cu
 #pragma unroll
                 for (int j = 0; j < 8; ++j) s[j] += r[j];
             }
-            float old[8]; load8<T>(dlow + i * 8, old);
+            if (acc & 1) {
+                float old[8]; load8<T>(dlow + i * 8, old);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) old[j] += s[j];
-            store8<T>(dlow + i * 8, old);
+                for (int j = 0; j < 8; ++j) s[j] += old[j];
+            }
+            store8<T>(dlow + i * 8, s);
         } else {
             const size_t k = i - nlow;
             const int cg = (int)(k % gs); const size_t v = k / gs;
-            float a[8], old[8];
-            load8<T>(g + v * C + Cu + cg * 8, a); load8<T>(dskip + k * 8, old);
+            float a[8];
+            load8<T>(g + v * C + Cu + cg * 8, a);
+            if (acc & 2) {
+                float old[8]; load8<T>(dskip + k * 8, old);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) old[j] += a[j];
-            store8<T>(dskip + k * 8, old);
+                for (int j = 0; j < 8; ++j) a[j] += old[j];
+            }
+            store8<T>(dskip + k * 8, a);
         }
     }
 }
 extern "C" int vg_concat_bwd(const void* g, int N, int D, int H, int W, int Cu, int Cs, void* dlow, void* dskip,
-                             int f32, vg_stream_t stream) {
+                             int f32, int accumulate, vg_stream_t stream) {
     vg_begin();
     if (!g || !dlow || !dskip || (Cu % 8) || (Cs % 8) || Cu < 8 || Cs < 8 || ((D | H | W) & 1)) return VG_EINVAL;
     const size_t total = (size_t)N * (D / 2) * (H / 2) * (W / 2) * (Cu / 8) + (size_t)N * D * H * W * (Cs / 8);
     int blocks = (int)((total + 255) / 256); if (blocks > 8191) blocks = 8191;
     if (f32) hipLaunchKernelGGL(concat_bwd_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)g, N, D, H, W, Cu,
-                                Cs, (float*)dlow, (float*)dskip);
+                                Cs, (float*)dlow, (float*)dskip, accumulate);
     else hipLaunchKernelGGL(concat_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)g, N, D, H, W, Cu,
-                            Cs, (bf16_t*)dlow, (bf16_t*)dskip);
+                            Cs, (bf16_t*)dlow, (bf16_t*)dskip, accumulate);
     return vg_check_launch();
 }
 

@@ -139,11 +139,22 @@ class Act:
         self.sums = arena.alloc((ops.STRIPES, N, C_, 2), torch.float32, zero=True) if want_sums else None
         self.count = float(dims[0] * dims[1] * dims[2])
         self.grad = None
+        self.grad_init = False
 
     def alloc_grad(self, arena: Arena):
+        """Gradient buffer, NOT zeroed: its first writer overwrites (first_write() says whether a writer is the first), every later
+        one accumulates.  (The ten buffers of a generator sweep were 185 MB of memsets per application at 128^3.)"""
         if self.grad is None:
-            self.grad = arena.alloc((self.N,) + self.dims + (self.C,), self.data.dtype, zero=True)
+            self.grad = arena.alloc((self.N,) + self.dims + (self.C,), self.data.dtype)
+            self.grad_init = False
         return self.grad
+
+    def first_write(self) -> bool:
+        """True exactly once after alloc_grad: the caller's launch must then OVERWRITE the buffer."""
+        if self.grad_init:
+            return False
+        self.grad_init = True
+        return True
 
 
 class Norm:
@@ -343,6 +354,7 @@ class ResUNet:
         inp = c['inp']
         if len(inp) == 1:            # encoder block: accumulate into the input's gradient
             gin = inp[0].alloc_grad(ar) if inp[0].grad is None else inp[0].grad
+            assert inp[0].grad_init, 'encoder input gradient must have had its first (overwriting) writer: the decoder skip path'
             self._dgrad_norm_bwd(ar, cb1, d_r, N, dp1, s1, c['n1'], Nn[name + '.cb1'], gin, ACT_RELU, accumulate=True)
             short.dgrad(d_sc, N, gin, accumulate=True)
         else:                        # decoder block: gradient of the virtual concat, then split / sum-pool
@@ -350,7 +362,8 @@ class ResUNet:
             dcat = ar.alloc((N,) + tuple(cb1.in_dims) + (s1.C,), self.dtype)
             self._dgrad_norm_bwd(ar, cb1, d_r, N, dp1, s1, c['n1'], Nn[name + '.cb1'], dcat, ACT_RELU, accumulate=False)
             short.dgrad(d_sc, N, dcat, accumulate=True)
-            ops.concat_bwd(dcat, (N,) + tuple(cb1.in_dims), low.C, skip.C, low.grad, skip.grad)
+            ops.concat_bwd(dcat, (N,) + tuple(cb1.in_dims), low.C, skip.C, low.grad, skip.grad,
+                           acc_low=not low.first_write(), acc_skip=not skip.first_write())
         ar.release(mk, defer=True)
 
     def backward(self, ar: Arena, ctx: dict, gy: torch.Tensor, inline_from: int = -1):
@@ -371,7 +384,7 @@ class ResUNet:
         ops.tanh_bwd(gy, ctx['y'], dpre)
         h = ctx['out']['inp']
         L['out'].wgrad(ctx['out']['so'], dpre)
-        L['out'].dgrad(dpre, N, h.grad, accumulate=True)
+        L['out'].dgrad(dpre, N, h.grad, accumulate=not h.first_write())
         for d in (0, 1, 2, 3):
             self._block_bwd(ar, 'dec%d' % d, ctx['dec%d' % d], N)
         # bridge
@@ -386,7 +399,7 @@ class ResUNet:
         cb1.wgrad(b['sb1'], d_b1)
         dp = ar.alloc((N,) + cb1.buf_dims + (b['inp'].C,), self.dtype)
         cb1.dgrad(d_b1, N, dp, accumulate=False)
-        self._norm_bwd(ar, dp, True, b['sb1'], b['nb1'], Nn['bridge.cb1'], b['inp'].grad, ACT_RELU, accumulate=True)
+        self._norm_bwd(ar, dp, True, b['sb1'], b['nb1'], Nn['bridge.cb1'], b['inp'].grad, ACT_RELU, accumulate=not b['inp'].first_write())
         ar.release(mk, defer=True)
         for e in (4, 3, 2, 1):
             if e <= inline_from:

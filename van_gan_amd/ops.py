@@ -765,10 +765,10 @@ def actnorm_bwd(g, g_padded, x, dims, C_, dx, **kw):
     actnorm_run(actnorm_desc(g, g_padded, x, dims, C_, dx, **kw))
 
 
-def concat_bwd(g, dims, Cu, Cs, dlow, dskip):
+def concat_bwd(g, dims, Cu, Cs, dlow, dskip, acc_low: bool = True, acc_skip: bool = True):
     N, D, H, W = dims
-    check(lib.vg_concat_bwd(_p(g), N, D, H, W, Cu, Cs, _p(dlow), _p(dskip), int(g.dtype == torch.float32), stream()),
-          'vg_concat_bwd')
+    check(lib.vg_concat_bwd(_p(g), N, D, H, W, Cu, Cs, _p(dlow), _p(dskip), int(g.dtype == torch.float32),
+                            int(bool(acc_low)) | (int(bool(acc_skip)) << 1), stream()), 'vg_concat_bwd')
 
 
 def tanh_bwd(dy, y, dpre):
