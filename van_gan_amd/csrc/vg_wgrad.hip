@@ -351,6 +351,8 @@ extern "C" int vg_conv3d_wgrad(const vg_conv_desc* d, const void* dy, int dy_f32
     if (d->Cout < 1 || (d->Cout != 1 && (d->Cout % 8))) return VG_EINVAL;
     if (dy_f32 && d->Cout != 1 && !d->f32) return VG_EINVAL;
     if (d->src0 && tap_idx_host[0] == 0) {
+        const int wrc = vg_wgrad_pw_dma(d, dy, dy_f32, T_total, dw, db, scratch, scratch_bytes, (hipStream_t)stream);      // 1x1x1 shortcuts
+        if (wrc <= 0) return wrc;
         const int prc = vg_pointwise_wgrad(d, dy, dy_f32, T_total, dw, db, scratch, scratch_bytes, (hipStream_t)stream);
         if (prc <= 0) return prc;
     }

@@ -537,3 +537,278 @@ int vg_wgrad_dma(const vg_conv_desc* d, const void* dy, int dy_f32, const int32_
     if (k.part) vg_launch_reduce_partials(k.part, bx, k.dw_elems, dw, s);
     return vg_check_launch();
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// 1x1x1 convolutions (the residual blocks' shortcuts, resunet_model.py:126-131: raw block input, stride 1 or 2, virtual
+// upsample + concat in the decoder): dW[ci][co] = sum_v X[v*istr][ci] * dY[v][co].  No taps, no halo, no on-read transform: both
+// tiles are copied by LDS-DMA straight from the stored tensors -- the upsample shift, the concat source and the stride live in the
+// per-lane source offsets, which are the same for every tile (even tile origins).  The slab is tiny (1 x 1 ... 24 x 8 fragments of
+// 16 x 16) and K = all voxels, so the eight waves split K as well as rows: wave (kgrp, rgrp) takes K-steps ks = kgrp mod KS and the
+// 16-channel row blocks r = rgrp mod RS (x all Q column blocks); the KS partial slabs of a workgroup are summed through LDS at the end.
+// These layers ran on the on-the-fly kernels at 4-10x their HBM time (dec1.short: 69 us for 38 MB).
+// ------------------------------------------------------------------------------------------------------------------
+struct WpwK {
+    const char* x0; const char* x1; const char* dy;
+    int c0, c1, sh0, istr;
+    int N, D, H, W, OD, OH, OW, Cin, Cout;
+    int FA, RS, KS, ksl, ncob, CO2, co2l;
+    int tdl, thl, twl, tiles_d, tiles_h, tiles_w, total_tiles;
+    int ppp, nA, nB, bufb, nbuf;          // 1-KiB pieces per 16-channel plane of the X tile (BM / 32), A / B pieces, buffer bytes, buffers
+    unsigned m_tpn, m_tw, m_th, m_ppp, m_ncob;
+    float* dw; float* db; float* part; int dw_elems;
+};
+
+template <int R, int Q>
+__global__ __launch_bounds__(512, 2) void wgrad_pw_dma_kernel(const WpwK p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lg = lane >> 4, li = lane & 15;
+    const int rgrp0 = fast_div(blockIdx.y, p.m_ncob), cob = blockIdx.y - rgrp0 * p.ncob;      // (row-block group of the workgroup: always 0 here)
+    (void)rgrp0;
+    const int kgrp = wave & (p.KS - 1), rgrp = wave >> p.ksl;
+    const int BM = 1 << (p.tdl + p.thl + p.twl);
+    const int nks = BM >> 5;
+    const int TWm = (1 << p.twl) - 1, THm = (1 << p.thl) - 1;
+    const int CO = p.CO2 >> 1;
+    const int Hs = p.H >> p.sh0, Ws = p.W >> p.sh0;
+    int aoffs[VG_WD_MAXA], boffs[VG_WD_MAXB];
+#pragma unroll
+    for (int k = 0; k < VG_WD_MAXA; ++k) {
+        const int piece = wave + 8 * k;
+        const int plane = fast_div(piece, p.m_ppp), pk = piece - plane * p.ppp;
+        const int m = pk * 32 + (lane >> 1);
+        const int c = plane * 16 + (lane & 1) * 8;
+        const int w = (m & TWm) * p.istr, h = ((m >> p.twl) & THm) * p.istr, d = (m >> (p.twl + p.thl)) * p.istr;
+        aoffs[k] = c < p.c0 ? ((((d >> p.sh0) * Hs + (h >> p.sh0)) * Ws + (w >> p.sh0)) * p.c0 + c) * 2
+                            : (((d * p.H + h) * p.W + w) * p.c1 + (c - p.c0)) * 2;
+    }
+#pragma unroll
+    for (int k = 0; k < VG_WD_MAXB; ++k) {
+        const int byte = (wave + 8 * k) * 1024 + lane * 16;
+        int m = byte >> p.co2l; const int s = (byte - (m << p.co2l)) >> 4;
+        if (m >= BM) m = 0;
+        const int f = p.CO2 == 128 ? (m >> 1) & 3 : (p.CO2 == 64 ? (m >> 2) & 1 : 0);
+        const int blk = (s >> 1) ^ f;
+        const int w = m & TWm, h = (m >> p.twl) & THm, d = m >> (p.twl + p.thl);
+        boffs[k] = (((d * p.OH + h) * p.OW + w) * p.Cout + cob * CO + blk * 16 + (s & 1) * 8) * 2;
+    }
+    const int tiles_per_n = p.tiles_d * p.tiles_h * p.tiles_w;
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_d*)smem;
+    auto issue = [&](int tile, int bufoff) {
+        int t = tile;
+        const int n = fast_div(t, p.m_tpn); t -= n * tiles_per_n;
+        const int t1 = fast_div(t, p.m_tw), ti_w = t - t1 * p.tiles_w;
+        const int ti_d = fast_div(t1, p.m_th), ti_h = t1 - ti_d * p.tiles_h;
+        const int od0 = ti_d << p.tdl, oh0 = ti_h << p.thl, ow0 = ti_w << p.twl;
+        const int id0 = od0 * p.istr, ih0 = oh0 * p.istr, iw0 = ow0 * p.istr;
+        const char* a0 = p.x0 + ((((size_t)n * (p.D >> p.sh0) + (id0 >> p.sh0)) * Hs + (ih0 >> p.sh0)) * Ws + (iw0 >> p.sh0)) * p.c0 * 2;
+        const char* a1 = p.x1 + ((((size_t)n * p.D + id0) * p.H + ih0) * p.W + iw0) * p.c1 * 2;
+        const char* bbase = p.dy + ((((size_t)n * p.OD + od0) * p.OH + oh0) * p.OW + ow0) * p.Cout * 2;
+#pragma unroll
+        for (int k = 0; k < VG_WD_MAXA; ++k) {
+            const int piece = wave + 8 * k;
+            if (piece < p.nA) {
+                const bool lo = fast_div(piece, p.m_ppp) * 16 < p.c0;          // wave-uniform: a piece is one plane
+                glds16(lo ? a0 : a1, aoffs[k], lds0 + bufoff + piece * 1024);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < VG_WD_MAXB; ++k) {
+            const int piece = wave + 8 * k;
+            if (piece < p.nB) glds16(bbase, boffs[k], lds0 + bufoff + (p.nA + piece) * 1024);
+        }
+    };
+    const int ntw = ((int)blockIdx.x < p.total_tiles) ? (p.total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+    const int n_w = (wave < p.nA ? (p.nA - wave + 7) >> 3 : 0) + (wave < p.nB ? (p.nB - wave + 7) >> 3 : 0);
+    for (int j = 0; j < p.nbuf - 1 && j < ntw; ++j) issue(blockIdx.x + j * gridDim.x, j * p.bufb);
+
+    // row blocks of this wave: plane = rgrp + RS * j (beyond FA: plane 0, dropped at the write)
+    int poff[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) { const int pl = rgrp + p.RS * j; poff[j] = (pl < p.FA ? pl : 0) * (BM * 32); }
+    f32x4 acc[R][Q];
+#pragma unroll
+    for (int j = 0; j < R; ++j)
+#pragma unroll
+        for (int q = 0; q < Q; ++q) acc[j][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int m0l = 4 * lg + (li >> 2);
+    const int fsw = p.CO2 == 128 ? (m0l >> 1) & 3 : (p.CO2 == 64 ? (m0l >> 2) & 1 : 0);
+    int yq[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) yq[q] = m0l * p.CO2 + 32 * (q ^ fsw) + 8 * (li & 3);
+    const int lx = m0l * 32 + 8 * (li & 3);
+    const int ystep = 32 * p.CO2, y16 = 16 * p.CO2;
+    const bool do_db = p.db != nullptr;
+    float dbs[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dbs[e] = 0.f;
+    const int nslots = CO >> 3;
+    const int db_s = tid % nslots, db_v0 = tid / nslots, db_vs = 512 / nslots;
+
+    int cur = 0, nxt = p.nbuf - 1;
+    for (int it = 0; it < ntw; ++it) {
+        const char* hb = smem + cur * p.bufb;
+        const int newer = min(p.nbuf - 2, ntw - 1 - it);
+        wait_vmcnt(newer * n_w);
+        __syncthreads();
+        if (it + p.nbuf - 1 < ntw) issue(blockIdx.x + (it + p.nbuf - 1) * gridDim.x, nxt * p.bufb);
+        cur = cur + 1 == p.nbuf ? 0 : cur + 1; nxt = nxt + 1 == p.nbuf ? 0 : nxt + 1;
+        const char* yb = hb + p.nA * 1024;
+        if (do_db) {
+            for (int v = db_v0; v < BM; v += db_vs) {
+                const bf16x8 r = *(const bf16x8*)(yb + v * p.CO2 + db_s * 16);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dbs[e] += bf2f((bf16_t)r[e]);
+            }
+        }
+        for (int ks = kgrp; ks < nks; ks += p.KS) {
+            bf16x8 A[R], B[Q];
+            const char* hk = hb + ks * 1024 + lx;
+            const char* yk = yb + ks * ystep;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) B[q] = tr_frag_d(yk + yq[q], yk + yq[q] + y16);
+#pragma unroll
+            for (int j = 0; j < R; ++j) A[j] = tr_frag_d(hk + poff[j], hk + poff[j] + 512);
+#pragma unroll
+            for (int j = 0; j < R; ++j)
+#pragma unroll
+                for (int q = 0; q < Q; ++q) acc[j][q] = VG_MFMA16(A[j], B[q], acc[j][q]);
+        }
+    }
+    // ---- sum the KS partial slabs of the workgroup through LDS (pairwise rounds), then the kgrp == 0 waves write ----
+    float* red = (float*)smem;
+    int sl = 1;                                               // log2(2 * step)
+    for (int step = 1; step < p.KS; step <<= 1, ++sl) {
+        // receivers of this round: kgrp a multiple of 2 * step; slot = (row group, kgrp / (2 * step)): at most 4 slots of R * Q KiB
+        const int slot = rgrp * (p.KS >> sl) + (kgrp >> sl);
+        __syncthreads();
+        if ((kgrp & (2 * step - 1)) == step) {                  // sender -> the receiver step waves below it (same slot index)
+            float* dst = red + (size_t)(slot * R * Q) * 256 + lane * 4;
+#pragma unroll
+            for (int j = 0; j < R; ++j)
+#pragma unroll
+                for (int q = 0; q < Q; ++q) *(f32x4*)(dst + (j * Q + q) * 256) = acc[j][q];
+        }
+        __syncthreads();
+        if ((kgrp & (2 * step - 1)) == 0) {
+            const float* src = red + (size_t)(slot * R * Q) * 256 + lane * 4;
+#pragma unroll
+            for (int j = 0; j < R; ++j)
+#pragma unroll
+                for (int q = 0; q < Q; ++q) acc[j][q] += *(const f32x4*)(src + (j * Q + q) * 256);
+        }
+    }
+    if (kgrp == 0) {
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const int pl = rgrp + p.RS * j;
+            if (pl >= p.FA) continue;
+            const int ci0 = pl * 16 + 4 * lg;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const int co = cob * CO + q * 16 + li;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const size_t i = (size_t)(ci0 + e) * p.Cout + co;
+                    if (p.part) p.part[(size_t)blockIdx.x * p.dw_elems + i] = acc[j][q][e];
+                    else atomicAdd(&p.dw[i], acc[j][q][e]);
+                }
+            }
+        }
+    }
+    if (do_db) {
+        __syncthreads();
+        if (tid < CO) red[tid] = 0.f;
+        __syncthreads();
+        if (db_v0 < BM) {
+            const int fv = p.CO2 == 128 ? (db_v0 >> 1) & 3 : (p.CO2 == 64 ? (db_v0 >> 2) & 1 : 0);
+            const int ch = 16 * ((db_s >> 1) ^ fv) + 8 * (db_s & 1);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) atomicAdd(&red[ch + e], dbs[e]);
+        }
+        __syncthreads();
+        if (tid < CO) atomicAdd(&p.db[cob * CO + tid], red[tid]);
+    }
+}
+
+template <int R, int Q>
+static void launch_wpw(const WpwK& k, dim3 grid, int lds, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)wgrad_pw_dma_kernel<R, Q>, hipFuncAttributeMaxDynamicSharedMemorySize, VG_LDS_LIMIT);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((wgrad_pw_dma_kernel<R, Q>), grid, dim3(512), lds, s, k);
+}
+
+// Serve a 1x1x1 weight gradient (raw multi-channel source).  VG_OK served, 1 not one of its shapes, < 0 error.
+int vg_wgrad_pw_dma(const vg_conv_desc* d, const void* dy, int dy_f32, int T_total, float* dw, float* db, float* scratch,
+                    int64_t scratch_bytes, hipStream_t s) {
+    if (!vg_tune("WGRAD_PW_DMA", 1)) return 1;
+    const int Cin = d->c_src0 + d->c_src1;
+    if (d->f32 || dy_f32 || d->src_f32 || d->wpack || d->ntaps != 1 || T_total != 1 || d->tap_d[0] || d->tap_h[0] || d->tap_w[0]) return 1;
+    if (d->in_scale || d->act != VG_ACT_NONE || d->noise || !scratch) return 1;
+    if (Cin < 16 || (Cin % 16) || (d->Cout % 16) || (d->c_src0 % 16) || (d->c_src1 % 16)) return 1;
+    if (d->istr < 1 || d->istr > 2 || d->OD * d->istr != d->D || d->OH * d->istr != d->H || d->OW * d->istr != d->W) return 1;
+    if (d->src0_shift && d->istr != 1) return 1;
+    const int FA = Cin / 16;
+    const int CO = d->Cout >= 64 ? 64 : d->Cout;
+    if ((d->Cout % CO) || FA > 24) return 1;
+    const int Q = CO / 16, ncob = d->Cout / CO;
+    // rows per wave / K split: the instantiated (R, Q); RS row groups x KS K groups = 8 waves
+    int R = 0, RS = 1;
+    if (Q == 1) { R = 3; } else if (Q == 2) { R = 6; } else { R = FA <= 4 ? 4 : 6; }
+    while (RS < 8 && RS * R < FA) RS <<= 1;
+    if (RS * R < FA) return 1;
+    const int KS = 8 / RS;
+    // tile: even origins (upsample shift), TW in {8, 16}, TW * TH >= 32; two to four buffers
+    int best[5] = {0, 0, 0, 0, 0};
+    for (int bm = 512; bm >= 64 && !best[0]; bm >>= 1) {
+        const int nA = FA * (bm / 32), nB = bm * CO * 2 / 1024;
+        if (nA > 8 * VG_WD_MAXA || nB > 8 * VG_WD_MAXB || nB < 1) continue;
+        const int bufb = (nA + nB) * 1024;
+        if (2 * bufb > VG_LDS_LIMIT || (bm / 32) < KS) continue;
+        if (8 * R * Q * 1024 / 2 > VG_LDS_LIMIT) continue;         // the reduction's largest round: half the waves' slabs
+        for (int tw = 16; tw >= 8 && !best[0]; tw >>= 1) {
+            if (d->OW % tw) continue;
+            for (int th = 2; th <= d->OH && tw * th <= bm; th <<= 1) {
+                if ((d->OH % th) || tw * th < 32) continue;
+                const int td = bm / (tw * th);
+                if (td > d->OD || (d->OD % td) || (d->src0_shift && (td & 1))) continue;
+                int nb = VG_LDS_LIMIT / bufb; if (nb > 4) nb = 4;
+                best[0] = td; best[1] = th; best[2] = tw; best[3] = bufb; best[4] = nb;
+                break;
+            }
+        }
+    }
+    if (!best[0]) return 1;
+    const int TD = best[0], TH = best[1], TW = best[2], BM = TD * TH * TW;
+    if (d->src0_shift && ((TD | TH | TW) & 1)) return 1;
+    WpwK k;
+    k.x0 = (const char*)d->src0; k.x1 = (const char*)d->src1; k.dy = (const char*)dy;
+    k.c0 = d->c_src0; k.c1 = d->c_src1; k.sh0 = d->src0_shift ? 1 : 0; k.istr = d->istr;
+    k.N = d->N; k.D = d->D; k.H = d->H; k.W = d->W; k.OD = d->OD; k.OH = d->OH; k.OW = d->OW; k.Cin = Cin; k.Cout = d->Cout;
+    k.FA = FA; k.RS = RS; k.KS = KS; k.ksl = ilog2_exact(KS); k.ncob = ncob; k.CO2 = CO * 2; k.co2l = ilog2_exact(CO * 2);
+    k.tdl = ilog2_exact(TD); k.thl = ilog2_exact(TH); k.twl = ilog2_exact(TW);
+    k.tiles_d = d->OD / TD; k.tiles_h = d->OH / TH; k.tiles_w = d->OW / TW;
+    k.total_tiles = d->N * k.tiles_d * k.tiles_h * k.tiles_w;
+    k.ppp = BM / 32; k.nA = FA * k.ppp; k.nB = BM * CO * 2 / 1024; k.bufb = best[3]; k.nbuf = best[4];
+    auto magic = [](int dd) { return dd <= 1 ? 0u : (unsigned)((1ULL << 32) / (unsigned)dd + 1ULL); };
+    k.m_tpn = magic(k.tiles_d * k.tiles_h * k.tiles_w); k.m_tw = magic(k.tiles_w); k.m_th = magic(k.tiles_h); k.m_ppp = magic(k.ppp); k.m_ncob = magic(ncob);
+    k.dw = dw; k.db = db; k.dw_elems = Cin * d->Cout;
+    if (k.total_tiles * ncob < 32) return 1;          // a handful of tiles (8^3 level): two launches cost more than the on-the-fly kernel (22 vs 18 us)
+    int bx = vg_tune("WGRAD_PW_WGS", 256) / ncob; if (bx < 1) bx = 1; if (bx > k.total_tiles) bx = k.total_tiles;
+    const int64_t part_bytes = (int64_t)bx * k.dw_elems * 4;
+    if (part_bytes > scratch_bytes) return 1;
+    k.part = (float*)scratch;
+    int lds = k.nbuf * k.bufb; { const int rl = 4 * R * Q * 1024; if (rl > lds) lds = rl; }
+    if (vg_dry("wgrad_pw_dma<%d,%d>|bm%d|rs%d|s%d|u%d|nb%d|walk%d", R, Q, BM, RS, d->istr, k.sh0, k.nbuf, k.total_tiles > bx ? 1 : 0)) return VG_OK;
+    const dim3 grid(bx, ncob, 1);
+    if (Q == 1) launch_wpw<3, 1>(k, grid, lds, s);
+    else if (Q == 2) launch_wpw<6, 2>(k, grid, lds, s);
+    else if (R == 4) launch_wpw<4, 4>(k, grid, lds, s);
+    else launch_wpw<6, 4>(k, grid, lds, s);
+    vg_launch_reduce_partials(k.part, bx, k.dw_elems, dw, s);
+    return vg_check_launch();
+}
