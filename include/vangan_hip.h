@@ -287,8 +287,10 @@ int vg_divide_crop(const float* pred, const float* cnt, int X, int Y, int Z, int
  * Multi-tensor Adam with per-tensor clip-by-norm (tf.keras.optimizers.Adam(2e-4, 0.5, 0.9,
  * clipnorm=100), vangan.py:220-235, applied by optimizer.minimize at vangan.py:426-438).
  * w,g,m,v: flat fp32 buffers of `total` elements; seg_off[T+1] tensor boundaries (device int64);
- * norms[T] scratch.  grad_scale multiplies g before clipping (1/world for mean, 1 for the
- * reference's SUM all-reduce).
+ * norms[T + 2 * ceil(total / 4096)] scratch (T squared norms, then per-block partial sums: the norms
+ * are added in a fixed order, so replicas holding the same reduced gradients apply bit-identical
+ * updates).  grad_scale multiplies g before clipping (1/world for mean, 1 for the reference's SUM
+ * all-reduce).
  * --------------------------------------------------------------------------------------------- */
 int vg_adam_clip(float* w, const float* g, float* m, float* v, const int64_t* seg_off_dev, int T,
                  int64_t total, float* norms, float lr_t, float beta1, float beta2, float eps,

@@ -87,7 +87,9 @@ def test_two_ranks_equal_one_process_with_batch_two(tmp_path, backend):
     a, b = torch.load(out % 0), torch.load(out % 1)
     # every rank applied the same update
     for k in a['w']:
-        assert torch.equal(a['w'][k], b['w'][k]), k
+        ne = a['w'][k] != b['w'][k]
+        assert not bool(ne.any()), '%s: %d of %d weights differ between the ranks, max |diff| %.3e' % (
+            k, int(ne.sum()), ne.numel(), float((a['w'][k] - b['w'][k]).abs().max()))
     assert a['res'] == b['res']
     # per-replica noise / dropout streams: different keys, uncorrelated draws of the expected spread
     assert a['noise_key'] != b['noise_key']

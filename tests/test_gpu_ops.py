@@ -374,12 +374,13 @@ def test_soft_skeleton_and_cldice():
 def test_adam_clip():
     from van_gan_amd import ops
     from van_gan_amd.nets import ParamStore
-    specs = [('a', (1000,), 'x'), ('b', (3, 3, 3, 16, 16), 'x'), ('c', (7,), 'x'), ('d', (33, 65), 'x')]
+    specs = [('a', (1000,), 'x'), ('b', (3, 3, 3, 16, 16), 'x'), ('c', (7,), 'x'), ('d', (33, 65), 'x'), ('e', (21001,), 'x'), ('f', (5,), 'x')]
     st = ParamStore(specs, _dev())
     g = torch.Generator().manual_seed(8)
     P = {n: torch.randn(sh, generator=g) for n, sh, _ in specs}
     G = {n: torch.randn(sh, generator=g) for n, sh, _ in specs}
     G['b'] = G['b'] * 50.0                  # norm >> 100: clipped
+    G['e'] = G['e'] * 3.0                   # a clipped tensor spread over seven 4096-element blocks
     st.load(P)
     state = {}
     for step in range(1, 3):
@@ -394,6 +395,17 @@ def test_adam_clip():
     for n in P:
         assert (out[n].double() - Pd[n]).abs().max() < 1e-6, n      # fp32 ulp at |w|~4 is 4.8e-7
     assert abs(float(st.norms[1]) - float((G['b'].double() ** 2).sum())) < 1e-3 * float((G['b'].double() ** 2).sum())
+    assert abs(float(st.norms[4]) - float((G['e'].double() ** 2).sum())) < 1e-3 * float((G['e'].double() ** 2).sum())
+    # the clip factor is reproducible bit for bit (fixed summation order: replicas must not drift apart)
+    w_first = st.w.clone()
+    for rep in range(20):
+        st.load(P); st.m.zero_(); st.v.zero_()
+        for step in range(1, 3):
+            for n in P:
+                st.grad(n).copy_(G[n])
+            lr_t = 2e-4 * math.sqrt(1 - 0.9 ** step) / (1 - 0.5 ** step)
+            ops.adam_clip(st.w, st.g, st.m, st.v, st.seg_off, st.T, st.norms, lr_t, 0.5, 0.9, 1e-7, 100.0)
+        assert torch.equal(st.w, w_first), rep
 
 
 def test_rng_statistics():

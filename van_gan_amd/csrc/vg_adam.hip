@@ -14,7 +14,13 @@ __device__ __forceinline__ int find_seg(const int64_t* off, int T, int64_t i) {
 
 // Every block owns a contiguous span of ADAM_SPAN elements of the flat buffer.  A span inside one tensor (all but ~one per
 // tensor) is streamed with 16-byte loads/stores, consecutive lanes on consecutive float4s; a span that straddles tensors
-// walks its tensors one after the other.  Per (block, tensor) there is ONE norm atomic.
+// walks its tensors one after the other.
+//
+// The squared norms are summed in a FIXED order (no float atomics): data-parallel replicas apply the clip factor to bit-identical
+// reduced buckets and must come out with bit-identical weights, or they drift apart step by step.  A tensor that lies inside one
+// span is summed by that block straight into norms[seg]; a tensor spread over several spans leaves one partial per block in
+// bp[2 * block + slot] (slot 0: the piece starts at the block's first element, slot 1: it starts inside the block -- only a tensor's
+// first piece can) and adam_kernel adds the partials of its tensor in block order.
 #define ADAM_SPAN 4096
 typedef const __attribute__((address_space(1))) f32x4* gp_f32x4;
 
@@ -26,12 +32,13 @@ __device__ __forceinline__ float block_sum(float s, float* red) {
     return red[0] + red[1] + red[2] + red[3];
 }
 
-__global__ __launch_bounds__(256) void sqnorm_kernel(const float* g, const int64_t* off, int T, int64_t total, float scale, float* norms) {
+__global__ __launch_bounds__(256) void sqnorm_kernel(const float* g, const int64_t* off, int T, int64_t total, float scale, float* norms, float* bp) {
     __shared__ float red[4];
     const int tid = threadIdx.x;
     const int64_t b0 = (int64_t)blockIdx.x * ADAM_SPAN;
     const int64_t b1 = b0 + ADAM_SPAN < total ? b0 + ADAM_SPAN : total;
     int seg = find_seg(off, T, b0);
+    if (tid < 2) bp[2 * blockIdx.x + tid] = 0.f;
     if (off[seg + 1] >= b1 && b1 - b0 == ADAM_SPAN) {
         float s = 0.f;
 #pragma unroll
@@ -41,7 +48,10 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const float* g, const int64
             for (int e = 0; e < 4; ++e) { const float x = v[e] * scale; s += x * x; }
         }
         s = block_sum(s, red);
-        if (tid == 0) atomicAdd(&norms[seg], s);
+        if (tid == 0) {
+            if (off[seg] == b0 && off[seg + 1] == b1) norms[seg] = s;          // the tensor is exactly this span
+            else bp[2 * blockIdx.x] = s;
+        }
         return;
     }
     for (; seg < T && off[seg] < b1; ++seg) {                      // block-uniform loop over the tensors of the span
@@ -49,8 +59,23 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const float* g, const int64
         float s = 0.f;
         for (int64_t i = lo + tid; i < hi; i += 256) { const float x = g[i] * scale; s += x * x; }
         s = block_sum(s, red);
-        if (tid == 0 && hi > lo) atomicAdd(&norms[seg], s);
+        if (tid == 0 && hi > lo) {
+            if (off[seg] >= b0 && off[seg + 1] <= b1) norms[seg] = s;          // whole tensor inside the span
+            else bp[2 * blockIdx.x + (lo == b0 ? 0 : 1)] = s;
+        }
     }
+}
+
+// squared norm of tensor seg: norms[seg] when one block summed it, else its per-block partials in block order (block-uniform call)
+__device__ __forceinline__ float seg_sqnorm(float* norms, const float* bp, const int64_t* off, int seg, float* red) {
+    const int64_t lo = off[seg], hi = off[seg + 1];
+    const int64_t bl = lo / ADAM_SPAN, bh = (hi - 1) / ADAM_SPAN;
+    if (bl == bh) return norms[seg];
+    float s = 0.f;
+    for (int64_t b = bl + threadIdx.x; b <= bh; b += 256) s += bp[2 * b + ((b == bl && lo != bl * ADAM_SPAN) ? 1 : 0)];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0 && (int64_t)blockIdx.x == bl) norms[seg] = s;      // for the caller's diagnostics; nobody reads it back
+    return s;
 }
 
 __device__ __forceinline__ void adam_elem(float& w, float g, float& m, float& v, float f, float lr_t, float b1, float b2, float eps) {
@@ -61,14 +86,15 @@ __device__ __forceinline__ void adam_elem(float& w, float g, float& m, float& v,
 }
 
 __global__ __launch_bounds__(256) void adam_kernel(float* w, const float* g, float* m, float* v, const int64_t* off, int T,
-                                                   int64_t total, const float* norms, float lr_t, float b1, float b2, float eps,
+                                                   int64_t total, float* norms, const float* bp, float lr_t, float b1, float b2, float eps,
                                                    float clip, float scale) {
+    __shared__ float red[4];
     const int tid = threadIdx.x;
     const int64_t s0 = (int64_t)blockIdx.x * ADAM_SPAN;
     const int64_t s1 = s0 + ADAM_SPAN < total ? s0 + ADAM_SPAN : total;
     int seg = find_seg(off, T, s0);
     if (off[seg + 1] >= s1 && s1 - s0 == ADAM_SPAN) {
-        const float nrm = sqrtf(norms[seg]);
+        const float nrm = sqrtf(seg_sqnorm(norms, bp, off, seg, red));
         const float f = ((clip > 0.f && nrm > clip) ? clip / nrm : 1.f);
         f32x4 gv[ADAM_SPAN / 1024], mv[ADAM_SPAN / 1024], vv[ADAM_SPAN / 1024], wv[ADAM_SPAN / 1024];
 #pragma unroll
@@ -92,7 +118,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* w, const float* g, flo
     }
     for (; seg < T && off[seg] < s1; ++seg) {
         const int64_t lo = off[seg] > s0 ? off[seg] : s0, hi = off[seg + 1] < s1 ? off[seg + 1] : s1;
-        const float nrm = sqrtf(norms[seg]);
+        const float nrm = sqrtf(seg_sqnorm(norms, bp, off, seg, red));
         const float f = ((clip > 0.f && nrm > clip) ? clip / nrm : 1.f);
         for (int64_t i = lo + tid; i < hi; i += 256) adam_elem(w[i], g[i] * scale, m[i], v[i], f, lr_t, b1, b2, eps);
     }
@@ -103,10 +129,10 @@ extern "C" int vg_adam_clip(float* w, const float* g, float* m, float* v, const 
     vg_begin();
     if (!w || !g || !m || !v || !seg_off_dev || !norms || T < 1 || total < 1) return VG_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(norms, 0, T * sizeof(float), s) != hipSuccess) return VG_ELAUNCH;
     const int blocks = (int)((total + ADAM_SPAN - 1) / ADAM_SPAN);
-    hipLaunchKernelGGL(sqnorm_kernel, dim3(blocks), dim3(256), 0, s, g, seg_off_dev, T, total, grad_scale, norms);
-    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, s, w, g, m, v, seg_off_dev, T, total, norms, lr_t, beta1, beta2, eps,
+    float* bp = norms + T;                       // [blocks][2] per-block partials of the tensors that span several blocks
+    hipLaunchKernelGGL(sqnorm_kernel, dim3(blocks), dim3(256), 0, s, g, seg_off_dev, T, total, grad_scale, norms, bp);
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, s, w, g, m, v, seg_off_dev, T, total, norms, bp, lr_t, beta1, beta2, eps,
                        clipnorm, grad_scale);
     return vg_check_launch();
 }

@@ -83,7 +83,8 @@ class ParamStore:
         self.m = torch.zeros(off, dtype=torch.float32, device=device)
         self.v = torch.zeros(off, dtype=torch.float32, device=device)
         self.seg_off = torch.tensor(bounds, dtype=torch.int64, device=device)
-        self.norms = torch.zeros(self.T, dtype=torch.float32, device=device)
+        # T squared norms + two partial sums per 4096-element block (vg_adam_clip adds the norms in a fixed order)
+        self.norms = torch.zeros(self.T + 2 * ((self.total + 4095) // 4096), dtype=torch.float32, device=device)
         self.step = 0
 
     def _view(self, buf, name):

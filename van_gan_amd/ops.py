@@ -842,6 +842,7 @@ def axpby(a, alpha, b, beta, y, accumulate=False):
 
 
 def adam_clip(w, g, m, v, seg_off, T, norms, lr_t, beta1, beta2, eps, clipnorm, grad_scale=1.0):
+    assert norms.numel() >= T + 2 * ((w.numel() + 4095) // 4096), 'norms: T squared norms + 2 partial sums per 4096-element block'
     check(lib.vg_adam_clip(_p(w), _p(g), _p(m), _p(v), _p(seg_off), T, w.numel(), _p(norms), lr_t, beta1, beta2, eps,
                            clipnorm, grad_scale, stream()), 'vg_adam_clip')
 
