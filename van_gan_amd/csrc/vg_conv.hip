@@ -147,6 +147,15 @@ __global__ __launch_bounds__(256, ((BN / 16) * MSUB >= VG_CONV_MW2 ? 2 : VG_CONV
     int Ktot = p.Ktot, kc_pad = p.kc_pad, WRS = p.WRS;
     const void* wsrc = p.wp;
     int c_od = p.ood, c_oh = p.ooh, c_ow = p.oow, c_OD = p.OD, c_OH = p.OH, c_OW = p.OW;
+    // K split over workgroups (small deep-level grids: 8^3 / 16^3 voxels, hundreds of channels -- a tile's dependent chain of
+    // hundreds of K-steps on a handful of workgroups is all latency): blockIdx.x = walker * ks + slice, slice s multiplies the
+    // channel chunks [s * nchunks / ks, (s + 1) * nchunks / ks) of every tile and leaves its fp32 partial tile in p.ks_part; the
+    // slice that arrives last (p.ks_cnt) adds the partials in slice order and runs the epilogue.
+    int ks_slice = 0, cps = p.nchunks;
+    if constexpr (MC == 0 && !DMA) {
+        if (p.ks > 1) { ks_slice = __builtin_amdgcn_readfirstlane(bx % p.ks); bx /= p.ks; gx /= p.ks; cps = p.nchunks / p.ks; }
+    }
+    const int c_lo = ks_slice * cps;
     if constexpr (MC == 2) {
         const int cls = __builtin_amdgcn_readfirstlane(bx % q.ncls);
         bx /= q.ncls; gx /= q.ncls;
@@ -337,7 +346,7 @@ __global__ __launch_bounds__(256, ((BN / 16) * MSUB >= VG_CONV_MW2 ? 2 : VG_CONV
 #pragma unroll
         for (int i = 0; i < MW; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-        for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+        for (int chunk = c_lo; chunk < c_lo + cps; ++chunk) {
             char* hb = halo;
             if constexpr (DMA) {
                 hb = halo + (sidx & 1) * hbytes;
@@ -363,12 +372,12 @@ __global__ __launch_bounds__(256, ((BN / 16) * MSUB >= VG_CONV_MW2 ? 2 : VG_CONV
                 __syncthreads();                       // previous readers of the halo tile are done; this tile's axis tables visible
                 if (p.nchunks > 1) { stage_scale_shift(g, scs, n, chunk, tid); __syncthreads(); }
                 if (!(g.dbg & 1)) stage_halo_tile<T, NOISE, (NOISE ? 4 : 6), (C1 ? 1 : 3)>(g, halo, scs, utab, rtab + (it & 1) * RTN, n, od0, chunk, tid);
-                if (chunk == 0 && tile + gx < tiles_per_n) {       // axis tables of the next tile, other buffer
+                if (chunk == c_lo && tile + gx < tiles_per_n) {       // axis tables of the next tile, other buffer
                     stage_resolve_axes<(C1 ? 1 : 3)>(g, rtab + ((it + 1) & 1) * RTN, nx_h0, nx_w0, tid);
                 }
-                if (chunk == 0) VG_STAMP(1);
+                if (chunk == c_lo) VG_STAMP(1);
                 __syncthreads();
-                if (chunk == 0) VG_STAMP(2);
+                if (chunk == c_lo) VG_STAMP(2);
             }
             const size_t kbase = (size_t)chunk * kc_pad;
             if (g.dbg & 4) continue;
@@ -376,7 +385,43 @@ __global__ __launch_bounds__(256, ((BN / 16) * MSUB >= VG_CONV_MW2 ? 2 : VG_CONV
             else conv_mfma_chunk<T, MW>(acc, wrow_g + kbase, hb, rowbase, tapoff, koff, ksteps, nt, g.CK, g.CS, lane);
         }
         VG_STAMP(3);
-        if (!(g.dbg & 8)) {
+        bool ks_last = true;
+        if constexpr (MC == 0 && !DMA) {
+            if (p.ks > 1) {
+                // The exchange uses device-scope relaxed atomic stores / loads (write-through to, resp. read from, the level the
+                // XCDs share) instead of __threadfence(): an agent-scope fence is buffer_wbl2 + buffer_inv -- it writes back and
+                // invalidates this XCD's whole L2 under every kernel of the other streams (measured: 24.7 -> 30.2 ms per step).
+                constexpr int SLOT = 256 * MW * 4;                       // floats of one partial tile: lane-linear accumulator dump
+                const size_t cell = (size_t)(n * gridDim.y + ntile) * tiles_per_n + tile;
+                float* slot = p.ks_part + (cell * p.ks + ks_slice) * SLOT;
+#pragma unroll
+                for (int i = 0; i < MW; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        __hip_atomic_store(slot + (i * 4 + r) * 256 + tid, acc[i][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this thread's partial has been written through ...
+                __syncthreads();                                         // ... every thread's, before the ticket
+                int* flag = tapoff + (VG_MAX_TAPS - 1);                  // (the host keeps ntaps < VG_MAX_TAPS for split launches)
+                if (tid == 0) *flag = (int)__hip_atomic_fetch_add(p.ks_cnt + cell, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __syncthreads();
+                ks_last = *flag == p.ks - 1;
+                if (ks_last) {
+                    const float* base = p.ks_part + cell * p.ks * SLOT;
+#pragma unroll
+                    for (int i = 0; i < MW; ++i)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[i][r] = __hip_atomic_load(base + (i * 4 + r) * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (int sl = 1; sl < p.ks; ++sl)
+#pragma unroll
+                        for (int i = 0; i < MW; ++i)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                acc[i][r] += __hip_atomic_load(base + (size_t)sl * SLOT + (i * 4 + r) * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (tid == 0) __hip_atomic_store(p.ks_cnt + cell, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch on this stream
+                }
+            }
+        }
+        if (ks_last && !(g.dbg & 8)) {
 #include "vg_conv_epilogue.inc"
         }
         }
@@ -616,6 +661,26 @@ __global__ __launch_bounds__(256, 2) void conv32_kernel(const GatherIn g, const 
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
+// K-split scratch: per stream (launches of one stream are ordered, launches of different streams may overlap) one device buffer
+// [VG_KS_CELLS arrival counters][VG_KS_PART_BYTES of partial tiles], allocated at the stream's first split launch and kept for the
+// life of the process.  The counters are zeroed once, on that stream; every launch leaves them at zero.
+#define VG_KS_CELLS 4096
+#define VG_KS_PART_BYTES (24L << 20)
+static int vg_ks_scratch(hipStream_t s, float** part, unsigned** cnt) {
+    struct Ent { hipStream_t s; char* p; };
+    static Ent pool[32];
+    static int npool = 0;
+    for (int i = 0; i < npool; ++i)
+        if (pool[i].s == s) { *cnt = (unsigned*)pool[i].p; *part = (float*)(pool[i].p + VG_KS_CELLS * 4); return VG_OK; }
+    if (npool == 32) return VG_EINVAL;
+    char* p = nullptr;
+    if (hipMalloc((void**)&p, VG_KS_CELLS * 4 + VG_KS_PART_BYTES) != hipSuccess) return VG_ELAUNCH;
+    if (hipMemsetAsync(p, 0, VG_KS_CELLS * 4, s) != hipSuccess) return VG_ELAUNCH;
+    pool[npool++] = Ent{s, p};
+    *cnt = (unsigned*)p; *part = (float*)(p + VG_KS_CELLS * 4);
+    return VG_OK;
+}
+
 static int conv_lds_bytes(const GatherIn& g, int BN, int CK, int wbytes, int dma = 0, int ksteps_total = 0) {
     const int nunits = dma ? 5 * (g.DS >> 4) : stage_table_ints(g);
     const int ksteps = ksteps_total > 0 ? ksteps_total : (g.ntaps * (CK >> 3) + 3) >> 2;
@@ -741,6 +806,7 @@ static int fill_conv(const vg_conv_desc* d, GatherIn& g, ConvOut& k, ConvCls& q,
     k.bias = d->bias; k.res = d->res; k.rs = d->res_scale; k.rb = d->res_shift; k.tanh_out = d->tanh_out;
     k.out = d->out; k.out_f32 = (d->out_f32 || d->f32) ? 1 : 0; k.accumulate = d->accumulate; k.sums = d->out_sums;
     k.bs_x0 = nullptr;
+    k.ks = 1; k.ks_part = nullptr; k.ks_cnt = nullptr;
     if (const vg_actnorm_bwd_desc* b = d->bstat) {       // validated by vg_conv3d
         k.bs_x0 = b->x; k.bs_x1 = b->x1; k.bs_c0 = b->x1 ? b->c_x0 : b->C; k.bs_sh = b->x1 ? (b->x0_shift ? 1 : 0) : 0;
         k.bs_act = b->act; k.bs_pad = b->g_padded ? 1 : 0; k.bs_D = b->D; k.bs_H = b->H; k.bs_W = b->W;
@@ -861,10 +927,26 @@ static int launch_conv3(const GatherIn& g, const ConvOut& k, const ConvCls& q, i
     const int ny = (k.Cout + BN - 1) / BN;
     const int ncp = MC == 2 ? q.ncls : 1;
     int bx = wg_target / (ny * g.N * ncp); if (bx < 1) bx = 1; if (bx > tiles) bx = tiles;
-    dim3 grid(bx * ncp, ny, g.N);
-    if (vg_dry("conv<%s,%d,%d,n%d,wl%d,dma%d,mc%d,c1%d>|walk%d|ch%d", sizeof(T) == 4 ? "f32" : "bf16", BN, MSUB, (int)NOISE, (int)WL, (int)DMA,
-               MC, (int)C1, tiles > bx ? 1 : 0, k.nchunks > 1 ? 1 : 0)) return VG_OK;
-    hipLaunchKernelGGL((conv_kernel<T, BN, MSUB, NOISE, WL, DMA, MC, C1>), grid, dim3(256), lds, s, g, k, q);
+    // K split (see the kernel): grids that leave most of the chip empty and have several channel chunks per tile.  Not with the weight
+    // panel in LDS (every slice would copy the whole panel: dec3.short 29 -> 44 us).  Solo times at 128^3 (rocprofv3, serial schedule):
+    // 256->256 at 8^3 50.8 -> 27.1 us, the 16^3 forward layers 42.9 -> 33.0, D.out 99.8 -> 60.1, the 8^3 data gradients 52.1 -> 48.1:
+    // -0.7 ms of kernel time per step -- and no change of the concurrent step (24.2 ms either way): these launches occupy a
+    // fraction of the chip and their latency is covered by the other lane and the weight-gradient streams.
+    int ks = 1;
+    const long cells = (long)tiles * ny * g.N;
+    if (MC == 0 && !DMA && !WL && k.nchunks > 1 && g.ntaps < VG_MAX_TAPS && bx == tiles && cells <= vg_tune("CONV_KSPLIT_CELLS", 256) && cells <= VG_KS_CELLS) {
+        const int cap = vg_tune("CONV_KSPLIT", 8);
+        constexpr long SLOTB = 256L * (MSUB * (BN / 16)) * 16;
+        for (int c = k.nchunks; c >= 2; --c)
+            if (k.nchunks % c == 0 && c <= cap && cells * c <= 1024 && cells * c * SLOTB <= VG_KS_PART_BYTES) { ks = c; break; }
+    }
+    dim3 grid(bx * ncp * ks, ny, g.N);
+    if (vg_dry("conv<%s,%d,%d,n%d,wl%d,dma%d,mc%d,c1%d>|walk%d|ch%d|ks%d", sizeof(T) == 4 ? "f32" : "bf16", BN, MSUB, (int)NOISE, (int)WL, (int)DMA,
+               MC, (int)C1, tiles > bx ? 1 : 0, k.nchunks > 1 ? 1 : 0, ks)) return VG_OK;
+    ConvOut k2 = k;
+    k2.ks = ks; k2.ks_part = nullptr; k2.ks_cnt = nullptr;
+    if (ks > 1) { const int rc = vg_ks_scratch(s, &k2.ks_part, &k2.ks_cnt); if (rc != VG_OK) return rc; }
+    hipLaunchKernelGGL((conv_kernel<T, BN, MSUB, NOISE, WL, DMA, MC, C1>), grid, dim3(256), lds, s, g, k2, q);
     return vg_check_launch();
 }
 template <typename T, int BN, int MSUB, bool NOISE>

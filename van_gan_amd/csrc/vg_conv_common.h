@@ -15,6 +15,8 @@ struct ConvOut {
     // pre-norm tensor(s) of the layer whose gradient this launch produces and its per-(sample, channel) constants
     const void* bs_x0; const void* bs_x1; int bs_c0, bs_sh, bs_act, bs_pad, bs_D, bs_H, bs_W;
     const float* bs_sc; const float* bs_sf; const float* bs_mu; const float* bs_rs; const float* bs_ml;
+    // K split over workgroups (conv_kernel, small grids): slices per tile, fp32 partial tiles, arrival counters per (sample, panel, tile)
+    int ks; float* ks_part; unsigned* ks_cnt;
 };
 // output-parity classes fused into one launch (data gradient of a strided conv): a separate kernel argument that only the
 // multi-class kernel variants read
