@@ -107,6 +107,7 @@ __global__ __launch_bounds__(256) void materialize_kernel(const MatK p) {
 // ------------------------------------------------------------------------------------------------------------------
 #define VG_WD_MAXA 9          // A (halo) DMA pieces per wave and tile (8 waves x 9 KiB = 72 KiB of halo planes per buffer)
 #define VG_WD_MAXB 4          // B (dY) pieces per wave and tile (32 KiB)
+#define VG_WD_TAB 64          // DIRECT: entries of one per-tile source offset table (HD + HH + HW)
 
 struct WgdK {
     const char* P; const char* dy;
@@ -122,6 +123,11 @@ struct WgdK {
     float* dw; float* db; float* part; int dw_elems;
     unsigned m_imgp, m_hhw, m_hw, m_pl, m_tpn, m_tw, m_th, m_ncob;     // floor(2^32 / d) + 1 of the run-time divisors (fast_div)
     int co2l;                         // log2(CO2)
+    // DIRECT (no materialised operand): the stored sources ([voxel][C] bf16; x0 optionally at half resolution = virtual nearest
+    // upsample, x1 the concat partner), the input grid, the input position of padded index 0, the on-read transform
+    const char* x0; const char* x1; int c0, c1, sh0;
+    int D, H, W, pmin_d, pmin_h, pmin_w;
+    const float* in_scale; const float* in_shift; float slope;
     unsigned long long* stamps;       // diagnostic (vg_set_stamp_buffer): per workgroup 8 words of phase cycle sums, else NULL
 };
 
@@ -159,7 +165,12 @@ __device__ __forceinline__ bf16x8 tr_frag_d(const char* base0, const char* base1
     return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
-template <int R, int Q>
+// DIRECT: the halo planes are copied from the STORED tensors (reflection padding, virtual upsample + concat and the stride-2
+// de-interleave all live in the per-lane source address, separable per axis: three small per-tile tables) and transformed in place
+// in LDS (InstanceNorm affine + activation, each lane on the 16 bytes it copied itself -- between its own vmcnt wait and the tile's
+// barrier, so no extra synchronisation).  For the thin full-resolution layers (Cin <= 48) the operand pass was as large as the weight
+// gradient itself: 38 us to rewrite 67 MB for a 67 us kernel.
+template <int R, int Q, bool DIRECT>
 __global__ __launch_bounds__(512, 2) void wgrad_dma_kernel(const WgdK p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -178,6 +189,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_dma_kernel(const WgdK p) {
 
     // ---- per-lane DMA source offsets (the halo box has the same shape for every tile: P is padded, tiles divide the grid) ----
     int aoffs[VG_WD_MAXA], boffs[VG_WD_MAXB];
+    int acst[DIRECT ? VG_WD_MAXA : 1];
     {
         const int nvox = p.HD * p.HH * p.HW;
 #pragma unroll
@@ -188,8 +200,17 @@ __global__ __launch_bounds__(512, 2) void wgrad_dma_kernel(const WgdK p) {
             if (iv >= nvox) iv = 0;
             const int hd = fast_div(iv, p.m_hhw), rem = iv - hd * (p.HH * p.HW);
             const int hh = fast_div(rem, p.m_hw), ws = rem - hh * p.HW;
-            const int gw = p.deint ? (ws < p.HWE ? ws : p.WEP + ws - p.HWE) : ws;
-            aoffs[k] = pl * p.plane_bytes + ((hd * p.Hp + hh) * p.Wps + gw) * 32 + (lane & 1) * 16;
+            if constexpr (DIRECT) {
+                // packed table indices (D, H, W axis entry of this lane's voxel) + source select; acst: channel bytes inside the source row
+                const int j = p.deint ? (ws < p.HWE ? 2 * ws : 2 * (ws - p.HWE) + 1) : ws;
+                const int c = (cib * p.PL + pl) * 16 + (lane & 1) * 8;
+                const int src1 = c >= p.c0 ? 1 : 0;
+                aoffs[k] = hd | ((p.HD + hh) << 8) | ((p.HD + p.HH + j) << 16) | (src1 << 24);
+                acst[k] = (src1 ? c - p.c0 : c) * 2;
+            } else {
+                const int gw = p.deint ? (ws < p.HWE ? ws : p.WEP + ws - p.HWE) : ws;
+                aoffs[k] = pl * p.plane_bytes + ((hd * p.Hp + hh) * p.Wps + gw) * 32 + (lane & 1) * 16;
+            }
         }
 #pragma unroll
         for (int k = 0; k < VG_WD_MAXB; ++k) {
@@ -204,19 +225,58 @@ __global__ __launch_bounds__(512, 2) void wgrad_dma_kernel(const WgdK p) {
     }
     const int tiles_per_n = p.tiles_d * p.tiles_h * p.tiles_w;
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_d*)smem;
-    auto issue = [&](int tile, int bufoff) {
+    // DIRECT: per-tile source offset tables, [2 buffers][2 sources][VG_WD_TAB] bytes-from-sample-base per axis entry (D entries, then
+    // H, then W); built by the first 2 * (HD + HH + HW) threads for the tile about to be requested, published by the tile barrier
+    int* otab = tapoff + VG_MAX_TAPS;
+    float* scs = (float*)(otab + 4 * VG_WD_TAB);                 // [N][2][PL * 16]: scale, shift of this workgroup's channels
+    auto build_tab = [&](int tile, int tb) {
+        const int L = p.HD + p.HH + p.HW;
+        if (tid >= 2 * L) return;
+        int t = tile;
+        const int n = fast_div(t, p.m_tpn); t -= n * tiles_per_n;
+        const int t1 = fast_div(t, p.m_tw), ti_w = t - t1 * p.tiles_w;
+        const int ti_d = fast_div(t1, p.m_th), ti_h = t1 - ti_d * p.tiles_h;
+        const int src1 = tid >= L ? 1 : 0, e = tid - src1 * L;
+        const int sh = src1 ? 0 : p.sh0, C2 = (src1 ? p.c1 : p.c0) * 2;
+        const int Hs = p.H >> sh, Ws = p.W >> sh;
+        int pos, nn, mul;
+        if (e < p.HD) { pos = (ti_d << p.tdl) * p.istr + p.pmin_d + e; nn = p.D; mul = Hs * Ws * C2; }
+        else if (e < p.HD + p.HH) { pos = (ti_h << p.thl) * p.istr + p.pmin_h + e - p.HD; nn = p.H; mul = Ws * C2; }
+        else { pos = (ti_w << p.twl) * p.istr + p.pmin_w + e - p.HD - p.HH; nn = p.W; mul = C2; }
+        pos = pos < 0 ? -pos : pos; pos = pos >= nn ? 2 * nn - 2 - pos : pos;              // reflection (the host admits single reflections only)
+        pos = min(max(pos, 0), nn - 1);
+        otab[(tb * 2 + src1) * VG_WD_TAB + e] = (pos >> sh) * mul;
+    };
+    auto issue = [&](int tile, int bufoff, int tb) {
         int t = tile;
         const int n = fast_div(t, p.m_tpn); t -= n * tiles_per_n;
         const int t1 = fast_div(t, p.m_tw), ti_w = t - t1 * p.tiles_w;
         const int ti_d = fast_div(t1, p.m_th), ti_h = t1 - ti_d * p.tiles_h;
         const int od0 = ti_d << p.tdl, oh0 = ti_h << p.thl, ow0 = ti_w << p.twl;
-        const char* abase = p.P + (size_t)(n * p.NPL + cib * p.PL) * p.plane_bytes
-                            + (size_t)((od0 * p.istr * p.Hp + oh0 * p.istr) * p.Wps + (p.deint ? ow0 : ow0 * p.istr)) * 32;
         const char* bbase = p.dy + ((((size_t)n * p.OD + od0) * p.OH + oh0) * p.OW + ow0) * p.Cout * 2;
+        if constexpr (DIRECT) {
+            const char* a0 = p.x0 + (size_t)n * (p.D >> p.sh0) * (p.H >> p.sh0) * (p.W >> p.sh0) * p.c0 * 2;
+            const char* a1 = p.x1 + (size_t)n * p.D * p.H * p.W * p.c1 * 2;
+            const int* tb0 = otab + tb * 2 * VG_WD_TAB;
 #pragma unroll
-        for (int k = 0; k < VG_WD_MAXA; ++k) {
-            const int piece = wave + 8 * k;
-            if (piece < p.nA) glds16(abase, aoffs[k], lds0 + bufoff + piece * 1024);
+            for (int k = 0; k < VG_WD_MAXA; ++k) {
+                const int piece = wave + 8 * k;
+                if (piece < p.nA) {
+                    const int cr = aoffs[k];
+                    const int* tq = tb0 + (cr >> 24) * VG_WD_TAB;
+                    const int off = tq[cr & 255] + tq[(cr >> 8) & 255] + tq[(cr >> 16) & 255] + acst[k];
+                    const bool lo = (fast_div(piece, p.m_imgp) + cib * p.PL) * 16 < p.c0;      // wave-uniform: a piece is one plane
+                    glds16(lo ? a0 : a1, off, lds0 + bufoff + piece * 1024);
+                }
+            }
+        } else {
+            const char* abase = p.P + (size_t)(n * p.NPL + cib * p.PL) * p.plane_bytes
+                                + (size_t)((od0 * p.istr * p.Hp + oh0 * p.istr) * p.Wps + (p.deint ? ow0 : ow0 * p.istr)) * 32;
+#pragma unroll
+            for (int k = 0; k < VG_WD_MAXA; ++k) {
+                const int piece = wave + 8 * k;
+                if (piece < p.nA) glds16(abase, aoffs[k], lds0 + bufoff + piece * 1024);
+            }
         }
 #pragma unroll
         for (int k = 0; k < VG_WD_MAXB; ++k) {
@@ -227,7 +287,20 @@ __global__ __launch_bounds__(512, 2) void wgrad_dma_kernel(const WgdK p) {
     // this workgroup's tiles: blockIdx.x, + gridDim.x, ...; nbuf - 1 of them are kept in flight ahead of the one being multiplied
     const int ntw = ((int)blockIdx.x < p.total_tiles) ? (p.total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
     const int n_w = (wave < p.nA ? (p.nA - wave + 7) >> 3 : 0) + (wave < p.nB ? (p.nB - wave + 7) >> 3 : 0);     // this wave's copies per tile
-    for (int j = 0; j < p.nbuf - 1 && j < ntw; ++j) issue(blockIdx.x + j * gridDim.x, j * p.bufb);
+    if constexpr (DIRECT) {
+        for (int i = tid; i < p.N * 2 * p.PL * 16; i += 512) {
+            const int n = i / (2 * p.PL * 16), r = i - n * 2 * p.PL * 16, sf = r >= p.PL * 16 ? 1 : 0, c = r - sf * p.PL * 16;
+            const float* src = sf ? p.in_shift : p.in_scale;
+            scs[i] = src ? src[n * p.Cin + cib * p.PL * 16 + c] : (sf ? 0.f : 1.f);
+        }
+        for (int j = 0; j < p.nbuf - 1 && j < ntw; ++j) {
+            build_tab(blockIdx.x + j * gridDim.x, j & 1);
+            __syncthreads();
+            issue(blockIdx.x + j * gridDim.x, j * p.bufb, j & 1);
+        }
+    } else {
+        for (int j = 0; j < p.nbuf - 1 && j < ntw; ++j) issue(blockIdx.x + j * gridDim.x, j * p.bufb, 0);
+    }
 
     // ---- table: tap offsets inside the halo image ----
     if (tid < p.ntaps)
@@ -277,10 +350,39 @@ __global__ __launch_bounds__(512, 2) void wgrad_dma_kernel(const WgdK p) {
         char* hb = smem + cur * p.bufb;
         if (stamp) t_a = __builtin_readcyclecounter();
         const int newer = min(p.nbuf - 2, ntw - 1 - it);         // tiles requested after this one
+        const int itn = it + p.nbuf - 1;                         // the tile requested in this iteration
+        if constexpr (DIRECT) { if (itn < ntw) build_tab(blockIdx.x + itn * gridDim.x, itn & 1); }
         wait_vmcnt(newer * n_w);                             // this wave's share of the tile has landed ...
+        if constexpr (DIRECT) {
+            // ... and is transformed where it lies: P = act(x * scale + shift), rounded to bf16 exactly as materialize_kernel does
+            const int n_cur = fast_div((int)blockIdx.x + it * (int)gridDim.x, p.m_tpn);
+            const float* sc0 = scs + n_cur * 2 * p.PL * 16 + (lane & 1) * 8;
+#pragma unroll
+            for (int k = 0; k < VG_WD_MAXA; ++k) {
+                const int piece = wave + 8 * k;
+                if (piece < p.nA) {
+                    const int pl = fast_div(piece, p.m_imgp);
+                    bf16x8* u = (bf16x8*)(hb + piece * 1024 + lane * 16);
+                    const f32x4 s0 = *(const f32x4*)(sc0 + pl * 16), s1 = *(const f32x4*)(sc0 + pl * 16 + 4);
+                    const f32x4 f0 = *(const f32x4*)(sc0 + (p.PL + pl) * 16), f1 = *(const f32x4*)(sc0 + (p.PL + pl) * 16 + 4);
+                    const bf16x8 raw = *u;
+                    bf16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float a = bf2f((bf16_t)raw[e]) * s0[e] + f0[e], b = bf2f((bf16_t)raw[4 + e]) * s1[e] + f1[e];
+                        a = fmaxf(a, a * p.slope); b = fmaxf(b, b * p.slope);
+                        o[e] = (short)f2bf(a); o[4 + e] = (short)f2bf(b);
+                    }
+                    *u = o;
+                    // (Spreading the NEXT tile's transform over the K-steps of the current one -- its copies landed a tile ago with three
+                    // buffers -- was measured slower, 98 vs 89 us on the 16->16 layers: LDS returns in order, so waiting for the
+                    // transform's read drains the K loop's prefetched fragments.)
+                }
+            }
+        }
         __syncthreads();                                     // ... everybody's has; and the buffer multiplied last is no longer being read
         if (stamp) { const unsigned long long t = __builtin_readcyclecounter(); s_wait += t - t_a; t_a = t; }
-        if (it + p.nbuf - 1 < ntw) issue(blockIdx.x + (it + p.nbuf - 1) * gridDim.x, nxt * p.bufb);
+        if (itn < ntw) issue(blockIdx.x + itn * gridDim.x, nxt * p.bufb, itn & 1);
         if (stamp) { const unsigned long long t = __builtin_readcyclecounter(); s_issue += t - t_a; t_a = t; }
         cur = cur + 1 == p.nbuf ? 0 : cur + 1; nxt = nxt + 1 == p.nbuf ? 0 : nxt + 1;
         const char* yb = hb + p.nA * 1024;
@@ -379,14 +481,18 @@ __global__ __launch_bounds__(512, 2) void wgrad_dma_kernel(const WgdK p) {
     }
 }
 
-template <int R, int Q>
-static void launch_wd(const WgdK& k, dim3 grid, int lds, hipStream_t s) {
+template <int R, int Q, bool DIRECT>
+static void launch_wd2(const WgdK& k, dim3 grid, int lds, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)wgrad_dma_kernel<R, Q>, hipFuncAttributeMaxDynamicSharedMemorySize, VG_LDS_LIMIT);
+        (void)hipFuncSetAttribute((const void*)wgrad_dma_kernel<R, Q, DIRECT>, hipFuncAttributeMaxDynamicSharedMemorySize, VG_LDS_LIMIT);
         attr_set = true;
     }
-    hipLaunchKernelGGL((wgrad_dma_kernel<R, Q>), grid, dim3(512), lds, s, k);
+    hipLaunchKernelGGL((wgrad_dma_kernel<R, Q, DIRECT>), grid, dim3(512), lds, s, k);
+}
+template <int R, int Q>
+static void launch_wd(const WgdK& k, bool direct, dim3 grid, int lds, hipStream_t s) {
+    if (direct) launch_wd2<R, Q, true>(k, grid, lds, s); else launch_wd2<R, Q, false>(k, grid, lds, s);
 }
 
 // Serve vg_conv3d_wgrad through the materialised-operand path.  Returns VG_OK when served, 1 when the call is not one of its
@@ -415,7 +521,11 @@ int vg_wgrad_dma(const vg_conv_desc* d, const void* dy, int dy_f32, const int32_
     const int Dp = (d->OD - 1) * d->istr + ex[0], Hp = (d->OH - 1) * d->istr + ex[1], Wp = (d->OW - 1) * d->istr + ex[2];
     const int WE = (Wp + 1) / 2, Wps = deint ? 2 * WE : Wp;
     const int64_t plane_bytes = (int64_t)Dp * Hp * Wps * 32;
-    const int64_t p_bytes = ((plane_bytes * NPL * d->N + 255) / 256) * 256;
+    // thin reflect-padded noise-free layers: no operand pass, the kernel copies the stored tensors (wgrad_dma_kernel<.., DIRECT>)
+    const bool direct = vg_tune("WGRAD_DMA_DIRECT", 1) && d->pad_mode == VG_PAD_REFLECT && !d->noise && Cin <= vg_tune("WGRAD_DMA_DIRECT_CIN", 48)
+                        && (d->c_src1 == 0 || (d->c_src0 % 16) == 0) && (!d->src0_shift || (!(d->D & 1) && !(d->H & 1) && !(d->W & 1)))
+                        && (int64_t)d->D * d->H * d->W * (d->c_src0 > d->c_src1 ? d->c_src0 : d->c_src1) * 2 < (1LL << 31);
+    const int64_t p_bytes = direct ? 0 : ((plane_bytes * NPL * d->N + 255) / 256) * 256;
     if (p_bytes >= (1LL << 31)) return 1;
     const int64_t dw_elems = (int64_t)T_total * Cin * d->Cout;
     // ---- plan: column block CO (16 * Q channels), planes per workgroup PL, tile, K split bx.  Every candidate (CO, PL) with an
@@ -457,7 +567,8 @@ int vg_wgrad_dma(const vg_conv_desc* d, const void* dy, int dy_f32, const int32_
                         const int imgp = (HD * HH * HW * 32 + 1023) / 1024;
                         const int nA = PL * imgp, nB = bm * CO * 2 / 1024;
                         if (nA > 8 * VG_WD_MAXA || nB > 8 * VG_WD_MAXB || nB < 1) continue;
-                        const int tabs = VG_MAX_TAPS * 4;
+                        if (direct && (HD + HH + HW > VG_WD_TAB || d->N * PL > 16)) continue;
+                        const int tabs = VG_MAX_TAPS * 4 + (direct ? 4 * VG_WD_TAB * 4 + d->N * 2 * PL * 16 * 4 : 0);
                         if (2 * (nA + nB) * 1024 + tabs > lds_cap) continue;
                         int nb_ = (lds_cap - tabs) / ((nA + nB) * 1024); if (nb_ > nbuf_cap) nb_ = nbuf_cap; if (nb_ < 2) nb_ = 2;
                         const int lds = nb_ * (nA + nB) * 1024 + tabs;
@@ -521,7 +632,13 @@ int vg_wgrad_dma(const vg_conv_desc* d, const void* dy, int dy_f32, const int32_
     const int bx = best.bx;
     k.P = (const char*)scratch; k.dy = (const char*)dy;
     k.part = bx > 1 ? (float*)((char*)scratch + p_bytes) : nullptr;
-    if (vg_dry("wgrad_dma<%d,%d>|bm%d|pl%d|s%d|nb%d|part%d|walk%d", Rsel, Q, BM, PL, d->istr, k.nbuf, k.part ? 1 : 0, k.total_tiles > bx ? 1 : 0)) return VG_OK;
+    k.x0 = (const char*)d->src0; k.x1 = (const char*)d->src1; k.c0 = d->c_src0; k.c1 = d->c_src1; k.sh0 = d->src0_shift ? 1 : 0;
+    k.D = d->D; k.H = d->H; k.W = d->W; k.pmin_d = mn[0]; k.pmin_h = mn[1]; k.pmin_w = mn[2];
+    k.in_scale = d->in_scale; k.in_shift = d->in_shift;
+    k.slope = d->act == VG_ACT_RELU ? 0.f : (d->act == VG_ACT_LRELU ? VG_LRELU : 1.f);
+    if (vg_dry("wgrad_dma<%d,%d>|bm%d|pl%d|s%d|nb%d|part%d|walk%d|dir%d", Rsel, Q, BM, PL, d->istr, k.nbuf, k.part ? 1 : 0, k.total_tiles > bx ? 1 : 0, direct ? 1 : 0)) return VG_OK;
+    const dim3 grid(bx, columns, 1);
+    if (!direct) {
     MatK m;
     m.src0 = d->src0; m.src1 = d->src1; m.c0 = d->c_src0; m.c1 = d->c_src1; m.shift0 = d->src0_shift ? 1 : 0;
     m.N = d->N; m.D = d->D; m.H = d->H; m.W = d->W; m.Cin = Cin;
@@ -530,10 +647,10 @@ int vg_wgrad_dma(const vg_conv_desc* d, const void* dy, int dy_f32, const int32_
     m.pmin_d = mn[0]; m.pmin_h = mn[1]; m.pmin_w = mn[2]; m.Dp = Dp; m.Hp = Hp; m.Wp = Wp;
     m.deint = deint; m.WE = WE; m.Wps = Wps; m.out = (bf16_t*)scratch;
     hipLaunchKernelGGL(materialize_kernel, dim3(d->N * Dp * Hp), dim3(256), 0, s, m);
-    const dim3 grid(bx, columns, 1);
-    if (Q == 4) launch_wd<8, 4>(k, grid, lds, s);
-    else if (Q == 2) { if (Rsel == 4) launch_wd<4, 2>(k, grid, lds, s); else launch_wd<8, 2>(k, grid, lds, s); }
-    else { if (Rsel == 4) launch_wd<4, 1>(k, grid, lds, s); else if (Rsel == 8) launch_wd<8, 1>(k, grid, lds, s); else launch_wd<12, 1>(k, grid, lds, s); }
+    }
+    if (Q == 4) launch_wd<8, 4>(k, direct, grid, lds, s);
+    else if (Q == 2) { if (Rsel == 4) launch_wd<4, 2>(k, direct, grid, lds, s); else launch_wd<8, 2>(k, direct, grid, lds, s); }
+    else { if (Rsel == 4) launch_wd<4, 1>(k, direct, grid, lds, s); else if (Rsel == 8) launch_wd<8, 1>(k, direct, grid, lds, s); else launch_wd<12, 1>(k, direct, grid, lds, s); }
     if (k.part) vg_launch_reduce_partials(k.part, bx, k.dw_elems, dw, s);
     return vg_check_launch();
 }
