@@ -50,8 +50,10 @@ def variant_of(kernel_name: str):
         return 'pw_gemm<%s,%s,g%s,a%s>' % (args[0], args[1], b(args[2]), b(args[3]))
     if k == 'conv32' and len(args) == 4:
         return 'conv32<%s,%s,n%s,cp%s>' % (args[0], args[1], b(args[2]), b(args[3]))
-    if k == 'wgrad_dma' and len(args) == 2:
-        return 'wgrad_dma<%s,%s>' % (args[0], args[1])
+    if k == 'wgrad_dma' and len(args) == 3:
+        return 'wgrad_dma<%s,%s,d%s>' % (args[0], args[1], b(args[2]))
+    if k == 'wgrad_pw_dma' and len(args) == 2:
+        return 'wgrad_pw_dma<%s,%s>' % (args[0], args[1])
     if k == 'wgrad' and len(args) == 4:
         return 'wgrad<%s,%s,%s,n%s>' % (tname(args[0]), args[1], args[2], b(args[3]))
     if k in ('pw_cto1', 'pw_ctoc') and len(args) == 2:

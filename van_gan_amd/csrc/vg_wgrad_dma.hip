@@ -636,7 +636,7 @@ int vg_wgrad_dma(const vg_conv_desc* d, const void* dy, int dy_f32, const int32_
     k.D = d->D; k.H = d->H; k.W = d->W; k.pmin_d = mn[0]; k.pmin_h = mn[1]; k.pmin_w = mn[2];
     k.in_scale = d->in_scale; k.in_shift = d->in_shift;
     k.slope = d->act == VG_ACT_RELU ? 0.f : (d->act == VG_ACT_LRELU ? VG_LRELU : 1.f);
-    if (vg_dry("wgrad_dma<%d,%d>|bm%d|pl%d|s%d|nb%d|part%d|walk%d|dir%d", Rsel, Q, BM, PL, d->istr, k.nbuf, k.part ? 1 : 0, k.total_tiles > bx ? 1 : 0, direct ? 1 : 0)) return VG_OK;
+    if (vg_dry("wgrad_dma<%d,%d,d%d>|bm%d|pl%d|s%d|nb%d|part%d|walk%d", Rsel, Q, direct ? 1 : 0, BM, PL, d->istr, k.nbuf, k.part ? 1 : 0, k.total_tiles > bx ? 1 : 0)) return VG_OK;
     const dim3 grid(bx, columns, 1);
     if (!direct) {
     MatK m;
