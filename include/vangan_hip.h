@@ -226,6 +226,14 @@ int vg_in_param_grads(const float* red, int N, int C, float* dgamma, float* dbet
 int vg_concat_bwd(const void* g, int N, int D, int H, int W, int Cu, int Cs, void* dlow, void* dskip,
                   int f32, int accumulate, vg_stream_t stream);
 
+/* The data gradient of a decoder block's 1x1x1 shortcut convolution (resunet_model.py:126-131 over the concat of :175-181) FUSED with
+ * vg_concat_bwd: d is the descriptor of the accumulating data-gradient launch (src0 = gradient of the shortcut's output, out = the
+ * gradient of the virtual concat [N][D][H][W][c_low + Cs] holding the convolution branch's part; it is only READ); the sums go to
+ * dskip / (over every 2x2x2 block) dlow with vg_concat_bwd's accumulate bits -- the concat gradient is neither rewritten nor re-read
+ * (804 -> 486 MB per application at 128^3).  Returns VG_OK when launched, 1 when the shape is not served (the caller then runs
+ * vg_conv3d(d) + vg_concat_bwd), < 0 on error. */
+int vg_shortcut_dgrad_concat(const vg_conv_desc* d, void* dlow, void* dskip, int c_low, int accumulate, vg_stream_t stream);
+
 /* d_pre = dy * (1 - y*y)   (tanh output activation, resunet_model.py:245), all fp32 */
 int vg_tanh_bwd(const float* dy, const float* y, float* dpre, int64_t n, vg_stream_t stream);
 

@@ -455,3 +455,50 @@ def test_table_repack_equals_per_layer_pack(net):
             assert torch.equal(it[2], a), l.name
             n += 1
     assert n >= (30 if net == 'gen' else 5)
+
+
+@pytest.mark.parametrize('c_low,c_skip,cout,dims', [(32, 16, 16, (16, 16, 32)), (64, 32, 32, (8, 16, 16)), (64, 32, 64, (8, 8, 16)),
+                                                    (32, 16, 16, (6, 10, 12))])
+@pytest.mark.parametrize('acc_low,acc_skip', [(False, False), (True, True), (True, False)])
+def test_shortcut_dgrad_concat_fused(c_low, c_skip, cout, dims, acc_low, acc_skip):
+    """vg_shortcut_dgrad_concat (the decoder shortcut's data gradient + the backward of UpSampling3D + concatenate in one launch,
+    resunet_model.py:126-131,175-181) against float64 on the same bf16 operands: dskip (+)= (dcat + dy W^T)[..., c_low:],
+    dlow (+)= sum over every 2x2x2 block of (dcat + dy W^T)[..., :c_low]; and dcat itself must stay untouched."""
+    from van_gan_amd import ops
+    dev = _dev()
+    N, cin = 2, c_low + c_skip
+    st, lay = make_layer(1, cin, cout, 1, 'same', dims, bias=True, seed=3)
+    g = torch.Generator().manual_seed(11)
+    D, H, W = dims
+    dy = torch.randn(N, D, H, W, cout, generator=g).to(torch.bfloat16)
+    dcat = torch.randn(N, D, H, W, cin, generator=g).to(torch.bfloat16)
+    dlow0 = torch.randn(N, D // 2, H // 2, W // 2, c_low, generator=g).to(torch.bfloat16)
+    dskip0 = torch.randn(N, D, H, W, c_skip, generator=g).to(torch.bfloat16)
+    dcat_d, dlow, dskip = dcat.to(dev), dlow0.to(dev).clone(), dskip0.to(dev).clone()
+    assert ops.FUSE_CONCAT
+    lay.dgrad_concat(dy.to(dev), N, dcat_d, c_low, dlow, dskip, acc_low=acc_low, acc_skip=acc_skip)
+    torch.cuda.synchronize()
+    assert torch.equal(dcat_d.cpu(), dcat), 'the concat gradient is read-only in the fused launch'
+    w = bf(st.param('c.w').cpu()).view(cin, cout)
+    full = dcat.double() + dy.double() @ w.t()
+    low = full[..., :c_low].view(N, D // 2, 2, H // 2, 2, W // 2, 2, c_low).sum(dim=(2, 4, 6))
+    skip = full[..., c_low:]
+    if acc_low:
+        low = low + dlow0.double()
+    if acc_skip:
+        skip = skip + dskip0.double()
+    close_bf16(dlow, low, 'dlow')
+    close_bf16(dskip, skip, 'dskip')
+    # and the two-step path it replaces gives the same within the bf16 rounding of the intermediate
+    os.environ['VG_PW_SPLIT'] = '0'
+    from van_gan_amd import _lib
+    _lib.lib.vg_set_tuning(b'PW_SPLIT', 0, 0)
+    try:
+        dcat2, dlow2, dskip2 = dcat.to(dev), dlow0.to(dev).clone(), dskip0.to(dev).clone()
+        lay.dgrad_concat(dy.to(dev), N, dcat2, c_low, dlow2, dskip2, acc_low=acc_low, acc_skip=acc_skip)
+        torch.cuda.synchronize()
+    finally:
+        _lib.lib.vg_set_tuning(b'PW_SPLIT', 0, 1)
+        del os.environ['VG_PW_SPLIT']
+    assert not torch.equal(dcat2.cpu(), dcat)            # the fallback did accumulate into the concat gradient
+    assert rel_l2(dlow2, low) < 1e-2 and rel_l2(dskip2, skip) < 1e-2

@@ -46,7 +46,9 @@ def variant_of(kernel_name: str):
         return 'conv<%s,%s,%s,n%s,wl%s,dma%s,mc%s,c1%s>' % (tname(args[0]), args[1], args[2], b(args[3]), b(args[4]), b(args[5]), args[6], b(args[7]))
     if k == 'conv_thin' and len(args) >= 4:
         return 'conv_thin<m%s,b%s,r%s,s%s%s>' % (args[0], b(args[1]), b(args[2]), b(args[3]), ',bs' if len(args) > 4 and b(args[4]) == '1' else '')
-    if k == 'pw_gemm' and len(args) == 5:
+    if k == 'pw_gemm' and len(args) == 6 and args[5] == 'true':
+        return 'pw_gemm_split<%s,%s>' % (args[0], args[1])
+    if k == 'pw_gemm' and len(args) in (5, 6):
         return 'pw_gemm<%s,%s,g%s,a%s>' % (args[0], args[1], b(args[2]), b(args[3]))
     if k == 'conv32' and len(args) == 4:
         return 'conv32<%s,%s,n%s,cp%s>' % (args[0], args[1], b(args[2]), b(args[3]))

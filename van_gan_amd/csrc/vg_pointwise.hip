@@ -221,6 +221,10 @@ struct PWG {
     int BD, BH, BW, ostr, od0, oh0, ow0;
     int Cout; int SO;
     unsigned long long* stamps;          // diagnostic (vg_set_stamp_buffer): s_memrealtime at wave start / end, else NULL
+    // SPLIT (data gradient of a decoder shortcut, fused with the backward of UpSampling3D + concatenate): `out` is only READ (the
+    // gradient of the virtual concat left there by the conv branch); the sum goes to dskip (channels >= sc0, per voxel) and, summed
+    // over every 2x2x2 block, to dlow (channels < sc0, half resolution).  acc bit 0: dlow accumulates, bit 1: dskip accumulates.
+    bf16_t* dlow; bf16_t* dskip; int sc0, sacc;
 };
 }
 extern unsigned long long* g_vg_stamps;
@@ -229,8 +233,9 @@ typedef __attribute__((ext_vector_type(2))) float pw_f32x2;
 typedef __attribute__((ext_vector_type(2))) unsigned pw_u32x2;
 typedef __attribute__((ext_vector_type(4))) unsigned pw_u32x4;
 
-template <int KS, int NB, bool GEO, bool ACC, bool STATS>
+template <int KS, int NB, bool GEO, bool ACC, bool STATS, bool SPLIT = false>
 __global__ __launch_bounds__(256) void pw_gemm_kernel(const PWG p) {
+    static_assert(!SPLIT || (ACC && !GEO && !STATS), "SPLIT: accumulating, same-grid launches");
     constexpr int MS = (KS * NB <= 2) ? 4 : 2;
     __shared__ float stat[NB * 32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, kg = lane >> 4;
@@ -268,6 +273,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const PWG p) {
         bf16x8 xb[MS][KS];
         bool vok[MS], oks[MS / 2];
         size_t i0s[MS], i1s[MS], ovs[MS / 2];           // ovs / oks: the sub-tile this lane STORES of each pair (jp + jodd)
+        size_t ovf[MS / 2];                             // SPLIT: its voxel index (sample included)
 #pragma unroll
         for (int jp = 0; jp < MS; jp += 2) {
             size_t ovp[2];
@@ -283,10 +289,19 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const PWG p) {
                     i0s[i] = (((size_t)n * ID2 + (id >> p.sh)) * IH2 + (ih >> p.sh)) * IW2 + (iw >> p.sh);
                     i1s[i] = (((size_t)n * p.ID + id) * p.IH + ih) * p.IW + iw;
                     ovp[e] = (((size_t)n * p.BD + od * p.ostr + p.od0) * p.BH + oh * p.ostr + p.oh0) * p.BW + ow * p.ostr + p.ow0;
+                } else if (SPLIT) {
+                    // voxels enumerated block-major: 8 consecutive indices are one 2x2x2 block, so that the 16 voxels of a sub-tile
+                    // are two whole blocks and the pooling is a reduction over 8 neighbouring lanes
+                    const int cb = vc >> 3, j = vc & 7;
+                    const int CW = p.OW >> 1, CHW = (p.OH >> 1) * CW;
+                    const int cd = cb / CHW, rem = cb - cd * CHW, ch = rem / CW, cw = rem - ch * CW;
+                    const int vf = ((2 * cd + (j >> 2)) * p.OH + 2 * ch + ((j >> 1) & 1)) * p.OW + 2 * cw + (j & 1);
+                    i0s[i] = i1s[i] = ovp[e] = (size_t)n * p.SO + vf;
                 } else {
                     i0s[i] = i1s[i] = ovp[e] = (size_t)n * p.SO + vc;
                 }
             }
+            ovf[jp >> 1] = jodd ? ovp[1] : ovp[0];
             ovs[jp >> 1] = (jodd ? ovp[1] : ovp[0]) * p.Cout + chof;
             oks[jp >> 1] = jodd ? vok[jp + 1] : vok[jp];
         }
@@ -347,6 +362,29 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const PWG p) {
                     }
                     // the bias of the received half belongs to the neighbouring row's channels: e_b was added before the swap
                     float q[8]; raw_unpack(oldv[ACC ? jp >> 1 : 0][ACC ? nb : 0], q);
+                    if (SPLIT) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) o[i] += q[i];
+                        if (nb * 16 < p.sc0) {
+                            // low-resolution source: sum over the 2x2x2 block = lanes r, r^1, r^2, r^4 of the 16-lane row
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) {
+                                o[i] += __shfl_xor(o[i], 1); o[i] += __shfl_xor(o[i], 2); o[i] += __shfl_xor(o[i], 4);
+                            }
+                            if (ok && (r & 7) == 0) {
+                                const int sub = jp + jodd;
+                                const size_t cidx = (size_t)n * (p.SO >> 3) + (size_t)wt * (MS * 2) + sub * 2 + (r >> 3);
+                                bf16_t* dst = p.dlow + cidx * p.sc0 + nb * 16 + chof;
+                                if (p.sacc & 1) { float old[8]; load8<bf16_t>(dst, old); for (int i = 0; i < 8; ++i) o[i] += old[i]; }
+                                store8<bf16_t>(dst, o);
+                            }
+                        } else if (ok) {
+                            bf16_t* dst = p.dskip + ovf[jp >> 1] * (p.Cout - p.sc0) + (nb * 16 - p.sc0) + chof;
+                            if (p.sacc & 2) { float old[8]; load8<bf16_t>(dst, old); for (int i = 0; i < 8; ++i) o[i] += old[i]; }
+                            store8<bf16_t>(dst, o);
+                        }
+                        continue;
+                    }
                     bf16x8 pk;
 #pragma unroll
                     for (int i = 0; i < 8; ++i) pk[i] = (short)f2bf(o[i] + q[i]);
@@ -796,6 +834,12 @@ bool pwg_launch(int KS, int NB, dim3 grid, hipStream_t s, const PWG& p) {
 #undef PWG_CASE
     return false;
 }
+bool pwg_launch_split(int KS, int NB, dim3 grid, hipStream_t s, const PWG& p) {
+#define PWG_CASE(ks, nb) if (KS == ks && NB == nb) { hipLaunchKernelGGL((pw_gemm_kernel<ks, nb, false, true, false, true>), grid, dim3(256), 0, s, p); return true; }
+    PWG_CASE(1, 3) PWG_CASE(1, 6) PWG_CASE(2, 6)
+#undef PWG_CASE
+    return false;
+}
 bool pwg_case_ok(int KS, int NB) {
     static const int tab[][2] = {{1, 1}, {1, 2}, {1, 3}, {1, 4}, {1, 6}, {2, 1}, {2, 2}, {3, 2}, {4, 4}, {6, 4}, {2, 8}};
     for (auto& t : tab) if (t[0] == KS && t[1] == NB) return true;
@@ -840,6 +884,40 @@ int pw_gemm_conv(const vg_conv_desc* d, hipStream_t s) {
     return ok ? vg_check_launch() : 1;
 }
 
+// Data gradient of a decoder shortcut fused with the backward of UpSampling3D + concatenate: d describes the accumulating launch
+// (src0 = gradient of the shortcut's output, out = gradient of the virtual concat with the conv branch's part already in it);
+// instead of adding into `out` and leaving the split / 2x2x2 sum to vg_concat_bwd, the sums go to dskip / dlow directly.
+int pw_gemm_split(const vg_conv_desc* d, void* dlow, void* dskip, int c_low, int acc, hipStream_t s) {
+    if (!pw_enabled() || !vg_tune("PW_GEMM", 1) || !vg_tune("PW_SPLIT", 1)) return 1;
+    if (d->ntaps != 1 || d->tap_d[0] || d->tap_h[0] || d->tap_w[0] || d->noise || d->wpack || d->nclass > 1) return 1;
+    if (d->f32 || d->src_f32 || d->out_f32 || d->in_scale || d->act != VG_ACT_NONE || d->res || d->tanh_out || d->out_sums || d->bias) return 1;
+    const int Cin = d->c_src0;
+    if (d->c_src1 || d->src0_shift || Cin < 8 || (Cin % 8) || d->Cout < 32 || (d->Cout % 16) || (d->CK % 8) || !d->accumulate) return 1;
+    if (c_low < 16 || (c_low % 16) || c_low >= d->Cout) return 1;
+    if (d->istr != 1 || d->ostr != 1 || d->ooff_d || d->ooff_h || d->ooff_w || d->BD != d->OD || d->BH != d->OH || d->BW != d->OW
+        || d->OD != d->D || d->OH != d->H || d->OW != d->W || ((d->D | d->H | d->W) & 1)) return 1;
+    const int64_t SO = (int64_t)d->OD * d->OH * d->OW;
+    if (SO < 8 || SO > (1 << 30)) return 1;
+    const int KS = (Cin + 31) / 32, NB = d->Cout / 16;
+    if (!((KS == 1 && (NB == 3 || NB == 6)) || (KS == 2 && NB == 6))) return 1;
+    PWG p = {};
+    p.x0 = (const bf16_t*)d->src0; p.x1 = p.x0; p.c0 = Cin; p.c1 = 1; p.Cin = Cin; p.sh = 0;
+    p.w = (const bf16_t*)d->wpacked; p.CK = d->CK; p.kc_pad = ((d->CK + 31) / 32) * 32; p.Ktot = ((Cin + d->CK - 1) / d->CK) * p.kc_pad;
+    p.bias = nullptr; p.out = (bf16_t*)d->out; p.sums = nullptr;
+    p.N = d->N; p.ID = d->D; p.IH = d->H; p.IW = d->W; p.OD = d->OD; p.OH = d->OH; p.OW = d->OW; p.istr = 1;
+    p.BD = d->BD; p.BH = d->BH; p.BW = d->BW; p.ostr = 1;
+    p.Cout = d->Cout; p.SO = (int)SO; p.stamps = g_vg_stamps;
+    p.dlow = (bf16_t*)dlow; p.dskip = (bf16_t*)dskip; p.sc0 = c_low; p.sacc = acc;
+    const int MS = (KS * NB <= 2) ? 4 : 2;
+    const int64_t nwt = (SO + MS * 16 - 1) / (MS * 16);
+    int64_t b = (nwt + 3) / 4;
+    const int capt = vg_tune("PW_GEMM_CAP", 2047);
+    const int64_t cap = (capt / d->N) > 0 ? (capt / d->N) : 1;
+    if (b > cap) b = cap;
+    if (vg_dry("pw_gemm_split<%d,%d>", KS, NB)) return VG_OK;
+    return pwg_launch_split(KS, NB, dim3((int)b, d->N), s, p) ? vg_check_launch() : 1;
+}
+
 int pw_wgrad_cc(const vg_conv_desc* d, const void* dy, int dy_f32, int T_total, float* dw, float* db, float* scratch,
                 int64_t scratch_bytes, hipStream_t s) {
     if (!pw_enabled() || !vg_tune("PW_WGRAD_CC", 1)) return 1;
@@ -877,6 +955,12 @@ int pw_wgrad_cc(const vg_conv_desc* d, const void* dy, int dy_f32, int T_total, 
 }
 
 }  // namespace
+
+extern "C" int vg_shortcut_dgrad_concat(const vg_conv_desc* d, void* dlow, void* dskip, int c_low, int accumulate, vg_stream_t stream) {
+    vg_begin();
+    if (!d || !d->src0 || !d->out || !d->wpacked || !dlow || !dskip) return VG_EINVAL;
+    return pw_gemm_split(d, dlow, dskip, c_low, accumulate, (hipStream_t)stream);
+}
 
 // returns VG_OK when the launch was done here, 1 when the shape is not one of the pointwise cases (caller continues), < 0 on error
 int vg_pointwise_conv(const vg_conv_desc* d, hipStream_t s) {

@@ -362,9 +362,7 @@ class ResUNet:
             low, skip = inp
             dcat = ar.alloc((N,) + tuple(cb1.in_dims) + (s1.C,), self.dtype)
             self._dgrad_norm_bwd(ar, cb1, d_r, N, dp1, s1, c['n1'], Nn[name + '.cb1'], dcat, ACT_RELU, accumulate=False)
-            short.dgrad(d_sc, N, dcat, accumulate=True)
-            ops.concat_bwd(dcat, (N,) + tuple(cb1.in_dims), low.C, skip.C, low.grad, skip.grad,
-                           acc_low=not low.first_write(), acc_skip=not skip.first_write())
+            short.dgrad_concat(d_sc, N, dcat, low.C, low.grad, skip.grad, acc_low=not low.first_write(), acc_skip=not skip.first_write())
         ar.release(mk, defer=True)
 
     def backward(self, ar: Arena, ctx: dict, gy: torch.Tensor, inline_from: int = -1):

@@ -192,6 +192,7 @@ PROF: Optional[KernelProfile] = None
 WGRAD_INLINE = False        # set by ResUNet.backward for the tail of a lane's last sweep
 LAZY_RELEASE = os.environ.get('VG_LAZY_RELEASE', '1') != '0'
 FORK_SHORT = os.environ.get('VG_FORK_SHORT', '1') != '0'   # forward shortcut branches on the lane's side stream
+FUSE_CONCAT = os.environ.get('VG_FUSE_CONCAT', '1') != '0'       # decoder shortcut data gradient + concat backward in one launch (ConvLayer.dgrad_concat)
 BSTAT = os.environ.get('VG_BSTAT', '1') != '0'       # IN-backward statistics with the data-gradient launch (ConvLayer.dgrad(bstat=...))
 SIDE: Optional[bool] = None                   # truthy: weight-gradient side streams enabled (one per issuing stream)
 _SIDE_OF = {}                                  # (device index, issuing stream handle) -> its side stream.  The default stream
@@ -688,6 +689,44 @@ class ConvLayer:
                          N * (4 if self.f32 else 2) * (math.prod(self.out_dims) * self.cout * len(c['taps']) / self.k ** 3
                                                        + math.prod(c['iters']) * self.cin), conv_variant(d), self.name)
         return use_bs
+
+
+    def dgrad_concat(self, dy: torch.Tensor, N: int, dcat: torch.Tensor, c_low: int, dlow: torch.Tensor, dskip: torch.Tensor,
+                     acc_low: bool, acc_skip: bool):
+        """Decoder shortcut (1x1x1, stride 1): the data gradient added to the concat gradient `dcat` (which already holds the conv
+        branch's part) and the backward of UpSampling3D + concatenate in one launch (vg_shortcut_dgrad_concat): the sums are written
+        to dlow / dskip, dcat is only read.  Falls back to dgrad(accumulate) + concat_bwd where the fused kernel does not serve the
+        shape (and in the dry-run / per-launch timing passes, which enumerate the convolution calls)."""
+        fused = (FUSE_CONCAT and DRY is None and not self.f32 and self.k == 1 and self.stride == 1 and len(self.d_classes) == 1
+                 and not self.d_fused and dcat.dtype == torch.bfloat16)
+        if fused:
+            c = self.d_classes[0]
+            d = ConvDesc()
+            d.src1 = None
+            d.c_src0, d.c_src1, d.src0_shift = self.cout, 0, 0
+            d.D, d.H, d.W = self.out_dims
+            d.act, d.istr, d.pad_mode = ACT_NONE, 1, PAD_ZERO
+            _set_taps(d, c['taps'])
+            d.OD, d.OH, d.OW = c['iters']
+            d.ostr = self.stride
+            d.ooff_d, d.ooff_h, d.ooff_w = c['off']
+            d.BD, d.BH, d.BW = self.buf_dims
+            d.Cout, d.wpacked, d.CK = self.cin, _p(c['wp']), c['ck']
+            d.f32 = self.f32
+            d.src0, d.N = _p(dy), N
+            d.out, d.out_f32, d.accumulate = _p(dcat), 0, 1
+            e0 = PROF.begin() if PROF is not None else None
+            rc = lib.vg_shortcut_dgrad_concat(C.byref(d), _p(dlow), _p(dskip), c_low, int(bool(acc_low)) | (int(bool(acc_skip)) << 1), stream())
+            if rc == 0:
+                if e0 is not None:
+                    PROF.end('conv_dgrad', 2.0 * N * math.prod(c['iters']) * self.cin * self.cout, e0,
+                             N * 2 * (math.prod(self.out_dims) * self.cout + math.prod(self.buf_dims) * self.cin),
+                             'pw_gemm_split<%d,%d>' % ((self.cout + 31) // 32, self.cin // 16), self.name)
+                return
+            if rc < 0:
+                check(rc, 'vg_shortcut_dgrad_concat ' + self.name)
+        self.dgrad(dy, N, dcat, accumulate=True)
+        concat_bwd(dcat, (N,) + tuple(self.in_dims), c_low, self.cin - c_low, dlow, dskip, acc_low=acc_low, acc_skip=acc_skip)
 
 
 class PackTable:
