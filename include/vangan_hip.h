@@ -233,6 +233,14 @@ int vg_concat_bwd(const void* g, int N, int D, int H, int W, int Cu, int Cs, voi
  * (804 -> 486 MB per application at 128^3).  Returns VG_OK when launched, 1 when the shape is not served (the caller then runs
  * vg_conv3d(d) + vg_concat_bwd), < 0 on error. */
 int vg_shortcut_dgrad_concat(const vg_conv_desc* d, void* dlow, void* dskip, int c_low, int accumulate, vg_stream_t stream);
+/* The same with the block's first convolution branch folded in: the concat gradient is never stored.  b describes the (InstanceNorm ->
+ * act) backward of that convolution's input (g = its data gradient on the reflection-padded grid, x / x1 = the virtual concat's
+ * sources, statistics already in b->red: vg_actnorm_bwd_stats or the data-gradient epilogue); the launch computes
+ * dx = gamma * rstd * (dn - mean(dn) - xhat * mean(dn * xhat)) per voxel where vg_actnorm_bwd_apply would have written it, adds the
+ * shortcut's data gradient, and writes dskip / dlow as above; d->out is not used; b->dgamma / b->dbeta are added as the apply pass does.
+ * 838 -> 436 MB per application at 128^3.  Returns 1 when the shape is not served (caller: vg_actnorm_bwd_apply + the call above). */
+int vg_shortcut_dgrad_concat_norm(const vg_conv_desc* d, const vg_actnorm_bwd_desc* b, void* dlow, void* dskip, int c_low,
+                                  int accumulate, vg_stream_t stream);
 
 /* d_pre = dy * (1 - y*y)   (tanh output activation, resunet_model.py:245), all fp32 */
 int vg_tanh_bwd(const float* dy, const float* y, float* dpre, int64_t n, vg_stream_t stream);

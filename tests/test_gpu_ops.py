@@ -502,3 +502,59 @@ def test_shortcut_dgrad_concat_fused(c_low, c_skip, cout, dims, acc_low, acc_ski
         del os.environ['VG_PW_SPLIT']
     assert not torch.equal(dcat2.cpu(), dcat)            # the fallback did accumulate into the concat gradient
     assert rel_l2(dlow2, low) < 1e-2 and rel_l2(dskip2, skip) < 1e-2
+
+
+@pytest.mark.parametrize('c_low,c_skip,cout,dims', [(32, 16, 16, (16, 16, 32)), (64, 32, 32, (8, 16, 16)), (32, 16, 16, (6, 10, 12)),
+                                                    (64, 32, 64, (4, 4, 8))])
+@pytest.mark.parametrize('acc', [False, True])
+def test_shortcut_dgrad_concat_norm_fused(c_low, c_skip, cout, dims, acc):
+    """vg_shortcut_dgrad_concat_norm: the decoder block's input gradient in ONE launch -- (InstanceNorm -> ReLU) backward of the first
+    convolution's input from its reflection-padded data gradient (pad transposed on read), + the shortcut's data gradient, split and
+    2x2x2 sum-pooled into the gradients of the two concat sources (resunet_model.py:103-143,175-181) -- against float64 autograd
+    semantics written out by hand on the same bf16 operands."""
+    from van_gan_amd import ops
+    dev = _dev()
+    N, C_ = 2, c_low + c_skip
+    D, H, W = dims
+    S = D * H * W
+    st, lay = make_layer(1, C_, cout, 1, 'same', dims, bias=True, seed=5)
+    g = torch.Generator().manual_seed(13)
+    dy = torch.randn(N, D, H, W, cout, generator=g).to(torch.bfloat16)
+    dp1 = torch.randn(N, D + 2, H + 2, W + 2, C_, generator=g).to(torch.bfloat16)
+    low = torch.randn(N, D // 2, H // 2, W // 2, c_low, generator=g).to(torch.bfloat16)
+    skip = torch.randn(N, D, H, W, c_skip, generator=g).to(torch.bfloat16)
+    gamma, beta = torch.rand(C_, generator=g) + 0.5, torch.randn(C_, generator=g) * 0.2
+    mean, rstd = torch.randn(N, C_, generator=g) * 0.3, torch.rand(N, C_, generator=g) + 0.5
+    scale = gamma.view(1, C_) * rstd
+    shift = beta.view(1, C_) - mean * scale
+    dlow0 = torch.randn(N, D // 2, H // 2, W // 2, c_low, generator=g).to(torch.bfloat16)
+    dskip0 = torch.randn(N, D, H, W, c_skip, generator=g).to(torch.bfloat16)
+    dgamma, dbeta = torch.zeros(C_, device=dev), torch.zeros(C_, device=dev)
+    red = torch.zeros(ops.STRIPES * N * C_ * 2 + 4, device=dev)
+    dlow, dskip = dlow0.to(dev).clone(), dskip0.to(dev).clone()
+    nd = ops.actnorm_desc(dp1.to(dev), True, low.to(dev), (N, D, H, W), C_, None, scale=scale.to(dev), shift=shift.to(dev), act=ops.ACT_RELU,
+                          norm=True, gamma=gamma.to(dev), mean=mean.to(dev), rstd=rstd.to(dev), red=red, accumulate=False,
+                          x1=skip.to(dev), c_x0=c_low, x0_shift=1, dgamma=dgamma, dbeta=dbeta)
+    ops.actnorm_stats(nd)
+    served = lay.dgrad_concat_norm(dy.to(dev), N, nd, c_low, dlow, dskip, acc_low=acc, acc_skip=acc)
+    torch.cuda.synchronize()
+    assert served
+    # reference
+    x = torch.cat([low.double().repeat_interleave(2, 1).repeat_interleave(2, 2).repeat_interleave(2, 3), skip.double()], dim=-1)
+    z = torch.zeros(N, C_, D, H, W, dtype=torch.float64, requires_grad=True)
+    (O.reflect_pad1(z) * dp1.double().permute(0, 4, 1, 2, 3)).sum().backward()
+    gf = z.grad.permute(0, 2, 3, 4, 1)                                    # transpose of the reflection pad
+    v = lambda t: t.double().view(N, 1, 1, 1, C_)
+    dn = gf * ((x * v(scale) + v(shift)) > 0)
+    xh = (x - v(mean)) * v(rstd)
+    r0, r1 = dn.sum(dim=(1, 2, 3), keepdim=True), (dn * xh).sum(dim=(1, 2, 3), keepdim=True)
+    dx = gamma.double().view(1, 1, 1, 1, C_) * v(rstd) * (dn - r0 / S - xh * r1 / S)
+    w = bf(st.param('c.w').cpu()).view(C_, cout)
+    full = dx + dy.double() @ w.t()
+    rlow = full[..., :c_low].view(N, D // 2, 2, H // 2, 2, W // 2, 2, c_low).sum(dim=(2, 4, 6))
+    rskip = full[..., c_low:]
+    if acc:
+        rlow, rskip = rlow + dlow0.double(), rskip + dskip0.double()
+    close_bf16(dlow, rlow, 'dlow')
+    close_bf16(dskip, rskip, 'dskip')
+    assert rel_l2(dbeta, r0.sum(0).flatten()) < 1e-4 and rel_l2(dgamma, r1.sum(0).flatten()) < 1e-4

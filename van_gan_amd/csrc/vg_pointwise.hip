@@ -225,6 +225,12 @@ struct PWG {
     // gradient of the virtual concat left there by the conv branch); the sum goes to dskip (channels >= sc0, per voxel) and, summed
     // over every 2x2x2 block, to dlow (channels < sc0, half resolution).  acc bit 0: dlow accumulates, bit 1: dskip accumulates.
     bf16_t* dlow; bf16_t* dskip; int sc0, sacc;
+    // SPLIT == 2: the conv branch's part of the concat gradient is not stored at all -- it is the (InstanceNorm -> act) backward of
+    // the block's first convolution, computed here from that convolution's padded data gradient `ng` (reflection pad folded on
+    // read), the forward operands nx0 (low resolution, channels < sc0) / nx1 and the per-(sample, channel) constants
+    const bf16_t* ng; const bf16_t* nx0; const bf16_t* nx1;
+    const float* n_scale; const float* n_shift; const float* n_mean; const float* n_rstd; const float* n_gamma; const float* n_mult;
+    const float* n_red; float* n_dgamma; float* n_dbeta; int n_act;
 };
 }
 extern unsigned long long* g_vg_stamps;
@@ -233,7 +239,30 @@ typedef __attribute__((ext_vector_type(2))) float pw_f32x2;
 typedef __attribute__((ext_vector_type(2))) unsigned pw_u32x2;
 typedef __attribute__((ext_vector_type(4))) unsigned pw_u32x4;
 
-template <int KS, int NB, bool GEO, bool ACC, bool STATS, bool SPLIT = false>
+// g[0..7] += the mirrored copies of voxel (dk, hk, wk) on a reflection-padded grid [D+2][H+2][W+2][C] (gp: sample base + channel):
+// every combination of {own, mirrored} per axis except the all-own one (the caller loaded it); index 1 mirrors to padded 0, index
+// n - 2 to padded n + 1 (extents >= 4: an index has at most one mirror per axis).  The seven loads go out together on clamped
+// addresses (a serial loop made the 30 % of waves that hold a border voxel wait for up to seven round trips).
+__device__ __forceinline__ void vg_reflect_fold8(const bf16_t* gp, int C, int D, int H, int W, int dk, int hk, int wk, float* g) {
+    const int PH = H + 2, PW_ = W + 2;
+    const int md = dk == 1 ? 0 : (dk == D - 2 ? D + 1 : -1), mh = hk == 1 ? 0 : (hk == H - 2 ? H + 1 : -1), mw = wk == 1 ? 0 : (wk == W - 2 ? W + 1 : -1);
+    Raw8<bf16_t> rr[7];
+    bool val[7];
+#pragma unroll
+    for (int t = 1; t < 8; ++t) {
+        const int qd = (t & 4) ? md : dk + 1, qh = (t & 2) ? mh : hk + 1, qw = (t & 1) ? mw : wk + 1;
+        val[t - 1] = (qd | qh | qw) >= 0;
+        raw_load(rr[t - 1], gp + (val[t - 1] ? ((size_t)(qd * PH + qh) * PW_ + qw) * C : ((size_t)((dk + 1) * PH + hk + 1) * PW_ + wk + 1) * C));
+    }
+#pragma unroll
+    for (int t = 0; t < 7; ++t) {
+        float r[8]; raw_unpack(rr[t], r);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g[j] += val[t] ? r[j] : 0.f;
+    }
+}
+
+template <int KS, int NB, bool GEO, bool ACC, bool STATS, int SPLIT = 0>
 __global__ __launch_bounds__(256) void pw_gemm_kernel(const PWG p) {
     static_assert(!SPLIT || (ACC && !GEO && !STATS), "SPLIT: accumulating, same-grid launches");
     constexpr int MS = (KS * NB <= 2) ? 4 : 2;
@@ -241,6 +270,31 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const PWG p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, kg = lane >> 4;
     const int n = blockIdx.y;
     if (p.stamps && lane == 0) p.stamps[((size_t)blockIdx.x * 4 + wave) * 8] = __builtin_amdgcn_s_memrealtime();
+    // SPLIT == 2: dx = A * m * g - B - Cc * x per channel of sample n, m = 1 where x * scale + shift > 0 else the activation's slope
+    // (the IN backward k0 * dn - k1 - k2 * xhat of vg_elem.hip with dn = g * mult * m and xhat = (x - mean) * rstd, constants
+    // folded); the 8 statistics stripes are added up here, and workgroup 0 of the sample adds the gamma / beta gradients
+    float* ntab = nullptr;
+    if constexpr (SPLIT == 2) {
+        __shared__ float ntab_s[5 * NB * 16];
+        ntab = ntab_s;
+        constexpr int C = NB * 16;
+        if (tid < C && tid < p.Cout) {
+            const int nc = n * p.Cout + tid;
+            const size_t total = (size_t)p.N * p.Cout * 2;
+            float r0 = 0.f, r1 = 0.f;
+#pragma unroll
+            for (int t = 0; t < VG_STRIPES; ++t) { r0 += p.n_red[t * total + (size_t)nc * 2]; r1 += p.n_red[t * total + (size_t)nc * 2 + 1]; }
+            if (p.n_dgamma && blockIdx.x == 0) { atomicAdd(&p.n_dbeta[tid], r0); atomicAdd(&p.n_dgamma[tid], r1); }
+            const float cnt = (float)p.SO, rs = p.n_rstd[nc], mu = p.n_mean[nc], gr = p.n_gamma[tid] * rs;
+            const float k1 = gr * r0 / cnt, k2 = gr * r1 / cnt, cc = k2 * rs;
+            ntab_s[tid] = p.n_scale ? p.n_scale[nc] : 1.f;
+            ntab_s[C + tid] = p.n_scale ? p.n_shift[nc] : 0.f;
+            ntab_s[2 * C + tid] = gr * (p.n_mult ? p.n_mult[nc] : 1.f);
+            ntab_s[3 * C + tid] = k1 - cc * mu;
+            ntab_s[4 * C + tid] = cc;
+        }
+        __syncthreads();
+    }
     bf16x8 wA[NB][KS];
     pw_f32x2 e_b[NB][2];
 #pragma unroll
@@ -269,11 +323,30 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const PWG p) {
     const int ID2 = p.ID >> p.sh, IH2 = p.IH >> p.sh, IW2 = p.IW >> p.sh;
     const int nwt = (p.SO + MS * 16 - 1) / (MS * 16);
     const int jodd = kg & 1, chof = (kg & ~1) * 4;
+    // SPLIT: the lane holds channels nb*16 + chof .. + 7 of one voxel of sub-tile jp + jodd.  Low-resolution source: sum over the
+    // 2x2x2 block = lanes r, r^1, r^2, r^4 of the 16-lane row, one lane of eight stores; skip source: plain store per voxel.
+    auto split_store = [&](int wt, int jp, int nb, float* o, bool ok, size_t vox) {
+        if (nb * 16 < p.sc0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { o[i] += __shfl_xor(o[i], 1); o[i] += __shfl_xor(o[i], 2); o[i] += __shfl_xor(o[i], 4); }
+            if (ok && (r & 7) == 0) {
+                const size_t cidx = (size_t)n * (p.SO >> 3) + (size_t)wt * (MS * 2) + (jp + jodd) * 2 + (r >> 3);
+                bf16_t* dst = p.dlow + cidx * p.sc0 + nb * 16 + chof;
+                if (p.sacc & 1) { float old[8]; load8<bf16_t>(dst, old); for (int i = 0; i < 8; ++i) o[i] += old[i]; }
+                store8<bf16_t>(dst, o);
+            }
+        } else if (ok) {
+            bf16_t* dst = p.dskip + vox * (p.Cout - p.sc0) + (nb * 16 - p.sc0) + chof;
+            if (p.sacc & 2) { float old[8]; load8<bf16_t>(dst, old); for (int i = 0; i < 8; ++i) o[i] += old[i]; }
+            store8<bf16_t>(dst, o);
+        }
+    };
     for (int wt = blockIdx.x * 4 + wave; wt < nwt; wt += gridDim.x * 4) {
         bf16x8 xb[MS][KS];
         bool vok[MS], oks[MS / 2];
         size_t i0s[MS], i1s[MS], ovs[MS / 2];           // ovs / oks: the sub-tile this lane STORES of each pair (jp + jodd)
         size_t ovf[MS / 2];                             // SPLIT: its voxel index (sample included)
+        int fdhw[MS / 2];                               // SPLIT == 2: its coordinates, packed
 #pragma unroll
         for (int jp = 0; jp < MS; jp += 2) {
             size_t ovp[2];
@@ -295,8 +368,10 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const PWG p) {
                     const int cb = vc >> 3, j = vc & 7;
                     const int CW = p.OW >> 1, CHW = (p.OH >> 1) * CW;
                     const int cd = cb / CHW, rem = cb - cd * CHW, ch = rem / CW, cw = rem - ch * CW;
-                    const int vf = ((2 * cd + (j >> 2)) * p.OH + 2 * ch + ((j >> 1) & 1)) * p.OW + 2 * cw + (j & 1);
+                    const int fd = 2 * cd + (j >> 2), fh = 2 * ch + ((j >> 1) & 1), fw = 2 * cw + (j & 1);
+                    const int vf = (fd * p.OH + fh) * p.OW + fw;
                     i0s[i] = i1s[i] = ovp[e] = (size_t)n * p.SO + vf;
+                    if (e == jodd) fdhw[jp >> 1] = fd | (fh << 10) | (fw << 20);
                 } else {
                     i0s[i] = i1s[i] = ovp[e] = (size_t)n * p.SO + vc;
                 }
@@ -308,7 +383,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const PWG p) {
         // accumulate mode: the old values are fetched together with the operands (out-of-range voxels were clamped to the last
         // one: a valid address)
         Raw8<bf16_t> oldv[ACC ? MS / 2 : 1][ACC ? NB : 1];
-        if (ACC) {
+        if (ACC && SPLIT != 2) {
 #pragma unroll
             for (int jh = 0; jh < MS / 2; ++jh)
 #pragma unroll
@@ -331,6 +406,70 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const PWG p) {
                 xb[i][ks] = t.v;
             }
         if (p.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (lane == 0) p.stamps[((size_t)blockIdx.x * 4 + wave) * 8 + 2] = __builtin_amdgcn_s_memrealtime(); }
+        if constexpr (SPLIT == 2) {
+            // One channel block at a time -- loads of the padded data gradient (interior position) and the forward operand, the
+            // block's MFMAs, the IN backward, split / pool / store -- so that the live state is one block's, not all NB blocks'
+            // (all at once: 216-305 VGPRs, one or two waves per SIMD on an HBM-bound kernel: 171 us where 72 + 115 were to be beaten).
+            const int PH = p.OH + 2, PW_ = p.OW + 2;
+            size_t gi[MS / 2], li[MS / 2], si[MS / 2];
+            bool bord[MS / 2];
+#pragma unroll
+            for (int jh = 0; jh < MS / 2; ++jh) {
+                const int fd = fdhw[jh] & 1023, fh = (fdhw[jh] >> 10) & 1023, fw = fdhw[jh] >> 20;
+                gi[jh] = ((((size_t)n * (p.OD + 2) + fd + 1) * PH + fh + 1) * PW_ + fw + 1) * p.Cout + chof;
+                li[jh] = ((((size_t)n * (p.OD >> 1) + (fd >> 1)) * (p.OH >> 1) + (fh >> 1)) * (p.OW >> 1) + (fw >> 1)) * p.sc0 + chof;
+                si[jh] = ovf[jh] * (p.Cout - p.sc0) + chof;
+                bord[jh] = fd == 1 || fd == p.OD - 2 || fh == 1 || fh == p.OH - 2 || fw == 1 || fw == p.OW - 2;
+            }
+            constexpr int C = NB * 16;
+            const float slope = pw_slope(p.n_act);
+            // every load of the wave-tile goes out first (7 KB in flight per wave: the kernel is HBM-bound), the blocks are then
+            // finished one by one
+            Raw8<bf16_t> gq[NB][MS / 2], xq[NB][MS / 2];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int jh = 0; jh < MS / 2; ++jh) {
+                    raw_load(gq[nb][jh], p.ng + gi[jh] + nb * 16);
+                    raw_load(xq[nb][jh], nb * 16 < p.sc0 ? p.nx0 + li[jh] + nb * 16 : p.nx1 + si[jh] + (nb * 16 - p.sc0));
+                }
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                f32x4 a[MS];
+#pragma unroll
+                for (int i = 0; i < MS; ++i) {
+                    a[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) a[i] = VG_MFMA16(wA[nb][ks], xb[i][ks], a[i]);
+                }
+                const float* tb = ntab + nb * 16 + chof;
+#pragma unroll
+                for (int jp = 0; jp < MS; jp += 2) {
+                    float o[8];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const pw_u32x2 x = __builtin_amdgcn_permlane16_swap(__float_as_uint(a[jp][i]), __float_as_uint(a[jp + 1][i]), false, false);
+                        o[i] = __uint_as_float(x[0]); o[4 + i] = __uint_as_float(x[1]);
+                    }
+                    float q[8], xv[8];
+                    raw_unpack(gq[nb][jp >> 1], q); raw_unpack(xq[nb][jp >> 1], xv);
+                    // transpose of the reflection pad: voxels next to a face also own the mirrored positions of the padded grid
+                    if (bord[jp >> 1]) {
+                        const int fd = fdhw[jp >> 1] & 1023, fh = (fdhw[jp >> 1] >> 10) & 1023, fw = fdhw[jp >> 1] >> 20;
+                        vg_reflect_fold8(p.ng + (size_t)n * (p.OD + 2) * PH * PW_ * p.Cout + nb * 16 + chof, p.Cout, p.OD, p.OH, p.OW, fd, fh, fw, q);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float pre = xv[i] * tb[i] + tb[C + i];
+                        const float m = (pre > 0.f || p.n_act == VG_ACT_NONE) ? 1.f : slope;
+                        o[i] += tb[2 * C + i] * m * q[i] - tb[3 * C + i] - tb[4 * C + i] * xv[i];
+                    }
+                    split_store(wt, jp, nb, o, oks[jp >> 1], ovf[jp >> 1]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            continue;
+        }
         f32x4 acc[MS][NB];
 #pragma unroll
         for (int i = 0; i < MS; ++i)
@@ -365,24 +504,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const PWG p) {
                     if (SPLIT) {
 #pragma unroll
                         for (int i = 0; i < 8; ++i) o[i] += q[i];
-                        if (nb * 16 < p.sc0) {
-                            // low-resolution source: sum over the 2x2x2 block = lanes r, r^1, r^2, r^4 of the 16-lane row
-#pragma unroll
-                            for (int i = 0; i < 8; ++i) {
-                                o[i] += __shfl_xor(o[i], 1); o[i] += __shfl_xor(o[i], 2); o[i] += __shfl_xor(o[i], 4);
-                            }
-                            if (ok && (r & 7) == 0) {
-                                const int sub = jp + jodd;
-                                const size_t cidx = (size_t)n * (p.SO >> 3) + (size_t)wt * (MS * 2) + sub * 2 + (r >> 3);
-                                bf16_t* dst = p.dlow + cidx * p.sc0 + nb * 16 + chof;
-                                if (p.sacc & 1) { float old[8]; load8<bf16_t>(dst, old); for (int i = 0; i < 8; ++i) o[i] += old[i]; }
-                                store8<bf16_t>(dst, o);
-                            }
-                        } else if (ok) {
-                            bf16_t* dst = p.dskip + ovf[jp >> 1] * (p.Cout - p.sc0) + (nb * 16 - p.sc0) + chof;
-                            if (p.sacc & 2) { float old[8]; load8<bf16_t>(dst, old); for (int i = 0; i < 8; ++i) o[i] += old[i]; }
-                            store8<bf16_t>(dst, o);
-                        }
+                        split_store(wt, jp, nb, o, ok, ovf[jp >> 1]);
                         continue;
                     }
                     bf16x8 pk;
@@ -834,8 +956,9 @@ bool pwg_launch(int KS, int NB, dim3 grid, hipStream_t s, const PWG& p) {
 #undef PWG_CASE
     return false;
 }
+template <int SPLIT>
 bool pwg_launch_split(int KS, int NB, dim3 grid, hipStream_t s, const PWG& p) {
-#define PWG_CASE(ks, nb) if (KS == ks && NB == nb) { hipLaunchKernelGGL((pw_gemm_kernel<ks, nb, false, true, false, true>), grid, dim3(256), 0, s, p); return true; }
+#define PWG_CASE(ks, nb) if (KS == ks && NB == nb) { hipLaunchKernelGGL((pw_gemm_kernel<ks, nb, false, true, false, SPLIT>), grid, dim3(256), 0, s, p); return true; }
     PWG_CASE(1, 3) PWG_CASE(1, 6) PWG_CASE(2, 6)
 #undef PWG_CASE
     return false;
@@ -887,12 +1010,17 @@ int pw_gemm_conv(const vg_conv_desc* d, hipStream_t s) {
 // Data gradient of a decoder shortcut fused with the backward of UpSampling3D + concatenate: d describes the accumulating launch
 // (src0 = gradient of the shortcut's output, out = gradient of the virtual concat with the conv branch's part already in it);
 // instead of adding into `out` and leaving the split / 2x2x2 sum to vg_concat_bwd, the sums go to dskip / dlow directly.
-int pw_gemm_split(const vg_conv_desc* d, void* dlow, void* dskip, int c_low, int acc, hipStream_t s) {
+int pw_gemm_split(const vg_conv_desc* d, const vg_actnorm_bwd_desc* nb_, void* dlow, void* dskip, int c_low, int acc, hipStream_t s) {
     if (!pw_enabled() || !vg_tune("PW_GEMM", 1) || !vg_tune("PW_SPLIT", 1)) return 1;
     if (d->ntaps != 1 || d->tap_d[0] || d->tap_h[0] || d->tap_w[0] || d->noise || d->wpack || d->nclass > 1) return 1;
     if (d->f32 || d->src_f32 || d->out_f32 || d->in_scale || d->act != VG_ACT_NONE || d->res || d->tanh_out || d->out_sums || d->bias) return 1;
     const int Cin = d->c_src0;
-    if (d->c_src1 || d->src0_shift || Cin < 8 || (Cin % 8) || d->Cout < 32 || (d->Cout % 16) || (d->CK % 8) || !d->accumulate) return 1;
+    if (d->c_src1 || d->src0_shift || Cin < 8 || (Cin % 8) || d->Cout < 32 || (d->Cout % 16) || (d->CK % 8) || (!d->accumulate && !nb_)) return 1;
+    if (nb_) {          // the conv branch's (InstanceNorm -> act) backward computed in the launch (SPLIT == 2)
+        if (!nb_->norm || !nb_->g_padded || nb_->f32 || nb_->x_f32 || !nb_->g || !nb_->x || !nb_->x1 || !nb_->x0_shift || nb_->c_x0 != c_low) return 1;
+        if (nb_->C != d->Cout || nb_->N != d->N || nb_->D != d->D || nb_->H != d->H || nb_->W != d->W || !nb_->gamma || !nb_->mean || !nb_->rstd || !nb_->red) return 1;
+        if (d->D < 4 || d->H < 4 || d->W < 4 || d->D > 1023 || d->H > 1023 || d->W > 1023) return 1;
+    }
     if (c_low < 16 || (c_low % 16) || c_low >= d->Cout) return 1;
     if (d->istr != 1 || d->ostr != 1 || d->ooff_d || d->ooff_h || d->ooff_w || d->BD != d->OD || d->BH != d->OH || d->BW != d->OW
         || d->OD != d->D || d->OH != d->H || d->OW != d->W || ((d->D | d->H | d->W) & 1)) return 1;
@@ -908,14 +1036,20 @@ int pw_gemm_split(const vg_conv_desc* d, void* dlow, void* dskip, int c_low, int
     p.BD = d->BD; p.BH = d->BH; p.BW = d->BW; p.ostr = 1;
     p.Cout = d->Cout; p.SO = (int)SO; p.stamps = g_vg_stamps;
     p.dlow = (bf16_t*)dlow; p.dskip = (bf16_t*)dskip; p.sc0 = c_low; p.sacc = acc;
+    if (nb_) {
+        p.ng = (const bf16_t*)nb_->g; p.nx0 = (const bf16_t*)nb_->x; p.nx1 = (const bf16_t*)nb_->x1;
+        p.n_scale = nb_->scale; p.n_shift = nb_->shift; p.n_mean = nb_->mean; p.n_rstd = nb_->rstd; p.n_gamma = nb_->gamma; p.n_mult = nb_->mult;
+        p.n_red = nb_->red; p.n_dgamma = (nb_->dgamma && nb_->dbeta) ? nb_->dgamma : nullptr; p.n_dbeta = nb_->dbeta; p.n_act = nb_->act;
+    }
     const int MS = (KS * NB <= 2) ? 4 : 2;
     const int64_t nwt = (SO + MS * 16 - 1) / (MS * 16);
     int64_t b = (nwt + 3) / 4;
     const int capt = vg_tune("PW_GEMM_CAP", 2047);
     const int64_t cap = (capt / d->N) > 0 ? (capt / d->N) : 1;
     if (b > cap) b = cap;
-    if (vg_dry("pw_gemm_split<%d,%d>", KS, NB)) return VG_OK;
-    return pwg_launch_split(KS, NB, dim3((int)b, d->N), s, p) ? vg_check_launch() : 1;
+    if (vg_dry("pw_gemm_split<%d,%d,n%d>", KS, NB, nb_ ? 1 : 0)) return VG_OK;
+    const bool ok = nb_ ? pwg_launch_split<2>(KS, NB, dim3((int)b, d->N), s, p) : pwg_launch_split<1>(KS, NB, dim3((int)b, d->N), s, p);
+    return ok ? vg_check_launch() : 1;
 }
 
 int pw_wgrad_cc(const vg_conv_desc* d, const void* dy, int dy_f32, int T_total, float* dw, float* db, float* scratch,
@@ -959,7 +1093,14 @@ int pw_wgrad_cc(const vg_conv_desc* d, const void* dy, int dy_f32, int T_total, 
 extern "C" int vg_shortcut_dgrad_concat(const vg_conv_desc* d, void* dlow, void* dskip, int c_low, int accumulate, vg_stream_t stream) {
     vg_begin();
     if (!d || !d->src0 || !d->out || !d->wpacked || !dlow || !dskip) return VG_EINVAL;
-    return pw_gemm_split(d, dlow, dskip, c_low, accumulate, (hipStream_t)stream);
+    return pw_gemm_split(d, nullptr, dlow, dskip, c_low, accumulate, (hipStream_t)stream);
+}
+extern "C" int vg_shortcut_dgrad_concat_norm(const vg_conv_desc* d, const vg_actnorm_bwd_desc* b, void* dlow, void* dskip, int c_low,
+                                             int accumulate, vg_stream_t stream) {
+    vg_begin();
+    if (!d || !b || !d->src0 || !d->wpacked || !dlow || !dskip) return VG_EINVAL;
+    if (!vg_tune("PW_SPLIT_NORM", 1)) return 1;
+    return pw_gemm_split(d, b, dlow, dskip, c_low, accumulate, (hipStream_t)stream);
 }
 
 // returns VG_OK when the launch was done here, 1 when the shape is not one of the pointwise cases (caller continues), < 0 on error

@@ -360,9 +360,20 @@ class ResUNet:
             short.dgrad(d_sc, N, gin, accumulate=True)
         else:                        # decoder block: gradient of the virtual concat, then split / sum-pool
             low, skip = inp
-            dcat = ar.alloc((N,) + tuple(cb1.in_dims) + (s1.C,), self.dtype)
-            self._dgrad_norm_bwd(ar, cb1, d_r, N, dp1, s1, c['n1'], Nn[name + '.cb1'], dcat, ACT_RELU, accumulate=False)
-            short.dgrad_concat(d_sc, N, dcat, low.C, low.grad, skip.grad, acc_low=not low.first_write(), acc_skip=not skip.first_write())
+            # conv branch: data gradient of cb1 on the padded grid (+ the statistics of its input's IN backward); then ONE launch adds
+            # the shortcut's data gradient, applies the IN backward and splits / sum-pools into the gradients of the two concat sources
+            # (ops.ConvLayer.dgrad_concat_norm).  Where that launch does not serve the shape: apply pass into a concat-gradient
+            # buffer, then the shortcut's data gradient fused with the concat backward (or, failing that too, three launches).
+            dsc = self._norm_desc(ar, dp1, True, s1, c['n1'], Nn[name + '.cb1'], None, ACT_RELU, accumulate=False)
+            stats_done = cb1.dgrad(d_r, N, dp1, accumulate=False, bstat=dsc)
+            if not stats_done:
+                ops.actnorm_stats(dsc)
+            a_low, a_skip = not low.first_write(), not skip.first_write()
+            if not short.dgrad_concat_norm(d_sc, N, dsc, low.C, low.grad, skip.grad, acc_low=a_low, acc_skip=a_skip):
+                dcat = ar.alloc((N,) + tuple(cb1.in_dims) + (s1.C,), self.dtype)
+                ops.actnorm_set_dx(dsc, dcat)
+                ops.actnorm_run(dsc, stats_done=True)
+                short.dgrad_concat(d_sc, N, dcat, low.C, low.grad, skip.grad, acc_low=a_low, acc_skip=a_skip)
         ar.release(mk, defer=True)
 
     def backward(self, ar: Arena, ctx: dict, gy: torch.Tensor, inline_from: int = -1):

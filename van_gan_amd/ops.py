@@ -192,6 +192,7 @@ PROF: Optional[KernelProfile] = None
 WGRAD_INLINE = False        # set by ResUNet.backward for the tail of a lane's last sweep
 LAZY_RELEASE = os.environ.get('VG_LAZY_RELEASE', '1') != '0'
 FORK_SHORT = os.environ.get('VG_FORK_SHORT', '1') != '0'   # forward shortcut branches on the lane's side stream
+FUSE_CONCAT_NORM = os.environ.get('VG_FUSE_CONCAT_NORM', '1') != '0'   # ... and the conv branch's IN backward apply in the same launch
 FUSE_CONCAT = os.environ.get('VG_FUSE_CONCAT', '1') != '0'       # decoder shortcut data gradient + concat backward in one launch (ConvLayer.dgrad_concat)
 BSTAT = os.environ.get('VG_BSTAT', '1') != '0'       # IN-backward statistics with the data-gradient launch (ConvLayer.dgrad(bstat=...))
 SIDE: Optional[bool] = None                   # truthy: weight-gradient side streams enabled (one per issuing stream)
@@ -691,6 +692,44 @@ class ConvLayer:
         return use_bs
 
 
+    def _sc_desc(self, dy, N):
+        c = self.d_classes[0]
+        d = ConvDesc()
+        d.src1 = None
+        d.c_src0, d.c_src1, d.src0_shift = self.cout, 0, 0
+        d.D, d.H, d.W = self.out_dims
+        d.act, d.istr, d.pad_mode = ACT_NONE, 1, PAD_ZERO
+        _set_taps(d, c['taps'])
+        d.OD, d.OH, d.OW = c['iters']
+        d.ostr = self.stride
+        d.ooff_d, d.ooff_h, d.ooff_w = c['off']
+        d.BD, d.BH, d.BW = self.buf_dims
+        d.Cout, d.wpacked, d.CK = self.cin, _p(c['wp']), c['ck']
+        d.f32 = self.f32
+        d.src0, d.N = _p(dy), N
+        return d
+
+    def dgrad_concat_norm(self, dy: torch.Tensor, N: int, nd: 'ActNormBwdDesc', c_low: int, dlow: torch.Tensor, dskip: torch.Tensor,
+                          acc_low: bool, acc_skip: bool) -> bool:
+        """dgrad_concat with the conv branch folded in (vg_shortcut_dgrad_concat_norm): nd is the actnorm_desc of the block's first
+        convolution's input (statistics already in nd.red); nothing of the concat gradient is stored.  False: not served -- the
+        caller runs the apply pass into a concat-gradient buffer and dgrad_concat."""
+        if not (FUSE_CONCAT and FUSE_CONCAT_NORM and DRY is None and not self.f32 and self.k == 1 and self.stride == 1
+                and len(self.d_classes) == 1 and not self.d_fused):
+            return False
+        c = self.d_classes[0]
+        d = self._sc_desc(dy, N)
+        e0 = PROF.begin() if PROF is not None else None
+        rc = lib.vg_shortcut_dgrad_concat_norm(C.byref(d), C.byref(nd), _p(dlow), _p(dskip), c_low,
+                                               int(bool(acc_low)) | (int(bool(acc_skip)) << 1), stream())
+        if rc < 0:
+            check(rc, 'vg_shortcut_dgrad_concat_norm ' + self.name)
+        if rc == 0 and e0 is not None:
+            PROF.end('conv_dgrad', 2.0 * N * math.prod(c['iters']) * self.cin * self.cout, e0,
+                     N * 2 * (math.prod(self.out_dims) * self.cout + math.prod(self.buf_dims) * self.cin),
+                     'pw_gemm_split<%d,%d,n1>' % ((self.cout + 31) // 32, self.cin // 16), self.name)
+        return rc == 0
+
     def dgrad_concat(self, dy: torch.Tensor, N: int, dcat: torch.Tensor, c_low: int, dlow: torch.Tensor, dskip: torch.Tensor,
                      acc_low: bool, acc_skip: bool):
         """Decoder shortcut (1x1x1, stride 1): the data gradient added to the concat gradient `dcat` (which already holds the conv
@@ -721,7 +760,7 @@ class ConvLayer:
                 if e0 is not None:
                     PROF.end('conv_dgrad', 2.0 * N * math.prod(c['iters']) * self.cin * self.cout, e0,
                              N * 2 * (math.prod(self.out_dims) * self.cout + math.prod(self.buf_dims) * self.cin),
-                             'pw_gemm_split<%d,%d>' % ((self.cout + 31) // 32, self.cin // 16), self.name)
+                             'pw_gemm_split<%d,%d,n0>' % ((self.cout + 31) // 32, self.cin // 16), self.name)
                 return
             if rc < 0:
                 check(rc, 'vg_shortcut_dgrad_concat ' + self.name)
@@ -781,7 +820,7 @@ def actnorm_desc(g, g_padded, x, dims, C_, dx, *, scale=None, shift=None, mult=N
     d.C = C_
     d.scale, d.shift, d.mult, d.act, d.norm = _p(scale), _p(shift), _p(mult), act, int(norm)
     d.gamma, d.mean, d.rstd, d.red = _p(gamma), _p(mean), _p(rstd), _p(red)
-    d.dx, d.dx_f32, d.accumulate = _p(dx), int(dx.dtype == torch.float32), int(accumulate)
+    d.dx, d.dx_f32, d.accumulate = _p(dx), int(dx is not None and dx.dtype == torch.float32), int(accumulate)       # dx may be set later
     d.dx_cstride, d.dx_coff = dx_cstride, dx_coff
     d.f32 = int(g.dtype == torch.float32)
     d.dgamma, d.dbeta = _p(dgamma), _p(dbeta)      # parameter gradients come out of the statistics pass
@@ -789,6 +828,15 @@ def actnorm_desc(g, g_padded, x, dims, C_, dx, *, scale=None, shift=None, mult=N
     d.ticket = (red.data_ptr() + 4 * nred) if (red is not None and red.dim() == 1 and red.numel() == nred + 4) else None
     d._keep = (g, x, dx, scale, shift, mult, gamma, mean, rstd, red, x1, dgamma, dbeta)
     return d
+
+
+def actnorm_stats(d: ActNormBwdDesc):
+    check(lib.vg_actnorm_bwd_stats(C.byref(d), stream()), 'vg_actnorm_bwd_stats')
+
+
+def actnorm_set_dx(d: ActNormBwdDesc, dx: torch.Tensor):
+    d.dx, d.dx_f32 = _p(dx), int(dx.dtype == torch.float32)
+    d._keep = d._keep + (dx,)
 
 
 def actnorm_run(d: ActNormBwdDesc, stats_done: bool = False):
