@@ -376,7 +376,8 @@ __global__ __launch_bounds__(512, 2) void wgrad_dma_kernel(const WgdK p) {
                     *u = o;
                     // (Spreading the NEXT tile's transform over the K-steps of the current one -- its copies landed a tile ago with three
                     // buffers -- was measured slower, 98 vs 89 us on the 16->16 layers: LDS returns in order, so waiting for the
-                    // transform's read drains the K loop's prefetched fragments.)
+                    // transform's read drains the K loop's prefetched fragments.  Packed arithmetic -- v_pk_fma_f32, ReLU as v_pk_max_i16 on
+                    // the rounded pair, the plane's constants loaded once per tile -- was slower as well: 95 vs 90 us.)
                 }
             }
         }
