@@ -30,8 +30,8 @@ NEEDED = ('128^3 B1', '64^3 B2', '128x128x64 B2')
 
 
 def enumerate_config(dims, B, precision='bf16'):
-    """-> [(kind, layer name, variant, recipe)] of one train step's conv launches (one generator application, one
-    discriminator with its two backward sweeps: the other applications repeat the same calls)."""
+    """-> [(kind, layer name, variant, recipe)] of one train step's conv launches (one generator: a forward application and the
+    backward sweep over both applications; one discriminator with its two backward sweeps: the others repeat the same calls)."""
     from van_gan_amd import ops
     from van_gan_amd.nets import ParamStore, PatchGAN, ResUNet, disc_param_specs, gen_param_specs
     dt = torch.bfloat16 if precision == 'bf16' else torch.float32
@@ -40,10 +40,20 @@ def enumerate_config(dims, B, precision='bf16'):
     D = PatchGAN(ParamStore(disc_param_specs(), 'cpu'), dims, dt)
     ar = ops.Arena(int(B * S * 5200 * 2) + (512 << 20), 'cpu')          # never touched: dry runs do not write
     with ops.DryRun() as dry:
-        x, y = ar.alloc((B,) + dims + (1,), torch.float32), ar.alloc((B,) + dims + (1,), torch.float32)
-        ctx = G.forward(ar, x, y)
-        G.backward(ar, ctx, y)
+        # as in VanGan._losses_and_backward: the two applications of a generator are B-sample forward passes into paired 2B-sample
+        # tensors and ONE 2B-sample backward sweep (the second forward repeats the first one's calls: not recorded twice)
+        from van_gan_amd.nets import pair_ctx
         x2 = ar.alloc((2 * B,) + dims + (1,), torch.float32)
+        y, yb = ar.alloc((B,) + dims + (1,), torch.float32), ar.alloc((B,) + dims + (1,), torch.float32)
+        ar.pair_begin('g', 0)
+        ctx = G.forward(ar, x2[:B], y)
+        ar.pair_end()
+        n0 = len(dry.records)
+        ar.pair_begin('g', 1)
+        G.forward(ar, x2[B:], yb)
+        ar.pair_end()
+        del dry.records[n0:]; del dry.recipes[n0:]
+        G.backward(ar, pair_ctx(ar, ctx, x2, (y, yb), G.lv[0]), x2)
         lg = ar.alloc((2 * B,) + tuple(n // 8 for n in dims) + (1,), torch.float32)
         noise = {k: torch.empty(shp, dtype=torch.bfloat16) for k, shp in D.noise_shapes(2 * B).items()}
         drop = {k: torch.empty(2 * B, c) for k, c in (('down0', 128), ('down1', 256), ('down2', 512))}

@@ -168,13 +168,61 @@ class Norm:
 
     def finalize(self, arena: Arena, a0: Act, a1: Optional[Act] = None, mult=None):
         N = a0.N
-        blk = arena.alloc((4, N, self.C), torch.float32)           # one allocation, four views
-        st = {'scale': blk[0], 'shift': blk[1], 'mean': blk[2], 'rstd': blk[3]}
+        # (four allocations with the sample index leading: the paired arena mode doubles the leading dimension)
+        st = {k: arena.alloc((N, self.C), torch.float32) for k in ('scale', 'shift', 'mean', 'rstd')}
         ops.in_finalize(a0.sums, a0.C, a0.count, self.gamma, self.beta, N, st['scale'], st['shift'], st['mean'],
                         st['rstd'], sums1=None if a1 is None else a1.sums, c1=0 if a1 is None else a1.C,
                         count1=1.0 if a1 is None else a1.count, mult=mult)
         st['mult'] = mult
         return st
+
+
+def pair_ctx(ar: Arena, ctx: dict, x_full: torch.Tensor, ys, lv0) -> dict:
+    """The backward context of BOTH applications of a generator whose forward passes ran in the arena's paired mode
+    (Arena.pair_begin): ctx is the first application's context; every stored tensor is replaced by the 2N-sample tensor it is the
+    first half of (object identity between the entries is preserved: the gradient buffers hang on the Act objects).  x_full: the
+    [2N, D, H, W, 1] input volumes of the two applications, ys: their two output volumes."""
+    import copy
+    memo = {}
+
+    def full(t):
+        f = ar.full_of(t)
+        return t if f is None else f
+
+    def m(o):
+        if o is None or isinstance(o, (int, float, str, bool)):
+            return o
+        k = id(o)
+        if k in memo:
+            return memo[k]
+        if isinstance(o, torch.Tensor):
+            r = full(o)
+        elif isinstance(o, Act):
+            assert ar.full_of(o.data) is not None, 'activation was not allocated in paired mode'
+            r = copy.copy(o)
+            r.data = full(o.data); r.N = r.data.shape[0]; r.sums = None; r.grad = None; r.grad_init = False
+        elif isinstance(o, Src):
+            r = copy.copy(o)
+            r.x0, r.x1, r.scale, r.shift = full(o.x0), full(o.x1), full(o.scale), full(o.shift)
+            r.N = r.x0.shape[0]
+        elif isinstance(o, dict):
+            r = {}
+            memo[k] = r
+            for kk, v in o.items():
+                r[kk] = m(v)
+            return r
+        elif isinstance(o, (tuple, list)):
+            r = type(o)(m(v) for v in o)
+        else:
+            r = o
+        memo[k] = r
+        return r
+
+    out = m(ctx)
+    N2 = 2 * ctx['N']
+    out['N'], out['x'], out['y'] = N2, x_full, list(ys)
+    out['stem']['sx'] = Src(x_full, (N2,) + tuple(lv0), 1, f32=True)
+    return out
 
 
 # ======================================================================================================
@@ -391,7 +439,12 @@ class ResUNet:
             a.alloc_grad(ar)
         # output conv + tanh
         dpre = ar.alloc(gy.shape, torch.float32)
-        ops.tanh_bwd(gy, ctx['y'], dpre)
+        if isinstance(ctx['y'], list):               # paired context: the two applications' outputs are separate volumes
+            nb = N // len(ctx['y'])
+            for i, yi in enumerate(ctx['y']):
+                ops.tanh_bwd(gy[i * nb:(i + 1) * nb], yi, dpre[i * nb:(i + 1) * nb])
+        else:
+            ops.tanh_bwd(gy, ctx['y'], dpre)
         h = ctx['out']['inp']
         L['out'].wgrad(ctx['out']['so'], dpre)
         L['out'].dgrad(dpre, N, h.grad, accumulate=not h.first_write())

@@ -281,8 +281,25 @@ class Arena:
         self.peak = 0
         self.lazy_ok = True         # False: this arena is shared by sweeps of both lanes (VG_LANES=0), so release() always recycles
         self.zpool.zero_()
+        self._pair, self._pairs, self._pair_pos, self._full = None, {}, 0, {}
+
+    # Paired allocation (the two applications of one generator in a train step): while pair_begin(key, 0) is active every
+    # non-zeroed allocation [N, ...] reserves [2N, ...] and returns the first half; pair_begin(key, 1) replays the SAME allocation
+    # sequence and returns the second halves.  The forward passes stay ordinary N-sample launches on contiguous sample slices, the
+    # backward sweep runs ONCE over the 2N-sample tensors (full_of maps a first-half view to its whole).
+    def pair_begin(self, key, slot: int):
+        self._pair, self._pair_pos = (key, slot), 0
+        if slot == 0:
+            self._pairs[key] = []
+
+    def pair_end(self):
+        self._pair = None
+
+    def full_of(self, t):
+        return None if t is None else self._full.get(t.data_ptr())
 
     def reset(self):
+        self._pair, self._pairs, self._pair_pos, self._full = None, {}, 0, {}
         self.off = 0
         if self.zoff:
             self.zpool[:self.zoff].zero_()
@@ -291,6 +308,20 @@ class Arena:
     _ESZ = {torch.float32: 4, torch.bfloat16: 2, torch.float16: 2, torch.int32: 4, torch.int64: 8, torch.uint8: 1, torch.float64: 8}
 
     def alloc(self, shape: Sequence[int], dtype: torch.dtype, zero: bool = False) -> torch.Tensor:
+        if self._pair is not None and not zero:
+            key, slot = self._pair
+            shape = tuple(shape)
+            if slot == 0:
+                self._pair = None
+                full = self.alloc((2 * shape[0],) + shape[1:], dtype)
+                self._pair = (key, slot)
+                self._pairs[key].append(full)
+                self._full[full.data_ptr()] = full
+                return full[:shape[0]]
+            full = self._pairs[key][self._pair_pos]
+            self._pair_pos += 1
+            assert tuple(full.shape) == (2 * shape[0],) + shape[1:] and full.dtype == dtype, 'paired allocation sequences differ'
+            return full[shape[0]:]
         n = int(math.prod(shape))
         nbytes = n * self._ESZ[dtype]
         if zero and nbytes <= 65536:

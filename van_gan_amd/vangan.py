@@ -17,7 +17,7 @@ import torch
 
 from . import ops
 from .dist import GradSync
-from .nets import PatchGAN, ParamStore, ResUNet, disc_param_specs, gen_param_specs, init_reference
+from .nets import pair_ctx, PatchGAN, ParamStore, ResUNet, disc_param_specs, gen_param_specs, init_reference
 from .ops import Arena
 
 RESULT_KEYS = ['total_IS_loss', 'total_SI_loss', 'D_I_loss', 'D_S_loss', 'gen_IS_loss', 'gen_SI_loss',
@@ -26,6 +26,7 @@ _BFIRST = int(os.environ.get('VG_BFIRST', '0'))
 _NOJOIN = os.environ.get('VG_NOJOIN', '1') != '0'
 _LAZY_AR = os.environ.get('VG_LAZY_AR', '1') != '0'
 _INLINE = int(os.environ.get('VG_WGRAD_INLINE', '3'))      # encoder blocks <= this and the stem; sweep with the DMA weight gradients: off 24.96, 1: 24.92, 2: 24.74, 3: 24.59, 4: 24.62 ms
+_PAIR_BWD = os.environ.get('VG_PAIR_BWD', '1') != '0'       # one 2B-sample backward sweep per generator (both applications) instead of two
 NETS = ['gen_IS', 'gen_SI', 'disc_I', 'disc_S']
 
 
@@ -216,21 +217,39 @@ class VanGan:
         mmS, nS = ar.alloc((B, 4), f32), ar.alloc(vol, f32)
         ops.minmax(rS, B, S, mmS); ops.minmax_apply(rS, mmS, B, S, nS)                   # lane A, first thing: lane B needs nS at 5.8 ms
         ev_nS = main.record_event() if lane_b is not None else None
+        # Both applications of a generator share 2B-sample tensors (Arena paired mode): the forward passes are B-sample launches on
+        # the two sample halves, the backward runs ONE 2B-sample sweep per generator instead of two B-sample sweeps (half the
+        # launches, twice the work per launch on the latency-bound deep levels, the weight gradients' slab writes once for both).
+        pair = do_backward and _PAIR_BWD
+        def paired(key, slot):
+            if pair:
+                ar.pair_begin(key, slot)
         self._need('gen_IS')
+        paired('gen_IS', 0)
         c1 = self.gen_IS.forward(ar, rI, fake_S)                     # vangan.py:295   (lane A)
+        ar.pair_end()
         self._mark('A G1 fwd')
         with laneB():
             self._need('gen_SI')
+            paired('gen_SI', 0)
             c2 = self.gen_SI.forward(ar, rS, fake_I)                 # :297            (lane B)
+            ar.pair_end()
             ev_fakeI = lane_b.record_event() if lane_b is not None else None
             self._mark('B G1 fwd')
         self._need('gen_SI')
+        paired('gen_SI', 1)
         c4 = self.gen_SI.forward(ar, fake_S, cyc_I)                  # :305            (lane A)
+        ar.pair_end()
         self._mark('A G2 fwd')
         with laneB():
             self._need('gen_IS')
+            paired('gen_IS', 1)
             c3 = self.gen_IS.forward(ar, fake_I, cyc_S)              # :300            (lane B)
+            ar.pair_end()
             self._mark('B G2 fwd')
+        # upstream gradients of the two applications, adjacent: [adversarial (through the discriminator); cycle]
+        gS2 = ar.alloc((2 * B, D, H, W, 1), f32) if do_backward else None
+        gI2 = ar.alloc((2 * B, D, H, W, 1), f32) if do_backward else None
 
         # ---- cycle / segmentation losses on cycled_S (loss_functions.py:185-190, 211-226): lane B; target skeleton: lane A ----
         imgs_t, skels_t = ar.alloc((it + 2,) + vol, f32), ar.alloc((it + 1,) + vol, f32)
@@ -259,13 +278,13 @@ class VanGan:
                 ops.cldice_grads(nS, skel_t, coef, gskel, g_ncS, accumulate=True)
                 work = ar.alloc((3,) + vol, f32)
                 ops.soft_skel_bwd(imgs_p, skels_p, gskel, dims4, it, work, g_ncS)
-                g_cS = ar.alloc(vol, f32)
+                g_cS = gS2[B:]
                 tmp2 = ar.alloc((B, 2), f32, zero=True)
                 ops.minmax_bwd(cyc_S, ncS, g_ncS, mmcS, B, S, tmp2, g_cS)
             self._mark('B clDice')
 
         # ---- cycle MSE + SSIM reconstruction on cycled_I (loss_functions.py:179-180, 193-208) ----
-        g_cI = ar.alloc(vol, f32) if do_backward else None
+        g_cI = gI2[B:] if do_backward else None
         ops.mse(rI, cyc_I, acc[1:2], self.lambda_cycle / (S * gbs), g_cI, accumulate=False)
         mmI, mmcI = ar.alloc((B, 4), f32), ar.alloc((B, 4), f32)
         nI, ncI = ar.alloc(vol, f32), ar.alloc(vol, f32)
@@ -325,7 +344,7 @@ class VanGan:
             # Backward lanes: lane A = D_S sweeps + both gen_IS applications, lane B = D_I sweeps + both gen_SI applications
             # (total_loss_I only reaches gen_IS, total_loss_S only gen_SI; each lane accumulates into its own networks'
             # gradient buffers).  Per network: D loss over [real;fake] (weights), generator loss through the fake half.
-            g_fS, g_fI = ar.alloc(vol, f32), ar.alloc(vol, f32)
+            g_fS, g_fI = gS2[:B], gI2[:B]
             arB = ar
             if lane_b is not None:
                 arB = self.arena_b
@@ -354,10 +373,14 @@ class VanGan:
             mkb = arB.mark()
 
             def a_adv():
+                if pair:
+                    return
                 self.gen_IS.backward(ar, c1, g_fS); ar.release(mk, defer=True)        # adversarial application
                 self._mark('A G adv bwd')
 
             def b_adv():
+                if pair:
+                    return
                 with laneB():
                     self.gen_SI.backward(arB, c2, g_fI); arB.release(mkb, defer=True)
                     self._mark('B G adv bwd')
@@ -365,7 +388,11 @@ class VanGan:
             def a_cyc():
                 if ev_bfwd is not None:
                     main.wait_event(ev_bfwd)                                          # c3 and g_cS are lane B's
-                self.gen_IS.backward(ar, c3, g_cS, inline_from=_INLINE); ar.release(mk, defer=True)    # cycle application
+                if pair:                # both applications in one 2B-sample sweep: [adversarial; cycle]
+                    cc = pair_ctx(ar, c1, bufI, (fake_S, cyc_S), self.gen_IS.lv[0])
+                    self.gen_IS.backward(ar, cc, gS2, inline_from=_INLINE); ar.release(mk, defer=True)
+                else:
+                    self.gen_IS.backward(ar, c3, g_cS, inline_from=_INLINE); ar.release(mk, defer=True)    # cycle application
                 self._mark('A G cyc bwd')
                 self._start_allreduce(['gen_IS'], lazy=apply)
                 if apply:
@@ -373,7 +400,11 @@ class VanGan:
 
             def b_cyc():
                 with laneB():
-                    self.gen_SI.backward(arB, c4, g_cI, inline_from=_INLINE); arB.release(mkb, defer=True)
+                    if pair:
+                        cc = pair_ctx(ar, c2, bufS, (fake_I, cyc_I), self.gen_SI.lv[0])
+                        self.gen_SI.backward(arB, cc, gI2, inline_from=_INLINE); arB.release(mkb, defer=True)
+                    else:
+                        self.gen_SI.backward(arB, c4, g_cI, inline_from=_INLINE); arB.release(mkb, defer=True)
                     self._mark('B G cyc bwd')
                     self._start_allreduce(['gen_SI'], lazy=apply)
                     if apply:
