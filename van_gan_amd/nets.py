@@ -177,6 +177,16 @@ class Norm:
         return st
 
 
+def run_to_end(it):
+    """Exhaust a generator and return its value (the *_iter methods of the networks are generators so that the engine can enqueue
+    two of them alternately; called directly they run in one go)."""
+    try:
+        while True:
+            next(it)
+    except StopIteration as e:
+        return e.value
+
+
 def pair_ctx(ar: Arena, ctx: dict, x_full: torch.Tensor, ys, lv0) -> dict:
     """The backward context of BOTH applications of a generator whose forward passes ran in the arena's paired mode
     (Arena.pair_begin): ctx is the first application's context; every stored tensor is replaced by the 2N-sample tensor it is the
@@ -317,6 +327,12 @@ class ResUNet:
     def forward(self, ar: Arena, x: torch.Tensor, y: torch.Tensor, save: bool = True) -> dict:
         """x: fp32 [N,D,H,W,1]; y: fp32 [N,D,H,W,1] output buffer (tanh).  Returns the context for backward
         (save=True) or a stub (save=False: forward-only, block temporaries are recycled -- sliding-window inference)."""
+        return run_to_end(self.forward_iter(ar, x, y, save))
+
+    def forward_iter(self, ar: Arena, x: torch.Tensor, y: torch.Tensor, save: bool = True):
+        """forward() as a generator that yields between blocks: the host enqueues ~60 launches per application, and two
+        applications on two stream lanes enqueued one after the other leave the second lane idle for the first one's whole enqueue
+        time; the engine steps two of these alternately (vangan.interleave)."""
         N = x.shape[0]
         f, lv, L, Nn = GEN_F, self.lv, self.L, self.Nn
         ctx = {'N': N, 'x': x, 'y': y}
@@ -331,6 +347,7 @@ class ResUNet:
         h = Act(ar, N, lv[0], f[0], dtype=self.dtype)
         L['stem.cb'].forward(s1, h.data, sums=h.sums, res=sc.data, res_scale=ns['scale'], res_shift=ns['shift'])
         ctx['stem'] = dict(sx=sx, c1=c1, sc=sc, ns=ns, n1=n1, s1=s1, out=h)
+        yield
         skips = [h]
         for e in range(1, 5):
             raw = Src(h.data, (N,) + lv[e - 1], f[e - 1])
@@ -338,6 +355,7 @@ class ResUNet:
             if save:
                 ctx['enc%d' % e]['inp'] = (skips[-1],)
             skips.append(h)
+            yield
         nb1 = Nn['bridge.cb1'].finalize(ar, h)
         sb1 = Src(h.data, (N,) + lv[4], f[4], scale=nb1['scale'], shift=nb1['shift'], act=ACT_RELU)
         b1 = Act(ar, N, lv[4], f[4], dtype=self.dtype)
@@ -352,6 +370,7 @@ class ResUNet:
             skip = skips[d]
             raw = Src(h.data, (N,) + lv[d], h.C, skip.data, skip.C, shift0=1)       # virtual upsample + concat
             low = h
+            yield
             h = self._block_fwd(ar, 'dec%d' % d, N, raw, (low, skip), lv[d], f[d], ctx, save)
             if save:
                 ctx['dec%d' % d]['inp'] = (low, skip)
@@ -425,6 +444,9 @@ class ResUNet:
         ar.release(mk, defer=True)
 
     def backward(self, ar: Arena, ctx: dict, gy: torch.Tensor, inline_from: int = -1):
+        run_to_end(self.backward_iter(ar, ctx, gy, inline_from))
+
+    def backward_iter(self, ar: Arena, ctx: dict, gy: torch.Tensor, inline_from: int = -1):
         """gy: fp32 [N,D,H,W,1] gradient w.r.t. the tanh output.  Adds parameter gradients into store.g.
         inline_from (the LAST sweep of a lane): the weight gradients of encoder blocks <= inline_from and of the stem are launched on
         the lane itself instead of its side stream -- at the end of a step the side stream is a couple of milliseconds behind the
@@ -450,6 +472,7 @@ class ResUNet:
         L['out'].dgrad(dpre, N, h.grad, accumulate=not h.first_write())
         for d in (0, 1, 2, 3):
             self._block_bwd(ar, 'dec%d' % d, ctx['dec%d' % d], N)
+            yield
         # bridge
         b = ctx['bridge']
         mk = ar.mark()
@@ -465,9 +488,11 @@ class ResUNet:
         self._norm_bwd(ar, dp, True, b['sb1'], b['nb1'], Nn['bridge.cb1'], b['inp'].grad, ACT_RELU, accumulate=not b['inp'].first_write())
         ar.release(mk, defer=True)
         for e in (4, 3, 2, 1):
-            if e <= inline_from:
-                ops.WGRAD_INLINE = True          # (see backward(): the sweep's last weight gradients on the lane itself)
+            yield                                # (ops.WGRAD_INLINE is a module flag: it is off whenever another sweep may run)
+            ops.WGRAD_INLINE = e <= inline_from  # (see backward(): the sweep's last weight gradients on the lane itself)
             self._block_bwd(ar, 'enc%d' % e, ctx['enc%d' % e], N)
+            ops.WGRAD_INLINE = False
+        yield
         if inline_from >= 0:
             ops.WGRAD_INLINE = True
         # stem

@@ -281,16 +281,21 @@ class Arena:
         self.peak = 0
         self.lazy_ok = True         # False: this arena is shared by sweeps of both lanes (VG_LANES=0), so release() always recycles
         self.zpool.zero_()
-        self._pair, self._pairs, self._pair_pos, self._full = None, {}, 0, {}
+        self._pair, self._pairs, self._pair_pos, self._full = None, {}, {}, {}
 
     # Paired allocation (the two applications of one generator in a train step): while pair_begin(key, 0) is active every
     # non-zeroed allocation [N, ...] reserves [2N, ...] and returns the first half; pair_begin(key, 1) replays the SAME allocation
     # sequence and returns the second halves.  The forward passes stay ordinary N-sample launches on contiguous sample slices, the
     # backward sweep runs ONCE over the 2N-sample tensors (full_of maps a first-half view to its whole).
     def pair_begin(self, key, slot: int):
-        self._pair, self._pair_pos = (key, slot), 0
+        self._pair = (key, slot)
+        self._pair_pos[key] = 0
         if slot == 0:
             self._pairs[key] = []
+
+    def pair_resume(self, key, slot: int):
+        """Continue the sequence of (key, slot) after other allocations (two forward passes enqueued alternately)."""
+        self._pair = (key, slot)
 
     def pair_end(self):
         self._pair = None
@@ -299,7 +304,7 @@ class Arena:
         return None if t is None else self._full.get(t.data_ptr())
 
     def reset(self):
-        self._pair, self._pairs, self._pair_pos, self._full = None, {}, 0, {}
+        self._pair, self._pairs, self._pair_pos, self._full = None, {}, {}, {}
         self.off = 0
         if self.zoff:
             self.zpool[:self.zoff].zero_()
@@ -318,8 +323,8 @@ class Arena:
                 self._pairs[key].append(full)
                 self._full[full.data_ptr()] = full
                 return full[:shape[0]]
-            full = self._pairs[key][self._pair_pos]
-            self._pair_pos += 1
+            full = self._pairs[key][self._pair_pos[key]]
+            self._pair_pos[key] += 1
             assert tuple(full.shape) == (2 * shape[0],) + shape[1:] and full.dtype == dtype, 'paired allocation sequences differ'
             return full[shape[0]:]
         n = int(math.prod(shape))

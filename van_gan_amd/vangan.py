@@ -22,11 +22,32 @@ from .ops import Arena
 
 RESULT_KEYS = ['total_IS_loss', 'total_SI_loss', 'D_I_loss', 'D_S_loss', 'gen_IS_loss', 'gen_SI_loss',
                'cycle_gen_SIS_loss', 'cycle_gen_ISI_loss', 'seg_loss', 'reconstruction_loss_I']
-_BFIRST = int(os.environ.get('VG_BFIRST', '0'))
+_BFIRST = int(os.environ.get('VG_BFIRST', '5'))       # re-swept with the paired sweeps: 0: 22.27, 4: 21.98, 5: 21.83 ms
 _NOJOIN = os.environ.get('VG_NOJOIN', '1') != '0'
 _LAZY_AR = os.environ.get('VG_LAZY_AR', '1') != '0'
 _INLINE = int(os.environ.get('VG_WGRAD_INLINE', '3'))      # encoder blocks <= this and the stem; sweep with the DMA weight gradients: off 24.96, 1: 24.92, 2: 24.74, 3: 24.59, 4: 24.62 ms
 _PAIR_BWD = os.environ.get('VG_PAIR_BWD', '1') != '0'       # one 2B-sample backward sweep per generator (both applications) instead of two
+_INTERLEAVE = os.environ.get('VG_INTERLEAVE', '0') != '0'   # the two lanes' enqueue sequences alternate block by block on the host: measured neutral (21.69 vs 21.63 ms), off
+
+
+def interleave(*seqs, on=True):
+    """seqs: (stream context factory, generator).  Steps the generators alternately, each inside its stream context, until all
+    are exhausted; returns their values.  on=False: one after the other."""
+    vals = [None] * len(seqs)
+    live = list(range(len(seqs)))
+    while live:
+        for i in list(live):
+            ctxf, gen = seqs[i]
+            with ctxf():
+                try:
+                    while True:
+                        next(gen)
+                        if on:
+                            break
+                except StopIteration as e:
+                    vals[i] = e.value
+                    live.remove(i)
+    return vals
 NETS = ['gen_IS', 'gen_SI', 'disc_I', 'disc_S']
 
 
@@ -221,31 +242,38 @@ class VanGan:
         # the two sample halves, the backward runs ONE 2B-sample sweep per generator instead of two B-sample sweeps (half the
         # launches, twice the work per launch on the latency-bound deep levels, the weight gradients' slab writes once for both).
         pair = do_backward and _PAIR_BWD
-        def paired(key, slot):
+        def fwd(gen, key, slot, x, y):
+            """A generator application as a resumable enqueue sequence; its allocations go to the paired slot (key, slot)."""
+            it = gen.forward_iter(ar, x, y)
             if pair:
-                ar.pair_begin(key, slot)
-        self._need('gen_IS')
-        paired('gen_IS', 0)
-        c1 = self.gen_IS.forward(ar, rI, fake_S)                     # vangan.py:295   (lane A)
-        ar.pair_end()
+                ar.pair_begin(key, slot); ar.pair_end()
+            def steps():
+                while True:
+                    if pair:
+                        ar.pair_resume(key, slot)
+                    try:
+                        next(it)
+                    except StopIteration as e:
+                        return e.value
+                    finally:
+                        ar.pair_end()
+                    yield
+            return steps()
+        # (VG_INTERLEAVE=1 enqueues the two lanes' sequences ALTERNATELY, block by block -- the idea: enqueued one after the other, the
+        # second lane's stream sits empty for the first one's enqueue time.  Measured neutral: the host runs far enough ahead.)
+        self._need('gen_IS'); self._need('gen_SI')
+        with laneB():
+            self._need('gen_SI'); self._need('gen_IS')
+        c1, c2 = interleave((contextlib.nullcontext, fwd(self.gen_IS, 'gen_IS', 0, rI, fake_S)),       # vangan.py:295   (lane A)
+                            (laneB, fwd(self.gen_SI, 'gen_SI', 0, rS, fake_I)), on=_INTERLEAVE)           # :297            (lane B)
         self._mark('A G1 fwd')
         with laneB():
-            self._need('gen_SI')
-            paired('gen_SI', 0)
-            c2 = self.gen_SI.forward(ar, rS, fake_I)                 # :297            (lane B)
-            ar.pair_end()
             ev_fakeI = lane_b.record_event() if lane_b is not None else None
             self._mark('B G1 fwd')
-        self._need('gen_SI')
-        paired('gen_SI', 1)
-        c4 = self.gen_SI.forward(ar, fake_S, cyc_I)                  # :305            (lane A)
-        ar.pair_end()
+        c4, c3 = interleave((contextlib.nullcontext, fwd(self.gen_SI, 'gen_SI', 1, fake_S, cyc_I)),     # :305            (lane A)
+                            (laneB, fwd(self.gen_IS, 'gen_IS', 1, fake_I, cyc_S)), on=_INTERLEAVE)        # :300            (lane B)
         self._mark('A G2 fwd')
         with laneB():
-            self._need('gen_IS')
-            paired('gen_IS', 1)
-            c3 = self.gen_IS.forward(ar, fake_I, cyc_S)              # :300            (lane B)
-            ar.pair_end()
             self._mark('B G2 fwd')
         # upstream gradients of the two applications, adjacent: [adversarial (through the discriminator); cycle]
         gS2 = ar.alloc((2 * B, D, H, W, 1), f32) if do_backward else None
@@ -388,11 +416,7 @@ class VanGan:
             def a_cyc():
                 if ev_bfwd is not None:
                     main.wait_event(ev_bfwd)                                          # c3 and g_cS are lane B's
-                if pair:                # both applications in one 2B-sample sweep: [adversarial; cycle]
-                    cc = pair_ctx(ar, c1, bufI, (fake_S, cyc_S), self.gen_IS.lv[0])
-                    self.gen_IS.backward(ar, cc, gS2, inline_from=_INLINE); ar.release(mk, defer=True)
-                else:
-                    self.gen_IS.backward(ar, c3, g_cS, inline_from=_INLINE); ar.release(mk, defer=True)    # cycle application
+                self.gen_IS.backward(ar, c3, g_cS, inline_from=_INLINE); ar.release(mk, defer=True)    # cycle application
                 self._mark('A G cyc bwd')
                 self._start_allreduce(['gen_IS'], lazy=apply)
                 if apply:
@@ -400,22 +424,39 @@ class VanGan:
 
             def b_cyc():
                 with laneB():
-                    if pair:
-                        cc = pair_ctx(ar, c2, bufS, (fake_I, cyc_I), self.gen_SI.lv[0])
-                        self.gen_SI.backward(arB, cc, gI2, inline_from=_INLINE); arB.release(mkb, defer=True)
-                    else:
-                        self.gen_SI.backward(arB, c4, g_cI, inline_from=_INLINE); arB.release(mkb, defer=True)
+                    self.gen_SI.backward(arB, c4, g_cI, inline_from=_INLINE); arB.release(mkb, defer=True)
                     self._mark('B G cyc bwd')
                     self._start_allreduce(['gen_SI'], lazy=apply)
                     if apply:
                         self._schedule_update('gen_SI')
 
             # host enqueue order per stage (bit i of VG_BFIRST: lane B's sweep of stage i is enqueued before lane A's)
-            for i, (fa, fb) in enumerate(((a_disc, b_disc), (a_adv, b_adv), (a_cyc, b_cyc))):
+            stages = ((a_disc, b_disc), (a_adv, b_adv)) if pair else ((a_disc, b_disc), (a_adv, b_adv), (a_cyc, b_cyc))
+            for i, (fa, fb) in enumerate(stages):
                 if (_BFIRST >> i) & 1:
                     fb(); fa()
                 else:
                     fa(); fb()
+            if pair:
+                # the generators' 2B-sample sweeps over both applications ([adversarial; cycle]), enqueued alternately block by block
+                if ev_bfwd is not None:
+                    main.wait_event(ev_bfwd)                                          # c3 and g_cS are lane B's
+                ccA = pair_ctx(ar, c1, bufI, (fake_S, cyc_S), self.gen_IS.lv[0])
+                ccB = pair_ctx(ar, c2, bufS, (fake_I, cyc_I), self.gen_SI.lv[0])
+                order = ((laneB, self.gen_SI.backward_iter(arB, ccB, gI2, inline_from=_INLINE)),
+                         (contextlib.nullcontext, self.gen_IS.backward_iter(ar, ccA, gS2, inline_from=_INLINE)))
+                interleave(*(order if (_BFIRST >> 2) & 1 else order[::-1]), on=_INTERLEAVE)
+                ar.release(mk, defer=True)
+                self._mark('A G cyc bwd')
+                self._start_allreduce(['gen_IS'], lazy=apply)
+                if apply:
+                    self._schedule_update('gen_IS')
+                with laneB():
+                    arB.release(mkb, defer=True)
+                    self._mark('B G cyc bwd')
+                    self._start_allreduce(['gen_SI'], lazy=apply)
+                    if apply:
+                        self._schedule_update('gen_SI')
             if lane_b is not None:
                 with laneB():
                     ops.side_join()                 # lane B's weight gradients (its lane no longer waits for them on the way)
