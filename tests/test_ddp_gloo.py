@@ -44,7 +44,11 @@ def _worker(rank, world, port, out):
             stores[k].grad(n).copy_(grads[k][n])
     sync = GradSync({k: s.g for k, s in stores.items()}, dist.group.WORLD, {k: s.w for k, s in stores.items()})
     sync.broadcast_weights(0)
-    sync.start(['disc_I', 'disc_S']); sync.start(['gen_IS']); sync.start(['gen_SI'])
+    # gen_IS in two pieces, as the engine does it: the suffix a backward sweep finishes first (enc4 ... output head), then the rest
+    off = stores['gen_IS'].offsets['enc4.cb1.in.gamma'][0]
+    assert 0 < off < stores['gen_IS'].total and off % 4 == 0
+    sync.start(['disc_I', 'disc_S']); sync.start(['gen_IS'], lo=off); sync.start(['gen_IS'], hi=off); sync.start(['gen_SI'])
+    assert len(sync.pending['gen_IS']) == 2
     # per-bucket completion: a network's optimizer step waits for ITS bucket only
     sync.finish(['disc_S'])
     assert 'disc_S' not in sync.pending and {'disc_I', 'gen_IS', 'gen_SI'} <= set(sync.pending)

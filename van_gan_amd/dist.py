@@ -22,15 +22,20 @@ class GradSync:
         dev = next(iter(buckets.values())).device
         self.cuda = dev.type == 'cuda'
         self.stream = torch.cuda.Stream(device=dev) if (self.cuda and self.world > 1) else None
-        self.pending: Dict[str, object] = {}        # bucket name -> CUDA event on the comm stream / async work handle
+        self.pending: Dict[str, list] = {}          # bucket name -> CUDA events on the comm stream / async work handles (one per piece)
         self.rank = dist.get_rank(process_group) if process_group is not None else 0
 
-    def start(self, names: Iterable[str], also=None):
+    def start(self, names: Iterable[str], also=None, lo: int = 0, hi: Optional[int] = None):
         """Issue the all-reduce of these buckets; on GPU it runs on the side stream behind everything already queued
         on the current stream (and behind the event `also`: the weight gradients a lane handed to ITS side stream), so the
-        remaining backward sweeps overlap with it."""
+        remaining backward sweeps overlap with it.
+        lo / hi: only the elements [lo, hi) of the flat bucket (one name).  A backward sweep completes a generator's gradients from
+        the END of the flat buffer towards its start (output head, decoder, bridge, encoder, stem -- the reverse of the parameter
+        order), so the engine reduces a finished suffix while the sweep is still running; finish(name) waits for every piece."""
         if self.world == 1:
             return
+        names = list(names)
+        assert (lo == 0 and hi is None) or len(names) == 1
         if self.stream is not None:
             ev = torch.cuda.Event()
             ev.record()
@@ -39,13 +44,13 @@ class GradSync:
                 self.stream.wait_event(also)
             with torch.cuda.stream(self.stream):
                 for n in names:
-                    dist.all_reduce(self.buckets[n], op=dist.ReduceOp.SUM, group=self.pg)
+                    dist.all_reduce(self.buckets[n][lo:hi], op=dist.ReduceOp.SUM, group=self.pg)
                     done = torch.cuda.Event()
                     done.record()
-                    self.pending[n] = done
+                    self.pending.setdefault(n, []).append(done)
         else:
             for n in names:
-                self.pending[n] = dist.all_reduce(self.buckets[n], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+                self.pending.setdefault(n, []).append(dist.all_reduce(self.buckets[n][lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
     def finish(self, names: Optional[Iterable[str]] = None):
         """The current stream (GPU) / the host (CPU tensors) waits until the reduced buckets `names` (default: all that
@@ -54,13 +59,11 @@ class GradSync:
         if self.world == 1:
             return
         for n in (list(self.pending) if names is None else list(names)):
-            h = self.pending.pop(n, None)
-            if h is None:
-                continue
-            if self.stream is not None:
-                torch.cuda.current_stream().wait_event(h)
-            else:
-                h.wait()
+            for h in self.pending.pop(n, []):
+                if self.stream is not None:
+                    torch.cuda.current_stream().wait_event(h)
+                else:
+                    h.wait()
 
     def reduce_dict(self, d: Dict[str, float], keys: List[str]) -> Dict[str, float]:
         """vangan.py:472-473: strategy.reduce(SUM) of every result scalar."""

@@ -446,7 +446,12 @@ class ResUNet:
     def backward(self, ar: Arena, ctx: dict, gy: torch.Tensor, inline_from: int = -1):
         run_to_end(self.backward_iter(ar, ctx, gy, inline_from))
 
-    def backward_iter(self, ar: Arena, ctx: dict, gy: torch.Tensor, inline_from: int = -1):
+    def grad_suffix_offset(self, first_param: str = 'enc4.cb1.in.gamma') -> int:
+        """Offset of `first_param` in the flat parameter / gradient buffer: everything from there to the end (enc4, bridge, decoder,
+        output head: 34 of the 38 MB) is complete once the backward sweep has finished block enc4."""
+        return self.store.offsets[first_param][0]
+
+    def backward_iter(self, ar: Arena, ctx: dict, gy: torch.Tensor, inline_from: int = -1, on_suffix_done=None):
         """gy: fp32 [N,D,H,W,1] gradient w.r.t. the tanh output.  Adds parameter gradients into store.g.
         inline_from (the LAST sweep of a lane): the weight gradients of encoder blocks <= inline_from and of the stem are launched on
         the lane itself instead of its side stream -- at the end of a step the side stream is a couple of milliseconds behind the
@@ -492,6 +497,8 @@ class ResUNet:
             ops.WGRAD_INLINE = e <= inline_from  # (see backward(): the sweep's last weight gradients on the lane itself)
             self._block_bwd(ar, 'enc%d' % e, ctx['enc%d' % e], N)
             ops.WGRAD_INLINE = False
+            if e == 4 and on_suffix_done is not None:
+                on_suffix_done()                 # gradients of enc4 ... output head are complete (data parallel: reduce them now)
         yield
         if inline_from >= 0:
             ops.WGRAD_INLINE = True

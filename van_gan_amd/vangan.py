@@ -27,6 +27,7 @@ _NOJOIN = os.environ.get('VG_NOJOIN', '1') != '0'
 _LAZY_AR = os.environ.get('VG_LAZY_AR', '1') != '0'
 _INLINE = int(os.environ.get('VG_WGRAD_INLINE', '3'))      # encoder blocks <= this and the stem; sweep with the DMA weight gradients: off 24.96, 1: 24.92, 2: 24.74, 3: 24.59, 4: 24.62 ms
 _PAIR_BWD = os.environ.get('VG_PAIR_BWD', '1') != '0'       # one 2B-sample backward sweep per generator (both applications) instead of two
+_AR_SPLIT = os.environ.get('VG_AR_SPLIT', '1') != '0'       # world > 1: a generator's finished gradient suffix is all-reduced while its sweep still runs
 _INTERLEAVE = os.environ.get('VG_INTERLEAVE', '0') != '0'   # the two lanes' enqueue sequences alternate block by block on the host: measured neutral (21.69 vs 21.63 ms), off
 
 
@@ -443,18 +444,25 @@ class VanGan:
                     main.wait_event(ev_bfwd)                                          # c3 and g_cS are lane B's
                 ccA = pair_ctx(ar, c1, bufI, (fake_S, cyc_S), self.gen_IS.lv[0])
                 ccB = pair_ctx(ar, c2, bufS, (fake_I, cyc_I), self.gen_SI.lv[0])
-                order = ((laneB, self.gen_SI.backward_iter(arB, ccB, gI2, inline_from=_INLINE)),
-                         (contextlib.nullcontext, self.gen_IS.backward_iter(ar, ccA, gS2, inline_from=_INLINE)))
+                # data parallel: the finished suffix of a generator's gradient bucket (enc4 ... output head, 34 of 38 MB) goes to the
+                # all-reduce when the sweep has passed enc4 -- with ~40 % of the sweep still ahead; only the last 4 MB wait for its end
+                split = self.pg is not None and apply and _AR_SPLIT
+                def early(name, gen):
+                    return (lambda: self._start_allreduce([name], lazy=apply, lo=gen.grad_suffix_offset())) if split else None
+                order = ((laneB, self.gen_SI.backward_iter(arB, ccB, gI2, inline_from=_INLINE, on_suffix_done=early('gen_SI', self.gen_SI))),
+                         (contextlib.nullcontext, self.gen_IS.backward_iter(ar, ccA, gS2, inline_from=_INLINE, on_suffix_done=early('gen_IS', self.gen_IS))))
                 interleave(*(order if (_BFIRST >> 2) & 1 else order[::-1]), on=_INTERLEAVE)
+                hiA = self.gen_IS.grad_suffix_offset() if split else None
+                hiB = self.gen_SI.grad_suffix_offset() if split else None
                 ar.release(mk, defer=True)
                 self._mark('A G cyc bwd')
-                self._start_allreduce(['gen_IS'], lazy=apply)
+                self._start_allreduce(['gen_IS'], lazy=apply, hi=hiA)
                 if apply:
                     self._schedule_update('gen_IS')
                 with laneB():
                     arB.release(mkb, defer=True)
                     self._mark('B G cyc bwd')
-                    self._start_allreduce(['gen_SI'], lazy=apply)
+                    self._start_allreduce(['gen_SI'], lazy=apply, hi=hiB)
                     if apply:
                         self._schedule_update('gen_SI')
             if lane_b is not None:
@@ -483,7 +491,7 @@ class VanGan:
         return dict(zip(RESULT_KEYS, vals))
 
     # ------------------------------------------------------------------------------------------------
-    def _start_allreduce(self, names, lazy: bool = False):
+    def _start_allreduce(self, names, lazy: bool = False, lo: int = 0, hi=None):
         """The gradient buckets `names` are complete once the current lane AND its weight-gradient side stream have run what was
         issued so far.  lazy (an optimizer step follows on the optimizer stream): the lane itself does not wait for its side
         stream -- the all-reduce stream and the optimizer stream do (it used to stall, e.g. between the two discriminator sweeps,
@@ -492,10 +500,10 @@ class VanGan:
             ev = ops.side_event()
             for n in names:
                 self._side_ev[n] = ev
-            self.sync.start(names, also=ev)
+            self.sync.start(names, also=ev, lo=lo, hi=hi)
             return
         ops.side_join()                     # the weight gradients of these networks were issued on the side stream
-        self.sync.start(names)
+        self.sync.start(names, lo=lo, hi=hi)
 
     def _finish_allreduce(self):
         self.sync.finish()
