@@ -56,10 +56,13 @@ def main():
     ap.add_argument('--size', type=int, default=128)
     ap.add_argument('--layers', default='')
     ap.add_argument('--quick', action='store_true')
+    ap.add_argument('--gen-batch', type=int, default=2, help='samples of the generator layers (2: the paired backward sweep at batch 1)')
     args = ap.parse_args()
     dev = torch.device('cuda:0')
     S = args.size
     for name, k, cin, cout, stride, pad, lv, cat, N in layers(S):
+        if not name.startswith('D.'):
+            N = args.gen_batch
         if args.layers and not any(t in name for t in args.layers.split(',')):
             continue
         dims = (S >> lv,) * 3
