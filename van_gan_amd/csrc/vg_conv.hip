@@ -940,12 +940,13 @@ static int launch_conv3(const GatherIn& g, const ConvOut& k, const ConvCls& q, i
         for (int c = k.nchunks; c >= 2; --c)
             if (k.nchunks % c == 0 && c <= cap && cells * c <= 1024 && cells * c * SLOTB <= VG_KS_PART_BYTES) { ks = c; break; }
     }
-    dim3 grid(bx * ncp * ks, ny, g.N);
     if (vg_dry("conv<%s,%d,%d,n%d,wl%d,dma%d,mc%d,c1%d>|walk%d|ch%d|ks%d", sizeof(T) == 4 ? "f32" : "bf16", BN, MSUB, (int)NOISE, (int)WL, (int)DMA,
                MC, (int)C1, tiles > bx ? 1 : 0, k.nchunks > 1 ? 1 : 0, ks)) return VG_OK;
     ConvOut k2 = k;
     k2.ks = ks; k2.ks_part = nullptr; k2.ks_cnt = nullptr;
-    if (ks > 1) { const int rc = vg_ks_scratch(s, &k2.ks_part, &k2.ks_cnt); if (rc != VG_OK) return rc; }
+    // no scratch for this stream (allocation failed, or more than 32 streams have used the split): the launch runs unsplit
+    if (ks > 1 && vg_ks_scratch(s, &k2.ks_part, &k2.ks_cnt) != VG_OK) { (void)hipGetLastError(); k2.ks = ks = 1; k2.ks_part = nullptr; k2.ks_cnt = nullptr; }
+    dim3 grid(bx * ncp * ks, ny, g.N);
     hipLaunchKernelGGL((conv_kernel<T, BN, MSUB, NOISE, WL, DMA, MC, C1>), grid, dim3(256), lds, s, g, k2, q);
     return vg_check_launch();
 }
