@@ -54,9 +54,10 @@ def cpu_baseline(budget_s=12.0):
             break
     sps = n / el
     return {'value': sps * B * dims[0] * dims[1] * dims[2] / 1e6, 'unit': 'Mvoxels/s', 'steps_per_s': sps,
-            'cores': torch.get_num_threads(), 'kind': 'port',
+            'cores': torch.get_num_threads(), 'host_cpu_count': os.cpu_count(), 'kind': 'port',
             'sample': 'oracle.train_step (fp32 torch-CPU restatement of the reference graph, not TensorFlow) at '
-                      '32x32x32 batch 1, %d steps in %.1f s on %d host threads' % (n, el, torch.get_num_threads())}
+                      '32x32x32 batch 1, %d steps in %.1f s on %d torch threads (torch.get_num_threads) of %s host CPUs (os.cpu_count)'
+                      % (n, el, torch.get_num_threads(), os.cpu_count())}
 
 
 def time_infer(eng, device, steps, warmup, precision):
@@ -78,6 +79,32 @@ def time_infer(eng, device, steps, warmup, precision):
     return {'workload': 'GanMonitor.stitch_subvolumes 256x256x128, 50 windows of 128^3, stride 50, pad 0.1 (BASELINE config 5)',
             'dtype': precision or 'bf16', 'ms_per_volume': el * 1e3, 'volumes_per_sec': 1.0 / el, 'Mvoxels_per_sec': 256 * 256 * 128 / el / 1e6,
             'generator_tflops': 50 * 2 * 149.65e9 / el / 1e12, 'windows': 50, 'steps': steps, 'finite': bool(torch.isfinite(out).all())}
+
+
+def time_config(dims, B, device, steps=3, warmup=3):
+    """BASELINE configs 2 and 3 beside the headline: a full train_step at another patch size / batch on a fresh engine
+    (same kernels, same schedule, noise + dropout + clDice on), timed like the headline loop."""
+    import torch
+    from van_gan_amd import VanGan
+    eng = VanGan(dims, batch_size=B, device=device, seed=0)
+    rI, rS = synth_on_device(B, dims, 1234, device)
+    for _ in range(warmup):
+        eng.train_step(rI, rS, sync=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = None
+    for i in range(steps):
+        res = eng.train_step(rI, rS, sync=(i == steps - 1))
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / steps
+    S = dims[0] * dims[1] * dims[2]
+    out = {'workload': 'VanGan.train_step, %dx%dx%d volumes, batch %d, bf16, clDice on, disc noise+dropout on' % (dims + (B,)),
+           'ms_per_step': el * 1e3, 'train_steps_per_sec': 1.0 / el, 'Mvoxels_per_sec': B * S / el / 1e6,
+           'whole_step_conv_tflops': B * S * CONV_FLOP_PER_VOXEL / el / 1e12, 'steps': steps, 'warmup': warmup,
+           'finite': all(v == v and abs(v) != float('inf') for v in res.values()), 'arena_peak_gb': eng.arena.peak / 1e9}
+    del eng
+    torch.cuda.empty_cache()
+    return out
 
 
 def bench_infer(args, device):
@@ -120,6 +147,8 @@ def main():
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--dump-kernels', default='', help='write the per-kernel-template table of the timing step (JSON) here')
     ap.add_argument('--infer', action='store_true', help='BASELINE config 5 instead: 256x256x128 sliding-window generator inference')
+    ap.add_argument('--no-configs', action='store_true', help='skip the configs array (BASELINE configs 2 and 3) of the default N=1 line')
+    ap.add_argument('--no-synced', action='store_true', help='skip the second timed loop that reads the 10 result scalars every step')
     ap.add_argument('--no-infer', action='store_true', help='skip the inference object (config 5) of the default N=1 line')
     args = ap.parse_args()
 
@@ -129,6 +158,9 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    if 'WORLD_SIZE' in os.environ and world != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d in the environment: a %d-rank figure must not be recorded as the '
+                         '%d-GPU scaling point (launch with --nproc-per-node %d, or unset WORLD_SIZE)' % (args.gpus, world, world, args.gpus, args.gpus))
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         # plain `python bench.py --gpus N` (the reference's main.py:22 MirroredStrategy is single-command too): start the
         # one-process-per-GPU job as a CHILD, before anything here has touched the GPU (never exec from a GPU process), and relay
@@ -183,6 +215,22 @@ def main():
     steps_per_s = args.steps / el
     mvox = steps_per_s * gbatch * S / 1e6
 
+    # the reference loop (vangan.py:540-543) and train.train() consume the 10 result scalars EVERY step: the same loop with the host
+    # reading them each step (one device->host copy + sync per step), reported beside the headline
+    ms_synced = None
+    if not args.no_synced:
+        ns = max(3, min(10, args.steps))
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t1 = time.perf_counter()
+        for i in range(ns):
+            eng.train_step(rI, rS, sync=True)
+        torch.cuda.synchronize()
+        ms_synced = (time.perf_counter() - t1) / ns * 1e3
+    configs = None
+    if rank == 0 and world == 1 and args.size == 128 and not args.no_configs:
+        configs = [time_config((64, 64, 64), 2, device), time_config((128, 128, 64), 2, device)]
     infer = None
     if rank == 0 and world == 1 and args.size == 128 and not args.no_infer:
         # BASELINE config 5 beside the headline: the same engine's gen_IS, fp16 storage (and the bf16 figure next to it)
@@ -265,6 +313,7 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
             'config': {'workload': 'VanGan.train_step, %dx%dx%d volumes, batch %d per GPU (global %d), clDice on, disc noise+dropout on'
                                    % (dims + (B, gbatch)), 'parallelism': 'dp%d' % world},
+            'ms_per_step_synced': ms_synced, 'configs': configs,
             'losses': res, 'roofline': roof, 'cpu_baseline': cpu, 'inference': infer,
             'arena_peak_gb': eng.arena.peak / 1e9,
         }

@@ -7,7 +7,8 @@
  *
  * Rules of the boundary:
  *   - every pointer is a DEVICE pointer owned by the caller, valid on `stream` for the call;
- *   - the library never allocates/frees device memory and never synchronises: enqueue-only;
+ *   - the library never allocates/frees device memory and never synchronises: enqueue-only (launch plans that need
+ *     device workspace take it from the caller: vg_conv_desc::scratch, the scratch argument of vg_conv3d_wgrad);
  *   - every entry returns 0 on success, <0 on error (vg_status_string); no exception or abort
  *     crosses the ABI;
  *   - activations are NDHWC (channel innermost). "bf16" buffers hold 16-bit brain floats.
@@ -127,7 +128,15 @@ typedef struct {
        Either way the striped sums in red are complete when the call returns; the caller then runs vg_actnorm_bwd_apply (which adds
        the stripes up and produces dgamma / dbeta). */
     const struct vg_actnorm_bwd_desc_s* bstat;
+    /* Optional caller-owned device workspace for launches on THIS stream (the library never allocates).  Bytes
+       [0, VG_SCRATCH_CTR_BYTES) are arrival counters: zeroed ONCE by the caller when it allocates the buffer, left at zero by every
+       launch.  The rest carries no state between launches (fp32 partial tiles of K-split launches, the materialised operand of the
+       LDS-DMA convolution).  Two launches may share a scratch only if they are ordered (same stream).  NULL or too small: the
+       library chooses launch plans that need none. */
+    void* scratch;
+    int64_t scratch_bytes;
 } vg_conv_desc;
+#define VG_SCRATCH_CTR_BYTES 16384
 
 int vg_conv3d(const vg_conv_desc* d, vg_stream_t stream);
 

@@ -107,3 +107,23 @@ def test_engine_refuses_to_run_without_gpu():
         pytest.skip('GPU present')
     with pytest.raises(RuntimeError):
         VanGan((32, 32, 32))
+
+
+def test_library_never_allocates_device_memory():
+    """Boundary contract (include/vangan_hip.h, SURVEY 8b 'Ownership'): the library is enqueue-only on caller-owned buffers.  Neither
+    build may even IMPORT an allocating / freeing / synchronising HIP entry point (undefined dynamic symbols of the built .so)."""
+    import subprocess
+    from van_gan_amd import build
+    banned = re.compile(r'\b(hipMalloc\w*|hipFree\w*|hipHostMalloc|hipMallocAsync|hipDeviceSynchronize|hipStreamSynchronize|hipMemcpy)\b')
+    for lib in (build.LIB, build.LIB_H):
+        out = subprocess.run(['nm', '-D', '--undefined-only', lib], stdout=subprocess.PIPE, check=True).stdout.decode()
+        assert 'hipLaunchKernel' in out or 'hipModuleLaunchKernel' in out or '__hipPushCallConfiguration' in out      # sanity: nm sees the HIP imports
+        hits = sorted(set(banned.findall(out)))
+        assert not hits, '%s imports %s: the library must not allocate, free or synchronise' % (os.path.basename(lib), hits)
+
+
+def test_conv_desc_scratch_fields_trail_the_struct():
+    from van_gan_amd._lib import ConvDesc, SCRATCH_CTR_BYTES
+    assert ConvDesc.scratch.offset == ConvDesc.bstat.offset + 8 and ConvDesc.scratch_bytes.offset == ConvDesc.scratch.offset + 8
+    hdr = open(os.path.join(ROOT, 'include', 'vangan_hip.h')).read()
+    assert int(re.search(r'#define VG_SCRATCH_CTR_BYTES (\d+)', hdr).group(1)) == SCRATCH_CTR_BYTES

@@ -13,6 +13,7 @@ from . import build as _build
 VG_MAX_TAPS = 64
 ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
 PAD_ZERO, PAD_REFLECT = 0, 1
+SCRATCH_CTR_BYTES = 16384          # VG_SCRATCH_CTR_BYTES
 
 c_void_p, c_int, c_float, c_i64, c_u64 = C.c_void_p, C.c_int32, C.c_float, C.c_int64, C.c_uint64
 
@@ -31,6 +32,7 @@ class ConvDesc(C.Structure):
         ('out', c_void_p), ('out_f32', c_int), ('accumulate', c_int), ('out_sums', c_void_p), ('f32', c_int),
         ('nclass', c_int), ('cls_tap0', c_int * 9), ('cls_w', c_void_p * 8), ('cls_ooff', (c_int * 3) * 8),
         ('cls_iters', (c_int * 3) * 8), ('wpack', c_int), ('wpack_wmin', c_int), ('bstat', c_void_p),
+        ('scratch', c_void_p), ('scratch_bytes', c_i64),
     ]
 
 

@@ -661,25 +661,10 @@ __global__ __launch_bounds__(256, 2) void conv32_kernel(const GatherIn g, const 
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-// K-split scratch: per stream (launches of one stream are ordered, launches of different streams may overlap) one device buffer
-// [VG_KS_CELLS arrival counters][VG_KS_PART_BYTES of partial tiles], allocated at the stream's first split launch and kept for the
-// life of the process.  The counters are zeroed once, on that stream; every launch leaves them at zero.
-#define VG_KS_CELLS 4096
-#define VG_KS_PART_BYTES (24L << 20)
-static int vg_ks_scratch(hipStream_t s, float** part, unsigned** cnt) {
-    struct Ent { hipStream_t s; char* p; };
-    static Ent pool[32];
-    static int npool = 0;
-    for (int i = 0; i < npool; ++i)
-        if (pool[i].s == s) { *cnt = (unsigned*)pool[i].p; *part = (float*)(pool[i].p + VG_KS_CELLS * 4); return VG_OK; }
-    if (npool == 32) return VG_EINVAL;
-    char* p = nullptr;
-    if (hipMalloc((void**)&p, VG_KS_CELLS * 4 + VG_KS_PART_BYTES) != hipSuccess) return VG_ELAUNCH;
-    if (hipMemsetAsync(p, 0, VG_KS_CELLS * 4, s) != hipSuccess) return VG_ELAUNCH;
-    pool[npool++] = Ent{s, p};
-    *cnt = (unsigned*)p; *part = (float*)(p + VG_KS_CELLS * 4);
-    return VG_OK;
-}
+// K-split scratch: the caller's vg_conv_desc::scratch of the issuing stream (launches of one stream are ordered, launches of
+// different streams may overlap and must not share it): [VG_SCRATCH_CTR_BYTES of arrival counters][fp32 partial tiles].  The
+// caller zeroes the counters once; every launch leaves them at zero.  No scratch (or too small a one): the launch runs unsplit.
+#define VG_KS_CELLS (VG_SCRATCH_CTR_BYTES / 4)
 
 static int conv_lds_bytes(const GatherIn& g, int BN, int CK, int wbytes, int dma = 0, int ksteps_total = 0) {
     const int nunits = dma ? 5 * (g.DS >> 4) : stage_table_ints(g);
@@ -807,6 +792,7 @@ static int fill_conv(const vg_conv_desc* d, GatherIn& g, ConvOut& k, ConvCls& q,
     k.out = d->out; k.out_f32 = (d->out_f32 || d->f32) ? 1 : 0; k.accumulate = d->accumulate; k.sums = d->out_sums;
     k.bs_x0 = nullptr;
     k.ks = 1; k.ks_part = nullptr; k.ks_cnt = nullptr;
+    k.scratch = (char*)d->scratch; k.scratch_bytes = d->scratch ? d->scratch_bytes : 0;
     if (const vg_actnorm_bwd_desc* b = d->bstat) {       // validated by vg_conv3d
         k.bs_x0 = b->x; k.bs_x1 = b->x1; k.bs_c0 = b->x1 ? b->c_x0 : b->C; k.bs_sh = b->x1 ? (b->x0_shift ? 1 : 0) : 0;
         k.bs_act = b->act; k.bs_pad = b->g_padded ? 1 : 0; k.bs_D = b->D; k.bs_H = b->H; k.bs_W = b->W;
@@ -934,18 +920,18 @@ static int launch_conv3(const GatherIn& g, const ConvOut& k, const ConvCls& q, i
     // fraction of the chip and their latency is covered by the other lane and the weight-gradient streams.
     int ks = 1;
     const long cells = (long)tiles * ny * g.N;
+    const long ks_part_bytes = k.scratch_bytes - VG_SCRATCH_CTR_BYTES;          // <= 0: no scratch from the caller, no split
     if (MC == 0 && !DMA && !WL && k.nchunks > 1 && g.ntaps < VG_MAX_TAPS && bx == tiles && cells <= vg_tune("CONV_KSPLIT_CELLS", 256) && cells <= VG_KS_CELLS) {
         const int cap = vg_tune("CONV_KSPLIT", 8);
         constexpr long SLOTB = 256L * (MSUB * (BN / 16)) * 16;
         for (int c = k.nchunks; c >= 2; --c)
-            if (k.nchunks % c == 0 && c <= cap && cells * c <= 1024 && cells * c * SLOTB <= VG_KS_PART_BYTES) { ks = c; break; }
+            if (k.nchunks % c == 0 && c <= cap && cells * c <= 1024 && cells * c * SLOTB <= ks_part_bytes) { ks = c; break; }
     }
     if (vg_dry("conv<%s,%d,%d,n%d,wl%d,dma%d,mc%d,c1%d>|walk%d|ch%d|ks%d", sizeof(T) == 4 ? "f32" : "bf16", BN, MSUB, (int)NOISE, (int)WL, (int)DMA,
                MC, (int)C1, tiles > bx ? 1 : 0, k.nchunks > 1 ? 1 : 0, ks)) return VG_OK;
     ConvOut k2 = k;
     k2.ks = ks; k2.ks_part = nullptr; k2.ks_cnt = nullptr;
-    // no scratch for this stream (allocation failed, or more than 32 streams have used the split): the launch runs unsplit
-    if (ks > 1 && vg_ks_scratch(s, &k2.ks_part, &k2.ks_cnt) != VG_OK) { (void)hipGetLastError(); k2.ks = ks = 1; k2.ks_part = nullptr; k2.ks_cnt = nullptr; }
+    if (ks > 1) { k2.ks_cnt = (unsigned*)k.scratch; k2.ks_part = (float*)(k.scratch + VG_SCRATCH_CTR_BYTES); }
     dim3 grid(bx * ncp * ks, ny, g.N);
     hipLaunchKernelGGL((conv_kernel<T, BN, MSUB, NOISE, WL, DMA, MC, C1>), grid, dim3(256), lds, s, g, k2, q);
     return vg_check_launch();

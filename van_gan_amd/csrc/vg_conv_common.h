@@ -17,6 +17,7 @@ struct ConvOut {
     const float* bs_sc; const float* bs_sf; const float* bs_mu; const float* bs_rs; const float* bs_ml;
     // K split over workgroups (conv_kernel, small grids): slices per tile, fp32 partial tiles, arrival counters per (sample, panel, tile)
     int ks; float* ks_part; unsigned* ks_cnt;
+    char* scratch; long scratch_bytes;          // vg_conv_desc::scratch (host-side planning only)
 };
 // output-parity classes fused into one launch (data gradient of a strided conv): a separate kernel argument that only the
 // multi-class kernel variants read

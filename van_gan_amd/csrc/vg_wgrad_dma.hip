@@ -579,6 +579,8 @@ int vg_wgrad_dma(const vg_conv_desc* d, const void* dy, int dy_f32, const int32_
                 }
                 if (bvol < 0) continue;
                 const int tiles = d->N * (d->OD / t3[0]) * (d->OH / t3[1]) * (d->OW / t3[2]);
+                // fast_div(n, m) is exact while n * d < 2^32: the largest division of the kernel is tile index / tiles per sample
+                if ((int64_t)tiles * (tiles / d->N) >= (1LL << 32)) continue;
                 static const int BXC[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192, 256, 0};
                 for (int ib = 0; ib < 17; ++ib) {
                     int bxx = BXC[ib] ? BXC[ib] : wg_target * per_cu / columns;        // last candidate: exactly the target grid
@@ -915,6 +917,7 @@ int vg_wgrad_pw_dma(const vg_conv_desc* d, const void* dy, int dy_f32, int T_tot
     auto magic = [](int dd) { return dd <= 1 ? 0u : (unsigned)((1ULL << 32) / (unsigned)dd + 1ULL); };
     k.m_tpn = magic(k.tiles_d * k.tiles_h * k.tiles_w); k.m_tw = magic(k.tiles_w); k.m_th = magic(k.tiles_h); k.m_ppp = magic(k.ppp); k.m_ncob = magic(ncob);
     k.dw = dw; k.db = db; k.dw_elems = Cin * d->Cout;
+    if ((int64_t)k.total_tiles * (k.total_tiles / d->N) >= (1LL << 32)) return 1;      // beyond the exact range of fast_div (n * d < 2^32)
     if (k.total_tiles * ncob < 32) return 1;          // a handful of tiles (8^3 level): two launches cost more than the on-the-fly kernel (22 vs 18 us)
     int bx = vg_tune("WGRAD_PW_WGS", 256) / ncob; if (bx < 1) bx = 1; if (bx > k.total_tiles) bx = k.total_tiles;
     const int64_t part_bytes = (int64_t)bx * k.dw_elems * 4;

@@ -398,8 +398,9 @@ class ResUNet:
         dsc = self._norm_desc(ar, dp, True, src, st, norm, dx, act, accumulate=accumulate)
         ops.actnorm_run(dsc, stats_done=lay.dgrad(dy, N, dp, accumulate=False, bstat=dsc))
 
-    def _block_bwd(self, ar: Arena, name: str, c: dict, N: int):
-        """Backward of one residual block given the complete gradient of its output in c['out'].grad."""
+    def _block_bwd(self, ar: Arena, name: str, c: dict, N: int, inline: bool = False):
+        """Backward of one residual block given the complete gradient of its output in c['out'].grad.
+        inline: the block's weight gradients run on the lane itself (ConvLayer.wgrad)."""
         L, Nn = self.L, self.Nn
         out, r, sc = c['out'], c['r'], c['sc']
         d_out = out.grad
@@ -410,14 +411,14 @@ class ResUNet:
         ssc = Src(sc.data, (N,) + sc.dims, sc.C)
         self._norm_bwd(ar, d_out, False, ssc, c['ns'], Nn[name + '.short'], d_sc, ACT_NONE, accumulate=False)
         # conv2: weights + data gradient on the padded grid, folded through relu(IN(r))
-        cb2.wgrad(c['s2'], d_out)
+        cb2.wgrad(c['s2'], d_out, inline)
         dp = ar.alloc((N,) + cb2.buf_dims + (r.C,), self.dtype)
         d_r = ar.alloc(r.data.shape, self.dtype)
         self._dgrad_norm_bwd(ar, cb2, d_out, N, dp, c['s2'], c['n2'], Nn[name + '.cb2'], d_r, ACT_RELU, accumulate=False)
         # conv1 and shortcut conv read the block input (possibly the virtual concat)
         s1, raw = c['s1'], c['src_raw']
-        cb1.wgrad(s1, d_r)
-        short.wgrad(raw, d_sc)
+        cb1.wgrad(s1, d_r, inline)
+        short.wgrad(raw, d_sc, inline)
         dp1 = ar.alloc((N,) + cb1.buf_dims + (s1.C,), self.dtype)
         inp = c['inp']
         if len(inp) == 1:            # encoder block: accumulate into the input's gradient
@@ -493,15 +494,12 @@ class ResUNet:
         self._norm_bwd(ar, dp, True, b['sb1'], b['nb1'], Nn['bridge.cb1'], b['inp'].grad, ACT_RELU, accumulate=not b['inp'].first_write())
         ar.release(mk, defer=True)
         for e in (4, 3, 2, 1):
-            yield                                # (ops.WGRAD_INLINE is a module flag: it is off whenever another sweep may run)
-            ops.WGRAD_INLINE = e <= inline_from  # (see backward(): the sweep's last weight gradients on the lane itself)
-            self._block_bwd(ar, 'enc%d' % e, ctx['enc%d' % e], N)
-            ops.WGRAD_INLINE = False
+            yield
+            self._block_bwd(ar, 'enc%d' % e, ctx['enc%d' % e], N, inline=e <= inline_from)   # the sweep's last weight gradients on the lane itself
             if e == 4 and on_suffix_done is not None:
                 on_suffix_done()                 # gradients of enc4 ... output head are complete (data parallel: reduce them now)
         yield
-        if inline_from >= 0:
-            ops.WGRAD_INLINE = True
+        inl = inline_from >= 0
         # stem
         s = ctx['stem']
         d_out = s['out'].grad
@@ -509,13 +507,12 @@ class ResUNet:
         ssc = Src(s['sc'].data, (N,) + s['sc'].dims, s['sc'].C)
         self._norm_bwd(ar, d_out, False, ssc, s['ns'], Nn['stem.short'], d_sc, ACT_NONE, accumulate=False)
         cb = L['stem.cb']
-        cb.wgrad(s['s1'], d_out)
+        cb.wgrad(s['s1'], d_out, inl)
         dp = ar.alloc((N,) + cb.buf_dims + (s['c1'].C,), self.dtype)
         d_c1 = ar.alloc(s['c1'].data.shape, self.dtype)
         self._dgrad_norm_bwd(ar, cb, d_out, N, dp, s['s1'], s['n1'], Nn['stem.cb'], d_c1, ACT_RELU, accumulate=False)
-        L['stem.conv1'].wgrad(s['sx'], d_c1)
-        L['stem.short'].wgrad(s['sx'], d_sc)
-        ops.WGRAD_INLINE = False
+        L['stem.conv1'].wgrad(s['sx'], d_c1, inl)
+        L['stem.short'].wgrad(s['sx'], d_sc, inl)
 
 
 # ======================================================================================================

@@ -189,7 +189,6 @@ PROF: Optional[KernelProfile] = None
 # and the data-gradient chain (dY -> dX -> IN backward -> next layer) are independent, and on the small deep layers either
 # alone leaves most CUs idle.  The side stream waits for the producer of dY; the main stream waits for the side stream
 # before arena memory is recycled (Arena.release) and before the gradients are consumed (side_join).
-WGRAD_INLINE = False        # set by ResUNet.backward for the tail of a lane's last sweep
 LAZY_RELEASE = os.environ.get('VG_LAZY_RELEASE', '1') != '0'
 FORK_SHORT = os.environ.get('VG_FORK_SHORT', '1') != '0'   # forward shortcut branches on the lane's side stream
 FUSE_CONCAT_NORM = os.environ.get('VG_FUSE_CONCAT_NORM', '1') != '0'   # ... and the conv branch's IN backward apply in the same launch
@@ -260,6 +259,29 @@ def side_join():
         sd = _SIDE_OF.get(_side_key(cur))
         if sd is not None:
             cur.wait_stream(sd)
+
+
+CONV_SCRATCH = {}      # (device index, stream) -> uint8 workspace of vg_conv3d launches on that stream (vg_conv_desc::scratch)
+CONV_SCRATCH_BYTES = _lib.SCRATCH_CTR_BYTES + (int(os.environ.get('VG_CONV_SCRATCH_MB', '160')) << 20)
+
+
+def conv_scratch(d: ConvDesc, s_: int, device=None):
+    """Hand the issuing stream's workspace to a vg_conv3d descriptor: arrival counters (zeroed here, once; every launch leaves them
+    at zero) + fp32 partial tiles of K-split launches + the materialised operand of the LDS-DMA convolution.  One buffer per
+    (device, stream): launches of one stream are ordered, the lanes and their side streams run concurrently.  The library itself
+    never allocates (include/vangan_hip.h)."""
+    if DRY is not None:                       # dry runs plan exactly as the real launch does: same (dummy) workspace size
+        d.scratch, d.scratch_bytes = 1 << 20, CONV_SCRATCH_BYTES
+        return
+    key = (_DEV if device is None else device, s_)
+    sc = CONV_SCRATCH.get(key)
+    if sc is None:
+        dev = torch.device('cuda', key[0]) if key[0] is not None else torch.device('cuda')
+        sc = torch.empty(CONV_SCRATCH_BYTES, dtype=torch.uint8, device=dev)
+        # s_ is torch's current stream at every call site (ops.stream()): the memset precedes every launch that will use the buffer
+        sc[:_lib.SCRATCH_CTR_BYTES].zero_()
+        CONV_SCRATCH[key] = sc
+    d.scratch, d.scratch_bytes = sc.data_ptr(), sc.numel()
 
 
 WGRAD_SCRATCH = {}     # (device, stream) -> fp32 scratch of the weight gradients: materialised operand + partial slabs (384 MB)
@@ -584,19 +606,23 @@ class ConvLayer:
         d.tanh_out = int(tanh)
         d.out, d.out_f32, d.accumulate = _p(out), int(out.dtype == torch.float32), 0
         d.out_sums = _p(sums)
+        s_ = stream()
+        conv_scratch(d, s_, out.device.index)
         if DRY is not None:
             DRY.tag = ('fwd', self.name)
             DRY.recipe = dict(kind='fwd', layer=self.ctor, src=src.recipe(), res=res is not None, tanh=bool(tanh),
                               sums=sums is not None, out_f32=out.dtype == torch.float32)
         e0 = PROF.begin() if PROF is not None else None
-        check(lib.vg_conv3d(C.byref(d), stream()), 'vg_conv3d ' + self.name)
+        check(lib.vg_conv3d(C.byref(d), s_), 'vg_conv3d ' + self.name)
         if e0 is not None:
             esz = 4 if self.f32 else 2
             PROF.end('conv_fwd', 2.0 * src.N * math.prod(self.out_dims) * self.cout * self.cin * self.k ** 3, e0,
                      src.N * esz * (math.prod(self.in_dims) * self.cin + math.prod(self.out_dims) * self.cout), conv_variant(d), self.name)
 
-    def wgrad(self, src: Src, dy: torch.Tensor):
-        if SIDE is not None and PROF is None and DRY is None and not WGRAD_INLINE:   # the per-launch timing pass serialises (attributable durations)
+    def wgrad(self, src: Src, dy: torch.Tensor, inline: bool = False):
+        """inline: launch on the issuing stream itself instead of its side stream (the tail of a lane's last sweep, where the side
+        stream is the one that is behind); a per-call argument, so that two sweeps enqueued alternately cannot see each other's."""
+        if SIDE is not None and PROF is None and DRY is None and not inline:   # the per-launch timing pass serialises (attributable durations)
             cur = current_stream_obj()
             sd = _side_of(cur)
             sd.wait_stream(cur)                                  # dY (and everything before it) is ready
@@ -690,11 +716,14 @@ class ConvLayer:
             d.src_f32 = int(dy.dtype == torch.float32 and self.cout == 1)
             d.out, d.out_f32, d.accumulate = _p(out), int(out.dtype == torch.float32), int(accumulate)
             d.bstat = C.addressof(bstat) if use_bs else None
+            s_ = stream()
+            conv_scratch(d, s_, out.device.index)
             e0 = PROF.begin() if PROF is not None else None
-            check(lib.vg_conv3d(C.byref(d), stream()), 'vg_conv3d(dgrad, fused classes) ' + self.name)
+            check(lib.vg_conv3d(C.byref(d), s_), 'vg_conv3d(dgrad, fused classes) ' + self.name)
             if e0 is not None:
-                PROF.end('conv_dgrad', sum(2.0 * N * math.prod(c['iters']) * self.cin * self.cout * len(c['taps'])
-                                           for c in self.d_classes), e0,
+                # algorithmic FLOPs = the forward's (every (output voxel, tap) pair once); the padded-grid iteration space of the
+                # launch also multiplies dY's zero border, which is not counted
+                PROF.end('conv_dgrad', 2.0 * N * math.prod(self.out_dims) * self.cin * self.cout * self.k ** 3, e0,
                          N * 2 * (math.prod(self.out_dims) * self.cout + math.prod(self.buf_dims) * self.cin), conv_variant(d), self.name)
             return use_bs
         for c in self.d_classes:
@@ -719,10 +748,12 @@ class ConvLayer:
             d.src_f32 = int(dy.dtype == torch.float32 and self.cout == 1)
             d.out, d.out_f32, d.accumulate = _p(out), int(out.dtype == torch.float32), int(accumulate)
             d.bstat = C.addressof(bstat) if use_bs else None
+            s_ = stream()
+            conv_scratch(d, s_, out.device.index)
             e0 = PROF.begin() if PROF is not None else None
-            check(lib.vg_conv3d(C.byref(d), stream()), 'vg_conv3d(dgrad) ' + self.name)
+            check(lib.vg_conv3d(C.byref(d), s_), 'vg_conv3d(dgrad) ' + self.name)
             if e0 is not None:      # algorithmic FLOPs of this parity class: its taps only
-                PROF.end('conv_dgrad', 2.0 * N * math.prod(c['iters']) * self.cin * self.cout * len(c['taps']), e0,
+                PROF.end('conv_dgrad', 2.0 * N * math.prod(self.out_dims) * self.cin * self.cout * len(c['taps']), e0,
                          N * (4 if self.f32 else 2) * (math.prod(self.out_dims) * self.cout * len(c['taps']) / self.k ** 3
                                                        + math.prod(c['iters']) * self.cin), conv_variant(d), self.name)
         return use_bs

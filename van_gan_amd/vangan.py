@@ -145,6 +145,7 @@ class VanGan:
 
     def load_weights(self, P: Dict[str, Dict[str, torch.Tensor]]):
         ops.set_device(self.device.index)
+        self._join_updates()            # cross-step mode: a queued Adam step must not land on top of the loaded weights
         for k in NETS:
             self.stores[k].load({n: t.to(self.device) for n, t in P[k].items()})
         self.repack()
@@ -569,6 +570,7 @@ class VanGan:
 
     def broadcast_weights(self, src: int = 0):
         ops.set_device(self.device.index)
+        self._join_updates()            # (see load_weights)
         self.sync.broadcast_weights(src)
         self.repack()
 
@@ -622,6 +624,7 @@ class VanGan:
             print('Error: Checkpoint not found!')                  # vangan.py:267-268: prints, does not raise
             return False
         ck = torch.load(path, map_location='cpu')
+        self._join_updates()            # (see load_weights): the optimizer stream may still hold the last step's Adam + repack
         for k, s in self.stores.items():
             s.w.copy_(ck[k]['w']); s.m.copy_(ck[k]['m']); s.v.copy_(ck[k]['v']); s.step = ck[k]['step']
         self.rng_offset = int(ck.get('_rng_offset', 0))
