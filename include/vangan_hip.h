@@ -135,6 +135,11 @@ typedef struct {
        library chooses launch plans that need none. */
     void* scratch;
     int64_t scratch_bytes;
+    /* Layout of wpacked / cls_w: 0 = rows x Ktot (vg_pack_weights, the gather kernels); 64 / 128 = the block layout of the LDS-DMA
+       convolution with that channel-panel width (vg_pack_weights_dma; the caller asks vg_conv3d_dma_bn which layers take it and needs
+       a scratch big enough for the materialised operand).  A call whose weights are in the block layout is served by that kernel
+       family or fails with VG_EINVAL -- never by a silent fallback. */
+    int32_t wlayout;
 } vg_conv_desc;
 #define VG_SCRATCH_CTR_BYTES 16384
 
@@ -167,8 +172,18 @@ typedef struct {
     const float* w; const int32_t* tap_idx; void* out;
     int32_t Cin, Cout, ntaps, transpose, CK, out_f32;
     int32_t blk0, nblk;
+    int32_t bn;              /* > 0: the block layout of vg_pack_weights_dma with this panel width (CK / out_f32 unused) */
+    int32_t pad_;
 } vg_pack_item;
 int vg_pack_weights_multi(const vg_pack_item* items_dev, int n, int total_blocks, vg_stream_t stream);
+/* The LDS-DMA convolution (vg_conv_dma.hip: both MFMA operands staged by global_load_lds, the wide layers of discriminator.py:64-117
+ * and resunet_model.py:103-143 and their data gradients).  vg_conv3d_dma_bn: shape-only query -- the channel-panel width (64 / 128)
+ * with which vg_conv3d would serve this descriptor through that family, 0 if it would not; no pointer of d is looked at.
+ * vg_pack_weights_dma: fp32 DHWIO [T][Cin][Cout] -> bf16 [rows / bn][contraction / 16][tap][8-channel half][bn rows][8], rows =
+ * output channels (transpose 0) or input channels (transpose 1, data gradient); rows * contraction * ntaps elements. */
+int vg_conv3d_dma_bn(const vg_conv_desc* d);
+int vg_pack_weights_dma(const float* w, int T, int Cin, int Cout, const int32_t* tap_idx_dev, int ntaps, int transpose, int bn,
+                        void* out, vg_stream_t stream);
 int vg_packed_ktot(int ntaps, int C, int CK);
 int vg_packed_rows(int N);
 

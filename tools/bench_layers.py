@@ -31,6 +31,7 @@ def main():
     ap.add_argument('--size', type=int, default=128)
     ap.add_argument('--only', default='')
     ap.add_argument('--layers', default='')
+    ap.add_argument('--batch', type=int, default=1)
     args = ap.parse_args()
     dev = torch.device('cuda:0')
     S = args.size
@@ -55,7 +56,7 @@ def main():
         st.param('c.w').normal_(0, 0.05)
         lay = ConvLayer(st, 'c', k, cin, cout, stride, pad, True, dims)
         lay.pack()
-        N = 1
+        N = args.batch
         scale = torch.rand(N, cin, device=dev) + 0.5
         shift = torch.randn(N, cin, device=dev) * 0.1
         raw = 'short' in name                 # the shortcut convolutions read the block input as stored (no IN / activation)

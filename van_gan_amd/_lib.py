@@ -32,13 +32,13 @@ class ConvDesc(C.Structure):
         ('out', c_void_p), ('out_f32', c_int), ('accumulate', c_int), ('out_sums', c_void_p), ('f32', c_int),
         ('nclass', c_int), ('cls_tap0', c_int * 9), ('cls_w', c_void_p * 8), ('cls_ooff', (c_int * 3) * 8),
         ('cls_iters', (c_int * 3) * 8), ('wpack', c_int), ('wpack_wmin', c_int), ('bstat', c_void_p),
-        ('scratch', c_void_p), ('scratch_bytes', c_i64),
+        ('scratch', c_void_p), ('scratch_bytes', c_i64), ('wlayout', c_int),
     ]
 
 
 class PackItem(C.Structure):
     _fields_ = [('w', c_void_p), ('tap_idx', c_void_p), ('out', c_void_p), ('Cin', c_int), ('Cout', c_int), ('ntaps', c_int),
-                ('transpose', c_int), ('CK', c_int), ('out_f32', c_int), ('blk0', c_int), ('nblk', c_int)]
+                ('transpose', c_int), ('CK', c_int), ('out_f32', c_int), ('blk0', c_int), ('nblk', c_int), ('bn', c_int), ('pad_', c_int)]
 
 
 class ActNormBwdDesc(C.Structure):
@@ -68,6 +68,8 @@ _SIGS = {
     'vg_pack_weights_multi': ([c_void_p, c_int, c_int, c_void_p], c_int),
     'vg_crop_augment': ([c_void_p] + [c_int] * 13 + [c_void_p, c_void_p], c_int),
     'vg_crop_max': ([c_void_p] + [c_int] * 10 + [c_void_p, c_void_p], c_int),
+    'vg_conv3d_dma_bn': ([C.POINTER(ConvDesc)], c_int),
+    'vg_pack_weights_dma': ([c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p], c_int),
     'vg_packed_ktot': ([c_int, c_int, c_int], c_int),
     'vg_packed_rows': ([c_int], c_int),
     'vg_conv3d_wgrad': ([C.POINTER(ConvDesc), c_void_p, c_int, C.POINTER(c_int), c_int, c_void_p, c_void_p, c_void_p, c_i64,

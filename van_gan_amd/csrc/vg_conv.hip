@@ -17,6 +17,7 @@
 //   epilogue: bias, residual*scale+shift, tanh, bf16 round, per-(n,c) sum / sum-of-squares of
 //   the stored values (for the next InstanceNorm), store or accumulate.
 #include "vg_conv_common.h"
+#include "vg_dma_common.h"
 
 unsigned long long* g_vg_stamps = nullptr;
 extern "C" int vg_set_stamp_buffer(void* p) { g_vg_stamps = (unsigned long long*)p; return VG_OK; }
@@ -972,6 +973,7 @@ static int dispatch_conv(const GatherIn& g, const ConvOut& k, const ConvCls& q, 
 
 // did_stats: set when the launched kernel accumulated the IN-backward statistics of d->bstat itself (striped, unfolded)
 static int conv3d_impl(const vg_conv_desc* d, vg_stream_t stream, bool& did_stats) {
+    if (d && d->wlayout) return vg_conv_dma(d, (hipStream_t)stream);          // LDS-DMA family (weights in its block layout): served there or an error
     if (d && d->out && d->wpacked && d->src0) {           // 1x1x1 with a single channel on one side: HBM-bound VALU kernels
         const int prc = vg_pointwise_conv(d, (hipStream_t)stream);
         if (prc <= 0) return prc;
@@ -1045,6 +1047,7 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const vg_pack_i
     __syncthreads();
     const vg_pack_item it = items[sel];
     const int bx = blockIdx.x - it.blk0, gx = it.nblk;
+    if (it.bn > 0) { vg_pack_dma_units(it.w, it.tap_idx, (bf16_t*)it.out, it.Cin, it.Cout, it.ntaps, it.transpose, it.bn, bx * 256 + tid, gx * 256); return; }
     const int C = it.transpose ? it.Cout : it.Cin, NR = it.transpose ? it.Cin : it.Cout;
     const int nchunks = (C + it.CK - 1) / it.CK;
     const int kc_pad = ((it.ntaps * it.CK + 31) / 32) * 32;

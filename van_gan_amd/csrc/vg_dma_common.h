@@ -1,0 +1,78 @@
+// vg_dma_common.h -- shared by the LDS-DMA kernels (vg_wgrad_dma.hip: weight gradients; vg_conv_dma.hip: forward / data gradient):
+// the materialised operand P and its elementwise producer, the LDS-DMA copy and the counted vmcnt wait.
+#pragma once
+#include "vg_gather.h"
+
+typedef __attribute__((address_space(3))) void lds_void_d;
+typedef const __attribute__((address_space(1))) void glb_void_d;
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_d;
+
+// ------------------------------------------------------------------------------------------------------------------
+// operand materialisation
+// ------------------------------------------------------------------------------------------------------------------
+struct MatK {
+    const void* src0; const void* src1; int c0, c1, shift0;
+    int N, D, H, W, Cin;
+    const float* in_scale; const float* in_shift; int act;
+    const bf16_t* noise; int npad;
+    int pad_mode;
+    int pmin_d, pmin_h, pmin_w;      // input position of padded index 0
+    int Dp, Hp, Wp;                  // padded extents (positions)
+    int deint, WE, Wps;              // W stored de-interleaved: WE even positions first; Wps = stored row length (voxels)
+    bf16_t* out;
+};
+
+// launches materialize_kernel (vg_wgrad_dma.hip) on s
+void vg_launch_materialize(const MatK& m, hipStream_t s);
+
+// n / d for 0 <= n < 2^32 / d by one multiply-high, m = floor(2^32 / d) + 1 from the host (the integer divisions of the
+// prologue -- 13 DMA pieces x 3 divisions x ~40 instructions -- were 6 us of every workgroup's life)
+__device__ __forceinline__ int fast_div(int n, unsigned m) { return m ? (int)__umulhi((unsigned)n, m) : n; }       // m == 0: d == 1
+
+// One LDS-DMA piece: 64 lanes x 16 bytes from sbase + voff (per lane) to LDS bytes [lds_addr, lds_addr + 1024).  Inline asm on
+// purpose: for the builtin hipcc tracks the copy as a pending LDS write and drains it (s_waitcnt vmcnt(0)) in front of the next
+// ds_read -- the copy of tile t+1 must stay in flight under the MFMA loop of tile t.  The kernel counts it itself (vmcnt(0)
+// at the top of the tile loop, where nothing else is outstanding).  M0 = LDS base of the piece, restored afterwards.
+__device__ __forceinline__ void glds16(const char* sbase, int voff, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+}
+
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate): all but this wave's n youngest copies
+// have landed.  n beyond the table waits for more than asked (a smaller count is always safe).
+#define VG_VMCNT_CASE(i) case i: asm volatile("s_waitcnt vmcnt(" #i ")" ::: "memory"); break;
+__device__ __forceinline__ void wait_vmcnt(int n) {
+    switch (n) {
+        VG_VMCNT_CASE(0) VG_VMCNT_CASE(1) VG_VMCNT_CASE(2) VG_VMCNT_CASE(3) VG_VMCNT_CASE(4) VG_VMCNT_CASE(5) VG_VMCNT_CASE(6) VG_VMCNT_CASE(7)
+        VG_VMCNT_CASE(8) VG_VMCNT_CASE(9) VG_VMCNT_CASE(10) VG_VMCNT_CASE(11) VG_VMCNT_CASE(12) VG_VMCNT_CASE(13) VG_VMCNT_CASE(14) VG_VMCNT_CASE(15)
+        VG_VMCNT_CASE(16) VG_VMCNT_CASE(17) VG_VMCNT_CASE(18) VG_VMCNT_CASE(19) VG_VMCNT_CASE(20) VG_VMCNT_CASE(21) VG_VMCNT_CASE(22) VG_VMCNT_CASE(23)
+        VG_VMCNT_CASE(24) VG_VMCNT_CASE(25) VG_VMCNT_CASE(26) VG_VMCNT_CASE(27) VG_VMCNT_CASE(28) VG_VMCNT_CASE(29) VG_VMCNT_CASE(30) VG_VMCNT_CASE(31)
+        VG_VMCNT_CASE(32) VG_VMCNT_CASE(33) VG_VMCNT_CASE(34) VG_VMCNT_CASE(35) VG_VMCNT_CASE(36) VG_VMCNT_CASE(37) VG_VMCNT_CASE(38) VG_VMCNT_CASE(39)
+        default: asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); break;
+    }
+}
+
+
+// Kernel of vg_pack_weights_dma / the bn > 0 items of vg_pack_weights_multi: fp32 DHWIO [T][Cin][Cout] -> Wd (see the header).
+// transpose 0: rows = output channels, contraction = input channels (forward); 1: rows = input channels, contraction = output
+// channels (data gradient).  One thread per 16-byte unit (8 contraction channels of one row).
+__device__ __forceinline__ void vg_pack_dma_units(const float* __restrict__ w, const int* __restrict__ tap_idx, bf16_t* __restrict__ out, int Cin, int Cout,
+                                  int ntaps, int transpose, int bn, int u0, int ustride) {
+    const int NR = transpose ? Cin : Cout, C = transpose ? Cout : Cin;
+    const int npl = C >> 4;
+    const long units = (long)NR * npl * ntaps * 2;
+    for (long u = u0; u < units; u += ustride) {
+        long t = u;
+        const int row = (int)(t % bn); t /= bn;
+        const int half = (int)(t & 1); t >>= 1;
+        const int tap = (int)(t % ntaps); t /= ntaps;
+        const int plane = (int)(t % npl); const int cob = (int)(t / npl);
+        const int r = cob * bn + row, c0 = plane * 16 + half * 8, ts = tap_idx[tap];
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            v[e] = transpose ? w[((size_t)ts * Cin + r) * Cout + c0 + e] : w[((size_t)ts * Cin + c0 + e) * Cout + r];
+        store8<bf16_t>(out + u * 8, v);
+    }
+}

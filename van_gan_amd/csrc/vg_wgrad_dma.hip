@@ -23,26 +23,7 @@
 //               reads for CO = 32 / 64); the swizzle is applied on the DMA's per-lane SOURCE address, LDS stays linear.
 // K order inside a 32-voxel step: lane group lg reads voxels 4*lg..4*lg+3 and 16+4*lg..: any bijection is valid for a
 // contraction as long as both operands use it, and this one makes each half-wave read 8 consecutive voxels.
-#include "vg_gather.h"
-
-typedef __attribute__((address_space(3))) void lds_void_d;
-typedef const __attribute__((address_space(1))) void glb_void_d;
-typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_d;
-
-// ------------------------------------------------------------------------------------------------------------------
-// operand materialisation
-// ------------------------------------------------------------------------------------------------------------------
-struct MatK {
-    const void* src0; const void* src1; int c0, c1, shift0;
-    int N, D, H, W, Cin;
-    const float* in_scale; const float* in_shift; int act;
-    const bf16_t* noise; int npad;
-    int pad_mode;
-    int pmin_d, pmin_h, pmin_w;      // input position of padded index 0
-    int Dp, Hp, Wp;                  // padded extents (positions)
-    int deint, WE, Wps;              // W stored de-interleaved: WE even positions first; Wps = stored row length (voxels)
-    bf16_t* out;
-};
+#include "vg_dma_common.h"
 
 __global__ __launch_bounds__(256) void materialize_kernel(const MatK p) {
     const int tid = threadIdx.x;
@@ -102,6 +83,8 @@ __global__ __launch_bounds__(256) void materialize_kernel(const MatK p) {
     }
 }
 
+void vg_launch_materialize(const MatK& m, hipStream_t s) { hipLaunchKernelGGL(materialize_kernel, dim3(m.N * m.Dp * m.Hp), dim3(256), 0, s, m); }
+
 // ------------------------------------------------------------------------------------------------------------------
 // weight gradient
 // ------------------------------------------------------------------------------------------------------------------
@@ -130,34 +113,6 @@ struct WgdK {
     const float* in_scale; const float* in_shift; float slope;
     unsigned long long* stamps;       // diagnostic (vg_set_stamp_buffer): per workgroup 8 words of phase cycle sums, else NULL
 };
-
-// n / d for 0 <= n < 2^32 / d by one multiply-high, m = floor(2^32 / d) + 1 from the host (the integer divisions of the
-// prologue -- 13 DMA pieces x 3 divisions x ~40 instructions -- were 6 us of every workgroup's life)
-__device__ __forceinline__ int fast_div(int n, unsigned m) { return m ? (int)__umulhi((unsigned)n, m) : n; }       // m == 0: d == 1
-
-// One LDS-DMA piece: 64 lanes x 16 bytes from sbase + voff (per lane) to LDS bytes [lds_addr, lds_addr + 1024).  Inline asm on
-// purpose: for the builtin hipcc tracks the copy as a pending LDS write and drains it (s_waitcnt vmcnt(0)) in front of the next
-// ds_read -- the copy of tile t+1 must stay in flight under the MFMA loop of tile t.  The kernel counts it itself (vmcnt(0)
-// at the top of the tile loop, where nothing else is outstanding).  M0 = LDS base of the piece, restored afterwards.
-__device__ __forceinline__ void glds16(const char* sbase, int voff, unsigned lds_addr) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
-}
-
-// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate): all but this wave's n youngest copies
-// have landed.  n beyond the table waits for more than asked (a smaller count is always safe).
-#define VG_VMCNT_CASE(i) case i: asm volatile("s_waitcnt vmcnt(" #i ")" ::: "memory"); break;
-__device__ __forceinline__ void wait_vmcnt(int n) {
-    switch (n) {
-        VG_VMCNT_CASE(0) VG_VMCNT_CASE(1) VG_VMCNT_CASE(2) VG_VMCNT_CASE(3) VG_VMCNT_CASE(4) VG_VMCNT_CASE(5) VG_VMCNT_CASE(6) VG_VMCNT_CASE(7)
-        VG_VMCNT_CASE(8) VG_VMCNT_CASE(9) VG_VMCNT_CASE(10) VG_VMCNT_CASE(11) VG_VMCNT_CASE(12) VG_VMCNT_CASE(13) VG_VMCNT_CASE(14) VG_VMCNT_CASE(15)
-        VG_VMCNT_CASE(16) VG_VMCNT_CASE(17) VG_VMCNT_CASE(18) VG_VMCNT_CASE(19) VG_VMCNT_CASE(20) VG_VMCNT_CASE(21) VG_VMCNT_CASE(22) VG_VMCNT_CASE(23)
-        VG_VMCNT_CASE(24) VG_VMCNT_CASE(25) VG_VMCNT_CASE(26) VG_VMCNT_CASE(27) VG_VMCNT_CASE(28) VG_VMCNT_CASE(29) VG_VMCNT_CASE(30) VG_VMCNT_CASE(31)
-        VG_VMCNT_CASE(32) VG_VMCNT_CASE(33) VG_VMCNT_CASE(34) VG_VMCNT_CASE(35) VG_VMCNT_CASE(36) VG_VMCNT_CASE(37) VG_VMCNT_CASE(38) VG_VMCNT_CASE(39)
-        default: asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); break;
-    }
-}
 
 __device__ __forceinline__ bf16x8 tr_frag_d(const char* base0, const char* base1) {
     bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4_d*)base0);
@@ -649,7 +604,7 @@ int vg_wgrad_dma(const vg_conv_desc* d, const void* dy, int dy_f32, const int32_
     m.noise = (const bf16_t*)d->noise; m.npad = d->noise ? d->noise_pad : 0; m.pad_mode = d->pad_mode;
     m.pmin_d = mn[0]; m.pmin_h = mn[1]; m.pmin_w = mn[2]; m.Dp = Dp; m.Hp = Hp; m.Wp = Wp;
     m.deint = deint; m.WE = WE; m.Wps = Wps; m.out = (bf16_t*)scratch;
-    hipLaunchKernelGGL(materialize_kernel, dim3(d->N * Dp * Hp), dim3(256), 0, s, m);
+    vg_launch_materialize(m, s);
     }
     if (Q == 4) launch_wd<8, 4>(k, direct, grid, lds, s);
     else if (Q == 2) { if (Rsel == 4) launch_wd<4, 2>(k, direct, grid, lds, s); else launch_wd<8, 2>(k, direct, grid, lds, s); }

@@ -65,7 +65,7 @@ class DryRun:
     a box without a GPU to list the kernels a configuration would run (tests/test_variant_coverage.py).
     records: [(kind, layer name, variant string)], kind in fwd / dgrad / wgrad."""
 
-    _PASS = ('vg_conv3d_plan', 'vg_packed_ktot', 'vg_packed_rows', 'vg_conv3d_lds_bytes', 'vg_status_string', 'vg_set_tuning')
+    _PASS = ('vg_conv3d_dma_bn', 'vg_conv3d_plan', 'vg_packed_ktot', 'vg_packed_rows', 'vg_conv3d_lds_bytes', 'vg_status_string', 'vg_set_tuning')
 
     def __init__(self):
         self.records = []
@@ -464,11 +464,19 @@ class ConvLayer:
         T = self.f_T
         self.f_idx_host = (C.c_int32 * T)(*range(T))
         self.f_idx = torch.arange(T, dtype=torch.int32, device=dev)
-        self.f_ck = self._pick_ck(cin, self.f_taps, stride, in_dims, self.out_dims, cout, wpack=self.wpack)
-        self.f_ktot = check(lib.vg_packed_ktot(T, self.f_cin, self.f_ck), 'vg_packed_ktot')
-        self.f_wp = torch.zeros(lib.vg_packed_rows(cout), self.f_ktot, dtype=dtype, device=dev)
+        # the wide layers run on the LDS-DMA family (vg_conv_dma.hip): the library says which, and with which channel panel; their
+        # weights are packed in that kernel's block layout (vg_pack_weights_dma)
+        self.f_bn = self._dma_bn(cin, cout, self.f_taps, stride, in_dims, self.out_dims) if not self.wpack else 0
+        if self.f_bn:
+            self.f_ck = 16
+            self.f_wp = torch.zeros(cout * cin * T, dtype=dtype, device=dev)
+        else:
+            self.f_ck = self._pick_ck(cin, self.f_taps, stride, in_dims, self.out_dims, cout, wpack=self.wpack)
+            self.f_ktot = check(lib.vg_packed_ktot(T, self.f_cin, self.f_ck), 'vg_packed_ktot')
+            self.f_wp = torch.zeros(lib.vg_packed_rows(cout), self.f_ktot, dtype=dtype, device=dev)
         # ---- data gradient: one class per output parity; buffer = padded grid for 'reflect' ----
         self.d_classes = []
+        self.d_bn, self.d_fused = 0, False
         if need_dgrad:
             padded = pad == 'reflect'
             self.buf_dims = tuple(n + 2 for n in in_dims) if padded else tuple(in_dims)
@@ -492,10 +500,16 @@ class ConvLayer:
                                 for (c, oc) in tw:
                                     taps.append((oa, ob, oc)); idx.append((a * k + b) * k + c)
                         self.d_classes.append(dict(off=(pd, ph, pw), iters=(nd, nh, nw), taps=taps, idx_list=idx))
+            # the wide layers: ONE class-parallel launch of the LDS-DMA family over the zero-padded dY (every class a stride-1 walk)
+            self.d_fused = False
+            self.d_bn = self._dma_bn_dgrad()
+            if self.d_bn:
+                for c in self.d_classes:
+                    c['ck'] = 16
+                self.d_fused = True
             # strided convs: ONE fused launch computes all output-parity classes from a dY halo tile staged once, when
             # dY fits one channel chunk (<= 64 channels) and the plan is LDS-feasible; else one launch per class
-            self.d_fused = False
-            if len(self.d_classes) > 1 and cout <= 64 and not self.f32 and sum(len(c['taps']) for c in self.d_classes) <= _lib.VG_MAX_TAPS:
+            if not self.d_bn and len(self.d_classes) > 1 and cout <= 64 and not self.f32 and sum(len(c['taps']) for c in self.d_classes) <= _lib.VG_MAX_TAPS:
                 ck_f = -(-cout // 16) * 16
                 for c in self.d_classes:
                     c['ck'] = ck_f
@@ -503,7 +517,7 @@ class ConvLayer:
             # otherwise (several channel chunks of dY, or exact-parity mode): still ONE launch, class-parallel -- every
             # workgroup serves one class, so the launch carries all classes' tiles at once (8 launches of 8-64 workgroups
             # each left most of the chip idle on enc3/enc4/D.down1).  All classes share the chunk size.
-            if (not self.d_fused and len(self.d_classes) > 1 and os.environ.get('VG_CLS_PAR', '1') != '0'
+            if (not self.d_bn and not self.d_fused and len(self.d_classes) > 1 and os.environ.get('VG_CLS_PAR', '1') != '0'
                     and sum(len(c['taps']) for c in self.d_classes) <= _lib.VG_MAX_TAPS):
                 best, best_key = None, None
                 for ck in _ck_candidates(cout):
@@ -522,11 +536,39 @@ class ConvLayer:
                         c['ck'] = best
                     self.d_fused = True
             for c in self.d_classes:
+                c['idx'] = torch.tensor(c['idx_list'], dtype=torch.int32, device=dev)
+                if self.d_bn:
+                    c['wp'] = torch.zeros(cin * cout * len(c['taps']), dtype=dtype, device=dev)
+                    continue
                 if not self.d_fused:
                     c['ck'] = self._pick_ck(cout, c['taps'], 1, self.out_dims, c['iters'], cin)
                 c['ktot'] = check(lib.vg_packed_ktot(len(c['taps']), cout, c['ck']), 'vg_packed_ktot')
-                c['idx'] = torch.tensor(c['idx_list'], dtype=torch.int32, device=dev)
                 c['wp'] = torch.zeros(lib.vg_packed_rows(cin), c['ktot'], dtype=dtype, device=dev)
+
+    def _dma_bn(self, cin, cout, taps, istr, in_dims, out_dims) -> int:
+        """Channel-panel width with which the LDS-DMA family serves this forward convolution (0: the gather kernels do)."""
+        if self.f32 or os.environ.get('VG_CONV_DMA', '1') == '0' or len(taps) > _lib.VG_MAX_TAPS:
+            return 0
+        d = ConvDesc()
+        d.c_src0, d.c_src1, d.N = cin, 0, 1
+        d.D, d.H, d.W = in_dims
+        d.istr, d.pad_mode, d.ostr = istr, self.pad_mode, 1
+        _set_taps(d, taps)
+        d.OD, d.OH, d.OW = out_dims
+        d.BD, d.BH, d.BW = out_dims
+        d.Cout = cout
+        return max(0, lib.vg_conv3d_dma_bn(C.byref(d)))
+
+    def _dma_bn_dgrad(self) -> int:
+        """The same for the data gradient: all output-parity classes in one class-parallel launch."""
+        if self.f32 or os.environ.get('VG_CONV_DMA', '1') == '0' or not self.d_classes:
+            return 0
+        if sum(len(c['taps']) for c in self.d_classes) > _lib.VG_MAX_TAPS or len(self.d_classes) > 8:
+            return 0
+        for c in self.d_classes:
+            c.setdefault('ck', 16)
+        d = self._fused_desc(None, 1, None, False, probe=True, plan=False)
+        return max(0, lib.vg_conv3d_dma_bn(C.byref(d)))
 
     def _pick_ck(self, C_, taps, istr, in_dims, iters, rows, wpack=0) -> int:
         d = ConvDesc()
@@ -560,22 +602,30 @@ class ConvLayer:
         return best
 
     def pack_items(self):
-        """(w, tap_idx, out, Cin, Cout, ntaps, transpose, CK, f32) of every packed operand, for PackTable."""
+        """(w, tap_idx, out, Cin, Cout, ntaps, transpose, CK, f32, bn) of every packed operand, for PackTable (bn > 0: the block layout
+        of the LDS-DMA family with that panel width)."""
         T = self.f_T
-        items = [(self.w, self.f_idx, self.f_wp, self.f_cin, self.cout, T, 0, self.f_ck, self.f32)]
+        items = [(self.w, self.f_idx, self.f_wp, self.f_cin, self.cout, T, 0, self.f_ck, self.f32, self.f_bn)]
         for c in self.d_classes:
-            items.append((self.w, c['idx'], c['wp'], self.cin, self.cout, len(c['taps']), 1, c['ck'], self.f32))
+            items.append((self.w, c['idx'], c['wp'], self.cin, self.cout, len(c['taps']), 1, c['ck'], self.f32, self.d_bn))
         return items
 
     def pack(self):
         """fp32 master weights -> bf16 packed operands (after every optimizer step)."""
         T = self.f_T
         s = stream()
-        check(lib.vg_pack_weights(_p(self.w), T, self.f_cin, self.cout, _p(self.f_idx), T, 0, self.f_ck, _p(self.f_wp),
-                                  self.f32, s), 'pack')
+        if self.f_bn:
+            check(lib.vg_pack_weights_dma(_p(self.w), T, self.f_cin, self.cout, _p(self.f_idx), T, 0, self.f_bn, _p(self.f_wp), s), 'pack')
+        else:
+            check(lib.vg_pack_weights(_p(self.w), T, self.f_cin, self.cout, _p(self.f_idx), T, 0, self.f_ck, _p(self.f_wp),
+                                      self.f32, s), 'pack')
         for c in self.d_classes:
-            check(lib.vg_pack_weights(_p(self.w), self.k ** 3, self.cin, self.cout, _p(c['idx']), len(c['taps']), 1, c['ck'],
-                                      _p(c['wp']), self.f32, s), 'pack')
+            if self.d_bn:
+                check(lib.vg_pack_weights_dma(_p(self.w), self.k ** 3, self.cin, self.cout, _p(c['idx']), len(c['taps']), 1, self.d_bn,
+                                              _p(c['wp']), s), 'pack')
+            else:
+                check(lib.vg_pack_weights(_p(self.w), self.k ** 3, self.cin, self.cout, _p(c['idx']), len(c['taps']), 1, c['ck'],
+                                          _p(c['wp']), self.f32, s), 'pack')
 
     def _fwd_desc(self, src: Src) -> ConvDesc:
         # the static part (taps, geometry, packed weights) is built once and block-copied: filling ~100 ctypes fields from
@@ -591,6 +641,7 @@ class ConvLayer:
             t.BD, t.BH, t.BW = self.out_dims
             t.Cout, t.wpacked, t.CK = self.cout, _p(self.f_wp), self.f_ck
             t.f32 = self.f32
+            t.wlayout = self.f_bn
             self._fwd_tmpl = t
         d = ConvDesc()
         C.memmove(C.byref(d), C.byref(t), C.sizeof(ConvDesc))
@@ -652,8 +703,9 @@ class ConvLayer:
             PROF.end('conv_wgrad', 2.0 * src.N * math.prod(self.out_dims) * self.cout * self.cin * self.k ** 3, e0,
                      src.N * esz * (math.prod(self.in_dims) * self.cin + math.prod(self.out_dims) * self.cout), vb.value.decode(), self.name)
 
-    def _fused_desc(self, dy, N, out, accumulate, probe=False):
-        """Descriptor of the fused all-classes data gradient (probe=True: dummy pointers, returns None if infeasible)."""
+    def _fused_desc(self, dy, N, out, accumulate, probe=False, plan=True):
+        """Descriptor of the fused all-classes data gradient (probe=True: dummy pointers, returns None if infeasible; plan=False:
+        the bare descriptor, no feasibility check)."""
         d = ConvDesc()
         dummy = 1 << 20
         d.src0, d.src1 = (dummy if probe else _p(dy)), None
@@ -681,6 +733,9 @@ class ConvLayer:
                 d.cls_iters[i][a] = c['iters'][a]
         d.cls_tap0[len(self.d_classes)] = t0
         d.wpacked = d.cls_w[0]
+        d.wlayout = getattr(self, 'd_bn', 0)
+        if probe and not plan:
+            return d
         if probe:
             d.out = dummy
             plan = (C.c_int32 * 4)()
@@ -843,9 +898,9 @@ class PackTable:
         arr = (_lib.PackItem * len(items))()
         blk = 0
         per_block = int(os.environ.get('VG_PACK_ELEMS', 8192))     # packed elements per block: big operands get many blocks
-        for a, (w, idx, out, cin, cout, ntaps, tr, ck, f32) in zip(arr, items):
+        for a, (w, idx, out, cin, cout, ntaps, tr, ck, f32, bn) in zip(arr, items):
             a.w, a.tap_idx, a.out = w.data_ptr(), idx.data_ptr(), out.data_ptr()
-            a.Cin, a.Cout, a.ntaps, a.transpose, a.CK, a.out_f32 = cin, cout, ntaps, tr, ck, f32
+            a.Cin, a.Cout, a.ntaps, a.transpose, a.CK, a.out_f32, a.bn = cin, cout, ntaps, tr, ck, f32, bn
             a.blk0, a.nblk = blk, max(1, min(4096, -(-out.numel() // per_block)))
             blk += a.nblk
         self.total_blocks = blk
