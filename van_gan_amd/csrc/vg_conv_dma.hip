@@ -49,6 +49,7 @@ struct CdK {
     char* out;
     float* ks_part; unsigned* ks_cnt;
     unsigned m_ow, m_hw, m_hhw;          // fast_div magics: OW; HWb; HHb * HWb
+    int dbg;                             // development ablations (VG_CONV_DMA_DBG): 1 no copy waits, 2 no stage barriers, 4 no weight copies after the prologue
 };
 
 __global__ __launch_bounds__(256) void pack_weights_dma_kernel(const float* __restrict__ w, const int* __restrict__ tap_idx, bf16_t* __restrict__ out,
@@ -72,7 +73,7 @@ extern "C" int vg_pack_weights_dma(const float* w, int T, int Cin, int Cout, con
 // the kernel: NW = 32-channel blocks per wave (BN = 64 * NW), MW = 32-voxel sub-tiles per wave (BM = 128 * MW)
 //   acc layout (32x32x16, A = weights, B = activations): lane l holds voxel (l & 31), channels 8*jj + 4*(l >> 5) + r  (acc[4*jj + r])
 // ------------------------------------------------------------------------------------------------------------------
-template <int NW, int MW>
+template <int NW, int MW, int GT>
 __global__ __launch_bounds__(512, 2) void conv_dma_kernel(const CdK p) {
     constexpr int BN = 64 * NW, BM = 128 * MW;
     constexpr int PITCH = BN * 4 + 16;                     // bytes of one voxel row of the fp32 epilogue tile (16-byte skew: conflict-free 16-byte stores)
@@ -84,9 +85,16 @@ __global__ __launch_bounds__(512, 2) void conv_dma_kernel(const CdK p) {
     int* vtab = (int*)(smem + p.miscoff);                  // [BM]: voxel index of a tile voxel in the output buffer, -1 outside the grid
     float* stat = (float*)(vtab + BM);                     // [BN][2]: this workgroup's sums of the current unit
     int* flag = (int*)(stat + BN * 2);
-    int* tapL = flag + 16;                                 // [VG_MAX_TAPS]: p.tapoff in LDS (a scalar load per tap would be waited for in front of
-                                                           // every fragment read; LDS returns in order, so an offset read issued one step ahead is free)
-    if (tid < VG_MAX_TAPS) tapL[tid] = p.tapoff[tid];      // published by the first unit's first barrier
+    // [VG_MAX_TAPS + 16]: the tap offsets in LDS (a scalar load per tap would be waited for in front of every fragment read; LDS returns in
+    // order, so an offset read issued one step ahead is free).  Per class: its taps followed by a copy of its first two -- the read
+    // pointer runs two taps ahead of the multiplication and wraps at the end of a plane.
+    int* tapL = flag + 16;
+    if (tid < VG_MAX_TAPS + 16) {
+        int e = tid, ci = 0;
+        while (ci + 1 < p.ncls && e >= p.cls[ci].nt + 2) { e -= p.cls[ci].nt + 2; ++ci; }
+        const int nt = p.cls[ci].nt;
+        tapL[tid] = e < nt + 2 ? p.tapoff[p.cls[ci].tap0 + (e < nt ? e : e - nt)] : 0;      // published by the first unit's first barrier
+    }
 
     // ---- per-lane source offsets of the activation image's DMA pieces: the halo box has the same shape for every tile ----
     int aoffs[VG_CD_MAXA];
@@ -105,9 +113,12 @@ __global__ __launch_bounds__(512, 2) void conv_dma_kernel(const CdK p) {
     const int wlane = (lk * BN + wn * NW * 32 + lv) * 16;                     // this lane's weight fragment inside a tap's [half][row] block
     const int CPT = 1 << p.cptl;                                              // 32-voxel chunks per D plane of a tile
 
-    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3, JX = gridDim.x >> 3;
-    const int u_lo = xcd * p.upx, u_hi = min(u_lo + p.upx, p.U);
-    for (int u = u_lo + jx; u < u_hi; u += JX) {
+    // one unit per workgroup.  blockIdx & 7 labels the workgroups that share an XCD (round-robin placement; speed only): label x takes
+    // the units [x * upx, (x + 1) * upx), which are consecutive in (class, panel, slice) -- its workgroups stream the same weights
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+    const int u = xcd * p.upx + jx;
+    if (u >= p.U || jx >= p.upx) return;
+    {
         // ---- unit -> (class, panel, slice, sample, tile) ----
         int t = u;
         const int tile = t % p.tiles; t /= p.tiles;
@@ -118,8 +129,9 @@ __global__ __launch_bounds__(512, 2) void conv_dma_kernel(const CdK p) {
         const int td_i = tile / p.tiles_q, qr = tile - td_i * p.tiles_q;
         const int d0 = td_i * p.TD, q0 = qr << p.qtl, h0 = fast_div(q0, p.m_ow);
         const int p_lo = slice * p.ppk, npl = p.ppk;
-        const int GT = c.GT, G = c.G, nst = npl * G;
-        const int nWp = (GT * BN) >> 5;                                       // 1-KiB pieces of one weight block
+        constexpr int gt = GT;                                                // taps per stage (every class: the host checks)
+        const int G = c.G, nst = npl * G;
+        const int nWp = (gt * BN) >> 5;                                       // 1-KiB pieces of one weight block
         const int n_w = wave < nWp ? (nWp - wave + 7) >> 3 : 0;
         const int wtap = 2 * BN * 16;                                         // bytes of one tap of a weight block
         const char* pbase = p.P + (size_t)n * p.n_bytes + (size_t)((d0 * p.HpA + h0) * p.WpA) * 32;
@@ -144,26 +156,35 @@ __global__ __launch_bounds__(512, 2) void conv_dma_kernel(const CdK p) {
         }
         if (tid < BN * 2) stat[tid] = 0.f;
 
-        auto issueA = [&](int pl, int buf) {
-            const char* b = pbase + (size_t)pl * p.plane_bytes;
+        // ---- K loop: ONE continuous fragment pipeline over all (plane, tap group, tap) of the unit.  Stage = (plane, tap group): its
+        // weight block sits in ring slot stage % nwb, its image in buffer plane & 1.  The only synchronisation is the EVENT in the last
+        // tap of a stage (that tap's fragments are in registers by then): counted vmcnt wait for the NEXT stage's copies + barrier --
+        // after it nobody reads this stage's weight slot any more (nor, in a plane's last stage, its image buffer), so the block nwb
+        // stages on and the image two planes on are requested into them, behind the MFMAs of the step.  Copies complete in issue
+        // order (prologue: image 0, image 1, blocks 0 .. nwb - 1; event j: [image], block j + nwb); `allow` = this wave's copies
+        // issued after the younger of the two things the next stage needs.  The weight blocks of consecutive stages are consecutive
+        // in memory (also across planes), the images one plane apart: two running source pointers. ----
+        const int nwb = p.nwb;
+        const char* asrc = pbase + (size_t)p_lo * p.plane_bytes;             // image of the next plane to request
+        const char* wsrc = wbase + (size_t)p_lo * c.nt * wtap;               // weight block of the next stage to request
+        const int wstage = gt * wtap;
+        auto issueA = [&](int buf) {
 #pragma unroll
             for (int k = 0; k < VG_CD_MAXA; ++k) {
                 const int piece = wave + 8 * k;
-                if (piece < p.nA) glds16(b, aoffs[k], lds0 + buf * p.abuf + piece * 1024);
+                if (piece < p.nA) glds16(asrc, aoffs[k], lds0 + buf * p.abuf + piece * 1024);
             }
+            asrc += p.plane_bytes;
         };
-        auto issueW = [&](int st, int buf) {
-            const int pl = st / G, g = st - pl * G;
-            const char* b = wbase + ((size_t)(p_lo + pl) * c.nt + g * GT) * wtap;
-#pragma unroll
-            for (int k = 0; k < VG_CD_MAXW; ++k) {
-                const int piece = wave + 8 * k;
-                if (piece < nWp) glds16(b, piece * 1024 + lane * 16, lds0 + p.woff + buf * p.wblk + piece * 1024);
-            }
+        const int wl0 = wave * 1024 + lane * 16;
+        auto issueW = [&](int buf) {
+            const unsigned dst = lds0 + p.woff + buf * p.wblk + wave * 1024;
+            for (int k = 0; k < n_w; ++k) glds16(wsrc, wl0 + k * 8192, dst + k * 8192);
+            wsrc += wstage;
         };
-        const int ahead = p.nwb - 1;
-        issueA(p_lo, 0);
-        for (int s2 = 0; s2 < ahead && s2 < nst; ++s2) issueW(s2, s2);
+        issueA(0);
+        if (npl > 1) issueA(1);
+        for (int s2 = 0; s2 < nwb && s2 < nst; ++s2) issueW(s2);
 
         f32x16_d acc[MW][NW];
 #pragma unroll
@@ -173,82 +194,94 @@ __global__ __launch_bounds__(512, 2) void conv_dma_kernel(const CdK p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.f;
 
-        // ---- stages: (plane, tap group).  A stage issues the weight block `ahead` stages on (and, in the first stage of a plane, the
-        // next plane's image) right after its barrier, then multiplies.  Copies complete in issue order; `allow` = this wave's copies
-        // that were issued after the ones this stage needs. ----
-        int pl = 0, g = 0, wb = 0;
-        for (int st = 0; st < nst; ++st) {
-            // Copies complete in issue order.  Issue order: prologue A(plane 0), W(0) .. W(ahead - 1); stage j: [A(next plane) in the first
-            // stage of a plane], then W(j + ahead).  This stage needs W(st) and the image of its plane; `allow` = this wave's copies issued
-            // after the younger of the two (walk back over the stages that issued since).
-            int allow = 0;
+        wait_vmcnt((min(nwb, nst) - 1) * n_w);
+        __syncthreads();                                                      // block 0 and image 0 have landed; vtab / stat are written
+        {
+            const int tl0 = (int)((const char*)tapL - smem) + (c.tap0 + 2 * ci) * 4;         // smem offset of this class's tap offsets
+            bf16x8 A[2][MW], W[2][NW];
             {
-                bool stopped = false;
-                int pj = pl, gj = g;
-                for (int j2 = st - 1; j2 > st - ahead && j2 >= 0; --j2) {
-                    if (gj == 0) { gj = G - 1; --pj; } else --gj;                 // (plane, group) of stage j2
-                    const bool a_j = gj == 0 && pj + 1 < npl, w_j = j2 + ahead < nst;
-                    if (a_j && pj + 1 == pl) { allow += w_j ? n_w : 0; stopped = true; break; }      // that image is this stage's: it must have landed
-                    allow += (a_j ? n_a : 0) + (w_j ? n_w : 0);
-                }
-                if (!stopped && st < ahead)
-                    for (int w2 = st + 1; w2 < ahead; ++w2) if (w2 < nst) allow += n_w;             // the prologue's later weight blocks
+                const int to = *(const int*)(smem + tl0);
+#pragma unroll
+                for (int i = 0; i < MW; ++i) A[0][i] = *(const bf16x8*)(smem + abase[i] + to);
+#pragma unroll
+                for (int jn = 0; jn < NW; ++jn) W[0][jn] = *(const bf16x8*)(smem + p.woff + wlane + jn * 512);
             }
-            wait_vmcnt(allow);
-            __syncthreads();                                                  // everybody's copies have landed; the buffers rewritten below are no longer read
-            if (g == 0 && pl + 1 < npl) issueA(p_lo + pl + 1, (pl + 1) & 1);
-            if (st + ahead < nst) { int nb = wb + ahead; if (nb >= p.nwb) nb -= p.nwb; issueW(st + ahead, nb); }
-            const char* ab = smem + (pl & 1) * p.abuf;
-            const char* wq = smem + p.woff + wb * p.wblk + wlane;
-            const int* tl = tapL + c.tap0 + g * GT;
-            {
-                bf16x8 A[2][MW], W[2][NW];
-                const int last = GT - 1;
-                int o1 = tl[min(1, last)];
-                {
-                    const int to = tl[0];
-#pragma unroll
-                    for (int i = 0; i < MW; ++i) A[0][i] = *(const bf16x8*)(ab + abase[i] + to);
-#pragma unroll
-                    for (int jn = 0; jn < NW; ++jn) W[0][jn] = *(const bf16x8*)(wq + jn * 512);
-                }
-                for (int tt = 0; tt < GT; tt += 2) {
-                    const int o2 = tl[min(tt + 2, last)];                     // offsets run one step ahead of the fragments that use them
-                    {
-                        const int t1 = min(tt + 1, last);
-#pragma unroll
-                        for (int i = 0; i < MW; ++i) A[1][i] = *(const bf16x8*)(ab + abase[i] + o1);
-#pragma unroll
-                        for (int jn = 0; jn < NW; ++jn) W[1][jn] = *(const bf16x8*)(wq + t1 * wtap + jn * 512);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int i = 0; i < MW; ++i)
-#pragma unroll
-                        for (int jn = 0; jn < NW; ++jn) acc[i][jn] = VG_MFMA32(W[0][jn], A[0][i], acc[i][jn]);
-                    __builtin_amdgcn_sched_barrier(0);
-                    o1 = tl[min(tt + 3, last)];
-                    {
-                        const int t2 = min(tt + 2, last);
-#pragma unroll
-                        for (int i = 0; i < MW; ++i) A[0][i] = *(const bf16x8*)(ab + abase[i] + o2);
-#pragma unroll
-                        for (int jn = 0; jn < NW; ++jn) W[0][jn] = *(const bf16x8*)(wq + t2 * wtap + jn * 512);
-                    }
-                    if (tt + 1 >= GT) {                                       // odd tap count: the phantom step adds zero
-#pragma unroll
-                        for (int jn = 0; jn < NW; ++jn) W[1][jn] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int i = 0; i < MW; ++i)
-#pragma unroll
-                        for (int jn = 0; jn < NW; ++jn) acc[i][jn] = VG_MFMA32(W[1][jn], A[1][i], acc[i][jn]);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+            // The stage loop.  Its body is straight-line: GT - 1 plain steps (multiply set t & 1, fetch tap t + 1 into the other set;
+            // fragment addresses are stage base + compile-time immediates) and the event step.  Every MFMA of the K loop sits in this
+            // one loop body: loop nests with MFMAs in several blocks made hipcc rename the 64 accumulator registers per block and
+            // copy them at every back-edge (7 vector instructions per MFMA), a per-tap loop with run-time tap bookkeeping cost 10
+            // scalar instructions per MFMA and several taken branches per tap.
+            int tlp = tl0;                                                    // smem offset of the table entry of the stage's first tap
+            int pl = 0, g = 0, wb = 0;
+            int aoff = 0, wrun = p.woff + wlane;                              // image buffer of the current plane; this lane's fragment of the stage's first tap
+#define VG_CD_LOAD(os, ao, wo)                                                                                                     \
+            {                                                                                                                      \
+                _Pragma("unroll") for (int i = 0; i < MW; ++i) A[os][i] = *(const bf16x8*)(smem + (abase[i] + (ao)));              \
+                _Pragma("unroll") for (int jn = 0; jn < NW; ++jn) W[os][jn] = *(const bf16x8*)(smem + (wo) + jn * 512);            \
             }
-            if (++g == G) { g = 0; ++pl; }
-            if (++wb == p.nwb) wb = 0;
+#define VG_CD_MFMA(cs)                                                                                                             \
+            {                                                                                                                      \
+                __builtin_amdgcn_sched_barrier(0);                                                                                 \
+                _Pragma("unroll") for (int i = 0; i < MW; ++i)                                                                     \
+                    _Pragma("unroll") for (int jn = 0; jn < NW; ++jn) acc[i][jn] = VG_MFMA32(W[cs][jn], A[cs][i], acc[i][jn]);     \
+                __builtin_amdgcn_sched_barrier(0);                                                                                 \
+            }
+            for (int st = 0; st < nst; ++st) {
+                int o[GT];
+#pragma unroll
+                for (int t = 1; t < GT; ++t) o[t] = *(const int*)(smem + tlp + 4 * t);
+                const int onext = *(const int*)(smem + tlp + 4 * gt);         // first tap of the next stage (the table repeats a class's first taps behind its last)
+#pragma unroll
+                for (int t = 0; t < GT - 1; ++t) {
+                    VG_CD_LOAD((t + 1) & 1, aoff + o[t + 1], wrun + (t + 1) * wtap)
+                    VG_CD_MFMA(t & 1)
+                }
+                // ---- event step: the stage's last tap (set (gt - 1) & 1) ----
+                const bool more = st + 1 < nst;
+                int nwbuf = wb, npl_ = pl, ng = g, ntlp = tlp, naoff = aoff, nwrun = wrun, on = 0;
+                if (more) {
+                    int allow;
+                    if (G >= nwb - 1 && st >= nwb - 1) {
+                        // steady state: the events st - nwb + 2 .. st - 1 issued after the needed block; at most one of them an image
+                        int nw_ = min(st - 1, nst - nwb - 1) - (st + 2 - nwb) + 1; nw_ = nw_ < 0 ? 0 : nw_;
+                        allow = nw_ * n_w + ((pl >= 1 && g <= nwb - 3 && pl + 1 < npl) ? n_a : 0);
+                    } else {
+                        allow = 0;
+                        int j2 = st - 1, pj = pl, gj = g;
+                        for (; j2 >= 0; --j2) {
+                            if (gj == 0) { gj = G - 1; --pj; } else --gj;
+                            const bool a_j = gj == G - 1 && pj + 2 < npl, w_j = j2 + nwb < nst;
+                            if (w_j && j2 + nwb == st + 1) break;
+                            if (a_j && g == G - 1 && pj + 2 == pl + 1) { allow += w_j ? n_w : 0; break; }
+                            allow += (a_j ? n_a : 0) + (w_j ? n_w : 0);
+                        }
+                        if (j2 < 0 && st + 1 < nwb) allow += (min(nwb, nst) - 2 - st) * n_w;
+                    }
+                    if (!(p.dbg & 1)) wait_vmcnt(allow);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (!(p.dbg & 2)) __builtin_amdgcn_s_barrier();
+                    nwbuf = wb + 1 == nwb ? 0 : wb + 1;
+                    if (++ng == G) { ng = 0; ++npl_; }
+                    ntlp = ng == 0 ? tl0 : tlp + 4 * gt;
+                    naoff = (npl_ & 1) * p.abuf;
+                    nwrun = p.woff + nwbuf * p.wblk + wlane;
+                    on = onext;
+                }
+                if constexpr ((GT - 1) & 1) {                                 // last tap in set 1: the next stage's first tap goes to set 0 ahead of the MFMAs
+                    VG_CD_LOAD(0, naoff + on, nwrun)
+                    VG_CD_MFMA(1)
+                } else {                                                      // last tap in set 0: multiply, then refill set 0 (an LDS round trip per stage in the open)
+                    VG_CD_MFMA(0)
+                    VG_CD_LOAD(0, naoff + on, nwrun)
+                }
+                if (more) {
+                    if (g == G - 1 && pl + 2 < npl) issueA(pl & 1);
+                    if (st + nwb < nst && !(p.dbg & 4)) issueW(wb);
+                }
+                wb = nwbuf; pl = npl_; g = ng; tlp = ntlp; aoff = naoff; wrun = nwrun;
+            }
+#undef VG_CD_LOAD
+#undef VG_CD_MFMA
         }
 
         // ---- K split: leave the partial tile in scratch; the slice that arrives last adds all of them in slice order ----
@@ -268,7 +301,7 @@ __global__ __launch_bounds__(512, 2) void conv_dma_kernel(const CdK p) {
             if (tid == 0) *flag = (int)__hip_atomic_fetch_add(p.ks_cnt + cell, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __syncthreads();
             const bool last = *flag == p.ks - 1;
-            if (!last) continue;
+            if (!last) return;
             const float* base = p.ks_part + cell * p.ks * SLOT;
 #pragma unroll
             for (int i = 0; i < MW; ++i)
@@ -352,14 +385,24 @@ __global__ __launch_bounds__(512, 2) void conv_dma_kernel(const CdK p) {
     }
 }
 
-template <int NW, int MW>
-static void launch_cd(const CdK& k, int grid, int lds, hipStream_t s) {
+template <int NW, int MW, int GT>
+static void launch_cd3(const CdK& k, int grid, int lds, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_dma_kernel<NW, MW>, hipFuncAttributeMaxDynamicSharedMemorySize, VG_LDS_LIMIT);
+        (void)hipFuncSetAttribute((const void*)conv_dma_kernel<NW, MW, GT>, hipFuncAttributeMaxDynamicSharedMemorySize, VG_LDS_LIMIT);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_dma_kernel<NW, MW>), dim3(grid), dim3(512), lds, s, k);
+    hipLaunchKernelGGL((conv_dma_kernel<NW, MW, GT>), dim3(grid), dim3(512), lds, s, k);
+}
+// GT (template): the stage body is unrolled for this many taps; classes with fewer taps per stage skip the steps they do not have
+template <int NW, int MW>
+static int launch_cd(const CdK& k, int gtmax, int grid, int lds, hipStream_t s) {
+    if (gtmax == 9) launch_cd3<NW, MW, 9>(k, grid, lds, s);
+    else if (gtmax == 8) launch_cd3<NW, MW, 8>(k, grid, lds, s);
+    else if (gtmax == 3) launch_cd3<NW, MW, 3>(k, grid, lds, s);
+    else if (gtmax == 4) launch_cd3<NW, MW, 4>(k, grid, lds, s);
+    else return VG_EINVAL;
+    return VG_OK;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -404,13 +447,11 @@ static int cd_plan(const vg_conv_desc* d, CdPlan& pl) {
     // (a divisor of the tap count, <= 9; a class of <= 9 taps is one stage per plane) and the depth of the weight ring: the ring must
     // cover the copies' latency, (nwb - 1) * GT >= ~12 taps of MFMA time, with stages as long as the LDS allows.
     const int BM = 256, plane = d->OH * d->OW;
-    const int tile_bytes = BM * (BN * 4 + 16), misc = BM * 4 + BN * 8 + 64 + VG_MAX_TAPS * 4;
+    const int tile_bytes = BM * (BN * 4 + 16), misc = BM * 4 + BN * 8 + 64 + (VG_MAX_TAPS + 16) * 4;
     const int wtap = 2 * BN * 16;
-    int ntmax = 0; bool small = true;
-    for (int c = 0; c < pl.ncls; ++c) { if (pl.nt[c] > ntmax) ntmax = pl.nt[c]; if (pl.nt[c] > 9) small = false; }
-    if (!small && pl.ncls > 1) {                           // several classes with more than 9 taps: they must agree on GT
-        for (int c = 1; c < pl.ncls; ++c) if (pl.nt[c] != pl.nt[0]) return 0;
-    }
+    const int ntmax = pl.nt[0];
+    for (int c = 1; c < pl.ncls; ++c) if (pl.nt[c] != ntmax) return 0;       // the kernel's stage body is unrolled for ONE tap count per stage
+    const bool small = false;
     long best = -1;
     for (int TD = 1; TD <= 8; TD <<= 1) {
         const int QT = BM / TD;
@@ -423,7 +464,8 @@ static int cd_plan(const vg_conv_desc* d, CdPlan& pl) {
         const int abuf = 2 * IMG * 16;
         int bGT = 0, bnwb = 0; long bq = -1;
         for (int GT = small ? ntmax : 9; GT >= 1; --GT) {
-            if (!small && (ntmax % GT)) continue;
+            if ((ntmax % GT) || (GT != 9 && GT != 8 && GT != 4 && GT != 3)) continue;
+            if (!small && vg_tune("CONV_DMA_GT", 0) && GT != vg_tune("CONV_DMA_GT", 0) && (ntmax % vg_tune("CONV_DMA_GT", 0)) == 0) continue;
             if (GT * BN / 32 > 8 * VG_CD_MAXW) continue;
             int nwb = (VG_LDS_LIMIT - misc - 2 * abuf) / (GT * wtap); if (nwb > 8) nwb = 8;
             if (vg_tune("CONV_DMA_NWB", 0) && nwb > vg_tune("CONV_DMA_NWB", 0)) nwb = vg_tune("CONV_DMA_NWB", 0);
@@ -507,7 +549,7 @@ int vg_conv_dma(const vg_conv_desc* d, hipStream_t s) {
     k.TD = pl.TD; k.QT = pl.QT; k.qtl = ilog2_exact(pl.QT); k.cptl = ilog2_exact(pl.QT / 32); k.tiles_q = pl.tiles_q; k.tiles = tiles;
     k.HHb = pl.HHb; k.HWb = pl.HWb; k.IMG = pl.IMG; k.nvox = pl.nvox; k.nA = pl.nA; k.abuf = pl.abuf;
     k.wblk = pl.wblk; k.nwb = pl.nwb; k.woff = 2 * pl.abuf;
-    k.miscoff = pl.lds - (256 * 4 + BN * 8 + 64 + VG_MAX_TAPS * 4);
+    k.miscoff = pl.lds - (256 * 4 + BN * 8 + 64 + (VG_MAX_TAPS + 16) * 4);
     k.ncob = ncob; k.ks = ks; k.ppk = NPL / ks;
     const long U = units0 * ks;
     if (U >= (1L << 30)) return VG_EINVAL;
@@ -516,10 +558,10 @@ int vg_conv_dma(const vg_conv_desc* d, hipStream_t s) {
     k.out = (char*)d->out;
     k.ks_cnt = (unsigned*)d->scratch; k.ks_part = (float*)((char*)d->scratch + VG_SCRATCH_CTR_BYTES + p_bytes);
     auto magic = [](int dd) { return dd <= 1 ? 0u : (unsigned)((1ULL << 32) / (unsigned)dd + 1ULL); };
+    k.dbg = vg_tune("CONV_DMA_DBG", 0);
     k.m_ow = magic(d->OW); k.m_hw = magic(pl.HWb); k.m_hhw = magic(pl.HHb * pl.HWb);
-    int per_x = vg_tune("CONV_DMA_GRID", 256) / 8; if (per_x < 1) per_x = 1; if (per_x > k.upx) per_x = k.upx;
-    const int grid = 8 * per_x;
-    if (vg_dry("conv_dma<%d,%d>|td%d|gt%d|nwb%d|ks%d|cls%d|walk%d", BN, 256, pl.TD, pl.GT[0], pl.nwb, ks > 1 ? 1 : 0, pl.ncls > 1 ? 1 : 0, U > grid ? 1 : 0)) return VG_OK;
+    const int grid = 8 * k.upx;                            // one unit per workgroup
+    if (vg_dry("conv_dma<%d,%d>|td%d|gt%d|nwb%d|ks%d|cls%d|walk%d", BN, 256, pl.TD, pl.GT[0], pl.nwb, ks > 1 ? 1 : 0, pl.ncls > 1 ? 1 : 0, U > 256 ? 1 : 0)) return VG_OK;
     MatK m;
     m.src0 = d->src0; m.src1 = d->src1; m.c0 = d->c_src0; m.c1 = d->c_src1; m.shift0 = d->src0_shift ? 1 : 0;
     m.N = d->N; m.D = d->D; m.H = d->H; m.W = d->W; m.Cin = Cin;
@@ -528,6 +570,8 @@ int vg_conv_dma(const vg_conv_desc* d, hipStream_t s) {
     m.pmin_d = pl.mn[0]; m.pmin_h = pl.mn[1]; m.pmin_w = pl.mn[2]; m.Dp = pl.DpA; m.Hp = pl.HpA; m.Wp = pl.WpA;
     m.deint = 0; m.WE = 0; m.Wps = pl.WpA; m.out = (bf16_t*)k.P;
     vg_launch_materialize(m, s);
-    if (BN == 128) launch_cd<2, 2>(k, grid, pl.lds, s); else launch_cd<1, 2>(k, grid, pl.lds, s);
+    int gtmax = 0; for (int c = 0; c < pl.ncls; ++c) if (pl.GT[c] > gtmax) gtmax = pl.GT[c];
+    const int lrc = BN == 128 ? launch_cd<2, 2>(k, gtmax, grid, pl.lds, s) : launch_cd<1, 2>(k, gtmax, grid, pl.lds, s);
+    if (lrc != VG_OK) return lrc;
     return vg_check_launch();
 }

@@ -40,19 +40,29 @@ __device__ __forceinline__ void glds16(const char* sbase, int voff, unsigned lds
 }
 
 // s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate): all but this wave's n youngest copies
-// have landed.  n beyond the table waits for more than asked (a smaller count is always safe).
-#define VG_VMCNT_CASE(i) case i: asm volatile("s_waitcnt vmcnt(" #i ")" ::: "memory"); break;
-__device__ __forceinline__ void wait_vmcnt(int n) {
-    switch (n) {
-        VG_VMCNT_CASE(0) VG_VMCNT_CASE(1) VG_VMCNT_CASE(2) VG_VMCNT_CASE(3) VG_VMCNT_CASE(4) VG_VMCNT_CASE(5) VG_VMCNT_CASE(6) VG_VMCNT_CASE(7)
-        VG_VMCNT_CASE(8) VG_VMCNT_CASE(9) VG_VMCNT_CASE(10) VG_VMCNT_CASE(11) VG_VMCNT_CASE(12) VG_VMCNT_CASE(13) VG_VMCNT_CASE(14) VG_VMCNT_CASE(15)
-        VG_VMCNT_CASE(16) VG_VMCNT_CASE(17) VG_VMCNT_CASE(18) VG_VMCNT_CASE(19) VG_VMCNT_CASE(20) VG_VMCNT_CASE(21) VG_VMCNT_CASE(22) VG_VMCNT_CASE(23)
-        VG_VMCNT_CASE(24) VG_VMCNT_CASE(25) VG_VMCNT_CASE(26) VG_VMCNT_CASE(27) VG_VMCNT_CASE(28) VG_VMCNT_CASE(29) VG_VMCNT_CASE(30) VG_VMCNT_CASE(31)
-        VG_VMCNT_CASE(32) VG_VMCNT_CASE(33) VG_VMCNT_CASE(34) VG_VMCNT_CASE(35) VG_VMCNT_CASE(36) VG_VMCNT_CASE(37) VG_VMCNT_CASE(38) VG_VMCNT_CASE(39)
-        default: asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); break;
-    }
+// have landed.  n beyond the table waits for more than asked (a smaller count is always safe).  A computed jump into a table of
+// (s_waitcnt vmcnt(i); s_branch end) pairs, 8 bytes each: hipcc lowers a 41-way switch over inline-asm cases into a chain of
+// ~100 scalar compare / branch instructions, which the LDS-DMA kernels paid once per stage.
+#define VG_VM1(i) "s_waitcnt vmcnt(" #i ")\n\ts_branch 2f\n\t"
+#define VG_VM8(a, b, c, d, e, f, g, h) VG_VM1(a) VG_VM1(b) VG_VM1(c) VG_VM1(d) VG_VM1(e) VG_VM1(f) VG_VM1(g) VG_VM1(h)
+__device__ __forceinline__ void wait_vmcnt(int n_) {
+    const int n = __builtin_amdgcn_readfirstlane(n_);          // wave-uniform by contract; pins it to a scalar register
+    asm volatile(
+        "s_min_u32 s42, %0, 40\n\t"
+        "s_lshl_b32 s42, s42, 3\n\t"
+        "s_getpc_b64 s[40:41]\n"
+        "0:\n\t"
+        "s_add_u32 s40, s40, s42\n\t"
+        "s_addc_u32 s41, s41, 0\n\t"
+        "s_add_u32 s40, s40, 1f-0b\n\t"
+        "s_addc_u32 s41, s41, 0\n\t"
+        "s_setpc_b64 s[40:41]\n"
+        "1:\n\t"
+        VG_VM8(0, 1, 2, 3, 4, 5, 6, 7) VG_VM8(8, 9, 10, 11, 12, 13, 14, 15) VG_VM8(16, 17, 18, 19, 20, 21, 22, 23)
+        VG_VM8(24, 25, 26, 27, 28, 29, 30, 31) VG_VM8(32, 33, 34, 35, 36, 37, 38, 39) VG_VM1(40)
+        "2:\n\t"
+        : : "s"(n) : "s40", "s41", "s42", "scc", "memory");
 }
-
 
 // Kernel of vg_pack_weights_dma / the bn > 0 items of vg_pack_weights_multi: fp32 DHWIO [T][Cin][Cout] -> Wd (see the header).
 // transpose 0: rows = output channels, contraction = input channels (forward); 1: rows = input channels, contraction = output

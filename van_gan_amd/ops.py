@@ -546,8 +546,14 @@ class ConvLayer:
                 c['wp'] = torch.zeros(lib.vg_packed_rows(cin), c['ktot'], dtype=dtype, device=dev)
 
     def _dma_bn(self, cin, cout, taps, istr, in_dims, out_dims) -> int:
-        """Channel-panel width with which the LDS-DMA family serves this forward convolution (0: the gather kernels do)."""
+        """Channel-panel width with which the LDS-DMA family serves this forward convolution (0: the gather kernels do).
+        Policy (measured layer by layer, DESIGN 6.17): the family is bound by LDS read bandwidth at ~50 % of the MFMA rate of its CUs;
+        it beats the gather kernels where their staging is expensive -- the decoder's first convolutions over the virtual upsample +
+        concat (>= 192 input channels) -- and loses to conv32_kernel's register-streamed weights on the plain wide layers."""
         if self.f32 or os.environ.get('VG_CONV_DMA', '1') == '0' or len(taps) > _lib.VG_MAX_TAPS:
+            return 0
+        pol = os.environ.get('VG_CONV_DMA_FWD', 'cat')
+        if pol == 'none' or (pol == 'cat' and cin < 192) or math.prod(out_dims) < int(os.environ.get('VG_CONV_DMA_MINVOX', '4096')):
             return 0
         d = ConvDesc()
         d.c_src0, d.c_src1, d.N = cin, 0, 1
@@ -562,6 +568,13 @@ class ConvLayer:
     def _dma_bn_dgrad(self) -> int:
         """The same for the data gradient: all output-parity classes in one class-parallel launch."""
         if self.f32 or os.environ.get('VG_CONV_DMA', '1') == '0' or not self.d_classes:
+            return 0
+        # data gradients iterate over padded / parity-class grids (17^3, 18^3, 33^3, 34^3 ...): the family's linear tiles fill those
+        # to 85-97 % where box tiles reach 43-68 %.  Not at the 8^3 level (a handful of tiles: the K split's exchange costs more)
+        pol = os.environ.get('VG_CONV_DMA_DGRAD', 'all')
+        if pol == 'none' or math.prod(self.out_dims) < int(os.environ.get('VG_CONV_DMA_MINVOX', '4096')):
+            return 0
+        if pol == 'big' and self.cin * self.cout < 128 * 64:
             return 0
         if sum(len(c['taps']) for c in self.d_classes) > _lib.VG_MAX_TAPS or len(self.d_classes) > 8:
             return 0
