@@ -29,7 +29,10 @@ def test_every_variant_of_the_baseline_configs_has_a_gpu_parity_case():
                  'c1k3_fwd', 'c1k3_wgrad', 'wgrad<bf16,24,1', 'wgrad<bf16,7,4', 'wgrad<bf16,6,4', 'walk1', 'ch1', 'part1', 'n1',
                  'wgrad_dma<4,1,d0>', 'wgrad_dma<4,1,d1>', 'wgrad_dma<12,1,d1>', 'wgrad_dma<4,2,d0>', 'wgrad_dma<4,2,d1>', 'wgrad_dma<8,2,d0>', 'wgrad_dma<8,4,d0>', '|s2|', '|nb3|', '|ks4', '|ks2',
                  'conv_thin<m0', 'conv_thin<m1', 'pw_gemm<2,1,g1,a0>', 'pw_gemm<1,3,g0,a1>', 'pw_gemm<1,1,g1,a1>',
-                 'wgrad_pw_dma<3,1>', 'wgrad_pw_dma<6,2>', 'wgrad_pw_dma<4,4>', 'wgrad_pw_dma<6,4>', '|s1|u1|', '|s2|u0|'):
+                 'wgrad_pw_dma<3,1>', 'wgrad_pw_dma<6,2>', 'wgrad_pw_dma<4,4>', 'wgrad_pw_dma<6,4>', '|s1|u1|', '|s2|u0|',
+                 # the LDS-DMA forward / data-gradient family: both panel widths, 4^3 and 3^3 stage bodies, K split, class-parallel strided
+                 # data gradients, launches with more units than CUs
+                 'conv_dma<128,256>', 'conv_dma<64,256>', '|gt8|', '|gt9|', 'ks1|cls0', 'ks0|cls1', 'cls1|walk1'):
         assert frag in names, frag
 
 

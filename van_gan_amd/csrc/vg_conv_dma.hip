@@ -470,8 +470,8 @@ static int cd_plan(const vg_conv_desc* d, CdPlan& pl) {
             int nwb = (VG_LDS_LIMIT - misc - 2 * abuf) / (GT * wtap); if (nwb > 8) nwb = 8;
             if (vg_tune("CONV_DMA_NWB", 0) && nwb > vg_tune("CONV_DMA_NWB", 0)) nwb = vg_tune("CONV_DMA_NWB", 0);
             if (nwb < 2) { if (small) break; continue; }
-            const int cover = (nwb - 1) * GT;
-            const long q = (cover >= 12 ? 1000 : 0) + (cover >= 12 ? GT * 10 : cover * 10) + (nwb <= 4 ? 1 : 0);
+            const int cover = (nwb - 1) * GT, need = vg_tune("CONV_DMA_COVER", 8);
+            const long q = (cover >= need ? 1000 : 0) + (cover >= need ? GT * 10 : cover * 10) + (nwb <= 4 ? 1 : 0);
             if (q > bq) { bq = q; bGT = GT; bnwb = nwb; }
             if (small) break;                               // the classes' own tap counts are the stages
         }
@@ -481,7 +481,7 @@ static int cd_plan(const vg_conv_desc* d, CdPlan& pl) {
         int body = 2 * abuf + bnwb * bGT * wtap; if (body < tile_bytes) body = tile_bytes;
         if (body + misc > VG_LDS_LIMIT) continue;
         const int tiles_d = (d->OD + TD - 1) / TD, tiles_q = (plane + QT - 1) / QT;
-        const long score = (long)tiles_d * tiles_q * 100000 + nvox + ((bnwb - 1) * bGT < 12 ? 40000 : 0);
+        const long score = (long)tiles_d * tiles_q * 100000 + nvox + ((bnwb - 1) * bGT < vg_tune("CONV_DMA_COVER", 8) ? 40000 : 0);
         if (best < 0 || score < best) {
             best = score;
             pl.TD = TD; pl.QT = QT; pl.HD = HD; pl.HHb = HHb; pl.HWb = HWb; pl.IMG = IMG; pl.nvox = nvox; pl.nA = nA; pl.abuf = abuf;

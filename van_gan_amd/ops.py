@@ -547,12 +547,13 @@ class ConvLayer:
 
     def _dma_bn(self, cin, cout, taps, istr, in_dims, out_dims) -> int:
         """Channel-panel width with which the LDS-DMA family serves this forward convolution (0: the gather kernels do).
-        Policy (measured layer by layer, DESIGN 6.17): the family is bound by LDS read bandwidth at ~50 % of the MFMA rate of its CUs;
-        it beats the gather kernels where their staging is expensive -- the decoder's first convolutions over the virtual upsample +
-        concat (>= 192 input channels) -- and loses to conv32_kernel's register-streamed weights on the plain wide layers."""
+        Policy (measured layer by layer and in the step): the family is bound by LDS read bandwidth at ~50 % of the MFMA rate
+        of its CUs.  Solo it beats the gather kernels only where their staging is expensive (the decoder's first convolutions over the
+        virtual upsample + concat, >= 192 input channels: 'cat') and loses to conv32_kernel's register-streamed weights on the plain wide
+        layers; in the concurrent step the forward gains nothing (20.66 vs 20.51 ms), so forwards stay on the gather kernels ('none')."""
         if self.f32 or os.environ.get('VG_CONV_DMA', '1') == '0' or len(taps) > _lib.VG_MAX_TAPS:
             return 0
-        pol = os.environ.get('VG_CONV_DMA_FWD', 'cat')
+        pol = os.environ.get('VG_CONV_DMA_FWD', 'none')
         if pol == 'none' or (pol == 'cat' and cin < 192) or math.prod(out_dims) < int(os.environ.get('VG_CONV_DMA_MINVOX', '4096')):
             return 0
         d = ConvDesc()
