@@ -47,7 +47,7 @@ def perturb(P, seed):
     return P
 
 
-def grad_report(got: dict, ref: dict, label: str, rel_tol=1e-1, cos_tol=0.99, check=True):
+def grad_report(got: dict, ref: dict, label: str, rel_tol=1e-1, cos_tol=0.99, check=True, abs_tol=2e-3):
     gmax = max(float(v.double().norm()) for v in ref.values())
     rows, bad = [], []
     for k in ref:
@@ -57,7 +57,7 @@ def grad_report(got: dict, ref: dict, label: str, rel_tol=1e-1, cos_tol=0.99, ch
         cos = float((a @ b) / (a.norm() * b.norm() + 1e-30))
         rows.append((k, nb, err / (nb + 1e-30), cos))
         if nb < 1e-2 * gmax:         # small tensors: absolute check against the largest gradient norm
-            if err > 2e-3 * gmax:
+            if err > abs_tol * gmax:
                 bad.append((k, 'abs', err, gmax))
         elif err / nb > rel_tol or cos < cos_tol:
             bad.append((k, 'rel', err / nb, cos))

@@ -476,6 +476,10 @@ class VanGan:
             self._mark('A all joined')
         self._acc, self._coef = acc, coef
         self._aux = dict(fake_S=fake_S, fake_I=fake_I, cycled_S=cyc_S, cycled_I=cyc_I, logits_S=logS, logits_I=logI)
+        # forward contexts of this step (views into the arena, valid until the next step resets it): what the engine STORED, for the
+        # teacher-forced parity test (tests/test_gpu_teacher.py).  G_IS.a = G_IS(real_I), G_SI.a = G_SI(real_S), G_IS.b = G_IS(fake_I),
+        # G_SI.b = G_SI(fake_S); the discriminators ran on [real; fake] batches
+        self._fwd_ctx = {'G_IS.a': c1, 'G_SI.a': c2, 'G_IS.b': c3, 'G_SI.b': c4, 'D_S': dS, 'D_I': dI}
         return B, S, nps
 
     def _results(self, B, S, nps) -> Dict[str, float]:
