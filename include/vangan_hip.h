@@ -96,7 +96,7 @@ typedef struct {
     const void* res;         /* bf16 [N][BD][BH][BW][Cout] residual operand or NULL */
     const float* res_scale;  /* [N][Cout] affine on the residual (InstanceNorm of the shortcut) */
     const float* res_shift;
-    int32_t tanh_out;
+    int32_t tanh_out;        /* tanh after everything else; with accumulate: out = tanh(out + value) (last tap chunk of a 7^3 head) */
     void* out;               /* bf16 (or f32 when out_f32) [N][BD][BH][BW][Cout] */
     int32_t out_f32;
     int32_t accumulate;      /* out += value (data-gradient accumulation) */
@@ -265,6 +265,12 @@ int vg_shortcut_dgrad_concat(const vg_conv_desc* d, void* dlow, void* dskip, int
  * 838 -> 436 MB per application at 128^3.  Returns 1 when the shape is not served (caller: vg_actnorm_bwd_apply + the call above). */
 int vg_shortcut_dgrad_concat_norm(const vg_conv_desc* d, const vg_actnorm_bwd_desc* b, void* dlow, void* dskip, int c_low,
                                   int accumulate, vg_stream_t stream);
+
+/* out = act(a * a_scale + a_shift) + (b * b_scale + b_shift): layers.add([input_tensor, InstanceNorm(conv2)]) of the ResNet generator's
+ * residual block (building_blocks.py:68-123; generator.py:52-56), both operands [N][S][C] bf16 (f32: float) with their pending on-read
+ * affine [N][C] (NULL: none); a_act a VG_ACT_* applied to the first operand after its affine. */
+int vg_affine_add(const void* a, const float* a_scale, const float* a_shift, int a_act, const void* b, const float* b_scale,
+                  const float* b_shift, int N, int64_t S, int C, void* out, int f32, vg_stream_t stream);
 
 /* d_pre = dy * (1 - y*y)   (tanh output activation, resunet_model.py:245), all fp32 */
 int vg_tanh_bwd(const float* dy, const float* y, float* dpre, int64_t n, vg_stream_t stream);

@@ -96,3 +96,13 @@ def test_unbuildable_reference_variants_raise_like_the_reference():
         ResUNet(st, (32, 32, 32), upsample_mode='bilinear')
     with pytest.raises(ValueError):
         ResUNet(st, (48, 40, 32))                       # spatial dims must be multiples of 16 (4 stride-2 stages)
+
+
+def test_resnet_generator_specs_match_the_oracle():
+    """The non-default ResNet generator exchanges weights with its oracle restatement 1:1: same names, order, shapes,
+    25 176 897 parameters (generator.py:7-73 with filters=32, 3 + 6 + 3 blocks as vangan.py:127-134 configures it)."""
+    from oracle import vangan_oracle as O
+    from van_gan_amd.nets import resnet_param_specs
+    a, b = resnet_param_specs(), O.resnet_param_specs()
+    assert [(n, tuple(s)) for n, s, _ in a] == [(n, tuple(s)) for n, s, _ in b]
+    assert O.n_params(b) == 25176897

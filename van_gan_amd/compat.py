@@ -34,8 +34,10 @@ def engine_kwargs_from_args(args, lambda_cycle=10.0, lambda_identity=5, lambda_r
     if gen_s2i not in KNOWN_GENERATORS:
         raise ValueError('SI Generator type not recognised')          # vangan.py:164
     if gen_i2s != 'resUnet' or gen_s2i != 'resUnet':
-        raise NotImplementedError("only the default generators (gen_i2s='resUnet', gen_s2i='resUnet', main.py:196-200) are "
-                                  'built for MI355X; resnet / vnet are SURVEY section 8(f)4')
+        raise NotImplementedError("train_step is built for the default generators only (gen_i2s='resUnet', gen_s2i='resUnet', "
+                                  "main.py:196-200).  SURVEY section 8(f)4: the 'resnet' generator (generator.py:7-73) exists as a FORWARD "
+                                  'network for inference (van_gan_amd.nets.ResNetGenerator, parity tests/test_gpu_resnet.py), its backward '
+                                  "and 'vnet' are not built")
     if wasserstein:
         raise NotImplementedError('the WGAN-GP branch (vangan.py:355-378,400-423) is not built: SURVEY section 8(f)4')
     if semi_supervised:

@@ -509,6 +509,43 @@ extern "C" int vg_bf16_to_f32(const void* x, float* y, int64_t n, vg_stream_t st
     return vg_check_launch();
 }
 
+// out = act_a(a * sa + ha) + (b * sb + hb): the Add of the ResNet generator's residual block (building_blocks.py:68-123:
+// layers.add([input_tensor, InstanceNorm(conv2)])), both operands read with their pending on-read affine -- the block input may
+// still be the un-normalised output of the convolution in front of it.  8 channels per thread.
+template <typename T>
+__global__ __launch_bounds__(256) void affine_add_kernel(const T* __restrict__ a, const float* __restrict__ sa, const float* __restrict__ ha, int act_a,
+                                                         const T* __restrict__ b, const float* __restrict__ sb, const float* __restrict__ hb,
+                                                         int64_t S, int C, int64_t units, T* __restrict__ out) {
+    const int cg = C >> 3;
+    const float slope = act_a == VG_ACT_RELU ? 0.f : (act_a == VG_ACT_LRELU ? VG_LRELU : 1.f);
+    for (int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x; u < units; u += (int64_t)gridDim.x * 256) {
+        const int c = (int)(u % cg) * 8;
+        const int64_t v = u / cg;
+        const int n = (int)(v / S);
+        float x[8], y[8];
+        load8<T>(a + v * C + c, x); load8<T>(b + v * C + c, y);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float p = sa ? x[e] * sa[n * C + c + e] + ha[n * C + c + e] : x[e];
+            p = fmaxf(p, p * slope);
+            const float q = sb ? y[e] * sb[n * C + c + e] + hb[n * C + c + e] : y[e];
+            x[e] = p + q;
+        }
+        store8<T>(out + v * C + c, x);
+    }
+}
+extern "C" int vg_affine_add(const void* a, const float* a_scale, const float* a_shift, int a_act, const void* b, const float* b_scale,
+                             const float* b_shift, int N, int64_t S, int C, void* out, int f32, vg_stream_t stream) {
+    vg_begin();
+    if (!a || !b || !out || N < 1 || S < 1 || C < 8 || (C % 8) || (a_scale && !a_shift) || (b_scale && !b_shift)) return VG_EINVAL;
+    const int64_t units = (int64_t)N * S * (C / 8);
+    if (f32) hipLaunchKernelGGL(affine_add_kernel<float>, dim3(ew_blocks(units)), dim3(256), 0, (hipStream_t)stream, (const float*)a, a_scale, a_shift,
+                                a_act, (const float*)b, b_scale, b_shift, S, C, units, (float*)out);
+    else hipLaunchKernelGGL(affine_add_kernel<bf16_t>, dim3(ew_blocks(units)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a, a_scale, a_shift,
+                            a_act, (const bf16_t*)b, b_scale, b_shift, S, C, units, (bf16_t*)out);
+    return vg_check_launch();
+}
+
 // ------------------------------------------------------------------------------------------------
 // counter-based RNG (Philox-4x32-10) for GaussianNoise / SpatialDropout3D
 // ------------------------------------------------------------------------------------------------

@@ -516,6 +516,132 @@ class ResUNet:
 
 
 # ======================================================================================================
+# (f)4: the ResNet generator (generator.py:7-73) -- forward only (inference / test_step-style use)
+# ======================================================================================================
+RESNET_F, RESNET_DOWN, RESNET_RES, RESNET_UP = 32, 3, 6, 3
+
+
+def resnet_param_specs() -> List[Tuple[str, Tuple[int, ...], str]]:
+    """Names / order / layouts of oracle.vangan_oracle.resnet_param_specs (weights exchange 1:1)."""
+    s: List[Tuple[str, Tuple[int, ...], str]] = []
+
+    def inorm(name, c):
+        s.append((name + '.gamma', (c,), 'ones')); s.append((name + '.beta', (c,), 'zeros'))
+
+    f = RESNET_F
+    s.append(('c7.w', (7, 7, 7, 1, f), 'he_normal')); inorm('c7.in', f)
+    for i in range(RESNET_DOWN):
+        s.append(('down%d.w' % i, (3, 3, 3, f, 2 * f), 'he_normal')); inorm('down%d.in' % i, 2 * f)
+        f *= 2
+    for j in range(RESNET_RES):
+        for c in ('c1', 'c2'):
+            s.append(('res%d.%s.w' % (j, c), (3, 3, 3, f, f), 'he_normal')); inorm('res%d.%s.in' % (j, c), f)
+    for i in range(RESNET_UP):
+        s.append(('up%d.w' % i, (4, 4, 4, f, f // 2), 'he_normal')); inorm('up%d.in' % i, f // 2)
+        f //= 2
+    s.append(('out.w', (7, 7, 7, f, 1), 'glorot_uniform')); s.append(('out.b', (1,), 'zeros'))
+    return s
+
+
+class ResNetGenerator:
+    """get_resnet_generator (generator.py:7-73) as vangan.py:88-97,127-134 configures it (filters 32, three stride-2 stages, six
+    residual blocks, three UpSampling3D + 4^3 'same' stages, 7^3 head with tanh), FORWARD ONLY: the non-default generator of SURVEY
+    8(f)4 for inference.  Built from the same kernels as the ResUNet:
+      * the 7^3 stem reads the single-channel volume W-packed (49 (d, h) taps x 7 pseudo-channels: the path of D.conv0);
+      * every InstanceNorm + ReLU (+ SpatialDropout3D multipliers in training mode) is applied on read by the next convolution;
+      * UpSampling3D is virtual (the gather reads the low-resolution tensor at idx >> 1), the 4^3 'same' convolution is D.down2's;
+      * the residual Add -- input + InstanceNorm(conv2), whose statistics exist only after conv2 has finished -- is vg_affine_add;
+      * the 7^3 head (343 taps; a launch takes 64) is a chain of seven 49-tap chunks accumulating into the fp32 output, tanh in the
+        last one (vg_conv_desc::tanh_out with accumulate).
+    Spatial sizes: n -> n - 4 -> three times floor((m - 1) / 2) + 1 -> x 8; the output has the input's size when n is a multiple of 16."""
+
+    def __init__(self, store: ParamStore, dims: Tuple[int, int, int], dtype: torch.dtype = torch.bfloat16):
+        if any(n % 16 or n < 32 for n in dims):
+            raise ValueError('spatial dims must be multiples of 16 and >= 32')
+        self.dtype, self.store, self.dims = dtype, store, tuple(dims)
+        L, Nn = {}, {}
+        f = RESNET_F
+        d = tuple(dims)
+        L['c7'] = ConvLayer(store, 'c7', 7, 1, f, 1, 'reflect', False, d, need_dgrad=False, dtype=dtype)
+        Nn['c7'] = Norm(store, 'c7.in', f)
+        d = L['c7'].out_dims
+        for i in range(RESNET_DOWN):
+            k = 'down%d' % i
+            L[k] = ConvLayer(store, k, 3, f, 2 * f, 2, 'reflect', False, d, need_dgrad=False, dtype=dtype)
+            Nn[k] = Norm(store, k + '.in', 2 * f)
+            d, f = L[k].out_dims, 2 * f
+        for j in range(RESNET_RES):
+            for c in ('c1', 'c2'):
+                k = 'res%d.%s' % (j, c)
+                L[k] = ConvLayer(store, k, 3, f, f, 1, 'reflect', False, d, need_dgrad=False, dtype=dtype)
+                Nn[k] = Norm(store, k + '.in', f)
+        for i in range(RESNET_UP):
+            k = 'up%d' % i
+            d = tuple(2 * n for n in d)
+            L[k] = ConvLayer(store, k, 4, f, f // 2, 1, 'same', False, d, need_dgrad=False, dtype=dtype)
+            Nn[k] = Norm(store, k + '.in', f // 2)
+            f //= 2
+        assert d == tuple(dims), (d, dims)
+        # the head: one chunk per kernel depth slice (49 taps); only the first adds the bias
+        self.head = [ConvLayer(store, 'out', 7, f, 1, 1, 'same', a == 0, d, need_dgrad=False, dtype=dtype,
+                               tap_subset=list(range(a * 49, (a + 1) * 49))) for a in range(7)]
+        self.L, self.Nn = L, Nn
+
+    def pack(self):
+        if getattr(self, '_ptab', None) is None:
+            self._ptab = ops.PackTable(list(self.L.values()) + self.head, self.store.w.device)
+        self._ptab.run()
+
+    def forward(self, ar: Arena, x: torch.Tensor, y: torch.Tensor, drop: Optional[dict] = None) -> dict:
+        """x: fp32 [N,D,H,W,1]; y: fp32 [N,D,H,W,1] output (tanh).  drop: SpatialDropout3D multipliers [N,C] for 'c7' and
+        'down0..2' (training=True behaviour), None = inference.  Returns the stored tensors (taps) for the parity tests."""
+        drop = drop or {}
+        L, Nn = self.L, self.Nn
+        N = x.shape[0]
+        taps = {}
+        h = Act(ar, N, L['c7'].out_dims, L['c7'].cout, dtype=self.dtype)
+        L['c7'].forward(Src(x, (N,) + self.dims, 1, f32=True), h.data, sums=h.sums)
+        taps['c7'] = h
+        key = 'c7'
+        for i in range(RESNET_DOWN):
+            k = 'down%d' % i
+            st = Nn[key].finalize(ar, h, mult=drop.get(key))
+            src = Src(h.data, (N,) + h.dims, h.C, scale=st['scale'], shift=st['shift'], act=ACT_RELU)
+            a = Act(ar, N, L[k].out_dims, L[k].cout, dtype=self.dtype)
+            L[k].forward(src, a.data, sums=a.sums)
+            taps[k] = a
+            h, key = a, k
+        st = Nn[key].finalize(ar, h, mult=drop.get(key))
+        cur, sc, sf, act = h.data, st['scale'], st['shift'], ACT_RELU          # the block input with its pending on-read transform
+        dims, C_ = h.dims, h.C
+        S = dims[0] * dims[1] * dims[2]
+        for j in range(RESNET_RES):
+            k = 'res%d' % j
+            r1 = Act(ar, N, dims, C_, dtype=self.dtype)
+            L[k + '.c1'].forward(Src(cur, (N,) + dims, C_, scale=sc, shift=sf, act=act), r1.data, sums=r1.sums)
+            n1 = Nn[k + '.c1'].finalize(ar, r1)
+            r2 = Act(ar, N, dims, C_, dtype=self.dtype)
+            L[k + '.c2'].forward(Src(r1.data, (N,) + dims, C_, scale=n1['scale'], shift=n1['shift'], act=ACT_RELU), r2.data, sums=r2.sums)
+            n2 = Nn[k + '.c2'].finalize(ar, r2)
+            out = ar.alloc((N,) + dims + (C_,), self.dtype)
+            ops.affine_add(cur, sc, sf, act, r2.data, n2['scale'], n2['shift'], N, S, C_, out)
+            taps[k] = out
+            cur, sc, sf, act = out, None, None, ACT_NONE
+        for i in range(RESNET_UP):
+            k = 'up%d' % i
+            dims = tuple(2 * n for n in dims)
+            a = Act(ar, N, dims, L[k].cout, dtype=self.dtype)
+            L[k].forward(Src(cur, (N,) + dims, C_, shift0=1, scale=sc, shift=sf, act=act), a.data, sums=a.sums)
+            taps[k] = a
+            st = Nn[k].finalize(ar, a)
+            cur, sc, sf, act, C_ = a.data, st['scale'], st['shift'], ACT_RELU, L[k].cout
+        src = Src(cur, (N,) + dims, C_, scale=sc, shift=sf, act=act)
+        for a_, lay in enumerate(self.head):
+            lay.forward(src, y, tanh=(a_ == len(self.head) - 1), accumulate=(a_ > 0))
+        return taps
+
+
+# ======================================================================================================
 # Discriminator
 # ======================================================================================================
 class PatchGAN:

@@ -433,7 +433,12 @@ class ConvLayer:
     packed bf16 weights for the forward and for every output-parity class of the data gradient."""
 
     def __init__(self, store, name: str, k: int, cin: int, cout: int, stride: int, pad: str, bias: bool,
-                 in_dims: Tuple[int, int, int], need_dgrad: bool = True, dtype: torch.dtype = torch.bfloat16):
+                 in_dims: Tuple[int, int, int], need_dgrad: bool = True, dtype: torch.dtype = torch.bfloat16,
+                 tap_subset: Optional[Sequence[int]] = None):
+        """tap_subset (forward only): this object multiplies only the listed taps (indices into the k^3 raster order of the DHWIO
+        kernel) -- a 7^3 convolution (343 taps, VG_MAX_TAPS is 64) is a chain of such chunks accumulating into one output
+        (nets.ResNetGenerator's head, generator.py:68)."""
+        assert tap_subset is None or not need_dgrad
         self.dtype, self.f32 = dtype, int(dtype == torch.float32)
         self.ctor = dict(k=k, cin=cin, cout=cout, stride=stride, pad=pad, bias=bias, in_dims=tuple(in_dims), need_dgrad=need_dgrad)
         self.name, self.k, self.cin, self.cout, self.stride, self.pad, self.has_bias = name, k, cin, cout, stride, pad, bias
@@ -454,19 +459,24 @@ class ConvLayer:
         # ---- forward ----
         # single-channel source with k > 1: W-packed (include/vangan_hip.h: wpack) -- the k taps along W become k
         # pseudo-channels, k*k (d, h) taps remain; the DHWIO kernel is read as [k*k][k][cout] without moving a byte
-        self.wpack = k if (cin == 1 and 1 < k <= 8 and os.environ.get('VG_WPACK', '1') != '0') else 0
-        if self.wpack:
+        self.wpack = k if (cin == 1 and 1 < k <= 8 and tap_subset is None and os.environ.get('VG_WPACK', '1') != '0') else 0
+        if tap_subset is not None:
+            full = [(a - self.pb[0], b - self.pb[1], c - self.pb[2]) for a in range(k) for b in range(k) for c in range(k)]
+            self.f_taps = [full[i] for i in tap_subset]
+            self.f_T, self.f_cin = len(self.f_taps), cin
+        elif self.wpack:
             self.f_taps = [(a - self.pb[0], b - self.pb[1], 0) for a in range(k) for b in range(k)]
             self.f_T, self.f_cin = k * k, k
         else:
             self.f_taps = [(a - self.pb[0], b - self.pb[1], c - self.pb[2]) for a in range(k) for b in range(k) for c in range(k)]
             self.f_T, self.f_cin = T, cin
         T = self.f_T
-        self.f_idx_host = (C.c_int32 * T)(*range(T))
-        self.f_idx = torch.arange(T, dtype=torch.int32, device=dev)
+        sub = list(range(T)) if tap_subset is None else [int(i) for i in tap_subset]
+        self.f_idx_host = (C.c_int32 * T)(*sub)
+        self.f_idx = torch.tensor(sub, dtype=torch.int32, device=dev)
         # the wide layers run on the LDS-DMA family (vg_conv_dma.hip): the library says which, and with which channel panel; their
         # weights are packed in that kernel's block layout (vg_pack_weights_dma)
-        self.f_bn = self._dma_bn(cin, cout, self.f_taps, stride, in_dims, self.out_dims) if not self.wpack else 0
+        self.f_bn = self._dma_bn(cin, cout, self.f_taps, stride, in_dims, self.out_dims) if (not self.wpack and tap_subset is None) else 0
         if self.f_bn:
             self.f_ck = 16
             self.f_wp = torch.zeros(cout * cin * T, dtype=dtype, device=dev)
@@ -631,8 +641,8 @@ class ConvLayer:
         if self.f_bn:
             check(lib.vg_pack_weights_dma(_p(self.w), T, self.f_cin, self.cout, _p(self.f_idx), T, 0, self.f_bn, _p(self.f_wp), s), 'pack')
         else:
-            check(lib.vg_pack_weights(_p(self.w), T, self.f_cin, self.cout, _p(self.f_idx), T, 0, self.f_ck, _p(self.f_wp),
-                                      self.f32, s), 'pack')
+            check(lib.vg_pack_weights(_p(self.w), max(T, self.k ** 3 if not self.wpack else T), self.f_cin, self.cout, _p(self.f_idx), T, 0,
+                                      self.f_ck, _p(self.f_wp), self.f32, s), 'pack')
         for c in self.d_classes:
             if self.d_bn:
                 check(lib.vg_pack_weights_dma(_p(self.w), self.k ** 3, self.cin, self.cout, _p(c['idx']), len(c['taps']), 1, self.d_bn,
@@ -663,13 +673,13 @@ class ConvLayer:
         return d
 
     def forward(self, src: Src, out: torch.Tensor, sums=None, res=None, res_scale=None, res_shift=None,
-                tanh: bool = False):
+                tanh: bool = False, accumulate: bool = False):
         assert src.C == self.cin and (src.D, src.H, src.W) == tuple(self.in_dims)
         d = self._fwd_desc(src)
         d.bias = _p(self.b)
         d.res, d.res_scale, d.res_shift = _p(res), _p(res_scale), _p(res_shift)
         d.tanh_out = int(tanh)
-        d.out, d.out_f32, d.accumulate = _p(out), int(out.dtype == torch.float32), 0
+        d.out, d.out_f32, d.accumulate = _p(out), int(out.dtype == torch.float32), int(bool(accumulate))
         d.out_sums = _p(sums)
         s_ = stream()
         conv_scratch(d, s_, out.device.index)
@@ -992,6 +1002,12 @@ def concat_bwd(g, dims, Cu, Cs, dlow, dskip, acc_low: bool = True, acc_skip: boo
     N, D, H, W = dims
     check(lib.vg_concat_bwd(_p(g), N, D, H, W, Cu, Cs, _p(dlow), _p(dskip), int(g.dtype == torch.float32),
                             int(bool(acc_low)) | (int(bool(acc_skip)) << 1), stream()), 'vg_concat_bwd')
+
+
+def affine_add(a, a_scale, a_shift, a_act, b, b_scale, b_shift, N, S, C_, out):
+    """out = act(a * a_scale + a_shift) + (b * b_scale + b_shift)   (vg_affine_add: the residual Add of the ResNet generator)"""
+    check(lib.vg_affine_add(_p(a), _p(a_scale), _p(a_shift), a_act, _p(b), _p(b_scale), _p(b_shift), N, S, C_, _p(out),
+                            int(out.dtype == torch.float32), stream()), 'vg_affine_add')
 
 
 def tanh_bwd(dy, y, dpre):
