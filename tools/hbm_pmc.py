@@ -16,9 +16,9 @@ def sums(d, counter):
         if r['Counter_Name'] != counter:
             continue
         name = r['Kernel_Name']
-        fam = 'conv' if any(k in name for k in ('conv_kernel', 'conv32_kernel', 'conv_thin_kernel', 'wgrad_kernel', 'wgrad_dma_kernel', 'wgrad_pw_dma_kernel', 'pw_cto', 'pw_1toc', 'pw_wgrad', 'pw_gemm', 'c1k3_')) else 'other'
+        fam = 'conv' if any(k in name for k in ('conv_kernel', 'conv32_kernel', 'conv_thin_kernel', 'conv_dma_kernel', 'wgrad_kernel', 'wgrad_dma_kernel', 'wgrad_pw_dma_kernel', 'pw_cto', 'pw_1toc', 'pw_wgrad', 'pw_gemm', 'c1k3_')) else 'other'
         if name.startswith('materialize_kernel') or name.startswith('reduce_partials_kernel'):
-            fam = 'conv_aux'           # passes that belong to a vg_conv3d_wgrad call: their bytes count for the family, not as launches
+            fam = 'conv_aux'           # passes that belong to a vg_conv3d_wgrad / LDS-DMA vg_conv3d call: their bytes count for the family, not as launches
         kb[fam] += float(r['Counter_Value'])
         n[fam] += 1
     return kb, n
@@ -39,7 +39,7 @@ def main():
         'csrc_hash': _b._src_hash(),
         'command': 'rocprofv3 --pmc FETCH_SIZE (and, in a separate pass, WRITE_SIZE) --kernel-trace --output-format csv -- '
                    'python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline   (tools/hbm_pmc.py)',
-        'note': 'sums over every conv_kernel/conv32_kernel/conv_thin_kernel/wgrad_dma_kernel (+ its materialize / reduce_partials passes)/wgrad_pw_dma_kernel/wgrad_kernel/pw_* dispatch of 2 train steps (128^3, batch 1); FETCH_SIZE in '
+        'note': 'sums over every conv_kernel/conv32_kernel/conv_thin_kernel/conv_dma_kernel/wgrad_dma_kernel (+ its materialize / reduce_partials passes)/wgrad_pw_dma_kernel/wgrad_kernel/pw_* dispatch of 2 train steps (128^3, batch 1); FETCH_SIZE in '
                 'KB doubled per MI355X_MICROARCH.md (gfx950 counts 128-B read requests at 64 B); WRITE_SIZE in KB taken as is '
                 '(calibrated for 16-B/lane stores; the epilogue stores are 8 B/lane, so it is approximate)',
         'raw': {'FETCH_SIZE': {'sum_kb_2_steps': fk, 'dispatches_2_steps': fn},

@@ -14,7 +14,7 @@ def main():
     raw = {'other': {}, 'conv': {}, 'wgrad': {}, 'wgrad_dma': {}}
     for r in csv.DictReader(open(f)):
         n = r['Kernel_Name']
-        fam = 'wgrad_dma' if ('wgrad_dma_kernel' in n or 'wgrad_pw_dma_kernel' in n) else 'wgrad' if 'wgrad_kernel' in n else ('conv' if ('conv_kernel' in n or 'conv32_kernel' in n or 'conv_thin_kernel' in n or 'pw_gemm_kernel' in n) else 'other')
+        fam = 'wgrad_dma' if ('wgrad_dma_kernel' in n or 'wgrad_pw_dma_kernel' in n) else 'wgrad' if 'wgrad_kernel' in n else ('conv' if ('conv_kernel' in n or 'conv32_kernel' in n or 'conv_thin_kernel' in n or 'conv_dma_kernel' in n or 'pw_gemm_kernel' in n) else 'other')
         raw[fam][r['Counter_Name']] = raw[fam].get(r['Counter_Name'], 0.0) + float(r['Counter_Value'])
 
     def util(fams):
@@ -29,7 +29,7 @@ def main():
                 'GRBM_GUI_ACTIVE / 8 XCDs): busy MFMA-pipe cycles over available SIMD cycles while the kernel family runs (includes the '
                 'zero-padded channels/taps the kernels multiply, so it sits above the algorithmic fraction of bench.py)',
         'raw': raw,
-        'mfma_utilisation': {'conv_kernel+conv32_kernel+conv_thin_kernel+pw_gemm_kernel': util(['conv']), 'wgrad_kernel': util(['wgrad']), 'wgrad_dma_kernel+wgrad_pw_dma_kernel': util(['wgrad_dma']), 'conv family': util(['conv', 'wgrad', 'wgrad_dma'])},
+        'mfma_utilisation': {'conv_kernel+conv32_kernel+conv_thin_kernel+conv_dma_kernel+pw_gemm_kernel': util(['conv']), 'wgrad_kernel': util(['wgrad']), 'wgrad_dma_kernel+wgrad_pw_dma_kernel': util(['wgrad_dma']), 'conv family': util(['conv', 'wgrad', 'wgrad_dma'])},
     }, open(out, 'w'), indent=1)
     print(open(out).read()[-400:])
 

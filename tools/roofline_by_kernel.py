@@ -35,7 +35,7 @@ def variant_of(kernel_name: str):
     if 'pw_wgrad_cc_kernel' in kernel_name:
         return 'pw_wgrad_cc'
     if kernel_name.startswith('materialize_kernel'):          # the operand pass and the partial-slab sum of the DMA weight gradients:
-        return 'wgrad_dma:materialize'                        # rows of their own (time and HBM bytes; their FLOPs are the wgrad_dma rows')
+        return 'wgrad_dma:materialize'                        # (also the operand pass of conv_dma) rows of their own (time and HBM bytes; their FLOPs are the wgrad_dma rows')
     if kernel_name.startswith('reduce_partials_kernel'):
         return 'wgrad:reduce_partials'
     m = re.search(r'(\w+)_kernel<([^>]*)>', kernel_name)
@@ -50,6 +50,8 @@ def variant_of(kernel_name: str):
         return 'pw_gemm_split<%s,%s>' % (args[0], args[1])
     if k == 'pw_gemm' and len(args) in (5, 6):
         return 'pw_gemm<%s,%s,g%s,a%s>' % (args[0], args[1], b(args[2]), b(args[3]))
+    if k == 'conv_dma' and len(args) == 3:                 # <NW, MW, GT>: the variant string names the tile (BN = 64 NW, BM = 128 MW); the GT instances share a row
+        return 'conv_dma<%d,%d>' % (64 * int(args[0]), 128 * int(args[1]))
     if k == 'conv32' and len(args) == 4:
         return 'conv32<%s,%s,n%s,cp%s>' % (args[0], args[1], b(args[2]), b(args[3]))
     if k == 'wgrad_dma' and len(args) == 3:
