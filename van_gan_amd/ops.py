@@ -304,6 +304,7 @@ class Arena:
         self.lazy_ok = True         # False: this arena is shared by sweeps of both lanes (VG_LANES=0), so release() always recycles
         self.zpool.zero_()
         self._pair, self._pairs, self._pair_pos, self._full = None, {}, {}, {}
+        self._cache, self._cpos, self._halves = [], 0, {}
 
     # Paired allocation (the two applications of one generator in a train step): while pair_begin(key, 0) is active every
     # non-zeroed allocation [N, ...] reserves [2N, ...] and returns the first half; pair_begin(key, 1) replays the SAME allocation
@@ -327,6 +328,7 @@ class Arena:
 
     def reset(self):
         self._pair, self._pairs, self._pair_pos, self._full = None, {}, {}, {}
+        self._cpos = 0
         self.off = 0
         if self.zoff:
             self.zpool[:self.zoff].zero_()
@@ -335,27 +337,56 @@ class Arena:
     _ESZ = {torch.float32: 4, torch.bfloat16: 2, torch.float16: 2, torch.int32: 4, torch.int64: 8, torch.uint8: 1, torch.float64: 8}
 
     def alloc(self, shape: Sequence[int], dtype: torch.dtype, zero: bool = False) -> torch.Tensor:
+        shape = tuple(shape)
         if self._pair is not None and not zero:
             key, slot = self._pair
-            shape = tuple(shape)
             if slot == 0:
                 self._pair = None
                 full = self.alloc((2 * shape[0],) + shape[1:], dtype)
                 self._pair = (key, slot)
                 self._pairs[key].append(full)
                 self._full[full.data_ptr()] = full
-                return full[:shape[0]]
+                h = self._halves.get(full.data_ptr())            # (whole, first half, second half): views made once, not once per step
+                if h is None or h[0] is not full:
+                    h = self._halves[full.data_ptr()] = (full, full[:shape[0]], full[shape[0]:])
+                return h[1]
             full = self._pairs[key][self._pair_pos[key]]
             self._pair_pos[key] += 1
             assert tuple(full.shape) == (2 * shape[0],) + shape[1:] and full.dtype == dtype, 'paired allocation sequences differ'
-            return full[shape[0]:]
+            return self._halves[full.data_ptr()][2]
+        # A train step asks for the same ~1300 blocks in the same order every time, and the three torch view operations behind a block
+        # cost ~3 us: a quarter of the host's enqueue time per step (cProfile, tools/host_profile.py).  The sequence is cached -- entry
+        # i is reused while the request (offsets, shape, type) repeats, and rebuilt from the first difference on.
+        i, cache = self._cpos, self._cache
+        if i < len(cache):
+            e = cache[i]
+            if e[0] == self.off and e[1] == self.zoff and e[2] == shape and e[3] is dtype and e[4] == zero:
+                self._cpos = i + 1
+                self.off, self.zoff = e[5], e[6]
+                if self.off > self.peak:
+                    self.peak = self.off
+                if e[8] and DRY is None:
+                    e[7].zero_()
+                return e[7]
+        off0, zoff0 = self.off, self.zoff
+        t, big_zero = self._carve(shape, dtype, zero)
+        entry = (off0, zoff0, shape, dtype, zero, self.off, self.zoff, t, big_zero)
+        if i < len(cache):
+            cache[i] = entry
+            del cache[i + 1:]
+        else:
+            cache.append(entry)
+        self._cpos = i + 1
+        return t
+
+    def _carve(self, shape, dtype, zero):
         n = int(math.prod(shape))
         nbytes = n * self._ESZ[dtype]
         if zero and nbytes <= 65536:
             zs = (self.zoff + 255) // 256 * 256
             if zs + nbytes <= self.ZPOOL:
                 self.zoff = zs + nbytes
-                return self.zpool[zs:zs + nbytes].view(dtype).view(*shape)
+                return self.zpool[zs:zs + nbytes].view(dtype).view(*shape), False
         start = (self.off + 255) // 256 * 256
         if start + nbytes > self.buf.numel():
             raise MemoryError('arena exhausted: need %d more bytes' % (start + nbytes - self.buf.numel()))
@@ -364,7 +395,7 @@ class Arena:
         t = self.buf[start:start + nbytes].view(dtype).view(*shape)
         if zero and DRY is None:
             t.zero_()
-        return t
+        return t, bool(zero)
 
     def mark(self) -> int:
         return self.off
