@@ -139,3 +139,50 @@ def test_bench_two_ranks_completes():
     assert d['n_gpus'] == 2 and d['steps'] == 2 and d['scaling'] == 'weak' and d['value'] > 0
     assert d['roofline'] is not None and d['cpu_baseline'] is None
     assert d['config']['parallelism'] == 'dp2'
+
+
+def test_weights_loaded_behind_an_unsynchronised_step_are_not_overwritten(tmp_path):
+    """Cross-step mode (train_step(sync=False): Adam + repack of the step are still queued on the optimizer stream when the call
+    returns).  load_checkpoint / load_weights / broadcast_weights right behind such a step must leave exactly the loaded values
+    in the stores AND in the packed kernel weights -- the queued update must not land on top of them (vangan.py:252-268: the
+    reference restores into idle variables).  Checked on a process group of one rank so that broadcast_weights runs too."""
+    import torch.distributed as dist
+    from oracle.vangan_oracle import synth_volumes
+    from van_gan_amd.vangan import VanGan
+    dist.init_process_group('gloo', rank=0, world_size=1, init_method='tcp://127.0.0.1:%d' % _free_port())
+    try:
+        eng = VanGan(DIMS, batch_size=1, device='cuda:0', seed=3, output_dir=str(tmp_path), process_group=dist.group.WORLD)
+        rI, rS = synth_volumes(1, *DIMS, seed=9)
+        rI, rS = rI.cuda(), rS.cuda()
+        eng.train_step(rI, rS)
+        path = eng.save_checkpoint(0)
+        ck = torch.load(path, map_location='cpu')
+        ref = eng.test_step(rI, rS)                         # losses of the checkpointed weights
+        for mode in ('checkpoint', 'weights', 'broadcast'):
+            for _ in range(3):
+                eng.train_step(rI, rS, sync=False)          # returns with the last update still in flight
+            if mode == 'checkpoint':
+                assert eng.load_checkpoint(1)
+            elif mode == 'weights':
+                for k, s in eng.stores.items():
+                    s.step = ck[k]['step']
+                eng.load_weights({k: {n: t.clone() for n, t in exp.items()} for k, exp in saved.items()})
+            else:
+                eng.train_step(rI, rS, sync=False)
+                before = {k: s.w.clone() for k, s in eng.stores.items()}      # reads on the current stream: not ordered behind the update
+                eng.broadcast_weights(0)                    # one rank: the weights of the finished step, repacked
+                torch.cuda.synchronize()
+                after = {k: s.w.clone() for k, s in eng.stores.items()}
+                eng.train_step(rI, rS)                      # and the engine still steps
+                assert all(torch.isfinite(after[k]).all() for k in after) and before.keys() == after.keys()
+                continue
+            torch.cuda.synchronize()
+            for k, s in eng.stores.items():
+                assert torch.equal(s.w.cpu(), ck[k]['w']), (mode, k)
+            got = eng.test_step(rI, rS)                     # the PACKED weights are the loaded ones too
+            for key, v in ref.items():
+                assert abs(got[key] - v) <= 2e-2 * abs(v) + 1e-4, (mode, key, got[key], v)
+            if mode == 'checkpoint':
+                saved = eng.export_weights()
+    finally:
+        dist.destroy_process_group()
