@@ -791,7 +791,7 @@ static int fill_conv(const vg_conv_desc* d, GatherIn& g, ConvOut& k, ConvCls& q,
     k.wp = d->wpacked;
     k.bias = d->bias; k.res = d->res; k.rs = d->res_scale; k.rb = d->res_shift; k.tanh_out = d->tanh_out;
     k.out = d->out; k.out_f32 = (d->out_f32 || d->f32) ? 1 : 0; k.accumulate = d->accumulate; k.sums = d->out_sums;
-    k.bs_x0 = nullptr;
+    k.bs_x0 = nullptr; k.xw = 0;
     k.ks = 1; k.ks_part = nullptr; k.ks_cnt = nullptr;
     k.scratch = (char*)d->scratch; k.scratch_bytes = d->scratch ? d->scratch_bytes : 0;
     if (const vg_actnorm_bwd_desc* b = d->bstat) {       // validated by vg_conv3d

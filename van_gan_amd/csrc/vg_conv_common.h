@@ -10,6 +10,7 @@ struct ConvOut {
     void* out; int out_f32, accumulate; float* sums;
     int w_lds;          // 1: the BN x Ktot weight panel of this workgroup is copied to LDS once (row stride WRS bytes)
     int dma;            // 1: LDS-DMA double-buffered staging (planar bf16 image, weights in LDS)
+    int xw;             // conv_thin_kernel: XCD-aware tile walk (set by its launcher)
     int WRS;
     // IN-backward statistics of the output fused into the epilogue (conv_thin_kernel<..., BSTAT>; vg_conv_desc::bstat): the
     // pre-norm tensor(s) of the layer whose gradient this launch produces and its per-(sample, channel) constants

@@ -18,6 +18,12 @@
 #include "vg_conv_common.h"
 #include <type_traits>
 
+#ifndef VG_THIN_WPE
+#define VG_THIN_WPE 2      // waves per SIMD the register allocation allows (3 would fit the LDS, 53.5 KB per workgroup, but spills 40-120 registers)
+#endif
+#ifndef VG_THIN_PD
+#define VG_THIN_PD 1      // K-steps of fragments in flight ahead of the MFMAs (2 measured the same; 1 leaves the registers for the staged loads)
+#endif
 namespace {
 constexpr int TW = 16, TH = 8, TD = 4;                 // output tile
 constexpr int HW = 18, HH = 10, HD = 6;                // halo (3x3x3, stride 1)
@@ -32,12 +38,98 @@ constexpr int KCPAD = 448;                             // packed K of one 16-cha
 
 __device__ __forceinline__ void lds_only_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// Staging of the specialist: stage_halo_lean<T, MODE, 3, 256, false, 2, HD> cut in two.  thin_issue() starts all nine 16-byte loads
+// of a thread's three (column, D-segment) items (720 items = 360 columns x 2 segments of 3 planes over 256 threads: items tid,
+// tid + 256, tid + 512); thin_commit() transforms and writes them into the halo image.  The kernel issues the loads of the NEXT
+// (tile, chunk) right before the MFMA loop of the current one and commits them after it, so the global round trip runs under the
+// matrix work.  (The lean routine takes its items one after the other -- three round trips per tile and chunk, in the open: with two
+// workgroups per CU there is little else to run under them.  Skipping the staging altogether took 27 % off the 16 -> 16 layer;
+// skipping the MFMAs nothing.)  Only the raw data stay in registers across the loop: commit re-reads the table words it needs.
+struct ThinItem { int hoff, cg; bool cv; const char* pc; const int* dt; };
+template <bool PLAIN>
+__device__ __forceinline__ ThinItem thin_item(const GatherIn& g, const int* ctab, const int* rt, const char* b0, const char* b1, int chunk, int item) {
+    constexpr int NCOLS = HH * HW * 2, SEGL = HD / 2;
+    const int L = stage_axis_len3(g);
+    ThinItem t;
+    const int seg = item >= NCOLS ? 1 : 0, col = item - seg * NCOLS;
+    const int e = ctab[2 * col];
+    t.hoff = ctab[2 * col + 1] + seg * SEGL * DSB;
+    const int hh = e & 1023, hw = (e >> 10) & 1023;
+    t.cg = e >> 20;
+    const int c = chunk * 16 + t.cg * 8;
+    const bool from0 = c < g.c0;
+    const int* rs = rt + (from0 ? 0 : L);
+    const int oh = rs[hh], ow = rs[HH + hw];
+    t.cv = !PLAIN || (c < g.Cin && (oh | ow) >= 0);
+    t.pc = t.cv ? (from0 ? b0 + (size_t)c * 2 : b1 + (size_t)(c - g.c0) * 2) + (oh + ow) : b0;          // invalid columns read a dummy, then zero
+    t.dt = rs + HH + HW + seg * SEGL;
+    return t;
+}
+template <int MODE>
+__device__ __forceinline__ void thin_issue(const GatherIn& g, const int* ctab, const int* rt, int n, int chunk, int tid, Raw8<bf16_t> (&raw)[3][HD / 2]) {
+    typedef bf16_t T;
+    constexpr int NITEMS = 4 * HH * HW, SEGL = HD / 2;
+    const int sh = g.shift0;
+    const char* b0 = (const char*)g.src0 + (size_t)n * (g.D >> sh) * (g.H >> sh) * (g.W >> sh) * g.c0 * 2;
+    const char* b1 = (const char*)g.src1 + (size_t)n * g.D * g.H * g.W * g.c1 * 2;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int item = tid + 256 * i;
+        if (i < 2 || item < NITEMS) {
+            const ThinItem t = thin_item<MODE == VG_STAGE_PLAIN>(g, ctab, rt, b0, b1, chunk, item);
+#pragma unroll
+            for (int k = 0; k < SEGL; ++k) raw_load(raw[i][k], (const T*)(t.pc + (unsigned)max(t.dt[k], 0)));
+        }
+    }
+}
+template <int MODE>
+__device__ __forceinline__ void thin_commit(const GatherIn& g, char* halo, const float* scs, const int* ctab, const int* rt, int chunk, int tid,
+                                            Raw8<bf16_t> (&raw)[3][HD / 2]) {
+    typedef bf16_t T;
+    constexpr bool plain = MODE == VG_STAGE_PLAIN;
+    constexpr int NITEMS = 4 * HH * HW, SEGL = HD / 2;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int item = tid + 256 * i;
+        if (i < 2 || item < NITEMS) {
+            const ThinItem t = thin_item<plain>(g, ctab, rt, nullptr, nullptr, chunk, item);
+            f32x2 sc[4], sf[4];
+            if (!plain) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    sc[j] = (f32x2){scs[t.cg * 8 + 2 * j], scs[t.cg * 8 + 2 * j + 1]};
+                    sf[j] = (f32x2){scs[16 + t.cg * 8 + 2 * j], scs[16 + t.cg * 8 + 2 * j + 1]};
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < SEGL; ++k) {
+                T* dst = (T*)(halo + t.hoff + k * DSB);
+                if (plain) {
+                    Raw8<T> r = raw[i][k];
+                    raw_mask(r, t.cv && t.dt[k] >= 0);
+                    *(Raw8<T>*)dst = r;
+                } else {
+                    float x[8];
+                    raw_unpack(raw[i][k], x);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        f32x2 v = {x[2 * j], x[2 * j + 1]};
+                        v = v * sc[j] + sf[j];
+                        x[2 * j] = fmaxf(v[0], 0.f); x[2 * j + 1] = fmaxf(v[1], 0.f);
+                    }
+                    store8<T>(dst, x);
+                }
+            }
+        }
+    }
+}
+
 // MODE: VG_STAGE_PLAIN (data-gradient operand, zero padded) or VG_STAGE_RELU (forward: IN affine + ReLU, reflect padded)
 // BSTAT (data gradient): the epilogue also accumulates the statistics of the IN backward that consumes this output --
 // sum dn and sum dn * xhat with dn = g * mult * act'(x * scale + shift) taken at the reflect-folded position of the pre-norm
 // tensor x -- into p.sums (same striped layout as the forward statistics), so that the statistics pass need not re-read g.
 template <int MODE, bool BIAS, bool RES, bool STATS, bool BSTAT = false>
-__global__ __launch_bounds__(256, 2) void conv_thin_kernel(const GatherIn g, const ConvOut p) {
+__global__ __launch_bounds__(256, VG_THIN_WPE) void conv_thin_kernel(const GatherIn g, const ConvOut p) {
     typedef bf16_t T;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -103,12 +195,20 @@ __global__ __launch_bounds__(256, 2) void conv_thin_kernel(const GatherIn g, con
     const int jodd = kg & 1;
 
     const int tiles_per_n = g.tiles_d * g.tiles_h * g.tiles_w;
+    // tile walk.  p.xw (gridDim.x a multiple of 8): the workgroups that share an XCD (blockIdx.x & 7: round-robin placement; speed only)
+    // walk ONE contiguous slab of the tile sequence (w fastest, then h, then d) side by side, so the halo voxels that neighbouring tiles
+    // share -- 2.1 x the tile with this 16 x 8 x 4 shape -- are found in that XCD's L2 instead of being fetched once per XCD
+    int t0 = blockIdx.x, tstep = gridDim.x, tend = tiles_per_n;
+    if (p.xw) {
+        const int slab = (tiles_per_n + 7) >> 3, xcd = blockIdx.x & 7;
+        t0 = xcd * slab + ((int)blockIdx.x >> 3); tstep = gridDim.x >> 3; tend = min(tiles_per_n, (xcd + 1) * slab);
+    }
     int gs_w, gs_h, gs_d;
-    { int t = gridDim.x; gs_w = t % g.tiles_w; t /= g.tiles_w; gs_h = t % g.tiles_h; gs_d = t / g.tiles_h; }
+    { int t = tstep; gs_w = t % g.tiles_w; t /= g.tiles_w; gs_h = t % g.tiles_h; gs_d = t / g.tiles_h; }
     int ti_w, ti_h, ti_d;
-    { int t = blockIdx.x; ti_w = t % g.tiles_w; t /= g.tiles_w; ti_h = t % g.tiles_h; ti_d = t / g.tiles_h; }
+    { int t = t0; ti_w = t % g.tiles_w; t /= g.tiles_w; ti_h = t % g.tiles_h; ti_d = t / g.tiles_h; }
     if (nchunks == 1) stage_scale_shift(g, scs, n, 0, tid);
-    if ((int)blockIdx.x < tiles_per_n) stage_resolve_axes3(g, rtab, ti_d * TD, ti_h * TH, ti_w * TW, tid);
+    if (t0 < tend) stage_resolve_axes3(g, rtab, ti_d * TD, ti_h * TH, ti_w * TW, tid);
     lds_only_barrier();
     int boff[KSTEPS];
     {
@@ -122,40 +222,53 @@ __global__ __launch_bounds__(256, 2) void conv_thin_kernel(const GatherIn g, con
 
     typedef const __attribute__((address_space(3))) bf16x8 lds_frag;
     int it = 0;
-    for (int tile = blockIdx.x; tile < tiles_per_n; tile += gridDim.x, ++it) {
+    // PF: the loads of the NEXT (tile, chunk) are issued ahead of the MFMA loop and stay in registers across it.  Forward instances
+    // only (16 -> 16: 68 -> 64 us, 48 -> 16: 148 -> 142 us); the data-gradient instances got SLOWER with it (16 -> 48: 178 -> 195 us;
+    // the BSTAT one sits at the register cap and spilled the nine units): they load, then commit, back to back.
+    constexpr bool PF = MODE == VG_STAGE_RELU;
+    Raw8<T> raw[3][HD / 2];
+    if (PF && t0 < tend) thin_issue<MODE>(g, utab, rtab, n, 0, tid, raw);
+    for (int tile = t0; tile < tend; tile += tstep, ++it) {
         const int od0 = ti_d * TD, oh0 = ti_h * TH, ow0 = ti_w * TW;
         ti_w += gs_w; if (ti_w >= g.tiles_w) { ti_w -= g.tiles_w; ++ti_h; }
         ti_h += gs_h; if (ti_h >= g.tiles_h) { ti_h -= g.tiles_h; ++ti_d; }
         ti_d += gs_d;
+        const bool more = tile + tstep < tend;
         f32x4 acc[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         for (int chunk = 0; chunk < nchunks; ++chunk) {
             if (it | chunk) lds_only_barrier();                            // previous readers of the halo image / weight panel are done
             if (nchunks > 1) { stage_scale_shift(g, scs, n, chunk, tid); if (it | chunk) load_weights(chunk); lds_only_barrier(); }
-            stage_halo_lean<T, MODE, 3, 256, false, 2, HD>(g, halo, scs, utab, rtab + (it & 1) * RTN, n, chunk, tid);
-            if (chunk == 0 && tile + (int)gridDim.x < tiles_per_n)
-                stage_resolve_axes3(g, rtab + ((it + 1) & 1) * RTN, ti_d * TD, ti_h * TH, ti_w * TW, tid);
+            if (!PF) thin_issue<MODE>(g, utab, rtab + (it & 1) * RTN, n, chunk, tid, raw);
+            thin_commit<MODE>(g, halo, scs, utab, rtab + (it & 1) * RTN, chunk, tid, raw);
+            if (chunk == 0 && more) stage_resolve_axes3(g, rtab + ((it + 1) & 1) * RTN, ti_d * TD, ti_h * TH, ti_w * TW, tid);
             lds_only_barrier();
+            // the next (tile, chunk)'s loads go out now and land under the MFMA loop (its axis tables were published by the barrier above)
+            if (PF) {
+                if (chunk + 1 < nchunks) thin_issue<MODE>(g, utab, rtab + (it & 1) * RTN, n, chunk + 1, tid, raw);
+                else if (more) thin_issue<MODE>(g, utab, rtab + ((it + 1) & 1) * RTN, n, 0, tid, raw);
+            }
             // ---- MFMA loop: 14 K-steps x 8 sub-tiles, every address an immediate, fragments of two K-steps ahead in flight
             const char* wb = wlds + wbase;
-            bf16x8 a[3], b[3][8];
+            constexpr int PD = VG_THIN_PD, NB = PD + 1;                    // K-steps of fragments in flight ahead of the MFMAs
+            bf16x8 a[NB], b[NB][8];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < PD; ++u) {
                 a[u] = *(lds_frag*)(wb + u * 64);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) b[u][j] = *(lds_frag*)(halo + boff[u] + j * ROWB);
             }
 #pragma unroll
             for (int s = 0; s < KSTEPS; ++s) {
-                if (s + 2 < KSTEPS) {
-                    a[(s + 2) % 3] = *(lds_frag*)(wb + (s + 2) * 64);
+                if (s + PD < KSTEPS) {
+                    a[(s + PD) % NB] = *(lds_frag*)(wb + (s + PD) * 64);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) b[(s + 2) % 3][j] = *(lds_frag*)(halo + boff[s + 2] + j * ROWB);
+                    for (int j = 0; j < 8; ++j) b[(s + PD) % NB][j] = *(lds_frag*)(halo + boff[s + PD] + j * ROWB);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[j] = VG_MFMA16(a[s % 3], b[s % 3][j], acc[j]);
+                for (int j = 0; j < 8; ++j) acc[j] = VG_MFMA16(a[s % NB], b[s % NB][j], acc[j]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -299,10 +412,12 @@ static int launch_thin(const GatherIn& g, const ConvOut& k, int lds, hipStream_t
     const int ny = k.Cout / 16;
     const int wg = vg_tune("CONV_THIN_WGS", 0) > 0 ? vg_tune("CONV_THIN_WGS", 0) : 256 * per_cu;
     int bx = wg / (ny * g.N); if (bx < 1) bx = 1; if (bx > tiles) bx = tiles;
+    ConvOut k2 = k; k2.xw = 0;
+    if (vg_tune("CONV_THIN_XCD", 1) && bx >= 16 && tiles >= 4 * bx) { bx &= ~7; k2.xw = 1; }
     // bs1 / bs2: IN-backward statistics in the epilogue, of a plain / a virtually concatenated (half-resolution + skip) pre-norm tensor
     if (vg_dry(BSTAT ? (k.bs_x1 ? "conv_thin<m%d,b%d,r%d,s%d,bs2>|walk%d|ch%d" : "conv_thin<m%d,b%d,r%d,s%d,bs1>|walk%d|ch%d") : "conv_thin<m%d,b%d,r%d,s%d>|walk%d|ch%d",
                MODE, (int)BIAS, (int)RES, (int)STATS, tiles > bx ? 1 : 0, k.nchunks > 1 ? 1 : 0)) return VG_OK;
-    hipLaunchKernelGGL((conv_thin_kernel<MODE, BIAS, RES, STATS, BSTAT>), dim3(bx, ny, g.N), dim3(256), lds, s, g, k);
+    hipLaunchKernelGGL((conv_thin_kernel<MODE, BIAS, RES, STATS, BSTAT>), dim3(bx, ny, g.N), dim3(256), lds, s, g, k2);
     return vg_check_launch();
 }
 
