@@ -150,6 +150,10 @@ int vg_conv3d_lds_bytes(const vg_conv_desc* d);
 /* the launch plan vg_conv3d would use for this descriptor: plan[0] = channel panel BN, plan[1] = voxels per tile,
    plan[2] = LDS bytes, plan[3] = workgroups; lets the host compare channel-chunk sizes (CK) before packing weights */
 int vg_conv3d_plan(const vg_conv_desc* d, int32_t* plan4);
+/* Shape-only: 2 when the two-panel instance of the thin-channel specialist (3x3x3, stride 1, 16-channel chunks, 32 output channels
+   per workgroup: the 32-channel layers at 64^3) would serve d -- the host then packs those weights with CK = 16; else 0.  d->CK is
+   ignored.  (Replaces nothing in the reference: tile planning of resunet_model.py:36-43,82-95's Conv3D calls.) */
+int vg_conv3d_thin_np(const vg_conv_desc* d);
 /* Dry run of vg_conv3d: the whole dispatch runs, nothing is launched, and buf receives the name of the kernel variant the
    call would launch, e.g. "conv<bf16,16,8,n0,wl1,dma0,mc0,c10>|walk1|ch0" (template arguments, then walk = a workgroup
    visits more than one tile, ch = several channel chunks per tile) or "pw_cto1<bf16,2>".  The parity tests use it to prove

@@ -32,6 +32,8 @@ def test_every_variant_of_the_baseline_configs_has_a_gpu_parity_case():
                  'wgrad_pw_dma<3,1>', 'wgrad_pw_dma<6,2>', 'wgrad_pw_dma<4,4>', 'wgrad_pw_dma<6,4>', '|s1|u1|', '|s2|u0|',
                  # the LDS-DMA forward / data-gradient family: both panel widths, 4^3 and 3^3 stage bodies, K split, class-parallel strided
                  # data gradients, launches with more units than CUs
+                 # the two-panel instance of the thin-channel specialist (32-channel layers at 64^3), forward and data gradient
+                 'conv_thin2<m1', 'conv_thin2<m0',
                  'conv_dma<128,256>', 'conv_dma<64,256>', '|gt8|', '|gt9|', 'ks1|cls0', 'ks0|cls1', 'cls1|walk1'):
         assert frag in names, frag
 

@@ -62,6 +62,7 @@ _SIGS = {
     'vg_conv3d_lds_bytes': ([C.POINTER(ConvDesc)], c_int),
     'vg_conv3d_plan': ([C.POINTER(ConvDesc), C.POINTER(C.c_int32)], c_int),
     'vg_conv3d_variant': ([C.POINTER(ConvDesc), C.c_char_p, c_int], c_int),
+    'vg_conv3d_thin_np': ([C.POINTER(ConvDesc)], c_int),
     'vg_set_tuning': ([C.c_char_p, c_int, c_int], c_int),
     'vg_conv3d_wgrad_variant': ([C.POINTER(ConvDesc), c_int, C.POINTER(c_int), c_int, c_i64, C.c_char_p, c_int], c_int),
     'vg_pack_weights': ([c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p], c_int),

@@ -971,6 +971,22 @@ static int dispatch_conv(const GatherIn& g, const ConvOut& k, const ConvCls& q, 
     return MSUB == 2 ? launch_conv<T, 64, 2>(g, k, q, lds, s) : launch_conv<T, 64, 1>(g, k, q, lds, s);
 }
 
+static inline bool thin2_shape(const vg_conv_desc* d, const ConvOut& k, const ConvCls& q) {
+    return !d->f32 && d->CK == 16 && d->Cout >= 32 && (d->Cout % 32) == 0 && q.ncls == 1 && d->ntaps == 27;
+}
+
+// Shape-only: 2 when the two-panel instance of the thin-channel specialist (conv_thin_kernel<..., NP = 2>) serves this convolution
+// with 16-channel chunks (d->CK is ignored) -- the caller then packs the weights with CK = 16; else 0.
+extern "C" int vg_conv3d_thin_np(const vg_conv_desc* d0) {
+    vg_begin();
+    if (!d0) return 0;
+    vg_conv_desc d = *d0; d.CK = 16;
+    GatherIn g, g2; ConvOut k; ConvCls q; int BN, MSUB, lds;
+    if (fill_conv(&d, g, k, q, BN, MSUB, lds) != VG_OK || !thin2_shape(&d, k, q)) return 0;
+    if (fill_gather(&d, g2, 16, 512) != VG_OK || !vg_conv_thin_ok(&d, g2, k, q, 2)) return 0;
+    return vg_conv_thin_lds_bytes(g2, 2) <= VG_LDS_LIMIT ? 2 : 0;
+}
+
 // did_stats: set when the launched kernel accumulated the IN-backward statistics of d->bstat itself (striped, unfolded)
 static int conv3d_impl(const vg_conv_desc* d, vg_stream_t stream, bool& did_stats) {
     if (d && d->wlayout) return vg_conv_dma(d, (hipStream_t)stream);          // LDS-DMA family (weights in its block layout): served there or an error
@@ -982,9 +998,16 @@ static int conv3d_impl(const vg_conv_desc* d, vg_stream_t stream, bool& did_stat
     int rc = fill_conv(d, g, k, q, BN, MSUB, lds);
     if (rc != VG_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
+    if (thin2_shape(d, k, q)) {        // 32-channel panels of the thin-channel specialist (weights packed with 16-channel chunks for it)
+        GatherIn g2;
+        if (fill_gather(d, g2, 16, 512) == VG_OK && vg_conv_thin_ok(d, g2, k, q, 2)) {
+            const int trc = vg_launch_conv_thin(g2, k, 2, s, d->bstat ? d->bstat->red : nullptr, did_stats);
+            if (trc <= 0) return trc;
+        }
+    }
     { GatherIn g2; int bn2, ms2, lds2; if (plan_conv32(d, k, q, g2, bn2, ms2, lds2) == VG_OK) return launch_conv32(g2, k, q, bn2, ms2, lds2, s); }
-    if (!d->f32 && MSUB == 8 && BN == 16 && vg_conv_thin_ok(d, g, k, q)) {
-        const int trc = vg_launch_conv_thin(g, k, s, d->bstat ? d->bstat->red : nullptr, did_stats);
+    if (!d->f32 && MSUB == 8 && BN == 16 && vg_conv_thin_ok(d, g, k, q, 1)) {
+        const int trc = vg_launch_conv_thin(g, k, 1, s, d->bstat ? d->bstat->red : nullptr, did_stats);
         if (trc <= 0) return trc;
     }
     return d->f32 ? dispatch_conv<float>(g, k, q, BN, MSUB, lds, s) : dispatch_conv<bf16_t>(g, k, q, BN, MSUB, lds, s);

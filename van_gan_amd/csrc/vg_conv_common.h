@@ -150,6 +150,7 @@ __device__ __forceinline__ void conv_mfma_chunk(f32x4 (&acc)[MW], WP w, const ch
 
 
 // vg_conv_thin.hip: specialist for the 16-channel-chunk 3x3x3 stride-1 layers with a fixed 16x8x4 tile
-bool vg_conv_thin_ok(const vg_conv_desc* d, const GatherIn& g, const ConvOut& k, const ConvCls& q);
+bool vg_conv_thin_ok(const vg_conv_desc* d, const GatherIn& g, const ConvOut& k, const ConvCls& q, int np);       // np: 16-channel panels per workgroup (1 / 2)
+int vg_conv_thin_lds_bytes(const GatherIn& g, int np);
 // red != NULL: accumulate the IN-backward statistics (ConvOut::bs_*) into red in the epilogue when the instance exists (did_stats)
-int vg_launch_conv_thin(const GatherIn& g, const ConvOut& k, hipStream_t s, float* red, bool& did_stats);       // VG_OK, < 0 on error, 1: not one of its combinations
+int vg_launch_conv_thin(const GatherIn& g, const ConvOut& k, int np, hipStream_t s, float* red, bool& did_stats);       // VG_OK, < 0 on error, 1: not one of its combinations

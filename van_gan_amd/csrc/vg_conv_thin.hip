@@ -17,9 +17,13 @@
 // Everything else (persistent workgroups, tables, InstanceNorm statistics carried in registers) follows conv_kernel.
 #include "vg_conv_common.h"
 #include <type_traits>
+#include <cstdio>
 
 #ifndef VG_THIN_WPE
 #define VG_THIN_WPE 2      // waves per SIMD the register allocation allows (3 would fit the LDS, 53.5 KB per workgroup, but spills 40-120 registers)
+#endif
+#ifndef VG_THIN_PF2
+#define VG_THIN_PF2 0     // prefetch of the next halo under the MFMA loop in the two-panel forward instances too: spills 14-58 registers there
 #endif
 #ifndef VG_THIN_PD
 #define VG_THIN_PD 1      // K-steps of fragments in flight ahead of the MFMAs (2 measured the same; 1 leaves the registers for the staged loads)
@@ -128,19 +132,21 @@ __device__ __forceinline__ void thin_commit(const GatherIn& g, char* halo, const
 // BSTAT (data gradient): the epilogue also accumulates the statistics of the IN backward that consumes this output --
 // sum dn and sum dn * xhat with dn = g * mult * act'(x * scale + shift) taken at the reflect-folded position of the pre-norm
 // tensor x -- into p.sums (same striped layout as the forward statistics), so that the statistics pass need not re-read g.
-template <int MODE, bool BIAS, bool RES, bool STATS, bool BSTAT = false>
+template <int MODE, bool BIAS, bool RES, bool STATS, bool BSTAT = false, int NP = 1>
 __global__ __launch_bounds__(256, VG_THIN_WPE) void conv_thin_kernel(const GatherIn g, const ConvOut p) {
+    // NP: 16-channel output panels per workgroup.  NP = 2 (the 32-channel layers at 64^3, conv_thin2 in the variant names): every B
+    // fragment feeds two MFMAs -- 10 fragment reads per 16 MFMAs instead of 9 per 8 -- and the halo is staged once per 32 channels.
     typedef bf16_t T;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, kg = lane >> 4;
     const int n = blockIdx.z, ntile = blockIdx.y;
-    // ---- LDS: [halo][scale/shift 2*16 floats][statistics 32 floats][tap offsets 32 ints][column table][axis tables x 2]
-    //           [weights of ONE 16-channel chunk: 16 rows x (448 + 8) bf16]
+    // ---- LDS: [halo][scale/shift 2*16 floats][statistics 32*NP floats][tap offsets 32 ints][column table][axis tables x 2]
+    //           [weights of ONE 16-channel chunk: 16*NP rows x (448 + 8) bf16]
     char* halo = smem;
     float* scs = (float*)(smem + HALO);
     float* stat = scs + 32;
-    int* tapb = (int*)(stat + 32);
+    int* tapb = (int*)(stat + 32 * NP);
     int* utab = tapb + 32;
     constexpr int NCOLS = HH * HW * 2;
     int* rtab = utab + 2 * NCOLS;
@@ -149,49 +155,64 @@ __global__ __launch_bounds__(256, VG_THIN_WPE) void conv_thin_kernel(const Gathe
     wlds = (char*)(((size_t)wlds + 15) & ~(size_t)15);
     const int Ktot = p.Ktot, nchunks = p.nchunks;
     constexpr int WRS = KCPAD * 2 + 16;                  // LDS row stride of the chunk panel (16 bytes of padding: bank spread)
+    const int cop = ntile * 16 * NP;                     // first output channel of this workgroup
 
     build_column_table(g, utab, tid);
-    if (tid < 32) stat[tid] = 0.f;
+    if (tid < 32 * NP) stat[tid] = 0.f;
     if (tid < 27) tapb[tid] = (g.td[tid] - g.tmin_d) * DSB + (g.th[tid] - g.tmin_h) * ROWB + (g.tw[tid] - g.tmin_w) * UNIT;
-    // the 16 x 448 weight panel of one chunk -> LDS: 16 rows x 56 units of 16 bytes, 3.5 per thread
+    // the (16 NP) x 448 weight panel of one chunk -> LDS: 16 NP rows x 56 units of 16 bytes, 3.5 NP per thread
     auto load_weights = [&](int chunk) {
-        const char* src = (const char*)p.wp + ((size_t)(ntile * 16) * Ktot + (size_t)chunk * KCPAD) * 2;
-        f32x4 v[4];
+        const char* src = (const char*)p.wp + ((size_t)cop * Ktot + (size_t)chunk * KCPAD) * 2;
+        constexpr int NU = 16 * NP * 56, NK = (NU + 255) / 256;
+        f32x4 v[NK];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int u = min(tid + k * 256, 16 * 56 - 1);
+        for (int k = 0; k < NK; ++k) {
+            const int u = min(tid + k * 256, NU - 1);
             const int r = u / 56, c = u - r * 56;
             v[k] = *(const __attribute__((address_space(1))) f32x4*)(uintptr_t)(src + (size_t)r * Ktot * 2 + c * 16);
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < NK; ++k) {
             const int u = tid + k * 256;
-            if (u < 16 * 56) { const int r = u / 56, c = u - r * 56; *(f32x4*)(wlds + r * WRS + c * 16) = v[k]; }
+            if (u < NU) { const int r = u / 56, c = u - r * 56; *(f32x4*)(wlds + r * WRS + c * 16) = v[k]; }
         }
     };
     load_weights(0);
     // ---- per-lane constants of the MFMA loop: B-fragment base of every K-step (tap and channel group of this lane's k-group)
-    const int wbase = li * WRS + kg * 16;                                // A fragment: row li of the panel, k-group kg
-    const int co0 = ntile * 16 + 4 * kg;                                 // this lane's 4 output channels
-    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-    f32x2 e_b[2] = {{0.f, 0.f}, {0.f, 0.f}}, e_rs[2], e_rb[2];
-    if (BIAS) { e_b[0] = (f32x2){p.bias[co0], p.bias[co0 + 1]}; e_b[1] = (f32x2){p.bias[co0 + 2], p.bias[co0 + 3]}; }
-    if (RES) {
-        e_rs[0] = (f32x2){p.rs[n * p.Cout + co0], p.rs[n * p.Cout + co0 + 1]}; e_rs[1] = (f32x2){p.rs[n * p.Cout + co0 + 2], p.rs[n * p.Cout + co0 + 3]};
-        e_rb[0] = (f32x2){p.rb[n * p.Cout + co0], p.rb[n * p.Cout + co0 + 1]}; e_rb[1] = (f32x2){p.rb[n * p.Cout + co0 + 2], p.rb[n * p.Cout + co0 + 3]};
+    const int wbase = li * WRS + kg * 16;                                // A fragment: row li of panel 0, k-group kg (panel q: + 16 q rows)
+    const int co0 = cop + 4 * kg;                                        // this lane's 4 output channels of panel 0 (panel q: + 16 q)
+    float s1[NP][4], s2[NP][4];
+    f32x2 e_b[NP][2], e_rs[NP][2], e_rb[NP][2];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        const int c = co0 + 16 * q;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s1[q][r] = 0.f; s2[q][r] = 0.f; }
+        e_b[q][0] = (f32x2){0.f, 0.f}; e_b[q][1] = e_b[q][0];
+        if (BIAS && NP == 1) { e_b[q][0] = (f32x2){p.bias[c], p.bias[c + 1]}; e_b[q][1] = (f32x2){p.bias[c + 2], p.bias[c + 3]}; }
+        if (RES && NP == 1) {
+            e_rs[q][0] = (f32x2){p.rs[n * p.Cout + c], p.rs[n * p.Cout + c + 1]}; e_rs[q][1] = (f32x2){p.rs[n * p.Cout + c + 2], p.rs[n * p.Cout + c + 3]};
+            e_rb[q][0] = (f32x2){p.rb[n * p.Cout + c], p.rb[n * p.Cout + c + 1]}; e_rb[q][1] = (f32x2){p.rb[n * p.Cout + c + 2], p.rb[n * p.Cout + c + 3]};
+        }
     }
-    // BSTAT: the source tensor of this workgroup's 16-channel panel (the per-channel constants are fetched in the epilogue:
+    // BSTAT: the source tensor of each 16-channel panel (the per-channel constants are fetched in the epilogue:
     // held across the MFMA loop they pushed this instance over its register cap)
-    const T* b_x = nullptr; int b_cs = 0, b_sh = 0; float b_slope = 1.f;
+    const T* b_x[NP]; int b_cs[NP], b_sh[NP]; float b_slope = 1.f;
+#pragma unroll
+    for (int q = 0; q < NP; ++q) { b_x[q] = nullptr; b_cs[q] = 0; b_sh[q] = 0; }
     if (BSTAT) {
-        const bool lo = co0 < p.bs_c0;                                   // panel-uniform (bs_c0 is a multiple of 16)
-        b_sh = lo ? p.bs_sh : 0; b_cs = lo ? p.bs_c0 : p.Cout - p.bs_c0;
-        b_x = (lo ? (const T*)p.bs_x0 + co0 : (const T*)p.bs_x1 + (co0 - p.bs_c0))
-              + (size_t)n * (p.bs_D >> b_sh) * (p.bs_H >> b_sh) * (p.bs_W >> b_sh) * b_cs;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const int c = co0 + 16 * q;
+            const bool lo = c < p.bs_c0;                                 // panel-uniform (bs_c0 is a multiple of 16)
+            b_sh[q] = lo ? p.bs_sh : 0; b_cs[q] = lo ? p.bs_c0 : p.Cout - p.bs_c0;
+            b_x[q] = (lo ? (const T*)p.bs_x0 + c : (const T*)p.bs_x1 + (c - p.bs_c0))
+                     + (size_t)n * (p.bs_D >> b_sh[q]) * (p.bs_H >> b_sh[q]) * (p.bs_W >> b_sh[q]) * b_cs[q];
+        }
         b_slope = p.bs_act == VG_ACT_RELU ? 0.f : (p.bs_act == VG_ACT_LRELU ? VG_LRELU : 1.f);
     }
     // 16-byte stores: after the row swap an even k-group lane holds channels 8*(kg/2)..+7 of sub-tile j, an odd one of j+1
-    const int cst = ntile * 16 + 8 * (kg >> 1);
+    const int cst = cop + 8 * (kg >> 1);
     const int jodd = kg & 1;
 
     const int tiles_per_n = g.tiles_d * g.tiles_h * g.tiles_w;
@@ -225,7 +246,7 @@ __global__ __launch_bounds__(256, VG_THIN_WPE) void conv_thin_kernel(const Gathe
     // PF: the loads of the NEXT (tile, chunk) are issued ahead of the MFMA loop and stay in registers across it.  Forward instances
     // only (16 -> 16: 68 -> 64 us, 48 -> 16: 148 -> 142 us); the data-gradient instances got SLOWER with it (16 -> 48: 178 -> 195 us;
     // the BSTAT one sits at the register cap and spilled the nine units): they load, then commit, back to back.
-    constexpr bool PF = MODE == VG_STAGE_RELU;
+    constexpr bool PF = MODE == VG_STAGE_RELU && (NP == 1 || VG_THIN_PF2);
     Raw8<T> raw[3][HD / 2];
     if (PF && t0 < tend) thin_issue<MODE>(g, utab, rtab, n, 0, tid, raw);
     for (int tile = t0; tile < tend; tile += tstep, ++it) {
@@ -234,9 +255,11 @@ __global__ __launch_bounds__(256, VG_THIN_WPE) void conv_thin_kernel(const Gathe
         ti_h += gs_h; if (ti_h >= g.tiles_h) { ti_h -= g.tiles_h; ++ti_d; }
         ti_d += gs_d;
         const bool more = tile + tstep < tend;
-        f32x4 acc[8];
+        f32x4 acc[NP][8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < NP; ++q)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[q][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         for (int chunk = 0; chunk < nchunks; ++chunk) {
             if (it | chunk) lds_only_barrier();                            // previous readers of the halo image / weight panel are done
             if (nchunks > 1) { stage_scale_shift(g, scs, n, chunk, tid); if (it | chunk) load_weights(chunk); lds_only_barrier(); }
@@ -249,27 +272,60 @@ __global__ __launch_bounds__(256, VG_THIN_WPE) void conv_thin_kernel(const Gathe
                 if (chunk + 1 < nchunks) thin_issue<MODE>(g, utab, rtab + (it & 1) * RTN, n, chunk + 1, tid, raw);
                 else if (more) thin_issue<MODE>(g, utab, rtab + ((it + 1) & 1) * RTN, n, 0, tid, raw);
             }
-            // ---- MFMA loop: 14 K-steps x 8 sub-tiles, every address an immediate, fragments of two K-steps ahead in flight
+            // ---- MFMA loop: 14 K-steps x 8 sub-tiles x NP panels, every address an immediate, the fragments of the next K-step in flight
             const char* wb = wlds + wbase;
             constexpr int PD = VG_THIN_PD, NB = PD + 1;                    // K-steps of fragments in flight ahead of the MFMAs
-            bf16x8 a[NB], b[NB][8];
+            if constexpr (NP == 1) {
+                bf16x8 a[NB][NP], b[NB][8];
 #pragma unroll
-            for (int u = 0; u < PD; ++u) {
-                a[u] = *(lds_frag*)(wb + u * 64);
+                for (int u = 0; u < PD; ++u) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) b[u][j] = *(lds_frag*)(halo + boff[u] + j * ROWB);
-            }
+                    for (int q = 0; q < NP; ++q) a[u][q] = *(lds_frag*)(wb + q * 16 * WRS + u * 64);
 #pragma unroll
-            for (int s = 0; s < KSTEPS; ++s) {
-                if (s + PD < KSTEPS) {
-                    a[(s + PD) % NB] = *(lds_frag*)(wb + (s + PD) * 64);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) b[(s + PD) % NB][j] = *(lds_frag*)(halo + boff[s + PD] + j * ROWB);
+                    for (int j = 0; j < 8; ++j) b[u][j] = *(lds_frag*)(halo + boff[u] + j * ROWB);
                 }
-                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[j] = VG_MFMA16(a[s % NB], b[s % NB][j], acc[j]);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int s = 0; s < KSTEPS; ++s) {
+                    if (s + PD < KSTEPS) {
+#pragma unroll
+                        for (int q = 0; q < NP; ++q) a[(s + PD) % NB][q] = *(lds_frag*)(wb + q * 16 * WRS + (s + PD) * 64);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) b[(s + PD) % NB][j] = *(lds_frag*)(halo + boff[s + PD] + j * ROWB);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int q = 0; q < NP; ++q)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc[q][j] = VG_MFMA16(a[s % NB][q], b[s % NB][j], acc[q][j]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+                // two panels: a K-step is 16 MFMAs (256 cycles), so the B fragments are double-buffered per HALF step (4 sub-tiles:
+                // 8 MFMAs cover the LDS round trip of the next four) -- 32 registers of fragments instead of 64; the accumulators take 64
+                bf16x8 a[2][NP], b[2][4];
+#pragma unroll
+                for (int q = 0; q < NP; ++q) a[0][q] = *(lds_frag*)(wb + q * 16 * WRS);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) b[0][j] = *(lds_frag*)(halo + boff[0] + j * ROWB);
+#pragma unroll
+                for (int hs = 0; hs < 2 * KSTEPS; ++hs) {
+                    const int s = hs >> 1, h = hs & 1;
+                    if (hs + 1 < 2 * KSTEPS) {
+                        const int s2 = (hs + 1) >> 1, h2 = (hs + 1) & 1;
+                        if (h2 == 0) {
+#pragma unroll
+                            for (int q = 0; q < NP; ++q) a[s2 & 1][q] = *(lds_frag*)(wb + q * 16 * WRS + s2 * 64);
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) b[(hs + 1) & 1][j] = *(lds_frag*)(halo + boff[s2] + (4 * h2 + j) * ROWB);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int q = 0; q < NP; ++q)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[q][4 * h + j] = VG_MFMA16(a[s & 1][q], b[hs & 1][j], acc[q][4 * h + j]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
         // ---- epilogue: wave = D-plane `wave` of the tile, sub-tile j = H row j, lane li = voxel W, lanes own 4 channels;
@@ -279,8 +335,6 @@ __global__ __launch_bounds__(256, VG_THIN_WPE) void conv_thin_kernel(const Gathe
         const int od = od0 + wave, ow = ow0 + li;
         const size_t rowpitch = (size_t)p.BW * p.Cout;                                       // elements per output H row (ostr == 1)
         const size_t obase = (((size_t)(n * p.BD + od + p.ood) * p.BH + oh0 + p.ooh) * p.BW + ow + p.oow) * p.Cout;
-        T* const optr = (T*)p.out + obase + cst;
-        const T* const rptr = RES ? (const T*)p.res + obase + co0 : nullptr;
         const bool full = od0 + TD <= p.OD && oh0 + TH <= p.OH && ow0 + TW <= p.OW;
         auto epilogue = [&](auto masked_tag) {
             constexpr bool MASKED = decltype(masked_tag)::value;
@@ -288,10 +342,25 @@ __global__ __launch_bounds__(256, VG_THIN_WPE) void conv_thin_kernel(const Gathe
             const int nrow = MASKED ? p.OH - oh0 : TH;                                        // valid H rows of this tile
             typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
             typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+            T* const optr = (T*)p.out + obase + cst + 16 * q;
+            const T* const rptr = RES ? (const T*)p.res + obase + co0 + 16 * q : nullptr;
+            f32x2 eb[2], ers[2], erb[2];
+            if constexpr (NP == 1) { eb[0] = e_b[0][0]; eb[1] = e_b[0][1]; if (RES) { ers[0] = e_rs[0][0]; ers[1] = e_rs[0][1]; erb[0] = e_rb[0][0]; erb[1] = e_rb[0][1]; } }
+            else {              // (two panels: fetched here -- held across the MFMA loop they cost 24 registers the accumulators need)
+                const int c = co0 + 16 * q;
+                typedef const __attribute__((address_space(1))) f32x4 gf4;
+                if (BIAS) { const f32x4 t = *(gf4*)(uintptr_t)(p.bias + c); eb[0] = (f32x2){t[0], t[1]}; eb[1] = (f32x2){t[2], t[3]}; }
+                if (RES) {
+                    const f32x4 t = *(gf4*)(uintptr_t)(p.rs + n * p.Cout + c), u = *(gf4*)(uintptr_t)(p.rb + n * p.Cout + c);
+                    ers[0] = (f32x2){t[0], t[1]}; ers[1] = (f32x2){t[2], t[3]}; erb[0] = (f32x2){u[0], u[1]}; erb[1] = (f32x2){u[2], u[3]};
+                }
+            }
             bf16x4 bx[BSTAT ? 8 : 1];
             f32x2 b_sc[2], b_sf[2], b_rs[2], b_nm[2];
             if (BSTAT) {
-                const int nc = n * p.Cout + co0;
+                const int nc = n * p.Cout + co0 + 16 * q;
                 typedef const __attribute__((address_space(1))) f32x4 gf4;
                 const f32x4 c_sc = *(gf4*)(uintptr_t)(p.bs_sc + nc), c_sf = *(gf4*)(uintptr_t)(p.bs_sf + nc), c_rs = *(gf4*)(uintptr_t)(p.bs_rs + nc),
                             c_mu = *(gf4*)(uintptr_t)(p.bs_mu + nc);
@@ -300,14 +369,14 @@ __global__ __launch_bounds__(256, VG_THIN_WPE) void conv_thin_kernel(const Gathe
                 b_nm[0] = (f32x2){-c_mu[0] * c_rs[0], -c_mu[1] * c_rs[1]}; b_nm[1] = (f32x2){-c_mu[2] * c_rs[2], -c_mu[3] * c_rs[3]};
                 // padded output coordinate -> interior coordinate -> transpose of the reflection pad (-1 -> 1, n -> n-2); rows of a
                 // masked tile that lie outside are clamped (their contribution is zeroed below).  All 8 loads are issued up front.
-                auto fold = [&](int q, int nn) { int i = q - p.bs_pad; i = i < 0 ? -i : i; i = i >= nn ? 2 * nn - 2 - i : i; return min(max(i, 0), nn - 1); };
-                const int XH = p.bs_H >> b_sh, XW = p.bs_W >> b_sh;
-                const int id = fold(od + p.ood, p.bs_D) >> b_sh, iw = fold(ow + p.oow, p.bs_W) >> b_sh;
-                const T* xcol = b_x + ((size_t)id * XH * XW + iw) * b_cs;
+                auto fold = [&](int qq, int nn) { int i = qq - p.bs_pad; i = i < 0 ? -i : i; i = i >= nn ? 2 * nn - 2 - i : i; return min(max(i, 0), nn - 1); };
+                const int XH = p.bs_H >> b_sh[q], XW = p.bs_W >> b_sh[q];
+                const int id = fold(od + p.ood, p.bs_D) >> b_sh[q], iw = fold(ow + p.oow, p.bs_W) >> b_sh[q];
+                const T* xcol = b_x[q] + ((size_t)id * XH * XW + iw) * b_cs[q];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const int ih = fold(oh0 + j + p.ooh, p.bs_H) >> b_sh;
-                    bx[j] = *(const __attribute__((address_space(1))) bf16x4*)(uintptr_t)(xcol + (size_t)ih * XW * b_cs);
+                    const int ih = fold(oh0 + j + p.ooh, p.bs_H) >> b_sh[q];
+                    bx[j] = *(const __attribute__((address_space(1))) bf16x4*)(uintptr_t)(xcol + (size_t)ih * XW * b_cs[q]);
                 }
             }
 #pragma unroll
@@ -317,20 +386,20 @@ __global__ __launch_bounds__(256, VG_THIN_WPE) void conv_thin_kernel(const Gathe
                 for (int e = 0; e < 2; ++e) {
                     const int j = jp + e;
                     const bool ok = !MASKED || (dw_ok && j < nrow);
-                    f32x2 v0 = {acc[j][0], acc[j][1]}, v1 = {acc[j][2], acc[j][3]};
-                    if (BIAS) { v0 += e_b[0]; v1 += e_b[1]; }
+                    f32x2 v0 = {acc[q][j][0], acc[q][j][1]}, v1 = {acc[q][j][2], acc[q][j][3]};
+                    if (BIAS) { v0 += eb[0]; v1 += eb[1]; }
                     if (RES) {
                         const bf16x4 r = *(const __attribute__((address_space(1))) bf16x4*)(uintptr_t)(ok ? rptr + j * rowpitch : rptr);
                         const f32x2 r0 = {bf2f((bf16_t)r[0]), bf2f((bf16_t)r[1])}, r1 = {bf2f((bf16_t)r[2]), bf2f((bf16_t)r[3])};
-                        v0 += r0 * e_rs[0] + e_rb[0]; v1 += r1 * e_rs[1] + e_rb[1];
+                        v0 += r0 * ers[0] + erb[0]; v1 += r1 * ers[1] + erb[1];
                     }
                     pk[e] = (bf16x4){(short)f2bf(v0[0]), (short)f2bf(v0[1]), (short)f2bf(v1[0]), (short)f2bf(v1[1])};
                     if (STATS) {
                         f32x2 q0 = {bf2f((bf16_t)pk[e][0]), bf2f((bf16_t)pk[e][1])}, q1 = {bf2f((bf16_t)pk[e][2]), bf2f((bf16_t)pk[e][3])};
                         if (MASKED && !ok) { q0 = (f32x2){0.f, 0.f}; q1 = q0; }
-                        f32x2 a0 = {s1[0], s1[1]}, a1 = {s1[2], s1[3]}, c0 = {s2[0], s2[1]}, c1 = {s2[2], s2[3]};
+                        f32x2 a0 = {s1[q][0], s1[q][1]}, a1 = {s1[q][2], s1[q][3]}, c0 = {s2[q][0], s2[q][1]}, c1 = {s2[q][2], s2[q][3]};
                         a0 += q0; a1 += q1; c0 += q0 * q0; c1 += q1 * q1;
-                        s1[0] = a0[0]; s1[1] = a0[1]; s1[2] = a1[0]; s1[3] = a1[1]; s2[0] = c0[0]; s2[1] = c0[1]; s2[2] = c1[0]; s2[3] = c1[1];
+                        s1[q][0] = a0[0]; s1[q][1] = a0[1]; s1[q][2] = a1[0]; s1[q][3] = a1[1]; s2[q][0] = c0[0]; s2[q][1] = c0[1]; s2[q][2] = c1[0]; s2[q][3] = c1[1];
                     }
                     if (BSTAT) {
                         f32x2 q0 = {bf2f((bf16_t)pk[e][0]), bf2f((bf16_t)pk[e][1])}, q1 = {bf2f((bf16_t)pk[e][2]), bf2f((bf16_t)pk[e][3])};
@@ -342,9 +411,9 @@ __global__ __launch_bounds__(256, VG_THIN_WPE) void conv_thin_kernel(const Gathe
                         const f32x2 d1 = {pre1[0] > 0.f ? 1.f : b_slope, pre1[1] > 0.f ? 1.f : b_slope};
                         const f32x2 dn0 = q0 * d0, dn1 = q1 * d1;                                          // (no dropout multiplier on this path)
                         const f32x2 xh0 = x0 * b_rs[0] + b_nm[0], xh1 = x1 * b_rs[1] + b_nm[1];
-                        f32x2 a0 = {s1[0], s1[1]}, a1 = {s1[2], s1[3]}, c0 = {s2[0], s2[1]}, c1 = {s2[2], s2[3]};
+                        f32x2 a0 = {s1[q][0], s1[q][1]}, a1 = {s1[q][2], s1[q][3]}, c0 = {s2[q][0], s2[q][1]}, c1 = {s2[q][2], s2[q][3]};
                         a0 += dn0; a1 += dn1; c0 += dn0 * xh0; c1 += dn1 * xh1;
-                        s1[0] = a0[0]; s1[1] = a0[1]; s1[2] = a1[0]; s1[3] = a1[1]; s2[0] = c0[0]; s2[1] = c0[1]; s2[2] = c1[0]; s2[3] = c1[1];
+                        s1[q][0] = a0[0]; s1[q][1] = a0[1]; s1[q][2] = a1[0]; s1[q][3] = a1[1]; s2[q][0] = c0[0]; s2[q][1] = c0[1]; s2[q][2] = c1[0]; s2[q][3] = c1[1];
                     }
                 }
                 // rows (16-lane groups) 1,3 of pk[0] <-> rows 0,2 of pk[1]: even rows end with sub-tile jp channels [4kg..4kg+7],
@@ -356,20 +425,23 @@ __global__ __launch_bounds__(256, VG_THIN_WPE) void conv_thin_kernel(const Gathe
                 const int j = jp + jodd;
                 if (!MASKED || (dw_ok && j < nrow)) *(u32x4*)(optr + j * rowpitch) = outv;
             }
+            }
         };
         if (full) epilogue(std::false_type{}); else epilogue(std::true_type{});
     }
     if ((STATS || BSTAT) && p.sums) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float a = s1[r], b = s2[r];
+        for (int q = 0; q < NP; ++q)
 #pragma unroll
-            for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
-            if (li == 0) { atomicAdd(&stat[(4 * kg + r) * 2], a); atomicAdd(&stat[(4 * kg + r) * 2 + 1], b); }
-        }
+            for (int r = 0; r < 4; ++r) {
+                float a = s1[q][r], b = s2[q][r];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+                if (li == 0) { atomicAdd(&stat[(16 * q + 4 * kg + r) * 2], a); atomicAdd(&stat[(16 * q + 4 * kg + r) * 2 + 1], b); }
+            }
         __syncthreads();
-        if (tid < 32) {
-            const int co = ntile * 16 + (tid >> 1);
+        if (tid < 32 * NP) {
+            const int co = cop + (tid >> 1);
             const int stripe = blockIdx.x & (VG_STRIPES - 1);
             if (co < p.Cout) atomicAdd(&p.sums[(((size_t)stripe * gridDim.z + n) * p.Cout + co) * 2 + (tid & 1)], stat[tid]);
         }
@@ -379,15 +451,15 @@ __global__ __launch_bounds__(256, VG_THIN_WPE) void conv_thin_kernel(const Gathe
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-int vg_conv_thin_lds_bytes(const GatherIn& g) {
-    return HALO + (32 + 32 + 32) * 4 + (2 * HH * HW * 2 + 6 * stage_axis_len3(g)) * 4 + 16 + 16 * (KCPAD * 2 + 16);
+int vg_conv_thin_lds_bytes(const GatherIn& g, int np) {
+    return HALO + (32 + 32 * np + 32) * 4 + (2 * HH * HW * 2 + 6 * stage_axis_len3(g)) * 4 + 16 + 16 * np * (KCPAD * 2 + 16);
 }
 
-// Does this launch have the one shape the specialist serves?  (g from fill_gather for a 512-voxel tile)
-bool vg_conv_thin_ok(const vg_conv_desc* d, const GatherIn& g, const ConvOut& k, const ConvCls& q) {
+// Does this launch have the one shape the specialist serves?  (g from fill_gather for a 512-voxel tile; np: 16-channel panels per workgroup)
+bool vg_conv_thin_ok(const vg_conv_desc* d, const GatherIn& g, const ConvOut& k, const ConvCls& q, int np) {
     if (!vg_tune("CONV_THIN", 1)) return false;
     if (d->f32 || d->noise || q.ncls != 1 || d->istr != 1 || d->ostr != 1 || d->CK != 16 || d->ntaps != 27 || d->wpack) return false;
-    if ((d->c_src0 + d->c_src1) % 16 || (d->Cout % 16) || d->tanh_out || d->accumulate || d->out_f32) return false;
+    if ((d->c_src0 + d->c_src1) % 16 || (d->Cout % (16 * np)) || d->tanh_out || d->accumulate || d->out_f32) return false;
     if (g.lean != VG_STAGE_PLAIN && g.lean != VG_STAGE_RELU) return false;
     if (!g.planar || g.HW != HW || g.HH != HH || g.HD != HD || g.HWp != HW || g.HHp != HH || g.DS != DSB || g.PSB != PSB) return false;
     if ((1 << g.twl) != TW || (1 << g.thl) != TH || (1 << g.tdl) != TD) return false;
@@ -395,50 +467,62 @@ bool vg_conv_thin_ok(const vg_conv_desc* d, const GatherIn& g, const ConvOut& k,
     if (k.Ktot != k.nchunks * KCPAD) return false;
     for (int i = 0; i < 27; ++i)                                       // a full 3x3x3 stencil (any order)
         if (d->tap_d[i] - g.tmin_d > 2 || d->tap_h[i] - g.tmin_h > 2 || d->tap_w[i] - g.tmin_w > 2) return false;
+    if (np > 1) {
+        // two panels per workgroup halve the workgroup count: only where the grid still fills the chip (the 32-channel layers at 64^3)
+        const long wgs = (long)g.tiles_d * g.tiles_h * g.tiles_w * (d->Cout / (16 * np)) * d->N;
+        if (!vg_tune("CONV_THIN2", 1) || wgs < vg_tune("CONV_THIN2_MINWG", 384)) return false;
+    }
     return true;
 }
 
-template <int MODE, bool BIAS, bool RES, bool STATS, bool BSTAT = false>
-static int launch_thin(const GatherIn& g, const ConvOut& k, int lds, hipStream_t s) {
+template <int MODE, bool BIAS, bool RES, bool STATS, bool BSTAT, int NP>
+static int launch_thin_np(const GatherIn& g, const ConvOut& k, int lds, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_thin_kernel<MODE, BIAS, RES, STATS, BSTAT>, hipFuncAttributeMaxDynamicSharedMemorySize, VG_LDS_LIMIT);
+        (void)hipFuncSetAttribute((const void*)conv_thin_kernel<MODE, BIAS, RES, STATS, BSTAT, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, VG_LDS_LIMIT);
         attr_set = true;
     }
     int per_cu = 2;
     if (lds > 0 && VG_LDS_LIMIT / lds < per_cu) per_cu = VG_LDS_LIMIT / lds;
     if (per_cu < 1) per_cu = 1;
     const int tiles = g.tiles_d * g.tiles_h * g.tiles_w;
-    const int ny = k.Cout / 16;
+    const int ny = k.Cout / (16 * NP);
     const int wg = vg_tune("CONV_THIN_WGS", 0) > 0 ? vg_tune("CONV_THIN_WGS", 0) : 256 * per_cu;
     int bx = wg / (ny * g.N); if (bx < 1) bx = 1; if (bx > tiles) bx = tiles;
     ConvOut k2 = k; k2.xw = 0;
     if (vg_tune("CONV_THIN_XCD", 1) && bx >= 16 && tiles >= 4 * bx) { bx &= ~7; k2.xw = 1; }
     // bs1 / bs2: IN-backward statistics in the epilogue, of a plain / a virtually concatenated (half-resolution + skip) pre-norm tensor
-    if (vg_dry(BSTAT ? (k.bs_x1 ? "conv_thin<m%d,b%d,r%d,s%d,bs2>|walk%d|ch%d" : "conv_thin<m%d,b%d,r%d,s%d,bs1>|walk%d|ch%d") : "conv_thin<m%d,b%d,r%d,s%d>|walk%d|ch%d",
-               MODE, (int)BIAS, (int)RES, (int)STATS, tiles > bx ? 1 : 0, k.nchunks > 1 ? 1 : 0)) return VG_OK;
-    hipLaunchKernelGGL((conv_thin_kernel<MODE, BIAS, RES, STATS, BSTAT>), dim3(bx, ny, g.N), dim3(256), lds, s, g, k2);
+    char name[96];
+    snprintf(name, sizeof name, "%s<m%%d,b%%d,r%%d,s%%d%s>|walk%%d|ch%%d", NP == 2 ? "conv_thin2" : "conv_thin", BSTAT ? (k.bs_x1 ? ",bs2" : ",bs1") : "");
+    if (vg_dry(name, MODE, (int)BIAS, (int)RES, (int)STATS, tiles > bx ? 1 : 0, k.nchunks > 1 ? 1 : 0)) return VG_OK;
+    hipLaunchKernelGGL((conv_thin_kernel<MODE, BIAS, RES, STATS, BSTAT, NP>), dim3(bx, ny, g.N), dim3(256), lds, s, g, k2);
     return vg_check_launch();
 }
-
-int vg_launch_conv_thin(const GatherIn& g, const ConvOut& k, hipStream_t s, float* red, bool& did_stats) {
-    const int lds = vg_conv_thin_lds_bytes(g);
+template <int MODE, bool BIAS, bool RES, bool STATS, bool BSTAT = false>
+static int launch_thin(const GatherIn& g, const ConvOut& k, int np, hipStream_t s) {
+    const int lds = vg_conv_thin_lds_bytes(g, np);
     if (lds > VG_LDS_LIMIT) return VG_ELDS;
+    if constexpr (!BSTAT) { if (np == 2) return launch_thin_np<MODE, BIAS, RES, STATS, BSTAT, 2>(g, k, lds, s); }
+    return np == 1 ? launch_thin_np<MODE, BIAS, RES, STATS, BSTAT, 1>(g, k, lds, s) : VG_EINVAL;
+}
+
+int vg_launch_conv_thin(const GatherIn& g, const ConvOut& k, int np, hipStream_t s, float* red, bool& did_stats) {
     const bool st = k.sums != nullptr;
     if (g.lean == VG_STAGE_PLAIN) {
-        // data gradient (no bias / residual / statistics) and raw-source forward convolutions
-        if (red && k.bs_x0 && !k.bs_ml && k.bs_sc && k.bias == nullptr && k.res == nullptr && !st && (k.bs_c0 % 16) == 0 && (k.bs_c0 == k.Cout || k.bs_x1)
+        // data gradient (no bias / residual / statistics) and raw-source forward convolutions.  (The two-panel instance with the
+        // IN-backward statistics in its epilogue spills 86 registers: those launches leave the statistics to the pass behind them.)
+        if (np == 1 && red && k.bs_x0 && !k.bs_ml && k.bs_sc && k.bias == nullptr && k.res == nullptr && !st && (k.bs_c0 % 16) == 0 && (k.bs_c0 == k.Cout || k.bs_x1)
             && k.OD == k.BD && k.OH == k.BH && k.OW == k.BW && !k.ood && !k.ooh && !k.oow && vg_tune("CONV_BSTAT", 1)) {
             ConvOut k2 = k; k2.sums = red;                 // the IN-backward statistics take the place of the forward ones
             did_stats = !vg_dry_on();
-            return launch_thin<VG_STAGE_PLAIN, false, false, false, true>(g, k2, lds, s);
+            return launch_thin<VG_STAGE_PLAIN, false, false, false, true>(g, k2, np, s);
         }
-        if (k.bias == nullptr && k.res == nullptr && !st) return launch_thin<VG_STAGE_PLAIN, false, false, false>(g, k, lds, s);
-        if (k.bias != nullptr && k.res == nullptr) return st ? launch_thin<VG_STAGE_PLAIN, true, false, true>(g, k, lds, s)
-                                                             : launch_thin<VG_STAGE_PLAIN, true, false, false>(g, k, lds, s);
+        if (k.bias == nullptr && k.res == nullptr && !st) return launch_thin<VG_STAGE_PLAIN, false, false, false>(g, k, np, s);
+        if (k.bias != nullptr && k.res == nullptr) return st ? launch_thin<VG_STAGE_PLAIN, true, false, true>(g, k, np, s)
+                                                             : launch_thin<VG_STAGE_PLAIN, true, false, false>(g, k, np, s);
         return 1;
     }
     if (k.bias == nullptr) return 1;
-    if (k.res != nullptr) return st ? launch_thin<VG_STAGE_RELU, true, true, true>(g, k, lds, s) : launch_thin<VG_STAGE_RELU, true, true, false>(g, k, lds, s);
-    return st ? launch_thin<VG_STAGE_RELU, true, false, true>(g, k, lds, s) : launch_thin<VG_STAGE_RELU, true, false, false>(g, k, lds, s);
+    if (k.res != nullptr) return st ? launch_thin<VG_STAGE_RELU, true, true, true>(g, k, np, s) : launch_thin<VG_STAGE_RELU, true, true, false>(g, k, np, s);
+    return st ? launch_thin<VG_STAGE_RELU, true, false, true>(g, k, np, s) : launch_thin<VG_STAGE_RELU, true, false, false>(g, k, np, s);
 }

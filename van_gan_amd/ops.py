@@ -65,7 +65,7 @@ class DryRun:
     a box without a GPU to list the kernels a configuration would run (tests/test_variant_coverage.py).
     records: [(kind, layer name, variant string)], kind in fwd / dgrad / wgrad."""
 
-    _PASS = ('vg_conv3d_dma_bn', 'vg_conv3d_plan', 'vg_packed_ktot', 'vg_packed_rows', 'vg_conv3d_lds_bytes', 'vg_status_string', 'vg_set_tuning')
+    _PASS = ('vg_conv3d_dma_bn', 'vg_conv3d_thin_np', 'vg_conv3d_plan', 'vg_packed_ktot', 'vg_packed_rows', 'vg_conv3d_lds_bytes', 'vg_status_string', 'vg_set_tuning')
 
     def __init__(self):
         self.records = []
@@ -641,6 +641,9 @@ class ConvLayer:
         # per output and more MFMAs per barrier), then two resident workgroups per CU (<= 80 KiB), then the largest
         # chunk (every further chunk is another staging pass per tile).  Measured on D.down0 (64->128, k4 s2, 64^3):
         # CK 32 / 128-voxel tile 0.128 ms, CK 16 / 128 voxels 0.196 ms, CK 64 / 64 voxels 0.247 ms.
+        # the 32-channel layers at 64^3: two-panel instance of the thin-channel specialist, which wants 16-channel chunks
+        if not wpack and not self.f32 and os.environ.get('VG_CONV_THIN2', '1') != '0' and lib.vg_conv3d_thin_np(C.byref(d)) == 2:
+            return 16
         best, best_key = None, None
         plan = (C.c_int32 * 4)()
         for ck in _ck_candidates(C_):
