@@ -250,7 +250,7 @@ int vg_in_param_grads(const float* red, int N, int C, float* dgamma, float* dbet
 /* Backward of the virtual upsample+concat (resunet_model.py:175-181): g is bf16 [N][D][H][W][Cu+Cs];
  * dlow[N][D/2][H/2][W/2][Cu] (+)= sum of the 8 children, dskip[N][D][H][W][Cs] (+)= g[..., Cu:].
  * accumulate: bit 0 -- add to dlow (else overwrite), bit 1 -- add to dskip: the first writer of a gradient buffer overwrites,
- * so the buffers need no memset. */
+ * so the buffers need no memset.  Cs == 0 (dskip ignored): the backward of a bare UpSampling3D (generator.py:58-66), a 2x2x2 sum-pool. */
 int vg_concat_bwd(const void* g, int N, int D, int H, int W, int Cu, int Cs, void* dlow, void* dskip,
                   int f32, int accumulate, vg_stream_t stream);
 

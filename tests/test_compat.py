@@ -62,9 +62,13 @@ def test_error_behaviour_follows_the_reference():
         VanGan(_args(), None, gen_i2s='unet++', gen_s2i='resUnet', engine_factory=_FakeEngine)
     with pytest.raises(ValueError, match='SI Generator type not recognised'):          # vangan.py:164
         VanGan(_args(), None, gen_i2s='resUnet', gen_s2i='nope', engine_factory=_FakeEngine)
-    # the constructor defaults of the reference select 'resnet' (main.py overrides them): known, not built
+    # the constructor defaults of the reference select 'resnet' (main.py overrides them): built since round 4
+    assert engine_kwargs_from_args(_args())['generator'] == 'resnet'
+    assert engine_kwargs_from_args(_args(), gen_i2s='resUnet', gen_s2i='resUnet')['generator'] == 'resUnet'
     with pytest.raises(NotImplementedError):
-        VanGan(_args(), None, engine_factory=_FakeEngine)
+        VanGan(_args(), None, gen_i2s='vnet', gen_s2i='vnet', engine_factory=_FakeEngine)
+    with pytest.raises(NotImplementedError):
+        VanGan(_args(), None, gen_i2s='resnet', gen_s2i='resUnet', engine_factory=_FakeEngine)
     with pytest.raises(NotImplementedError):
         engine_kwargs_from_args(_args(), gen_i2s='resUnet', gen_s2i='resUnet', wasserstein=True)
     with pytest.raises(NotImplementedError):

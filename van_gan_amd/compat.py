@@ -7,9 +7,9 @@ mirrored here.  What is read from ``args`` is exactly what the reference reads (
 INPUT_IMG_SIZE, CHANNELS, GLOBAL_BATCH_SIZE, DIMENSIONS, SUBVOL_PATCH_SIZE, train_steps, BATCH_SIZE, output_dir``.
 
 Differences that are deliberate and loud:
-  * only the default path is built: 3-D, single channel, ``gen_i2s == gen_s2i == 'resUnet'``, non-Wasserstein,
+  * built: 3-D, single channel, ``gen_i2s == gen_s2i == 'resUnet'`` (the default path) or ``== 'resnet'``, non-Wasserstein,
     not semi-supervised.  Unknown generator names raise the reference's own ``ValueError`` (vangan.py:124,164); known but
-    unbuilt variants ('resnet', 'vnet', Wasserstein, 2-D) raise ``NotImplementedError`` naming SURVEY section 8(f)4;
+    unbuilt variants ('vnet', mixed generator pairs, Wasserstein, 2-D) raise ``NotImplementedError`` naming SURVEY section 8(f)4;
   * ``N_DEVICES == 0`` (what ``len(GPUs)`` gives on a box TensorFlow sees no GPU on, main.py:62-105) is read as 1: the
     reference would divide by zero in cycle_seg_loss (loss_functions.py:226) and build with GLOBAL_BATCH_SIZE 0;
   * ``strategy`` is accepted and ignored (None is fine): data parallelism is one process per GPU with a
@@ -33,11 +33,10 @@ def engine_kwargs_from_args(args, lambda_cycle=10.0, lambda_identity=5, lambda_r
         raise ValueError('IS Generator type not recognised')          # vangan.py:124
     if gen_s2i not in KNOWN_GENERATORS:
         raise ValueError('SI Generator type not recognised')          # vangan.py:164
-    if gen_i2s != 'resUnet' or gen_s2i != 'resUnet':
-        raise NotImplementedError("train_step is built for the default generators only (gen_i2s='resUnet', gen_s2i='resUnet', "
-                                  "main.py:196-200).  SURVEY section 8(f)4: the 'resnet' generator (generator.py:7-73) exists as a FORWARD "
-                                  'network for inference (van_gan_amd.nets.ResNetGenerator, parity tests/test_gpu_resnet.py), its backward '
-                                  "and 'vnet' are not built")
+    if gen_i2s != gen_s2i or gen_i2s == 'vnet':
+        raise NotImplementedError("train_step is built for gen_i2s == gen_s2i == 'resUnet' (the default, main.py:196-200) and, SURVEY "
+                                  "section 8(f)4, for gen_i2s == gen_s2i == 'resnet' (generator.py:7-73: van_gan_amd.nets.ResNetGenerator, "
+                                  "tests/test_gpu_resnet.py); 'vnet' and mixed pairs are not built")
     if wasserstein:
         raise NotImplementedError('the WGAN-GP branch (vangan.py:355-378,400-423) is not built: SURVEY section 8(f)4')
     if semi_supervised:
@@ -59,7 +58,7 @@ def engine_kwargs_from_args(args, lambda_cycle=10.0, lambda_identity=5, lambda_r
         gbs = batch * n_dev                                           # N_DEVICES 0 made it 0 in main.py:70-71
     return dict(subvol_patch_size=patch, batch_size=batch, global_batch_size=gbs, n_devices=n_dev,
                 lambda_cycle=float(lambda_cycle), lambda_reconstruction=float(lambda_reconstruction),
-                lambda_topology=float(lambda_topology), output_dir=getattr(args, 'output_dir', None))
+                lambda_topology=float(lambda_topology), output_dir=getattr(args, 'output_dir', None), generator=gen_i2s)
 
 
 def to_device_volume(t, device) -> torch.Tensor:

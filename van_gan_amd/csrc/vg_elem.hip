@@ -452,7 +452,8 @@ __global__ void concat_bwd_kernel(const T* g, int N, int D, int H, int W, int Cu
 extern "C" int vg_concat_bwd(const void* g, int N, int D, int H, int W, int Cu, int Cs, void* dlow, void* dskip,
                              int f32, int accumulate, vg_stream_t stream) {
     vg_begin();
-    if (!g || !dlow || !dskip || (Cu % 8) || (Cs % 8) || Cu < 8 || Cs < 8 || ((D | H | W) & 1)) return VG_EINVAL;
+    // Cs == 0 (dskip ignored): the backward of a bare UpSampling3D -- the 2x2x2 sum-pool (ResNet generator, generator.py:58-66)
+    if (!g || !dlow || (Cs && !dskip) || (Cu % 8) || (Cs % 8) || Cu < 8 || (Cs && Cs < 8) || ((D | H | W) & 1)) return VG_EINVAL;
     const size_t total = (size_t)N * (D / 2) * (H / 2) * (W / 2) * (Cu / 8) + (size_t)N * D * H * W * (Cs / 8);
     int blocks = (int)((total + 255) / 256); if (blocks > 8191) blocks = 8191;
     if (f32) hipLaunchKernelGGL(concat_bwd_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)g, N, D, H, W, Cu,

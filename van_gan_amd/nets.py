@@ -545,8 +545,8 @@ def resnet_param_specs() -> List[Tuple[str, Tuple[int, ...], str]]:
 
 class ResNetGenerator:
     """get_resnet_generator (generator.py:7-73) as vangan.py:88-97,127-134 configures it (filters 32, three stride-2 stages, six
-    residual blocks, three UpSampling3D + 4^3 'same' stages, 7^3 head with tanh), FORWARD ONLY: the non-default generator of SURVEY
-    8(f)4 for inference.  Built from the same kernels as the ResUNet:
+    residual blocks, three UpSampling3D + 4^3 'same' stages, 7^3 head with tanh): the non-default generator of SURVEY 8(f)4, forward
+    and backward (parameter gradients).  Built from the same kernels as the ResUNet:
       * the 7^3 stem reads the single-channel volume W-packed (49 (d, h) taps x 7 pseudo-channels: the path of D.conv0);
       * every InstanceNorm + ReLU (+ SpatialDropout3D multipliers in training mode) is applied on read by the next convolution;
       * UpSampling3D is virtual (the gather reads the low-resolution tensor at idx >> 1), the 4^3 'same' convolution is D.down2's;
@@ -567,23 +567,23 @@ class ResNetGenerator:
         d = L['c7'].out_dims
         for i in range(RESNET_DOWN):
             k = 'down%d' % i
-            L[k] = ConvLayer(store, k, 3, f, 2 * f, 2, 'reflect', False, d, need_dgrad=False, dtype=dtype)
+            L[k] = ConvLayer(store, k, 3, f, 2 * f, 2, 'reflect', False, d, need_dgrad=True, dtype=dtype)
             Nn[k] = Norm(store, k + '.in', 2 * f)
             d, f = L[k].out_dims, 2 * f
         for j in range(RESNET_RES):
             for c in ('c1', 'c2'):
                 k = 'res%d.%s' % (j, c)
-                L[k] = ConvLayer(store, k, 3, f, f, 1, 'reflect', False, d, need_dgrad=False, dtype=dtype)
+                L[k] = ConvLayer(store, k, 3, f, f, 1, 'reflect', False, d, need_dgrad=True, dtype=dtype)
                 Nn[k] = Norm(store, k + '.in', f)
         for i in range(RESNET_UP):
             k = 'up%d' % i
             d = tuple(2 * n for n in d)
-            L[k] = ConvLayer(store, k, 4, f, f // 2, 1, 'same', False, d, need_dgrad=False, dtype=dtype)
+            L[k] = ConvLayer(store, k, 4, f, f // 2, 1, 'same', False, d, need_dgrad=True, dtype=dtype)
             Nn[k] = Norm(store, k + '.in', f // 2)
             f //= 2
         assert d == tuple(dims), (d, dims)
         # the head: one chunk per kernel depth slice (49 taps); only the first adds the bias
-        self.head = [ConvLayer(store, 'out', 7, f, 1, 1, 'same', a == 0, d, need_dgrad=False, dtype=dtype,
+        self.head = [ConvLayer(store, 'out', 7, f, 1, 1, 'same', a == 0, d, need_dgrad=True, dtype=dtype,
                                tap_subset=list(range(a * 49, (a + 1) * 49))) for a in range(7)]
         self.L, self.Nn = L, Nn
 
@@ -599,10 +599,13 @@ class ResNetGenerator:
         L, Nn = self.L, self.Nn
         N = x.shape[0]
         taps = {}
+        ctx = {'N': N, 'y': y, 'chain': [], 'res': [], 'ups': []}      # what backward() needs: every convolution's source, output, statistics
         h = Act(ar, N, L['c7'].out_dims, L['c7'].cout, dtype=self.dtype)
-        L['c7'].forward(Src(x, (N,) + self.dims, 1, f32=True), h.data, sums=h.sums)
+        src = Src(x, (N,) + self.dims, 1, f32=True)
+        L['c7'].forward(src, h.data, sums=h.sums)
         taps['c7'] = h
         key = 'c7'
+        ctx['c7'] = src
         for i in range(RESNET_DOWN):
             k = 'down%d' % i
             st = Nn[key].finalize(ar, h, mult=drop.get(key))
@@ -610,35 +613,127 @@ class ResNetGenerator:
             a = Act(ar, N, L[k].out_dims, L[k].cout, dtype=self.dtype)
             L[k].forward(src, a.data, sums=a.sums)
             taps[k] = a
+            ctx['chain'].append((k, src, h, st, key))                   # (conv, its source, the source's raw tensor, its statistics, its norm)
             h, key = a, k
         st = Nn[key].finalize(ar, h, mult=drop.get(key))
+        ctx['trunk_in'] = (h, st, key)
         cur, sc, sf, act = h.data, st['scale'], st['shift'], ACT_RELU          # the block input with its pending on-read transform
         dims, C_ = h.dims, h.C
         S = dims[0] * dims[1] * dims[2]
         for j in range(RESNET_RES):
             k = 'res%d' % j
             r1 = Act(ar, N, dims, C_, dtype=self.dtype)
-            L[k + '.c1'].forward(Src(cur, (N,) + dims, C_, scale=sc, shift=sf, act=act), r1.data, sums=r1.sums)
+            s1 = Src(cur, (N,) + dims, C_, scale=sc, shift=sf, act=act)
+            L[k + '.c1'].forward(s1, r1.data, sums=r1.sums)
             n1 = Nn[k + '.c1'].finalize(ar, r1)
             r2 = Act(ar, N, dims, C_, dtype=self.dtype)
-            L[k + '.c2'].forward(Src(r1.data, (N,) + dims, C_, scale=n1['scale'], shift=n1['shift'], act=ACT_RELU), r2.data, sums=r2.sums)
+            s2 = Src(r1.data, (N,) + dims, C_, scale=n1['scale'], shift=n1['shift'], act=ACT_RELU)
+            L[k + '.c2'].forward(s2, r2.data, sums=r2.sums)
             n2 = Nn[k + '.c2'].finalize(ar, r2)
             out = ar.alloc((N,) + dims + (C_,), self.dtype)
             ops.affine_add(cur, sc, sf, act, r2.data, n2['scale'], n2['shift'], N, S, C_, out)
             taps[k] = out
+            ctx['res'].append((k, s1, r1, n1, s2, r2, n2))
             cur, sc, sf, act = out, None, None, ACT_NONE
         for i in range(RESNET_UP):
             k = 'up%d' % i
             dims = tuple(2 * n for n in dims)
             a = Act(ar, N, dims, L[k].cout, dtype=self.dtype)
-            L[k].forward(Src(cur, (N,) + dims, C_, shift0=1, scale=sc, shift=sf, act=act), a.data, sums=a.sums)
+            su = Src(cur, (N,) + dims, C_, shift0=1, scale=sc, shift=sf, act=act)
+            L[k].forward(su, a.data, sums=a.sums)
             taps[k] = a
             st = Nn[k].finalize(ar, a)
+            ctx['ups'].append((k, su, a, st))
             cur, sc, sf, act, C_ = a.data, st['scale'], st['shift'], ACT_RELU, L[k].cout
         src = Src(cur, (N,) + dims, C_, scale=sc, shift=sf, act=act)
         for a_, lay in enumerate(self.head):
             lay.forward(src, y, tanh=(a_ == len(self.head) - 1), accumulate=(a_ > 0))
+        ctx['head'] = src
+        taps['_ctx'] = ctx
         return taps
+
+    DROP_RATES = {'c7': 0.5, 'down0': 0.2, 'down1': 0.2, 'down2': 0.2}      # generator.py:44, building_blocks.py downsample()
+    DROP_CH = {'c7': RESNET_F, 'down0': 2 * RESNET_F, 'down1': 4 * RESNET_F, 'down2': 8 * RESNET_F}
+
+    def forward_iter(self, ar: Arena, x: torch.Tensor, y: torch.Tensor, drop: Optional[dict] = None):
+        """The engine's resumable-enqueue protocol (ResUNet.forward_iter): this network is enqueued in one piece."""
+        return self.forward(ar, x, y, drop() if callable(drop) else drop)
+        yield
+
+    def _in_bwd(self, ar: Arena, g, g_padded: bool, raw: 'Act', st: dict, norm: 'Norm', act: int):
+        """(InstanceNorm -> act -> dropout) backward of the tensor raw.data given the gradient g of its transformed value (on the
+        reflect-padded grid when g_padded): returns the gradient of raw.data; gamma / beta gradients are added."""
+        N = raw.N
+        dx = ar.alloc((N,) + raw.dims + (raw.C,), self.dtype)
+        red = ops.alloc_red(ar, N, raw.C)
+        ops.actnorm_bwd(g, g_padded, raw.data, (N,) + raw.dims, raw.C, dx, scale=st['scale'], shift=st['shift'], mult=st.get('mult'),
+                        act=act, norm=True, gamma=norm.gamma, mean=st['mean'], rstd=st['rstd'], red=red, accumulate=False,
+                        dgamma=norm.dgamma, dbeta=norm.dbeta)
+        return dx
+
+    def backward(self, ar: Arena, taps: dict, gy: torch.Tensor, inline_from: int = -1):
+        """gy: fp32 [N,D,H,W,1], gradient w.r.t. the tanh output of forward() (whose return value is `taps`).  Adds the parameter
+        gradients of every layer into store.g (generator.py:7-73 under tf.GradientTape, vangan.py:426-438).  The generator's input
+        gradient is not needed: each generator's loss reaches only its own applications (vangan.py:321-353).
+        Every step is an existing launch: tanh backward; per convolution the weight gradient from its on-read source, the data gradient
+        (all 49-tap chunks of the head accumulate into one buffer), the transpose of the reflection pad folded into the IN backward of
+        the source; UpSampling3D's backward is the 2x2x2 sum-pool of vg_concat_bwd without a skip half; the residual Add hands its
+        gradient to both operands -- the convolution branch's IN backward reads it, the identity branch accumulates the folded data
+        gradient of the block's first convolution into it."""
+        ctx = taps['_ctx']
+        L, Nn, N = self.L, self.Nn, ctx['N']
+        mk = ar.mark()
+        dpre = ar.alloc(gy.shape, torch.float32)
+        ops.tanh_bwd(gy, ctx['y'], dpre)
+        # ---- head: seven 49-tap chunks over one source
+        src = ctx['head']
+        k_up, su, a_up, st_up = ctx['ups'][-1]
+        dp = ar.alloc((N,) + tuple(self.head[0].buf_dims) + (a_up.C,), self.dtype)
+        for i, lay in enumerate(self.head):
+            lay.wgrad(src, dpre)
+            lay.dgrad(dpre, N, dp, accumulate=(i > 0))
+        g = self._in_bwd(ar, dp, False, a_up, st_up, Nn[k_up], ACT_RELU)                 # gradient of up2's raw output
+        # ---- up stages: 4^3 'same' over the virtual UpSampling3D of the previous tensor
+        for i in range(RESNET_UP - 1, -1, -1):
+            k, su, a, st = ctx['ups'][i]
+            lay = L[k]
+            lay.wgrad(su, g)
+            fine = tuple(lay.in_dims)
+            dpf = ar.alloc((N,) + fine + (lay.cin,), self.dtype)
+            lay.dgrad(g, N, dpf, accumulate=False)
+            low = tuple(n // 2 for n in fine)
+            gl = ar.alloc((N,) + low + (lay.cin,), self.dtype)
+            ops.concat_bwd(dpf, (N,) + fine, lay.cin, 0, gl, None, acc_low=False, acc_skip=False)
+            if i > 0:
+                kp, _, ap, stp = ctx['ups'][i - 1]
+                g = self._in_bwd(ar, gl, False, ap, stp, Nn[kp], ACT_RELU)
+            else:
+                g = gl                                                                  # gradient of the trunk's output (no pending transform)
+        # ---- residual blocks
+        h_in, st_in, key_in = ctx['trunk_in']
+        for j in range(RESNET_RES - 1, -1, -1):
+            k, s1, r1, n1, s2, r2, n2 = ctx['res'][j]
+            c1, c2 = L[k + '.c1'], L[k + '.c2']
+            d_r2 = self._in_bwd(ar, g, False, r2, n2, Nn[k + '.c2'], ACT_NONE)
+            c2.wgrad(s2, d_r2)
+            dp2 = ar.alloc((N,) + tuple(c2.buf_dims) + (c2.cin,), self.dtype)
+            c2.dgrad(d_r2, N, dp2, accumulate=False)
+            d_r1 = self._in_bwd(ar, dp2, True, r1, n1, Nn[k + '.c1'], ACT_RELU)
+            c1.wgrad(s1, d_r1)
+            dp1 = ar.alloc((N,) + tuple(c1.buf_dims) + (c1.cin,), self.dtype)
+            c1.dgrad(d_r1, N, dp1, accumulate=False)
+            # identity branch: g (the Add's gradient) + the folded data gradient of c1 = gradient of the block input's transformed value
+            ops.actnorm_bwd(dp1, True, None, (N,) + tuple(c1.in_dims), c1.cin, g, act=ACT_NONE, norm=False, accumulate=True)
+        g = self._in_bwd(ar, g, False, h_in, st_in, Nn[key_in], ACT_RELU)                # through down2's IN + ReLU + dropout
+        # ---- stride-2 stages, then the stem (weights only)
+        for (k, src, h_prev, st_prev, key_prev) in reversed(ctx['chain']):
+            lay = L[k]
+            lay.wgrad(src, g)
+            dp = ar.alloc((N,) + tuple(lay.buf_dims) + (lay.cin,), self.dtype)
+            lay.dgrad(g, N, dp, accumulate=False)
+            g = self._in_bwd(ar, dp, True, h_prev, st_prev, Nn[key_prev], ACT_RELU)
+        L['c7'].wgrad(ctx['c7'], g)
+        ar.release(mk, defer=True)
 
 
 # ======================================================================================================

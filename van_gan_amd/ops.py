@@ -469,7 +469,7 @@ class ConvLayer:
         """tap_subset (forward only): this object multiplies only the listed taps (indices into the k^3 raster order of the DHWIO
         kernel) -- a 7^3 convolution (343 taps, VG_MAX_TAPS is 64) is a chain of such chunks accumulating into one output
         (nets.ResNetGenerator's head, generator.py:68)."""
-        assert tap_subset is None or not need_dgrad
+        assert tap_subset is None or stride == 1            # (a chunk's data gradient: one output-parity class with the chunk's taps)
         self.dtype, self.f32 = dtype, int(dtype == torch.float32)
         self.ctor = dict(k=k, cin=cin, cout=cout, stride=stride, pad=pad, bias=bias, in_dims=tuple(in_dims), need_dgrad=need_dgrad)
         self.name, self.k, self.cin, self.cout, self.stride, self.pad, self.has_bias = name, k, cin, cout, stride, pad, bias
@@ -503,6 +503,14 @@ class ConvLayer:
             self.f_T, self.f_cin = T, cin
         T = self.f_T
         sub = list(range(T)) if tap_subset is None else [int(i) for i in tap_subset]
+        # weight gradient of a tap chunk: the chunk's taps are a contiguous run of the DHWIO tensor [tap][ci][co], so its dW is a
+        # contiguous slice of the gradient buffer (the partial-slab path sums whole [T][ci][co] slabs: it must not see foreign taps)
+        self.gw_w, self.w_idx_host = self.gw, None
+        if tap_subset is not None:
+            assert sub == list(range(sub[0], sub[0] + len(sub))), 'tap_subset must be a contiguous run of taps'
+            per_tap = cin * cout
+            self.gw_w = self.gw.view(-1)[sub[0] * per_tap:(sub[0] + len(sub)) * per_tap]
+            self.w_idx_host = (C.c_int32 * len(sub))(*range(len(sub)))
         self.f_idx_host = (C.c_int32 * T)(*sub)
         self.f_idx = torch.tensor(sub, dtype=torch.int32, device=dev)
         # the wide layers run on the LDS-DMA family (vg_conv_dma.hip): the library says which, and with which channel panel; their
@@ -539,6 +547,8 @@ class ConvLayer:
                         for (a, oa) in td:
                             for (b, ob) in th:
                                 for (c, oc) in tw:
+                                    if tap_subset is not None and ((a * k + b) * k + c) not in sub:
+                                        continue
                                     taps.append((oa, ob, oc)); idx.append((a * k + b) * k + c)
                         self.d_classes.append(dict(off=(pd, ph, pw), iters=(nd, nh, nw), taps=taps, idx_list=idx))
             # the wide layers: ONE class-parallel launch of the LDS-DMA family over the zero-padded dY (every class a stride-1 walk)
@@ -752,12 +762,13 @@ class ConvLayer:
         sc = WGRAD_SCRATCH.get(key)
         if sc is None:
             sc = WGRAD_SCRATCH[key] = torch.empty(WGRAD_SCRATCH_ELEMS, dtype=torch.float32, device=dy.device)
-        check(lib.vg_conv3d_wgrad(C.byref(d), _p(dy), int(dy.dtype == torch.float32), self.f_idx_host, self.f_T,
-                                  _p(self.gw), _p(self.gb), _p(sc), sc.numel() * 4, s_), 'vg_conv3d_wgrad ' + self.name)
+        widx = self.f_idx_host if self.w_idx_host is None else self.w_idx_host
+        check(lib.vg_conv3d_wgrad(C.byref(d), _p(dy), int(dy.dtype == torch.float32), widx, self.f_T,
+                                  _p(self.gw_w), _p(self.gb), _p(sc), sc.numel() * 4, s_), 'vg_conv3d_wgrad ' + self.name)
         if e0 is not None:
             esz = 4 if self.f32 else 2
             vb = C.create_string_buffer(512)
-            _lib.lib.vg_conv3d_wgrad_variant(C.byref(d), int(dy.dtype == torch.float32), self.f_idx_host, self.f_T, sc.numel() * 4, vb, 512)
+            _lib.lib.vg_conv3d_wgrad_variant(C.byref(d), int(dy.dtype == torch.float32), widx, self.f_T, sc.numel() * 4, vb, 512)
             PROF.end('conv_wgrad', 2.0 * src.N * math.prod(self.out_dims) * self.cout * self.cin * self.k ** 3, e0,
                      src.N * esz * (math.prod(self.in_dims) * self.cin + math.prod(self.out_dims) * self.cout), vb.value.decode(), self.name)
 

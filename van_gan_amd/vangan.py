@@ -17,7 +17,8 @@ import torch
 
 from . import ops
 from .dist import GradSync
-from .nets import pair_ctx, PatchGAN, ParamStore, ResUNet, disc_param_specs, gen_param_specs, init_reference
+from .nets import (pair_ctx, PatchGAN, ParamStore, ResNetGenerator, ResUNet, disc_param_specs, gen_param_specs, init_reference,
+                   resnet_param_specs)
 from .ops import Arena
 
 RESULT_KEYS = ['total_IS_loss', 'total_SI_loss', 'D_I_loss', 'D_S_loss', 'gen_IS_loss', 'gen_SI_loss',
@@ -58,11 +59,14 @@ class VanGan:
                  lambda_reconstruction: float = 5.0, lambda_topology: float = 5.0, lr: float = 2e-4,
                  beta_1: float = 0.5, beta_2: float = 0.9, clipnorm: float = 100.0, layer_noise: float = 0.1,
                  dropout_rate: float = 0.2, skel_iters: int = 15, output_dir: Optional[str] = None,
-                 process_group=None, arena_bytes: Optional[int] = None, precision: str = 'bf16'):
+                 process_group=None, arena_bytes: Optional[int] = None, precision: str = 'bf16', generator: str = 'resUnet'):
         if not torch.cuda.is_available():
             raise RuntimeError('VanGan engine needs an MI355X (HIP device); there is no CPU fallback')
         if precision not in ('bf16', 'fp32'):
             raise ValueError("precision must be 'bf16' (product path) or 'fp32' (exact-parity mode)")
+        if generator not in ('resUnet', 'resnet'):
+            raise ValueError("generator must be 'resUnet' (default, vangan.py:113-123) or 'resnet' (vangan.py:88-97)")
+        self.generator = generator                # both generators of one engine have the same architecture
         self.precision = precision
         self.dtype = torch.bfloat16 if precision == 'bf16' else torch.float32
         self.device = torch.device(device)
@@ -94,11 +98,13 @@ class VanGan:
         self.rng_offset = 0                       # Philox counter; persisted in the checkpoint
         self.stores: Dict[str, ParamStore] = {}
         for i, name in enumerate(NETS):
-            st = ParamStore(gen_param_specs() if name.startswith('gen') else disc_param_specs(), self.device)
+            gspecs = gen_param_specs() if generator == 'resUnet' else resnet_param_specs()
+            st = ParamStore(gspecs if name.startswith('gen') else disc_param_specs(), self.device)
             init_reference(st, seed + i)
             self.stores[name] = st
-        self.gen_IS = ResUNet(self.stores['gen_IS'], self.dims, self.dtype)
-        self.gen_SI = ResUNet(self.stores['gen_SI'], self.dims, self.dtype)
+        GenNet = ResUNet if generator == 'resUnet' else ResNetGenerator
+        self.gen_IS = GenNet(self.stores['gen_IS'], self.dims, self.dtype)
+        self.gen_SI = GenNet(self.stores['gen_SI'], self.dims, self.dtype)
         self.disc_I = PatchGAN(self.stores['disc_I'], self.dims, self.dtype)
         self.disc_S = PatchGAN(self.stores['disc_S'], self.dims, self.dtype)
         self.nets = {'gen_IS': self.gen_IS, 'gen_SI': self.gen_SI, 'disc_I': self.disc_I, 'disc_S': self.disc_S}
@@ -177,6 +183,16 @@ class VanGan:
                 drop[k] = t
         return noise, drop
 
+    def _make_gen_drop(self, N: int, ar: Arena):
+        """Channel multipliers of the ResNet generator's SpatialDropout3D layers for one application (ResNetGenerator.DROP_RATES)."""
+        out = {}
+        for k, rate in ResNetGenerator.DROP_RATES.items():
+            t = ar.alloc((N, ResNetGenerator.DROP_CH[k]), torch.float32)
+            ops.dropout_mask(t, rate, self.drop_key + 31, self.rng_offset)
+            self.rng_offset += t.numel()
+            out[k] = t
+        return out
+
     def _join_updates(self):
         """Cross-step mode: the current stream waits for every optimizer step still queued (consumers outside train_step)."""
         if self._upd_ev and self._opt is not None:
@@ -243,10 +259,23 @@ class VanGan:
         # Both applications of a generator share 2B-sample tensors (Arena paired mode): the forward passes are B-sample launches on
         # the two sample halves, the backward runs ONE 2B-sample sweep per generator instead of two B-sample sweeps (half the
         # launches, twice the work per launch on the latency-bound deep levels, the weight gradients' slab writes once for both).
-        pair = do_backward and _PAIR_BWD
+        pair = do_backward and _PAIR_BWD and self.generator == 'resUnet'       # (the ResNet generator: one B-sample sweep per application)
+        gdrop = (drop or {}) if self.generator == 'resnet' else {}
         def fwd(gen, key, slot, x, y):
             """A generator application as a resumable enqueue sequence; its allocations go to the paired slot (key, slot)."""
-            it = gen.forward_iter(ar, x, y)
+            if self.generator == 'resnet':
+                # SpatialDropout3D of generator.py:44 / downsample(): per-application channel masks (training only); a test may hand
+                # them in as drop['G_IS.a'] ... (application names of oracle.compute_losses)
+                app = 'G_%s.%s' % (key[4:], 'ab'[slot])
+                if app in gdrop:
+                    gd = gdrop[app]
+                elif training and noise is None and self.dropout_rate > 0:
+                    gd = lambda: self._make_gen_drop(B, ar)           # drawn when the application is enqueued, on ITS lane's stream
+                else:
+                    gd = None
+                it = gen.forward_iter(ar, x, y, gd)
+            else:
+                it = gen.forward_iter(ar, x, y)
             if pair:
                 ar.pair_begin(key, slot); ar.pair_end()
             def steps():
@@ -588,7 +617,8 @@ class VanGan:
         with ops.Fp16():
             net = self._fp16_nets.get(gen)
             if net is None:
-                net = self._fp16_nets[gen] = ResUNet(self.stores[gen], self.dims, torch.float16)
+                GenNet = ResUNet if self.generator == 'resUnet' else ResNetGenerator
+                net = self._fp16_nets[gen] = GenNet(self.stores[gen], self.dims, torch.float16)
             net.pack()
         return net
 
