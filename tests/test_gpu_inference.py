@@ -78,3 +78,24 @@ def test_window_origins_follow_reference_loop():
     assert window_origins(306, 128, 50) == [0, 50, 100, 150, 178] and window_origins(152, 128, 50) == [0, 24]
     # clamped duplicates are kept (they are counted twice by pix_tracker, as in the reference)
     assert window_origins(128, 128, 25) == [0, 0]
+
+
+def test_stitch_subvolumes_with_the_resnet_generator():
+    """The same sliding-window path over an engine built with the ResNet generators."""
+    from van_gan_amd import VanGan
+    k = (32, 32, 32)
+    eng = VanGan(k, batch_size=4, device='cuda:0', seed=6, precision='fp32', generator='resnet')
+    P = eng.export_weights()['gen_IS']
+    g = torch.Generator().manual_seed(4)
+    vol = torch.rand(56, 48, 40, 1, generator=g) * 2 - 1
+
+    def gen(a):
+        with torch.no_grad():
+            return O.resnet_forward(P, torch.from_numpy(np.ascontiguousarray(a)).float()).numpy()
+
+    ref = S.stitch_subvolumes(gen, vol.numpy(), (1,) + k + (1,), stride=(20, 20, 16), complete=True, padFactor=0.25, process_img=True)
+    got = eng.stitch_subvolumes('gen_IS', vol, k, stride=(20, 20, 16), complete=True, padFactor=0.25, process_img=True,
+                                window_batch=3).cpu().numpy()
+    err = np.abs(got - ref).max()
+    print('stitch (resnet generator) max abs err (0..255 scale): %.4f' % err)
+    assert got.shape == ref.shape and err < 0.05

@@ -592,7 +592,7 @@ class ResNetGenerator:
             self._ptab = ops.PackTable(list(self.L.values()) + self.head, self.store.w.device)
         self._ptab.run()
 
-    def forward(self, ar: Arena, x: torch.Tensor, y: torch.Tensor, drop: Optional[dict] = None) -> dict:
+    def forward(self, ar: Arena, x: torch.Tensor, y: torch.Tensor, drop: Optional[dict] = None, save: bool = True) -> dict:
         """x: fp32 [N,D,H,W,1]; y: fp32 [N,D,H,W,1] output (tanh).  drop: SpatialDropout3D multipliers [N,C] for 'c7' and
         'down0..2' (training=True behaviour), None = inference.  Returns the stored tensors (taps) for the parity tests."""
         drop = drop or {}
