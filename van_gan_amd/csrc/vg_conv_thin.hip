@@ -50,10 +50,32 @@ __device__ __forceinline__ void lds_only_barrier() { asm volatile("s_waitcnt lgk
 // workgroups per CU there is little else to run under them.  Skipping the staging altogether took 27 % off the 16 -> 16 layer;
 // skipping the MFMAs nothing.)  Only the raw data stay in registers across the loop: commit re-reads the table words it needs.
 struct ThinItem { int hoff, cg; bool cv; const char* pc; const int* dt; };
+// Axis tables of the WHOLE grid, built once per workgroup (thin_axis_tables): per source (src0, then src1) the byte offsets (or -1) of
+// every H, W and D position a tile of this launch can touch -- entry (o0 + j) of an axis is halo position j of the tile with origin o0.
+// (The per-tile tables of the lean routine cost 157 vector instructions per tile on three of the four waves: a sixth of a tile's vector
+// work in a kernel that is bound by exactly that)
+struct ThinTab { const int* tab; int AL, NH, NW, od0, oh0, ow0; };
+__device__ __forceinline__ void thin_axis_tables(const GatherIn& g, int* tab, int NH, int NW, int ND, int tid) {
+    const int AL = NH + NW + ND, sh = g.shift0;
+    for (int i = tid; i < 2 * AL; i += 256) {
+        const int set = i >= AL ? 1 : 0, j = i - set * AL;
+        if (set == 1 && g.c1 == 0) { tab[i] = -1; continue; }
+        const int axis = j < NH ? 1 : (j < NH + NW ? 2 : 0);                              // 1 H, 2 W, 0 D
+        const int jj = axis == 1 ? j : (axis == 2 ? j - NH : j - NH - NW);
+        const int n_ax = axis == 1 ? g.H : (axis == 2 ? g.W : g.D);
+        int p = (axis == 1 ? g.tmin_h : (axis == 2 ? g.tmin_w : g.tmin_d)) + jj;
+        const bool valid = resolve_pos(p, n_ax, g.pad_mode);
+        long off;
+        if (set == 0) {
+            const int ps = p >> sh, Ws = g.W >> sh, Hs = g.H >> sh;
+            off = axis == 1 ? (long)ps * Ws * g.c0 : (axis == 2 ? (long)ps * g.c0 : (long)ps * Hs * Ws * g.c0);
+        } else off = axis == 1 ? (long)p * g.W * g.c1 : (axis == 2 ? (long)p * g.c1 : (long)p * g.H * g.W * g.c1);
+        tab[i] = valid ? (int)(off * 2) : -1;
+    }
+}
 template <bool PLAIN>
-__device__ __forceinline__ ThinItem thin_item(const GatherIn& g, const int* ctab, const int* rt, const char* b0, const char* b1, int chunk, int item) {
+__device__ __forceinline__ ThinItem thin_item(const GatherIn& g, const int* ctab, const ThinTab& tt, const char* b0, const char* b1, int chunk, int item) {
     constexpr int NCOLS = HH * HW * 2, SEGL = HD / 2;
-    const int L = stage_axis_len3(g);
     ThinItem t;
     const int seg = item >= NCOLS ? 1 : 0, col = item - seg * NCOLS;
     const int e = ctab[2 * col];
@@ -62,15 +84,15 @@ __device__ __forceinline__ ThinItem thin_item(const GatherIn& g, const int* ctab
     t.cg = e >> 20;
     const int c = chunk * 16 + t.cg * 8;
     const bool from0 = c < g.c0;
-    const int* rs = rt + (from0 ? 0 : L);
-    const int oh = rs[hh], ow = rs[HH + hw];
+    const int* rs = tt.tab + (from0 ? 0 : tt.AL);
+    const int oh = rs[tt.oh0 + hh], ow = rs[tt.NH + tt.ow0 + hw];
     t.cv = !PLAIN || (c < g.Cin && (oh | ow) >= 0);
     t.pc = t.cv ? (from0 ? b0 + (size_t)c * 2 : b1 + (size_t)(c - g.c0) * 2) + (oh + ow) : b0;          // invalid columns read a dummy, then zero
-    t.dt = rs + HH + HW + seg * SEGL;
+    t.dt = rs + tt.NH + tt.NW + tt.od0 + seg * SEGL;
     return t;
 }
 template <int MODE>
-__device__ __forceinline__ void thin_issue(const GatherIn& g, const int* ctab, const int* rt, int n, int chunk, int tid, Raw8<bf16_t> (&raw)[3][HD / 2]) {
+__device__ __forceinline__ void thin_issue(const GatherIn& g, const int* ctab, const ThinTab& rt, int n, int chunk, int tid, Raw8<bf16_t> (&raw)[3][HD / 2]) {
     typedef bf16_t T;
     constexpr int NITEMS = 4 * HH * HW, SEGL = HD / 2;
     const int sh = g.shift0;
@@ -87,7 +109,7 @@ __device__ __forceinline__ void thin_issue(const GatherIn& g, const int* ctab, c
     }
 }
 template <int MODE>
-__device__ __forceinline__ void thin_commit(const GatherIn& g, char* halo, const float* scs, const int* ctab, const int* rt, int chunk, int tid,
+__device__ __forceinline__ void thin_commit(const GatherIn& g, char* halo, const float* scs, const int* ctab, const ThinTab& rt, int chunk, int tid,
                                             Raw8<bf16_t> (&raw)[3][HD / 2]) {
     typedef bf16_t T;
     constexpr bool plain = MODE == VG_STAGE_PLAIN;
@@ -149,9 +171,9 @@ __global__ __launch_bounds__(256, VG_THIN_WPE) void conv_thin_kernel(const Gathe
     int* tapb = (int*)(stat + 32 * NP);
     int* utab = tapb + 32;
     constexpr int NCOLS = HH * HW * 2;
-    int* rtab = utab + 2 * NCOLS;
-    const int RTN = 3 * stage_axis_len3(g);
-    char* wlds = (char*)(rtab + 2 * RTN);
+    int* xtab = utab + 2 * NCOLS;                        // axis tables of the whole grid (thin_axis_tables)
+    const int NHt = g.tiles_h * TH + 2, NWt = g.tiles_w * TW + 2, NDt = g.tiles_d * TD + 2;
+    char* wlds = (char*)(xtab + 2 * (NHt + NWt + NDt));
     wlds = (char*)(((size_t)wlds + 15) & ~(size_t)15);
     const int Ktot = p.Ktot, nchunks = p.nchunks;
     constexpr int WRS = KCPAD * 2 + 16;                  // LDS row stride of the chunk panel (16 bytes of padding: bank spread)
@@ -229,8 +251,9 @@ __global__ __launch_bounds__(256, VG_THIN_WPE) void conv_thin_kernel(const Gathe
     int ti_w, ti_h, ti_d;
     { int t = t0; ti_w = t % g.tiles_w; t /= g.tiles_w; ti_h = t % g.tiles_h; ti_d = t / g.tiles_h; }
     if (nchunks == 1) stage_scale_shift(g, scs, n, 0, tid);
-    if (t0 < tend) stage_resolve_axes3(g, rtab, ti_d * TD, ti_h * TH, ti_w * TW, tid);
+    thin_axis_tables(g, xtab, NHt, NWt, NDt, tid);
     lds_only_barrier();
+    auto tabat = [&](int od0_, int oh0_, int ow0_) { return ThinTab{xtab, NHt + NWt + NDt, NHt, NWt, od0_, oh0_, ow0_}; };
     int boff[KSTEPS];
     {
         const int rowbase = wave * DSB + li * UNIT;                      // sub-tile 0 of this wave's plane, this lane's voxel
@@ -248,7 +271,7 @@ __global__ __launch_bounds__(256, VG_THIN_WPE) void conv_thin_kernel(const Gathe
     // the BSTAT one sits at the register cap and spilled the nine units): they load, then commit, back to back.
     constexpr bool PF = MODE == VG_STAGE_RELU && (NP == 1 || VG_THIN_PF2);
     Raw8<T> raw[3][HD / 2];
-    if (PF && t0 < tend) thin_issue<MODE>(g, utab, rtab, n, 0, tid, raw);
+    if (PF && t0 < tend) thin_issue<MODE>(g, utab, tabat(ti_d * TD, ti_h * TH, ti_w * TW), n, 0, tid, raw);
     for (int tile = t0; tile < tend; tile += tstep, ++it) {
         const int od0 = ti_d * TD, oh0 = ti_h * TH, ow0 = ti_w * TW;
         ti_w += gs_w; if (ti_w >= g.tiles_w) { ti_w -= g.tiles_w; ++ti_h; }
@@ -263,14 +286,13 @@ __global__ __launch_bounds__(256, VG_THIN_WPE) void conv_thin_kernel(const Gathe
         for (int chunk = 0; chunk < nchunks; ++chunk) {
             if (it | chunk) lds_only_barrier();                            // previous readers of the halo image / weight panel are done
             if (nchunks > 1) { stage_scale_shift(g, scs, n, chunk, tid); if (it | chunk) load_weights(chunk); lds_only_barrier(); }
-            if (!PF) thin_issue<MODE>(g, utab, rtab + (it & 1) * RTN, n, chunk, tid, raw);
-            thin_commit<MODE>(g, halo, scs, utab, rtab + (it & 1) * RTN, chunk, tid, raw);
-            if (chunk == 0 && more) stage_resolve_axes3(g, rtab + ((it + 1) & 1) * RTN, ti_d * TD, ti_h * TH, ti_w * TW, tid);
+            if (!PF) thin_issue<MODE>(g, utab, tabat(od0, oh0, ow0), n, chunk, tid, raw);
+            thin_commit<MODE>(g, halo, scs, utab, tabat(od0, oh0, ow0), chunk, tid, raw);
             lds_only_barrier();
-            // the next (tile, chunk)'s loads go out now and land under the MFMA loop (its axis tables were published by the barrier above)
+            // the next (tile, chunk)'s loads go out now and land under the MFMA loop
             if (PF) {
-                if (chunk + 1 < nchunks) thin_issue<MODE>(g, utab, rtab + (it & 1) * RTN, n, chunk + 1, tid, raw);
-                else if (more) thin_issue<MODE>(g, utab, rtab + ((it + 1) & 1) * RTN, n, 0, tid, raw);
+                if (chunk + 1 < nchunks) thin_issue<MODE>(g, utab, tabat(od0, oh0, ow0), n, chunk + 1, tid, raw);
+                else if (more) thin_issue<MODE>(g, utab, tabat(ti_d * TD, ti_h * TH, ti_w * TW), n, 0, tid, raw);
             }
             // ---- MFMA loop: 14 K-steps x 8 sub-tiles x NP panels, every address an immediate, the fragments of the next K-step in flight
             const char* wb = wlds + wbase;
@@ -452,7 +474,8 @@ __global__ __launch_bounds__(256, VG_THIN_WPE) void conv_thin_kernel(const Gathe
 // host side
 // ------------------------------------------------------------------------------------------------
 int vg_conv_thin_lds_bytes(const GatherIn& g, int np) {
-    return HALO + (32 + 32 * np + 32) * 4 + (2 * HH * HW * 2 + 6 * stage_axis_len3(g)) * 4 + 16 + 16 * np * (KCPAD * 2 + 16);
+    const int AL = (g.tiles_h * TH + 2) + (g.tiles_w * TW + 2) + (g.tiles_d * TD + 2);          // axis tables of the whole grid, two sources
+    return HALO + (32 + 32 * np + 32) * 4 + (2 * HH * HW * 2 + 2 * AL) * 4 + 16 + 16 * np * (KCPAD * 2 + 16);
 }
 
 // Does this launch have the one shape the specialist serves?  (g from fill_gather for a 512-voxel tile; np: 16-channel panels per workgroup)
