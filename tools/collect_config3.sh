@@ -19,7 +19,7 @@ rm -rf $O/stats $O/fetch $O/write $O/mfma
 cp $O/kernel_stats.csv $R/profiles/${tag}_config3_kernel_stats.csv; cp $O/hbm_pmc.json $R/profiles/${tag}_config3_hbm_pmc.json
 cp $O/mfma_pmc.json $R/profiles/${tag}_config3_mfma_pmc.json; cp $O/bench_line.json $R/profiles/${tag}_config3_line.json
 cp $R/profiles/${tag}_config3_* $O/ 2>/dev/null
-cut -c1-400 $O/bench_line.json; tail -3 $O/hbm_pmc.log $O/mfma_pmc.log
+cut -c1-400 $O/bench_line.json
 python3 - <<PY
 import json
 for f in ('$R/profiles/${tag}_config3_hbm_pmc.json', '$R/profiles/${tag}_config3_mfma_pmc.json'):
