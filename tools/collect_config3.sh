@@ -18,8 +18,6 @@ cp $(find $O/stats -name '*kernel_stats.csv' | head -1) $O/kernel_stats.csv
 rm -rf $O/stats $O/fetch $O/write $O/mfma
 cp $O/kernel_stats.csv $R/profiles/${tag}_config3_kernel_stats.csv; cp $O/hbm_pmc.json $R/profiles/${tag}_config3_hbm_pmc.json
 cp $O/mfma_pmc.json $R/profiles/${tag}_config3_mfma_pmc.json; cp $O/bench_line.json $R/profiles/${tag}_config3_line.json
-cp $R/profiles/${tag}_config3_* $O/ 2>/dev/null
-cut -c1-400 $O/bench_line.json
 python3 - <<PY
 import json
 for f in ('$R/profiles/${tag}_config3_hbm_pmc.json', '$R/profiles/${tag}_config3_mfma_pmc.json'):
@@ -27,3 +25,5 @@ for f in ('$R/profiles/${tag}_config3_hbm_pmc.json', '$R/profiles/${tag}_config3
     j['workload'] = 'BASELINE config 3: VanGan.train_step, 128x128x64 volumes, batch 2, bf16, clDice on (bench.py --dims 128 128 64 --batch 2); read that for the "(128^3, batch 1)" of the note'
     json.dump(j, open(f, 'w'), indent=1)
 PY
+cp $R/profiles/${tag}_config3_* $O/ 2>/dev/null
+cut -c1-400 $O/bench_line.json
