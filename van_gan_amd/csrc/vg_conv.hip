@@ -1002,13 +1002,13 @@ static int conv3d_impl(const vg_conv_desc* d, vg_stream_t stream, bool& did_stat
         GatherIn g2;
         if (fill_gather(d, g2, 16, 512) == VG_OK && vg_conv_thin_ok(d, g2, k, q, 2)) {
             const int trc = vg_launch_conv_thin(g2, k, 2, s, d->bstat ? d->bstat->red : nullptr, did_stats);
-            if (trc <= 0) return trc;
+            if (trc <= 0 && trc != VG_ELDS) return trc;      // (its whole-grid axis tables do not fit the LDS on an enormous grid: the gather kernels serve it)
         }
     }
     { GatherIn g2; int bn2, ms2, lds2; if (plan_conv32(d, k, q, g2, bn2, ms2, lds2) == VG_OK) return launch_conv32(g2, k, q, bn2, ms2, lds2, s); }
     if (!d->f32 && MSUB == 8 && BN == 16 && vg_conv_thin_ok(d, g, k, q, 1)) {
         const int trc = vg_launch_conv_thin(g, k, 1, s, d->bstat ? d->bstat->red : nullptr, did_stats);
-        if (trc <= 0) return trc;
+        if (trc <= 0 && trc != VG_ELDS) return trc;
     }
     return d->f32 ? dispatch_conv<float>(g, k, q, BN, MSUB, lds, s) : dispatch_conv<bf16_t>(g, k, q, BN, MSUB, lds, s);
 }

@@ -537,8 +537,9 @@ int vg_launch_conv_thin(const GatherIn& g, const ConvOut& k, int np, hipStream_t
         if (np == 1 && red && k.bs_x0 && !k.bs_ml && k.bs_sc && k.bias == nullptr && k.res == nullptr && !st && (k.bs_c0 % 16) == 0 && (k.bs_c0 == k.Cout || k.bs_x1)
             && k.OD == k.BD && k.OH == k.BH && k.OW == k.BW && !k.ood && !k.ooh && !k.oow && vg_tune("CONV_BSTAT", 1)) {
             ConvOut k2 = k; k2.sums = red;                 // the IN-backward statistics take the place of the forward ones
-            did_stats = !vg_dry_on();
-            return launch_thin<VG_STAGE_PLAIN, false, false, false, true>(g, k2, np, s);
+            const int rc = launch_thin<VG_STAGE_PLAIN, false, false, false, true>(g, k2, np, s);
+            did_stats = rc == VG_OK && !vg_dry_on();
+            return rc;
         }
         if (k.bias == nullptr && k.res == nullptr && !st) return launch_thin<VG_STAGE_PLAIN, false, false, false>(g, k, np, s);
         if (k.bias != nullptr && k.res == nullptr) return st ? launch_thin<VG_STAGE_PLAIN, true, false, true>(g, k, np, s)
