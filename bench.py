@@ -81,7 +81,7 @@ def time_infer(eng, device, steps, warmup, precision):
             'generator_tflops': 50 * 2 * 149.65e9 / el / 1e12, 'windows': 50, 'steps': steps, 'finite': bool(torch.isfinite(out).all())}
 
 
-def time_config(dims, B, device, steps=3, warmup=3):
+def time_config(dims, B, device, steps=20, warmup=5):
     """BASELINE configs 2 and 3 beside the headline: a full train_step at another patch size / batch on a fresh engine
     (same kernels, same schedule, noise + dropout + clDice on), timed like the headline loop."""
     import torch

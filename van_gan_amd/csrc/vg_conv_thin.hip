@@ -491,9 +491,10 @@ bool vg_conv_thin_ok(const vg_conv_desc* d, const GatherIn& g, const ConvOut& k,
     for (int i = 0; i < 27; ++i)                                       // a full 3x3x3 stencil (any order)
         if (d->tap_d[i] - g.tmin_d > 2 || d->tap_h[i] - g.tmin_h > 2 || d->tap_w[i] - g.tmin_w > 2) return false;
     if (np > 1) {
-        // two panels per workgroup halve the workgroup count: only where the grid still fills the chip (the 32-channel layers at 64^3)
+        // two panels per workgroup halve the workgroup count: not below ~100 workgroups (threshold swept on BASELINE configs 2-4: 384 / 192 /
+        // 96 -> 64^3 batch 2: 9.53 / 9.47 / 9.40 ms per step, 128x128x64 batch 2: 21.32 / 21.20 / 21.22, 128^3: 19.42 / 19.52 / 19.35)
         const long wgs = (long)g.tiles_d * g.tiles_h * g.tiles_w * (d->Cout / (16 * np)) * d->N;
-        if (!vg_tune("CONV_THIN2", 1) || wgs < vg_tune("CONV_THIN2_MINWG", 384)) return false;
+        if (!vg_tune("CONV_THIN2", 1) || wgs < vg_tune("CONV_THIN2_MINWG", 96)) return false;
     }
     return true;
 }
