@@ -244,6 +244,16 @@ int vg_actnorm_bwd_stats(const vg_actnorm_bwd_desc* d, vg_stream_t stream);
 int vg_actnorm_bwd_apply(const vg_actnorm_bwd_desc* d, vg_stream_t stream);
 /* both passes in one call (statistics only when d->norm) */
 int vg_actnorm_bwd(const vg_actnorm_bwd_desc* d, vg_stream_t stream);
+/* The kernel gradient of a 1x1x1 convolution of a SINGLE-channel input x followed by InstanceNorm (no activation), WITHOUT the gradient
+ * of its output: the stem's shortcut (resunet_model.py:96-99; its input is the volume, so no data gradient exists).  Its output
+ * w[c]*x + b[c] normalises to xhat = w[c]*rstd*(x - mean x): the loss depends on w[c] only through eps in rstd, and
+ *     dL/dw[c] = sum_n eps * gamma[c] * rstd[n][c]^2 * (sum_v dn*xhat)[n][c] / w[c],        dL/db[c] = 0 identically,
+ * with sum_v dn*xhat the second moment of vg_actnorm_bwd_stats (red: [VG_STRIPES][N][C][2]).  Well conditioned where the explicit path
+ * (apply pass -> gradient tensor -> weight-gradient launch) sums a million cancelling terms.  w: the C kernel weights as the forward
+ * used them (round16 != 0: rounded to the library's 16-bit storage format first); adds dw[C]; dgamma / dbeta (optional) as the apply
+ * pass would add them. */
+int vg_in_scale_invariant_wgrad(const float* red, const float* rstd, const float* gamma, const float* w, int N, int C, float eps,
+                                int round16, float* dw, float* dgamma, float* dbeta, vg_stream_t stream);
 /* dgamma[c] += sum_{stripes,n} red[.][n][c][1], dbeta[c] += sum red[.][n][c][0] */
 int vg_in_param_grads(const float* red, int N, int C, float* dgamma, float* dbeta, vg_stream_t stream);
 

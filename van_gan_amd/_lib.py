@@ -80,6 +80,8 @@ _SIGS = {
     'vg_actnorm_bwd_stats': ([C.POINTER(ActNormBwdDesc), c_void_p], c_int),
     'vg_actnorm_bwd_apply': ([C.POINTER(ActNormBwdDesc), c_void_p], c_int),
     'vg_actnorm_bwd': ([C.POINTER(ActNormBwdDesc), c_void_p], c_int),
+    'vg_in_scale_invariant_wgrad': ([c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, C.c_float, c_int, c_void_p, c_void_p, c_void_p,
+                                    c_void_p], c_int),
     'vg_in_param_grads': ([c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p], c_int),
     'vg_concat_bwd': ([c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p], c_int),
     'vg_shortcut_dgrad_concat': ([C.POINTER(ConvDesc), c_void_p, c_void_p, c_int, c_int, c_void_p], c_int),

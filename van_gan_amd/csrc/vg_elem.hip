@@ -400,6 +400,30 @@ __global__ void in_param_grads_kernel(const float* red, int N, int C, float* dga
     for (int n = 0; n < N * VG_STRIPES; ++n) { a += red[((size_t)n * C + c) * 2]; b += red[((size_t)n * C + c) * 2 + 1]; }
     dbeta[c] += a; dgamma[c] += b;
 }
+__global__ void in_scale_invariant_wgrad_kernel(const float* red, const float* rstd, const float* gamma, const float* w, int N, int C,
+                                                float eps, int round16, float* dw, float* dgamma, float* dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float acc = 0.f, dg = 0.f, db = 0.f;
+    for (int n = 0; n < N; ++n) {
+        float r0 = 0.f, r1 = 0.f;
+        for (int t = 0; t < VG_STRIPES; ++t) { const float* r = red + (((size_t)t * N + n) * C + c) * 2; r0 += r[0]; r1 += r[1]; }
+        const float rs = rstd[n * C + c];
+        acc += rs * rs * r1;
+        db += r0; dg += r1;
+    }
+    const float wc = round16 ? bf2f(f2bf(w[c])) : w[c];
+    dw[c] += eps * gamma[c] * acc / wc;
+    if (dgamma) { dgamma[c] += dg; dbeta[c] += db; }
+}
+extern "C" int vg_in_scale_invariant_wgrad(const float* red, const float* rstd, const float* gamma, const float* w, int N, int C, float eps,
+                                           int round16, float* dw, float* dgamma, float* dbeta, vg_stream_t stream) {
+    vg_begin();
+    if (!red || !rstd || !gamma || !w || !dw || N < 1 || C < 1 || (dgamma && !dbeta)) return VG_EINVAL;
+    hipLaunchKernelGGL(in_scale_invariant_wgrad_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, red, rstd, gamma, w, N, C, eps,
+                       round16, dw, dgamma, dbeta);
+    return vg_check_launch();
+}
 extern "C" int vg_in_param_grads(const float* red, int N, int C, float* dgamma, float* dbeta, vg_stream_t stream) {
     vg_begin();
     if (!red || !dgamma || !dbeta || N < 1 || C < 1) return VG_EINVAL;

@@ -1025,6 +1025,13 @@ def actnorm_stats(d: ActNormBwdDesc):
     check(lib.vg_actnorm_bwd_stats(C.byref(d), stream()), 'vg_actnorm_bwd_stats')
 
 
+def in_scale_invariant_wgrad(red, rstd, gamma, w, N, C_, dw, dgamma=None, dbeta=None, round16=True):
+    """Kernel gradient of a single-channel 1x1x1 convolution in front of an InstanceNorm from the norm's backward statistics alone
+    (vg_in_scale_invariant_wgrad); adds dgamma / dbeta too -- no apply pass, no gradient tensor, no weight-gradient launch."""
+    check(lib.vg_in_scale_invariant_wgrad(_p(red), _p(rstd), _p(gamma), _p(w), N, C_, IN_EPS, int(round16), _p(dw), _p(dgamma), _p(dbeta),
+                                          stream()), 'vg_in_scale_invariant_wgrad')
+
+
 def actnorm_set_dx(d: ActNormBwdDesc, dx: torch.Tensor):
     d.dx, d.dx_f32 = _p(dx), int(dx.dtype == torch.float32)
     d._keep = d._keep + (dx,)
