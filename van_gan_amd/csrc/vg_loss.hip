@@ -526,7 +526,9 @@ __global__ __launch_bounds__(256) void skel_bwd_local_kernel(const float* __rest
     }
 }
 // part 2: d img_j += erode^T(d img_{j+1})
-__global__ __launch_bounds__(256) void erode_bwd_kernel(const float* __restrict__ imgj, const float* __restrict__ dimgj1,
+// (dimgj1 is consumed: every element is read by exactly one thread, which leaves a zero behind -- the buffer is the NEXT iteration's
+// accumulator, and the memset launch between two iterations sat on lane B's dependent chain)
+__global__ __launch_bounds__(256) void erode_bwd_kernel(const float* __restrict__ imgj, float* __restrict__ dimgj1,
                                                         int D, int H, int W, float* dimgj) {
     __shared__ float t[SK_TD + 2][SK_TH + 2][SK_TW + 2];
     const int tid = threadIdx.x;
@@ -540,6 +542,7 @@ __global__ __launch_bounds__(256) void erode_bwd_kernel(const float* __restrict_
         const size_t i = vol + ((size_t)gd * H + gh) * W + gw;
         const float g = dimgj1[i];
         if (g == 0.f) continue;
+        dimgj1[i] = 0.f;
         float best = INFINITY; int o = 0;
 #define SK_ER(a, b, c) { const float v = t[z + 1 + (a)][ty + 1 + (b)][tx + 1 + (c)]; if (v < best) { best = v; o = ((a) * H + (b)) * W + (c); } }
 #pragma unroll
@@ -574,10 +577,7 @@ extern "C" int vg_soft_skel_bwd(const float* imgs, const float* skels, const flo
         hipLaunchKernelGGL(skel_bwd_local_kernel, grid, dim3(256), 0, s, imgs + j * n, imgs + (j + 1) * n,
                            j ? skels + (j - 1) * n : (const float*)nullptr, D, H, W, gs, bufB, bufA);
         hipLaunchKernelGGL(erode_bwd_kernel, grid, dim3(256), 0, s, imgs + j * n, bufA, D, H, W, bufB);
-        if (j > 0) {
-            if (hipMemsetAsync(bufA, 0, n * sizeof(float), s) != hipSuccess) return VG_ELAUNCH;
-            float* t = bufA; bufA = bufB; bufB = t;
-        }
+        if (j > 0) { float* t = bufA; bufA = bufB; bufB = t; }          // (bufA was zeroed by erode_bwd_kernel as it was read)
     }
     // bufB = d img_0
     return vg_axpby(bufB, 1.f, nullptr, 0.f, n, gimg, 1, stream);
