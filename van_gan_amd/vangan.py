@@ -26,7 +26,7 @@ RESULT_KEYS = ['total_IS_loss', 'total_SI_loss', 'D_I_loss', 'D_S_loss', 'gen_IS
 _BFIRST = int(os.environ.get('VG_BFIRST', '5'))       # re-swept with the paired sweeps: 0: 22.27, 4: 21.98, 5: 21.83 ms
 _NOJOIN = os.environ.get('VG_NOJOIN', '1') != '0'
 _LAZY_AR = os.environ.get('VG_LAZY_AR', '1') != '0'
-_INLINE = int(os.environ.get('VG_WGRAD_INLINE', '3'))      # encoder blocks <= this and the stem; sweep with the DMA weight gradients: off 24.96, 1: 24.92, 2: 24.74, 3: 24.59, 4: 24.62 ms
+_INLINE = int(os.environ.get('VG_WGRAD_INLINE', '2'))      # encoder blocks <= this and the stem; round 3 (DMA weight gradients): off 24.96, 1: 24.92, 2: 24.74, 3: 24.59, 4: 24.62 ms; round 4, final kernels, alternating: 2: 18.85 / 18.88 / 18.87, 3: 18.99 / 18.91 / 19.01
 _PAIR_BWD = os.environ.get('VG_PAIR_BWD', '1') != '0'       # one 2B-sample backward sweep per generator (both applications) instead of two
 _AR_SPLIT = os.environ.get('VG_AR_SPLIT', '1') != '0'       # world > 1: a generator's finished gradient suffix is all-reduced while its sweep still runs
 _INTERLEAVE = os.environ.get('VG_INTERLEAVE', '0') != '0'   # the two lanes' enqueue sequences alternate block by block on the host: measured neutral (21.69 vs 21.63 ms), off
