@@ -107,6 +107,72 @@ def time_config(dims, B, device, steps=20, warmup=5):
     return out
 
 
+def _timed_steps(eng, rI, rS, steps, warmup):
+    import torch
+    for _ in range(warmup):
+        eng.train_step(rI, rS, sync=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        eng.train_step(rI, rS, sync=(i == steps - 1))
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
+def ddp_fake_child(args):
+    """Child process of the N=1 line (`--ddp-fake`): BASELINE config 4's per-GPU workload with the DATA-PARALLEL schedule switched on
+    for one process (VG_FAKE_AR=1: communication on its stream, per-bucket events, early suffix pieces, cross-step optimizer overlap;
+    every all-reduce replaced by vg_local_exchange moving the same bytes, optionally held for a ring's duration) next to the plain
+    single-GPU schedule of the SAME process.  Prints {"ddp_fake": ...}."""
+    import torch
+    from van_gan_amd import VanGan
+    device = 'cuda:0'
+    torch.cuda.set_device(0)
+    dims, B = (args.size,) * 3, args.batch
+    rI, rS = synth_on_device(B, dims, 1234, device)
+    out = {'workload': 'VanGan.train_step %dx%dx%d batch %d, one process' % (dims + (B,)), 'steps': args.steps, 'warmup': args.warmup, 'legs': []}
+    os.environ['VG_FAKE_AR'] = '0'
+    eng = VanGan(dims, batch_size=B, device=device, seed=0)
+    plain = _timed_steps(eng, rI, rS, args.steps, args.warmup)
+    del eng
+    torch.cuda.empty_cache()
+    os.environ['VG_FAKE_AR'] = '1'
+    for gbps in (0.0, 150.0):
+        os.environ['VG_FAKE_AR_GBPS'] = str(gbps)
+        eng = VanGan(dims, batch_size=B, device=device, seed=0)
+        eng.broadcast_weights(0)
+        ms = _timed_steps(eng, rI, rS, args.steps, args.warmup)
+        n = args.steps + args.warmup
+        out['legs'].append({'ring_bus_GBps_emulated': gbps or None, 'ms_per_step': ms, 'delta_ms': ms - plain,
+                            'moved_MB_per_step': eng.sync.moved_bytes / n / 1e6, 'workgroups': eng.sync._wg,
+                            'comm_stream': 'optimizer stream' if eng.sync.stream is eng._opt else 'own stream',
+                            'xstep': bool(eng._xstep)})
+        del eng
+        torch.cuda.empty_cache()
+    out['plain_ms_per_step'] = plain
+    out['ms_per_step'] = out['legs'][-1]['ms_per_step']
+    out['delta_ms'] = out['legs'][-1]['delta_ms']
+    out['note'] = ('world == 1: GradSync runs the real data-parallel schedule with vg_local_exchange in place of ncclAllReduce (include/vangan_hip.h); '
+                   'ms_per_step / delta_ms are the leg whose exchange kernels hold their stream for the duration of an 8-GPU ring at 150 GB/s bus bandwidth; '
+                   'RCCL itself has not run')
+    print(json.dumps({'ddp_fake': out}))
+
+
+def ddp_fake(args):
+    """Run ddp_fake_child in a fresh process (its streams are created in the data-parallel order) and return its object."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), '--ddp-fake', '--steps', str(args.steps), '--warmup', str(args.warmup),
+           '--size', str(args.size), '--batch', str(args.batch)]
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    except subprocess.TimeoutExpired:
+        return {'error': 'timeout'}
+    for line in r.stdout.decode(errors='replace').splitlines():
+        if line.startswith('{"ddp_fake"'):
+            return json.loads(line)['ddp_fake']
+    return {'error': 'rc %d: %s' % (r.returncode, r.stderr.decode(errors='replace')[-800:])}
+
+
 def bench_infer(args, device):
     import torch  # noqa: F401
     from van_gan_amd import VanGan
@@ -151,7 +217,11 @@ def main():
     ap.add_argument('--no-configs', action='store_true', help='skip the configs array (BASELINE configs 2 and 3) of the default N=1 line')
     ap.add_argument('--no-synced', action='store_true', help='skip the second timed loop that reads the 10 result scalars every step')
     ap.add_argument('--no-infer', action='store_true', help='skip the inference object (config 5) of the default N=1 line')
+    ap.add_argument('--no-ddp-path', action='store_true', help='skip the ddp_path object (the data-parallel schedule with a stand-in all-reduce, in a child process) of the default N=1 line')
+    ap.add_argument('--ddp-fake', action='store_true', help='(child mode of ddp_path) time the data-parallel schedule on one GPU with vg_local_exchange in place of the all-reduce')
     args = ap.parse_args()
+    if args.ddp_fake:
+        return ddp_fake_child(args)
 
     import torch
     import torch.distributed as dist
@@ -288,7 +358,7 @@ def main():
         if byvar:
             # the single kernel template with the most time in the step, by itself (the family figure above averages ~70
             # templates): algorithmic FLOPs of ITS launches / ITS summed HIP-event durations
-            dom = byvar[0]
+            dom = byvar[0]                 # rows are keyed by the rocprof kernel template (run-time regimes of one template summed)
             roof['dominant_kernel'] = {'kernel': dom['kernel'], 'kind': dom['kind'], 'launches_per_step': dom['launches'],
                                        'ms_per_step': dom['ms'], 'avg_launch_ms': dom['ms'] / dom['launches'],
                                        'achieved': dom['tflops'], 'frac': dom['tflops'] / PEAK_BF16_TFLOPS,
@@ -305,6 +375,9 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
+    ddp = None
+    if rank == 0 and world == 1 and args.size == 128 and not args.no_ddp_path:
+        ddp = ddp_fake(args)
 
     if world > 1:
         dist.barrier()
@@ -318,7 +391,7 @@ def main():
                                    % (dims + (B, gbatch)), 'parallelism': 'dp%d' % world},
             'ms_per_step_synced': ms_synced, 'configs': configs,
             'losses': res, 'roofline': roof, 'cpu_baseline': cpu, 'inference': infer,
-            'arena_peak_gb': eng.arena.peak / 1e9,
+            'arena_peak_gb': eng.arena.peak / 1e9, 'ddp_path': ddp,
         }
         print(json.dumps(out))
     if world > 1:

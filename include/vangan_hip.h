@@ -186,6 +186,11 @@ int vg_pack_weights_multi(const vg_pack_item* items_dev, int n, int total_blocks
  * vg_pack_weights_dma: fp32 DHWIO [T][Cin][Cout] -> bf16 [rows / bn][contraction / 16][tap][8-channel half][bn rows][8], rows =
  * output channels (transpose 0) or input channels (transpose 1, data gradient); rows * contraction * ntaps elements. */
 int vg_conv3d_dma_bn(const vg_conv_desc* d);
+/* Bytes of vg_conv_desc::scratch with which a call whose weights are in the block layout (wlayout != 0) runs at its preferred plan:
+ * counters + the materialised operand -- which grows with d->N, the one thing the shape-only query above cannot see -- + the partial
+ * tiles of its K split.  A smaller scratch drops the K split first; one that cannot hold the operand makes vg_conv3d return VG_EINVAL
+ * (block-layout weights have no other kernel).  0 for every other descriptor.  The caller sizes / grows its workspace with this. */
+int64_t vg_conv3d_scratch_bytes(const vg_conv_desc* d);
 int vg_pack_weights_dma(const float* w, int T, int Cin, int Cout, const int32_t* tap_idx_dev, int ntaps, int transpose, int bn,
                         void* out, vg_stream_t stream);
 int vg_packed_ktot(int ntaps, int C, int CK);
@@ -355,6 +360,14 @@ int vg_divide_crop(const float* pred, const float* cnt, int X, int Y, int Z, int
 int vg_adam_clip(float* w, const float* g, float* m, float* v, const int64_t* seg_off_dev, int T,
                  int64_t total, float* norms, float lr_t, float beta1, float beta2, float eps,
                  float clipnorm, float grad_scale, vg_stream_t stream);
+
+/* Stand-in for the RCCL SUM all-reduce of a gradient bucket (the implicit all-reduce of optimizer.minimize under MirroredStrategy,
+ * vangan.py:426-438; main.py:22) on a box with ONE GPU, so that the data-parallel schedule -- communication stream, per-bucket
+ * events, early suffix pieces, cross-step optimizer overlap -- can be timed without a second device: `workgroups` workgroups (RCCL
+ * channels) move buf[0, n) to scratch and back (2 x 4n bytes read + written, buf ends bit-identical; n a multiple of 4, both
+ * pointers 16-byte aligned) and then hold their CUs until min_us microseconds of wall clock have passed since they started (the
+ * time a ring over xGMI would take for the message; 0: none).  Never part of a real multi-GPU run. */
+int vg_local_exchange(float* buf, float* scratch, int64_t n, int workgroups, int min_us, vg_stream_t stream);
 
 /* N(0,std) noise as bf16 and SpatialDropout3D channel masks {0,1/(1-rate)} (fp32), counter-based RNG */
 int vg_randn_bf16(void* out, int64_t n, float std, uint64_t seed, uint64_t offset, vg_stream_t stream);

@@ -311,3 +311,47 @@ def run_recipe(recipe, expect_variant, dev, seed=1, precision='bf16'):
     if prior is not None:
         ref = ref + prior.to(dt)
     close_bf16(dp, ref, 'data gradient', rel=2.5e-2, floor=6e-3)
+
+
+def stress_recipe(recipe, expect_variant, dev, launches=200, seed=3):
+    """K-split exchange under load: the recorded call `launches` times back to back, alternating between two streams (each with its
+    own output buffer; the library's per-stream scratch -- partial tiles + arrival counters -- is reused by every launch of a
+    stream), every output compared BITWISE with the first launch's.  The slices' partial tiles are added in slice order, so any
+    difference is a partial tile read before it was complete, or a counter that did not return to zero."""
+    L = recipe['layer']
+    kind = recipe['kind']
+    g = torch.Generator().manual_seed(seed)
+    st, lay = make_layer_from(L, dev)
+    lay.pack()
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    if kind == 'fwd':
+        sr = recipe['src']
+        src, _ = make_operand(sr, L['pad'], dev, g)
+        odt = torch.float32 if recipe['out_f32'] else torch.bfloat16
+        outs = [torch.zeros(sr['N'], *lay.out_dims, L['cout'], dtype=odt, device=dev) for _ in range(3)]
+        call = lambda o: lay.forward(src, o, tanh=recipe['tanh'])
+    else:
+        assert kind == 'dgrad' and not recipe['accumulate'] and not recipe.get('bstat')
+        N = recipe['N']
+        dy = torch.randn(N, *lay.out_dims, L['cout'], generator=g)
+        dys = (dy if recipe['dy_f32'] else dy.to(torch.bfloat16)).to(dev)
+        odt = torch.float32 if recipe['out_f32'] else torch.bfloat16
+        outs = [torch.zeros((N,) + tuple(lay.buf_dims) + (L['cin'],), dtype=odt, device=dev) for _ in range(3)]
+        call = lambda o: lay.dgrad(dys, N, o, accumulate=False)
+    got = dry_variants(lambda: call(outs[2]))
+    assert got == [expect_variant], (got, expect_variant)
+    call(outs[2])
+    torch.cuda.synchronize()
+    ref = outs[2].clone()
+    assert bool(torch.isfinite(ref.float()).all()) and float(ref.float().abs().max()) > 0
+    for s in streams:
+        s.wait_stream(torch.cuda.current_stream())
+    bad = 0
+    for i in range(launches):
+        with torch.cuda.stream(streams[i & 1]):
+            outs[i & 1].fill_(7.0)
+            call(outs[i & 1])
+            bad = bad + (outs[i & 1] != ref).sum()             # device-side count: no host sync between the launches
+    torch.cuda.synchronize()
+    bad = int(bad)
+    assert bad == 0, '%d elements differ from the first launch over %d launches on two streams' % (bad, launches)

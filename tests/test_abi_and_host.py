@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_exports_every_declared_symbol():
     from van_gan_amd import _lib
     hdr = open(os.path.join(ROOT, 'include', 'vangan_hip.h')).read()
-    declared = set(re.findall(r'^(?:int|const char\*)\s+(vg_[a-z0-9_]+)\s*\(', hdr, flags=re.M))
+    declared = set(re.findall(r'^(?:int|int64_t|const char\*)\s+(vg_[a-z0-9_]+)\s*\(', hdr, flags=re.M))
     assert len(declared) >= 30
     for name in sorted(declared):
         assert hasattr(_lib.lib, name), 'libvangan_hip.so does not export %s' % name
@@ -127,3 +127,36 @@ def test_conv_desc_scratch_fields_trail_the_struct():
     assert ConvDesc.scratch.offset == ConvDesc.bstat.offset + 8 and ConvDesc.scratch_bytes.offset == ConvDesc.scratch.offset + 8
     hdr = open(os.path.join(ROOT, 'include', 'vangan_hip.h')).read()
     assert int(re.search(r'#define VG_SCRATCH_CTR_BYTES (\d+)', hdr).group(1)) == SCRATCH_CTR_BYTES
+
+
+def test_dma_layers_plan_at_any_batch():
+    """the LDS-DMA layout is chosen per layer from the shape alone, its operand grows with the batch, and block-layout
+    weights have no other kernel -- with a fixed 160 MB workspace the PatchGAN's data gradients at 128^3 planned for batch 4 and
+    returned VG_EINVAL for batch 8.  The host now sizes the workspace per call from vg_conv3d_scratch_bytes: every batch plans."""
+    import ctypes as C
+    from van_gan_amd import ops
+    from van_gan_amd._lib import lib
+    from van_gan_amd.nets import ParamStore, PatchGAN, disc_param_specs
+    dims = (128, 128, 128)
+    D = PatchGAN(ParamStore(disc_param_specs(), 'cpu'), dims, torch.bfloat16)
+    for B in (1, 8):                                                  # 2B samples through the discriminator ([real; fake])
+        ar = ops.Arena(24 << 30, 'cpu')                              # never touched (dry runs do not write): virtual memory only
+        with ops.DryRun() as dry:
+            x2 = torch.empty((2 * B,) + dims + (1,))
+            lg = torch.empty((2 * B,) + tuple(n // 8 for n in dims) + (1,))
+            noise = {k: torch.empty(shp, dtype=torch.bfloat16) for k, shp in D.noise_shapes(2 * B).items()}
+            drop = {k: torch.empty(2 * B, c) for k, c in (('down0', 128), ('down1', 256), ('down2', 512))}
+            ctx = D.forward(ar, x2, lg, noise, drop)
+            D.backward(ar, ctx, lg, 0, 2 * B, wgrad=False, dx=torch.empty((2 * B,) + dims + (1,)))
+        dma = [v for k, _, v in dry.records if k == 'dgrad' and v.startswith('conv_dma')]
+        assert len(dma) == 3, dry.records
+    # and the query itself: grows with N, zero for classic-layout descriptors
+    lay = D.L['down2']
+    assert lay.d_bn
+    need = []
+    for N in (2, 16):
+        d = lay._fused_desc(None, N, None, False, probe=True, plan=False)
+        need.append(int(lib.vg_conv3d_scratch_bytes(C.byref(d))))
+    assert need[1] > need[0] > 16384
+    d.wlayout = 0
+    assert lib.vg_conv3d_scratch_bytes(C.byref(d)) == 0

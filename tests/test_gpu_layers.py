@@ -24,3 +24,21 @@ def test_layer_variant_matches_oracle(kv):
     r = _REPS[kv]
     LR.run_recipe(r['recipe'], kv[1], torch.device('cuda:0'))
 
+
+
+_KSPLIT = [kv for kv in _KEYS if (kv[1].startswith('conv_dma') and '|ks1|' in kv[1] and kv[0] == 'dgrad' and not _REPS[kv]['recipe']['accumulate']
+                                  and not _REPS[kv]['recipe'].get('bstat'))
+           or (kv[1].startswith('conv<') and kv[1].rsplit('|ks', 1)[-1] not in ('0', '1') and kv[0] == 'fwd')]
+
+
+def test_ksplit_cases_exist():
+    assert any(kv[1].startswith('conv_dma') for kv in _KSPLIT) and any(kv[1].startswith('conv<') for kv in _KSPLIT)
+
+
+@pytest.mark.parametrize('kv', _KSPLIT, ids=[_id(kv) for kv in _KSPLIT])
+def test_ksplit_exchange_is_bitwise_stable_under_load(kv):
+    """the K-split exchange (relaxed agent-scope stores + vmcnt(0) + workgroup barrier + relaxed ticket; the
+    last arriver reads with agent-scope loads and resets the counter; DESIGN 3.1 has the hardware argument) has no fence.  200
+    launches of every K-split variant of both families, alternating between two streams, must reproduce the first launch bit for bit."""
+    r = _REPS[kv]
+    LR.stress_recipe(r['recipe'], kv[1], torch.device('cuda:0'), launches=200)

@@ -70,6 +70,7 @@ _SIGS = {
     'vg_crop_augment': ([c_void_p] + [c_int] * 13 + [c_void_p, c_void_p], c_int),
     'vg_crop_max': ([c_void_p] + [c_int] * 10 + [c_void_p, c_void_p], c_int),
     'vg_conv3d_dma_bn': ([C.POINTER(ConvDesc)], c_int),
+    'vg_conv3d_scratch_bytes': ([C.POINTER(ConvDesc)], c_i64),
     'vg_pack_weights_dma': ([c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p], c_int),
     'vg_packed_ktot': ([c_int, c_int, c_int], c_int),
     'vg_packed_rows': ([c_int], c_int),
@@ -106,6 +107,7 @@ _SIGS = {
     'vg_axpby': ([c_void_p, c_float, c_void_p, c_float, c_i64, c_void_p, c_int, c_void_p], c_int),
     'vg_adam_clip': ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_i64, c_void_p, c_float, c_float,
                       c_float, c_float, c_float, c_float, c_void_p], c_int),
+    'vg_local_exchange': ([c_void_p, c_void_p, c_i64, c_int, c_int, c_void_p], c_int),
     'vg_randn_bf16': ([c_void_p, c_i64, c_float, c_u64, c_u64, c_void_p], c_int),
     'vg_dropout_mask': ([c_void_p, c_i64, c_float, c_u64, c_u64, c_void_p], c_int),
     'vg_f32_to_bf16': ([c_void_p, c_void_p, c_i64, c_void_p], c_int),

@@ -60,6 +60,19 @@ def build(force: bool = False, verbose: bool = False) -> str:
             fcntl.flock(lk, fcntl.LOCK_UN)
 
 
+def _obj_hash(src: str, defs) -> str:
+    """What an object file depends on: its source, every header / include file of csrc/, the public header, the flags."""
+    import hashlib
+    h = hashlib.sha256(' '.join(defs).encode())
+    deps = [os.path.join(CSRC, src)] + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if not f.endswith('.hip'))
+    deps.append(os.path.join(HERE, '..', 'include', 'vangan_hip.h'))
+    for d in deps:
+        h.update(os.path.basename(d).encode())
+        with open(d, 'rb') as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def _build_locked(verbose: bool) -> str:
     hipcc = _hipcc()
     procs = []
@@ -69,14 +82,23 @@ def _build_locked(verbose: bool) -> str:
         for s in SOURCES:
             o = os.path.join(HERE, 'build', tag + s.replace('.hip', '.o'))
             objs[lib].append(o)
+            oh = _obj_hash(s, defs)
+            try:                                  # incremental: an object whose inputs did not change is kept
+                with open(o + '.hash') as f:
+                    if os.path.exists(o) and f.read().strip() == oh:
+                        continue
+            except OSError:
+                pass
             cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17'] + defs + ['-c', os.path.join(CSRC, s), '-o', o]
             if verbose:
                 print(' '.join(cmd))
-            procs.append((tag + s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-    for s, p in procs:
+            procs.append((tag + s, o, oh, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for s, o, oh, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError('hipcc failed on %s:\n%s' % (s, out.decode()))
+        with open(o + '.hash', 'w') as f:
+            f.write(oh)
     for _, lib, _ in variants:
         tmp = lib + '.tmp.%d' % os.getpid()
         cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', tmp] + objs[lib]

@@ -136,3 +136,27 @@ extern "C" int vg_adam_clip(float* w, const float* g, float* m, float* v, const 
                        clipnorm, grad_scale);
     return vg_check_launch();
 }
+
+// ---- stand-in for the gradient all-reduce on a box with ONE GPU (vg_local_exchange, include/vangan_hip.h) ----
+// A workgroup owns a contiguous slice (as an RCCL channel does) and moves it twice: buf -> scratch, then scratch -> buf; the second
+// pass re-reads what the same lanes wrote, so no workgroup depends on another and buf ends bit-identical.  Afterwards every workgroup
+// holds its CU until min_ticks of the 100 MHz wall clock have passed since it started: the time a ring over xGMI would occupy the
+// communication stream and its channels' CUs for a message of that size.
+__global__ __launch_bounds__(256) void local_exchange_kernel(float* buf, float* scratch, int64_t n4, int64_t per_wg, long long min_ticks) {
+    const long long t0 = wall_clock64();
+    const int64_t lo = (int64_t)blockIdx.x * per_wg, hi = lo + per_wg < n4 ? lo + per_wg : n4;
+    f32x4* b4 = (f32x4*)buf; f32x4* s4 = (f32x4*)scratch;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) s4[i] = b4[i];
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) b4[i] = s4[i];
+    while (wall_clock64() - t0 < min_ticks) __builtin_amdgcn_s_sleep(32);
+}
+extern "C" int vg_local_exchange(float* buf, float* scratch, int64_t n, int workgroups, int min_us, vg_stream_t stream) {
+    vg_begin();
+    if (!buf || !scratch || n < 0 || (n & 3) || workgroups < 1 || workgroups > 1024 || min_us < 0 || min_us > 100000
+        || (((uintptr_t)buf | (uintptr_t)scratch) & 15)) return VG_EINVAL;
+    if (n == 0) return VG_OK;
+    const int64_t n4 = n / 4, per_wg = (n4 + workgroups - 1) / workgroups;
+    hipLaunchKernelGGL(local_exchange_kernel, dim3(workgroups), dim3(256), 0, (hipStream_t)stream, buf, scratch, n4, per_wg,
+                       (long long)min_us * 100);
+    return vg_check_launch();
+}

@@ -503,6 +503,30 @@ extern "C" int vg_conv3d_dma_bn(const vg_conv_desc* d) {
     return cd_plan(d, pl);
 }
 
+// Workspace with which this family runs d at its preferred plan: counters + materialised operand (a function of d->N, which the
+// shape-only vg_conv3d_dma_bn cannot see) + the partial tiles of the K split it would choose given room.  0: not one of its shapes.
+extern "C" int64_t vg_conv3d_scratch_bytes(const vg_conv_desc* d) {
+    vg_begin();
+    if (!d || !d->wlayout || d->N < 1) return 0;
+    CdPlan pl;
+    const int BN = cd_plan(d, pl);
+    if (!BN || BN != d->wlayout) return 0;
+    const int Cin = d->c_src0 + d->c_src1, NPL = Cin / 16, ncob = d->Cout / BN;
+    const int64_t plane_bytes = (int64_t)pl.DpA * pl.HpA * pl.WpA * 32;
+    const int64_t p_bytes = ((plane_bytes * NPL * d->N + 255) / 256) * 256;
+    const long units0 = (long)pl.ncls * ncob * d->N * pl.tiles_d * pl.tiles_q;
+    const long target = vg_tune("CONV_DMA_WGS", 128);
+    const int64_t slot_bytes = 512LL * 2 * (BN / 64) * 16 * 4;
+    int ks = 1;
+    for (int c = 1; c <= NPL; ++c) {
+        if (NPL % c) continue;
+        if (c > 1 && units0 > VG_SCRATCH_CTR_BYTES / 4) break;
+        ks = c;
+        if (units0 * c >= target) break;
+    }
+    return VG_SCRATCH_CTR_BYTES + p_bytes + (ks > 1 ? units0 * ks * slot_bytes : 0);
+}
+
 // VG_OK: served; 1: not one of this family's shapes (only possible when d->wlayout == 0); < 0: error
 int vg_conv_dma(const vg_conv_desc* d, hipStream_t s) {
     CdPlan pl;

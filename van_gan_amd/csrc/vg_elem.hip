@@ -413,7 +413,10 @@ __global__ void in_scale_invariant_wgrad_kernel(const float* red, const float* r
         db += r0; dg += r1;
     }
     const float wc = round16 ? bf2f(f2bf(w[c])) : w[c];
-    dw[c] += eps * gamma[c] * acc / wc;
+    // w -> 0 (a pruned / zero-initialised checkpoint, or a weight that underflows in the 16-bit format): the closed form is 0/0 -- xhat
+    // and with it sum dn*xhat vanish with w -- and one NaN here would reach every generator parameter through the clip norm.  The
+    // channel's output is constant then (normalises to beta): the statistics carry no gradient for it, and none is added.
+    if (fabsf(wc) >= 1e-30f) dw[c] += eps * gamma[c] * acc / wc;
     if (dgamma) { dgamma[c] += dg; dbeta[c] += db; }
 }
 extern "C" int vg_in_scale_invariant_wgrad(const float* red, const float* rstd, const float* gamma, const float* w, int N, int C, float eps,

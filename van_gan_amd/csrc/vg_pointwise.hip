@@ -1129,6 +1129,9 @@ int vg_pointwise_conv(const vg_conv_desc* d, hipStream_t s) {
     { const int grc = pw_gemm_conv(d, s); if (grc <= 0) return grc; }
     if (!pw_shape_ok(d) || d->res) return 1;
     if (d->ostr != 1 || d->ooff_d || d->ooff_h || d->ooff_w || d->BD != d->OD || d->BH != d->OH || d->BW != d->OW) return 1;
+    // tanh_out with accumulate means out = tanh(out + value) (vg_conv_desc): these one-pass kernels accumulate AFTER the activation
+    // slot, so the combination goes to the MFMA path, whose epilogue implements it -- never a silently un-activated result
+    if (d->tanh_out && d->accumulate) return 1;
     const int Cin = d->c_src0;
     PW p = {};
     p.x = d->src0; p.x_f32 = d->src_f32; p.scale = d->in_scale; p.shift = d->in_shift; p.act = d->act;

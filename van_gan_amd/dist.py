@@ -9,21 +9,66 @@ pre-divided by the GLOBAL batch size on every replica (loss_functions.py:21-22) 
 Device-agnostic on purpose: the same class runs over gloo on CPU tensors (tests/test_ddp_gloo.py)."""
 from __future__ import annotations
 
+import os
 from typing import Dict, Iterable, List, Optional
 
 import torch
 import torch.distributed as dist
 
+RING_WORLD = 8          # the node size the stand-in's hold time is priced for (BASELINE config 4: 8 x MI355X)
+
 
 class GradSync:
-    def __init__(self, buckets: Dict[str, torch.Tensor], process_group=None, weights: Optional[Dict[str, torch.Tensor]] = None):
+    """`fake` (default: VG_FAKE_AR=1, only with one process on a GPU): the data-parallel schedule runs for real with world == 1 --
+    communication stream, per-bucket events, pieces, the engine's cross-step overlap -- and every all-reduce is replaced by
+    vg_local_exchange (include/vangan_hip.h): a device-local kernel on a second, inner stream (as ProcessGroupNCCL runs its
+    collectives on a stream of its own behind the caller's) that moves the bucket's bytes with VG_FAKE_AR_WG workgroups and holds
+    them for the time a ring over RING_WORLD GPUs would need at VG_FAKE_AR_GBPS GB/s of bus bandwidth (0: no hold).
+    `stream`: run the communication on this stream instead of a new one (the engine passes its optimizer stream: the bucket's
+    optimizer step is the only consumer, and HIP has 4 hardware queues for the streams of a process)."""
+
+    def __init__(self, buckets: Dict[str, torch.Tensor], process_group=None, weights: Optional[Dict[str, torch.Tensor]] = None,
+                 fake: Optional[bool] = None, stream=None):
         self.buckets, self.weights, self.pg = buckets, weights, process_group
         self.world = dist.get_world_size(process_group) if process_group is not None else 1
         dev = next(iter(buckets.values())).device
         self.cuda = dev.type == 'cuda'
-        self.stream = torch.cuda.Stream(device=dev) if (self.cuda and self.world > 1) else None
+        if fake is None:
+            fake = os.environ.get('VG_FAKE_AR', '0') == '1'
+        self.fake = bool(fake) and self.world == 1 and self.cuda
+        self.active = self.world > 1 or self.fake
+        self.stream = (stream if stream is not None else torch.cuda.Stream(device=dev)) if (self.cuda and self.active) else None
         self.pending: Dict[str, list] = {}          # bucket name -> CUDA events on the comm stream / async work handles (one per piece)
         self.rank = dist.get_rank(process_group) if process_group is not None else 0
+        self.moved_bytes = 0                        # fake mode: bytes handed to the stand-in so far
+        self._inner = self._scratch = None
+        if self.fake:
+            self._wg = int(os.environ.get('VG_FAKE_AR_WG', '32'))
+            self._gbps = float(os.environ.get('VG_FAKE_AR_GBPS', '0'))
+            self._scratch = torch.empty(max(b.numel() for b in buckets.values()), dtype=torch.float32, device=dev)
+
+    def _reduce(self, t: torch.Tensor):
+        """SUM all-reduce of a flat fp32 piece on the current (communication) stream."""
+        if not self.fake:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
+            return
+        from . import _lib
+        # only whole 16-byte units strictly inside the piece: the elements next to it may still be written by the backward sweep
+        a = t.data_ptr()
+        lo = (-(a // 4)) % 4
+        n = (t.numel() - lo) // 4 * 4
+        if n <= 0:
+            return
+        if self._inner is None:
+            self._inner = torch.cuda.Stream(device=t.device)
+        cur = torch.cuda.current_stream()
+        self._inner.wait_stream(cur)
+        nbytes = 4 * n
+        hold_us = int(nbytes * 2.0 * (RING_WORLD - 1) / RING_WORLD / (self._gbps * 1e3)) if self._gbps > 0 else 0
+        _lib.check(_lib.lib.vg_local_exchange(a + 4 * lo, self._scratch.data_ptr(), n, self._wg, min(hold_us, 100000),
+                                              self._inner.cuda_stream), 'vg_local_exchange')
+        cur.wait_stream(self._inner)
+        self.moved_bytes += nbytes
 
     def start(self, names: Iterable[str], also=None, lo: int = 0, hi: Optional[int] = None):
         """Issue the all-reduce of these buckets; on GPU it runs on the side stream behind everything already queued
@@ -32,7 +77,7 @@ class GradSync:
         lo / hi: only the elements [lo, hi) of the flat bucket (one name).  A backward sweep completes a generator's gradients from
         the END of the flat buffer towards its start (output head, decoder, bridge, encoder, stem -- the reverse of the parameter
         order), so the engine reduces a finished suffix while the sweep is still running; finish(name) waits for every piece."""
-        if self.world == 1:
+        if not self.active:
             return
         names = list(names)
         assert (lo == 0 and hi is None) or len(names) == 1
@@ -44,7 +89,7 @@ class GradSync:
                 self.stream.wait_event(also)
             with torch.cuda.stream(self.stream):
                 for n in names:
-                    dist.all_reduce(self.buckets[n][lo:hi], op=dist.ReduceOp.SUM, group=self.pg)
+                    self._reduce(self.buckets[n][lo:hi])
                     done = torch.cuda.Event()
                     done.record()
                     self.pending.setdefault(n, []).append(done)
@@ -75,6 +120,9 @@ class GradSync:
         return dict(zip(keys, t.cpu().tolist()))
 
     def broadcast_weights(self, src: int = 0):
+        if self.fake and self._inner is None:
+            # the first collective of a real run (this broadcast) is where ProcessGroupNCCL creates its internal stream
+            self._inner = torch.cuda.Stream(device=next(iter(self.buckets.values())).device)
         if self.world == 1 or self.weights is None:
             return
         for w in self.weights.values():

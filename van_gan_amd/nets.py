@@ -120,6 +120,10 @@ def init_reference(store: ParamStore, seed: int):
             t = torch.ones(shape)
         elif init == 'glorot_vec':
             t = (torch.rand(shape, generator=g) * 2 - 1) * math.sqrt(3.0 / shape[0])
+        elif init == 'he_vec':              # he_normal over a 1-D shape (C,): Keras' _compute_fans gives fan_in = fan_out = C
+            t = torch.empty(shape)
+            torch.nn.init.trunc_normal_(t, 0.0, 1.0, -2.0, 2.0, generator=g)
+            t = t * (math.sqrt(2.0 / shape[0]) / 0.87962566103423978)
         else:
             rf = shape[0] * shape[1] * shape[2]
             fan_in, fan_out = rf * shape[3], rf * shape[4]
@@ -540,11 +544,12 @@ RESNET_F, RESNET_DOWN, RESNET_RES, RESNET_UP = 32, 3, 6, 3
 
 
 def resnet_param_specs() -> List[Tuple[str, Tuple[int, ...], str]]:
-    """Names / order / layouts of oracle.vangan_oracle.resnet_param_specs (weights exchange 1:1)."""
+    """Names / order / layouts of oracle.vangan_oracle.resnet_param_specs (weights exchange 1:1).  Every InstanceNorm of this
+    generator is created with gamma_initializer='he_normal' (generator.py:14,40,49,55,62; building_blocks.py:107,121,190,277)."""
     s: List[Tuple[str, Tuple[int, ...], str]] = []
 
     def inorm(name, c):
-        s.append((name + '.gamma', (c,), 'ones')); s.append((name + '.beta', (c,), 'zeros'))
+        s.append((name + '.gamma', (c,), 'he_vec')); s.append((name + '.beta', (c,), 'zeros'))
 
     f = RESNET_F
     s.append(('c7.w', (7, 7, 7, 1, f), 'he_normal')); inorm('c7.in', f)

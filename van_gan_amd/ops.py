@@ -65,7 +65,7 @@ class DryRun:
     a box without a GPU to list the kernels a configuration would run (tests/test_variant_coverage.py).
     records: [(kind, layer name, variant string)], kind in fwd / dgrad / wgrad."""
 
-    _PASS = ('vg_conv3d_dma_bn', 'vg_conv3d_thin_np', 'vg_conv3d_plan', 'vg_packed_ktot', 'vg_packed_rows', 'vg_conv3d_lds_bytes', 'vg_status_string', 'vg_set_tuning')
+    _PASS = ('vg_conv3d_dma_bn', 'vg_conv3d_scratch_bytes', 'vg_conv3d_thin_np', 'vg_conv3d_plan', 'vg_packed_ktot', 'vg_packed_rows', 'vg_conv3d_lds_bytes', 'vg_status_string', 'vg_set_tuning')
 
     def __init__(self):
         self.records = []
@@ -148,10 +148,13 @@ class KernelProfile:
         r = self.rows.setdefault(kind, [0, 0.0, [], 0.0])
         r[0] += 1; r[1] += flops; r[2].append((e0, e1)); r[3] += nbytes
         if variant:
-            v = self.vrows.setdefault((kind, variant.split('|')[0]), [0, 0.0, [], 0.0])
+            # one row per kernel TEMPLATE, as rocprofv3 names kernels: the run-time regimes behind '|' and the bs1 / bs2 flavour of the
+            # thin specialist's statistics epilogue (one template, a kernel argument) are summed
+            tmpl = variant.split('|')[0].replace(',bs1>', ',bs>').replace(',bs2>', ',bs>')
+            v = self.vrows.setdefault((kind, tmpl), [0, 0.0, [], 0.0])
             v[0] += 1; v[1] += flops; v[2].append((e0, e1)); v[3] += nbytes
             if layer:
-                v = self.lrows.setdefault((kind, layer, variant.split('|')[0]), [0, 0.0, [], 0.0])
+                v = self.lrows.setdefault((kind, layer, tmpl), [0, 0.0, [], 0.0])
                 v[0] += 1; v[1] += flops; v[2].append((e0, e1)); v[3] += nbytes
 
     def by_layer(self):
@@ -263,6 +266,7 @@ def side_join():
 
 CONV_SCRATCH = {}      # (device index, stream) -> uint8 workspace of vg_conv3d launches on that stream (vg_conv_desc::scratch)
 CONV_SCRATCH_BYTES = _lib.SCRATCH_CTR_BYTES + (int(os.environ.get('VG_CONV_SCRATCH_MB', '160')) << 20)
+_SCRATCH_RETIRED = []   # outgrown workspaces (see conv_scratch)
 
 
 def conv_scratch(d: ConvDesc, s_: int, device=None):
@@ -270,14 +274,21 @@ def conv_scratch(d: ConvDesc, s_: int, device=None):
     at zero) + fp32 partial tiles of K-split launches + the materialised operand of the LDS-DMA convolution.  One buffer per
     (device, stream): launches of one stream are ordered, the lanes and their side streams run concurrently.  The library itself
     never allocates (include/vangan_hip.h)."""
+    # a call with weights in the LDS-DMA block layout has no other kernel, and its operand grows with the batch: the workspace is
+    # grown to what THIS call needs (vg_conv3d_scratch_bytes) instead of failing with VG_EINVAL on a larger batch or patch
+    need = CONV_SCRATCH_BYTES
+    if d.wlayout:
+        need = max(need, int(lib.vg_conv3d_scratch_bytes(C.byref(d))))
     if DRY is not None:                       # dry runs plan exactly as the real launch does: same (dummy) workspace size
-        d.scratch, d.scratch_bytes = 1 << 20, CONV_SCRATCH_BYTES
+        d.scratch, d.scratch_bytes = 1 << 20, need
         return
     key = (_DEV if device is None else device, s_)
     sc = CONV_SCRATCH.get(key)
-    if sc is None:
+    if sc is None or sc.numel() < need:
         dev = torch.device('cuda', key[0]) if key[0] is not None else torch.device('cuda')
-        sc = torch.empty(CONV_SCRATCH_BYTES, dtype=torch.uint8, device=dev)
+        if sc is not None:
+            _SCRATCH_RETIRED.append(sc)       # launches in flight on the stream may still use it: never handed back to the allocator
+        sc = torch.empty(need, dtype=torch.uint8, device=dev)
         # s_ is torch's current stream at every call site (ops.stream()): the memset precedes every launch that will use the buffer
         sc[:_lib.SCRATCH_CTR_BYTES].zero_()
         CONV_SCRATCH[key] = sc

@@ -60,10 +60,19 @@ class GanMonitor:
         self.updateDiscriminatorNoise(model, epoch)
 
 
+class NonFiniteLoss(FloatingPointError):
+    """A result scalar of a step is NaN / inf.  The reference has no such check (its check_numerics calls are commented out,
+    vangan.py:290-292) and min_max_norm_tf has no epsilon (utils.py:48): one constant patch turns every weight into NaN silently."""
+
+
 def train(ds, gan, epoch: int, steps: Optional[int] = None, training: bool = True,
-          monitor: Optional[GanMonitor] = None) -> Dict[str, List[float]]:
+          monitor: Optional[GanMonitor] = None, on_nonfinite: str = 'raise') -> Dict[str, List[float]]:
     """vangan.py:510-551: `steps` batches through distributed_train_step / distributed_test_step, results appended per
-    key.  `ds` is an iterable of (real_I, real_S) or an object with next_batch()."""
+    key.  `ds` is an iterable of (real_I, real_S) or an object with next_batch().
+    on_nonfinite: 'raise' (default; NonFiniteLoss names the step and the keys -- SURVEY section 5's failure-detection hook) or
+    'ignore' (the reference's behaviour: NaNs are appended and training goes on)."""
+    if on_nonfinite not in ('raise', 'ignore'):
+        raise ValueError("on_nonfinite must be 'raise' or 'ignore'")
     results: Dict[str, List[float]] = {}
     it = iter(ds) if hasattr(ds, '__iter__') else None
     cntr = 0
@@ -84,6 +93,12 @@ def train(ds, gan, epoch: int, steps: Optional[int] = None, training: bool = Tru
         cntr += 1
         for k, v in result.items():
             results.setdefault(k, []).append(v)
+        if on_nonfinite == 'raise':
+            bad = [k for k, v in result.items() if v != v or v in (float('inf'), float('-inf'))]
+            if bad:
+                raise NonFiniteLoss('epoch %d, step %d (%s): non-finite %s -- a constant patch makes min_max_norm divide by zero '
+                                    '(utils.py:48); the weights of this step are already updated, resume from the last checkpoint'
+                                    % (epoch, cntr - 1, 'train' if training else 'validation', ', '.join(bad)))
     return results
 
 

@@ -15,7 +15,7 @@ from typing import Dict, Optional
 
 import torch
 
-from . import ops
+from . import ops, roctx
 from .dist import GradSync
 from .nets import (pair_ctx, PatchGAN, ParamStore, ResNetGenerator, ResUNet, disc_param_specs, gen_param_specs, init_reference,
                    resnet_param_specs)
@@ -51,6 +51,13 @@ def interleave(*seqs, on=True):
                     live.remove(i)
     return vals
 NETS = ['gen_IS', 'gen_SI', 'disc_I', 'disc_S']
+# roctx range (VG_ROCTX=1) opened when a milestone of _mark() has been enqueued: the name of what the host enqueues NEXT
+_PHASE_AFTER = {'A start': 'enqueue: generators, first application (both lanes)', 'A G1 fwd': 'enqueue: lane B event', 'B G1 fwd': 'enqueue: generators, cycle application',
+                'A G2 fwd': 'enqueue: lane B mark', 'B G2 fwd': 'enqueue: target skeleton', 'A target skeleton': 'enqueue: lane B BCE + clDice (+ backward)',
+                'B clDice': 'enqueue: lane A MSE + SSIM (+ backward)', 'A cycle losses': 'enqueue: D_S forward + LSGAN', 'A D_S fwd': 'enqueue: D_I forward + LSGAN',
+                'A D fwd': 'enqueue: discriminator backward sweeps', 'A D bwd': 'enqueue: next sweep', 'B D bwd': 'enqueue: next sweep',
+                'A G adv bwd': 'enqueue: next sweep', 'B G adv bwd': 'enqueue: next sweep', 'A G cyc bwd': 'enqueue: all-reduce + optimizer (gen_IS)',
+                'B G cyc bwd': 'enqueue: all-reduce + optimizer (gen_SI)', 'A all joined': None}
 
 
 _ENGINE_STREAMS: Dict = {}
@@ -95,6 +102,10 @@ class VanGan:
         self.global_batch_size = global_batch_size if global_batch_size is not None else batch_size * n_devices
         self.lambda_cycle, self.lambda_reconstruction, self.lambda_topology = lambda_cycle, lambda_reconstruction, lambda_topology
         self.lr, self.beta_1, self.beta_2, self.clipnorm = lr, beta_1, beta_2, clipnorm
+        # per-network learning rate: None = self.lr; a float; or a schedule callable(step) evaluated at the network's optimizer
+        # iteration count when its Adam step is enqueued (the reference assigns a PolynomialDecay to each optimizer's .lr,
+        # custom_callback.py:343-365; Keras evaluates it at optimizer.iterations)
+        self.lrs: Dict[str, object] = {}
         self.adam_eps = 1e-7                      # TP: tf.keras Adam default epsilon
         self.layer_noise = layer_noise            # vangan.py:77 (GanMonitor decays it per epoch)
         self.dropout_rate = dropout_rate
@@ -131,24 +142,47 @@ class VanGan:
         # weight gradients go to a side stream of the stream that issues them (one per lane): within a layer they are
         # independent of the data-gradient chain.  36.9 vs 37.6 ms/step; a single side stream shared by both lanes cost 2 ms.
         ops.side_enable(self.device, os.environ.get('VG_SIDE_STREAM', '1') != '0')
-        # forward lanes: the I->S->I chain (G_IS(real_I), G_SI(fake_S), D_S, cycle losses on cycled_I) and the S->I->S chain
-        # are independent until the backward sweeps, so they run on two streams and fill each other's low-occupancy
-        # 8^3/16^3 layers
-        self._lane_b = _engine_stream(self.device, 'lane_b') if os.environ.get('VG_LANES', '1') != '0' else None
+        # Streams, in a DELIBERATE creation order (VG_STREAM_ORDER): HIP serves the streams of a process from GPU_MAX_HW_QUEUES (4)
+        # hardware queues handed out in creation order, and streams that share a queue run one after the other.
+        # Roles: lane_b (the second forward / backward lane; the first is the caller's current stream), opt (optimizer stream),
+        # side_a / side_b (weight-gradient side streams of the two lanes), comm (gradient all-reduce, data-parallel runs only).  The
+        # first four are the single-GPU set; the communication of a data-parallel run comes LAST so that it never displaces one of
+        # them -- and by default it is not a stream of its own at all: the all-reduce of a bucket is queued on the optimizer stream
+        # (VG_COMM_ON_OPT=0: own stream), in front of the optimizer step that is its only consumer; RCCL's internal stream (created by
+        # the first collective, the rank-0 weight broadcast) then is the fifth and only extra one.
+        lanes = os.environ.get('VG_LANES', '1') != '0'
+        self._lane_b = self._opt = None
+        self.ddp = self.pg is not None or (os.environ.get('VG_FAKE_AR', '0') == '1')
+        comm = None
+        for role in os.environ.get('VG_STREAM_ORDER', 'lane_b,opt,side_b,side_a,comm').split(','):
+            if role == 'lane_b' and lanes:
+                # forward lanes: the I->S->I chain (G_IS(real_I), G_SI(fake_S), D_S, cycle losses on cycled_I) and the S->I->S chain
+                # are independent until the backward sweeps, so they run on two streams and fill each other's low-occupancy layers
+                self._lane_b = _engine_stream(self.device, 'lane_b')
+            elif role == 'opt' and os.environ.get('VG_OPT_STREAM', '1') != '0':
+                # optimizer stream: a network's clip + Adam + weight repack is queued here as soon as ITS backward sweeps are issued
+                # and waits only for ITS gradient bucket (all-reduce event), while the other networks' backward sweeps still run
+                self._opt = _engine_stream(self.device, 'opt')
+            elif role == 'side_a' and ops.SIDE is not None:
+                ops._side_of(torch.cuda.current_stream(self.device))
+            elif role == 'side_b' and ops.SIDE is not None and self._lane_b is not None:
+                ops._side_of(self._lane_b)
+            elif role == 'comm' and self.ddp and not (self._opt is not None and os.environ.get('VG_COMM_ON_OPT', '1') != '0'):
+                comm = _engine_stream(self.device, 'comm')
+        if self.ddp and comm is None:
+            comm = self._opt                 # None (VG_OPT_STREAM=0): GradSync makes its own
         # second workspace for lane B's backward temporaries (bump allocators cannot interleave mark/release)
         self.arena_b = Arena(arena_bytes // 2, self.device) if self._lane_b is not None else None
         # one arena for every backward sweep (VG_LANES=0): the workspace is sized for the two-lane layout, so backward temporaries
         # are recycled there (joining release) instead of being kept until the next reset
         self.arena.lazy_ok = self._lane_b is not None
-        self.sync = GradSync({k: s.g for k, s in self.stores.items()}, self.pg, {k: s.w for k, s in self.stores.items()})
-        # optimizer stream: a network's clip + Adam + weight repack is queued here as soon as ITS backward sweeps are issued and
-        # waits only for ITS gradient bucket (all-reduce event), while the other networks' backward sweeps still run
-        self._opt = _engine_stream(self.device, 'opt') if os.environ.get('VG_OPT_STREAM', '1') != '0' else None
+        self.sync = GradSync({k: s.g for k, s in self.stores.items()}, self.pg, {k: s.w for k, s in self.stores.items()}, stream=comm)
+        self.ddp = self.sync.active
         self._tl = [] if os.environ.get('VG_TIMELINE') == '1' else None
         self._side_ev = {}
         # world > 1: the step does not end with a join of the optimizer stream -- the last buckets' all-reduce + Adam + repack run
         # under the head of the NEXT step, whose consumers wait for the update event of the network they read (VG_XSTEP=0: join)
-        self._xstep = self.pg is not None and self._opt is not None and os.environ.get('VG_XSTEP', '1') != '0'
+        self._xstep = self.ddp and self._opt is not None and os.environ.get('VG_XSTEP', '1') != '0'
         self._upd_ev = {}
         self._fp16_nets = {}
         self.checkpoint_dir = None
@@ -230,6 +264,8 @@ class VanGan:
             e = torch.cuda.Event(enable_timing=True)
             e.record()
             self._tl.append((name, e))
+        if roctx.ON:
+            roctx.phase(_PHASE_AFTER.get(name, 'after ' + name))
 
     def timeline(self):
         torch.cuda.synchronize(self.device)
@@ -491,7 +527,7 @@ class VanGan:
                 ccB = pair_ctx(ar, c2, bufS, (fake_I, cyc_I), self.gen_SI.lv[0])
                 # data parallel: the finished suffix of a generator's gradient bucket (enc4 ... output head, 34 of 38 MB) goes to the
                 # all-reduce when the sweep has passed enc4 -- with ~40 % of the sweep still ahead; only the last 4 MB wait for its end
-                split = self.pg is not None and apply and _AR_SPLIT
+                split = self.ddp and apply and _AR_SPLIT
                 def early(name, gen):
                     return (lambda: self._start_allreduce([name], lazy=apply, lo=gen.grad_suffix_offset())) if split else None
                 order = ((laneB, self.gen_SI.backward_iter(arB, ccB, gI2, inline_from=_INLINE, on_suffix_done=early('gen_SI', self.gen_SI))),
@@ -562,7 +598,9 @@ class VanGan:
         st = self.stores[name]
         st.step += 1
         t = st.step
-        lr_t = self.lr * math.sqrt(1.0 - self.beta_2 ** t) / (1.0 - self.beta_1 ** t)
+        lr = self.lrs.get(name)
+        lr = self.lr if lr is None else (float(lr(t - 1)) if callable(lr) else lr)       # iterations BEFORE this step, as Keras
+        lr_t = lr * math.sqrt(1.0 - self.beta_2 ** t) / (1.0 - self.beta_1 ** t)
         ops.adam_clip(st.w, st.g, st.m, st.v, st.seg_off, st.T, st.norms, lr_t, self.beta_1, self.beta_2,
                       self.adam_eps, self.clipnorm, 1.0)
         self.nets[name].pack()
@@ -621,6 +659,24 @@ class VanGan:
         self._join_updates()            # (see load_weights)
         self.sync.broadcast_weights(src)
         self.repack()
+
+    def generate(self, gen: str, x: torch.Tensor) -> torch.Tensor:
+        """gen(x, training=False) of the reference's callers (custom_callback.py:174-175): generator forward on fp32 [B,D,H,W,1]
+        device volumes at the engine's patch size, in chunks of the engine's batch size; returns fp32 [B,D,H,W,1] on the device."""
+        if gen not in ('gen_IS', 'gen_SI'):
+            raise ValueError('gen must be gen_IS or gen_SI')
+        if x.dim() != 5 or tuple(x.shape[1:]) != self.dims + (1,):
+            raise ValueError('expected [B, %d, %d, %d, 1] volumes, got %s' % (self.dims + (tuple(x.shape),)))
+        ops.set_device(self.device.index)
+        self._join_updates()
+        net = self.nets[gen]
+        out = torch.empty(x.shape, dtype=torch.float32, device=self.device)
+        nb = max(1, self.batch_size)
+        for i in range(0, x.shape[0], nb):
+            self.arena.reset()
+            xin = x[i:i + nb].to(self.device, torch.float32).contiguous()
+            net.forward(self.arena, xin, out[i:i + nb], save=False)
+        return out
 
     def fp16_generator(self, gen: str):
         """The generator `gen` as an fp16-storage network over the SAME fp32 master weights (forward only; built on first use),
