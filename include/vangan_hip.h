@@ -322,12 +322,19 @@ int vg_ssim_bwd(const float* t, const float* p, const float* part, int B, int D,
 
 /* clDice soft skeleton (clDice_func.py:8-80).  imgs: [iters+2][B][S] receives img_0..img_{iters+1}
  * (img_{j+1} = soft_erode(img_j)); skels: [iters+1][B][S] receives the skeleton after every step, the
- * last slab is soft_skel(img, iters). */
-int vg_soft_skel_fwd(const float* img, int B, int D, int H, int W, int iters, float* imgs, float* skels,
+ * last slab is soft_skel(img, iters).
+ * aux == NULL (a skeleton that is not differentiated: the target's): the erosion chain runs two steps per launch on tiles held in LDS
+ * with a 2-voxel halo, the skeleton recursion is one launch over the stored chain.
+ * aux != NULL ((iters+1) * B*S * 6 bytes: [iters+1][B][S] float delta_j, then [iters+1][B][S] uint8 arg-max codes of the dilation in
+ * delta_j = relu(img_j - dilate(img_{j+1})), then [iters+1][B][S] uint8 arg-min codes of the erosion img_{j+1} = erode(img_j); a code
+ * is ((a+1)*3 + (b+1))*3 + (c+1) for the offset (a, b, c) along (D, H, W) of the FIRST extremum in TensorFlow's scan order, TP): the
+ * forward pass files where every pooling gradient will go, and vg_soft_skel_bwd with the same aux routes by table lookup. */
+int vg_soft_skel_fwd(const float* img, int B, int D, int H, int W, int iters, float* imgs, float* skels, void* aux,
                      vg_stream_t stream);
-/* gimg += (d skel / d img)^T gskel; work: [3][B][S] scratch */
+/* gimg += (d skel / d img)^T gskel.  aux != NULL (what vg_soft_skel_fwd filed): iters + 2 streaming launches, work = [4][B][S] scratch
+ * (no initialisation needed); aux == NULL: two scan launches per step that recompute the arg-extrema from imgs, work = [3][B][S]. */
 int vg_soft_skel_bwd(const float* imgs, const float* skels, const float* gskel, int B, int D, int H, int W,
-                     int iters, float* work, float* gimg, vg_stream_t stream);
+                     int iters, float* work, float* gimg, const void* aux, vg_stream_t stream);
 /* Dice + clDice combination (clDice_func.py:83-149, loss_functions.py:223-226) without a host sync.
  * sums7 = (sum skel_p*t, sum skel_p, sum t, sum skel_t*p, sum skel_t, sum p, sum t*p);
  * coef6: gskel_p = c0*t - c1;  gp += c2*t + c3 + c4*skel_t;  c5 = w*((1-alpha)*dice + alpha*clDice). */

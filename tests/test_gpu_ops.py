@@ -336,6 +336,91 @@ def test_soft_skeleton_chain_kernel_is_bitwise_the_per_step_kernels():
     assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
 
 
+def test_multi_erosion_launches_are_bitwise_the_per_step_kernel():
+    """Round 5: four (two, one) erosions per launch on LDS tiles with a 4- (2-, 1-) voxel halo against one launch per erosion: the
+    whole stored chain img_0 .. img_{iters+1} and every skeleton bit for bit, ragged tiles, 7 erosions = one launch of each kind."""
+    from van_gan_amd import ops
+    from van_gan_amd._lib import lib
+    dev = _dev()
+    g = torch.Generator().manual_seed(23)
+    for (B, D, H, W, it) in ((2, 11, 13, 37, 6), (1, 32, 16, 64, 15), (1, 5, 3, 9, 3)):
+        p = torch.rand(B, D, H, W, 1, generator=g).to(dev)
+        vol = (B, D, H, W, 1)
+        out = []
+        for multi in (4, 2, 1):
+            lib.vg_set_tuning(b'SKEL_MULTI', multi, 0)
+            imgs, skels = torch.full((it + 2,) + vol, -5.0, device=dev), torch.full((it + 1,) + vol, 3.0, device=dev)
+            ops.soft_skel_fwd(p, (B, D, H, W), it, imgs, skels)
+            torch.cuda.synchronize()
+            out.append((imgs.cpu(), skels.cpu()))
+        lib.vg_set_tuning(b'SKEL_MULTI', 0, 1)
+        assert torch.equal(out[0][0][0], p.cpu())                          # img_0 filed by the first launch
+        for o in out[:2]:
+            assert torch.equal(o[0], out[2][0]) and torch.equal(o[1], out[2][1]), (B, D, H, W, it)
+
+
+def test_skeleton_backward_from_filed_codes_matches_the_scan_kernels():
+    """Round 5: with aux the forward pass files delta_j and the FIRST arg-max / arg-min code of every pooling window, and the backward
+    pass is iters + 2 streaming launches that route by table lookup.  Against the scan kernels (which recompute the arg-extrema from the
+    stored chain, two launches per step): same chain and skeletons bit for bit, every code equal to a brute-force first-candidate scan in
+    the reference's order (continuous data AND binary data full of ties), gradients equal up to the order of the float atomics."""
+    from van_gan_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(29)
+    for (B, D, H, W, it, binary) in ((2, 11, 13, 37, 6, False), (1, 16, 24, 40, 15, False), (1, 12, 10, 33, 5, True), (1, 5, 3, 9, 3, False)):
+        p = torch.rand(B, D, H, W, 1, generator=g)
+        if binary:
+            p = (F.avg_pool3d(p.permute(0, 4, 1, 2, 3), 3, 1, 1) > 0.5).float().permute(0, 2, 3, 4, 1).contiguous()
+        p = p.to(dev)
+        vol = (B, D, H, W, 1)
+        dims = (B, D, H, W)
+        n = B * D * H * W
+        imgs, skels = torch.zeros((it + 2,) + vol, device=dev), torch.zeros((it + 1,) + vol, device=dev)
+        ops.soft_skel_fwd(p, dims, it, imgs, skels)
+        imgs2, skels2 = torch.zeros((it + 2,) + vol, device=dev), torch.zeros((it + 1,) + vol, device=dev)
+        aux = torch.zeros(ops.skel_aux_bytes(dims, it), dtype=torch.uint8, device=dev)
+        ops.soft_skel_fwd(p, dims, it, imgs2, skels2, aux)
+        torch.cuda.synchronize()
+        assert torch.equal(imgs, imgs2) and torch.equal(skels, skels2)
+        # brute-force codes from the stored chain: first extremum in scan order (erode: the three 3x3 planes one after the other)
+        ic = imgs2.cpu()[..., 0]
+        codeM = aux[(it + 1) * n * 4:(it + 1) * n * 5].cpu().view(it + 1, B, D, H, W)
+        codeN = aux[(it + 1) * n * 5:].cpu().view(it + 1, B, D, H, W)
+        delta = aux[:(it + 1) * n * 4].view(torch.float32).cpu().view(it + 1, B, D, H, W)
+        er_order = [(a, b, 0) for a in (-1, 0, 1) for b in (-1, 0, 1)] + [(a, 0, c) for a in (-1, 0, 1) for c in (-1, 0, 1)] + \
+                   [(0, b, c) for b in (-1, 0, 1) for c in (-1, 0, 1)]
+        di_order = [(a, b, c) for a in (-1, 0, 1) for b in (-1, 0, 1) for c in (-1, 0, 1)]
+
+        def first_arg(x, order, sign):
+            """x: [B,D,H,W]; code of the first candidate (in `order`) attaining the extremum; sign=+1: max, -1: min."""
+            pad = F.pad(x * sign, (1, 1, 1, 1, 1, 1), value=float('-inf'))
+            best = torch.full_like(x, float('-inf')); code = torch.zeros_like(x, dtype=torch.int64)
+            for (a, b, c) in order:
+                v = pad[:, 1 + a:1 + a + D, 1 + b:1 + b + H, 1 + c:1 + c + W]
+                better = v > best
+                best = torch.where(better, v, best)
+                code = torch.where(better, torch.full_like(code, ((a + 1) * 3 + (b + 1)) * 3 + (c + 1)), code)
+            return code, best * sign
+        for j in range(it + 1):
+            cn, mn = first_arg(ic[j], er_order, -1)
+            assert torch.equal(mn, ic[j + 1]) and torch.equal(cn, codeN[j].long()), ('arg-min codes', j)
+            cm, mx = first_arg(ic[j + 1], di_order, +1)
+            dl = torch.relu(ic[j] - mx)
+            assert torch.equal(dl, delta[j]), ('delta', j)
+            assert torch.equal(cm, codeM[j].long()), ('arg-max codes', j)
+        gskel = torch.randn(vol, generator=g).to(dev)
+        res = []
+        for use_aux in (True, False):
+            gp = torch.full(vol, 0.25, device=dev)                      # accumulated into
+            work = torch.full((4,) + vol, float('nan'), device=dev) if use_aux else torch.zeros((3,) + vol, device=dev)
+            ops.soft_skel_bwd(imgs2, skels2, gskel, dims, it, work, gp, aux if use_aux else None)
+            torch.cuda.synchronize()
+            res.append(gp.cpu())
+        assert bool(torch.isfinite(res[0]).all())
+        err = float((res[0] - res[1]).abs().max()), float(res[1].abs().max())
+        assert err[0] <= 2e-5 * max(err[1], 1.0), (B, D, H, W, it, binary, err)
+
+
 def test_soft_skeleton_and_cldice():
     """soft_skel forward/backward and the Dice+clDice combination vs the oracle (continuous data: no ties)."""
     from van_gan_amd import ops
@@ -348,7 +433,8 @@ def test_soft_skeleton_and_cldice():
     imgs_p, skels_p = torch.zeros((it + 2,) + vol, device=dev), torch.zeros((it + 1,) + vol, device=dev)
     imgs_t, skels_t = torch.zeros((it + 2,) + vol, device=dev), torch.zeros((it + 1,) + vol, device=dev)
     pd, td = p.to(dev), t.to(dev)
-    ops.soft_skel_fwd(pd, (B, D, H, W), it, imgs_p, skels_p)
+    aux = torch.zeros(ops.skel_aux_bytes((B, D, H, W), it), dtype=torch.uint8, device=dev)
+    ops.soft_skel_fwd(pd, (B, D, H, W), it, imgs_p, skels_p, aux)
     ops.soft_skel_fwd(td, (B, D, H, W), it, imgs_t, skels_t)
     pr = p.double().requires_grad_(True)
     sk_p = O.soft_skel(pr[..., 0], it)
@@ -364,11 +450,17 @@ def test_soft_skeleton_and_cldice():
     ops.cldice_coef(sums, w, 0.5, coef)
     gskel, gp = torch.zeros(vol, device=dev), torch.zeros(vol, device=dev)
     ops.cldice_grads(td, skels_t[it], coef, gskel, gp)
-    work = torch.zeros((3,) + vol, device=dev)
-    ops.soft_skel_bwd(imgs_p, skels_p, gskel, (B, D, H, W), it, work, gp)
+    work = torch.full((4,) + vol, float('nan'), device=dev)          # scratch: needs no initialisation
+    gp0 = gp.clone()
+    ops.soft_skel_bwd(imgs_p, skels_p, gskel, (B, D, H, W), it, work, gp, aux)
     torch.cuda.synchronize()
     assert abs(float(coef[5]) - float(loss)) < 1e-4 * abs(float(loss))
     assert rel_l2(gp, pr.grad) < 1e-3
+    # the scan path (no aux: arg-extrema recomputed from the stored chain) against the same oracle gradient
+    work3 = torch.zeros((3,) + vol, device=dev)
+    ops.soft_skel_bwd(imgs_p, skels_p, gskel, (B, D, H, W), it, work3, gp0)
+    torch.cuda.synchronize()
+    assert rel_l2(gp0, pr.grad) < 1e-3
 
 
 def test_adam_clip():

@@ -97,8 +97,8 @@ _SIGS = {
     'vg_mse_const': ([c_void_p, c_int, c_float, c_i64, c_void_p, c_float, c_void_p, c_int, c_void_p], c_int),
     'vg_ssim_fwd': ([c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p], c_int),
     'vg_ssim_bwd': ([c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p], c_int),
-    'vg_soft_skel_fwd': ([c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p], c_int),
-    'vg_soft_skel_bwd': ([c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p], c_int),
+    'vg_soft_skel_fwd': ([c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p], c_int),
+    'vg_soft_skel_bwd': ([c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p], c_int),
     'vg_cldice_coef': ([c_void_p, c_float, c_float, c_void_p, c_void_p], c_int),
     'vg_cldice_grads': ([c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_int, c_void_p], c_int),
     'vg_dot_sums': ([c_void_p, c_void_p, c_i64, c_void_p, c_void_p], c_int),

@@ -381,8 +381,14 @@ __global__ __launch_bounds__(256) void skel_tile_kernel(const float* __restrict_
 // the STORED erosion chain, so a block keeps the running skeleton and img_j of its 32 x 8 x 8 tile in registers and only loads the
 // tile of img_{j+1} (with halo) per step: 20 instead of 36 bytes per voxel and step, and iters fewer launches per skeleton.  Same
 // arithmetic in the same order as skel_tile_kernel<false>: bitwise the same skeletons.
+// AUX (round 5, the skeleton that will be differentiated): the launch also files, per step j and voxel, delta_j and the code of the FIRST
+// arg-max of the dilation window (0..26 = ((a+1)*3 + (b+1))*3 + (c+1), offsets along D, H, W; the raster order of the reference's
+// scan) -- the backward pass then routes gradients by table lookup instead of re-scanning 27 + 19 neighbours per voxel and step.
+// The first maximum of each 3 x 3 slice window, then the first of the three slices: the raster order is slice-major, so this IS
+// the first candidate of the full scan.
+template <bool AUX>
 __global__ __launch_bounds__(256) void skel_chain_kernel(const float* __restrict__ imgs, int64_t n, int iters, int D, int H, int W,
-                                                         float* __restrict__ skels) {
+                                                         float* __restrict__ skels, float* __restrict__ deltas, unsigned char* __restrict__ codes) {
     __shared__ float t[SK_TD + 2][SK_TH + 2][SK_TW + 2];
     const int tid = threadIdx.x;
     const int tiles_w = (W + SK_TW - 1) / SK_TW, tiles_h = (H + SK_TH - 1) / SK_TH;
@@ -415,53 +421,125 @@ __global__ __launch_bounds__(256) void skel_chain_kernel(const float* __restrict
         }
         __syncthreads();
         float* __restrict__ out = skels + (size_t)j * n;
-        float p9[3];
+        float p9[3]; int k9[3];
 #pragma unroll
         for (int sl = 0; sl < SK_TD + 2; ++sl) {
             const float a00 = t[sl][ty][tx], a01 = t[sl][ty][tx + 1], a02 = t[sl][ty][tx + 2];
             const float a10 = t[sl][ty + 1][tx], a11 = t[sl][ty + 1][tx + 1], a12 = t[sl][ty + 1][tx + 2];
             const float a20 = t[sl][ty + 2][tx], a21 = t[sl][ty + 2][tx + 1], a22 = t[sl][ty + 2][tx + 2];
-            const float plus = fmaxf(fmaxf(fmaxf(a01, a21), fmaxf(a10, a12)), a11);
-            p9[sl % 3] = fmaxf(plus, fmaxf(fmaxf(a00, a02), fmaxf(a20, a22)));
+            if (AUX) {
+                float m = a00; int k = 0;                     // first maximum of the slice window, raster order (b, c), strict >
+                if (a01 > m) { m = a01; k = 1; } if (a02 > m) { m = a02; k = 2; }
+                if (a10 > m) { m = a10; k = 3; } if (a11 > m) { m = a11; k = 4; } if (a12 > m) { m = a12; k = 5; }
+                if (a20 > m) { m = a20; k = 6; } if (a21 > m) { m = a21; k = 7; } if (a22 > m) { m = a22; k = 8; }
+                p9[sl % 3] = m; k9[sl % 3] = k;
+            } else {
+                const float plus = fmaxf(fmaxf(fmaxf(a01, a21), fmaxf(a10, a12)), a11);
+                p9[sl % 3] = fmaxf(plus, fmaxf(fmaxf(a00, a02), fmaxf(a20, a22)));
+            }
             if (sl >= 2) {
                 const int k = sl - 2, gd = d0 + k;
                 const float nb = fmaxf(p9[(sl - 1) % 3], fmaxf(p9[(sl - 2) % 3], p9[sl % 3]));
                 const float delta = fmaxf(cen[k] - nb, 0.f);
                 const float sp = sk[k];
                 sk[k] = j ? sp + fmaxf(delta - sp * delta, 0.f) : delta;
-                if (col_ok && gd < D) out[vol + ((size_t)gd * H + gh) * W + gw] = sk[k];
+                if (col_ok && gd < D) {
+                    const size_t o = vol + ((size_t)gd * H + gh) * W + gw;
+                    out[o] = sk[k];
+                    if (AUX) {
+                        float best = p9[(sl - 2) % 3]; int code = k9[(sl - 2) % 3];
+                        if (p9[(sl - 1) % 3] > best) { best = p9[(sl - 1) % 3]; code = 9 + k9[(sl - 1) % 3]; }
+                        if (p9[sl % 3] > best) { best = p9[sl % 3]; code = 18 + k9[sl % 3]; }
+                        deltas[(size_t)j * n + o] = delta; codes[(size_t)j * n + o] = (unsigned char)code;
+                    }
+                }
             }
         }
 #pragma unroll
         for (int k = 0; k < SK_TD; ++k) cen[k] = t[k + 1][ty + 1][tx + 1];       // img_{j+1} is the next step's img_j
     }
 }
+#define SK_TILE_ORIGIN()                                                                                    \
+    const int tiles_w = (W + SK_TW - 1) / SK_TW, tiles_h = (H + SK_TH - 1) / SK_TH;                           \
+    int bt_ = blockIdx.x; const int tw_ = bt_ % tiles_w; bt_ /= tiles_w;                                      \
+    const int th_ = bt_ % tiles_h, td_ = bt_ / tiles_h;                                                       \
+    const int w0 = tw_ * SK_TW, h0 = th_ * SK_TH, d0 = td_ * SK_TD;                                           \
+    const size_t vol = (size_t)blockIdx.y * D * H * W;                                                        \
+    const int tx = tid & (SK_TW - 1), ty = tid >> 5; const int gw = w0 + tx, gh = h0 + ty;
+
+// ---- K erosions per launch (round 5).  img_{j+1} = soft_erode(img_j) has a dependency radius of one voxel per step, so a block that
+// holds its 32 x 8 x 8 tile with a halo of K voxels in LDS can run K erosions back to back: stage s reads the region with halo
+// K - s + 1 from one LDS buffer and leaves the region with halo K - s in the other (voxels outside the volume stay +inf =
+// "neighbour skipped", exactly as the per-step kernel pads), writing the tile's own voxels of img_{j+s} to HBM on the way -- every
+// intermediate volume is still stored (the skeleton chain and the backward pass read all of them), but the chain is READ once per
+// K steps instead of once per step, and a skeleton costs ceil((iters + 1) / K) launches instead of iters + 1.  Same column walk
+// with per-slice partial minima as skel_tile_kernel<true>; min is order-independent, so the volumes are bitwise the same.
+template <int E>
+__device__ __forceinline__ void erode_stage(const float* __restrict__ src, float* __restrict__ dst, int w0, int h0, int d0, int D, int H, int W,
+                                            size_t vol, float* __restrict__ out, int tid) {
+    constexpr int DD = SK_TD + 2 * E, DH = SK_TH + 2 * E, DW = SK_TW + 2 * E;       // destination region (halo E)
+    constexpr int SH = DH + 2, SW = DW + 2;                                          // source region (halo E + 1)
+    for (int col = tid; col < DH * DW; col += 256) {
+        const int y = col / DW, x = col - y * DW;
+        const int gh = h0 - E + y, gw = w0 - E + x;
+        const bool col_in = gh >= 0 && gh < H && gw >= 0 && gw < W;
+        const bool col_tile = y >= E && y < E + SK_TH && x >= E && x < E + SK_TW;
+        float p9[3], p5[3];
+#pragma unroll
+        for (int sl = 0; sl < DD + 2; ++sl) {
+            const float* r0 = src + (sl * SH + y) * SW + x;
+            const float* r1 = r0 + SW; const float* r2 = r1 + SW;
+            const float a00 = r0[0], a01 = r0[1], a02 = r0[2], a10 = r1[0], a11 = r1[1], a12 = r1[2], a20 = r2[0], a21 = r2[1], a22 = r2[2];
+            const float plus = fminf(fminf(fminf(a01, a21), fminf(a10, a12)), a11);
+            p9[sl % 3] = fminf(plus, fminf(fminf(a00, a02), fminf(a20, a22))); p5[sl % 3] = plus;
+            if (sl >= 2) {
+                const int z = sl - 2, gd = d0 - E + z;
+                const float nb = fminf(p9[(sl - 1) % 3], fminf(p5[(sl - 2) % 3], p5[sl % 3]));
+                const bool in = col_in && gd >= 0 && gd < D;
+                if (E > 0) dst[(z * DH + y) * DW + x] = in ? nb : INFINITY;
+                if (in && col_tile && z >= E && z < E + SK_TD) out[vol + ((size_t)gd * H + gh) * W + gw] = nb;
+            }
+        }
+    }
+}
+template <int K>
+__global__ __launch_bounds__(256) void erode_multi_kernel(const float* __restrict__ in, int D, int H, int W, int64_t n, float* __restrict__ outs,
+                                                          float* __restrict__ copy0) {
+    extern __shared__ float sk_lds[];
+    constexpr int XD = SK_TD + 2 * K, XH = SK_TH + 2 * K, XW = SK_TW + 2 * K;
+    float* A = sk_lds; float* Bf = sk_lds + XD * XH * XW;
+    const int tid = threadIdx.x;
+    SK_TILE_ORIGIN()
+    (void)tx; (void)ty; (void)gw; (void)gh;
+    for (int i = tid; i < XD * XH * XW; i += 256) {
+        const int x = i % XW; const int r = i / XW; const int y = r % XH, z = r / XH;
+        const int qw = w0 - K + x, qh = h0 - K + y, qd = d0 - K + z;
+        float v = INFINITY;
+        if (qw >= 0 && qw < W && qh >= 0 && qh < H && qd >= 0 && qd < D) {
+            const size_t o = vol + ((size_t)qd * H + qh) * W + qw;
+            v = in[o];
+            // the first launch of a skeleton also files its input as img_0 (the chain and the backward pass index the stored chain)
+            if (copy0 && x >= K && x < K + SK_TW && y >= K && y < K + SK_TH && z >= K && z < K + SK_TD) copy0[o] = v;
+        }
+        A[i] = v;
+    }
+    __syncthreads();
+    erode_stage<K - 1>(A, Bf, w0, h0, d0, D, H, W, vol, outs, tid);
+    if constexpr (K >= 2) { __syncthreads(); erode_stage<K - 2>(Bf, A, w0, h0, d0, D, H, W, vol, outs + n, tid); }
+    if constexpr (K >= 3) { __syncthreads(); erode_stage<K - 3>(A, Bf, w0, h0, d0, D, H, W, vol, outs + 2 * n, tid); }
+    if constexpr (K >= 4) { __syncthreads(); erode_stage<K - 4>(Bf, A, w0, h0, d0, D, H, W, vol, outs + 3 * n, tid); }
+}
+template <int K>
+static void launch_erode_multi(const float* in, int D, int H, int W, int64_t n, float* outs, float* copy0, dim3 grid, hipStream_t s) {
+    constexpr int XD = SK_TD + 2 * K, XH = SK_TH + 2 * K, XW = SK_TW + 2 * K;
+    constexpr int lds = (XD * XH * XW + (XD - 2) * (XH - 2) * (XW - 2)) * 4;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)erode_multi_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, VG_LDS_LIMIT); attr = true; }
+    hipLaunchKernelGGL(erode_multi_kernel<K>, grid, dim3(256), lds, s, in, D, H, W, n, outs, copy0);
+}
 static dim3 skel_grid(int B, int D, int H, int W) {
     return dim3(((W + SK_TW - 1) / SK_TW) * ((H + SK_TH - 1) / SK_TH) * ((D + SK_TD - 1) / SK_TD), B);
 }
-extern "C" int vg_soft_skel_fwd(const float* img, int B, int D, int H, int W, int iters, float* imgs, float* skels,
-                                vg_stream_t stream) {
-    vg_begin();
-    if (!img || !imgs || !skels || B < 1 || iters < 0) return VG_EINVAL;
-    hipStream_t s = (hipStream_t)stream;
-    const int64_t n = (int64_t)B * D * H * W;
-    const int blocks = lblocks(n);
-    if (hipMemcpyAsync(imgs, img, n * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return VG_ELAUNCH;
-    (void)blocks;
-    const dim3 grid = skel_grid(B, D, H, W);
-    for (int j = 0; j <= iters; ++j)
-        hipLaunchKernelGGL(skel_tile_kernel<true>, grid, dim3(256), 0, s, imgs + j * n, (const float*)nullptr, (const float*)nullptr,
-                           D, H, W, imgs + (j + 1) * n);
-    if (vg_tune("SKEL_CHAIN", 1)) {
-        hipLaunchKernelGGL(skel_chain_kernel, grid, dim3(256), 0, s, (const float*)imgs, n, iters, D, H, W, skels);
-        return vg_check_launch();
-    }
-    for (int j = 0; j <= iters; ++j)
-        hipLaunchKernelGGL(skel_tile_kernel<false>, grid, dim3(256), 0, s, imgs + (j + 1) * n, imgs + j * n,
-                           j ? skels + (j - 1) * n : (const float*)nullptr, D, H, W, skels + j * n);
-    return vg_check_launch();
-}
-
 // ---- backward steps, LDS-tiled like the forward ones.  The pooling gradients go to the FIRST arg-min / arg-max in the
 // reference's scan order (ties: TP, tf max_pool3d / -max_pool3d(-x) gradients), so the candidates are visited in exactly
 // that order; outside the volume the tile holds +-inf, which a strict comparison never selects.
@@ -477,14 +555,6 @@ __device__ __forceinline__ void sk_load_tile(float (&t)[SK_TD + 2][SK_TH + 2][SK
         (&t[0][0][0])[i] = v;
     }
 }
-#define SK_TILE_ORIGIN()                                                                                    \
-    const int tiles_w = (W + SK_TW - 1) / SK_TW, tiles_h = (H + SK_TH - 1) / SK_TH;                           \
-    int bt_ = blockIdx.x; const int tw_ = bt_ % tiles_w; bt_ /= tiles_w;                                      \
-    const int th_ = bt_ % tiles_h, td_ = bt_ / tiles_h;                                                       \
-    const int w0 = tw_ * SK_TW, h0 = th_ * SK_TH, d0 = td_ * SK_TD;                                           \
-    const size_t vol = (size_t)blockIdx.y * D * H * W;                                                        \
-    const int tx = tid & (SK_TW - 1), ty = tid >> 5; const int gw = w0 + tx, gh = h0 + ty;
-
 // backward step j, part 1: local gradients of the skeleton update
 __global__ __launch_bounds__(256) void skel_bwd_local_kernel(const float* __restrict__ imgj, const float* __restrict__ imgj1,
                                                              const float* __restrict__ prev, int D, int H, int W,
@@ -561,8 +631,165 @@ __global__ __launch_bounds__(256) void erode_bwd_kernel(const float* __restrict_
         atomicAdd(&dimgj[(int64_t)i + o], g);
     }
 }
+
+
+// soft_erode with the code of the FIRST arg-min in the reference's scan order (TP: the windows (3,3,1), (3,1,3), (1,3,3) one after
+// the other, raster order inside each, strict <): per slice the first minimum of the H-column (b; c = 0), of the W-row (c; b = 0) and
+// of the whole 3 x 3 window; then set 1 = the three slices' columns in slice order, set 2 = the rows, set 3 = the centre slice's
+// window.  Values are those of skel_tile_kernel<true> (min is order-independent): the stored chain is bitwise the same.
+__global__ __launch_bounds__(256) void skel_erode_code_kernel(const float* __restrict__ in, int D, int H, int W, float* __restrict__ out,
+                                                              unsigned char* __restrict__ codes) {
+    __shared__ float t[SK_TD + 2][SK_TH + 2][SK_TW + 2];
+    const int tid = threadIdx.x;
+    SK_TILE_ORIGIN()
+    sk_load_tile(t, in, vol, w0, h0, d0, D, H, W, INFINITY, tid);
+    __syncthreads();
+    float vC[3], vR[3], vF[3]; int iC[3], iR[3], iF[3];
+#pragma unroll
+    for (int sl = 0; sl < SK_TD + 2; ++sl) {
+        const float a00 = t[sl][ty][tx], a01 = t[sl][ty][tx + 1], a02 = t[sl][ty][tx + 2];
+        const float a10 = t[sl][ty + 1][tx], a11 = t[sl][ty + 1][tx + 1], a12 = t[sl][ty + 1][tx + 2];
+        const float a20 = t[sl][ty + 2][tx], a21 = t[sl][ty + 2][tx + 1], a22 = t[sl][ty + 2][tx + 2];
+        { float m = a01; int k = 0; if (a11 < m) { m = a11; k = 1; } if (a21 < m) { m = a21; k = 2; } vC[sl % 3] = m; iC[sl % 3] = k; }      // (b, 0)
+        { float m = a10; int k = 0; if (a11 < m) { m = a11; k = 1; } if (a12 < m) { m = a12; k = 2; } vR[sl % 3] = m; iR[sl % 3] = k; }      // (0, c)
+        { float m = a00; int k = 0;
+          if (a01 < m) { m = a01; k = 1; } if (a02 < m) { m = a02; k = 2; }
+          if (a10 < m) { m = a10; k = 3; } if (a11 < m) { m = a11; k = 4; } if (a12 < m) { m = a12; k = 5; }
+          if (a20 < m) { m = a20; k = 6; } if (a21 < m) { m = a21; k = 7; } if (a22 < m) { m = a22; k = 8; }
+          vF[sl % 3] = m; iF[sl % 3] = k; }
+        if (sl >= 2) {
+            const int gd = d0 + sl - 2;
+            const int lo = (sl - 2) % 3, c = (sl - 1) % 3, hi = sl % 3;
+            float best = vC[lo]; int code = iC[lo] * 3 + 1;                                  // set 1: (a, b, 0)
+            if (vC[c] < best) { best = vC[c]; code = 9 + iC[c] * 3 + 1; }
+            if (vC[hi] < best) { best = vC[hi]; code = 18 + iC[hi] * 3 + 1; }
+            if (vR[lo] < best) { best = vR[lo]; code = 3 + iR[lo]; }                         // set 2: (a, 0, c)
+            if (vR[c] < best) { best = vR[c]; code = 12 + iR[c]; }
+            if (vR[hi] < best) { best = vR[hi]; code = 21 + iR[hi]; }
+            if (vF[c] < best) { best = vF[c]; code = 9 + iF[c]; }                            // set 3: (0, b, c)
+            if (gw < W && gh < H && gd < D) {
+                const size_t o = vol + ((size_t)gd * H + gh) * W + gw;
+                out[o] = best; codes[o] = (unsigned char)code;
+            }
+        }
+    }
+}
+
+// ---- backward from the stored codes (round 5): pure streaming launches, no neighbourhood scans ----
+// Launch F_k (k = iters + 1 ... 0) runs two independent pieces that both accumulate into d img_k:
+//   A (k <= iters): erosion transpose of step k,   d img_k[i + off(argmin code_k[i])] += d img_{k+1}[i]      (d img_{k+1} is complete)
+//   B (k >= 1):     local gradient of step j = k-1, e = e_j(i) from (delta_j, skel_{j-1}, gs); gs <- d skel_{j-1} in place;
+//                   d img_j[i] = e (first writer: plain store);   d img_k[i + off(argmax code_j[i])] -= e
+// d img_{k+1} gets its last contribution in F_{k+1}, so the launches only need stream order.  iters + 2 launches per skeleton instead of
+// 2 (iters + 1) + memset + final add; the atomics are the sparse ones (e != 0 only on thin structures).
+__device__ __forceinline__ int64_t sk_off(int code, int H, int W) {
+    const int a = code / 9, r = code - a * 9, b = r / 3, c = r - b * 3;
+    return ((int64_t)(a - 1) * H + (b - 1)) * W + (c - 1);
+}
+template <int V> __device__ __forceinline__ void sk_ldf(const float* p, int64_t q, float* o) {
+    if constexpr (V == 4) { const f32x4 v = ((const f32x4*)p)[q]; o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3]; } else o[0] = p[q];
+}
+template <int V> __device__ __forceinline__ void sk_stf(float* p, int64_t q, const float* o) {
+    if constexpr (V == 4) ((f32x4*)p)[q] = (f32x4){o[0], o[1], o[2], o[3]}; else p[q] = o[0];
+}
+template <int V> __device__ __forceinline__ void sk_ldc(const unsigned char* p, int64_t q, int* o) {
+    if constexpr (V == 4) { const unsigned w = ((const unsigned*)p)[q]; o[0] = w & 255; o[1] = (w >> 8) & 255; o[2] = (w >> 16) & 255; o[3] = w >> 24; }
+    else o[0] = p[q];
+}
+template <int V>
+__global__ __launch_bounds__(256) void skel_bwd_stream_kernel(const float* __restrict__ d_in, const unsigned char* __restrict__ codeN,
+                                                              float* d_acc, float* d_out, int out_accumulate,
+                                                              const float* __restrict__ delta, const unsigned char* __restrict__ codeM,
+                                                              const float* __restrict__ prev, const float* gs_in, float* gs_out,
+                                                              int64_t n, int H, int W) {
+    // V voxels per thread and iteration (V = 4: 16-byte loads / stores, 4-byte code loads; the caller guarantees n % 4 == 0)
+    const int64_t nv = n / V;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nv; q += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i0 = q * V;
+        float g_in[V], dl[V], sp[V], g[V]; int cn[V], cm[V];
+        if (d_in) { sk_ldf<V>(d_in, q, g_in); sk_ldc<V>(codeN, q, cn); }
+        if (delta) { sk_ldf<V>(delta, q, dl); sk_ldf<V>(gs_in, q, g); sk_ldc<V>(codeM, q, cm); if (prev) sk_ldf<V>(prev, q, sp); }
+        if (d_in) {                                               // piece A
+#pragma unroll
+            for (int v = 0; v < V; ++v)
+                if (g_in[v] != 0.f) atomicAdd(&d_acc[i0 + v + sk_off(cn[v], H, W)], g_in[v]);
+        }
+        if (delta) {                                              // piece B
+            float e[V], gn[V];
+            bool changed = false;
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                float ddelta; gn[v] = g[v];
+                if (prev) {
+                    const float u = dl[v] - sp[v] * dl[v];
+                    const float dr = u > 0.f ? g[v] : 0.f;
+                    ddelta = dr * (1.f - sp[v]);
+                    gn[v] = g[v] - dr * dl[v];                    // d skel_{j-1}
+                } else ddelta = g[v];
+                e[v] = dl[v] > 0.f ? ddelta : 0.f;                // delta > 0 <=> raw > 0
+                changed |= gn[v] != g[v];
+                if (e[v] != 0.f) atomicAdd(&d_acc[i0 + v + sk_off(cm[v], H, W)], -e[v]);
+            }
+            // gs only moves where the skeleton update was active (thin structures): elsewhere the line is not rewritten -- unless this
+            // launch is the one that copies the caller's gradient into the private buffer
+            if (prev && (changed || gs_in != gs_out)) sk_stf<V>(gs_out, q, gn);
+            if (out_accumulate) {
+                float o[V]; sk_ldf<V>(d_out, q, o);
+#pragma unroll
+                for (int v = 0; v < V; ++v) e[v] += o[v];
+            }
+            sk_stf<V>(d_out, q, e);
+        }
+    }
+}
+extern "C" int vg_soft_skel_fwd(const float* img, int B, int D, int H, int W, int iters, float* imgs, float* skels, void* aux,
+                                vg_stream_t stream) {
+    vg_begin();
+    if (!img || !imgs || !skels || B < 1 || iters < 0) return VG_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n = (int64_t)B * D * H * W;
+    const dim3 grid = skel_grid(B, D, H, W);
+    const int multi = vg_tune("SKEL_MULTI", 2);
+    // aux (the skeleton that will be differentiated): [iters+1][n] float delta | [iters+1][n] u8 arg-max codes | [iters+1][n] u8 arg-min codes
+    float* deltas = (float*)aux;
+    unsigned char* codeM = aux ? (unsigned char*)(deltas + (size_t)(iters + 1) * n) : nullptr;
+    unsigned char* codeN = aux ? codeM + (size_t)(iters + 1) * n : nullptr;
+    if (aux) {
+        if (hipMemcpyAsync(imgs, img, n * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return VG_ELAUNCH;
+        for (int j = 0; j <= iters; ++j)
+            hipLaunchKernelGGL(skel_erode_code_kernel, grid, dim3(256), 0, s, (const float*)(imgs + j * n), D, H, W, imgs + (j + 1) * n, codeN + (size_t)j * n);
+    } else if (multi > 1) {
+        // K erosions per launch; the first launch files its input as img_0 (no copy launch in front)
+        for (int j = 0; j <= iters;) {
+            const int left = iters + 1 - j;
+            const float* in = j ? imgs + j * n : img;
+            float* c0 = j ? nullptr : imgs;
+            if (left >= 4 && multi >= 4) { launch_erode_multi<4>(in, D, H, W, n, imgs + (j + 1) * n, c0, grid, s); j += 4; }
+            else if (left >= 2) { launch_erode_multi<2>(in, D, H, W, n, imgs + (j + 1) * n, c0, grid, s); j += 2; }
+            else { launch_erode_multi<1>(in, D, H, W, n, imgs + (j + 1) * n, c0, grid, s); j += 1; }
+        }
+    } else {
+        if (hipMemcpyAsync(imgs, img, n * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return VG_ELAUNCH;
+        for (int j = 0; j <= iters; ++j)
+            hipLaunchKernelGGL(skel_tile_kernel<true>, grid, dim3(256), 0, s, imgs + j * n, (const float*)nullptr, (const float*)nullptr,
+                               D, H, W, imgs + (j + 1) * n);
+    }
+    if (aux) {
+        hipLaunchKernelGGL(skel_chain_kernel<true>, grid, dim3(256), 0, s, (const float*)imgs, n, iters, D, H, W, skels, deltas, codeM);
+        return vg_check_launch();
+    }
+    if (vg_tune("SKEL_CHAIN", 1)) {
+        hipLaunchKernelGGL(skel_chain_kernel<false>, grid, dim3(256), 0, s, (const float*)imgs, n, iters, D, H, W, skels, (float*)nullptr, (unsigned char*)nullptr);
+        return vg_check_launch();
+    }
+    for (int j = 0; j <= iters; ++j)
+        hipLaunchKernelGGL(skel_tile_kernel<false>, grid, dim3(256), 0, s, imgs + (j + 1) * n, imgs + j * n,
+                           j ? skels + (j - 1) * n : (const float*)nullptr, D, H, W, skels + j * n);
+    return vg_check_launch();
+}
+
 extern "C" int vg_soft_skel_bwd(const float* imgs, const float* skels, const float* gskel, int B, int D, int H, int W,
-                                int iters, float* work, float* gimg, vg_stream_t stream) {
+                                int iters, float* work, float* gimg, const void* aux, vg_stream_t stream) {
     vg_begin();
     if (!imgs || !skels || !gskel || !work || !gimg || B < 1 || iters < 0) return VG_EINVAL;
     hipStream_t s = (hipStream_t)stream;
@@ -570,6 +797,31 @@ extern "C" int vg_soft_skel_bwd(const float* imgs, const float* skels, const flo
     const int blocks = lblocks(n);
     (void)blocks;
     const dim3 grid = skel_grid(B, D, H, W);
+    if (aux) {
+        // streaming launches F_{iters+1} ... F_0 over the codes the forward pass filed (see skel_bwd_stream_kernel)
+        const float* deltas = (const float*)aux;
+        const unsigned char* codeM = (const unsigned char*)(deltas + (size_t)(iters + 1) * n);
+        const unsigned char* codeN = codeM + (size_t)(iters + 1) * n;
+        float* gs = work;
+        float* d[3] = {work + n, work + 2 * n, work + 3 * n};
+        if (hipMemsetAsync(d[(iters + 1) % 3], 0, n * sizeof(float), s) != hipSuccess) return VG_ELAUNCH;       // d img_{iters+1}: only scattered into
+        const bool vec = (n % 4) == 0 && ((((uintptr_t)work | (uintptr_t)gimg | (uintptr_t)gskel | (uintptr_t)skels | (uintptr_t)aux) & 15) == 0);
+        const int blocks = lblocks(vec ? n / 4 : n);
+        for (int k = iters + 1; k >= 0; --k) {
+            const int j = k - 1;                                                  // piece B's step
+            const bool A = k <= iters, Bp = k >= 1;
+            float* d_acc = k == 0 ? gimg : d[k % 3];                              // d img_k (k = 0: straight into the caller's gradient)
+            float* d_out = j == 0 ? gimg : (Bp ? d[j % 3] : nullptr);             // d img_j
+#define SK_BWD_ARGS A ? (const float*)d[(k + 1) % 3] : (const float*)nullptr, A ? codeN + (size_t)k * n : (const unsigned char*)nullptr, \
+                    d_acc, d_out, j == 0 ? 1 : 0, Bp ? deltas + (size_t)j * n : (const float*)nullptr,                                \
+                    Bp ? codeM + (size_t)j * n : (const unsigned char*)nullptr,                                                        \
+                    (Bp && j > 0) ? skels + (size_t)(j - 1) * n : (const float*)nullptr, k == iters + 1 ? gskel : (const float*)gs, gs, n, H, W
+            if (vec) hipLaunchKernelGGL(skel_bwd_stream_kernel<4>, dim3(blocks), dim3(256), 0, s, SK_BWD_ARGS);
+            else hipLaunchKernelGGL(skel_bwd_stream_kernel<1>, dim3(blocks), dim3(256), 0, s, SK_BWD_ARGS);
+#undef SK_BWD_ARGS
+        }
+        return vg_check_launch();
+    }
     float* gs = work; float* bufA = work + n; float* bufB = work + 2 * n;     // bufA = d img_{j+1}, bufB = d img_j
     if (hipMemcpyAsync(gs, gskel, n * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return VG_ELAUNCH;
     if (hipMemsetAsync(bufA, 0, 2 * n * sizeof(float), s) != hipSuccess) return VG_ELAUNCH;

@@ -21,9 +21,12 @@ RING_WORLD = 8          # the node size the stand-in's hold time is priced for (
 class GradSync:
     """`fake` (default: VG_FAKE_AR=1, only with one process on a GPU): the data-parallel schedule runs for real with world == 1 --
     communication stream, per-bucket events, pieces, the engine's cross-step overlap -- and every all-reduce is replaced by
-    vg_local_exchange (include/vangan_hip.h): a device-local kernel on a second, inner stream (as ProcessGroupNCCL runs its
-    collectives on a stream of its own behind the caller's) that moves the bucket's bytes with VG_FAKE_AR_WG workgroups and holds
-    them for the time a ring over RING_WORLD GPUs would need at VG_FAKE_AR_GBPS GB/s of bus bandwidth (0: no hold).
+    vg_local_exchange (include/vangan_hip.h): a device-local kernel ON THE COMMUNICATION STREAM (torch >= 2.7 launches a
+    synchronous collective -- async_op=False, what start() issues -- on the caller's current stream; ProcessGroupNCCL's internal
+    stream only serves async_op=True) that moves the bucket's bytes with VG_FAKE_AR_WG workgroups and holds them for the time a
+    ring over RING_WORLD GPUs would need at VG_FAKE_AR_GBPS GB/s of bus bandwidth (0: no hold).  VG_FAKE_AR_INNER=1 puts the
+    kernel on a second stream behind the communication stream instead (older torch); VG_FAKE_AR_NULL=1 launches nothing (the
+    schedule alone: events, waits, cross-step mode).
     `stream`: run the communication on this stream instead of a new one (the engine passes its optimizer stream: the bucket's
     optimizer step is the only consumer, and HIP has 4 hardware queues for the streams of a process)."""
 
@@ -59,16 +62,22 @@ class GradSync:
         n = (t.numel() - lo) // 4 * 4
         if n <= 0:
             return
-        if self._inner is None:
-            self._inner = torch.cuda.Stream(device=t.device)
-        cur = torch.cuda.current_stream()
-        self._inner.wait_stream(cur)
         nbytes = 4 * n
+        self.moved_bytes += nbytes
+        if os.environ.get('VG_FAKE_AR_NULL', '0') == '1':
+            return
+        cur = torch.cuda.current_stream()
+        on = cur
+        if os.environ.get('VG_FAKE_AR_INNER', '0') == '1':
+            if self._inner is None:
+                self._inner = torch.cuda.Stream(device=t.device)
+            on = self._inner
+            on.wait_stream(cur)
         hold_us = int(nbytes * 2.0 * (RING_WORLD - 1) / RING_WORLD / (self._gbps * 1e3)) if self._gbps > 0 else 0
         _lib.check(_lib.lib.vg_local_exchange(a + 4 * lo, self._scratch.data_ptr(), n, self._wg, min(hold_us, 100000),
-                                              self._inner.cuda_stream), 'vg_local_exchange')
-        cur.wait_stream(self._inner)
-        self.moved_bytes += nbytes
+                                              on.cuda_stream), 'vg_local_exchange')
+        if on is not cur:
+            cur.wait_stream(on)
 
     def start(self, names: Iterable[str], also=None, lo: int = 0, hi: Optional[int] = None):
         """Issue the all-reduce of these buckets; on GPU it runs on the side stream behind everything already queued
@@ -120,9 +129,6 @@ class GradSync:
         return dict(zip(keys, t.cpu().tolist()))
 
     def broadcast_weights(self, src: int = 0):
-        if self.fake and self._inner is None:
-            # the first collective of a real run (this broadcast) is where ProcessGroupNCCL creates its internal stream
-            self._inner = torch.cuda.Stream(device=next(iter(self.buckets.values())).device)
         if self.world == 1 or self.weights is None:
             return
         for w in self.weights.values():

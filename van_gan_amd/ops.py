@@ -1115,14 +1115,22 @@ def ssim_bwd(t, p, part, dims, gscale, gp, accumulate=False):
     check(lib.vg_ssim_bwd(_p(t), _p(p), _p(part), B, D, H, W, gscale, _p(gp), int(accumulate), stream()), 'vg_ssim_bwd')
 
 
-def soft_skel_fwd(img, dims, iters, imgs, skels):
+def skel_aux_bytes(dims, iters) -> int:
+    """Size of the aux buffer of soft_skel_fwd / soft_skel_bwd (include/vangan_hip.h): delta (fp32) + two code bytes per voxel and step."""
     B, D, H, W = dims
-    check(lib.vg_soft_skel_fwd(_p(img), B, D, H, W, iters, _p(imgs), _p(skels), stream()), 'vg_soft_skel_fwd')
+    return (iters + 1) * B * D * H * W * 6
 
 
-def soft_skel_bwd(imgs, skels, gskel, dims, iters, work, gimg):
+def soft_skel_fwd(img, dims, iters, imgs, skels, aux=None):
     B, D, H, W = dims
-    check(lib.vg_soft_skel_bwd(_p(imgs), _p(skels), _p(gskel), B, D, H, W, iters, _p(work), _p(gimg), stream()),
+    assert aux is None or aux.numel() * aux.element_size() >= skel_aux_bytes(dims, iters)
+    check(lib.vg_soft_skel_fwd(_p(img), B, D, H, W, iters, _p(imgs), _p(skels), _p(aux), stream()), 'vg_soft_skel_fwd')
+
+
+def soft_skel_bwd(imgs, skels, gskel, dims, iters, work, gimg, aux=None):
+    B, D, H, W = dims
+    assert work.numel() >= (4 if aux is not None else 3) * B * D * H * W
+    check(lib.vg_soft_skel_bwd(_p(imgs), _p(skels), _p(gskel), B, D, H, W, iters, _p(work), _p(gimg), _p(aux), stream()),
           'vg_soft_skel_bwd')
 
 

@@ -29,6 +29,7 @@ _LAZY_AR = os.environ.get('VG_LAZY_AR', '1') != '0'
 _INLINE = int(os.environ.get('VG_WGRAD_INLINE', '2'))      # encoder blocks <= this and the stem; round 3 (DMA weight gradients): off 24.96, 1: 24.92, 2: 24.74, 3: 24.59, 4: 24.62 ms; round 4, final kernels, alternating: 2: 18.85 / 18.88 / 18.87, 3: 18.99 / 18.91 / 19.01
 _PAIR_BWD = os.environ.get('VG_PAIR_BWD', '1') != '0'       # one 2B-sample backward sweep per generator (both applications) instead of two
 _AR_SPLIT = os.environ.get('VG_AR_SPLIT', '1') != '0'       # world > 1: a generator's finished gradient suffix is all-reduced while its sweep still runs
+_SKEL_AUX = os.environ.get('VG_SKEL_AUX', '0') != '0'        # clDice backward from codes filed by the forward pass (streaming launches) instead of re-scanning
 _INTERLEAVE = os.environ.get('VG_INTERLEAVE', '0') != '0'   # the two lanes' enqueue sequences alternate block by block on the host: measured neutral (21.69 vs 21.63 ms), off
 
 
@@ -375,7 +376,9 @@ class VanGan:
             g_ncS = ar.alloc(vol, f32) if do_backward else None
             ops.bce(nS, ncS, acc[0:1], self.lambda_cycle / (B * S * gbs), g_ncS, accumulate=False)
             imgs_p, skels_p = ar.alloc((it + 2,) + vol, f32), ar.alloc((it + 1,) + vol, f32)
-            ops.soft_skel_fwd(ncS, dims4, it, imgs_p, skels_p)
+            # the predicted skeleton is differentiated: its forward pass files delta and the pooling arg-extrema codes (6 B per voxel and step)
+            aux_p = ar.alloc((ops.skel_aux_bytes(dims4, it),), torch.uint8) if (do_backward and _SKEL_AUX) else None
+            ops.soft_skel_fwd(ncS, dims4, it, imgs_p, skels_p, aux_p)
             if lane_b is not None:
                 lane_b.wait_event(ev_skel_t)
             skel_p, skel_t = skels_p[it], skels_t[it]
@@ -386,8 +389,8 @@ class VanGan:
             if do_backward:
                 gskel = ar.alloc(vol, f32)
                 ops.cldice_grads(nS, skel_t, coef, gskel, g_ncS, accumulate=True)
-                work = ar.alloc((3,) + vol, f32)
-                ops.soft_skel_bwd(imgs_p, skels_p, gskel, dims4, it, work, g_ncS)
+                work = ar.alloc((4,) + vol, f32)
+                ops.soft_skel_bwd(imgs_p, skels_p, gskel, dims4, it, work, g_ncS, aux_p)
                 g_cS = gS2[B:]
                 tmp2 = ar.alloc((B, 2), f32, zero=True)
                 ops.minmax_bwd(cyc_S, ncS, g_ncS, mmcS, B, S, tmp2, g_cS)
