@@ -291,6 +291,13 @@ int vg_shortcut_dgrad_concat_norm(const vg_conv_desc* d, const vg_actnorm_bwd_de
 int vg_affine_add(const void* a, const float* a_scale, const float* a_shift, int a_act, const void* b, const float* b_scale,
                   const float* b_shift, int N, int64_t S, int C, void* out, int f32, vg_stream_t stream);
 
+/* db[c] += sum_rows dy[row][c]: the bias gradient of a layer from its output gradient dy [rows][C] (bf16, or float when f32).
+ * Conv3D's comes out of vg_conv3d_wgrad; this entry serves the k2 s2 Conv3DTranspose of the 'deconv' decoder (resunet_model.py:168-174,
+ * vnet_model.py:244-245), whose forward IS the strided data gradient of vg_conv3d (output-parity classes, one tap each, bias in the
+ * epilogue), whose data gradient is the forward convolution with the same packed weights and whose kernel gradient is
+ * vg_conv3d_wgrad with the roles of input and output gradient exchanged (van_gan_amd.ops.ConvTranspose3dK2S2 is the recipe). */
+int vg_bias_grad(const void* dy, int f32, int64_t rows, int C, float* db, vg_stream_t stream);
+
 /* d_pre = dy * (1 - y*y)   (tanh output activation, resunet_model.py:245), all fp32 */
 int vg_tanh_bwd(const float* dy, const float* y, float* dpre, int64_t n, vg_stream_t stream);
 

@@ -207,6 +207,42 @@ def test_conv_virtual_concat_residual_noise_tanh():
     assert rel_l2(o2, y2) < 1e-4
 
 
+@pytest.mark.parametrize('cin,filters,dims,N', [(32, 16, (8, 8, 8), 2), (128, 64, (4, 6, 8), 1), (256, 128, (4, 4, 4), 2), (48, 16, (16, 16, 16), 1)])
+def test_conv3d_transpose_k2s2(cin, filters, dims, N):
+    """the k2 s2 Conv3DTranspose of the 'deconv' decoder (resunet_model.py:168-174, vnet_model.py:244-245) as a recipe over
+    the strided data gradient (ops.ConvTranspose3dK2S2): forward + bias, data gradient, kernel and bias gradients against
+    F.conv_transpose3d / autograd through the oracle restatement, on identical bf16-rounded operands."""
+    from van_gan_amd import ops
+    from van_gan_amd.nets import ParamStore
+    dev = _dev()
+    g = torch.Generator().manual_seed(11)
+    st = ParamStore([('up.w', (2, 2, 2, filters, cin), 'x'), ('up.b', (filters,), 'x')], dev)
+    w = torch.randn(2, 2, 2, filters, cin, generator=g) / math.sqrt(cin)
+    b = torch.randn(filters, generator=g) * 0.1
+    st.load({'up.w': w, 'up.b': b})
+    lay = ops.ConvTranspose3dK2S2(st, 'up', cin, filters, dims)
+    lay.pack()
+    x = torch.randn(N, *dims, cin, generator=g).to(torch.bfloat16)
+    odims = tuple(2 * n for n in dims)
+    y = torch.full((N,) + odims + (filters,), 7.0, dtype=torch.bfloat16, device=dev)
+    lay.forward(x.to(dev), N, y)
+    dy = torch.randn(N, *odims, filters, generator=g).to(torch.bfloat16)
+    dx = torch.full((N,) + dims + (cin,), 7.0, dtype=torch.bfloat16, device=dev)
+    st.g.zero_()
+    lay.backward(x.to(dev), dy.to(dev), N, dx)
+    ops.side_join()
+    torch.cuda.synchronize()
+    xr = O.to_ncdhw(x.double()).requires_grad_(True)
+    wr = bf(w.double()).requires_grad_(True)
+    br = b.double().requires_grad_(True)
+    ref = O.conv3d_transpose_k2s2(xr, wr, br)
+    close_bf16(y, O.to_ndhwc(ref.detach()), 'Conv3DTranspose forward')
+    (ref * O.to_ncdhw(dy.double())).sum().backward()
+    close_bf16(dx, O.to_ndhwc(xr.grad), 'Conv3DTranspose data gradient')
+    assert rel_l2(st.grad('up.w'), wr.grad) < 2e-3
+    assert rel_l2(st.grad('up.b'), br.grad) < 2e-3
+
+
 def test_in_finalize_and_actnorm_bwd():
     """InstanceNorm scale/shift + (IN -> ReLU) backward with the reflect-pad transpose, vs autograd."""
     from van_gan_amd import ops

@@ -511,6 +511,38 @@ __global__ void bf16_to_f32_kernel(const bf16_t* x, float* y, int64_t n) {
 }
 static inline int ew_blocks(int64_t n) { int64_t b = (n + 255) / 256; return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b)); }
 
+// db[c] += sum over rows of dy[row][c] (bias gradient of a layer whose output gradient is dy: the k2 s2 Conv3DTranspose).  A block
+// walks a strided set of rows with C-contiguous lanes, sums in registers, then per channel through LDS; one atomic per (block, channel).
+template <typename T>
+__global__ __launch_bounds__(256) void bias_grad_kernel(const T* __restrict__ dy, int64_t rows, int C, float* db) {
+    __shared__ float sm[256];
+    const int lanes_per_row = C < 256 ? C : 256;                   // C <= 256: 256 / C rows in flight per block iteration
+    const int rpb = 256 / lanes_per_row;
+    const int c = threadIdx.x % lanes_per_row, r0 = threadIdx.x / lanes_per_row;
+    for (int cb = 0; cb < C; cb += lanes_per_row) {
+        float a = 0.f;
+        if (r0 < rpb && cb + c < C)
+            for (int64_t r = (int64_t)blockIdx.x * rpb + r0; r < rows; r += (int64_t)gridDim.x * rpb) a += ld1<T>(dy + r * C + cb + c);
+        sm[threadIdx.x] = a;
+        __syncthreads();
+        if (threadIdx.x < lanes_per_row && cb + threadIdx.x < C) {
+            float t = 0.f;
+            for (int k = 0; k < rpb; ++k) t += sm[k * lanes_per_row + threadIdx.x];
+            atomicAdd(&db[cb + threadIdx.x], t);
+        }
+        __syncthreads();
+    }
+}
+extern "C" int vg_bias_grad(const void* dy, int f32, int64_t rows, int C, float* db, vg_stream_t stream) {
+    vg_begin();
+    if (!dy || !db || rows < 1 || C < 1) return VG_EINVAL;
+    const int rpb = 256 / (C < 256 ? C : 256);
+    int64_t b = (rows + rpb - 1) / rpb; if (b > 1023) b = 1023;
+    if (f32) hipLaunchKernelGGL(bias_grad_kernel<float>, dim3((int)b), dim3(256), 0, (hipStream_t)stream, (const float*)dy, rows, C, db);
+    else hipLaunchKernelGGL(bias_grad_kernel<bf16_t>, dim3((int)b), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, rows, C, db);
+    return vg_check_launch();
+}
+
 extern "C" int vg_tanh_bwd(const float* dy, const float* y, float* dpre, int64_t n, vg_stream_t stream) {
     vg_begin();
     if (!dy || !y || !dpre || n < 0) return VG_EINVAL;

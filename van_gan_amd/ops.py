@@ -825,7 +825,7 @@ class ConvLayer:
         d.out, d.out_f32, d.accumulate = _p(out), int(out.dtype == torch.float32), int(accumulate)
         return d
 
-    def dgrad(self, dy: torch.Tensor, N: int, out: torch.Tensor, accumulate: bool, bstat=None) -> bool:
+    def dgrad(self, dy: torch.Tensor, N: int, out: torch.Tensor, accumulate: bool, bstat=None, bias=None) -> bool:
         """d/d input: writes the reflect-PADDED grid for 'reflect' convs (fold it with actnorm_bwd), the plain
         input grid for 'same' convs.  out: [N, *buf_dims, cin] bf16 (or f32 when cin==1).
         bstat: the actnorm_desc() of the IN backward that consumes `out` (bstat.g is out): when the data gradient is ONE launch,
@@ -851,6 +851,7 @@ class ConvLayer:
             d.src_f32 = int(dy.dtype == torch.float32 and self.cout == 1)
             d.out, d.out_f32, d.accumulate = _p(out), int(out.dtype == torch.float32), int(accumulate)
             d.bstat = C.addressof(bstat) if use_bs else None
+            d.bias = _p(bias)                 # (only the transposed-convolution use of this launch has one: ConvTranspose3dK2S2)
             s_ = stream()
             conv_scratch(d, s_, out.device.index)
             e0 = PROF.begin() if PROF is not None else None
@@ -883,6 +884,7 @@ class ConvLayer:
             d.src_f32 = int(dy.dtype == torch.float32 and self.cout == 1)
             d.out, d.out_f32, d.accumulate = _p(out), int(out.dtype == torch.float32), int(accumulate)
             d.bstat = C.addressof(bstat) if use_bs else None
+            d.bias = _p(bias)
             s_ = stream()
             conv_scratch(d, s_, out.device.index)
             e0 = PROF.begin() if PROF is not None else None
@@ -968,6 +970,40 @@ class ConvLayer:
                 check(rc, 'vg_shortcut_dgrad_concat ' + self.name)
         self.dgrad(dy, N, dcat, accumulate=True)
         concat_bwd(dcat, (N,) + tuple(self.in_dims), c_low, self.cin - c_low, dlow, dskip, acc_low=acc_low, acc_skip=acc_skip)
+
+
+class ConvTranspose3dK2S2:
+    """``Conv3DTranspose(filters, (2, 2, 2), strides=(2, 2, 2))`` of the reference's 'deconv' decoder (resunet_model.py:168-174 with
+    padding='valid', vnet_model.py:244-245 with 'same' -- the same thing for k = s) as a recipe over the existing entry points
+    (SURVEY 8(f)4).  TF defines conv_transpose as the gradient of conv w.r.t. its input with the kernel stored [kd][kh][kw][out][in]:
+    byte for byte the DHWIO kernel of a k2 s2 Conv3D from `filters` to `cin` channels, so
+      forward            = that Conv3D's strided DATA GRADIENT (8 output-parity classes of one tap each in one launch) + bias,
+      data gradient      = that Conv3D's FORWARD over the upstream gradient,
+      kernel gradient    = that Conv3D's WEIGHT gradient with the roles exchanged (source: upstream gradient, "dy": the layer's input),
+      bias gradient      = vg_bias_grad.
+    store parameters: name + '.w' [2,2,2,filters,cin] (Keras layout), name + '.b' [filters].  in_dims: the layer's INPUT grid."""
+
+    def __init__(self, store, name: str, cin: int, filters: int, in_dims: Tuple[int, int, int], dtype: torch.dtype = torch.bfloat16):
+        self.cin, self.filters, self.in_dims, self.out_dims = cin, filters, tuple(in_dims), tuple(2 * n for n in in_dims)
+        self.conv = ConvLayer(store, name, 2, filters, cin, 2, 'same', False, self.out_dims, need_dgrad=True, dtype=dtype)
+        self.b, self.gb = store.param(name + '.b'), store.grad(name + '.b')
+
+    def pack(self):
+        self.conv.pack()
+
+    def forward(self, x: torch.Tensor, N: int, out: torch.Tensor):
+        """x [N, *in_dims, cin] -> out [N, *2 in_dims, filters] (both in the network's 16-bit / exact-parity storage type)."""
+        assert tuple(x.shape) == (N,) + self.in_dims + (self.cin,) and tuple(out.shape) == (N,) + self.out_dims + (self.filters,)
+        self.conv.dgrad(x, N, out, accumulate=False, bias=self.b)
+
+    def backward(self, x: torch.Tensor, dy: torch.Tensor, N: int, dx: Optional[torch.Tensor]):
+        """dy [N, *2 in_dims, filters]: adds the kernel / bias gradients to the store's gradient buffers; dx [N, *in_dims, cin] (or None)."""
+        src = Src(dy, (N,) + self.out_dims, self.filters, f32=False)
+        if dx is not None:
+            self.conv.forward(src, dx)
+        self.conv.wgrad(src, x)
+        check(lib.vg_bias_grad(_p(dy), int(dy.dtype == torch.float32), N * math.prod(self.out_dims), self.filters, _p(self.gb), stream()),
+              'vg_bias_grad')
 
 
 class PackTable:
