@@ -81,9 +81,13 @@ def time_infer(eng, device, steps, warmup, precision):
             'generator_tflops': 50 * 2 * 149.65e9 / el / 1e12, 'windows': 50, 'steps': steps, 'finite': bool(torch.isfinite(out).all())}
 
 
-def time_config(dims, B, device, steps=20, warmup=5):
+def time_config(dims, B, device, steps=20, warmup=5, graph=True):
     """BASELINE configs 2 and 3 beside the headline: a full train_step at another patch size / batch on a fresh engine
-    (same kernels, same schedule, noise + dropout + clDice on), timed like the headline loop."""
+    (same kernels, same schedule, noise + dropout + clDice on), timed like the headline loop -- enqueued launch by launch
+    (`eager_ms_per_step`) and as replays of the step's recorded launch list (`replay_ms_per_step`, VanGan.train_step_replay: the same
+    kernels, streams and dependencies re-issued without the Python that builds them, the host refreshing a 32-byte parameter block per
+    step).  `ms_per_step` is the faster of the two paths and `path` names it.  (A HIP graph of the step -- VanGan.train_step_graph --
+    is correct and slower than either on ROCm 7.2: DESIGN 6.19.)"""
     import torch
     from van_gan_amd import VanGan
     eng = VanGan(dims, batch_size=B, device=device, seed=0)
@@ -97,11 +101,30 @@ def time_config(dims, B, device, steps=20, warmup=5):
         res = eng.train_step(rI, rS, sync=(i == steps - 1))
     torch.cuda.synchronize()
     el = (time.perf_counter() - t0) / steps
+    eager_ms, g_ms, g_err = el * 1e3, None, None
+    finite = all(v == v and abs(v) != float('inf') for v in res.values())
+    if graph:
+        try:
+            for _ in range(warmup):
+                eng.train_step_replay(rI, rS, sync=False)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                resg = eng.train_step_replay(rI, rS, sync=(i == steps - 1))
+            torch.cuda.synchronize()
+            g_ms = (time.perf_counter() - t0) / steps * 1e3
+            finite = finite and all(v == v and abs(v) != float('inf') for v in resg.values())
+            if g_ms < eager_ms:
+                el = g_ms * 1e-3
+        except Exception as e:              # the eager figure stands; the reason is on the line
+            g_err = '%s: %s' % (type(e).__name__, str(e)[:300])
     S = dims[0] * dims[1] * dims[2]
     out = {'workload': 'VanGan.train_step, %dx%dx%d volumes, batch %d, bf16, clDice on, disc noise+dropout on' % (dims + (B,)),
-           'ms_per_step': el * 1e3, 'train_steps_per_sec': 1.0 / el, 'Mvoxels_per_sec': B * S / el / 1e6,
+           'ms_per_step': el * 1e3, 'path': 'launch-list replay' if (g_ms is not None and g_ms < eager_ms) else 'eager enqueue',
+           'eager_ms_per_step': eager_ms, 'replay_ms_per_step': g_ms, 'replay_error': g_err,
+           'train_steps_per_sec': 1.0 / el, 'Mvoxels_per_sec': B * S / el / 1e6,
            'whole_step_conv_tflops': B * S * CONV_FLOP_PER_VOXEL / el / 1e12, 'steps': steps, 'warmup': warmup,
-           'finite': all(v == v and abs(v) != float('inf') for v in res.values()), 'arena_peak_gb': eng.arena.peak / 1e9}
+           'finite': finite, 'arena_peak_gb': eng.arena.peak / 1e9}
     del eng
     torch.cuda.empty_cache()
     return out
@@ -217,6 +240,8 @@ def main():
     ap.add_argument('--no-configs', action='store_true', help='skip the configs array (BASELINE configs 2 and 3) of the default N=1 line')
     ap.add_argument('--no-synced', action='store_true', help='skip the second timed loop that reads the 10 result scalars every step')
     ap.add_argument('--no-infer', action='store_true', help='skip the inference object (config 5) of the default N=1 line')
+    ap.add_argument('--no-replay', action='store_true', help='skip the launch-list replay figure (replay_ms_per_step) of the N=1 line')
+    ap.add_argument('--graph', action='store_true', help='also time the headline workload as HIP-graph replays (reported as graph_ms_per_step; the headline value stays the eager loop)')
     ap.add_argument('--no-ddp-path', action='store_true', help='skip the ddp_path object (the data-parallel schedule with a stand-in all-reduce, in a child process) of the default N=1 line')
     ap.add_argument('--ddp-fake', action='store_true', help='(child mode of ddp_path) time the data-parallel schedule on one GPU with vg_local_exchange in place of the all-reduce')
     args = ap.parse_args()
@@ -301,6 +326,27 @@ def main():
             eng.train_step(rI, rS, sync=True)
         torch.cuda.synchronize()
         ms_synced = (time.perf_counter() - t1) / ns * 1e3
+    graph_ms = replay_ms = None
+    if rank == 0 and world == 1 and not args.no_replay:
+        # the same step re-issued from its recorded launch list (VanGan.train_step_replay): what the host-bound configurations gain
+        for _ in range(args.warmup):
+            eng.train_step_replay(rI, rS, sync=False)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            eng.train_step_replay(rI, rS, sync=(i == args.steps - 1))
+        torch.cuda.synchronize()
+        replay_ms = (time.perf_counter() - t1) / args.steps * 1e3
+    if args.graph and world == 1:
+        eng.capture_train_step()
+        for _ in range(args.warmup):
+            eng.train_step_graph(rI, rS, sync=False)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            eng.train_step_graph(rI, rS, sync=(i == args.steps - 1))
+        torch.cuda.synchronize()
+        graph_ms = (time.perf_counter() - t1) / args.steps * 1e3
     configs = None
     if rank == 0 and world == 1 and args.size == 128 and not args.no_configs:
         configs = [time_config((64, 64, 64), 2, device), time_config((128, 128, 64), 2, device)]
@@ -389,7 +435,7 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
             'config': {'workload': 'VanGan.train_step, %dx%dx%d volumes, batch %d per GPU (global %d), clDice on, disc noise+dropout on'
                                    % (dims + (B, gbatch)), 'parallelism': 'dp%d' % world},
-            'ms_per_step_synced': ms_synced, 'configs': configs,
+            'ms_per_step_synced': ms_synced, 'replay_ms_per_step': replay_ms, 'graph_ms_per_step': graph_ms, 'configs': configs,
             'losses': res, 'roofline': roof, 'cpu_baseline': cpu, 'inference': infer,
             'arena_peak_gb': eng.arena.peak / 1e9, 'ddp_path': ddp,
         }

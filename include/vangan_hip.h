@@ -375,6 +375,17 @@ int vg_adam_clip(float* w, const float* g, float* m, float* v, const int64_t* se
                  int64_t total, float* norms, float lr_t, float beta1, float beta2, float eps,
                  float clipnorm, float grad_scale, vg_stream_t stream);
 
+/* The three entry points whose per-step host scalars change from step to step -- the Philox counter, the noise standard deviation
+ * (GanMonitor decays it per epoch, custom_callback.py:413-424) and Adam's bias-corrected rate lr_t -- with those scalars read from
+ * DEVICE memory: a HIP graph captured over one VanGan.train_step (vangan.py:380-440) is then replayable, the host refreshing a
+ * 32-byte parameter block before each replay instead of re-enqueueing ~900 launches.  offset = *offset_dev + offset_add. */
+int vg_randn_bf16_dev(void* out, int64_t n, const float* std_dev, uint64_t seed, const uint64_t* offset_dev, uint64_t offset_add,
+                      vg_stream_t stream);
+int vg_dropout_mask_dev(float* out, int64_t n, float rate, uint64_t seed, const uint64_t* offset_dev, uint64_t offset_add,
+                        vg_stream_t stream);
+int vg_adam_clip_dev(float* w, const float* g, float* m, float* v, const int64_t* seg_off_dev, int T, int64_t total, float* norms,
+                     const float* lr_t_dev, float beta1, float beta2, float eps, float clipnorm, float grad_scale, vg_stream_t stream);
+
 /* Stand-in for the RCCL SUM all-reduce of a gradient bucket (the implicit all-reduce of optimizer.minimize under MirroredStrategy,
  * vangan.py:426-438; main.py:22) on a box with ONE GPU, so that the data-parallel schedule -- communication stream, per-bucket
  * events, early suffix pieces, cross-step optimizer overlap -- can be timed without a second device: `workgroups` workgroups (RCCL
@@ -400,6 +411,11 @@ int vg_crop_augment(const float* vol, int X, int Y, int Z, int C, int x0, int y0
                     int flip_lr, int flip_ud, int rot_k, float* out, vg_stream_t stream);
 int vg_crop_max(const float* vol, int X, int Y, int Z, int C, int x0, int y0, int z0, int px, int py, int pz,
                 float* out, vg_stream_t stream);
+
+/* Device memset-to-zero / device-to-device copy on an explicit stream (hipMemsetAsync / hipMemcpyAsync): what a recorded launch list
+ * (van_gan_amd.VanGan.record_train_step) replays in place of torch's zero_() / copy_(), which would go to torch's current stream. */
+int vg_memset_zero(void* p, int64_t nbytes, vg_stream_t stream);
+int vg_copy_bytes(void* dst, const void* src, int64_t nbytes, vg_stream_t stream);
 
 /* f32 <-> bf16 copies */
 int vg_f32_to_bf16(const float* x, void* y, int64_t n, vg_stream_t stream);

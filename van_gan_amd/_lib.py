@@ -111,6 +111,12 @@ _SIGS = {
     'vg_local_exchange': ([c_void_p, c_void_p, c_i64, c_int, c_int, c_void_p], c_int),
     'vg_randn_bf16': ([c_void_p, c_i64, c_float, c_u64, c_u64, c_void_p], c_int),
     'vg_dropout_mask': ([c_void_p, c_i64, c_float, c_u64, c_u64, c_void_p], c_int),
+    'vg_randn_bf16_dev': ([c_void_p, c_i64, c_void_p, c_u64, c_void_p, c_u64, c_void_p], c_int),
+    'vg_dropout_mask_dev': ([c_void_p, c_i64, c_float, c_u64, c_void_p, c_u64, c_void_p], c_int),
+    'vg_adam_clip_dev': ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_i64, c_void_p, c_void_p, c_float,
+                          c_float, c_float, c_float, c_float, c_void_p], c_int),
+    'vg_memset_zero': ([c_void_p, c_i64, c_void_p], c_int),
+    'vg_copy_bytes': ([c_void_p, c_void_p, c_i64, c_void_p], c_int),
     'vg_f32_to_bf16': ([c_void_p, c_void_p, c_i64, c_void_p], c_int),
     'vg_bf16_to_f32': ([c_void_p, c_void_p, c_i64, c_void_p], c_int),
 }

@@ -87,8 +87,9 @@ __device__ __forceinline__ void adam_elem(float& w, float g, float& m, float& v,
 
 __global__ __launch_bounds__(256) void adam_kernel(float* w, const float* g, float* m, float* v, const int64_t* off, int T,
                                                    int64_t total, float* norms, const float* bp, float lr_t, float b1, float b2, float eps,
-                                                   float clip, float scale) {
+                                                   float clip, float scale, const float* lr_dev) {
     __shared__ float red[4];
+    if (lr_dev) lr_t = *lr_dev;                    // the bias-corrected rate of THIS step from device memory (replayable graphs)
     const int tid = threadIdx.x;
     const int64_t s0 = (int64_t)blockIdx.x * ADAM_SPAN;
     const int64_t s1 = s0 + ADAM_SPAN < total ? s0 + ADAM_SPAN : total;
@@ -123,9 +124,21 @@ __global__ __launch_bounds__(256) void adam_kernel(float* w, const float* g, flo
         for (int64_t i = lo + tid; i < hi; i += 256) adam_elem(w[i], g[i] * scale, m[i], v[i], f, lr_t, b1, b2, eps);
     }
 }
+static int adam_launch(float* w, const float* g, float* m, float* v, const int64_t* seg_off_dev, int T, int64_t total, float* norms, float lr_t,
+                       const float* lr_dev, float beta1, float beta2, float eps, float clipnorm, float grad_scale, vg_stream_t stream);
 extern "C" int vg_adam_clip(float* w, const float* g, float* m, float* v, const int64_t* seg_off_dev, int T, int64_t total,
                             float* norms, float lr_t, float beta1, float beta2, float eps, float clipnorm, float grad_scale,
                             vg_stream_t stream) {
+    return adam_launch(w, g, m, v, seg_off_dev, T, total, norms, lr_t, nullptr, beta1, beta2, eps, clipnorm, grad_scale, stream);
+}
+extern "C" int vg_adam_clip_dev(float* w, const float* g, float* m, float* v, const int64_t* seg_off_dev, int T, int64_t total,
+                                float* norms, const float* lr_t_dev, float beta1, float beta2, float eps, float clipnorm, float grad_scale,
+                                vg_stream_t stream) {
+    if (!lr_t_dev) return VG_EINVAL;
+    return adam_launch(w, g, m, v, seg_off_dev, T, total, norms, 0.f, lr_t_dev, beta1, beta2, eps, clipnorm, grad_scale, stream);
+}
+static int adam_launch(float* w, const float* g, float* m, float* v, const int64_t* seg_off_dev, int T, int64_t total, float* norms, float lr_t,
+                       const float* lr_dev, float beta1, float beta2, float eps, float clipnorm, float grad_scale, vg_stream_t stream) {
     vg_begin();
     if (!w || !g || !m || !v || !seg_off_dev || !norms || T < 1 || total < 1) return VG_EINVAL;
     hipStream_t s = (hipStream_t)stream;
@@ -133,7 +146,7 @@ extern "C" int vg_adam_clip(float* w, const float* g, float* m, float* v, const 
     float* bp = norms + T;                       // [blocks][2] per-block partials of the tensors that span several blocks
     hipLaunchKernelGGL(sqnorm_kernel, dim3(blocks), dim3(256), 0, s, g, seg_off_dev, T, total, grad_scale, norms, bp);
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, s, w, g, m, v, seg_off_dev, T, total, norms, bp, lr_t, beta1, beta2, eps,
-                       clipnorm, grad_scale);
+                       clipnorm, grad_scale, lr_dev);
     return vg_check_launch();
 }
 

@@ -621,7 +621,9 @@ __device__ __forceinline__ void philox4(uint32_t c[4], uint32_t k0, uint32_t k1)
 }
 __device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
 
-__global__ void randn_bf16_kernel(bf16_t* out, int64_t n, float std, uint64_t seed, uint64_t offset) {
+__global__ void randn_bf16_kernel(bf16_t* out, int64_t n, float std, uint64_t seed, uint64_t offset, const float* std_dev, const uint64_t* off_dev) {
+    if (std_dev) std = *std_dev;                  // per-step scalars from device memory: a captured graph of the step stays replayable
+    if (off_dev) offset += *off_dev;
     const int64_t nq = (n + 3) / 4;
     for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (int64_t)gridDim.x * blockDim.x) {
         const uint64_t ctr = offset + (uint64_t)q;
@@ -633,7 +635,8 @@ __global__ void randn_bf16_kernel(bf16_t* out, int64_t n, float std, uint64_t se
         for (int j = 0; j < 4; ++j) if (q * 4 + j < n) out[q * 4 + j] = f2bf(std * z[j]);
     }
 }
-__global__ void dropout_mask_kernel(float* out, int64_t n, float rate, uint64_t seed, uint64_t offset) {
+__global__ void dropout_mask_kernel(float* out, int64_t n, float rate, uint64_t seed, uint64_t offset, const uint64_t* off_dev) {
+    if (off_dev) offset += *off_dev;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const uint64_t ctr = offset + (uint64_t)i;
         uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0xd60bu, 0u};
@@ -644,14 +647,45 @@ __global__ void dropout_mask_kernel(float* out, int64_t n, float rate, uint64_t 
 extern "C" int vg_randn_bf16(void* out, int64_t n, float std, uint64_t seed, uint64_t offset, vg_stream_t stream) {
     vg_begin();
     if (!out || n < 0) return VG_EINVAL;
-    hipLaunchKernelGGL(randn_bf16_kernel, dim3(ew_blocks((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)out, n, std, seed, offset);
+    hipLaunchKernelGGL(randn_bf16_kernel, dim3(ew_blocks((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)out, n, std, seed, offset,
+                       (const float*)nullptr, (const uint64_t*)nullptr);
+    return vg_check_launch();
+}
+extern "C" int vg_randn_bf16_dev(void* out, int64_t n, const float* std_dev, uint64_t seed, const uint64_t* offset_dev, uint64_t offset_add,
+                                 vg_stream_t stream) {
+    vg_begin();
+    if (!out || n < 0 || !std_dev || !offset_dev) return VG_EINVAL;
+    hipLaunchKernelGGL(randn_bf16_kernel, dim3(ew_blocks((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)out, n, 0.f, seed, offset_add,
+                       std_dev, offset_dev);
     return vg_check_launch();
 }
 extern "C" int vg_dropout_mask(float* out, int64_t n, float rate, uint64_t seed, uint64_t offset, vg_stream_t stream) {
     vg_begin();
     if (!out || n < 0 || rate < 0.f || rate >= 1.f) return VG_EINVAL;
-    hipLaunchKernelGGL(dropout_mask_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, out, n, rate, seed, offset);
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, out, n, rate, seed, offset, (const uint64_t*)nullptr);
     return vg_check_launch();
+}
+extern "C" int vg_dropout_mask_dev(float* out, int64_t n, float rate, uint64_t seed, const uint64_t* offset_dev, uint64_t offset_add,
+                                   vg_stream_t stream) {
+    vg_begin();
+    if (!out || n < 0 || rate < 0.f || rate >= 1.f || !offset_dev) return VG_EINVAL;
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, out, n, rate, seed, offset_add, offset_dev);
+    return vg_check_launch();
+}
+
+// Plumbing with an explicit stream (a recorded launch list replays these instead of torch's zero_() / copy_(), which go to torch's
+// CURRENT stream): enqueue-only, caller-owned memory.
+extern "C" int vg_memset_zero(void* p, int64_t nbytes, vg_stream_t stream) {
+    vg_begin();
+    if (!p || nbytes < 0) return VG_EINVAL;
+    if (nbytes == 0) return VG_OK;
+    return hipMemsetAsync(p, 0, (size_t)nbytes, (hipStream_t)stream) == hipSuccess ? VG_OK : VG_ELAUNCH;
+}
+extern "C" int vg_copy_bytes(void* dst, const void* src, int64_t nbytes, vg_stream_t stream) {
+    vg_begin();
+    if (!dst || !src || nbytes < 0) return VG_EINVAL;
+    if (nbytes == 0) return VG_OK;
+    return hipMemcpyAsync(dst, src, (size_t)nbytes, hipMemcpyDeviceToDevice, (hipStream_t)stream) == hipSuccess ? VG_OK : VG_ELAUNCH;
 }
 
 extern "C" const char* vg_status_string(int code) {

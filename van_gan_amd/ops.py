@@ -111,6 +111,95 @@ class DryRun:
 DRY: Optional[DryRun] = None
 
 
+class Recorder:
+    """Context manager: every libvangan_hip.so call made through this module is executed AND appended to a launch list
+    (function, marshalled arguments -- device addresses, descriptors, the raw stream handle), together with the stream
+    dependencies issued through wait_stream / wait_event / record_event below.  A train step's list is a pure function of the
+    engine's static workspace, so replaying it (VanGan.train_step_replay) re-enqueues the step -- same kernels, same streams, same
+    dependencies -- without running the ~8 ms of Python that builds ~900 descriptors; the per-step scalars come from the device
+    parameter block (the *_dev entry points).  Unlike a HIP graph of the same step (VanGan.capture_train_step: correct, but
+    hipGraphLaunch serialises most of the lanes' overlap on ROCm 7.2 and costs ~4 ms per step) the replay keeps the eager schedule."""
+
+    _PURE = DryRun._PASS + ('vg_conv3d_variant', 'vg_conv3d_wgrad_variant', 'vg_abi_sizeof', 'vg_version', 'vg_storage16')
+
+    def __init__(self):
+        self.cmds = []           # (callable, args)
+        self.keep = []           # objects whose addresses are baked into descriptors (must outlive the list)
+        self._wrapped = {}
+
+    def __getattr__(self, name):
+        real = getattr(_lib.lib, name)
+        if name in self._PURE:
+            return real
+        w = self._wrapped.get(name)
+        if w is None:
+            cmds = self.cmds
+
+            def w(*a, _f=real):
+                rc = _f(*a)
+                cmds.append((_f, a))
+                return rc
+            self._wrapped[name] = w
+        return w
+
+    def __enter__(self):
+        global REC, lib
+        self._saved = lib
+        REC, lib = self, self
+        return self
+
+    def __exit__(self, *exc):
+        global REC, lib
+        REC, lib = None, self._saved
+        return False
+
+
+REC: Optional[Recorder] = None
+
+
+def _host(fn, *a):
+    """A host-side stream operation: done now and, while a step is being recorded, kept for the replay."""
+    fn(*a)
+    if REC is not None:
+        REC.cmds.append((fn, a))
+
+
+def wait_stream(waiter: torch.cuda.Stream, other: torch.cuda.Stream):
+    if REC is None:
+        waiter.wait_stream(other)
+        return
+    ev = torch.cuda.Event()              # a replay re-records the SAME event object in the same program order
+    _host(ev.record, other); _host(waiter.wait_event, ev)
+
+
+def wait_event(waiter: torch.cuda.Stream, ev):
+    _host(waiter.wait_event, ev)
+
+
+def record_event(stream: torch.cuda.Stream):
+    if REC is None:
+        return stream.record_event()
+    ev = torch.cuda.Event()
+    _host(ev.record, stream)
+    return ev
+
+
+def zero_fill(t: torch.Tensor):
+    """t.zero_() on the current stream (recorded as vg_memset_zero with that stream's handle)."""
+    if REC is None:
+        t.zero_()
+    else:
+        check(lib.vg_memset_zero(_p(t), t.numel() * t.element_size(), stream()), 'vg_memset_zero')
+
+
+def copy(dst: torch.Tensor, src: torch.Tensor):
+    if REC is None or not (dst.is_contiguous() and src.is_contiguous() and dst.dtype == src.dtype and dst.numel() == src.numel()):
+        assert REC is None, 'recorded copies must be contiguous and type-preserving'
+        dst.copy_(src)
+    else:
+        check(lib.vg_copy_bytes(_p(dst), _p(src), dst.numel() * dst.element_size(), stream()), 'vg_copy_bytes')
+
+
 class Fp16:
     """Context manager: every library call made through this module goes to libvangan_hip_h.so, the build whose 16-bit buffers
     hold IEEE half precision (fp16 sliding-window inference, BASELINE config 5).  Tensors handed to the calls inside must be
@@ -232,7 +321,7 @@ class fork_side:
         if self.on:
             self.cur = current_stream_obj()
             self.sd = _side_of(self.cur)
-            self.sd.wait_stream(self.cur)
+            wait_stream(self.sd, self.cur)
             self.ctx = torch.cuda.stream(self.sd)
             self.ctx.__enter__()
         return self
@@ -244,7 +333,7 @@ class fork_side:
 
     def join(self):
         if self.on:
-            self.cur.wait_stream(self.sd)
+            wait_stream(self.cur, self.sd)
 
 
 def side_event():
@@ -252,7 +341,7 @@ def side_event():
     if SIDE is None:
         return None
     sd = _SIDE_OF.get(_side_key(current_stream_obj()))
-    return None if sd is None else sd.record_event()
+    return None if sd is None else record_event(sd)
 
 
 def side_join():
@@ -261,7 +350,7 @@ def side_join():
         cur = current_stream_obj()
         sd = _SIDE_OF.get(_side_key(cur))
         if sd is not None:
-            cur.wait_stream(sd)
+            wait_stream(cur, sd)
 
 
 CONV_SCRATCH = {}      # (device index, stream) -> uint8 workspace of vg_conv3d launches on that stream (vg_conv_desc::scratch)
@@ -341,8 +430,12 @@ class Arena:
         self._pair, self._pairs, self._pair_pos, self._full = None, {}, {}, {}
         self._cpos = 0
         self.off = 0
-        if self.zoff:
-            self.zpool[:self.zoff].zero_()
+        self.zmax = max(getattr(self, 'zmax', 0), self.zoff)
+        # a RECORDED reset must clear what every later replay will have used, not what the step before the recording happened to use
+        # (nothing, on a fresh engine): the high-water mark of the pool, or all of it when no step has completed yet
+        nz = self.zoff if REC is None else (self.zmax or self.ZPOOL)
+        if nz:
+            zero_fill(self.zpool[:nz])
         self.zoff = 0
 
     _ESZ = {torch.float32: 4, torch.bfloat16: 2, torch.float16: 2, torch.int32: 4, torch.int64: 8, torch.uint8: 1, torch.float64: 8}
@@ -377,7 +470,7 @@ class Arena:
                 if self.off > self.peak:
                     self.peak = self.off
                 if e[8] and DRY is None:
-                    e[7].zero_()
+                    zero_fill(e[7])
                 return e[7]
         off0, zoff0 = self.off, self.zoff
         t, big_zero = self._carve(shape, dtype, zero)
@@ -405,7 +498,7 @@ class Arena:
         self.peak = max(self.peak, self.off)
         t = self.buf[start:start + nbytes].view(dtype).view(*shape)
         if zero and DRY is None:
-            t.zero_()
+            zero_fill(t)
         return t, bool(zero)
 
     def mark(self) -> int:
@@ -755,7 +848,7 @@ class ConvLayer:
         if SIDE is not None and PROF is None and DRY is None and not inline:   # the per-launch timing pass serialises (attributable durations)
             cur = current_stream_obj()
             sd = _side_of(cur)
-            sd.wait_stream(cur)                                  # dY (and everything before it) is ready
+            wait_stream(sd, cur)                                 # dY (and everything before it) is ready
             self._wgrad(src, dy, sd.cuda_stream)                 # launched on the side stream by handle: torch's current
         else:                                                    # stream is not switched (the context manager cost ~10 us)
             self._wgrad(src, dy)
@@ -841,6 +934,8 @@ class ConvLayer:
             DRY.recipe = dict(kind='dgrad', layer=self.ctor, N=N, accumulate=bool(accumulate), dy_f32=dy.dtype == torch.float32,
                               out_f32=out.dtype == torch.float32, bstat=None if not use_bs else dict(
                                   cat=bool(bstat.x1), c_x0=bstat.c_x0, act=bstat.act, pad=bool(bstat.g_padded)))
+        if REC is not None and use_bs:
+            REC.keep.append(bstat)               # its address is baked into the recorded descriptor
         if self.d_fused:
             t = getattr(self, '_dg_tmpl', None)
             if t is None:                            # static part once (taps / weights / offsets of every class), then block copies
@@ -1191,6 +1286,20 @@ def adam_clip(w, g, m, v, seg_off, T, norms, lr_t, beta1, beta2, eps, clipnorm, 
     assert norms.numel() >= T + 2 * ((w.numel() + 4095) // 4096), 'norms: T squared norms + 2 partial sums per 4096-element block'
     check(lib.vg_adam_clip(_p(w), _p(g), _p(m), _p(v), _p(seg_off), T, w.numel(), _p(norms), lr_t, beta1, beta2, eps,
                            clipnorm, grad_scale, stream()), 'vg_adam_clip')
+
+
+def adam_clip_dev(w, g, m, v, seg_off, T, norms, lr_t_dev: int, beta1, beta2, eps, clipnorm, grad_scale=1.0):
+    """adam_clip with the bias-corrected rate read from device memory (lr_t_dev: device address of one float): replayable graphs."""
+    check(lib.vg_adam_clip_dev(_p(w), _p(g), _p(m), _p(v), _p(seg_off), T, w.numel(), _p(norms), lr_t_dev, beta1, beta2, eps,
+                               clipnorm, grad_scale, stream()), 'vg_adam_clip_dev')
+
+
+def randn_bf16_dev(out, std_dev: int, seed, offset_dev: int, offset_add: int):
+    check(lib.vg_randn_bf16_dev(_p(out), out.numel(), std_dev, seed, offset_dev, offset_add, stream()), 'vg_randn_bf16_dev')
+
+
+def dropout_mask_dev(out, rate, seed, offset_dev: int, offset_add: int):
+    check(lib.vg_dropout_mask_dev(_p(out), out.numel(), rate, seed, offset_dev, offset_add, stream()), 'vg_dropout_mask_dev')
 
 
 def randn_bf16(out, std, seed, offset):

@@ -76,6 +76,29 @@ def _engine_stream(device, role: str):
     return s
 
 
+class _StepParams:
+    """Device block of the per-step host scalars of a captured train step (include/vangan_hip.h: the *_dev entry points): bytes
+    [0, 8) the Philox counter base, [8, 12) the discriminator noise standard deviation, [16, 32) lr_t of the four networks; a pinned
+    host mirror is refreshed and copied before every replay."""
+
+    def __init__(self, device):
+        self.dev = torch.zeros(32, dtype=torch.uint8, device=device)
+        self.host = torch.zeros(32, dtype=torch.uint8).pin_memory()
+        self.base = 0                   # Philox counter at the start of the captured step: launches carry offsets relative to it
+        self.per_step = 0               # counter advance of one step
+        p = self.dev.data_ptr()
+        self.off_ptr, self.std_ptr = p, p + 8
+
+    def lr_ptr(self, name: str) -> int:
+        return self.dev.data_ptr() + 16 + 4 * NETS.index(name)
+
+    def refresh(self, offset: int, std: float, lr_t):
+        self.host[0:8].view(torch.int64)[0] = int(offset)
+        self.host[8:12].view(torch.float32)[0] = float(std)
+        self.host[16:32].view(torch.float32).copy_(torch.tensor(lr_t, dtype=torch.float32))
+        self.dev.copy_(self.host, non_blocking=True)
+
+
 class VanGan:
     def __init__(self, subvol_patch_size=(128, 128, 128), batch_size: int = 1, global_batch_size: Optional[int] = None,
                  n_devices: int = 1, device: str = 'cuda:0', seed: int = 0, lambda_cycle: float = 10.0,
@@ -185,6 +208,8 @@ class VanGan:
         # under the head of the NEXT step, whose consumers wait for the update event of the network they read (VG_XSTEP=0: join)
         self._xstep = self.ddp and self._opt is not None and os.environ.get('VG_XSTEP', '1') != '0'
         self._upd_ev = {}
+        self._cap = None                 # _StepParams while a train step is being captured into a HIP graph (capture_train_step)
+        self._graph = None
         self._fp16_nets = {}
         self.checkpoint_dir = None
         if output_dir is not None:
@@ -222,13 +247,19 @@ class VanGan:
         if self.layer_noise > 0:
             for k, shp in disc.noise_shapes(N).items():
                 t = ar.alloc(shp, torch.bfloat16)
-                ops.randn_bf16(t, self.layer_noise, self.noise_key, self.rng_offset)
+                if self._cap is not None:       # under graph capture: counter base and standard deviation come from the device block
+                    ops.randn_bf16_dev(t, self._cap.std_ptr, self.noise_key, self._cap.off_ptr, self.rng_offset - self._cap.base)
+                else:
+                    ops.randn_bf16(t, self.layer_noise, self.noise_key, self.rng_offset)
                 self.rng_offset += (t.numel() + 3) // 4
                 noise[k] = t
         if self.dropout_rate > 0:
             for k, c in (('down0', 128), ('down1', 256), ('down2', 512)):
                 t = ar.alloc((N, c), torch.float32)
-                ops.dropout_mask(t, self.dropout_rate, self.drop_key, self.rng_offset)
+                if self._cap is not None:
+                    ops.dropout_mask_dev(t, self.dropout_rate, self.drop_key, self._cap.off_ptr, self.rng_offset - self._cap.base)
+                else:
+                    ops.dropout_mask(t, self.dropout_rate, self.drop_key, self.rng_offset)
                 self.rng_offset += t.numel()
                 drop[k] = t
         return noise, drop
@@ -238,7 +269,10 @@ class VanGan:
         out = {}
         for k, rate in ResNetGenerator.DROP_RATES.items():
             t = ar.alloc((N, ResNetGenerator.DROP_CH[k]), torch.float32)
-            ops.dropout_mask(t, rate, self.drop_key + 31, self.rng_offset)
+            if self._cap is not None:
+                ops.dropout_mask_dev(t, rate, self.drop_key + 31, self._cap.off_ptr, self.rng_offset - self._cap.base)
+            else:
+                ops.dropout_mask(t, rate, self.drop_key + 31, self.rng_offset)
             self.rng_offset += t.numel()
             out[k] = t
         return out
@@ -290,14 +324,14 @@ class VanGan:
         f32 = torch.float32
         acc = ar.alloc((16,), f32, zero=True)
         bufS, bufI = ar.alloc((2 * B, D, H, W, 1), f32), ar.alloc((2 * B, D, H, W, 1), f32)
-        bufS[:B].copy_(real_S); bufI[:B].copy_(real_I)
+        ops.copy(bufS[:B], real_S); ops.copy(bufI[:B], real_I)
         rI, rS, fake_S, fake_I = bufI[:B], bufS[:B], bufS[B:], bufI[B:]
         cyc_S, cyc_I = ar.alloc(vol, f32), ar.alloc(vol, f32)
         import contextlib
         main = torch.cuda.current_stream()
         lane_b = self._lane_b if ops.PROF is None else None        # the per-launch timing pass stays serial
         if lane_b is not None:
-            lane_b.wait_stream(main)                                 # inputs copied, arena reset
+            ops.wait_stream(lane_b, main)                                 # inputs copied, arena reset
         def laneB():
             return torch.cuda.stream(lane_b) if lane_b is not None else contextlib.nullcontext()
         # Lane balance (timeline from HIP events, tools/timeline.py): lane B carries the clDice skeletons, so lane A used to idle
@@ -307,7 +341,7 @@ class VanGan:
         dims4 = (B, D, H, W)
         mmS, nS = ar.alloc((B, 4), f32), ar.alloc(vol, f32)
         ops.minmax(rS, B, S, mmS); ops.minmax_apply(rS, mmS, B, S, nS)                   # lane A, first thing: lane B needs nS at 5.8 ms
-        ev_nS = main.record_event() if lane_b is not None else None
+        ev_nS = ops.record_event(main) if lane_b is not None else None
         # Both applications of a generator share 2B-sample tensors (Arena paired mode): the forward passes are B-sample launches on
         # the two sample halves, the backward runs ONE 2B-sample sweep per generator instead of two B-sample sweeps (half the
         # launches, twice the work per launch on the latency-bound deep levels, the weight gradients' slab writes once for both).
@@ -351,7 +385,7 @@ class VanGan:
                             (laneB, fwd(self.gen_SI, 'gen_SI', 0, rS, fake_I)), on=_INTERLEAVE)           # :297            (lane B)
         self._mark('A G1 fwd')
         with laneB():
-            ev_fakeI = lane_b.record_event() if lane_b is not None else None
+            ev_fakeI = ops.record_event(lane_b) if lane_b is not None else None
             self._mark('B G1 fwd')
         c4, c3 = interleave((contextlib.nullcontext, fwd(self.gen_SI, 'gen_SI', 1, fake_S, cyc_I)),     # :305            (lane A)
                             (laneB, fwd(self.gen_IS, 'gen_IS', 1, fake_I, cyc_S)), on=_INTERLEAVE)        # :300            (lane B)
@@ -365,11 +399,11 @@ class VanGan:
         # ---- cycle / segmentation losses on cycled_S (loss_functions.py:185-190, 211-226): lane B; target skeleton: lane A ----
         imgs_t, skels_t = ar.alloc((it + 2,) + vol, f32), ar.alloc((it + 1,) + vol, f32)
         ops.soft_skel_fwd(nS, dims4, it, imgs_t, skels_t)                                # lane A
-        ev_skel_t = main.record_event() if lane_b is not None else None
+        ev_skel_t = ops.record_event(main) if lane_b is not None else None
         self._mark('A target skeleton')
         with laneB():
             if lane_b is not None:
-                lane_b.wait_event(ev_nS)
+                ops.wait_event(lane_b, ev_nS)
             mmcS = ar.alloc((B, 4), f32)
             ncS = ar.alloc(vol, f32)
             ops.minmax(cyc_S, B, S, mmcS); ops.minmax_apply(cyc_S, mmcS, B, S, ncS)
@@ -380,7 +414,7 @@ class VanGan:
             aux_p = ar.alloc((ops.skel_aux_bytes(dims4, it),), torch.uint8) if (do_backward and _SKEL_AUX) else None
             ops.soft_skel_fwd(ncS, dims4, it, imgs_p, skels_p, aux_p)
             if lane_b is not None:
-                lane_b.wait_event(ev_skel_t)
+                ops.wait_event(lane_b, ev_skel_t)
             skel_p, skel_t = skels_p[it], skels_t[it]
             sums = ar.alloc((9,), f32, zero=True)
             coef = ar.alloc((8,), f32, zero=True)
@@ -434,7 +468,7 @@ class VanGan:
         ops.mse_const(logS[B:], 0.0, acc[6:7], 0.5 * gd, None if gS_D is None else gS_D[B:])
         self._mark('A D_S fwd')
         if lane_b is not None:
-            main.wait_event(ev_fakeI)                                                       # fake_I comes from lane B's first generator
+            ops.wait_event(main, ev_fakeI)                                                       # fake_I comes from lane B's first generator
         dI = self.disc_I.forward(ar, bufI, logI, nzI, dpI)                                  # lane A as well: lane B is the longer one
         ops.mse_const(logI[B:], 1.0, acc[4:5], gd, gI_G)                                  # gen_SI_loss
         ops.mse_const(logI[:B], 1.0, acc[7:8], 0.5 * gd, None if gI_D is None else gI_D[:B])
@@ -446,14 +480,14 @@ class VanGan:
         ev_bfwd = None
         if lane_b is not None:
             if nojoin:
-                ev_bfwd = lane_b.record_event()
+                ev_bfwd = ops.record_event(lane_b)
             else:
-                main.wait_stream(lane_b)                                                    # lanes join before the backward sweeps
+                ops.wait_stream(main, lane_b)                                                    # lanes join before the backward sweeps
 
         self._upd_ev = {}                # every stream that reads weights in this step has queued its waits (main: all four networks)
         if do_backward:
             for st in self.stores.values():
-                st.g.zero_()
+                ops.zero_fill(st.g)
             # Backward lanes: lane A = D_S sweeps + both gen_IS applications, lane B = D_I sweeps + both gen_SI applications
             # (total_loss_I only reaches gen_IS, total_loss_S only gen_SI; each lane accumulates into its own networks'
             # gradient buffers).  Per network: D loss over [real;fake] (weights), generator loss through the fake half.
@@ -462,7 +496,7 @@ class VanGan:
             if lane_b is not None:
                 arB = self.arena_b
                 arB.reset()
-                lane_b.wait_stream(main)
+                ops.wait_stream(lane_b, main)
             def a_disc():
                 self.disc_S.backward(ar, dS, gS_D, 0, 2 * B, wgrad=True)
                 self._start_allreduce(['disc_S'], lazy=apply)
@@ -500,7 +534,7 @@ class VanGan:
 
             def a_cyc():
                 if ev_bfwd is not None:
-                    main.wait_event(ev_bfwd)                                          # c3 and g_cS are lane B's
+                    ops.wait_event(main, ev_bfwd)                                          # c3 and g_cS are lane B's
                 self.gen_IS.backward(ar, c3, g_cS, inline_from=_INLINE); ar.release(mk, defer=True)    # cycle application
                 self._mark('A G cyc bwd')
                 self._start_allreduce(['gen_IS'], lazy=apply)
@@ -525,7 +559,7 @@ class VanGan:
             if pair:
                 # the generators' 2B-sample sweeps over both applications ([adversarial; cycle]), enqueued alternately block by block
                 if ev_bfwd is not None:
-                    main.wait_event(ev_bfwd)                                          # c3 and g_cS are lane B's
+                    ops.wait_event(main, ev_bfwd)                                          # c3 and g_cS are lane B's
                 ccA = pair_ctx(ar, c1, bufI, (fake_S, cyc_S), self.gen_IS.lv[0])
                 ccB = pair_ctx(ar, c2, bufS, (fake_I, cyc_I), self.gen_SI.lv[0])
                 # data parallel: the finished suffix of a generator's gradient bucket (enc4 ... output head, 34 of 38 MB) goes to the
@@ -552,10 +586,10 @@ class VanGan:
             if lane_b is not None:
                 with laneB():
                     ops.side_join()                 # lane B's weight gradients (its lane no longer waits for them on the way)
-                main.wait_stream(lane_b)
+                ops.wait_stream(main, lane_b)
             ops.side_join()
             if apply and self._opt is not None and not (self._xstep and ops.PROF is None):
-                main.wait_stream(self._opt)
+                ops.wait_stream(main, self._opt)
             self._mark('A all joined')
         self._acc, self._coef = acc, coef
         self._aux = dict(fake_S=fake_S, fake_I=fake_I, cycled_S=cyc_S, cycled_I=cyc_I, logits_S=logS, logits_I=logI)
@@ -601,12 +635,20 @@ class VanGan:
         st = self.stores[name]
         st.step += 1
         t = st.step
-        lr = self.lrs.get(name)
-        lr = self.lr if lr is None else (float(lr(t - 1)) if callable(lr) else lr)       # iterations BEFORE this step, as Keras
-        lr_t = lr * math.sqrt(1.0 - self.beta_2 ** t) / (1.0 - self.beta_1 ** t)
-        ops.adam_clip(st.w, st.g, st.m, st.v, st.seg_off, st.T, st.norms, lr_t, self.beta_1, self.beta_2,
-                      self.adam_eps, self.clipnorm, 1.0)
+        if self._cap is not None:              # under graph capture: lr_t of the replayed step comes from the device block
+            ops.adam_clip_dev(st.w, st.g, st.m, st.v, st.seg_off, st.T, st.norms, self._cap.lr_ptr(name), self.beta_1, self.beta_2,
+                              self.adam_eps, self.clipnorm, 1.0)
+        else:
+            ops.adam_clip(st.w, st.g, st.m, st.v, st.seg_off, st.T, st.norms, self._lr_t(name, t), self.beta_1, self.beta_2,
+                          self.adam_eps, self.clipnorm, 1.0)
         self.nets[name].pack()
+
+    def _lr_t(self, name: str, t: int) -> float:
+        """Adam's bias-corrected rate of network `name` at its step t (1-based); the base rate is self.lr, a per-network float or a
+        schedule evaluated at the iteration count BEFORE this step, as Keras does."""
+        lr = self.lrs.get(name)
+        lr = self.lr if lr is None else (float(lr(t - 1)) if callable(lr) else lr)
+        return lr * math.sqrt(1.0 - self.beta_2 ** t) / (1.0 - self.beta_1 ** t)
 
     def _schedule_update(self, name: str):
         """Queue clip + Adam + repack of one network behind (a) everything the current lane has issued for it and (b) the
@@ -616,12 +658,10 @@ class VanGan:
             self.sync.finish([name])
             self._adam(name)
             return
-        ev = torch.cuda.Event()
-        ev.record()
-        self._opt.wait_event(ev)
+        ops.wait_stream(self._opt, ops.current_stream_obj())
         sev = self._side_ev.pop(name, None)
         if sev is not None:
-            self._opt.wait_event(sev)           # ... and the weight gradients of this network on the lane's side stream
+            ops.wait_event(self._opt, sev)      # ... and the weight gradients of this network on the lane's side stream
         with torch.cuda.stream(self._opt):
             self.sync.finish([name])
             self._adam(name)
@@ -640,6 +680,120 @@ class VanGan:
         B, S, nps = self._losses_and_backward(real_I, real_S, True, noise, drop, True, apply=apply)
         self._finish_allreduce()                 # apply=False (tests): the reduced gradients stay in the buckets
         return self._results(B, S, nps) if sync else None
+
+    # ------------------------------------------------------------------------------------------------
+    def capture_train_step(self, warmup: int = 2):
+        """Capture one train step (forward, losses, the backward sweeps, 4 x Adam, weight repack: everything train_step enqueues, on
+        all of its streams) into a HIP graph.  train_step_graph() then replays it: the host refreshes a 32-byte parameter block
+        (Philox counter, noise standard deviation, the four lr_t) and the two input volumes instead of enqueueing ~900 launches --
+        for the configurations whose step the host cannot enqueue fast enough (64^3: 8.4 ms of Python for a 9.3 ms step).
+        Single process only (the all-reduce stays outside graphs); shapes, dropout rate, loss weights and the noise on/off decision
+        are those of the engine at capture time.  The library has been capture-legal since it stopped allocating (vg_conv_desc::scratch)."""
+        if self.sync.active:
+            raise NotImplementedError('graph capture covers the single-process step (the gradient all-reduce is not captured)')
+        ops.set_device(self.device.index)
+        B, (D, H, W) = self.batch_size, self.dims
+        self._g_in = (torch.zeros(B, D, H, W, 1, device=self.device), torch.zeros(B, D, H, W, 1, device=self.device))
+        self._g_stream = _engine_stream(self.device, 'graph')
+        cur = torch.cuda.current_stream()
+        self._g_stream.wait_stream(cur)
+        # eager steps ON the capture stream first: per-stream workspaces, side stream, arena sequence, kernel attributes -- nothing is
+        # allocated or configured while capturing.  (They are real steps: synthetic inputs would train on zeros, so the caller's
+        # first batch is used -- hand it in through warm_inputs, else the weights are restored afterwards.)
+        snap = {k: (s.w.clone(), s.m.clone(), s.v.clone(), s.step) for k, s in self.stores.items()}
+        rng0 = self.rng_offset
+        # The captured step runs WITHOUT the weight-gradient side streams: ROCm 7.2's hipStreamEndCapture takes the process down
+        # (SIGSEGV inside the runtime) on a capture that forks the two lanes AND a side stream per lane; lanes + optimizer stream, or
+        # side streams without the second lane, capture and replay fine (tools/graph_bisect.py).  The graph's branches still overlap.
+        side_saved, ops.SIDE = ops.SIDE, None
+        try:
+            return self._capture(cur, snap, rng0, warmup)
+        finally:
+            ops.SIDE = side_saved
+
+    def _capture(self, cur, snap, rng0, warmup):
+        with torch.cuda.stream(self._g_stream):
+            self._g_in[0].normal_(); self._g_in[1].normal_()
+            for _ in range(max(1, warmup)):
+                self.train_step(self._g_in[0], self._g_in[1], sync=False)
+        torch.cuda.synchronize(self.device)
+        for k, s in self.stores.items():
+            s.w.copy_(snap[k][0]); s.m.copy_(snap[k][1]); s.v.copy_(snap[k][2]); s.step = snap[k][3]
+        self.rng_offset = rng0
+        self.repack()
+        torch.cuda.synchronize(self.device)
+        cap = _StepParams(self.device)
+        cap.base = self.rng_offset
+        steps0 = {k: s.step for k, s in self.stores.items()}
+        g = torch.cuda.CUDAGraph()
+        self._cap = cap
+        try:
+            with torch.cuda.graph(g, stream=self._g_stream):
+                self._g_shape = self._losses_and_backward(self._g_in[0], self._g_in[1], True, None, None, True, apply=True)
+        finally:
+            self._cap = None
+        cap.per_step = self.rng_offset - cap.base
+        self.rng_offset = cap.base                      # nothing ran while capturing
+        for k, s in self.stores.items():
+            s.step = steps0[k]
+        self._graph, self._gcap = g, cap
+        cur.wait_stream(self._g_stream)
+        return g
+
+    def train_step_graph(self, real_I: torch.Tensor, real_S: torch.Tensor, sync: bool = True):
+        """One train step by replaying the captured graph (capture_train_step): same arithmetic, same streams' dependencies."""
+        if self._graph is None:
+            self.capture_train_step()
+        ops.set_device(self.device.index)
+        self._g_in[0].copy_(real_I); self._g_in[1].copy_(real_S)
+        lr_t = [self._lr_t(n, self.stores[n].step + 1) for n in NETS]
+        self._gcap.refresh(self.rng_offset, max(self.layer_noise, 0.0), lr_t)
+        self._graph.replay()
+        self.rng_offset += self._gcap.per_step
+        for n in NETS:
+            self.stores[n].step += 1
+        return self._results(*self._g_shape) if sync else None
+
+    def train_step_replay(self, real_I: torch.Tensor, real_S: torch.Tensor, sync: bool = True):
+        """train_step without the Python: the first call runs the step eagerly while recording every library launch and stream
+        dependency it enqueues (ops.Recorder; the per-step scalars go through the device parameter block, _StepParams); later calls
+        refresh the block and the two input volumes and re-issue the list -- ~1 000 C calls with baked arguments instead of ~8 ms of
+        descriptor building, on the same streams with the same dependencies as the eager step.  For the configurations whose step the
+        host cannot enqueue fast enough (64^3: 8.4 ms of enqueue for a 9.3 ms step).  Single process; shapes, dropout rate, loss
+        weights and the noise on/off decision are those of the first call."""
+        if self.sync.active:
+            raise NotImplementedError('the launch list covers the single-process step (no all-reduce)')
+        ops.set_device(self.device.index)
+        if getattr(self, '_rlist', None) is None:
+            B, (D, H, W) = self.batch_size, self.dims
+            self._r_in = (torch.zeros(B, D, H, W, 1, device=self.device), torch.zeros(B, D, H, W, 1, device=self.device))
+            self._rcap = cap = _StepParams(self.device)
+            self._r_main = torch.cuda.current_stream()
+        cap = self._rcap
+        if torch.cuda.current_stream() != self._r_main:
+            raise RuntimeError('train_step_replay must be called on the stream it was recorded on')
+        self._r_in[0].copy_(real_I); self._r_in[1].copy_(real_S)
+        lr_t = [self._lr_t(n, self.stores[n].step + 1) for n in NETS]
+        cap.base = self.rng_offset                      # recorded offsets are relative to the step's base counter
+        cap.refresh(self.rng_offset, max(self.layer_noise, 0.0), lr_t)
+        if getattr(self, '_rlist', None) is None:
+            self._cap = cap
+            try:
+                with ops.Recorder() as rec:
+                    self._r_shape = self._losses_and_backward(self._r_in[0], self._r_in[1], True, None, None, True, apply=True)
+            finally:
+                self._cap = None
+            cap.per_step = self.rng_offset - cap.base
+            self._rlist, self._rkeep = rec.cmds, rec.keep
+        else:
+            for f, a in self._rlist:
+                rc = f(*a)
+                if rc is not None and rc < 0:
+                    raise ops._lib.VgError('replayed launch %s failed: %s (%d)' % (getattr(f, '__name__', f), ops._lib.lib.vg_status_string(rc).decode(), rc))
+            self.rng_offset += cap.per_step
+            for n in NETS:
+                self.stores[n].step += 1
+        return self._results(*self._r_shape) if sync else None
 
     def test_step(self, real_I: torch.Tensor, real_S: torch.Tensor):
         """vangan.py:442-457: training=False => no noise, no dropout, no backward."""
