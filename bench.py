@@ -81,7 +81,7 @@ def time_infer(eng, device, steps, warmup, precision):
             'generator_tflops': 50 * 2 * 149.65e9 / el / 1e12, 'windows': 50, 'steps': steps, 'finite': bool(torch.isfinite(out).all())}
 
 
-def time_config(dims, B, device, steps=20, warmup=5, graph=True):
+def time_config(dims, B, device, steps=20, warmup=5, graph=True, generator='resUnet'):
     """BASELINE configs 2 and 3 beside the headline: a full train_step at another patch size / batch on a fresh engine
     (same kernels, same schedule, noise + dropout + clDice on), timed like the headline loop -- enqueued launch by launch
     (`eager_ms_per_step`) and as replays of the step's recorded launch list (`replay_ms_per_step`, VanGan.train_step_replay: the same
@@ -90,7 +90,7 @@ def time_config(dims, B, device, steps=20, warmup=5, graph=True):
     is correct and slower than either on ROCm 7.2: DESIGN 6.19.)"""
     import torch
     from van_gan_amd import VanGan
-    eng = VanGan(dims, batch_size=B, device=device, seed=0)
+    eng = VanGan(dims, batch_size=B, device=device, seed=0, generator=generator)
     rI, rS = synth_on_device(B, dims, 1234, device)
     for _ in range(warmup):
         eng.train_step(rI, rS, sync=False)
@@ -119,11 +119,12 @@ def time_config(dims, B, device, steps=20, warmup=5, graph=True):
         except Exception as e:              # the eager figure stands; the reason is on the line
             g_err = '%s: %s' % (type(e).__name__, str(e)[:300])
     S = dims[0] * dims[1] * dims[2]
-    out = {'workload': 'VanGan.train_step, %dx%dx%d volumes, batch %d, bf16, clDice on, disc noise+dropout on' % (dims + (B,)),
+    out = {'workload': 'VanGan.train_step, %dx%dx%d volumes, batch %d, bf16, clDice on, disc noise+dropout on' % (dims + (B,))
+                       + ('' if generator == 'resUnet' else ", generator='%s' (the non-default pair of vangan.py:88-97, SURVEY 8(f)4; its conv FLOPs are ~3x the ResUNet's: whole_step_conv_tflops does not apply)" % generator),
            'ms_per_step': el * 1e3, 'path': 'launch-list replay' if (g_ms is not None and g_ms < eager_ms) else 'eager enqueue',
            'eager_ms_per_step': eager_ms, 'replay_ms_per_step': g_ms, 'replay_error': g_err,
            'train_steps_per_sec': 1.0 / el, 'Mvoxels_per_sec': B * S / el / 1e6,
-           'whole_step_conv_tflops': B * S * CONV_FLOP_PER_VOXEL / el / 1e12, 'steps': steps, 'warmup': warmup,
+           'whole_step_conv_tflops': (B * S * CONV_FLOP_PER_VOXEL / el / 1e12) if generator == 'resUnet' else None, 'steps': steps, 'warmup': warmup,
            'finite': finite, 'arena_peak_gb': eng.arena.peak / 1e9}
     del eng
     torch.cuda.empty_cache()
@@ -349,7 +350,8 @@ def main():
         graph_ms = (time.perf_counter() - t1) / args.steps * 1e3
     configs = None
     if rank == 0 and world == 1 and args.size == 128 and not args.no_configs:
-        configs = [time_config((64, 64, 64), 2, device), time_config((128, 128, 64), 2, device)]
+        configs = [time_config((64, 64, 64), 2, device), time_config((128, 128, 64), 2, device),
+                   time_config((128, 128, 128), 1, device, steps=10, warmup=3, graph=False, generator='resnet')]
     infer = None
     if rank == 0 and world == 1 and args.size == 128 and not args.no_infer:
         # BASELINE config 5 beside the headline: the same engine's gen_IS, fp16 storage (and the bf16 figure next to it)

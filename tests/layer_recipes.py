@@ -63,6 +63,19 @@ def enumerate_config(dims, B, precision='bf16'):
     return [(k, n, v, r) for (k, n, v), r in zip(dry.records, dry.recipes)]
 
 
+def enumerate_resnet(dims, N):
+    """[(kind, layer, variant)] of one application (forward + backward) of the ResNet generator in dry-run mode."""
+    from van_gan_amd import ops
+    from van_gan_amd.nets import ParamStore, ResNetGenerator, resnet_param_specs
+    G = ResNetGenerator(ParamStore(resnet_param_specs(), 'cpu'), dims, torch.bfloat16)
+    ar = ops.Arena(int(N * dims[0] * dims[1] * dims[2] * 9000) + (512 << 20), 'cpu')
+    with ops.DryRun() as dry:
+        x, y = torch.empty((N,) + dims + (1,)), torch.empty((N,) + dims + (1,))
+        drop = {k: torch.empty(N, c) for k, c in ResNetGenerator.DROP_CH.items()}
+        G.backward(ar, G.forward(ar, x, y, drop), y)
+    return list(dry.records)
+
+
 def recipe_macs(r) -> float:
     L = r['layer']
     out = [(-(-n // L['stride'])) for n in L['in_dims']]

@@ -38,6 +38,24 @@ def test_every_variant_of_the_baseline_configs_has_a_gpu_parity_case():
         assert frag in names, frag
 
 
+def test_resnet_generator_walk():
+    """the kernel variants the ResNet generator launches at the 128^3 patch are all exercised by its teacher-forced GPU
+    tests (tests/test_gpu_resnet.py runs the whole network, forward and backward, at 32^3 batch 2, 64^3 and 128^3 -- the walk below
+    is what those runs launch), and the families one expects are there: the W-packed 7^3 stem, the seven 49-tap chunks of the head,
+    class-parallel strided data gradients on odd grids, the LDS-DMA data gradients and weight gradients of the 256-channel trunk."""
+    sizes = {'32^3 B2': ((32, 32, 32), 2), '64^3 B1': ((64, 64, 64), 1), '128^3 B1': ((128, 128, 128), 1)}
+    recs = {k: LR.enumerate_resnet(*v) for k, v in sizes.items()}
+    var = {k: {(kind, v) for kind, _, v in r} for k, r in recs.items()}
+    assert len(recs['128^3 B1']) == 77                      # 26 convolutions: 32 forward launches (head: 7), 32 + 13 backward
+    only_128 = var['128^3 B1'] - var['64^3 B1'] - var['32^3 B2']
+    assert len(only_128) >= 4, sorted(only_128)             # why the 128^3 GPU test exists (13 variants no smaller grid selects)
+    names = ' '.join(v for k in var for _, v in var[k])
+    for frag in ('c11', 'conv32<128', 'conv32<64', 'cp1', 'mc1', 'conv_dma<128,256>', 'wgrad_dma<8,2,d0>', 'wgrad_dma<8,4,d0>', 'wgrad<bf16,7,4'):
+        assert frag in names, frag
+    heads = [n for kind, n, _ in recs['128^3 B1'] if kind == 'fwd' and n == 'out']
+    assert len(heads) == 7
+
+
 def test_walk_is_complete():
     """One generator application is 30 forward + 29 weight-gradient + 28 data-gradient calls (stem.conv1 / stem.short have
     no data gradient; stem.short's weight gradient comes out of its InstanceNorm's statistics pass: vg_actnorm_bwd_aux_wgrad), one
