@@ -5,10 +5,10 @@
 tag=$1; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_$tag; mkdir -p $O
 export VG_NO_REBUILD=1
 cd /tmp; export TMPDIR=/tmp
-VG_LANES=0 VG_SIDE_STREAM=0 VG_OPT_STREAM=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-infer --no-configs --no-synced > $O/stats.log 2>&1     # 7 train steps in the trace
-VG_LANES=0 VG_SIDE_STREAM=0 VG_OPT_STREAM=0 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-infer --no-configs --no-synced > $O/fetch.log 2>&1
-VG_LANES=0 VG_SIDE_STREAM=0 VG_OPT_STREAM=0 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-infer --no-configs --no-synced > $O/write.log 2>&1
-VG_LANES=0 VG_SIDE_STREAM=0 VG_OPT_STREAM=0 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/mfma -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-infer --no-configs --no-synced > $O/mfma.log 2>&1
+VG_LANES=0 VG_SIDE_STREAM=0 VG_OPT_STREAM=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-infer --no-configs --no-synced --no-ddp-path --no-replay > $O/stats.log 2>&1     # 7 train steps in the trace
+VG_LANES=0 VG_SIDE_STREAM=0 VG_OPT_STREAM=0 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-infer --no-configs --no-synced --no-ddp-path --no-replay > $O/fetch.log 2>&1
+VG_LANES=0 VG_SIDE_STREAM=0 VG_OPT_STREAM=0 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-infer --no-configs --no-synced --no-ddp-path --no-replay > $O/write.log 2>&1
+VG_LANES=0 VG_SIDE_STREAM=0 VG_OPT_STREAM=0 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/mfma -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-infer --no-configs --no-synced --no-ddp-path --no-replay > $O/mfma.log 2>&1
 cd $R
 python3 tools/hbm_pmc.py $O/fetch $O/write $O/hbm_pmc.json > $O/hbm_pmc.log 2>&1
 cp $O/hbm_pmc.json $R/profiles/${tag}_hbm_pmc.json     # the bench line below quotes it (same kernel sources: hash-stamped)
