@@ -50,7 +50,7 @@ int vg_version(void);
  * post_training.py:38-39 / custom_callback.py:174-175).  Every "bf16" buffer of this header holds that format. */
 int vg_storage16(void);
 /* sizeof() of the descriptor structs as THIS library was compiled (which: 0 vg_conv_desc, 1 vg_actnorm_bwd_desc,
- * 2 vg_pack_item; else VG_EINVAL): a binding that mirrors the structs by hand checks its layout at load time. */
+ * 2 vg_pack_item, 3 vg_fin_desc; else VG_EINVAL): a binding that mirrors the structs by hand checks its layout at load time. */
 int vg_abi_sizeof(int which);
 
 /* ---------------------------------------------------------------------------------------------
@@ -66,6 +66,29 @@ int vg_abi_sizeof(int which);
  * out[n, o*ostr+ooff, co] (+)= sum_taps sum_ci f(src[n, bnd(o*istr + tap), ci]) * W[tap][ci][co]
  * --------------------------------------------------------------------------------------------- */
 struct vg_actnorm_bwd_desc_s;
+/* InstanceNorm finalisation of a convolution's OUTPUT by the launch that produces it (resunet_model.py:23-39 / building_blocks.py:190:
+ * tfa InstanceNormalization = per-(n, c) mean and biased variance over the volume, y = (x - mean) * rsqrt(var + eps) * gamma + beta).
+ * The producing kernel already accumulates (sum, sum of squares) of what it stores (out_sums); with a vg_fin_desc the workgroup that
+ * finishes LAST (ticket) turns them into the on-read affine of up to two consuming norms -- scale = gamma * rstd (* mult),
+ * shift = (beta - mean * gamma * rstd) (* mult), and mean / rstd for the backward pass -- instead of a vg_in_finalize launch
+ * between producer and consumer (120 launches of a train step, each on a lane's dependent chain).  A tensor may feed two norms
+ * (an encoder output: the next block's first norm and, as the skip half of a virtual concat, a decoder block's): job j writes
+ * channels [c_off, c_off + Cout) of arrays with c_tot channels per sample.  Kernel families without the epilogue are followed by a
+ * small kernel inside vg_conv3d: either way the arrays are complete, in stream order, when the call's launches have run. */
+typedef struct {
+    const float* gamma; const float* beta;    /* [c_tot] of the consuming norm (NULL: 1 / 0) */
+    const float* mult;                        /* [N][c_tot] SpatialDropout3D multipliers folded into scale / shift, or NULL */
+    float* scale; float* shift;               /* [N][c_tot] */
+    float* mean; float* rstd;                 /* [N][c_tot] or NULL */
+    int32_t c_off, c_tot;
+} vg_fin_job;
+typedef struct {
+    uint32_t* ticket;                         /* one zeroed word per launch (left non-zero) */
+    float count;                              /* voxels per (n, c) of the produced tensor */
+    float eps;
+    int32_t njobs;                            /* 1 or 2 */
+    vg_fin_job job[2];
+} vg_fin_desc;
 typedef struct {
     /* input: virtual concat of src0 (c_src0 channels) and src1 (c_src1 channels, may be 0) */
     const void* src0;
@@ -140,6 +163,9 @@ typedef struct {
        a scratch big enough for the materialised operand).  A call whose weights are in the block layout is served by that kernel
        family or fails with VG_EINVAL -- never by a silent fallback. */
     int32_t wlayout;
+    /* Optional (forward launches with out_sums): finalise the InstanceNorm statistics of this launch's output for its consumers
+       (see vg_fin_desc). */
+    const vg_fin_desc* fin;
 } vg_conv_desc;
 #define VG_SCRATCH_CTR_BYTES 16384
 

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(h, name), 'libvangan_hip_h.so does not export %s' % name
     assert h.vg_storage16() == 1 and h.vg_version() == 3
-    assert [h.vg_abi_sizeof(i) for i in range(3)] == [_lib.lib.vg_abi_sizeof(i) for i in range(3)]
+    assert [h.vg_abi_sizeof(i) for i in range(4)] == [_lib.lib.vg_abi_sizeof(i) for i in range(4)]
 
 
 def test_descriptor_struct_layout_matches_header():

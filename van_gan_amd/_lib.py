@@ -32,8 +32,17 @@ class ConvDesc(C.Structure):
         ('out', c_void_p), ('out_f32', c_int), ('accumulate', c_int), ('out_sums', c_void_p), ('f32', c_int),
         ('nclass', c_int), ('cls_tap0', c_int * 9), ('cls_w', c_void_p * 8), ('cls_ooff', (c_int * 3) * 8),
         ('cls_iters', (c_int * 3) * 8), ('wpack', c_int), ('wpack_wmin', c_int), ('bstat', c_void_p),
-        ('scratch', c_void_p), ('scratch_bytes', c_i64), ('wlayout', c_int),
+        ('scratch', c_void_p), ('scratch_bytes', c_i64), ('wlayout', c_int), ('fin', c_void_p),
     ]
+
+
+class FinJob(C.Structure):
+    _fields_ = [('gamma', c_void_p), ('beta', c_void_p), ('mult', c_void_p), ('scale', c_void_p), ('shift', c_void_p),
+                ('mean', c_void_p), ('rstd', c_void_p), ('c_off', c_int), ('c_tot', c_int)]
+
+
+class FinDesc(C.Structure):
+    _fields_ = [('ticket', c_void_p), ('count', c_float), ('eps', c_float), ('njobs', c_int), ('job', FinJob * 2)]
 
 
 class PackItem(C.Structure):
@@ -139,7 +148,7 @@ def _load(path=None, storage16=0):
         fn.restype = ret
     lib.vg_status_string.argtypes = [c_int]
     lib.vg_status_string.restype = C.c_char_p
-    for which, mirror in ((0, ConvDesc), (1, ActNormBwdDesc), (2, PackItem)):
+    for which, mirror in ((0, ConvDesc), (1, ActNormBwdDesc), (2, PackItem), (3, FinDesc)):
         got = lib.vg_abi_sizeof(which)
         if got != C.sizeof(mirror):
             raise ImportError('libvangan_hip.so ABI mismatch: sizeof(%s) is %d in the library, %d in van_gan_amd/_lib.py '

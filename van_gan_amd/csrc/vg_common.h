@@ -93,6 +93,59 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// ---- InstanceNorm finalisation as the tail of the producing launch (vg_fin_desc, include/vangan_hip.h) ----
+struct VgFin { unsigned* ticket; float count, eps; int njobs; vg_fin_job job[2]; };
+static inline VgFin vg_fin_of(const vg_conv_desc* d) {
+    VgFin f; f.ticket = nullptr; f.count = 1.f; f.eps = 0.f; f.njobs = 0;
+    if (d->fin && d->out_sums) { f.ticket = d->fin->ticket; f.count = d->fin->count; f.eps = d->fin->eps; f.njobs = d->fin->njobs;
+                                 f.job[0] = d->fin->job[0]; f.job[1] = d->fin->job[d->fin->njobs > 1 ? 1 : 0]; }
+    return f;
+}
+// scale / shift / mean / rstd of sample n, channel c from the 8 striped (sum, sum of squares) pairs: in_finalize_kernel's arithmetic
+__device__ __forceinline__ void vg_fin_one(const VgFin& f, float s, float ss, int n, int c) {
+    const float mean = s / f.count;
+    float var = ss / f.count - mean * mean;
+    var = var < 0.f ? 0.f : var;
+    const float rstd = rsqrtf(var + f.eps);
+    for (int j = 0; j < f.njobs; ++j) {
+        const vg_fin_job& q = f.job[j];
+        const int cc = q.c_off + c, i = n * q.c_tot + cc;
+        float sc = (q.gamma ? q.gamma[cc] : 1.f) * rstd;
+        float sh = (q.beta ? q.beta[cc] : 0.f) - mean * sc;
+        if (q.mult) { const float m = q.mult[i]; sc *= m; sh *= m; }
+        q.scale[i] = sc; q.shift[i] = sh;
+        if (q.mean) q.mean[i] = mean;
+        if (q.rstd) q.rstd[i] = rstd;
+    }
+}
+// Called by EVERY workgroup of the launch after its last atomicAdd into the striped sums.  The adds are device-scope atomics; a
+// workgroup takes its ticket once its own have been acknowledged (s_waitcnt vmcnt(0) per thread, then the workgroup barrier), so the
+// workgroup that draws the last ticket finds every contribution at the level the XCDs share and reads it there (agent-scope loads) --
+// the exchange of the K split, no __threadfence().
+// flag: one word of the workgroup's LDS that nobody uses any more (no static __shared__ here: the kernels raise their dynamic LDS limit
+// to all 160 KiB, which a single static byte makes an invalid request).
+__device__ __forceinline__ void vg_fin_tail(const VgFin& f, const float* sums, int N, int C, unsigned nblocks, int* flag) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0)
+        *flag = __hip_atomic_fetch_add(f.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nblocks - 1u ? 1 : 0;
+    __syncthreads();
+    if (!*flag) return;
+    for (int i = threadIdx.x; i < N * C; i += blockDim.x) {
+        const int n = i / C, c = i - n * C;
+        float s = 0.f, ss = 0.f;
+        for (int t = 0; t < VG_STRIPES; ++t) {
+            const float* p = sums + (((size_t)t * N + n) * C + c) * 2;
+            s += __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ss += __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        vg_fin_one(f, s, ss, n, c);
+    }
+}
+// the same as a launch of its own, for the kernel families without the tail (vg_conv.hip: vg_conv3d runs it right behind them)
+int vg_launch_fin(const vg_conv_desc* d, hipStream_t s);
+extern thread_local bool vg_fin_done;      // set by a launch function whose kernel carries the tail
+
 // ---- tuning knobs: vg_tune("CONV_BN", 0) reads the override set by vg_set_tuning, else the environment variable VG_CONV_BN
 // (once), else the default.  One registry for every host-side heuristic switch, so that tests can force kernel variants in
 // process (vg_set_tuning) and sweeps can use the environment.

@@ -446,6 +446,7 @@ __global__ __launch_bounds__(256, ((BN / 16) * MSUB >= VG_CONV_MW2 ? 2 : VG_CONV
             const int stripe = blockIdx.x & (VG_STRIPES - 1);
             if (co < p.Cout) atomicAdd(&p.sums[(((size_t)stripe * gridDim.z + n) * p.Cout + co) * 2 + (tid & 1)], stat[tid]);
         }
+        if (p.fin.ticket) vg_fin_tail(p.fin, p.sums, gridDim.z, p.Cout, gridDim.x * gridDim.y * gridDim.z, (int*)stat);
     }
 }
 
@@ -656,6 +657,7 @@ __global__ __launch_bounds__(256, 2) void conv32_kernel(const GatherIn g, const 
             const int stripe = blockIdx.x & (VG_STRIPES - 1);
             if (co < p.Cout) atomicAdd(&p.sums[(((size_t)stripe * gridDim.z + n) * p.Cout + co) * 2 + (tid & 1)], stat[tid]);
         }
+        if (p.fin.ticket) vg_fin_tail(p.fin, p.sums, gridDim.z, p.Cout, gridDim.x * gridDim.y * gridDim.z, (int*)stat);
     }
 }
 
@@ -793,6 +795,7 @@ static int fill_conv(const vg_conv_desc* d, GatherIn& g, ConvOut& k, ConvCls& q,
     k.out = d->out; k.out_f32 = (d->out_f32 || d->f32) ? 1 : 0; k.accumulate = d->accumulate; k.sums = d->out_sums;
     k.bs_x0 = nullptr; k.xw = 0;
     k.ks = 1; k.ks_part = nullptr; k.ks_cnt = nullptr;
+    k.fin = vg_fin_of(d);
     k.scratch = (char*)d->scratch; k.scratch_bytes = d->scratch ? d->scratch_bytes : 0;
     if (const vg_actnorm_bwd_desc* b = d->bstat) {       // validated by vg_conv3d
         k.bs_x0 = b->x; k.bs_x1 = b->x1; k.bs_c0 = b->x1 ? b->c_x0 : b->C; k.bs_sh = b->x1 ? (b->x0_shift ? 1 : 0) : 0;
@@ -851,6 +854,7 @@ static int launch_conv32b(const GatherIn& g, const ConvOut& k, const ConvCls& q,
     // (walk: a workgroup visits more than one tile; ch: several channel chunks per tile)
     if (vg_dry("conv32<%d,%d,n%d,cp%d>|walk%d|ch%d", BN, MSUB, (int)NOISE, (int)CP, tiles > bx ? 1 : 0, k.nchunks > 1 ? 1 : 0)) return VG_OK;
     hipLaunchKernelGGL((conv32_kernel<BN, MSUB, NOISE, CP>), dim3(bx * ncp, ny, g.N), dim3(256), lds, s, g, k, q);
+    if (k.fin.ticket && k.sums) vg_fin_done = true;
     return vg_check_launch();
 }
 static int launch_conv32(const GatherIn& g, const ConvOut& k, const ConvCls& q, int BN, int MSUB, int lds, hipStream_t s) {
@@ -935,6 +939,7 @@ static int launch_conv3(const GatherIn& g, const ConvOut& k, const ConvCls& q, i
     if (ks > 1) { k2.ks_cnt = (unsigned*)k.scratch; k2.ks_part = (float*)(k.scratch + VG_SCRATCH_CTR_BYTES); }
     dim3 grid(bx * ncp * ks, ny, g.N);
     hipLaunchKernelGGL((conv_kernel<T, BN, MSUB, NOISE, WL, DMA, MC, C1>), grid, dim3(256), lds, s, g, k2, q);
+    if (k2.fin.ticket && k2.sums) vg_fin_done = true;
     return vg_check_launch();
 }
 template <typename T, int BN, int MSUB, bool NOISE>
@@ -1013,9 +1018,38 @@ static int conv3d_impl(const vg_conv_desc* d, vg_stream_t stream, bool& did_stat
     return d->f32 ? dispatch_conv<float>(g, k, q, BN, MSUB, lds, s) : dispatch_conv<bf16_t>(g, k, q, BN, MSUB, lds, s);
 }
 
+thread_local bool vg_fin_done = false;
+__global__ void fin_kernel(VgFin f, const float* sums, int N, int C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * C) return;
+    const int n = i / C, c = i - n * C;
+    float s = 0.f, ss = 0.f;
+    for (int t = 0; t < VG_STRIPES; ++t) { const float* p = sums + (((size_t)t * N + n) * C + c) * 2; s += p[0]; ss += p[1]; }
+    vg_fin_one(f, s, ss, n, c);
+}
+int vg_launch_fin(const vg_conv_desc* d, hipStream_t s) {
+    const VgFin f = vg_fin_of(d);
+    if (!f.njobs) return VG_OK;
+    const int total = d->N * d->Cout;
+    hipLaunchKernelGGL(fin_kernel, dim3((total + 255) / 256), dim3(256), 0, s, f, (const float*)d->out_sums, d->N, d->Cout);
+    return vg_check_launch();
+}
+static int fin_check(const vg_conv_desc* d) {
+    const vg_fin_desc* f = d->fin;
+    if (!f) return VG_OK;
+    if (!d->out_sums || !f->ticket || f->njobs < 1 || f->njobs > 2 || !(f->count > 0.f)) return VG_EINVAL;
+    for (int j = 0; j < f->njobs; ++j) {
+        const vg_fin_job& q = f->job[j];
+        if (!q.scale || !q.shift || q.c_off < 0 || q.c_off + d->Cout > q.c_tot) return VG_EINVAL;
+    }
+    return VG_OK;
+}
+
 extern "C" int vg_conv3d(const vg_conv_desc* d, vg_stream_t stream) {
     vg_begin();
     if (!d) return VG_EINVAL;
+    if (fin_check(d) != VG_OK) return VG_EINVAL;
+    vg_fin_done = false;
     const vg_actnorm_bwd_desc* b = d->bstat;
     if (b) {
         // the statistics are those of THIS launch's complete output: same tensor, same grid, plain bf16 stores
@@ -1025,7 +1059,8 @@ extern "C" int vg_conv3d(const vg_conv_desc* d, vg_stream_t stream) {
             return VG_EINVAL;
     }
     bool did_stats = false;
-    const int rc = conv3d_impl(d, stream, did_stats);
+    int rc = conv3d_impl(d, stream, did_stats);
+    if (rc == VG_OK && d->fin && !vg_fin_done && !vg_dry_on()) rc = vg_launch_fin(d, (hipStream_t)stream);
     if (rc != VG_OK || !b || vg_dry_on()) return rc;
     if (did_stats) return rc;                       // the epilogue left the striped sums in b->red; the apply pass adds them up
     return vg_actnorm_bwd_stats(b, stream);

@@ -19,6 +19,7 @@ struct ConvOut {
     // K split over workgroups (conv_kernel, small grids): slices per tile, fp32 partial tiles, arrival counters per (sample, panel, tile)
     int ks; float* ks_part; unsigned* ks_cnt;
     char* scratch; long scratch_bytes;          // vg_conv_desc::scratch (host-side planning only)
+    VgFin fin;          // InstanceNorm finalisation of the output by the last workgroup (vg_conv_desc::fin); ticket == nullptr: off
 };
 // output-parity classes fused into one launch (data gradient of a strided conv): a separate kernel argument that only the
 // multi-class kernel variants read

@@ -771,6 +771,7 @@ extern "C" int vg_abi_sizeof(int which) {
         case 0: return (int)sizeof(vg_conv_desc);
         case 1: return (int)sizeof(vg_actnorm_bwd_desc);
         case 2: return (int)sizeof(vg_pack_item);
+        case 3: return (int)sizeof(vg_fin_desc);
         default: return VG_EINVAL;
     }
 }

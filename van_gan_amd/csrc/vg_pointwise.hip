@@ -24,6 +24,7 @@ struct PW {
     const void* dy; int dy_f32;            // weight gradient
     float* dw; float* db;
     int N, C; int64_t S;
+    VgFin fin;                             // InstanceNorm finalisation of the output by the last workgroup (pw_1toc)
 };
 
 __device__ __forceinline__ float pw_slope(int act) { return act == VG_ACT_RELU ? 0.f : (act == VG_ACT_LRELU ? VG_LRELU : 1.f); }
@@ -149,6 +150,7 @@ __global__ __launch_bounds__(256) void pw_1toc_kernel(const PW p) {
         for (int t = 0; t < vpb; ++t) a += src[t * gpc];
         atomicAdd(&dst[o], a);
     }
+    if (p.fin.ticket) vg_fin_tail(p.fin, p.sums, gridDim.y, p.C, gridDim.x * gridDim.y, (int*)part);
 }
 
 // ---- Cin (8 or 16) -> C, plain source (the data gradient of a 1x1x1 shortcut convolution, decoder level 0: 16 -> 48 at 128^3,
@@ -230,6 +232,7 @@ struct PWG {
     // read), the forward operands nx0 (low resolution, channels < sc0) / nx1 and the per-(sample, channel) constants
     const bf16_t* ng; const bf16_t* nx0; const bf16_t* nx1;
     const float* n_scale; const float* n_shift; const float* n_mean; const float* n_rstd; const float* n_gamma; const float* n_mult;
+    VgFin fin;                           // STATS launches: InstanceNorm finalisation of the output by the last workgroup
     const float* n_red; float* n_dgamma; float* n_dbeta; int n_act;
 };
 }
@@ -553,6 +556,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const PWG p) {
             const int stripe = blockIdx.x & (VG_STRIPES - 1);
             if (co < p.Cout) atomicAdd(&p.sums[(((size_t)stripe * gridDim.y + n) * p.Cout + co) * 2 + (tid & 1)], stat[tid]);
         }
+        if (p.fin.ticket) vg_fin_tail(p.fin, p.sums, gridDim.y, p.Cout, gridDim.x * gridDim.y, (int*)stat);
     }
 }
 
@@ -747,6 +751,7 @@ struct C1K3 {
     const float* bias; void* out; float* sums;
     const void* dy; float* dw; float* db;
     const float* scale; const float* shift;
+    VgFin fin;
 };
 __device__ __forceinline__ int c1_resolve(int p, int n, int reflect, bool& ok) {
     ok = true;
@@ -853,6 +858,7 @@ __global__ __launch_bounds__(256, 3) void c1k3_fwd_kernel(C1K3 p) {
         for (int t = 0; t < qpb; ++t) a += src[t * gpc];
         atomicAdd(&dst[o], a);
     }
+    if (p.fin.ticket) vg_fin_tail(p.fin, p.sums, gridDim.y, p.C, gridDim.x * gridDim.y, (int*)part);
 }
 
 // weight gradient: thread = (quad, 8-channel group, d-offset a): 3 x 3 x 8 accumulators dW[a][b][j][c] (+ bias gradient in the
@@ -993,6 +999,7 @@ int pw_gemm_conv(const vg_conv_desc* d, hipStream_t s) {
     p.N = d->N; p.ID = d->D; p.IH = d->H; p.IW = d->W; p.OD = d->OD; p.OH = d->OH; p.OW = d->OW; p.istr = d->istr;
     p.BD = d->BD; p.BH = d->BH; p.BW = d->BW; p.ostr = d->ostr; p.od0 = d->ooff_d; p.oh0 = d->ooff_h; p.ow0 = d->ooff_w;
     p.Cout = d->Cout; p.SO = (int)SO; p.stamps = g_vg_stamps;
+    p.fin = vg_fin_of(d);
     const int MS = (KS * NB <= 2) ? 4 : 2;
     const int64_t nwt = (SO + MS * 16 - 1) / (MS * 16);
     int64_t b = (nwt + 3) / 4;
@@ -1002,7 +1009,7 @@ int pw_gemm_conv(const vg_conv_desc* d, hipStream_t s) {
     const dim3 grid((int)b, d->N);
     if (vg_dry("pw_gemm<%d,%d,g%d,a%d>", KS, NB, (geo || !d->accumulate) ? 1 : 0, d->accumulate ? 1 : 0)) return VG_OK;
     bool ok;
-    if (!d->accumulate) ok = pwg_launch<true, false, true>(KS, NB, grid, s, p);
+    if (!d->accumulate) { ok = pwg_launch<true, false, true>(KS, NB, grid, s, p); if (ok && p.sums && p.fin.ticket) vg_fin_done = true; }
     else ok = geo ? pwg_launch<true, true, false>(KS, NB, grid, s, p) : pwg_launch<false, true, false>(KS, NB, grid, s, p);
     return ok ? vg_check_launch() : 1;
 }
@@ -1110,6 +1117,7 @@ int vg_pointwise_conv(const vg_conv_desc* d, hipStream_t s) {
         C1K3 c;
         if (c1k3_fill(d, c)) {
             c.w = d->wpacked; c.bias = d->bias; c.out = d->out; c.sums = d->out_sums;
+            c.fin = vg_fin_of(d);
             const int qpb = 256 / (c.C >> 3);
             int64_t b = ((int64_t)c.D * c.H * c.W4 + qpb - 1) / qpb;
             const int64_t cap = (2047 / d->N) > 0 ? (2047 / d->N) : 1;
@@ -1123,6 +1131,7 @@ int vg_pointwise_conv(const vg_conv_desc* d, hipStream_t s) {
                 if (d->src_f32) hipLaunchKernelGGL((c1k3_fwd_kernel<bf16_t, float>), grid, dim3(256), 0, s, c);
                 else hipLaunchKernelGGL((c1k3_fwd_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, s, c);
             }
+            if (c.sums && c.fin.ticket) vg_fin_done = true;
             return vg_check_launch();
         }
     }
@@ -1159,8 +1168,10 @@ int vg_pointwise_conv(const vg_conv_desc* d, hipStream_t s) {
         const int vpb = 256 / (p.C >> 3);
         const dim3 grid(pw_blocks((p.S + 3) / 4 * (256 / vpb), d->N), d->N);
         if (vg_dry("pw_1toc<%s>", d->f32 ? "f32" : "bf16")) return VG_OK;
+        p.fin = vg_fin_of(d);
         if (d->f32) hipLaunchKernelGGL((pw_1toc_kernel<float>), grid, dim3(256), 0, s, p);
         else hipLaunchKernelGGL((pw_1toc_kernel<bf16_t>), grid, dim3(256), 0, s, p);
+        if (p.sums && p.fin.ticket) vg_fin_done = true;
         return vg_check_launch();
     }
     if ((Cin == 8 || Cin == 16) && d->Cout >= 16 && d->Cout <= 128 && (d->Cout % 8) == 0 && !d->in_scale && d->act == VG_ACT_NONE

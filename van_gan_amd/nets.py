@@ -172,6 +172,17 @@ class Norm:
         self.gamma, self.beta = store.param(name + '.gamma'), store.param(name + '.beta')
         self.dgamma, self.dbeta = store.grad(name + '.gamma'), store.grad(name + '.beta')
 
+    def state(self, arena: Arena, N: int, mult=None) -> dict:
+        """The per-application arrays of this norm, to be filled by the launch(es) that produce its input (ops.fin_desc: the last
+        workgroup of the producing convolution finalises the statistics -- no vg_in_finalize launch between producer and consumer)."""
+        st = {k: arena.alloc((N, self.C), torch.float32) for k in ('scale', 'shift', 'mean', 'rstd')}
+        st['mult'] = mult
+        return st
+
+    def job(self, st: dict, c_off: int = 0):
+        """One consumer entry of ops.fin_desc: the producer's channels land at [c_off, c_off + its Cout) of this norm's arrays."""
+        return (self.gamma, self.beta, st['mult'], st, c_off, self.C)
+
     def finalize(self, arena: Arena, a0: Act, a1: Optional[Act] = None, mult=None):
         N = a0.N
         # (four allocations with the sample index leading: the paired arena mode doubles the leading dimension)
@@ -295,16 +306,21 @@ class ResUNet:
         self._ptab.run()
 
     # ---------------------------------------------------------------------------------------------
-    def _block_fwd(self, ar: Arena, name: str, N: int, src_raw: Src, nrm_inputs, out_dims, co, ctx, save: bool = True):
+    def _block_fwd(self, ar: Arena, name: str, N: int, src_raw: Src, nrm_inputs, out_dims, co, ctx, save: bool = True, n1=None,
+                   out_jobs=None):
         """residual_block (resunet_model.py:103-143): out = conv2(relu(IN(conv1(relu(IN(x)))))) + IN(short(x)).
         save=False (inference): the block output is allocated first and everything else the block allocates (r, the
-        shortcut, the InstanceNorm scale/shift vectors) is handed back to the arena once the block's kernels are queued."""
+        shortcut, the InstanceNorm scale/shift vectors) is handed back to the arena once the block's kernels are queued.
+        n1 / out_jobs (ops.FIN_TAIL): the state of the block's first norm, already filled by the launches that produced its input, and
+        the consumer entries (Norm.job) of the norms that read the block's OUTPUT -- finalised by the block's last convolution."""
         L, Nn = self.L, self.Nn
         out = mk = None
         if not save:
             out = Act(ar, N, out_dims, co, dtype=self.dtype)
             mk = ar.mark()
-        n1 = Nn[name + '.cb1'].finalize(ar, *nrm_inputs)
+        tail = n1 is not None
+        if not tail:
+            n1 = Nn[name + '.cb1'].finalize(ar, *nrm_inputs)
         s1 = Src(src_raw.x0, (N,) + tuple(L[name + '.cb1'].in_dims), src_raw.c0, src_raw.x1, src_raw.c1, src_raw.shift0,
                  scale=n1['scale'], shift=n1['shift'], act=ACT_RELU)
         r = Act(ar, N, out_dims, co, dtype=self.dtype)
@@ -313,17 +329,24 @@ class ResUNet:
         # lane's side stream (idle in the forward pass) it leaves the dependent chain, which on the deep levels is all latency
         # (28.45 -> 28.30 ms per step, inference 49.6 -> 48.4 ms per volume).  The same for the shortcut's IN backward on an
         # auxiliary stream per lane was measured slower (29.3 ms): the backward already runs four streams.
+        if tail:
+            ns, n2 = Nn[name + '.short'].state(ar, N), Nn[name + '.cb2'].state(ar, N)
+            f_s = ops.fin_desc(ar, sc.count, [Nn[name + '.short'].job(ns)])
+            f_1 = ops.fin_desc(ar, r.count, [Nn[name + '.cb2'].job(n2)])
         fork = ops.fork_side()
         with fork:
-            L[name + '.short'].forward(src_raw, sc.data, sums=sc.sums)
-            ns = Nn[name + '.short'].finalize(ar, sc)
-        L[name + '.cb1'].forward(s1, r.data, sums=r.sums)
-        n2 = Nn[name + '.cb2'].finalize(ar, r)
+            L[name + '.short'].forward(src_raw, sc.data, sums=sc.sums, fin=f_s if tail else None)
+            if not tail:
+                ns = Nn[name + '.short'].finalize(ar, sc)
+        L[name + '.cb1'].forward(s1, r.data, sums=r.sums, fin=f_1 if tail else None)
+        if not tail:
+            n2 = Nn[name + '.cb2'].finalize(ar, r)
         fork.join()
         s2 = Src(r.data, (N,) + tuple(out_dims), co, scale=n2['scale'], shift=n2['shift'], act=ACT_RELU)
         if out is None:
             out = Act(ar, N, out_dims, co, dtype=self.dtype)
-        L[name + '.cb2'].forward(s2, out.data, sums=out.sums, res=sc.data, res_scale=ns['scale'], res_shift=ns['shift'])
+        f_o = ops.fin_desc(ar, out.count, out_jobs) if (tail and out_jobs) else None
+        L[name + '.cb2'].forward(s2, out.data, sums=out.sums, res=sc.data, res_scale=ns['scale'], res_shift=ns['shift'], fin=f_o)
         if save:
             ctx[name] = dict(n1=n1, s1=s1, r=r, sc=sc, ns=ns, n2=n2, s2=s2, out=out, src_raw=src_raw)
         else:
@@ -342,34 +365,58 @@ class ResUNet:
         N = x.shape[0]
         f, lv, L, Nn = GEN_F, self.lv, self.L, self.Nn
         ctx = {'N': N, 'x': x, 'y': y}
+        # ops.FIN_TAIL: every InstanceNorm's scale / shift / mean / rstd is written by the last workgroup of the launch that produces
+        # the norm's input (vg_fin_desc) -- 30 vg_in_finalize launches per application leave the lane's dependent chain.  A block's
+        # FIRST norm reads the previous block's output (a decoder block's: [upsampled low-resolution output; encoder skip], two
+        # producers, two channel ranges of one array), so those states exist before the first launch.
+        tail = ops.FIN_TAIL
+        pre, jobs = {}, {}
+        if tail:
+            pre['stem.cb'], pre['stem.short'] = Nn['stem.cb'].state(ar, N), Nn['stem.short'].state(ar, N)
+            for b in ['enc%d' % e for e in range(1, 5)] + ['dec%d' % d for d in (3, 2, 1, 0)]:
+                pre[b] = Nn[b + '.cb1'].state(ar, N)
+            pre['bridge.cb1'], pre['bridge.cb2'] = Nn['bridge.cb1'].state(ar, N), Nn['bridge.cb2'].state(ar, N)
+            # consumers of every block output: skips[d] (stem, enc1..enc3) feeds enc(d+1).cb1 and, behind the f[d+1] upsampled
+            # channels, dec(d).cb1; enc4 feeds the bridge; bridge / dec outputs feed the next decoder block's low half
+            jobs['stem'] = [Nn['enc1.cb1'].job(pre['enc1']), Nn['dec0.cb1'].job(pre['dec0'], f[1])]
+            for e in range(1, 4):
+                jobs['enc%d' % e] = [Nn['enc%d.cb1' % (e + 1)].job(pre['enc%d' % (e + 1)]), Nn['dec%d.cb1' % e].job(pre['dec%d' % e], f[e + 1])]
+            jobs['enc4'] = [Nn['bridge.cb1'].job(pre['bridge.cb1'])]
+            jobs['bridge.cb1'] = [Nn['bridge.cb2'].job(pre['bridge.cb2'])]
+            jobs['bridge.cb2'] = [Nn['dec3.cb1'].job(pre['dec3'])]
+            for d in (3, 2, 1):
+                jobs['dec%d' % d] = [Nn['dec%d.cb1' % (d - 1)].job(pre['dec%d' % (d - 1)])]
+            jobs['dec0'] = None
         sx = Src(x, (N,) + lv[0], 1, f32=True)
         c1 = Act(ar, N, lv[0], f[0], dtype=self.dtype)
-        L['stem.conv1'].forward(sx, c1.data, sums=c1.sums)
+        L['stem.conv1'].forward(sx, c1.data, sums=c1.sums, fin=ops.fin_desc(ar, c1.count, [Nn['stem.cb'].job(pre['stem.cb'])]) if tail else None)
         sc = Act(ar, N, lv[0], f[0], dtype=self.dtype)
-        L['stem.short'].forward(sx, sc.data, sums=sc.sums)
-        ns = Nn['stem.short'].finalize(ar, sc)
-        n1 = Nn['stem.cb'].finalize(ar, c1)
+        L['stem.short'].forward(sx, sc.data, sums=sc.sums, fin=ops.fin_desc(ar, sc.count, [Nn['stem.short'].job(pre['stem.short'])]) if tail else None)
+        ns = pre['stem.short'] if tail else Nn['stem.short'].finalize(ar, sc)
+        n1 = pre['stem.cb'] if tail else Nn['stem.cb'].finalize(ar, c1)
         s1 = Src(c1.data, (N,) + lv[0], f[0], scale=n1['scale'], shift=n1['shift'], act=ACT_RELU)
         h = Act(ar, N, lv[0], f[0], dtype=self.dtype)
-        L['stem.cb'].forward(s1, h.data, sums=h.sums, res=sc.data, res_scale=ns['scale'], res_shift=ns['shift'])
+        L['stem.cb'].forward(s1, h.data, sums=h.sums, res=sc.data, res_scale=ns['scale'], res_shift=ns['shift'],
+                             fin=ops.fin_desc(ar, h.count, jobs['stem']) if tail else None)
         ctx['stem'] = dict(sx=sx, c1=c1, sc=sc, ns=ns, n1=n1, s1=s1, out=h)
         yield
         skips = [h]
         for e in range(1, 5):
             raw = Src(h.data, (N,) + lv[e - 1], f[e - 1])
-            h = self._block_fwd(ar, 'enc%d' % e, N, raw, (h,), lv[e], f[e], ctx, save)
+            b = 'enc%d' % e
+            h = self._block_fwd(ar, b, N, raw, (h,), lv[e], f[e], ctx, save, n1=pre.get(b), out_jobs=jobs.get(b))
             if save:
                 ctx['enc%d' % e]['inp'] = (skips[-1],)
             skips.append(h)
             yield
-        nb1 = Nn['bridge.cb1'].finalize(ar, h)
+        nb1 = pre['bridge.cb1'] if tail else Nn['bridge.cb1'].finalize(ar, h)
         sb1 = Src(h.data, (N,) + lv[4], f[4], scale=nb1['scale'], shift=nb1['shift'], act=ACT_RELU)
         b1 = Act(ar, N, lv[4], f[4], dtype=self.dtype)
-        L['bridge.cb1'].forward(sb1, b1.data, sums=b1.sums)
-        nb2 = Nn['bridge.cb2'].finalize(ar, b1)
+        L['bridge.cb1'].forward(sb1, b1.data, sums=b1.sums, fin=ops.fin_desc(ar, b1.count, jobs['bridge.cb1']) if tail else None)
+        nb2 = pre['bridge.cb2'] if tail else Nn['bridge.cb2'].finalize(ar, b1)
         sb2 = Src(b1.data, (N,) + lv[4], f[4], scale=nb2['scale'], shift=nb2['shift'], act=ACT_RELU)
         b2 = Act(ar, N, lv[4], f[4], dtype=self.dtype)
-        L['bridge.cb2'].forward(sb2, b2.data, sums=b2.sums)
+        L['bridge.cb2'].forward(sb2, b2.data, sums=b2.sums, fin=ops.fin_desc(ar, b2.count, jobs['bridge.cb2']) if tail else None)
         ctx['bridge'] = dict(inp=h, nb1=nb1, sb1=sb1, b1=b1, nb2=nb2, sb2=sb2, b2=b2)
         h = b2
         for d in (3, 2, 1, 0):
@@ -377,7 +424,8 @@ class ResUNet:
             raw = Src(h.data, (N,) + lv[d], h.C, skip.data, skip.C, shift0=1)       # virtual upsample + concat
             low = h
             yield
-            h = self._block_fwd(ar, 'dec%d' % d, N, raw, (low, skip), lv[d], f[d], ctx, save)
+            b = 'dec%d' % d
+            h = self._block_fwd(ar, b, N, raw, (low, skip), lv[d], f[d], ctx, save, n1=pre.get(b), out_jobs=jobs.get(b))
             if save:
                 ctx['dec%d' % d]['inp'] = (low, skip)
         so = Src(h.data, (N,) + lv[0], f[0])
@@ -803,12 +851,16 @@ class PatchGAN:
         ctx = {'N': N, 'x': x}
         src = Src(x, (N,) + lv[0], 1, f32=True, noise=noise.get('conv0'), noise_pad=1)
         acts, srcs, sts = [], [src], []
+        tail = ops.FIN_TAIL
         h = Act(ar, N, lv[1], 64, dtype=self.dtype)
-        L['conv0'].forward(src, h.data, sums=h.sums)
+        # (ops.FIN_TAIL: the norm behind a convolution -- with that layer's channel-dropout multipliers folded in -- is finalised by the
+        # convolution's own launch: four vg_in_finalize launches per application leave the chain)
+        nxt = Nn['conv0'].state(ar, N, mult=None) if tail else None
+        L['conv0'].forward(src, h.data, sums=h.sums, fin=ops.fin_desc(ar, h.count, [Nn['conv0'].job(nxt)]) if tail else None)
         acts.append(h)
         prev_drop = None
         for i, k in enumerate(['down0', 'down1', 'down2', 'out']):
-            st = Nn[self.NAMES[i]].finalize(ar, h, mult=prev_drop)
+            st = nxt if tail else Nn[self.NAMES[i]].finalize(ar, h, mult=prev_drop)
             sts.append(st)
             lay = L[k]
             src = Src(h.data, (N,) + tuple(lay.in_dims), h.C, scale=st['scale'], shift=st['shift'], act=ACT_LRELU,
@@ -818,9 +870,10 @@ class PatchGAN:
                 lay.forward(src, logits)
             else:
                 h = Act(ar, N, lay.out_dims, lay.cout, dtype=self.dtype)
-                lay.forward(src, h.data, sums=h.sums)
-                acts.append(h)
                 prev_drop = drop.get(k)
+                nxt = Nn[k].state(ar, N, mult=prev_drop) if tail else None
+                lay.forward(src, h.data, sums=h.sums, fin=ops.fin_desc(ar, h.count, [Nn[k].job(nxt)]) if tail else None)
+                acts.append(h)
         ctx.update(acts=acts, srcs=srcs, sts=sts)
         return ctx
 

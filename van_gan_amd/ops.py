@@ -11,7 +11,7 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, PAD_REFLECT, PAD_ZERO, ActNormBwdDesc, ConvDesc, check, lib
+from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, PAD_REFLECT, PAD_ZERO, ActNormBwdDesc, ConvDesc, FinDesc, check, lib
 
 IN_EPS = 1e-3          # tfa InstanceNormalization default epsilon (resunet_model.py:36)
 STRIPES = 8            # VG_STRIPES of include/vangan_hip.h
@@ -821,9 +821,16 @@ class ConvLayer:
         return d
 
     def forward(self, src: Src, out: torch.Tensor, sums=None, res=None, res_scale=None, res_shift=None,
-                tanh: bool = False, accumulate: bool = False):
+                tanh: bool = False, accumulate: bool = False, fin: Optional[FinDesc] = None):
+        """fin (ops.fin_desc, with sums): the launch also finalises the InstanceNorm statistics of `out` for its consuming norm(s)."""
         assert src.C == self.cin and (src.D, src.H, src.W) == tuple(self.in_dims)
         d = self._fwd_desc(src)
+        if fin is not None:
+            assert sums is not None
+            d.fin = C.addressof(fin)
+            d._fin_keep = fin
+            if REC is not None:
+                REC.keep.append(fin)
         d.bias = _p(self.b)
         d.res, d.res_scale, d.res_shift = _p(res), _p(res_scale), _p(res_shift)
         d.tanh_out = int(tanh)
@@ -1131,6 +1138,26 @@ def in_finalize(sums0, c0, count0, gamma, beta, N, scale, shift, mean=None, rstd
                 mult=None):
     check(lib.vg_in_finalize(_p(sums0), c0, float(count0), _p(sums1), c1, float(count1), _p(gamma), _p(beta), _p(mult),
                              N, IN_EPS, _p(scale), _p(shift), _p(mean), _p(rstd), stream()), 'vg_in_finalize')
+
+
+FIN_TAIL = os.environ.get('VG_FIN_TAIL', '1') != '0'     # InstanceNorm finalisation by the producing launch's last workgroup (vg_fin_desc)
+
+
+def fin_desc(ar: 'Arena', count: float, jobs) -> FinDesc:
+    """vg_fin_desc of a producing launch: jobs = [(gamma, beta, mult, state, c_off, c_tot)], state = {'scale', 'shift', 'mean', 'rstd'}
+    tensors [N, c_tot] of the consuming norm.  The ticket word comes from the arena's zero pool (cleared once per step)."""
+    f = FinDesc()
+    tk = ar.alloc((1,), torch.int32, zero=True)
+    f.ticket, f.count, f.eps, f.njobs = _p(tk), float(count), IN_EPS, len(jobs)
+    keep = [tk]
+    for j, (gamma, beta, mult, st, c_off, c_tot) in enumerate(jobs):
+        q = f.job[j]
+        q.gamma, q.beta, q.mult = _p(gamma), _p(beta), _p(mult)
+        q.scale, q.shift, q.mean, q.rstd = _p(st['scale']), _p(st['shift']), _p(st['mean']), _p(st['rstd'])
+        q.c_off, q.c_tot = c_off, c_tot
+        keep += [gamma, beta, mult, st]
+    f._keep = keep
+    return f
 
 
 def alloc_red(ar: 'Arena', N: int, C_: int) -> torch.Tensor:
