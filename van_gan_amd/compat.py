@@ -38,7 +38,10 @@ def engine_kwargs_from_args(args, lambda_cycle=10.0, lambda_identity=5, lambda_r
                                   "section 8(f)4, for gen_i2s == gen_s2i == 'resnet' (generator.py:7-73: van_gan_amd.nets.ResNetGenerator, "
                                   "tests/test_gpu_resnet.py); 'vnet' and mixed pairs are not built")
     if wasserstein:
-        raise NotImplementedError('the WGAN-GP branch (vangan.py:355-378,400-423) is not built: SURVEY section 8(f)4')
+        raise NotImplementedError('wasserstein=True is not built (SURVEY section 8(f)4).  Note that the reference cannot apply its own gradient '
+                                  'penalty: it is computed after the GradientTape has closed (vangan.py:394-398 vs :410-415) and the Python flags that '
+                                  'gate it are frozen when distributed_train_step is traced (@tf.function, :475; initModel / updateGen, :64-65): DESIGN.md '
+                                  'section 8')
     if semi_supervised:
         raise NotImplementedError('semi_supervised is never enabled by main.py and is not built')
     if int(args.DIMENSIONS) != 3:
