@@ -380,6 +380,18 @@ int vg_dot_sums(const float* a, const float* b, int64_t n, float* sums3, vg_stre
 int vg_axpby(const float* a, float alpha, const float* b, float beta, int64_t n, float* y, int accumulate,
              vg_stream_t stream);
 
+/* Wasserstein mode -- what `wasserstein=True` of the reference trains once traced (its gradient penalty never reaches a weight: DESIGN.md
+ * section 8): the discriminator's Flatten -> Dropout(0.2) -> Dense(1) head over the patch logits (discriminator.py:116-119),
+ *   z[s] = b + sum_i w[i] * mask[s][i] * x[s][i]          (mask: dropout multipliers {0, 1/(1-rate)} or NULL),
+ * its backward  dx[s][i] = gz[s] * mask[s][i] * w[i],  dw[i] += sum_s gz[s] * mask[s][i] * x[s][i],  db += sum_s gz[s]  (dx / dw / db
+ * optional), and the loss terms of loss_functions.py:325-355 on z = [real (B); fake (B)]: acc2[0] += sum z_real, acc2[1] += sum z_fake,
+ * gz_d[2B] = d(-reduce_mean(D(real) - D(fake)))/dz = (-inv ..., +inv ...), gz_g[B] = d(-reduce_mean(D(fake)))/dz_fake = -inv,
+ * inv = 1 / (B * global batch size) (reduce_mean(axis=None) averages over the batch too, loss_functions.py:21-22). */
+int vg_dense_head_fwd(const float* x, const float* mask, const float* w, const float* b, int N, int n, float* z, vg_stream_t stream);
+int vg_dense_head_bwd(const float* x, const float* mask, const float* w, const float* gz, int N, int n, float* dx, float* dw, float* db,
+                      vg_stream_t stream);
+int vg_wasserstein_terms(const float* z, int B, float inv, float* acc2, float* gz_d, float* gz_g, vg_stream_t stream);
+
 /* Sliding-window inference (GanMonitor.stitch_subvolumes, custom_callback.py:47-223): pred/cnt [X][Y][Z] fp32.
  * vg_overlap_add: pred[box] += window[crop], cnt[box] += 1 for the border-cropped box of one k^3 window at (x0,y0,z0)
  * (custom_callback.py:165-183); vg_divide_crop: out = pred/cnt on the un-padded sub-box (:192-200; 0/0 = NaN as numpy). */

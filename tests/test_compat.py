@@ -84,8 +84,10 @@ def test_error_behaviour_follows_the_reference():
         VanGan(_args(), None, gen_i2s='vnet', gen_s2i='vnet', engine_factory=_FakeEngine)
     with pytest.raises(NotImplementedError):
         VanGan(_args(), None, gen_i2s='resnet', gen_s2i='resUnet', engine_factory=_FakeEngine)
-    with pytest.raises(NotImplementedError):
-        engine_kwargs_from_args(_args(), gen_i2s='resUnet', gen_s2i='resUnet', wasserstein=True)
+    # wasserstein=True selects what the reference trains once its step is traced: Wasserstein losses, Dense head,
+    # the optimizers of vangan.py:195-203; the gradient penalty / n-critic arguments are accepted and inert
+    kw = engine_kwargs_from_args(_args(), gen_i2s='resUnet', gen_s2i='resUnet', wasserstein=True, ncritic=5, gp_weight=10.0)
+    assert kw['wasserstein'] is True and kw['lr'] == 1e-4 and kw['beta_1'] == 0.0 and kw['beta_2'] == 0.9 and kw['clipnorm'] == 0.0
     with pytest.raises(NotImplementedError):
         engine_kwargs_from_args(_args(DIMENSIONS=2), gen_i2s='resUnet', gen_s2i='resUnet')
 

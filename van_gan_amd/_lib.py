@@ -111,6 +111,9 @@ _SIGS = {
     'vg_soft_skel_bwd': ([c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p], c_int),
     'vg_cldice_coef': ([c_void_p, c_float, c_float, c_void_p, c_void_p], c_int),
     'vg_cldice_grads': ([c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_int, c_void_p], c_int),
+    'vg_dense_head_fwd': ([c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p], c_int),
+    'vg_dense_head_bwd': ([c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p], c_int),
+    'vg_wasserstein_terms': ([c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p], c_int),
     'vg_dot_sums': ([c_void_p, c_void_p, c_i64, c_void_p, c_void_p], c_int),
     'vg_overlap_add': ([c_void_p] + [c_int] * 12 + [c_void_p, c_void_p, c_void_p], c_int),
     'vg_divide_crop': ([c_void_p, c_void_p] + [c_int] * 9 + [c_void_p, c_void_p], c_int),

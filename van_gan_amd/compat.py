@@ -7,9 +7,11 @@ mirrored here.  What is read from ``args`` is exactly what the reference reads (
 INPUT_IMG_SIZE, CHANNELS, GLOBAL_BATCH_SIZE, DIMENSIONS, SUBVOL_PATCH_SIZE, train_steps, BATCH_SIZE, output_dir``.
 
 Differences that are deliberate and loud:
-  * built: 3-D, single channel, ``gen_i2s == gen_s2i == 'resUnet'`` (the default path) or ``== 'resnet'``, non-Wasserstein,
+  * built: 3-D, single channel, ``gen_i2s == gen_s2i == 'resUnet'`` (the default path) or ``== 'resnet'``, ``wasserstein`` False
+    or True (True = what the reference trains once its step is traced: Wasserstein losses, Dense head, the optimizers of
+    vangan.py:195-203; its gradient penalty never reaches a weight and ``ncritic`` is frozen at trace time -- DESIGN.md section 8),
     not semi-supervised.  Unknown generator names raise the reference's own ``ValueError`` (vangan.py:124,164); known but
-    unbuilt variants ('vnet', mixed generator pairs, Wasserstein, 2-D) raise ``NotImplementedError`` naming SURVEY section 8(f)4;
+    unbuilt variants ('vnet', mixed generator pairs, 2-D) raise ``NotImplementedError`` naming SURVEY section 8(f)4;
   * ``N_DEVICES == 0`` (what ``len(GPUs)`` gives on a box TensorFlow sees no GPU on, main.py:62-105) is read as 1: the
     reference would divide by zero in cycle_seg_loss (loss_functions.py:226) and build with GLOBAL_BATCH_SIZE 0;
   * ``strategy`` is accepted and ignored (None is fine): data parallelism is one process per GPU with a
@@ -37,11 +39,6 @@ def engine_kwargs_from_args(args, lambda_cycle=10.0, lambda_identity=5, lambda_r
         raise NotImplementedError("train_step is built for gen_i2s == gen_s2i == 'resUnet' (the default, main.py:196-200) and, SURVEY "
                                   "section 8(f)4, for gen_i2s == gen_s2i == 'resnet' (generator.py:7-73: van_gan_amd.nets.ResNetGenerator, "
                                   "tests/test_gpu_resnet.py); 'vnet' and mixed pairs are not built")
-    if wasserstein:
-        raise NotImplementedError('wasserstein=True is not built (SURVEY section 8(f)4).  Note that the reference cannot apply its own gradient '
-                                  'penalty: it is computed after the GradientTape has closed (vangan.py:394-398 vs :410-415) and the Python flags that '
-                                  'gate it are frozen when distributed_train_step is traced (@tf.function, :475; initModel / updateGen, :64-65): DESIGN.md '
-                                  'section 8')
     if semi_supervised:
         raise NotImplementedError('semi_supervised is never enabled by main.py and is not built')
     if int(args.DIMENSIONS) != 3:
@@ -61,7 +58,11 @@ def engine_kwargs_from_args(args, lambda_cycle=10.0, lambda_identity=5, lambda_r
         gbs = batch * n_dev                                           # N_DEVICES 0 made it 0 in main.py:70-71
     return dict(subvol_patch_size=patch, batch_size=batch, global_batch_size=gbs, n_devices=n_dev,
                 lambda_cycle=float(lambda_cycle), lambda_reconstruction=float(lambda_reconstruction),
-                lambda_topology=float(lambda_topology), output_dir=getattr(args, 'output_dir', None), generator=gen_i2s)
+                lambda_topology=float(lambda_topology), output_dir=getattr(args, 'output_dir', None), generator=gen_i2s,
+                # wasserstein=True: what the reference trains once distributed_train_step is traced -- Wasserstein losses, the Dense head,
+                # the optimizers of vangan.py:195-203, generators every step; its gradient penalty never reaches a weight and n-critic is
+                # frozen at trace time: ncritic / gp_weight are accepted and inert
+                **(dict(wasserstein=True, lr=1e-4, beta_1=0.0, beta_2=0.9, clipnorm=0.0) if wasserstein else {}))
 
 
 def to_device_volume(t, device) -> torch.Tensor:

@@ -890,6 +890,64 @@ extern "C" int vg_cldice_grads(const float* t, const float* skel_t, const float*
     return vg_check_launch();
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Wasserstein mode (what `wasserstein=True` of the reference actually trains): the discriminator's
+// Flatten -> Dropout(0.2) -> Dense(1) head over the patch logits (discriminator.py:116-119) and the critic / generator loss terms
+// (loss_functions.py:325-355: -reduce_mean(D(real) - D(fake)), -reduce_mean(D(fake))).  A few thousand values per sample: one workgroup each.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dense_head_fwd_kernel(const float* x, const float* mask, const float* w, const float* b, int n, float* z) {
+    __shared__ float sm[4];
+    const int s = blockIdx.x;
+    float a = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) a += x[(size_t)s * n + i] * (mask ? mask[(size_t)s * n + i] : 1.f) * w[i];
+    a = block_sum(a, sm);
+    if (threadIdx.x == 0) z[s] = a + (b ? b[0] : 0.f);
+}
+// dx[s][i] = gz[s] * m[s][i] * w[i];  dw[i] += sum_s gz[s] * m[s][i] * x[s][i];  db += sum_s gz[s]     (grid: ceil(n / 256) blocks)
+__global__ __launch_bounds__(256) void dense_head_bwd_kernel(const float* x, const float* mask, const float* w, const float* gz, int N, int n,
+                                                             float* dx, float* dw, float* db) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        float acc = 0.f;
+        const float wi = w[i];
+        for (int s = 0; s < N; ++s) {
+            const float m = mask ? mask[(size_t)s * n + i] : 1.f, g = gz[s];
+            if (dx) dx[(size_t)s * n + i] = g * m * wi;
+            acc += g * m * x[(size_t)s * n + i];
+        }
+        if (dw) dw[i] += acc;
+    }
+    if (db && blockIdx.x == 0 && threadIdx.x == 0) { float t = 0.f; for (int s = 0; s < N; ++s) t += gz[s]; db[0] += t; }
+}
+// z: [2B] head outputs of [real; fake].  acc[0] += sum z_real, acc[1] += sum z_fake; gz_d[2B] = d(D loss)/dz = (-inv ... , +inv ...),
+// gz_g[B] = d(G loss)/dz_fake = -inv, inv = 1 / (B * global batch size).
+__global__ void wasserstein_terms_kernel(const float* z, int B, float inv, float* acc, float* gz_d, float* gz_g) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    float r = 0.f, f = 0.f;
+    for (int s = 0; s < B; ++s) { r += z[s]; f += z[B + s]; if (gz_d) { gz_d[s] = -inv; gz_d[B + s] = inv; } if (gz_g) gz_g[s] = -inv; }
+    acc[0] += r; acc[1] += f;
+}
+extern "C" int vg_dense_head_fwd(const float* x, const float* mask, const float* w, const float* b, int N, int n, float* z, vg_stream_t stream) {
+    vg_begin();
+    if (!x || !w || !z || N < 1 || n < 1) return VG_EINVAL;
+    hipLaunchKernelGGL(dense_head_fwd_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, x, mask, w, b, n, z);
+    return vg_check_launch();
+}
+extern "C" int vg_dense_head_bwd(const float* x, const float* mask, const float* w, const float* gz, int N, int n, float* dx, float* dw, float* db,
+                                 vg_stream_t stream) {
+    vg_begin();
+    if (!x || !w || !gz || N < 1 || n < 1 || (!dx && !dw && !db)) return VG_EINVAL;
+    hipLaunchKernelGGL(dense_head_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, mask, w, gz, N, n, dx, dw, db);
+    return vg_check_launch();
+}
+extern "C" int vg_wasserstein_terms(const float* z, int B, float inv, float* acc2, float* gz_d, float* gz_g, vg_stream_t stream) {
+    vg_begin();
+    if (!z || !acc2 || B < 1) return VG_EINVAL;
+    hipLaunchKernelGGL(wasserstein_terms_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, z, B, inv, acc2, gz_d, gz_g);
+    return vg_check_launch();
+}
+
 // ------------------------------------------------------------------------------------------------
 // Sliding-window inference (custom_callback.py:47-223, stitch_subvolumes): overlap-add of border-cropped window
 // predictions with a coverage counter, then division.  Volumes are [X][Y][Z] fp32 (single channel).

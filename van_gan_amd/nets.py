@@ -50,7 +50,8 @@ def gen_param_specs() -> List[Tuple[str, Tuple[int, ...], str]]:
     return s
 
 
-def disc_param_specs() -> List[Tuple[str, Tuple[int, ...], str]]:
+def disc_param_specs(wasserstein_patches: int = 0) -> List[Tuple[str, Tuple[int, ...], str]]:
+    """wasserstein_patches = n > 0: + the Flatten -> Dropout(0.2) -> Dense(1) head of discriminator.py:116-119 over the n patch logits."""
     s: List[Tuple[str, Tuple[int, ...], str]] = []
     s.append(('conv0.w', (4, 4, 4, 1, 64), 'he_normal')); s.append(('conv0.b', (64,), 'zeros'))
     s.append(('conv0.in.gamma', (64,), 'glorot_vec')); s.append(('conv0.in.beta', (64,), 'zeros'))
@@ -61,6 +62,8 @@ def disc_param_specs() -> List[Tuple[str, Tuple[int, ...], str]]:
         s.append(('down%d.in.gamma' % i, (co,), 'glorot_vec')); s.append(('down%d.in.beta' % i, (co,), 'zeros'))
         ci = co
     s.append(('out.w', (3, 3, 3, 512, 1), 'he_normal')); s.append(('out.b', (1,), 'zeros'))
+    if wasserstein_patches:
+        s.append(('dense.w', (wasserstein_patches, 1), 'glorot_dense')); s.append(('dense.b', (1,), 'zeros'))
     return s
 
 
@@ -120,6 +123,8 @@ def init_reference(store: ParamStore, seed: int):
             t = torch.ones(shape)
         elif init == 'glorot_vec':
             t = (torch.rand(shape, generator=g) * 2 - 1) * math.sqrt(3.0 / shape[0])
+        elif init == 'glorot_dense':        # Dense kernel [in, out]
+            t = (torch.rand(shape, generator=g) * 2 - 1) * math.sqrt(6.0 / (shape[0] + shape[1]))
         elif init == 'he_vec':              # he_normal over a 1-D shape (C,): Keras' _compute_fans gives fan_in = fan_out = C
             t = torch.empty(shape)
             torch.nn.init.trunc_normal_(t, 0.0, 1.0, -2.0, 2.0, generator=g)
@@ -829,6 +834,21 @@ class PatchGAN:
         L['down2'] = ConvLayer(store, 'down2', 4, 256, 512, 1, 'same', False, lv[3], dtype=self.dtype)
         L['out'] = ConvLayer(store, 'out', 3, 512, 1, 1, 'same', True, lv[3], dtype=self.dtype)
         self.Nn = {k: Norm(store, k + '.in', c) for k, c in zip(self.NAMES[:4], self.ch[1:])}
+        # wasserstein=True (discriminator.py:116-119): Flatten -> Dropout(0.2) -> Dense(1) over the patch logits; present when the store has it
+        self.n_patch = lv[3][0] * lv[3][1] * lv[3][2]
+        self.dense = 'dense.w' in store.offsets
+        if self.dense:
+            self.dw_, self.db_ = store.param('dense.w'), store.param('dense.b')
+            self.gdw, self.gdb = store.grad('dense.w'), store.grad('dense.b')
+
+    def head_forward(self, logits: torch.Tensor, mask: Optional[torch.Tensor], z: torch.Tensor):
+        """z[N] = Dense(Dropout(Flatten(logits))): mask [N, n_patch] dropout multipliers (training) or None."""
+        ops.dense_head_fwd(logits, mask, self.dw_, self.db_, logits.shape[0], self.n_patch, z)
+
+    def head_backward(self, logits: torch.Tensor, mask: Optional[torch.Tensor], gz: torch.Tensor, dlogits: Optional[torch.Tensor], wgrad: bool):
+        """gz[N] = d loss / d z; dlogits (same shape as logits) is overwritten; wgrad: the Dense kernel / bias gradients are added."""
+        ops.dense_head_bwd(logits, mask, self.dw_, gz, logits.shape[0], self.n_patch, dx=dlogits, dw=self.gdw if wgrad else None,
+                           db=self.gdb if wgrad else None)
 
     def pack(self):
         if getattr(self, '_ptab', None) is None:

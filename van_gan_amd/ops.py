@@ -1305,6 +1305,18 @@ def dot_sums(a, b, sums3):
     check(lib.vg_dot_sums(_p(a), _p(b), a.numel(), _p(sums3), stream()), 'vg_dot_sums')
 
 
+def dense_head_fwd(x, mask, w, b, N, n, z):
+    check(lib.vg_dense_head_fwd(_p(x), _p(mask), _p(w), _p(b), N, n, _p(z), stream()), 'vg_dense_head_fwd')
+
+
+def dense_head_bwd(x, mask, w, gz, N, n, dx=None, dw=None, db=None):
+    check(lib.vg_dense_head_bwd(_p(x), _p(mask), _p(w), _p(gz), N, n, _p(dx), _p(dw), _p(db), stream()), 'vg_dense_head_bwd')
+
+
+def wasserstein_terms(z, B, inv, acc2, gz_d=None, gz_g=None):
+    check(lib.vg_wasserstein_terms(_p(z), B, inv, _p(acc2), _p(gz_d), _p(gz_g), stream()), 'vg_wasserstein_terms')
+
+
 def axpby(a, alpha, b, beta, y, accumulate=False):
     check(lib.vg_axpby(_p(a), alpha, _p(b), beta, a.numel(), _p(y), int(accumulate), stream()), 'vg_axpby')
 

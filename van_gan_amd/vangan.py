@@ -105,7 +105,12 @@ class VanGan:
                  lambda_reconstruction: float = 5.0, lambda_topology: float = 5.0, lr: float = 2e-4,
                  beta_1: float = 0.5, beta_2: float = 0.9, clipnorm: float = 100.0, layer_noise: float = 0.1,
                  dropout_rate: float = 0.2, skel_iters: int = 15, output_dir: Optional[str] = None,
-                 process_group=None, arena_bytes: Optional[int] = None, precision: str = 'bf16', generator: str = 'resUnet'):
+                 process_group=None, arena_bytes: Optional[int] = None, precision: str = 'bf16', generator: str = 'resUnet',
+                 wasserstein: bool = False):
+        """wasserstein=True: what the reference's wasserstein=True trains once its step is traced: Wasserstein critic /
+        generator losses (loss_functions.py:325-355), discriminators with the Flatten -> Dropout(0.2) -> Dense(1) head
+        (discriminator.py:116-119), generators updated every step, no gradient penalty (the reference's never reaches a weight).  Pass the
+        optimizers of vangan.py:195-203 explicitly: lr=1e-4, beta_1=0.0, beta_2=0.9, clipnorm=0 (compat.VanGan does)."""
         if not torch.cuda.is_available():
             raise RuntimeError('VanGan engine needs an MI355X (HIP device); there is no CPU fallback')
         if precision not in ('bf16', 'fp32'):
@@ -113,6 +118,7 @@ class VanGan:
         if generator not in ('resUnet', 'resnet'):
             raise ValueError("generator must be 'resUnet' (default, vangan.py:113-123) or 'resnet' (vangan.py:88-97)")
         self.generator = generator                # both generators of one engine have the same architecture
+        self.wasserstein = bool(wasserstein)
         self.precision = precision
         self.dtype = torch.bfloat16 if precision == 'bf16' else torch.float32
         self.device = torch.device(device)
@@ -149,7 +155,8 @@ class VanGan:
         self.stores: Dict[str, ParamStore] = {}
         for i, name in enumerate(NETS):
             gspecs = gen_param_specs() if generator == 'resUnet' else resnet_param_specs()
-            st = ParamStore(gspecs if name.startswith('gen') else disc_param_specs(), self.device)
+            n_patch = (self.dims[0] // 8) * (self.dims[1] // 8) * (self.dims[2] // 8) if self.wasserstein else 0
+            st = ParamStore(gspecs if name.startswith('gen') else disc_param_specs(n_patch), self.device)
             init_reference(st, seed + i)
             self.stores[name] = st
         GenNet = ResUNet if generator == 'resUnet' else ResNetGenerator
@@ -262,6 +269,14 @@ class VanGan:
                     ops.dropout_mask(t, self.dropout_rate, self.drop_key, self.rng_offset)
                 self.rng_offset += t.numel()
                 drop[k] = t
+            if self.wasserstein:                 # Dropout(0.2) in front of the Dense head: elementwise over the flattened patch logits
+                t = ar.alloc((N, disc.n_patch), torch.float32)
+                if self._cap is not None:
+                    ops.dropout_mask_dev(t, self.dropout_rate, self.drop_key + 77, self._cap.off_ptr, self.rng_offset - self._cap.base)
+                else:
+                    ops.dropout_mask(t, self.dropout_rate, self.drop_key + 77, self.rng_offset)
+                self.rng_offset += t.numel()
+                drop['head'] = t
         return noise, drop
 
     def _make_gen_drop(self, N: int, ar: Arena):
@@ -463,16 +478,32 @@ class VanGan:
         gd = 1.0 / (nps * gbs)
         gS_D, gI_D = (ar.alloc(logS.shape, f32), ar.alloc(logI.shape, f32)) if do_backward else (None, None)
         gS_G, gI_G = (ar.alloc(logS[B:].shape, f32), ar.alloc(logI[B:].shape, f32)) if do_backward else (None, None)
-        ops.mse_const(logS[B:], 1.0, acc[3:4], gd, gS_G)                                  # gen_IS_loss
-        ops.mse_const(logS[:B], 1.0, acc[5:6], 0.5 * gd, None if gS_D is None else gS_D[:B])
-        ops.mse_const(logS[B:], 0.0, acc[6:7], 0.5 * gd, None if gS_D is None else gS_D[B:])
+        wz = {}
+        def w_terms(tag, disc, logits, dp, a0):
+            """Wasserstein mode: Dense head over [real; fake] patch logits, sum z_real / sum z_fake into acc[a0:a0+2], d loss / d z of the
+            critic loss (2B) and of the generator loss (fake half) -- the head's backward runs with the sweeps (after the gradient buffers are cleared)."""
+            z = ar.alloc((2 * B,), f32)
+            mask = (dp or {}).get('head')
+            disc.head_forward(logits, mask, z)
+            gzd, gzg = (ar.alloc((2 * B,), f32), ar.alloc((B,), f32)) if do_backward else (None, None)
+            ops.wasserstein_terms(z, B, 1.0 / (B * gbs), acc[a0:a0 + 2], gzd, gzg)
+            wz[tag] = (mask, gzd, gzg)
+        if self.wasserstein:
+            w_terms('S', self.disc_S, logS, dpS, 9)
+        else:
+            ops.mse_const(logS[B:], 1.0, acc[3:4], gd, gS_G)                                  # gen_IS_loss
+            ops.mse_const(logS[:B], 1.0, acc[5:6], 0.5 * gd, None if gS_D is None else gS_D[:B])
+            ops.mse_const(logS[B:], 0.0, acc[6:7], 0.5 * gd, None if gS_D is None else gS_D[B:])
         self._mark('A D_S fwd')
         if lane_b is not None:
             ops.wait_event(main, ev_fakeI)                                                       # fake_I comes from lane B's first generator
         dI = self.disc_I.forward(ar, bufI, logI, nzI, dpI)                                  # lane A as well: lane B is the longer one
-        ops.mse_const(logI[B:], 1.0, acc[4:5], gd, gI_G)                                  # gen_SI_loss
-        ops.mse_const(logI[:B], 1.0, acc[7:8], 0.5 * gd, None if gI_D is None else gI_D[:B])
-        ops.mse_const(logI[B:], 0.0, acc[8:9], 0.5 * gd, None if gI_D is None else gI_D[B:])
+        if self.wasserstein:
+            w_terms('I', self.disc_I, logI, dpI, 11)
+        else:
+            ops.mse_const(logI[B:], 1.0, acc[4:5], gd, gI_G)                                  # gen_SI_loss
+            ops.mse_const(logI[:B], 1.0, acc[7:8], 0.5 * gd, None if gI_D is None else gI_D[:B])
+            ops.mse_const(logI[B:], 0.0, acc[8:9], 0.5 * gd, None if gI_D is None else gI_D[B:])
         self._mark('A D fwd')
         # No full join before the backward sweeps (VG_NOJOIN): lane A's discriminator sweeps and its adversarial generator sweep need
         # nothing of lane B; only its cycle sweep (c3 ran on lane B, g_cS comes out of lane B's clDice) waits for lane B's forward.
@@ -497,7 +528,14 @@ class VanGan:
                 arB = self.arena_b
                 arB.reset()
                 ops.wait_stream(lane_b, main)
+            def w_head_bwd(tag, disc, logits, g_D, g_G):
+                mask, gzd, gzg = wz[tag]
+                disc.head_backward(logits, mask, gzd, g_D, wgrad=True)                                   # critic loss: [real; fake], Dense gradients
+                disc.head_backward(logits[B:], None if mask is None else mask[B:], gzg, g_G, wgrad=False)  # generator loss through the fake half
+
             def a_disc():
+                if self.wasserstein:
+                    w_head_bwd('S', self.disc_S, logS, gS_D, gS_G)
                 self.disc_S.backward(ar, dS, gS_D, 0, 2 * B, wgrad=True)
                 self._start_allreduce(['disc_S'], lazy=apply)
                 self.disc_S.backward(ar, dS, gS_G, B, 2 * B, wgrad=False, dx=g_fS)       # still reads D_S's packed weights
@@ -509,6 +547,8 @@ class VanGan:
                 # (Moving D_I's D-loss sweep to lane A, whose sweeps finish 3.7 ms before lane B's, was measured: the main lanes then end
                 # at 26.8 / 23.4 ms but lane A's weight-gradient side stream becomes the tail -- 29.9 vs 29.4 ms per step.)
                 with laneB():
+                    if self.wasserstein:
+                        w_head_bwd('I', self.disc_I, logI, gI_D, gI_G)
                     self.disc_I.backward(arB, dI, gI_D, 0, 2 * B, wgrad=True)
                     self._start_allreduce(['disc_I'], lazy=apply)
                     self.disc_I.backward(arB, dI, gI_G, B, 2 * B, wgrad=False, dx=g_fI)
@@ -606,9 +646,13 @@ class VanGan:
         cyc_I = a[0] / (B * S * gbs) * self.lambda_cycle
         cyc_S = a[1] / (S * gbs) * self.lambda_cycle
         rec = a[2] / (B * S * gbs) * self.lambda_reconstruction
-        gIS, gSI = a[3] / (nps * gbs), a[4] / (nps * gbs)
-        dS = 0.5 * (a[5] + a[6]) / (nps * gbs)
-        dI = 0.5 * (a[7] + a[8]) / (nps * gbs)
+        if self.wasserstein:            # -reduce_mean(D(fake)), -reduce_mean(D(real) - D(fake)): acc[9:11] = (sum z_real, sum z_fake) of D_S, [11:13] of D_I
+            gIS, gSI = -a[10] / (B * gbs), -a[12] / (B * gbs)
+            dS, dI = -(a[9] - a[10]) / (B * gbs), -(a[11] - a[12]) / (B * gbs)
+        else:
+            gIS, gSI = a[3] / (nps * gbs), a[4] / (nps * gbs)
+            dS = 0.5 * (a[5] + a[6]) / (nps * gbs)
+            dI = 0.5 * (a[7] + a[8]) / (nps * gbs)
         vals = [gIS + cyc_I + seg, gSI + cyc_S + rec, dI, dS, gIS, gSI, cyc_I, cyc_S, seg, rec]
         return dict(zip(RESULT_KEYS, vals))
 
