@@ -270,6 +270,11 @@ typedef struct vg_actnorm_bwd_desc_s {
     float* dgamma;                            /* optional [C]: the APPLY pass adds d/d gamma and d/d beta of the InstanceNorm */
     float* dbeta;                             /* (summed over samples and stripes) instead of a separate vg_in_param_grads */
     int32_t* ticket;        /* unused (the stripes are added up by the apply pass); kept for layout stability */
+    /* Several upstream gradients of ONE forward sample in one launch (the discriminator's two backward sweeps -- the critic loss over
+       [real; fake] and the generator loss through the fake half, vangan.py:426-438 -- as one 3B-sample sweep): samples n >= alias_n0 of g /
+       dx / red read x, x1 and every per-(sample, channel) array (scale, shift, mean, rstd, mult) of sample n - alias_shift.  0: off.
+       pgrad_n > 0: only samples < pgrad_n add to dgamma / dbeta (the generator-loss gradient updates no discriminator parameter). */
+    int32_t alias_n0, alias_shift, pgrad_n, pad_;
 } vg_actnorm_bwd_desc;
 int vg_actnorm_bwd_stats(const vg_actnorm_bwd_desc* d, vg_stream_t stream);
 int vg_actnorm_bwd_apply(const vg_actnorm_bwd_desc* d, vg_stream_t stream);

@@ -58,8 +58,9 @@ def enumerate_config(dims, B, precision='bf16'):
         noise = {k: torch.empty(shp, dtype=torch.bfloat16) for k, shp in D.noise_shapes(2 * B).items()}
         drop = {k: torch.empty(2 * B, c) for k, c in (('down0', 128), ('down1', 256), ('down2', 512))}
         dctx = D.forward(ar, x2, lg, noise, drop)
-        D.backward(ar, dctx, lg, 0, 2 * B, wgrad=True)
-        D.backward(ar, dctx, lg[B:], B, 2 * B, wgrad=False, dx=ar.alloc((B,) + dims + (1,), torch.float32))
+        # the step's discriminator backward: ONE sweep over [d critic loss (2B); d generator loss (B)] (PatchGAN.backward_both)
+        lg3 = ar.alloc((3 * B,) + tuple(n // 8 for n in dims) + (1,), torch.float32)
+        D.backward_both(ar, dctx, lg3, B, ar.alloc((B,) + dims + (1,), torch.float32))
     return [(k, n, v, r) for (k, n, v), r in zip(dry.records, dry.recipes)]
 
 

@@ -59,6 +59,7 @@ class ActNormBwdDesc(C.Structure):
         ('gamma', c_void_p), ('mean', c_void_p), ('rstd', c_void_p), ('red', c_void_p),
         ('dx', c_void_p), ('dx_f32', c_int), ('accumulate', c_int), ('dx_cstride', c_int), ('dx_coff', c_int),
         ('f32', c_int), ('dgamma', c_void_p), ('dbeta', c_void_p), ('ticket', c_void_p),
+        ('alias_n0', c_int), ('alias_shift', c_int), ('pgrad_n', c_int), ('pad_', c_int),
     ]
 
 

@@ -61,7 +61,9 @@ struct ANB {
     int* ticket; float* dgamma; float* dbeta;      // fold by the last workgroup (stats kernel)
     void* dx; int dx_f32, accumulate, dx_cstride, dx_coff;
     int gpc, vpb;      // channel groups per voxel, voxels per block-iteration
+    int alias_n0, alias_sh, pgrad_n;      // samples >= alias_n0 read x and the per-(n, c) constants of sample n - alias_sh; parameter gradients from samples < pgrad_n (0: all)
 };
+__device__ __forceinline__ int anb_nx(const ANB& p, int n) { return (p.alias_n0 > 0 && n >= p.alias_n0) ? n - p.alias_sh : n; }
 
 // per-thread channel constants (the thread owns channels c..c+VEC-1 of sample n for its whole walk)
 template <int VEC> struct ChanK { float sc[VEC], sh[VEC], mu[VEC], rs[VEC], ml[VEC]; };
@@ -74,7 +76,7 @@ __device__ __forceinline__ void ldvec(const float* p, float* o, int n) {       /
 }
 template <int VEC>
 __device__ __forceinline__ void load_chank(const ANB& p, int n, int c, ChanK<VEC>& k) {
-    const int nc = n * p.C + c;
+    const int nc = anb_nx(p, n) * p.C + c;
 #pragma unroll
     for (int j = 0; j < VEC; ++j) { k.sc[j] = 1.f; k.sh[j] = 0.f; k.mu[j] = 0.f; k.rs[j] = 0.f; k.ml[j] = 1.f; }
     if (p.scale) { ldvec(p.scale + nc, k.sc, VEC); ldvec(p.shift + nc, k.sh, VEC); }
@@ -110,9 +112,10 @@ __device__ __forceinline__ void anb_walk_from(const ANB& p, int n, int c, int v,
     const int Hs = p.H >> xs, Ws = p.W >> xs;
     const int cx = p.x1 ? (cat0 ? p.c_x0 : p.C - p.c_x0) : p.C;
     const T* xp = nullptr;
-    if (VEC == 8) xp = p.x1 ? (cat0 ? (const T*)p.x + (size_t)n * (p.D >> xs) * Hs * Ws * cx + c : (const T*)p.x1 + (size_t)n * S * cx + (c - p.c_x0))
-                            : (const T*)p.x + (size_t)n * S * cx + c;
-    const void* x1p = (const char*)p.x + (size_t)n * S * (p.x_f32 ? 4 : 2);      // VEC == 1: f32 or bf16 volume
+    const int nx = anb_nx(p, n);              // the forward tensors' sample (a second gradient of the same sample: vg_actnorm_bwd_desc::alias_n0)
+    if (VEC == 8) xp = p.x1 ? (cat0 ? (const T*)p.x + (size_t)nx * (p.D >> xs) * Hs * Ws * cx + c : (const T*)p.x1 + (size_t)nx * S * cx + (c - p.c_x0))
+                            : (const T*)p.x + (size_t)nx * S * cx + c;
+    const void* x1p = (const char*)p.x + (size_t)nx * S * (p.x_f32 ? 4 : 2);      // VEC == 1: f32 or bf16 volume
     for (; v < S; v += UB * stride) {
         RawV<T, VEC> gr[UB], xr[UB];
         float x1v[UB];
@@ -274,7 +277,7 @@ __global__ __launch_bounds__(256) void actnorm_apply_kernel(const ANB p) {
         const int nc = n * p.C + c;
         const size_t total = (size_t)p.N * p.C * 2;
         float gm[VEC], rs[VEC], r[2 * VEC];
-        ldvec(p.gamma + c, gm, VEC); ldvec(p.rstd + nc, rs, VEC);
+        ldvec(p.gamma + c, gm, VEC); ldvec(p.rstd + anb_nx(p, n) * p.C + c, rs, VEC);
 #pragma unroll
         for (int j = 0; j < 2 * VEC; ++j) r[j] = 0.f;
 #pragma unroll
@@ -285,7 +288,7 @@ __global__ __launch_bounds__(256) void actnorm_apply_kernel(const ANB p) {
 #pragma unroll
             for (int j = 0; j < 2 * VEC; ++j) r[j] += q[j];
         }
-        if (p.dgamma && blockIdx.x == 0 && vl == 0) {          // sum(dn) is d/d beta, sum(dn * xhat) is d/d gamma (summed over samples)
+        if (p.dgamma && blockIdx.x == 0 && vl == 0 && (p.pgrad_n <= 0 || n < p.pgrad_n)) {          // sum(dn) is d/d beta, sum(dn * xhat) is d/d gamma (summed over samples)
 #pragma unroll
             for (int j = 0; j < VEC; ++j) { atomicAdd(&p.dbeta[c + j], r[2 * j]); atomicAdd(&p.dgamma[c + j], r[2 * j + 1]); }
         }
@@ -336,6 +339,8 @@ static int fill_anb(const vg_actnorm_bwd_desc* d, ANB& p, bool apply) {
     p.ticket = d->ticket; p.dgamma = (d->dgamma && d->dbeta) ? d->dgamma : nullptr; p.dbeta = d->dbeta;
     p.dx = d->dx; p.dx_f32 = (d->dx_f32 || d->f32) ? 1 : 0; p.accumulate = d->accumulate;
     p.dx_cstride = d->dx_cstride > 0 ? d->dx_cstride : d->C; p.dx_coff = d->dx_coff;
+    p.alias_n0 = d->alias_n0; p.alias_sh = d->alias_shift; p.pgrad_n = d->pgrad_n;
+    if (d->alias_n0 < 0 || (d->alias_n0 > 0 && (d->alias_shift < 1 || d->alias_shift > d->alias_n0 || d->alias_n0 >= d->N)) || d->pgrad_n < 0) return VG_EINVAL;
     p.gpc = d->C == 1 ? 1 : d->C / 8;
     if (p.gpc > 256 || d->C > 512) return VG_EINVAL;
     p.vpb = 256 / p.gpc;

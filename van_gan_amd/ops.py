@@ -1168,7 +1168,7 @@ def alloc_red(ar: 'Arena', N: int, C_: int) -> torch.Tensor:
 
 def actnorm_desc(g, g_padded, x, dims, C_, dx, *, scale=None, shift=None, mult=None, act=ACT_NONE, norm=False,
                  gamma=None, mean=None, rstd=None, red=None, accumulate=False, x1=None, c_x0=0, x0_shift=0,
-                 dx_cstride=0, dx_coff=0, dgamma=None, dbeta=None) -> ActNormBwdDesc:
+                 dx_cstride=0, dx_coff=0, dgamma=None, dbeta=None, alias_n0=0, alias_shift=0, pgrad_n=0) -> ActNormBwdDesc:
     """Descriptor of the (InstanceNorm -> act -> dropout) backward: statistics + apply (+ parameter gradients).  `red` from
     alloc_red() (with ticket word: one launch fewer) or a plain zeroed [STRIPES, N, C, 2] tensor.  The tensors are kept
     alive on the descriptor (it may be handed to ConvLayer.dgrad(bstat=...) before actnorm_run)."""
@@ -1184,6 +1184,7 @@ def actnorm_desc(g, g_padded, x, dims, C_, dx, *, scale=None, shift=None, mult=N
     d.dx_cstride, d.dx_coff = dx_cstride, dx_coff
     d.f32 = int(g.dtype == torch.float32)
     d.dgamma, d.dbeta = _p(dgamma), _p(dbeta)      # parameter gradients come out of the statistics pass
+    d.alias_n0, d.alias_shift, d.pgrad_n = alias_n0, alias_shift, pgrad_n
     nred = STRIPES * dims[0] * C_ * 2
     d.ticket = (red.data_ptr() + 4 * nred) if (red is not None and red.dim() == 1 and red.numel() == nred + 4) else None
     d._keep = (g, x, dx, scale, shift, mult, gamma, mean, rstd, red, x1, dgamma, dbeta)

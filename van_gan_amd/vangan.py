@@ -29,6 +29,8 @@ _LAZY_AR = os.environ.get('VG_LAZY_AR', '1') != '0'
 _INLINE = int(os.environ.get('VG_WGRAD_INLINE', '2'))      # encoder blocks <= this and the stem; round 3 (DMA weight gradients): off 24.96, 1: 24.92, 2: 24.74, 3: 24.59, 4: 24.62 ms; round 4, final kernels, alternating: 2: 18.85 / 18.88 / 18.87, 3: 18.99 / 18.91 / 19.01
 _PAIR_BWD = os.environ.get('VG_PAIR_BWD', '1') != '0'       # one 2B-sample backward sweep per generator (both applications) instead of two
 _AR_SPLIT = os.environ.get('VG_AR_SPLIT', '1') != '0'       # world > 1: a generator's finished gradient suffix is all-reduced while its sweep still runs
+_SKEL_BWD_A = int(os.environ.get('VG_SKEL_BWD_A', '0'))      # clDice backward on lane A: 1 before its discriminator sweeps, 2 right before its generator sweep
+_D_ONE_SWEEP = os.environ.get('VG_D_ONE_SWEEP', '1') != '0'    # one 3B-sample backward sweep per discriminator (PatchGAN.backward_both) instead of a 2B and a B sweep
 _SKEL_AUX = os.environ.get('VG_SKEL_AUX', '0') != '0'        # clDice backward from codes filed by the forward pass (streaming launches) instead of re-scanning
 _INTERLEAVE = os.environ.get('VG_INTERLEAVE', '0') != '0'   # the two lanes' enqueue sequences alternate block by block on the host: measured neutral (21.69 vs 21.63 ms), off
 
@@ -435,14 +437,20 @@ class VanGan:
             coef = ar.alloc((8,), f32, zero=True)
             ops.dot_sums(skel_p, nS, sums[0:3]); ops.dot_sums(skel_t, ncS, sums[3:6]); ops.dot_sums(nS, ncS, sums[6:9])
             ops.cldice_coef(sums, self.lambda_topology / self.n_devices, 0.5, coef)
-            if do_backward:
+            def cldice_backward():
                 gskel = ar.alloc(vol, f32)
                 ops.cldice_grads(nS, skel_t, coef, gskel, g_ncS, accumulate=True)
                 work = ar.alloc((4,) + vol, f32)
                 ops.soft_skel_bwd(imgs_p, skels_p, gskel, dims4, it, work, g_ncS, aux_p)
-                g_cS = gS2[B:]
                 tmp2 = ar.alloc((B, 2), f32, zero=True)
-                ops.minmax_bwd(cyc_S, ncS, g_ncS, mmcS, B, S, tmp2, g_cS)
+                ops.minmax_bwd(cyc_S, ncS, g_ncS, mmcS, B, S, tmp2, gS2[B:])
+            g_cS = gS2[B:] if do_backward else None
+            # VG_SKEL_BWD_A: the skeleton's backward (34 launches whose result only lane A's generator sweep consumes) on lane A, behind
+            # an event of lane B's clDice forward -- lane B is the longer lane (tools/timeline.py: lane A ends 1.2 ms before it)
+            skel_bwd_on_a = do_backward and _SKEL_BWD_A and lane_b is not None
+            ev_cldice = ops.record_event(lane_b) if skel_bwd_on_a else None
+            if do_backward and not skel_bwd_on_a:
+                cldice_backward()
             self._mark('B clDice')
 
         # ---- cycle MSE + SSIM reconstruction on cycled_I (loss_functions.py:179-180, 193-208) ----
@@ -476,8 +484,12 @@ class VanGan:
         self._need('disc_S', 'disc_I')
         dS = self.disc_S.forward(ar, bufS, logS, nzS, dpS)                                  # lane A: needs fake_S
         gd = 1.0 / (nps * gbs)
-        gS_D, gI_D = (ar.alloc(logS.shape, f32), ar.alloc(logI.shape, f32)) if do_backward else (None, None)
-        gS_G, gI_G = (ar.alloc(logS[B:].shape, f32), ar.alloc(logI[B:].shape, f32)) if do_backward else (None, None)
+        # upstream gradients at the patch logits, adjacent: [d critic loss (2B: real, fake); d generator loss (B: fake)] -- one 3B-sample
+        # backward sweep per discriminator reads them as one tensor (VG_D_ONE_SWEEP)
+        gS3 = ar.alloc((3 * B,) + tuple(logS.shape[1:]), f32) if do_backward else None
+        gI3 = ar.alloc((3 * B,) + tuple(logI.shape[1:]), f32) if do_backward else None
+        gS_D, gI_D = (gS3[:2 * B], gI3[:2 * B]) if do_backward else (None, None)
+        gS_G, gI_G = (gS3[2 * B:], gI3[2 * B:]) if do_backward else (None, None)
         wz = {}
         def w_terms(tag, disc, logits, dp, a0):
             """Wasserstein mode: Dense head over [real; fake] patch logits, sum z_real / sum z_fake into acc[a0:a0+2], d loss / d z of the
@@ -505,6 +517,9 @@ class VanGan:
             ops.mse_const(logI[:B], 1.0, acc[7:8], 0.5 * gd, None if gI_D is None else gI_D[:B])
             ops.mse_const(logI[B:], 0.0, acc[8:9], 0.5 * gd, None if gI_D is None else gI_D[B:])
         self._mark('A D fwd')
+        if skel_bwd_on_a and _SKEL_BWD_A == 1:
+            ops.wait_event(main, ev_cldice)
+            cldice_backward()
         # No full join before the backward sweeps (VG_NOJOIN): lane A's discriminator sweeps and its adversarial generator sweep need
         # nothing of lane B; only its cycle sweep (c3 ran on lane B, g_cS comes out of lane B's clDice) waits for lane B's forward.
         nojoin = lane_b is not None and do_backward and _NOJOIN
@@ -536,9 +551,13 @@ class VanGan:
             def a_disc():
                 if self.wasserstein:
                     w_head_bwd('S', self.disc_S, logS, gS_D, gS_G)
-                self.disc_S.backward(ar, dS, gS_D, 0, 2 * B, wgrad=True)
-                self._start_allreduce(['disc_S'], lazy=apply)
-                self.disc_S.backward(ar, dS, gS_G, B, 2 * B, wgrad=False, dx=g_fS)       # still reads D_S's packed weights
+                if _D_ONE_SWEEP:
+                    self.disc_S.backward_both(ar, dS, gS3, B, g_fS)
+                    self._start_allreduce(['disc_S'], lazy=apply)
+                else:
+                    self.disc_S.backward(ar, dS, gS_D, 0, 2 * B, wgrad=True)
+                    self._start_allreduce(['disc_S'], lazy=apply)
+                    self.disc_S.backward(ar, dS, gS_G, B, 2 * B, wgrad=False, dx=g_fS)       # still reads D_S's packed weights
                 if apply:
                     self._schedule_update('disc_S')
                 self._mark('A D bwd')
@@ -549,9 +568,13 @@ class VanGan:
                 with laneB():
                     if self.wasserstein:
                         w_head_bwd('I', self.disc_I, logI, gI_D, gI_G)
-                    self.disc_I.backward(arB, dI, gI_D, 0, 2 * B, wgrad=True)
-                    self._start_allreduce(['disc_I'], lazy=apply)
-                    self.disc_I.backward(arB, dI, gI_G, B, 2 * B, wgrad=False, dx=g_fI)
+                    if _D_ONE_SWEEP:
+                        self.disc_I.backward_both(arB, dI, gI3, B, g_fI)
+                        self._start_allreduce(['disc_I'], lazy=apply)
+                    else:
+                        self.disc_I.backward(arB, dI, gI_D, 0, 2 * B, wgrad=True)
+                        self._start_allreduce(['disc_I'], lazy=apply)
+                        self.disc_I.backward(arB, dI, gI_G, B, 2 * B, wgrad=False, dx=g_fI)
                     if apply:
                         self._schedule_update('disc_I')
                     self._mark('B D bwd')
@@ -598,6 +621,9 @@ class VanGan:
                     fa(); fb()
             if pair:
                 # the generators' 2B-sample sweeps over both applications ([adversarial; cycle]), enqueued alternately block by block
+                if skel_bwd_on_a and _SKEL_BWD_A == 2:
+                    ops.wait_event(main, ev_cldice)
+                    cldice_backward()
                 if ev_bfwd is not None:
                     ops.wait_event(main, ev_bfwd)                                          # c3 and g_cS are lane B's
                 ccA = pair_ctx(ar, c1, bufI, (fake_S, cyc_S), self.gen_IS.lv[0])
