@@ -120,6 +120,64 @@ def test_two_ranks_equal_one_process_with_batch_two(tmp_path, backend):
     assert bad <= 2e-3 * tot, (bad, tot)
 
 
+RCCL_ONE = r"""
+import os, sys, torch
+import torch.distributed as dist
+sys.path.insert(0, %(root)r)
+from van_gan_amd.vangan import VanGan
+from van_gan_amd.synth import synth_volumes
+torch.cuda.set_device(0)
+dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda:0'))
+assert dist.get_backend() == 'nccl'
+eng = VanGan(%(dims)r, batch_size=1, n_devices=1, device='cuda:0', seed=4, layer_noise=0.0, dropout_rate=0.0,
+             process_group=dist.group.WORLD, precision='fp32')
+assert eng.sync.active and eng.sync.forced and not eng.sync.fake and eng._xstep
+eng.broadcast_weights(0)                                   # ncclBroadcast of the four weight buffers
+rI, rS = synth_volumes(1, *%(dims)r, seed=5)
+rI, rS = rI.cuda(), rS.cuda()
+res = []
+for _ in range(3):
+    res.append(eng.distributed_train_step(rI, rS))         # ncclAllReduce: 4 buckets (two in two pieces) + the result scalars
+eng._join_updates()
+torch.cuda.synchronize()
+torch.save({'w': {k: s.w.cpu() for k, s in eng.stores.items()}, 'res': res}, %(out)r)
+dist.destroy_process_group()
+"""
+
+
+def test_rccl_process_group_of_one_rank_runs_the_collectives(tmp_path):
+    """What a 1-GPU box can execute of the RCCL path: torch.distributed 'nccl' (= RCCL on ROCm) with ONE rank and VG_DDP_FORCE=1, so
+    that GradSync issues every collective of the data-parallel step for real -- communicator set-up, rank-0 ncclBroadcast of the
+    weights, ncclAllReduce of the four flat buckets on the engine's optimizer stream (pieces, per-bucket events, cross-step mode),
+    the SUM of the result dict -- through the same code the 8-GPU job runs.  A SUM over one rank is the identity: three steps must
+    give the weights and losses of an engine without a process group (exact-parity mode, stochastic layers off; only float-atomic
+    summation orders differ -- tolerances as in the two-rank test)."""
+    from van_gan_amd.synth import synth_volumes
+    from van_gan_amd.vangan import VanGan
+    out = str(tmp_path / 'rccl1.pt')
+    script = tmp_path / 'rccl_one.py'
+    script.write_text(RCCL_ONE % dict(root=ROOT, dims=DIMS, out=out))
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY='0', VG_DDP_FORCE='1')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'VG_FAKE_AR'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert r.returncode == 0, r.stdout.decode()[-3000:]
+    a = torch.load(out)
+    eng = VanGan(DIMS, batch_size=1, n_devices=1, device='cuda:0', seed=4, layer_noise=0.0, dropout_rate=0.0, precision='fp32')
+    rI, rS = synth_volumes(1, *DIMS, seed=5)
+    rI, rS = rI.cuda(), rS.cuda()
+    for i in range(3):
+        res = eng.train_step(rI, rS)
+        for k, v in res.items():
+            assert abs(a['res'][i][k] - v) <= (1e-4 if i == 0 else 1e-2) * abs(v) + 1e-5, (i, k, a['res'][i][k], v)
+    torch.cuda.synchronize()
+    bad = tot = 0
+    for k, s in eng.stores.items():
+        d = (s.w.cpu() - a['w'][k]).abs()
+        bad += int((d > 1.5e-3).sum()); tot += d.numel()      # three sign-like Adam steps of 2e-4: a ~0 gradient that flips sign moves 4e-4 per step
+    assert bad <= 1e-2 * tot, (bad, tot)
+
+
 def test_bench_two_ranks_completes():
     """Plain `python bench.py --gpus 2` (bench.py starts its own one-process-per-GPU job as a child process; both ranks on
     cuda:0 over gloo here, VG_BENCH_ONE_DEVICE=1): the driver's multi-GPU contract -- barrier-bracketed timed steps, MAX over

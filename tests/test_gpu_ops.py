@@ -686,3 +686,66 @@ def test_shortcut_dgrad_concat_norm_fused(c_low, c_skip, cout, dims, acc):
     close_bf16(dlow, rlow, 'dlow')
     close_bf16(dskip, rskip, 'dskip')
     assert rel_l2(dbeta, r0.sum(0).flatten()) < 1e-4 and rel_l2(dgamma, r1.sum(0).flatten()) < 1e-4
+
+
+@pytest.mark.parametrize('pad,dims,src_f32,transform', [
+    ('reflect', (12, 24, 48), True, False),       # several tiles per axis, whole tiles
+    ('reflect', (9, 19, 37), False, True),        # ragged in every axis, bf16 source with the on-read affine + LeakyReLU
+    ('same', (6, 10, 12), True, True),            # zero padding
+    ('reflect', (2, 2, 2), True, False),          # the smallest grid reflection allows
+])
+def test_single_channel_stem_convolution_on_the_matrix_pipe(pad, dims, src_f32, transform):
+    """vg_c1k3.hip (1 -> 16, 3x3x3, the stem's first convolution, resunet_model.py:44-60): forward with bias, statistics and the
+    finalisation tail, weight and bias gradient -- against a float64 reference on the same rounded operands, and against the VALU
+    kernels of vg_pointwise.hip it replaces in the 16-bit builds (VG_C1K3M=0), which stay the exact-parity mode's kernels.
+    Tolerances: bf16 output rounding for the forward (close_bf16), fp32 summation order for the gradients (2e-3 relative L2
+    against float64; 1e-4 between the two kernel families)."""
+    from van_gan_amd import ops, _lib
+    from van_gan_amd.ops import Src
+    dev = _dev()
+    N, cout = 2, 16
+    st, lay = make_layer(3, 1, cout, 1, pad, dims, seed=3)
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(N, *dims, 1, generator=g)
+    xs = x if src_f32 else x.to(torch.bfloat16)
+    scale = (torch.rand(N, 1, generator=g) + 0.5) if transform else None
+    shift = (torch.randn(N, 1, generator=g) * 0.3) if transform else None
+    src = Src(xs.to(dev), (N,) + dims, 1, f32=src_f32, scale=None if scale is None else scale.to(dev),
+              shift=None if shift is None else shift.to(dev), act=ops.ACT_LRELU if transform else ops.ACT_NONE)
+    with ops.DryRun() as dry:                       # the launches below are the MFMA kernels' (then, with VG_C1K3M=0, the VALU ones')
+        lay.forward(src, torch.zeros(N, *dims, cout, dtype=torch.bfloat16, device=dev), sums=torch.zeros(8, N, cout, 2, device=dev))
+        lay.wgrad(src, torch.zeros(N, *dims, cout, dtype=torch.bfloat16, device=dev))
+    assert [v.split('<')[0] for _, _, v in dry.records] == ['c1k3m_fwd', 'c1k3m_wgrad'], dry.records
+    res = {}
+    for mode in (1, 0):
+        _lib.lib.vg_set_tuning(b'C1K3M', mode, 0)
+        try:
+            out = torch.zeros(N, *dims, cout, dtype=torch.bfloat16, device=dev)
+            sums = torch.zeros(8, N, cout, 2, device=dev)
+            lay.forward(src, out, sums=sums)
+            st.g.zero_()
+            dy = torch.randn(N, *dims, cout, generator=torch.Generator().manual_seed(11)).to(torch.bfloat16)
+            lay.wgrad(src, dy.to(dev))
+            torch.cuda.synchronize()
+            res[mode] = (out.float().cpu(), sums.sum(0).cpu(), st.grad('c.w').clone().cpu(), st.grad('c.b').clone().cpu())
+        finally:
+            _lib.lib.vg_set_tuning(b'C1K3M', 0, 1)
+    a = xs.double()
+    if transform:
+        a = F.leaky_relu(a * scale.double().view(N, 1, 1, 1, 1) + shift.double().view(N, 1, 1, 1, 1), 0.2)
+    a = bf(a)
+    w = bf(st.param('c.w').cpu()).requires_grad_(True)
+    b = st.param('c.b').cpu().double().requires_grad_(True)
+    y = O.to_ndhwc(ref_conv(O.to_ncdhw(a), w, b, 1, pad))
+    (y * bf(dy)).sum().backward()
+    out, sums, gw, gb = res[1]
+    close_bf16(out, y, 'forward')
+    yq = bf(y.detach())
+    ref_sums = torch.stack([yq.sum(dim=(1, 2, 3)), (yq ** 2).sum(dim=(1, 2, 3))], dim=-1)
+    assert rel_l2(sums, ref_sums) < 1e-4
+    assert rel_l2(gw, w.grad) < 2e-3 and rel_l2(gb, b.grad) < 2e-3
+    # the two kernel families multiply the same rounded operands: only the fp32 summation order differs
+    o0, s0, gw0, gb0 = res[0]
+    assert float((out - o0).abs().max()) <= 2 ** -7 * float(o0.abs().max())           # at most one bf16 ulp of the largest value
+    assert rel_l2(out, o0) < 2e-3 and rel_l2(sums, s0) < 1e-4
+    assert rel_l2(gw, gw0) < 1e-4 and rel_l2(gb, gb0) < 1e-4

@@ -69,6 +69,8 @@ def variant_of(kernel_name: str):
         return 'pw_wgrad<%s,%s>' % (tname(args[0]), 'cto1' if args[1] == 'true' else '1toc')
     if k in ('c1k3_fwd', 'c1k3_wgrad') and len(args) == 2:
         return '%s<%s,%s>' % (k, tname(args[0]), tname(args[1]))
+    if k in ('c1k3m_fwd', 'c1k3m_wgrad') and len(args) == 1:
+        return '%s<%s>' % (k, tname(args[0]))
     return None
 
 

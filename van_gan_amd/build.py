@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libvangan_hip.so')
 LIB_H = os.path.join(HERE, 'libvangan_hip_h.so')
-SOURCES = ['vg_conv.hip', 'vg_conv_thin.hip', 'vg_conv_dma.hip', 'vg_wgrad.hip', 'vg_wgrad_dma.hip', 'vg_pointwise.hip', 'vg_elem.hip', 'vg_loss.hip', 'vg_adam.hip']
+SOURCES = ['vg_conv.hip', 'vg_conv_thin.hip', 'vg_conv_dma.hip', 'vg_wgrad.hip', 'vg_wgrad_dma.hip', 'vg_pointwise.hip', 'vg_c1k3.hip', 'vg_elem.hip', 'vg_loss.hip', 'vg_adam.hip']
 
 
 def _hipcc() -> str:

@@ -10,6 +10,7 @@
 // packed weights, on-read transform y = act(x * scale + shift) rounded to the storage type before the product (as the LDS
 // halo image is), dY rounded to the storage type, fp32 accumulation.
 #include "vg_common.h"
+#include "vg_c1k3.h"
 #include <stdlib.h>
 
 namespace {
@@ -743,22 +744,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const PW p) {
 // ---- single-channel source, 3x3x3 taps (the stem convolution 1 -> 16, resunet_model.py:44-60): 27 x 16 MACs per voxel are
 // VALU work next to 4 + 32 bytes of traffic.  A thread owns 4 consecutive voxels along W and 8 output channels; the 3x3x6
 // source window lives in registers, the weights come from LDS as broadcast reads shared by the 4 voxels.
-struct C1K3 {
-    const void* x; int x_f32; float sc, sf; int act, pad_mode;
-    int D, H, W, C, W4;                     // C = Cout, W4 = quads per row
-    int td0, th0, tw0;                      // offset of the first tap per axis (-pad_before)
-    const void* w; int Ktot, CK;            // packed [Cout][Ktot], k = tap * CK + j  (W-packed layout)
-    const float* bias; void* out; float* sums;
-    const void* dy; float* dw; float* db;
-    const float* scale; const float* shift;
-    VgFin fin;
-};
-__device__ __forceinline__ int c1_resolve(int p, int n, int reflect, bool& ok) {
-    ok = true;
-    if (reflect) { if (p < 0) p = -p; if (p >= n) p = 2 * n - 2 - p; return p < 0 ? 0 : (p >= n ? n - 1 : p); }
-    ok = p >= 0 && p < n;
-    return ok ? p : 0;
-}
+// (struct C1K3, c1_resolve: vg_c1k3.h -- shared with the MFMA kernels of vg_c1k3.hip)
 // loads the rows (a, b) x 6 columns of the source window of quad (d, h, w0): NA d-offsets starting at a0
 // S = element type of the single-channel source (a run-time switch here would put every load under a branch, and the compiler
 // drains vmcnt at each of them)
@@ -1118,6 +1104,7 @@ int vg_pointwise_conv(const vg_conv_desc* d, hipStream_t s) {
         if (c1k3_fill(d, c)) {
             c.w = d->wpacked; c.bias = d->bias; c.out = d->out; c.sums = d->out_sums;
             c.fin = vg_fin_of(d);
+            if (!d->f32) { const int mrc = c1k3m_fwd(c, d->N, d->src_f32 != 0, s); if (mrc <= 0) { if (mrc == VG_OK && c.sums && c.fin.ticket && !vg_dry_on()) vg_fin_done = true; return mrc; } }
             const int qpb = 256 / (c.C >> 3);
             int64_t b = ((int64_t)c.D * c.H * c.W4 + qpb - 1) / qpb;
             const int64_t cap = (2047 / d->N) > 0 ? (2047 / d->N) : 1;
@@ -1200,6 +1187,7 @@ int vg_pointwise_wgrad(const vg_conv_desc* d, const void* dy, int dy_f32, int T_
         C1K3 c;
         if (c1k3_fill(d, c)) {
             c.dy = dy; c.dw = dw; c.db = db;
+            if (!d->f32 && !dy_f32) { const int mrc = c1k3m_wgrad(c, d->N, d->src_f32 != 0, s); if (mrc <= 0) return mrc; }
             const int qpb = 256 / (3 * (c.C >> 3));
             int64_t b = ((int64_t)c.D * c.H * c.W4 + (int64_t)qpb * 8 - 1) / ((int64_t)qpb * 8);
             const int64_t cap = (767 / d->N) > 0 ? (767 / d->N) : 1;

@@ -39,7 +39,10 @@ class GradSync:
         if fake is None:
             fake = os.environ.get('VG_FAKE_AR', '0') == '1'
         self.fake = bool(fake) and self.world == 1 and self.cuda
-        self.active = self.world > 1 or self.fake
+        # VG_DDP_FORCE=1: a process group of ONE rank still runs every collective (what a 1-GPU box can execute of the RCCL path:
+        # communicator set-up, ncclAllReduce / ncclBroadcast calls on the engine's streams -- tests/test_gpu_ddp.py)
+        self.forced = process_group is not None and self.world == 1 and not self.fake and os.environ.get('VG_DDP_FORCE', '0') == '1'
+        self.active = self.world > 1 or self.fake or self.forced
         self.stream = (stream if stream is not None else torch.cuda.Stream(device=dev)) if (self.cuda and self.active) else None
         self.pending: Dict[str, list] = {}          # bucket name -> CUDA events on the comm stream / async work handles (one per piece)
         self.rank = dist.get_rank(process_group) if process_group is not None else 0
@@ -110,7 +113,7 @@ class GradSync:
         """The current stream (GPU) / the host (CPU tensors) waits until the reduced buckets `names` (default: all that
         are in flight) have landed.  Per bucket, so that a network's optimizer step can run as soon as ITS bucket is
         there while the other networks' backward sweeps and all-reduces are still going."""
-        if self.world == 1:
+        if not self.active:
             return
         for n in (list(self.pending) if names is None else list(names)):
             for h in self.pending.pop(n, []):
@@ -121,7 +124,7 @@ class GradSync:
 
     def reduce_dict(self, d: Dict[str, float], keys: List[str]) -> Dict[str, float]:
         """vangan.py:472-473: strategy.reduce(SUM) of every result scalar."""
-        if self.world == 1:
+        if self.world == 1 and not self.forced:
             return d
         dev = next(iter(self.buckets.values())).device
         t = torch.tensor([d[k] for k in keys], dtype=torch.float32, device=dev)
@@ -129,7 +132,7 @@ class GradSync:
         return dict(zip(keys, t.cpu().tolist()))
 
     def broadcast_weights(self, src: int = 0):
-        if self.world == 1 or self.weights is None:
+        if (self.world == 1 and not self.forced) or self.weights is None:
             return
         for w in self.weights.values():
             dist.broadcast(w, src=src, group=self.pg)
