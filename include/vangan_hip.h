@@ -329,6 +329,16 @@ int vg_affine_add(const void* a, const float* a_scale, const float* a_shift, int
  * vg_conv3d_wgrad with the roles of input and output gradient exchanged (van_gan_amd.ops.ConvTranspose3dK2S2 is the recipe). */
 int vg_bias_grad(const void* dy, int f32, int64_t rows, int C, float* db, vg_stream_t stream);
 
+/* Data gradient of a 4x4x4 stride-2 Conv3D over ReflectionPadding3D(1) of a SINGLE-channel volume (discriminator.py:50-60 under the tape,
+ * vangan.py:433-438: the generator loss reaches the generators through it) as a stride-1 convolution over CELLS: cell c = the 2x2x2 block
+ * of reflect-padded positions 2c + r, all of which draw from dY voxels c - 1 + n, n in {0,1} per axis, with tap r + 2 - 2n.
+ * vg_pack_cell_weights: fp32 DHWIO kernel w [4][4][4][1][C] -> the packed operand (16-bit, [64][(C/16)*448]: rows 4rd+2rh+rw < 8, 27 taps
+ * n - 1 in -1..1 of which the n = 2 ones are zero, CK = 16) of a vg_conv3d call with src0 = dY [N][D/2][H/2][W/2][C], zero padding,
+ * OD/OH/OW = D/2+1 .., Cout = 16, out = cells.  vg_cells_fold: cells (16-bit [N][D/2+1][H/2+1][W/2+1][16]) -> dx fp32 [N][D][H][W]: depth to
+ * space and the transpose of the reflection pad (positions 0 and n+1 fold onto 1 and n-2).  D, H, W even and >= 4. */
+int vg_pack_cell_weights(const float* w, int C, void* out, vg_stream_t stream);
+int vg_cells_fold(const void* cells, int N, int D, int H, int W, float* dx, vg_stream_t stream);
+
 /* d_pre = dy * (1 - y*y)   (tanh output activation, resunet_model.py:245), all fp32 */
 int vg_tanh_bwd(const float* dy, const float* y, float* dpre, int64_t n, vg_stream_t stream);
 

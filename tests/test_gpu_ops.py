@@ -688,55 +688,67 @@ def test_shortcut_dgrad_concat_norm_fused(c_low, c_skip, cout, dims, acc):
     assert rel_l2(dbeta, r0.sum(0).flatten()) < 1e-4 and rel_l2(dgamma, r1.sum(0).flatten()) < 1e-4
 
 
-@pytest.mark.parametrize('pad,dims,src_f32,transform', [
-    ('reflect', (12, 24, 48), True, False),       # several tiles per axis, whole tiles
-    ('reflect', (9, 19, 37), False, True),        # ragged in every axis, bf16 source with the on-read affine + LeakyReLU
-    ('same', (6, 10, 12), True, True),            # zero padding
-    ('reflect', (2, 2, 2), True, False),          # the smallest grid reflection allows
+@pytest.mark.parametrize('k,pad,dims,src_f32,transform,noise', [
+    (3, 'reflect', (12, 24, 48), True, False, False),      # several tiles per axis, whole tiles
+    (3, 'reflect', (9, 19, 37), False, True, False),       # ragged in every axis, bf16 source with the on-read affine + LeakyReLU
+    (3, 'same', (6, 10, 12), True, True, False),           # zero padding
+    (3, 'reflect', (2, 2, 2), True, False, False),         # the smallest grid reflection allows
+    (4, 'reflect', (16, 32, 64), True, False, True),       # the discriminator's first layer: 4x4x4 stride 2 over reflect pad + noise
+    (4, 'reflect', (10, 14, 44), True, False, True),       # ragged tiles
+    (4, 'reflect', (8, 8, 16), False, True, False),        # bf16 source, on-read transform, no noise
 ])
-def test_single_channel_stem_convolution_on_the_matrix_pipe(pad, dims, src_f32, transform):
-    """vg_c1k3.hip (1 -> 16, 3x3x3, the stem's first convolution, resunet_model.py:44-60): forward with bias, statistics and the
-    finalisation tail, weight and bias gradient -- against a float64 reference on the same rounded operands, and against the VALU
-    kernels of vg_pointwise.hip it replaces in the 16-bit builds (VG_C1K3M=0), which stay the exact-parity mode's kernels.
+def test_single_channel_convolutions_on_the_matrix_pipe(k, pad, dims, src_f32, transform, noise):
+    """vg_c1k3.hip (1 -> 16, 3x3x3: the stem's first convolution, resunet_model.py:44-60; 1 -> 64, 4x4x4 stride 2 over the reflect-padded
+    volume + noise: the discriminator's, discriminator.py:50-60): forward with bias, statistics and the finalisation tail, weight and
+    bias gradient -- against a float64 reference on the same rounded operands, and against the kernels they replace in the 16-bit
+    builds (VG_C1M=0: the VALU kernels of vg_pointwise.hip / the W-packed generic MFMA kernels), which stay the exact-parity mode's.
     Tolerances: bf16 output rounding for the forward (close_bf16), fp32 summation order for the gradients (2e-3 relative L2
     against float64; 1e-4 between the two kernel families)."""
     from van_gan_amd import ops, _lib
     from van_gan_amd.ops import Src
     dev = _dev()
-    N, cout = 2, 16
-    st, lay = make_layer(3, 1, cout, 1, pad, dims, seed=3)
+    N, cout, stride = 2, (16 if k == 3 else 64), k - 2
+    st, lay = make_layer(k, 1, cout, stride, pad, dims, seed=3)
+    odims = tuple(lay.out_dims)
     g = torch.Generator().manual_seed(7)
     x = torch.randn(N, *dims, 1, generator=g)
     xs = x if src_f32 else x.to(torch.bfloat16)
     scale = (torch.rand(N, 1, generator=g) + 0.5) if transform else None
     shift = (torch.randn(N, 1, generator=g) * 0.3) if transform else None
+    nz = (torch.randn(N, *[n + 2 for n in dims], 1, generator=g) * 0.1).to(torch.bfloat16) if noise else None
     src = Src(xs.to(dev), (N,) + dims, 1, f32=src_f32, scale=None if scale is None else scale.to(dev),
-              shift=None if shift is None else shift.to(dev), act=ops.ACT_LRELU if transform else ops.ACT_NONE)
-    with ops.DryRun() as dry:                       # the launches below are the MFMA kernels' (then, with VG_C1K3M=0, the VALU ones')
-        lay.forward(src, torch.zeros(N, *dims, cout, dtype=torch.bfloat16, device=dev), sums=torch.zeros(8, N, cout, 2, device=dev))
-        lay.wgrad(src, torch.zeros(N, *dims, cout, dtype=torch.bfloat16, device=dev))
-    assert [v.split('<')[0] for _, _, v in dry.records] == ['c1k3m_fwd', 'c1k3m_wgrad'], dry.records
+              shift=None if shift is None else shift.to(dev), act=ops.ACT_LRELU if transform else ops.ACT_NONE,
+              noise=None if nz is None else nz.to(dev), noise_pad=1 if noise else 0)
+    with ops.DryRun() as dry:                       # the launches below are the MFMA kernels' (then, with VG_C1M=0, the older ones')
+        lay.forward(src, torch.zeros(N, *odims, cout, dtype=torch.bfloat16, device=dev), sums=torch.zeros(8, N, cout, 2, device=dev))
+        lay.wgrad(src, torch.zeros(N, *odims, cout, dtype=torch.bfloat16, device=dev))
+    assert [v.split('<')[0] for _, _, v in dry.records] == ['c1m_fwd', 'c1m_wgrad'], dry.records
     res = {}
     for mode in (1, 0):
-        _lib.lib.vg_set_tuning(b'C1K3M', mode, 0)
+        _lib.lib.vg_set_tuning(b'C1M', mode, 0)
         try:
-            out = torch.zeros(N, *dims, cout, dtype=torch.bfloat16, device=dev)
+            out = torch.zeros(N, *odims, cout, dtype=torch.bfloat16, device=dev)
             sums = torch.zeros(8, N, cout, 2, device=dev)
             lay.forward(src, out, sums=sums)
             st.g.zero_()
-            dy = torch.randn(N, *dims, cout, generator=torch.Generator().manual_seed(11)).to(torch.bfloat16)
+            dy = torch.randn(N, *odims, cout, generator=torch.Generator().manual_seed(11)).to(torch.bfloat16)
             lay.wgrad(src, dy.to(dev))
             torch.cuda.synchronize()
             res[mode] = (out.float().cpu(), sums.sum(0).cpu(), st.grad('c.w').clone().cpu(), st.grad('c.b').clone().cpu())
         finally:
-            _lib.lib.vg_set_tuning(b'C1K3M', 0, 1)
+            _lib.lib.vg_set_tuning(b'C1M', 0, 1)
     a = xs.double()
     if transform:
         a = F.leaky_relu(a * scale.double().view(N, 1, 1, 1, 1) + shift.double().view(N, 1, 1, 1, 1), 0.2)
+    a = O.to_ncdhw(a)
+    if pad == 'reflect':
+        a = O.reflect_pad1(a)
+    if noise:
+        a = a + O.to_ncdhw(nz.double())
     a = bf(a)
     w = bf(st.param('c.w').cpu()).requires_grad_(True)
     b = st.param('c.b').cpu().double().requires_grad_(True)
-    y = O.to_ndhwc(ref_conv(O.to_ncdhw(a), w, b, 1, pad))
+    y = O.to_ndhwc(O.conv3d(a, w, b, stride, 'valid' if pad == 'reflect' else 'same'))
     (y * bf(dy)).sum().backward()
     out, sums, gw, gb = res[1]
     close_bf16(out, y, 'forward')
@@ -749,3 +761,40 @@ def test_single_channel_stem_convolution_on_the_matrix_pipe(pad, dims, src_f32, 
     assert float((out - o0).abs().max()) <= 2 ** -7 * float(o0.abs().max())           # at most one bf16 ulp of the largest value
     assert rel_l2(out, o0) < 2e-3 and rel_l2(sums, s0) < 1e-4
     assert rel_l2(gw, gw0) < 1e-4 and rel_l2(gb, gb0) < 1e-4
+
+
+@pytest.mark.parametrize('dims,N', [((8, 12, 36), 2), ((4, 4, 4), 1), ((128, 128, 128), 1)])
+def test_strided_single_channel_data_gradient_in_cell_form(dims, N):
+    """ConvLayer.dgrad_input of the discriminators' first layer (4x4x4 stride 2 over the reflect-padded single-channel volume,
+    discriminator.py:50-60; the generator loss reaches the generators through it, vangan.py:433-438): a stride-1 convolution of dY
+    over 2x2x2 cells of the padded grid on the thin-channel specialist + vg_cells_fold, against (a) float64 autograd through
+    reflection pad + convolution on the same bf16-rounded operands (small grids) and (b) the generic form -- 8 output-parity classes
+    onto the padded grid + the fold of vg_actnorm_bwd -- at every size incl. the 128^3 patch of BASELINE config 1.  Both forms round
+    each padded-grid value to bf16 once and add up to 8 of them in fp32: they differ by fp32 summation order inside the MFMA only."""
+    from van_gan_amd import ops
+    from van_gan_amd.ops import Arena
+    dev = _dev()
+    cout = 64
+    st, lay = make_layer(4, 1, cout, 2, 'reflect', dims, seed=5)
+    assert lay.cell is not None
+    odims = tuple(lay.out_dims)
+    dy = torch.randn(N, *odims, cout, generator=torch.Generator().manual_seed(2)).to(torch.bfloat16)
+    ar = Arena(1 << 28, dev)
+    dx = torch.full((N,) + dims + (1,), 7.0, device=dev)
+    lay.dgrad_input(ar, dy.to(dev), N, dx)
+    # the generic form
+    dp = torch.zeros((N,) + tuple(lay.buf_dims) + (1,), dtype=torch.bfloat16, device=dev)
+    lay.dgrad(dy.to(dev), N, dp, accumulate=False)
+    dx0 = torch.full((N,) + dims + (1,), 7.0, device=dev)
+    ops.actnorm_bwd(dp, True, None, (N,) + dims, 1, dx0, act=ops.ACT_NONE, norm=False, accumulate=False)
+    torch.cuda.synchronize()
+    assert rel_l2(dx, dx0) < 2e-3
+    assert float((dx - dx0).abs().max()) <= 2e-2 * float(dx0.abs().max())
+    if math.prod(dims) <= 1 << 16:
+        x = torch.zeros(N, 1, *dims, dtype=torch.float64, requires_grad=True)
+        w = bf(st.param('c.w').cpu())
+        (O.conv3d(O.reflect_pad1(x), w, None, 2, 'valid') * O.to_ncdhw(bf(dy))).sum().backward()
+        ref = O.to_ndhwc(x.grad)
+        got = dx.double().cpu()
+        tol = 2.5e-2 * ref.abs() + 8e-3 * ref.abs().max()
+        assert ((got - ref).abs() <= tol).all(), 'max err %.3e of %.3e' % (float((got - ref).abs().max()), float(ref.abs().max()))

@@ -69,8 +69,10 @@ def variant_of(kernel_name: str):
         return 'pw_wgrad<%s,%s>' % (tname(args[0]), 'cto1' if args[1] == 'true' else '1toc')
     if k in ('c1k3_fwd', 'c1k3_wgrad') and len(args) == 2:
         return '%s<%s,%s>' % (k, tname(args[0]), tname(args[1]))
-    if k in ('c1k3m_fwd', 'c1k3m_wgrad') and len(args) == 1:
-        return '%s<%s>' % (k, tname(args[0]))
+    if k == 'c1m_fwd' and len(args) == 5:                   # <S, KS, ST, MT, NOISE>
+        return 'c1m_fwd<%s,%s,%s,%s,n%s>' % (tname(args[0]), args[1], args[2], args[3], b(args[4]))
+    if k == 'c1m_wgrad' and len(args) == 6:                 # <S, KS, ST, TH, NT, NOISE>
+        return 'c1m_wgrad<%s,%s,%s,%s,n%s>' % (tname(args[0]), args[1], args[2], args[4], b(args[5]))
     return None
 
 

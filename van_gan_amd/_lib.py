@@ -99,6 +99,8 @@ _SIGS = {
     'vg_shortcut_dgrad_concat_norm': ([C.POINTER(ConvDesc), C.POINTER(ActNormBwdDesc), c_void_p, c_void_p, c_int, c_int, c_void_p], c_int),
     'vg_affine_add': ([c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_i64, c_int, c_void_p, c_int, c_void_p], c_int),
     'vg_bias_grad': ([c_void_p, c_int, c_i64, c_int, c_void_p, c_void_p], c_int),
+    'vg_pack_cell_weights': ([c_void_p, c_int, c_void_p, c_void_p], c_int),
+    'vg_cells_fold': ([c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p], c_int),
     'vg_tanh_bwd': ([c_void_p, c_void_p, c_void_p, c_i64, c_void_p], c_int),
     'vg_minmax': ([c_void_p, c_int, c_i64, c_void_p, c_void_p], c_int),
     'vg_minmax_apply': ([c_void_p, c_void_p, c_int, c_i64, c_void_p, c_void_p], c_int),

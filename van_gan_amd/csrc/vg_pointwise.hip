@@ -1100,11 +1100,11 @@ extern "C" int vg_shortcut_dgrad_concat_norm(const vg_conv_desc* d, const vg_act
 int vg_pointwise_conv(const vg_conv_desc* d, hipStream_t s) {
     if (pw_enabled() && !d->res && !d->tanh_out && !d->accumulate && d->ostr == 1 && !d->ooff_d && !d->ooff_h && !d->ooff_w
         && d->BD == d->OD && d->BH == d->OH && d->BW == d->OW && !(d->out_f32 && !d->f32)) {
+        { const int mrc = c1m_fwd(d, s); if (mrc <= 0) return mrc; }            // 16-bit storage: the MFMA kernels of vg_c1k3.hip
         C1K3 c;
         if (c1k3_fill(d, c)) {
             c.w = d->wpacked; c.bias = d->bias; c.out = d->out; c.sums = d->out_sums;
             c.fin = vg_fin_of(d);
-            if (!d->f32) { const int mrc = c1k3m_fwd(c, d->N, d->src_f32 != 0, s); if (mrc <= 0) { if (mrc == VG_OK && c.sums && c.fin.ticket && !vg_dry_on()) vg_fin_done = true; return mrc; } }
             const int qpb = 256 / (c.C >> 3);
             int64_t b = ((int64_t)c.D * c.H * c.W4 + qpb - 1) / qpb;
             const int64_t cap = (2047 / d->N) > 0 ? (2047 / d->N) : 1;
@@ -1183,11 +1183,11 @@ int vg_pointwise_conv(const vg_conv_desc* d, hipStream_t s) {
 
 int vg_pointwise_wgrad(const vg_conv_desc* d, const void* dy, int dy_f32, int T_total, float* dw, float* db, float* scratch,
                        int64_t scratch_bytes, hipStream_t s) {
+    if (pw_enabled()) { const int mrc = c1m_wgrad(d, dy, dy_f32, T_total, dw, db, scratch, scratch_bytes, s); if (mrc <= 0) return mrc; }
     if (pw_enabled() && T_total == 9 && !(dy_f32 && !d->f32)) {
         C1K3 c;
         if (c1k3_fill(d, c)) {
             c.dy = dy; c.dw = dw; c.db = db;
-            if (!d->f32 && !dy_f32) { const int mrc = c1k3m_wgrad(c, d->N, d->src_f32 != 0, s); if (mrc <= 0) return mrc; }
             const int qpb = 256 / (3 * (c.C >> 3));
             int64_t b = ((int64_t)c.D * c.H * c.W4 + (int64_t)qpb * 8 - 1) / ((int64_t)qpb * 8);
             const int64_t cap = (767 / d->N) > 0 ? (767 / d->N) : 1;

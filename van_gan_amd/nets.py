@@ -925,9 +925,7 @@ class PatchGAN:
             g = dxa
         lay = L['conv0']
         lay.wgrad(ctx['srcs'][0], g[:N2])
-        dp = ar.alloc((B,) + tuple(lay.buf_dims) + (1,), self.dtype)
-        lay.dgrad(g[N2:], B, dp, accumulate=False)
-        ops.actnorm_bwd(dp, True, None, (B,) + self.lv[0], 1, dx, act=ACT_NONE, norm=False, accumulate=False)
+        lay.dgrad_input(ar, g[N2:], B, dx)
         ar.release(mk, defer=True)
 
     def backward(self, ar: Arena, ctx: dict, dlogits: torch.Tensor, n0: int, n1: int, wgrad: bool,
@@ -970,7 +968,5 @@ class PatchGAN:
         if wgrad:
             lay.wgrad(src, g)
         if dx is not None:
-            dp = ar.alloc((N,) + tuple(lay.buf_dims) + (1,), self.dtype)
-            lay.dgrad(g, N, dp, accumulate=False)
-            ops.actnorm_bwd(dp, True, None, (N,) + self.lv[0], 1, dx, act=ACT_NONE, norm=False, accumulate=False)
+            lay.dgrad_input(ar, g, N, dx)
         ar.release(mk, defer=True)

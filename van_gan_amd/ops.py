@@ -699,6 +699,16 @@ class ConvLayer:
                     c['ck'] = self._pick_ck(cout, c['taps'], 1, self.out_dims, c['iters'], cin)
                 c['ktot'] = check(lib.vg_packed_ktot(len(c['taps']), cout, c['ck']), 'vg_packed_ktot')
                 c['wp'] = torch.zeros(lib.vg_packed_rows(cin), c['ktot'], dtype=dtype, device=dev)
+        # 4x4x4 stride-2 layer over the reflect-padded SINGLE-channel volume (the discriminators' first layer): its data gradient as a
+        # stride-1 convolution over 2x2x2 cells of the padded grid on the thin-channel specialist + a fold (vg_pack_cell_weights,
+        # vg_cells_fold; dgrad_input below) instead of 8 output-parity classes with one live MFMA column each
+        self.cell = None
+        if (need_dgrad and cin == 1 and k == 4 and stride == 2 and pad == 'reflect' and not self.f32 and cout % 16 == 0 and tap_subset is None
+                and all(n % 2 == 0 and n >= 4 for n in in_dims) and os.environ.get('VG_CELL_DGRAD', '1') != '0'):
+            ktot = check(lib.vg_packed_ktot(27, cout, 16), 'vg_packed_ktot')
+            self.cell = dict(dims=tuple(n // 2 + 1 for n in in_dims), ktot=ktot,
+                             wp=torch.zeros(lib.vg_packed_rows(16), ktot, dtype=dtype, device=dev),
+                             taps=[(a - 1, b - 1, c - 1) for a in range(3) for b in range(3) for c in range(3)])
 
     def _dma_bn(self, cin, cout, taps, istr, in_dims, out_dims) -> int:
         """Channel-panel width with which the LDS-DMA family serves this forward convolution (0: the gather kernels do).
@@ -782,10 +792,16 @@ class ConvLayer:
             items.append((self.w, c['idx'], c['wp'], self.cin, self.cout, len(c['taps']), 1, c['ck'], self.f32, self.d_bn))
         return items
 
+    def pack_cell(self):
+        """The packed operand of the cell form of the data gradient (dgrad_input) from the fp32 master weights."""
+        if getattr(self, 'cell', None) is not None:
+            check(lib.vg_pack_cell_weights(_p(self.w), self.cout, _p(self.cell['wp']), stream()), 'vg_pack_cell_weights ' + self.name)
+
     def pack(self):
         """fp32 master weights -> bf16 packed operands (after every optimizer step)."""
         T = self.f_T
         s = stream()
+        self.pack_cell()
         if self.f_bn:
             check(lib.vg_pack_weights_dma(_p(self.w), T, self.f_cin, self.cout, _p(self.f_idx), T, 0, self.f_bn, _p(self.f_wp), s), 'pack')
         else:
@@ -1015,6 +1031,44 @@ class ConvLayer:
         d.src0, d.N = _p(dy), N
         return d
 
+    def dgrad_input(self, ar: 'Arena', dy: torch.Tensor, N: int, dx: torch.Tensor):
+        """d/d input of a layer that reads a single-channel volume, folded through the reflection pad: dx fp32 [N, D, H, W, 1] is
+        overwritten.  The 4x4x4 stride-2 layer runs in its cell form (see __init__; not in the dry-run walks, which enumerate the
+        generic launch -- tests/test_gpu_ops.py compares the two forms at the true shape); everything else is dgrad onto the
+        padded grid + the fold of vg_actnorm_bwd."""
+        assert self.cin == 1 and self.pad == 'reflect'
+        if self.cell is None or DRY is not None or dy.dtype not in (torch.bfloat16, torch.float16):
+            dp = ar.alloc((N,) + tuple(self.buf_dims) + (1,), self.dtype)
+            self.dgrad(dy, N, dp, accumulate=False)
+            actnorm_bwd(dp, True, None, (N,) + tuple(self.in_dims), 1, dx, act=ACT_NONE, norm=False, accumulate=False)
+            return
+        c = self.cell
+        cells = ar.alloc((N,) + c['dims'] + (16,), self.dtype)
+        t = c.get('tmpl')
+        if t is None:
+            t = c['tmpl'] = ConvDesc()
+            t.src1 = None
+            t.c_src0, t.c_src1, t.src0_shift = self.cout, 0, 0
+            t.D, t.H, t.W = self.out_dims
+            t.act, t.istr, t.pad_mode, t.ostr = ACT_NONE, 1, PAD_ZERO, 1
+            _set_taps(t, c['taps'])
+            t.OD, t.OH, t.OW = c['dims']
+            t.BD, t.BH, t.BW = c['dims']
+            t.Cout, t.wpacked, t.CK = 16, _p(c['wp']), 16
+            t.f32 = 0
+        d = ConvDesc()
+        C.memmove(C.byref(d), C.byref(t), C.sizeof(ConvDesc))
+        d.src0, d.N, d.out = _p(dy), N, _p(cells)
+        s_ = stream()
+        conv_scratch(d, s_, dy.device.index)
+        e0 = PROF.begin() if PROF is not None else None
+        check(lib.vg_conv3d(C.byref(d), s_), 'vg_conv3d(dgrad, cells) ' + self.name)
+        if e0 is not None:
+            PROF.end('conv_dgrad', 2.0 * N * math.prod(self.out_dims) * self.cin * self.cout * self.k ** 3, e0,
+                     N * 2 * (math.prod(self.out_dims) * self.cout + math.prod(c['dims']) * 16), conv_variant(d), self.name)
+        D_, H_, W_ = self.in_dims
+        check(lib.vg_cells_fold(_p(cells), N, D_, H_, W_, _p(dx), s_), 'vg_cells_fold ' + self.name)
+
     def dgrad_concat_norm(self, dy: torch.Tensor, N: int, nd: 'ActNormBwdDesc', c_low: int, dlow: torch.Tensor, dskip: torch.Tensor,
                           acc_low: bool, acc_skip: bool) -> bool:
         """dgrad_concat with the conv branch folded in (vg_shortcut_dgrad_concat_norm): nd is the actnorm_desc of the block's first
@@ -1126,9 +1180,12 @@ class PackTable:
         self.keep = items
         self.n = len(items)
         self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+        self.cells = [l for l in layers if getattr(l, 'cell', None) is not None]
 
     def run(self):
         check(lib.vg_pack_weights_multi(_p(self.table), self.n, self.total_blocks, stream()), 'vg_pack_weights_multi')
+        for l in self.cells:
+            l.pack_cell()
 
 
 # ------------------------------------------------------------------------------------------------------
