@@ -358,7 +358,9 @@ int c1m_wgrad(const vg_conv_desc* d, const void* dy, int dy_f32, int T_total, fl
     if (T_total != KS * KS) return 1;
     c.dy = dy; c.dw = dw; c.db = db;
     const int th = KS == 3 ? 8 : 4;
-    const dim3 grid = c1m_grid(c, d->N, th, vg_tune("C1M_WGRAD_WGS", 2));
+    // workgroups per CU: every workgroup hands in a slab of KS^3 * C sums, and the slab pass is a dependent chain over the slabs (measured at
+    // 128^3: 3x3x3 1 -> 16: 47 / 41 / 48 / 52 us for 1 / 2 / 3 / 4 per CU; 4x4x4 1 -> 64, two volumes: 84 / 101 / 152 / 158)
+    const dim3 grid = c1m_grid(c, d->N, th, vg_tune("C1M_WGRAD_WGS", KS == 3 ? 2 : 1));
     const int nslab = (int)(grid.x * grid.y), dw_elems = KS * KS * KS * c.C;
     c.part = (nslab > 4 && scratch && (int64_t)nslab * dw_elems * 4 <= scratch_bytes && vg_tune("C1M_WGRAD_PART", 1)) ? scratch : nullptr;
     if (vg_dry("c1m_wgrad<%s,%d,%d,%d,n%d>|part%d", d->src_f32 ? "f32" : "bf16", KS, KS - 2, c.C / 16, c.noise ? 1 : 0, c.part ? 1 : 0)) return VG_OK;

@@ -215,7 +215,7 @@ class VanGan:
         self._side_ev = {}
         # world > 1: the step does not end with a join of the optimizer stream -- the last buckets' all-reduce + Adam + repack run
         # under the head of the NEXT step, whose consumers wait for the update event of the network they read (VG_XSTEP=0: join)
-        self._xstep = self.ddp and self._opt is not None and os.environ.get('VG_XSTEP', '1') != '0'
+        self._xstep = (self.ddp or os.environ.get('VG_XSTEP_SINGLE', '0') == '1') and self._opt is not None and os.environ.get('VG_XSTEP', '1') != '0'
         self._upd_ev = {}
         self._cap = None                 # _StepParams while a train step is being captured into a HIP graph (capture_train_step)
         self._graph = None
