@@ -16,7 +16,7 @@ def sums(d, counter):
         if r['Counter_Name'] != counter:
             continue
         name = r['Kernel_Name']
-        fam = 'conv' if any(k in name for k in ('conv_kernel', 'conv32_kernel', 'conv_thin_kernel', 'conv_dma_kernel', 'wgrad_kernel', 'wgrad_dma_kernel', 'wgrad_pw_dma_kernel', 'pw_cto', 'pw_1toc', 'pw_wgrad', 'pw_gemm', 'c1k3_', 'c1m_')) else 'other'
+        fam = 'conv' if any(k in name for k in ('conv_kernel', 'conv32_kernel', 'conv_thin_kernel', 'conv_dma_kernel', 'wgrad_kernel', 'wgrad_dma_kernel', 'wgrad_pw_dma_kernel', 'wgrad_thin_kernel', 'wgrad_thin_reduce', 'pw_cto', 'pw_1toc', 'pw_wgrad', 'pw_gemm', 'c1k3_', 'c1m_')) else 'other'
         if name.startswith('materialize_kernel') or name.startswith('reduce_partials_kernel'):
             fam = 'conv_aux'           # passes that belong to a vg_conv3d_wgrad / LDS-DMA vg_conv3d call: their bytes count for the family, not as launches
         kb[fam] += float(r['Counter_Value'])

@@ -57,6 +57,8 @@ def variant_of(kernel_name: str):
         return 'conv32<%s,%s,n%s,cp%s>' % (args[0], args[1], b(args[2]), b(args[3]))
     if k == 'wgrad_dma' and len(args) == 3:
         return 'wgrad_dma<%s,%s,d%s>' % (args[0], args[1], b(args[2]))
+    if k == 'wgrad_thin' and len(args) == 1:
+        return 'wgrad_thin<m%s>' % args[0]
     if k == 'wgrad_pw_dma' and len(args) == 2:
         return 'wgrad_pw_dma<%s,%s>' % (args[0], args[1])
     if k == 'wgrad' and len(args) == 4:

@@ -554,3 +554,266 @@ int vg_launch_conv_thin(const GatherIn& g, const ConvOut& k, int np, hipStream_t
     if (k.res != nullptr) return st ? launch_thin<VG_STAGE_RELU, true, true, true>(g, k, np, s) : launch_thin<VG_STAGE_RELU, true, true, false>(g, k, np, s);
     return st ? launch_thin<VG_STAGE_RELU, true, false, true>(g, k, np, s) : launch_thin<VG_STAGE_RELU, true, false, false>(g, k, np, s);
 }
+
+// ================================================================================================================================
+// Weight gradient of the same layers (3x3x3, stride 1, 16-channel chunks, 16 output channels): wgrad_thin_kernel
+// ================================================================================================================================
+// dW[tap][ci][co] = sum over voxels X[voxel + tap][ci] * dY[voxel][co] with X the operand exactly as the forward kernel stages it (same
+// routine: thin_issue / thin_commit, same transform, same single rounding).  wgrad_dma_kernel<R,1,DIRECT> gives each of its 8 waves a few
+// (tap, plane) ROWS and walks all voxels of a tile with them: 10 LDS fragment reads per 4 MFMAs, every K-step a dependent LDS round trip
+// (290 cycles per K-step for 64 cycles of MFMA).  Here the waves split the VOXELS (wave = D-plane of the tile) and every wave
+// holds the WHOLE slab -- 27 taps x 16 ci x 16 co = 27 accumulator tiles (+ 1 for the bias gradient) -- so a K-step of 32 voxels is 2
+// fragment reads of dY and 27 x 2 of X feeding 28 independent MFMAs: nothing in the loop waits for anything but LDS bandwidth.
+//   * both operands are needed voxel-major per lane while X lies [channel group][voxel][8 ch] and dY [voxel][16 ch] in LDS:
+//     ds_read_b64_tr_b16 hands a 16-lane group a 4 (voxels) x 16 (channels) block transposed; each lane supplies its own row address, so
+//     the two channel-group planes of the halo image are one block, and the tap is an immediate offset (a DSB + b ROWB + c UNIT) on one
+//     base register -- no address arithmetic in the loop;
+//   * bank conflicts: the plane stride carries a 64-byte skew (fill_gather's skew) so that the two planes of the same 4 voxels take
+//     different banks; the dY rows are padded by 128 bytes per 8 voxels for the same reason;
+//   * a workgroup keeps its 28 accumulator tiles over all its tiles, the four waves' copies are added in wave order through LDS, and the
+//     slab goes to a partial buffer that wgrad_thin_reduce_kernel sums in a fixed order (16 loads of 16 bytes in flight per lane).
+struct WgThin { const void* dy; float* part; float* dw; float* db; int Cin, nslab, dbg; unsigned* tickets; int ntickets, xw; };
+namespace {
+constexpr int WT_DYROW = TW * 32 + 128;                 // 640: 16 voxels x 32 bytes + 128 bytes behind the first 8
+constexpr int WT_DYB = TD * TH * WT_DYROW;              // 20480
+constexpr int WT_SLAB = 28 * 256;                       // floats: [tap 0..26 | bias][ci 16][co 16]
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void wgrad_thin_kernel(const GatherIn g, const WgThin p) {
+    typedef bf16_t T;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int chunk = blockIdx.y, n = blockIdx.z;
+    const int PSBs = g.PSB;                                               // plane stride incl. the skew
+    char* halo = smem;
+    float* scs = (float*)(smem + 2 * PSBs);
+    int* utab = (int*)(scs + 32);
+    constexpr int NCOLS = HH * HW * 2;
+    int* xtab = utab + 2 * NCOLS;
+    const int NHt = g.tiles_h * TH + 2, NWt = g.tiles_w * TW + 2, NDt = g.tiles_d * TD + 2;
+    char* dyt = (char*)(xtab + 2 * (NHt + NWt + NDt));
+    dyt = (char*)(((size_t)dyt + 15) & ~(size_t)15);
+    build_column_table(g, utab, tid);
+    stage_scale_shift(g, scs, n, chunk, tid);
+    thin_axis_tables(g, xtab, NHt, NWt, NDt, tid);
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid < p.ntickets) p.tickets[tid] = 0u;      // the slab pass's tickets (it runs behind this launch)
+    __syncthreads();                                                         // the tables are read by the first tile's loads
+    auto tabat = [&](int od0_, int oh0_, int ow0_) { return ThinTab{xtab, NHt + NWt + NDt, NHt, NWt, od0_, oh0_, ow0_}; };
+    // transposed-read addresses: lane 4 q + pp of 16-lane group gq supplies voxel row q (+ 4 for the second read), channels 4 pp .. + 3;
+    // the K-step's 32 voxels: tile row y = 2 s + (gq >> 1), column w = 8 (gq & 1) + q (+ 4)
+    const int gq = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const int wq = 8 * (gq & 1) + q, yq = gq >> 1;
+    const int abase = (pp >> 1) * PSBs + ((wave * HH + yq) * HW + wq) * UNIT + (pp & 1) * 8;
+    const int bbase = (wave * TH + yq) * WT_DYROW + wq * 32 + (wq >> 3) * 128 + pp * 8;
+    f32x4 acc[28];
+#pragma unroll
+    for (int t = 0; t < 28; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 ones;
+    { const short o = (short)f2bf(1.f); ones = (bf16x8){o, o, o, o, o, o, o, o}; }
+    typedef __attribute__((ext_vector_type(4))) short s16x4;
+    typedef __attribute__((address_space(3))) s16x4 lds_s4;
+    const int tiles_per_n = g.tiles_d * g.tiles_h * g.tiles_w;
+    const T* dyn = (const T*)p.dy + (size_t)n * g.D * g.H * g.W * 16;
+    // the loads of a tile (9 + 4 units of 16 bytes per thread) are issued ahead of the previous tile's K loop and land under it
+    Raw8<T> raw[3][HD / 2];
+    f32x4 dv[4];
+    auto origin = [&](int tile, int& od0, int& oh0, int& ow0) {
+        const int ti_w = tile % g.tiles_w, t2 = tile / g.tiles_w, ti_h = t2 % g.tiles_h, ti_d = t2 / g.tiles_h;
+        od0 = ti_d * TD; oh0 = ti_h * TH; ow0 = ti_w * TW;
+    };
+    auto issue = [&](int od0, int oh0, int ow0) {
+        thin_issue<MODE>(g, utab, tabat(od0, oh0, ow0), n, chunk, tid, raw);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                                       // dY of the tile: 1024 units of 16 bytes (out of range: zeros)
+            const int u = tid + 256 * i, vox = u >> 1, w = vox & 15, y = (vox >> 4) & 7, z = vox >> 7;
+            const bool ok = od0 + z < g.D && oh0 + y < g.H && ow0 + w < g.W;
+            const T* src = dyn + (((size_t)min(od0 + z, g.D - 1) * g.H + min(oh0 + y, g.H - 1)) * g.W + min(ow0 + w, g.W - 1)) * 16 + (u & 1) * 8;
+            dv[i] = *(const __attribute__((address_space(1))) f32x4*)(uintptr_t)src;
+            if (!ok) dv[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    // tile walk as the forward kernel's (p.xw: gridDim.x a multiple of 8): the workgroups that share an XCD (blockIdx.x & 7) walk ONE contiguous
+    // eighth of the tile sequence side by side, so the halo voxels neighbouring tiles share (2.1 x the tile) are found in that XCD's L2
+    int t0 = blockIdx.x, tstep = gridDim.x, tend = tiles_per_n;
+    if (p.xw) {
+        const int sl = (tiles_per_n + 7) >> 3, xcd = blockIdx.x & 7;
+        t0 = xcd * sl + ((int)blockIdx.x >> 3); tstep = gridDim.x >> 3; tend = min(tiles_per_n, (xcd + 1) * sl);
+    }
+    int od0, oh0, ow0;
+    if (t0 < tend) { origin(t0, od0, oh0, ow0); issue(od0, oh0, ow0); }
+    for (int tile = t0; tile < tend; tile += tstep) {
+        __syncthreads();                                                     // the previous tile's fragment reads are done
+        if (!(p.dbg & 2)) thin_commit<MODE>(g, halo, scs, utab, tabat(od0, oh0, ow0), chunk, tid, raw);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int u = tid + 256 * i, vox = u >> 1, w = vox & 15;
+            *(f32x4*)(dyt + (vox >> 4) * WT_DYROW + w * 32 + (w >> 3) * 128 + (u & 1) * 16) = dv[i];
+        }
+        __syncthreads();
+        if (!(p.dbg & 4) && tile + tstep < tend) { origin(tile + tstep, od0, oh0, ow0); issue(od0, oh0, ow0); }
+        if (p.dbg & 1) continue;
+        // the tile's 4 x 27 (K-step, tap) products in 18 groups of six; the fragments of group i + 1 are read while the MFMAs of group i issue
+        // (two register sets of 6 x 4).  Without the explicit order the scheduler hoists all 54 reads of a K-step and spills the prefetched
+        // tile; nine per group spill 40 registers.
+        constexpr int WG_ = 6, NG_ = 4 * 27 / WG_;
+        bf16x8 afr[2][WG_], bfr[2];
+        auto load_b = [&](int s) {
+            const s16x4 bl = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(dyt + bbase + s * 2 * WT_DYROW));
+            const s16x4 bh = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(dyt + bbase + s * 2 * WT_DYROW + 128));
+            bfr[s & 1] = (bf16x8){bl[0], bl[1], bl[2], bl[3], bh[0], bh[1], bh[2], bh[3]};
+        };
+        auto load_group = [&](int i, int set) {
+#pragma unroll
+            for (int k = 0; k < WG_; ++k) {
+                const int e = i * WG_ + k, s = e / 27, t = e - 27 * s;
+                if (t == 0) load_b(s);
+                const int o = abase + (t / 9) * DSB + ((t / 3) % 3 + 2 * s) * ROWB + (t % 3) * UNIT;
+                const s16x4 al = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(halo + o));
+                const s16x4 ah = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(halo + o + 4 * UNIT));
+                afr[set][k] = (bf16x8){al[0], al[1], al[2], al[3], ah[0], ah[1], ah[2], ah[3]};
+            }
+        };
+        load_group(0, 0);
+#pragma unroll
+        for (int i = 0; i < NG_; ++i) {
+            if (i + 1 < NG_) load_group(i + 1, (i + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < WG_; ++k) {
+                const int e = i * WG_ + k, s = e / 27, t = e - 27 * s;
+                acc[t] = VG_MFMA16(afr[i & 1][k], bfr[s & 1], acc[t]);
+                if (t == 26) acc[27] = VG_MFMA16(ones, bfr[s & 1], acc[27]);   // every row: the column sums of dY (bias gradient)
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // the four waves' slabs added in wave order (deterministic), then one store per element into this workgroup's partial slab:
+    // lane (kg, li) of tile t holds [ci = 4 kg + e][co = li]
+    float* red = (float*)halo;
+    for (int w = 0; w < 4; ++w) {
+        __syncthreads();
+        if (wave == w) {
+#pragma unroll
+            for (int t = 0; t < 28; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float* r = red + (t * 4 + e) * 64 + lane;
+                    *r = w == 0 ? acc[t][e] : *r + acc[t][e];
+                }
+        }
+    }
+    __syncthreads();
+    float* slab = p.part + ((size_t)chunk * p.nslab + (size_t)n * gridDim.x + blockIdx.x) * WT_SLAB;
+    for (int i = tid; i < 28 * 256; i += 256) {
+        const int l = i & 63, e = (i >> 6) & 3, t = i >> 8;
+        slab[t * 256 + (4 * (l >> 4) + e) * 16 + (l & 15)] = red[i];
+    }
+}
+
+// dw[(t Cin + 16 chunk + ci) 16 + co] += sum over the chunk's slabs, in a fixed order whatever the timing: block (column of 256 elements,
+// chunk, group gr of WT_RG) -- wave w adds the slabs 4 gr + w, + 4 WT_RG, .. (16 loads of 16 bytes in flight per lane), the four waves are
+// added as ((0 + 1) + 2) + 3, the group's partial goes to part2, and the group that takes the column's last ticket adds the WT_RG partials in
+// group order and hands the result to dw (the bias row, t = 27, ci = 0 of chunk 0, to db).  28 x chunks x WT_RG blocks instead of 28 x chunks:
+// the slab pass of a 512-workgroup launch is a 2-deep chain of loads, not a 16-deep one.
+constexpr int WT_RG = 8;
+__global__ __launch_bounds__(256) void wgrad_thin_reduce_kernel(const float* part, int nslab, int Cin, float* dw, float* db, float* part2, unsigned* tickets) {
+    __shared__ f32x4 sm[4][64];
+    __shared__ int last;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, chunk = blockIdx.y, gr = blockIdx.z;
+    const int j = (blockIdx.x * 64 + lane) * 4;                          // slab-local element of this lane's 4
+    const float* base = part + (size_t)chunk * nslab * WT_SLAB + j;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    int b = 4 * gr + w;
+    for (; b + 60 * WT_RG < nslab; b += 64 * WT_RG) {
+        f32x4 v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = *(const f32x4*)(base + (size_t)(b + 4 * WT_RG * k) * WT_SLAB);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += v[k];
+    }
+    for (; b < nslab; b += 4 * WT_RG) s += *(const f32x4*)(base + (size_t)b * WT_SLAB);
+    sm[w][lane] = s;
+    __syncthreads();
+    float* col = part2 + ((size_t)(chunk * 28 + blockIdx.x) * WT_RG) * 256;           // [group][256 elements] of this column
+    if (w == 0) {
+        const f32x4 r = ((sm[0][lane] + sm[1][lane]) + sm[2][lane]) + sm[3][lane];
+        float* o = col + gr * 256 + lane * 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) __hip_atomic_store(o + k, r[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // the partial is written through before the ticket (the K split's exchange)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned* tk = tickets + chunk * 28 + blockIdx.x;
+        const unsigned old = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = old == WT_RG - 1;
+        if (last) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!last || w != 0) return;
+    f32x4 r = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g2 = 0; g2 < WT_RG; ++g2)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r[k] += __hip_atomic_load(col + g2 * 256 + lane * 4 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int t = j >> 8, ci = (j >> 4) & 15, co = j & 15;              // 4 consecutive co
+    if (t < 27) {
+        float* o = dw + ((size_t)t * Cin + 16 * chunk + ci) * 16 + co;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) atomicAdd(o + k, r[k]);              // (atomic: two applications of a network may add into one gradient buffer)
+    } else if (ci == 0 && chunk == 0 && db) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) atomicAdd(db + co + k, r[k]);
+    }
+}
+
+// VG_OK when served (or recorded by a dry run), 1 when the shape is not one of this kernel's, < 0 on error
+int vg_wgrad_thin(const vg_conv_desc* d, const void* dy, int dy_f32, const int32_t* tap_idx_host, int T_total, float* dw, float* db,
+                  float* scratch, int64_t scratch_bytes, hipStream_t s) {
+    if (!vg_tune("WGRAD_THIN", 1) || d->f32 || dy_f32 || d->src_f32 || d->wpack || d->noise || d->nclass > 1) return 1;
+    const int Cin = d->c_src0 + d->c_src1;
+    if (d->ntaps != 27 || T_total != 27 || d->istr != 1 || d->Cout != 16 || (Cin % 16) || Cin < 16 || Cin > 64 || d->CK != 16) return 1;
+    if (d->OD != d->D || d->OH != d->H || d->OW != d->W) return 1;
+    if ((int64_t)d->D * d->H * d->W < vg_tune("WGRAD_THIN_MINVOX", 65536)) return 1;     // small grids: the slab costs more than the K loop
+    int tmin[3] = {d->tap_d[0], d->tap_h[0], d->tap_w[0]};
+    for (int t = 0; t < 27; ++t)                                         // raster order: the tap is an immediate offset in the loop
+        if (tap_idx_host[t] != t || d->tap_d[t] != tmin[0] + t / 9 || d->tap_h[t] != tmin[1] + (t / 3) % 3 || d->tap_w[t] != tmin[2] + t % 3) return 1;
+    GatherIn g;
+    if (fill_gather(d, g, 16, 512) != VG_OK) return 1;                   // (the forward kernel's tile: 16 x 8 x 4; a skew argument would change the shape search)
+    if (g.lean != VG_STAGE_PLAIN && g.lean != VG_STAGE_RELU) return 1;
+    if (!g.planar || g.HW != HW || g.HH != HH || g.HD != HD || g.HWp != HW || g.HHp != HH || g.DS != DSB || g.PSB != PSB) return 1;
+    g.PSB += 64; g.CS = g.PSB;                                           // plane stride + 64 bytes: the two planes of a voxel on different banks
+    if ((1 << g.twl) != TW || (1 << g.thl) != TH || (1 << g.tdl) != TD) return 1;
+    const int AL = (g.tiles_h * TH + 2) + (g.tiles_w * TW + 2) + (g.tiles_d * TD + 2);
+    const int lds = 2 * g.PSB + 32 * 4 + (2 * HH * HW * 2 + 2 * AL) * 4 + 16 + WT_DYB;
+    if (lds > VG_LDS_LIMIT || 2 * g.PSB < WT_SLAB * 4) return 1;
+    const int nchunks = Cin / 16, tiles = g.tiles_d * g.tiles_h * g.tiles_w;
+    // persistent grid: the kernel is bound by latency -- loads, commit, K loop and the barriers between them run one after the other inside
+    // a workgroup, two workgroups per CU at most (LDS) -- so alone it wants every slot (16 -> 16 at 128^3, two volumes: 173 / 152 / 128 us for
+    // 256 / 384 / 512 workgroups), but it runs on a side stream next to its lane: in the step 384 is as fast as 512 or faster (17.79-17.86 vs 17.86-17.99 ms)
+    int bx = vg_tune("WGRAD_THIN_WGS", 512) / (nchunks * d->N);
+    if (bx < 1) bx = 1; if (bx > tiles) bx = tiles;
+    int xw = 0;
+    if (vg_tune("WGRAD_THIN_XCD", 1) && bx >= 16 && tiles >= 4 * bx) { bx &= ~7; xw = 1; }
+    const int nslab = bx * d->N;
+    // scratch: [chunks][slabs][WT_SLAB] partial slabs | [chunks][28][WT_RG][256] group partials of the slab pass | its tickets
+    const int64_t slab_f = (int64_t)nchunks * nslab * WT_SLAB, part2_f = (int64_t)nchunks * 28 * WT_RG * 256;
+    if (!scratch || (slab_f + part2_f + nchunks * 28 + 64) * 4 > scratch_bytes) return 1;
+    if (vg_dry("wgrad_thin<m%d>|ch%d|walk%d", g.lean, nchunks > 1 ? 1 : 0, tiles > bx ? 1 : 0)) return VG_OK;
+    float* part2 = scratch + slab_f;
+    unsigned* tickets = (unsigned*)(part2 + part2_f);
+    WgThin p = {dy, scratch, dw, db, Cin, nslab, vg_tune("WT_DBG", 0), tickets, nchunks * 28, xw};
+    const dim3 grid(bx, nchunks, d->N);
+    if (g.lean == VG_STAGE_PLAIN) {
+        static bool a0 = false;
+        if (!a0) { (void)hipFuncSetAttribute((const void*)wgrad_thin_kernel<VG_STAGE_PLAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, VG_LDS_LIMIT); a0 = true; }
+        hipLaunchKernelGGL((wgrad_thin_kernel<VG_STAGE_PLAIN>), grid, dim3(256), lds, s, g, p);
+    } else {
+        static bool a1 = false;
+        if (!a1) { (void)hipFuncSetAttribute((const void*)wgrad_thin_kernel<VG_STAGE_RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, VG_LDS_LIMIT); a1 = true; }
+        hipLaunchKernelGGL((wgrad_thin_kernel<VG_STAGE_RELU>), grid, dim3(256), lds, s, g, p);
+    }
+    hipLaunchKernelGGL(wgrad_thin_reduce_kernel, dim3(WT_SLAB / 256, nchunks, WT_RG), dim3(256), 0, s, (const float*)scratch, nslab, Cin, dw, db, part2, tickets);
+    return vg_check_launch();
+}

@@ -356,6 +356,10 @@ extern "C" int vg_conv3d_wgrad(const vg_conv_desc* d, const void* dy, int dy_f32
         const int prc = vg_pointwise_wgrad(d, dy, dy_f32, T_total, dw, db, scratch, scratch_bytes, (hipStream_t)stream);
         if (prc <= 0) return prc;
     }
+    {   // the thin full-resolution layers (16-channel chunks, 16 output channels): voxel-split waves holding the whole slab (vg_conv_thin.hip)
+        const int trc = vg_wgrad_thin(d, dy, dy_f32, tap_idx_host, T_total, dw, db, scratch, scratch_bytes, (hipStream_t)stream);
+        if (trc <= 0) return trc;
+    }
     {   // materialised operand + LDS-DMA staging (vg_wgrad_dma.hip) where the shape is one of its
         const int drc = vg_wgrad_dma(d, dy, dy_f32, tap_idx_host, T_total, dw, db, scratch, scratch_bytes, (hipStream_t)stream);
         if (drc <= 0) return drc;
