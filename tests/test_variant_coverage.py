@@ -27,7 +27,7 @@ def test_every_variant_of_the_baseline_configs_has_a_gpu_parity_case():
     names = ' '.join(v for _, v in needed)
     for frag in ('conv<bf16,16,8', 'conv<bf16,32,4', 'conv32<128', 'conv32<64', 'mc1', 'mc2', 'cp1', 'c11', 'pw_cto1', 'pw_1toc',
                  'c1m_fwd<f32,3,1,1,n0>', 'c1m_wgrad<f32,3,1,1,n0>', 'c1m_fwd<f32,4,2,4,n1>', 'c1m_wgrad<f32,4,2,4,n1>', 'wgrad<bf16,24,1', 'wgrad<bf16,7,4', 'walk1', 'ch1', 'part1', 'n1',
-                 'wgrad_dma<4,1,d0>', 'wgrad_dma<4,1,d1>', 'wgrad_thin<m1>|ch0', 'wgrad_thin<m1>|ch1', 'wgrad_dma<4,2,d0>', 'wgrad_dma<4,2,d1>', 'wgrad_dma<8,2,d0>', 'wgrad_dma<8,4,d0>', '|s2|', '|nb3|', '|ks4', '|ks2',
+                 'wgrad_dma<4,1,d0>', 'wgrad_thin<m1>|ch0', 'wgrad_thin<m1>|ch1', 'wgrad_dma<4,2,d0>', 'wgrad_dma<4,2,d1>', 'wgrad_dma<8,2,d0>', 'wgrad_dma<8,4,d0>', '|s2|', '|nb3|', '|ks4', '|ks2',
                  'conv_thin<m0', 'conv_thin<m1', 'pw_gemm<2,1,g1,a0>', 'pw_gemm<1,3,g0,a1>', 'pw_gemm<1,1,g1,a1>',
                  'wgrad_pw_dma<3,1>', 'wgrad_pw_dma<6,2>', 'wgrad_pw_dma<4,4>', 'wgrad_pw_dma<6,4>', '|s1|u1|', '|s2|u0|',
                  # the LDS-DMA forward / data-gradient family: both panel widths, 4^3 and 3^3 stage bodies, K split, class-parallel strided
