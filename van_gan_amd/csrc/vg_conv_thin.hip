@@ -642,15 +642,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_thin_kernel(const GatherIn g, co
     }
     int od0, oh0, ow0;
     if (t0 < tend) { origin(t0, od0, oh0, ow0); issue(od0, oh0, ow0); }
+    unsigned long long c_wait0 = 0, c_commit = 0, c_wait1 = 0, c_k = 0, t_a = 0, t_b = 0;
     for (int tile = t0; tile < tend; tile += tstep) {
+        if (p.dbg & 8) t_a = __builtin_amdgcn_s_memtime();
         __syncthreads();                                                     // the previous tile's fragment reads are done
+        if (p.dbg & 8) { t_b = __builtin_amdgcn_s_memtime(); c_wait0 += t_b - t_a; }
         if (!(p.dbg & 2)) thin_commit<MODE>(g, halo, scs, utab, tabat(od0, oh0, ow0), chunk, tid, raw);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int u = tid + 256 * i, vox = u >> 1, w = vox & 15;
             *(f32x4*)(dyt + (vox >> 4) * WT_DYROW + w * 32 + (w >> 3) * 128 + (u & 1) * 16) = dv[i];
         }
+        if (p.dbg & 8) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); t_a = __builtin_amdgcn_s_memtime(); c_commit += t_a - t_b; }
         __syncthreads();
+        if (p.dbg & 8) { t_b = __builtin_amdgcn_s_memtime(); c_wait1 += t_b - t_a; }
         if (!(p.dbg & 4) && tile + tstep < tend) { origin(tile + tstep, od0, oh0, ow0); issue(od0, oh0, ow0); }
         if (p.dbg & 1) continue;
         // the tile's 4 x 27 (K-step, tap) products in 18 groups of six; the fragments of group i + 1 are read while the MFMAs of group i issue
@@ -687,6 +692,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_thin_kernel(const GatherIn g, co
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (p.dbg & 8) { t_a = __builtin_amdgcn_s_memtime(); c_k += t_a - t_b; }
+    }
+    if ((p.dbg & 8) && tid == 0) {
+        unsigned long long* o = (unsigned long long*)(p.tickets + 4096) + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4;
+        o[0] = c_wait0; o[1] = c_commit; o[2] = c_wait1; o[3] = c_k;
     }
     // the four waves' slabs added in wave order (deterministic), then one store per element into this workgroup's partial slab:
     // lane (kg, li) of tile t holds [ci = 4 kg + e][co = li]
@@ -799,7 +809,7 @@ int vg_wgrad_thin(const vg_conv_desc* d, const void* dy, int dy_f32, const int32
     const int nslab = bx * d->N;
     // scratch: [chunks][slabs][WT_SLAB] partial slabs | [chunks][28][WT_RG][256] group partials of the slab pass | its tickets
     const int64_t slab_f = (int64_t)nchunks * nslab * WT_SLAB, part2_f = (int64_t)nchunks * 28 * WT_RG * 256;
-    if (!scratch || (slab_f + part2_f + nchunks * 28 + 64) * 4 > scratch_bytes) return 1;
+    if (!scratch || (slab_f + part2_f + nchunks * 28 + 64 + 4096 + 8 * 4096) * 4 > scratch_bytes) return 1;
     if (vg_dry("wgrad_thin<m%d>|ch%d|walk%d", g.lean, nchunks > 1 ? 1 : 0, tiles > bx ? 1 : 0)) return VG_OK;
     float* part2 = scratch + slab_f;
     unsigned* tickets = (unsigned*)(part2 + part2_f);
