@@ -711,14 +711,14 @@ extern "C" const char* vg_status_string(int code) {
 #include <mutex>
 namespace {
 struct TuneEntry { char key[32]; int value; int state; };      // state: 0 unset, 1 from env/default (cached), 2 forced
-TuneEntry g_tune[64];
+TuneEntry g_tune[256];          // (64 overflowed in round 5: a full table silently turned vg_set_tuning into a no-op for new keys)
 int g_ntune = 0;
 std::mutex g_tune_mu;
 thread_local char* t_dry_buf = nullptr;
 thread_local int t_dry_len = 0;
 TuneEntry* tune_find(const char* key, bool create) {
     for (int i = 0; i < g_ntune; ++i) if (!strcmp(g_tune[i].key, key)) return &g_tune[i];
-    if (!create || g_ntune >= 64 || strlen(key) >= sizeof(g_tune[0].key)) return nullptr;
+    if (!create || g_ntune >= 256 || strlen(key) >= sizeof(g_tune[0].key)) return nullptr;
     TuneEntry* e = &g_tune[g_ntune++];
     strcpy(e->key, key); e->value = 0; e->state = 0;
     return e;
