@@ -397,7 +397,7 @@ def main():
         roof = {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS,
                 'traffic': traffic, 'traffic_unit': 'HBM bytes per launch (read + write), PMC', 'traffic_source': traffic_src,
                 'algorithmic_bytes_per_launch': alg_bytes / n,
-                'kernel': 'conv_kernel / conv32_kernel / conv_thin_kernel / conv_dma_kernel (+ its materialize pass) / wgrad_dma_kernel (+ its materialize and reduce_partials passes) / wgrad_kernel<bf16,*> + the pointwise pw_* / c1k3_* kernels of the 1x1x1 and single-channel layers (every vg_conv3d / vg_conv3d_wgrad call of one step)',
+                'kernel': 'conv_kernel / conv32_kernel / conv_thin_kernel / conv_dma_kernel (+ its materialize pass) / wgrad_dma_kernel (+ its materialize and reduce_partials passes) / wgrad_thin_kernel (+ its slab pass) / wgrad_kernel<bf16,*> + the pointwise pw_* kernels of the 1x1x1 layers and the c1m_* kernels of the single-channel layers (every vg_conv3d / vg_conv3d_wgrad call of one step)',
                 'launches_per_step': n, 'avg_launch_ms': tot_ms / n, 'kernel_ms_per_step': tot_ms,
                 'algorithmic_gflop_per_step': tot_fl / 1e9,
                 'by_kind': {k: {'launches': v['launches'], 'ms': round(v['ms'], 3),
