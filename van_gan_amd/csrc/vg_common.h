@@ -177,7 +177,7 @@ int vg_wgrad_pw_dma(const vg_conv_desc* d, const void* dy, int dy_f32, int T_tot
 int vg_wgrad_thin(const vg_conv_desc* d, const void* dy, int dy_f32, const int32_t* tap_idx_host, int T_total, float* dw, float* db,
                   float* scratch, int64_t scratch_bytes, hipStream_t s);
 // vg_conv_dma.hip: forward / data gradient with both operands staged by LDS-DMA (VG_OK served, 1 not one of its shapes, < 0 error)
-int vg_conv_dma(const vg_conv_desc* d, hipStream_t s);
+int vg_conv_dma(const vg_conv_desc* d, hipStream_t s, bool* did_stats = nullptr);
 // vg_wgrad.hip: dw[i] += sum_b part[b][i] in a fixed order (partial slabs written by weight-gradient workgroups)
 void vg_launch_reduce_partials(const float* part, int nb, int n, float* dw, hipStream_t s);
 static inline int ilog2_exact(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }

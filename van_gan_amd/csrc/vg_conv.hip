@@ -994,7 +994,7 @@ extern "C" int vg_conv3d_thin_np(const vg_conv_desc* d0) {
 
 // did_stats: set when the launched kernel accumulated the IN-backward statistics of d->bstat itself (striped, unfolded)
 static int conv3d_impl(const vg_conv_desc* d, vg_stream_t stream, bool& did_stats) {
-    if (d && d->wlayout) return vg_conv_dma(d, (hipStream_t)stream);          // LDS-DMA family (weights in its block layout): served there or an error
+    if (d && d->wlayout) return vg_conv_dma(d, (hipStream_t)stream, &did_stats);   // LDS-DMA family (weights in its block layout): served there or an error
     if (d && d->out && d->wpacked && d->src0) {           // 1x1x1 with a single channel on one side: HBM-bound VALU kernels
         const int prc = vg_pointwise_conv(d, (hipStream_t)stream);
         if (prc <= 0) return prc;

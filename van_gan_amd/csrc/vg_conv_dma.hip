@@ -50,6 +50,12 @@ struct CdK {
     float* ks_part; unsigned* ks_cnt;
     unsigned m_ow, m_hw, m_hhw;          // fast_div magics: OW; HWb; HHb * HWb
     int dbg;                             // development ablations (VG_CONV_DMA_DBG): 1 no copy waits, 2 no stage barriers, 4 no weight copies after the prologue
+    // BSTAT (data gradients): the statistics pass of the IN backward that consumes this launch's output, in the epilogue -- sum dn and
+    // sum dn * xhat with dn = g * mult * act'(x * scale + shift) at the reflect-folded position of the pre-norm tensor x (ConvOut::bs_* of
+    // the thin-channel specialist; here also the channel-dropout multipliers and the sample aliasing of vg_actnorm_bwd_desc)
+    const char* bs_x0; const char* bs_x1; int bs_c0, bs_sh, bs_act, bs_pad, bs_D, bs_H, bs_W, bs_an0, bs_ash;
+    const float* bs_sc; const float* bs_sf; const float* bs_mu; const float* bs_rs; const float* bs_ml; float* bs_red;
+    unsigned m_bw, m_bh;                 // fast_div magics: BW, BH
 };
 
 __global__ __launch_bounds__(256) void pack_weights_dma_kernel(const float* __restrict__ w, const int* __restrict__ tap_idx, bf16_t* __restrict__ out,
@@ -73,7 +79,7 @@ extern "C" int vg_pack_weights_dma(const float* w, int T, int Cin, int Cout, con
 // the kernel: NW = 32-channel blocks per wave (BN = 64 * NW), MW = 32-voxel sub-tiles per wave (BM = 128 * MW)
 //   acc layout (32x32x16, A = weights, B = activations): lane l holds voxel (l & 31), channels 8*jj + 4*(l >> 5) + r  (acc[4*jj + r])
 // ------------------------------------------------------------------------------------------------------------------
-template <int NW, int MW, int GT>
+template <int NW, int MW, int GT, bool BSTAT = false>
 __global__ __launch_bounds__(512, 2) void conv_dma_kernel(const CdK p) {
     constexpr int BN = 64 * NW, BM = 128 * MW;
     constexpr int PITCH = BN * 4 + 16;                     // bytes of one voxel row of the fp32 epilogue tile (16-byte skew: conflict-free 16-byte stores)
@@ -347,6 +353,61 @@ __global__ __launch_bounds__(512, 2) void conv_dma_kernel(const CdK p) {
                 rb8[e] = p.res ? p.rb[n * p.Cout + co + e] : 0.f;
                 s1[e] = 0.f; s2[e] = 0.f;
             }
+            if constexpr (BSTAT) {
+                // data gradient with the consuming IN backward's statistics (no bias / residual / accumulate on this path: the host checks).
+                // The pre-norm values x of ALL this thread's voxels are requested first (KV loads of 16 bytes in flight: one latency per unit,
+                // not one per voxel), then each voxel is rounded, stored and counted: dn = g * mult * act'(x * scale + shift), xhat = (x - mean) * rstd
+                // at the reflect-folded interior position of the buffer position.
+                constexpr int KV = BM / NVS;
+                const int nx = (p.bs_an0 > 0 && n >= p.bs_an0) ? n - p.bs_ash : n;       // forward tensors' sample (vg_actnorm_bwd_desc::alias_n0)
+                float q_sc[8], q_sf[8], q_rs[8], q_nm[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int i = nx * p.Cout + co + e;
+                    q_sc[e] = p.bs_sc ? p.bs_sc[i] : 1.f; q_sf[e] = p.bs_sc ? p.bs_sf[i] : 0.f;
+                    q_rs[e] = p.bs_rs[i]; q_nm[e] = -p.bs_mu[i] * q_rs[e];
+                }
+                const bool lo = !p.bs_x1 || co < p.bs_c0;                                // group-uniform (bs_c0 is a multiple of 8)
+                const int q_sh = (p.bs_x1 && lo) ? p.bs_sh : 0, q_cs = p.bs_x1 ? (lo ? p.bs_c0 : p.Cout - p.bs_c0) : p.Cout;
+                const bf16_t* q_x = (const bf16_t*)(lo ? p.bs_x0 : p.bs_x1) + (size_t)nx * (p.bs_D >> q_sh) * (p.bs_H >> q_sh) * (p.bs_W >> q_sh) * q_cs + (lo ? co : co - p.bs_c0);
+                const float q_slope = p.bs_act == VG_ACT_RELU ? 0.f : (p.bs_act == VG_ACT_LRELU ? VG_LRELU : 1.f);
+                const bool q_noact = p.bs_act == VG_ACT_NONE;
+                Raw8<bf16_t> xr[KV]; int idxs[KV];
+#pragma unroll
+                for (int k = 0; k < KV; ++k) {
+                    const int idx = vtab[vs + k * NVS];
+                    idxs[k] = idx;
+                    // buffer position -> interior position -> transpose of the reflection pad (-1 -> 1, n -> n - 2); outside voxels read voxel 0
+                    const int r = max(idx, n * (p.BD * p.BH * p.BW)) - n * (p.BD * p.BH * p.BW);
+                    const int t1 = fast_div(r, p.m_bw), bw = r - t1 * p.BW, bd = fast_div(t1, p.m_bh), bh = t1 - bd * p.BH;
+                    auto fold = [&](int q, int nn) { int i = q - p.bs_pad; i = i < 0 ? -i : i; i = i >= nn ? 2 * nn - 2 - i : i; return min(max(i, 0), nn - 1); };
+                    const int fd = fold(bd, p.bs_D) >> q_sh, fh = fold(bh, p.bs_H) >> q_sh, fw = fold(bw, p.bs_W) >> q_sh;
+                    raw_load(xr[k], q_x + ((size_t)(fd * (p.bs_H >> q_sh) + fh) * (p.bs_W >> q_sh) + fw) * q_cs);
+                }
+#pragma unroll
+                for (int k = 0; k < KV; ++k) {
+                    const int idx = idxs[k], v = vs + k * NVS;
+                    if (idx < 0) continue;
+                    const f32x4 x0 = *(const f32x4*)(smem + v * PITCH + cg * 32), x1 = *(const f32x4*)(smem + v * PITCH + cg * 32 + 16);
+                    const float x[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+                    bf16x8 pk;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) pk[e] = (short)f2bf(x[e]);
+                    *(bf16x8*)((bf16_t*)p.out + (size_t)idx * p.Cout + co) = pk;
+                    float xv[8];
+                    raw_unpack(xr[k], xv);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float pre = xv[e] * q_sc[e] + q_sf[e];
+                        const float gv = bf2f((bf16_t)pk[e]) * ((pre > 0.f || q_noact) ? 1.f : q_slope);
+                        s1[e] += gv; s2[e] += gv * (xv[e] * q_rs[e] + q_nm[e]);
+                    }
+                }
+                if (p.bs_ml) {                                                           // the channel-dropout multiplier is a per-channel constant: applied to the sums
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { const float m = p.bs_ml[nx * p.Cout + co + e]; s1[e] *= m; s2[e] *= m; }
+                }
+            } else {
             for (int v = vs; v < BM; v += NVS) {
                 const int idx = vtab[v];
                 if (idx < 0) continue;
@@ -372,37 +433,53 @@ __global__ __launch_bounds__(512, 2) void conv_dma_kernel(const CdK p) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { const float y = bf2f((bf16_t)pk[e]); s1[e] += y; s2[e] += y * y; }
             }
-            if (p.sums) {
+            }
+            float* const sums_dst = BSTAT ? p.bs_red : p.sums;
+            if (sums_dst) {
+                // the workgroup's sums without LDS atomics (NVS threads per channel group on the same 16 words serialise: with the statistics
+                // in a data gradient's epilogue that was as long as a thin unit's K loop): partials [value][thread] over the fp32 tile's
+                // memory, then thread (channel, moment) adds the NVS partials of its channel group in a fixed order
+                constexpr int PR = 512 + 1;                                   // row pitch in floats (bank spread of the column sums)
+                float* part = (float*)smem;
+                __syncthreads();                                             // every thread is done with the tile
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { atomicAdd(&stat[(cg * 8 + e) * 2], s1[e]); atomicAdd(&stat[(cg * 8 + e) * 2 + 1], s2[e]); }
+                for (int e = 0; e < 8; ++e) { part[(2 * e) * PR + tid] = s1[e]; part[(2 * e + 1) * PR + tid] = s2[e]; }
                 __syncthreads();
                 if (tid < BN * 2) {
+                    const int ch = tid >> 1, mom = tid & 1;
+                    const float* src = part + (2 * (ch & 7) + mom) * PR + (ch >> 3);
+                    float a = 0.f;
+                    for (int t = 0; t < NVS; ++t) a += src[t * NCG];
                     const int stripe = blockIdx.x & (VG_STRIPES - 1);
-                    atomicAdd(&p.sums[(((size_t)stripe * p.N + n) * p.Cout + cob * BN + (tid >> 1)) * 2 + (tid & 1)], stat[tid]);
+                    atomicAdd(&sums_dst[(((size_t)stripe * p.N + n) * p.Cout + cob * BN + ch) * 2 + mom], a);
                 }
             }
         }
     }
 }
 
-template <int NW, int MW, int GT>
+template <int NW, int MW, int GT, bool BSTAT>
 static void launch_cd3(const CdK& k, int grid, int lds, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_dma_kernel<NW, MW, GT>, hipFuncAttributeMaxDynamicSharedMemorySize, VG_LDS_LIMIT);
+        (void)hipFuncSetAttribute((const void*)conv_dma_kernel<NW, MW, GT, BSTAT>, hipFuncAttributeMaxDynamicSharedMemorySize, VG_LDS_LIMIT);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_dma_kernel<NW, MW, GT>), dim3(grid), dim3(512), lds, s, k);
+    hipLaunchKernelGGL((conv_dma_kernel<NW, MW, GT, BSTAT>), dim3(grid), dim3(512), lds, s, k);
 }
 // GT (template): the stage body is unrolled for this many taps; classes with fewer taps per stage skip the steps they do not have
-template <int NW, int MW>
-static int launch_cd(const CdK& k, int gtmax, int grid, int lds, hipStream_t s) {
-    if (gtmax == 9) launch_cd3<NW, MW, 9>(k, grid, lds, s);
-    else if (gtmax == 8) launch_cd3<NW, MW, 8>(k, grid, lds, s);
-    else if (gtmax == 3) launch_cd3<NW, MW, 3>(k, grid, lds, s);
-    else if (gtmax == 4) launch_cd3<NW, MW, 4>(k, grid, lds, s);
+template <int NW, int MW, bool BSTAT>
+static int launch_cd2(const CdK& k, int gtmax, int grid, int lds, hipStream_t s) {
+    if (gtmax == 9) launch_cd3<NW, MW, 9, BSTAT>(k, grid, lds, s);
+    else if (gtmax == 8) launch_cd3<NW, MW, 8, BSTAT>(k, grid, lds, s);
+    else if (gtmax == 3) launch_cd3<NW, MW, 3, BSTAT>(k, grid, lds, s);
+    else if (gtmax == 4) launch_cd3<NW, MW, 4, BSTAT>(k, grid, lds, s);
     else return VG_EINVAL;
     return VG_OK;
+}
+template <int NW, int MW>
+static int launch_cd(const CdK& k, int gtmax, int grid, int lds, hipStream_t s) {
+    return k.bs_x0 ? launch_cd2<NW, MW, true>(k, gtmax, grid, lds, s) : launch_cd2<NW, MW, false>(k, gtmax, grid, lds, s);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -528,7 +605,7 @@ extern "C" int64_t vg_conv3d_scratch_bytes(const vg_conv_desc* d) {
 }
 
 // VG_OK: served; 1: not one of this family's shapes (only possible when d->wlayout == 0); < 0: error
-int vg_conv_dma(const vg_conv_desc* d, hipStream_t s) {
+int vg_conv_dma(const vg_conv_desc* d, hipStream_t s, bool* did_stats) {
     CdPlan pl;
     const int BN = cd_plan(d, pl);
     if (!BN) return d->wlayout ? VG_EINVAL : 1;
@@ -585,7 +662,20 @@ int vg_conv_dma(const vg_conv_desc* d, hipStream_t s) {
     k.dbg = vg_tune("CONV_DMA_DBG", 0);
     k.m_ow = magic(d->OW); k.m_hw = magic(pl.HWb); k.m_hhw = magic(pl.HHb * pl.HWb);
     const int grid = 8 * k.upx;                            // one unit per workgroup
-    if (vg_dry("conv_dma<%d,%d>|td%d|gt%d|nwb%d|ks%d|cls%d|walk%d", BN, 256, pl.TD, pl.GT[0], pl.nwb, ks > 1 ? 1 : 0, pl.ncls > 1 ? 1 : 0, U > 256 ? 1 : 0)) return VG_OK;
+    // the statistics of the consuming IN backward in the epilogue (vg_conv3d has checked that b describes exactly this launch's output)
+    k.bs_x0 = nullptr; k.bs_red = nullptr;
+    const vg_actnorm_bwd_desc* b = d->bstat;
+    if (b && vg_tune("CONV_DMA_BSTAT", 1) && b->norm && !b->f32 && !b->x_f32 && b->x && b->mean && b->rstd && b->red && b->C == d->Cout
+        && !d->accumulate && !d->out_sums && !d->res && !d->bias && (!b->x1 || (b->c_x0 > 0 && b->c_x0 < b->C && (b->c_x0 % 8) == 0))
+        && (!b->x1 || !b->x0_shift || !((b->D | b->H | b->W) & 1))) {
+        k.bs_x0 = (const char*)b->x; k.bs_x1 = (const char*)b->x1; k.bs_c0 = b->x1 ? b->c_x0 : b->C; k.bs_sh = (b->x1 && b->x0_shift) ? 1 : 0;
+        k.bs_act = b->act; k.bs_pad = b->g_padded ? 1 : 0; k.bs_D = b->D; k.bs_H = b->H; k.bs_W = b->W;
+        k.bs_an0 = b->alias_n0; k.bs_ash = b->alias_shift;
+        k.bs_sc = b->scale; k.bs_sf = b->shift; k.bs_mu = b->mean; k.bs_rs = b->rstd; k.bs_ml = b->mult; k.bs_red = b->red;
+        k.m_bw = magic(d->BW); k.m_bh = magic(d->BH);
+    }
+    if (vg_dry("conv_dma<%d,%d>|td%d|gt%d|nwb%d|ks%d|cls%d|walk%d|bs%d", BN, 256, pl.TD, pl.GT[0], pl.nwb, ks > 1 ? 1 : 0, pl.ncls > 1 ? 1 : 0, U > 256 ? 1 : 0, k.bs_x0 ? 1 : 0)) return VG_OK;
+    if (k.bs_x0 && did_stats) *did_stats = true;
     MatK m;
     m.src0 = d->src0; m.src1 = d->src1; m.c0 = d->c_src0; m.c1 = d->c_src1; m.shift0 = d->src0_shift ? 1 : 0;
     m.N = d->N; m.D = d->D; m.H = d->H; m.W = d->W; m.Cin = Cin;

@@ -544,13 +544,11 @@ class ResUNet:
         cb2, cb1 = L['bridge.cb2'], L['bridge.cb1']
         cb2.wgrad(b['sb2'], b['b2'].grad)
         dp = ar.alloc((N,) + cb2.buf_dims + (b['b1'].C,), self.dtype)
-        cb2.dgrad(b['b2'].grad, N, dp, accumulate=False)
         d_b1 = ar.alloc(b['b1'].data.shape, self.dtype)
-        self._norm_bwd(ar, dp, True, b['sb2'], b['nb2'], Nn['bridge.cb2'], d_b1, ACT_RELU, accumulate=False)
+        self._dgrad_norm_bwd(ar, cb2, b['b2'].grad, N, dp, b['sb2'], b['nb2'], Nn['bridge.cb2'], d_b1, ACT_RELU, accumulate=False)
         cb1.wgrad(b['sb1'], d_b1)
         dp = ar.alloc((N,) + cb1.buf_dims + (b['inp'].C,), self.dtype)
-        cb1.dgrad(d_b1, N, dp, accumulate=False)
-        self._norm_bwd(ar, dp, True, b['sb1'], b['nb1'], Nn['bridge.cb1'], b['inp'].grad, ACT_RELU, accumulate=not b['inp'].first_write())
+        self._dgrad_norm_bwd(ar, cb1, d_b1, N, dp, b['sb1'], b['nb1'], Nn['bridge.cb1'], b['inp'].grad, ACT_RELU, accumulate=not b['inp'].first_write())
         ar.release(mk, defer=True)
         for e in (4, 3, 2, 1):
             yield
@@ -914,14 +912,15 @@ class PatchGAN:
             lay.wgrad(ctx['srcs'][li], g[:N2])
             a = ctx['acts'][li - 1]
             dp = ar.alloc((N3,) + tuple(lay.buf_dims) + (lay.cin,), self.dtype)
-            lay.dgrad(g, N3, dp, accumulate=False)
             st = ctx['sts'][li - 1]
             nrm = Nn[self.NAMES[li - 1]]
             red = ops.alloc_red(ar, N3, a.C)
             dxa = ar.alloc((N3,) + a.dims + (a.C,), self.dtype)
-            ops.actnorm_bwd(dp, lay.pad == 'reflect', a.data, (N3,) + a.dims, a.C, dxa, scale=st['scale'], shift=st['shift'],
-                            mult=st['mult'], act=ACT_LRELU, norm=True, gamma=nrm.gamma, mean=st['mean'], rstd=st['rstd'], red=red,
-                            accumulate=False, dgamma=nrm.dgamma, dbeta=nrm.dbeta, alias_n0=N2, alias_shift=B, pgrad_n=N2)
+            dsc = ops.actnorm_desc(dp, lay.pad == 'reflect', a.data, (N3,) + a.dims, a.C, dxa, scale=st['scale'], shift=st['shift'],
+                                   mult=st['mult'], act=ACT_LRELU, norm=True, gamma=nrm.gamma, mean=st['mean'], rstd=st['rstd'], red=red,
+                                   accumulate=False, dgamma=nrm.dgamma, dbeta=nrm.dbeta, alias_n0=N2, alias_shift=B, pgrad_n=N2)
+            # (the statistics pass rides in the data gradient's epilogue where the LDS-DMA family serves the layer)
+            ops.actnorm_run(dsc, stats_done=lay.dgrad(g, N3, dp, accumulate=False, bstat=dsc))
             g = dxa
         lay = L['conv0']
         lay.wgrad(ctx['srcs'][0], g[:N2])

@@ -286,6 +286,11 @@ FORK_SHORT = os.environ.get('VG_FORK_SHORT', '1') != '0'   # forward shortcut br
 FUSE_CONCAT_NORM = os.environ.get('VG_FUSE_CONCAT_NORM', '1') != '0'   # ... and the conv branch's IN backward apply in the same launch
 FUSE_CONCAT = os.environ.get('VG_FUSE_CONCAT', '1') != '0'       # decoder shortcut data gradient + concat backward in one launch (ConvLayer.dgrad_concat)
 BSTAT = os.environ.get('VG_BSTAT', '1') != '0'       # IN-backward statistics with the data-gradient launch (ConvLayer.dgrad(bstat=...))
+# ... also in the epilogue of the LDS-DMA family for its strided / dropout-carrying / sample-aliased uses (the encoder's stride-2 layers, the
+# discriminators).  Off: measured, the epilogue's gathered loads of the pre-norm tensor cost the thin units of those launches more than the
+# statistics pass they replace (D.down0: +65 us against 37); the stride-1 wide layers of the generators carry them either way (neutral in
+# time, 18 launches fewer per step)
+BSTAT_DMA = os.environ.get('VG_BSTAT_DMA', '0') != '0'
 SIDE: Optional[bool] = None                   # truthy: weight-gradient side streams enabled (one per issuing stream)
 _SIDE_OF = {}                                  # (device index, issuing stream handle) -> its side stream.  The default stream
 #                                                has handle 0 on every device, hence the device index in the key; entries
@@ -949,14 +954,17 @@ class ConvLayer:
         returned -- the caller then runs actnorm_run(bstat, stats_done=True)."""
         # only where the 16-channel specialist (which carries the statistics in its epilogue) is the expected kernel: elsewhere the
         # separate statistics launch stays where it was
-        use_bs = bstat is not None and BSTAT and not accumulate and not self.f32 and out.dtype == torch.bfloat16 and bstat.norm \
-            and len(self.d_classes) == 1 and self.stride == 1 and self.k == 3 and self.pad == 'reflect' \
-            and self.d_classes[0]['ck'] == 16 and self.cin % 16 == 0 and self.cout % 16 == 0 and not bstat.mult
+        # ... or the LDS-DMA family, whose epilogue goes through LDS (any class structure, channel-dropout multipliers, sample aliasing)
+        use_bs = bstat is not None and BSTAT and not accumulate and not self.f32 and out.dtype in (torch.bfloat16, torch.float16) and bstat.norm \
+            and ((len(self.d_classes) == 1 and self.stride == 1 and self.k == 3 and self.pad == 'reflect'
+                  and self.d_classes[0]['ck'] == 16 and self.cin % 16 == 0 and self.cout % 16 == 0 and not bstat.mult)
+                 or (bool(self.d_bn) and BSTAT_DMA))
         if DRY is not None:
             DRY.tag = ('dgrad', self.name)
             DRY.recipe = dict(kind='dgrad', layer=self.ctor, N=N, accumulate=bool(accumulate), dy_f32=dy.dtype == torch.float32,
                               out_f32=out.dtype == torch.float32, bstat=None if not use_bs else dict(
-                                  cat=bool(bstat.x1), c_x0=bstat.c_x0, act=bstat.act, pad=bool(bstat.g_padded)))
+                                  cat=bool(bstat.x1), c_x0=bstat.c_x0, act=bstat.act, pad=bool(bstat.g_padded), mult=bool(bstat.mult),
+                                  alias_n0=bstat.alias_n0, alias_shift=bstat.alias_shift))
         if REC is not None and use_bs:
             REC.keep.append(bstat)               # its address is baked into the recorded descriptor
         if self.d_fused:
