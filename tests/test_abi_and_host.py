@@ -160,3 +160,16 @@ def test_dma_layers_plan_at_any_batch():
     assert need[1] > need[0] > 16384
     d.wlayout = 0
     assert lib.vg_conv3d_scratch_bytes(C.byref(d)) == 0
+
+
+def test_tuning_registry_holds_every_key():
+    """vg_set_tuning / vg_tune share one table of switches keyed by name (the VG_* environment variables without the prefix).  In round 5
+    the library passed 64 distinct keys and the table was full: vg_set_tuning of a key first seen late in a process returned VG_EINVAL
+    (unchecked by the callers) and the switch kept its default -- a test that forces a kernel family then silently tests the other one.
+    The table holds 256 now; a rejected key is an error the caller can see."""
+    from van_gan_amd import _lib
+    for i in range(150):
+        assert _lib.lib.vg_set_tuning(b'TEST_KEY_%03d' % i, i, 0) == 0
+    for i in range(150):
+        assert _lib.lib.vg_set_tuning(b'TEST_KEY_%03d' % i, 0, 1) == 0          # reset: back to environment / default
+    assert _lib.lib.vg_set_tuning(b'X' * 40, 1, 0) < 0                           # over-long key: refused, not truncated

@@ -798,3 +798,42 @@ def test_strided_single_channel_data_gradient_in_cell_form(dims, N):
         got = dx.double().cpu()
         tol = 2.5e-2 * ref.abs() + 8e-3 * ref.abs().max()
         assert ((got - ref).abs() <= tol).all(), 'max err %.3e of %.3e' % (float((got - ref).abs().max()), float(ref.abs().max()))
+
+
+@pytest.mark.parametrize('cin,cat', [(16, None), (48, (32, 16))])
+def test_thin_layer_weight_gradient_families_agree_and_are_deterministic(cin, cat):
+    """wgrad_thin_kernel (vg_conv_thin.hip: the waves split the voxels and hold the whole 27 x 16 x 16 slab; operand staged by the forward
+    kernel's routine; slabs added in a fixed two-level order) against wgrad_dma_kernel<.,1,DIRECT> (VG_WGRAD_THIN=0) on a 64^3 layer
+    with the decoder's virtual upsample + concat source, IN affine + ReLU on read: the same rounded operands, fp32 sums in a different
+    order (rel 1e-4); two launches of the new kernel give bitwise the same gradient (no float atomics between workgroups).  Parity with
+    the float64 oracle at the true layer shapes: tests/test_gpu_layers.py (every variant of the BASELINE configurations)."""
+    from van_gan_amd import ops, _lib
+    from van_gan_amd.ops import Src
+    dev = _dev()
+    dims, N, cout = (64, 64, 64), 2, 16
+    st, lay = make_layer(3, cin, cout, 1, 'reflect', dims, seed=9)
+    g = torch.Generator().manual_seed(4)
+    scale, shift = (torch.rand(N, cin, generator=g) + 0.5).to(dev), (torch.randn(N, cin, generator=g) * 0.2).to(dev)
+    if cat:
+        low = torch.randn(N, *[d // 2 for d in dims], cat[0], generator=g).to(torch.bfloat16).to(dev)
+        skip = torch.randn(N, *dims, cat[1], generator=g).to(torch.bfloat16).to(dev)
+        src = Src(low, (N,) + dims, cat[0], skip, cat[1], shift0=1, scale=scale, shift=shift, act=ops.ACT_RELU)
+    else:
+        src = Src(torch.randn(N, *dims, cin, generator=g).to(torch.bfloat16).to(dev), (N,) + dims, cin, scale=scale, shift=shift, act=ops.ACT_RELU)
+    dy = torch.randn(N, *dims, cout, generator=g).to(torch.bfloat16).to(dev)
+    with ops.DryRun() as dry:
+        lay.wgrad(src, dy)
+    assert dry.records[0][2].startswith('wgrad_thin<m1>'), dry.records
+    res = []
+    for mode in (1, 1, 0):
+        _lib.lib.vg_set_tuning(b'WGRAD_THIN', mode, 0)
+        try:
+            st.g.zero_()
+            lay.wgrad(src, dy)
+            torch.cuda.synchronize()
+            res.append((st.grad('c.w').clone(), st.grad('c.b').clone()))
+        finally:
+            _lib.lib.vg_set_tuning(b'WGRAD_THIN', 0, 1)
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert float(res[0][0].abs().max()) > 0
+    assert rel_l2(res[0][0], res[2][0]) < 1e-4 and rel_l2(res[0][1], res[2][1]) < 1e-4
