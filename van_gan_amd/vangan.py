@@ -26,7 +26,7 @@ RESULT_KEYS = ['total_IS_loss', 'total_SI_loss', 'D_I_loss', 'D_S_loss', 'gen_IS
 _BFIRST = int(os.environ.get('VG_BFIRST', '5'))       # re-swept with the paired sweeps: 0: 22.27, 4: 21.98, 5: 21.83 ms
 _NOJOIN = os.environ.get('VG_NOJOIN', '1') != '0'
 _LAZY_AR = os.environ.get('VG_LAZY_AR', '1') != '0'
-_INLINE = int(os.environ.get('VG_WGRAD_INLINE', '2'))      # encoder blocks <= this and the stem; round 3 (DMA weight gradients): off 24.96, 1: 24.92, 2: 24.74, 3: 24.59, 4: 24.62 ms; round 4, final kernels, alternating: 2: 18.85 / 18.88 / 18.87, 3: 18.99 / 18.91 / 19.01
+_INLINE = int(os.environ.get('VG_WGRAD_INLINE', '0'))      # encoder blocks <= this and the stem; round 3 (DMA weight gradients): off 24.96, 1: 24.92, 2: 24.74, 3: 24.59, 4: 24.62 ms; round 4, final kernels, alternating: 2: 18.85 / 18.88 / 18.87, 3: 18.99 / 18.91 / 19.01; round 5 (wgrad_thin: the side streams are no longer behind at the end of a sweep), same box: -1: 17.78 / 17.79 / 17.94, 0: 17.84 / 17.89 / 17.89, 1: 17.82 / 17.92 / 17.96, 2: 17.93 / 17.97 / 18.08, 3: 17.95 / 18.00, 4: 18.07 / 18.08
 _PAIR_BWD = os.environ.get('VG_PAIR_BWD', '1') != '0'       # one 2B-sample backward sweep per generator (both applications) instead of two
 _AR_SPLIT = os.environ.get('VG_AR_SPLIT', '1') != '0'       # world > 1: a generator's finished gradient suffix is all-reduced while its sweep still runs
 _SKEL_BWD_A = int(os.environ.get('VG_SKEL_BWD_A', '0'))      # clDice backward on lane A: 1 before its discriminator sweeps, 2 right before its generator sweep
