@@ -278,6 +278,10 @@ typedef struct vg_actnorm_bwd_desc_s {
 } vg_actnorm_bwd_desc;
 int vg_actnorm_bwd_stats(const vg_actnorm_bwd_desc* d, vg_stream_t stream);
 int vg_actnorm_bwd_apply(const vg_actnorm_bwd_desc* d, vg_stream_t stream);
+/* the apply passes of two independent norms of one batch (same N; statistics of both complete) in one launch -- a residual block's shortcut
+ * norm and the norm in front of its second convolution (resunet_model.py:103-143 under the tape); two launches where the pair does not share
+ * a kernel instance */
+int vg_actnorm_bwd_apply2(const vg_actnorm_bwd_desc* d1, const vg_actnorm_bwd_desc* d2, vg_stream_t stream);
 /* both passes in one call (statistics only when d->norm) */
 int vg_actnorm_bwd(const vg_actnorm_bwd_desc* d, vg_stream_t stream);
 /* The kernel gradient of a 1x1x1 convolution of a SINGLE-channel input x followed by InstanceNorm (no activation), WITHOUT the gradient

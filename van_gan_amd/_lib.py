@@ -90,6 +90,7 @@ _SIGS = {
                         c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], c_int),
     'vg_actnorm_bwd_stats': ([C.POINTER(ActNormBwdDesc), c_void_p], c_int),
     'vg_actnorm_bwd_apply': ([C.POINTER(ActNormBwdDesc), c_void_p], c_int),
+    'vg_actnorm_bwd_apply2': ([C.POINTER(ActNormBwdDesc), C.POINTER(ActNormBwdDesc), c_void_p], c_int),
     'vg_actnorm_bwd': ([C.POINTER(ActNormBwdDesc), c_void_p], c_int),
     'vg_in_scale_invariant_wgrad': ([c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, C.c_float, c_int, c_void_p, c_void_p, c_void_p,
                                     c_void_p], c_int),

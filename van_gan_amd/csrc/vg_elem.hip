@@ -257,8 +257,9 @@ __global__ __launch_bounds__(256) void actnorm_stats_kernel(const ANB p) {
     for (int i = tid; i < p.C * 2; i += 256) atomicAdd(&dst[i], red[i]);
 }
 
+// bx / gx: this workgroup's index and the number of workgroups of ITS job (a launch may carry two jobs: actnorm_apply2_kernel)
 template <typename T, int VEC>
-__global__ __launch_bounds__(256) void actnorm_apply_kernel(const ANB p) {
+__device__ __forceinline__ void actnorm_apply_body(const ANB& p, const int bx, const int gx) {
     const int n = blockIdx.y;
     const int tid = threadIdx.x;
     const int nthr = p.gpc * p.vpb;
@@ -288,7 +289,7 @@ __global__ __launch_bounds__(256) void actnorm_apply_kernel(const ANB p) {
 #pragma unroll
             for (int j = 0; j < 2 * VEC; ++j) r[j] += q[j];
         }
-        if (p.dgamma && blockIdx.x == 0 && vl == 0 && (p.pgrad_n <= 0 || n < p.pgrad_n)) {          // sum(dn) is d/d beta, sum(dn * xhat) is d/d gamma (summed over samples)
+        if (p.dgamma && bx == 0 && vl == 0 && (p.pgrad_n <= 0 || n < p.pgrad_n)) {          // sum(dn) is d/d beta, sum(dn * xhat) is d/d gamma (summed over samples)
 #pragma unroll
             for (int j = 0; j < VEC; ++j) { atomicAdd(&p.dbeta[c + j], r[2 * j]); atomicAdd(&p.dgamma[c + j], r[2 * j + 1]); }
         }
@@ -298,7 +299,7 @@ __global__ __launch_bounds__(256) void actnorm_apply_kernel(const ANB p) {
     }
     ChanK<VEC> ck;
     load_chank<VEC>(p, n, c, ck);
-    anb_walk<T, VEC, 4>(p, n, c, vl, ck, [&](int v, const float* dn, const float* xh) {
+    anb_walk_from<T, VEC, 4>(p, n, c, bx * p.vpb + vl, gx * p.vpb, ck, [&](int v, const float* dn, const float* xh) {
         float o[VEC];
 #pragma unroll
         for (int j = 0; j < VEC; ++j) o[j] = k0[j] * dn[j] - k1[j] - k2[j] * xh[j];
@@ -320,6 +321,15 @@ __global__ __launch_bounds__(256) void actnorm_apply_kernel(const ANB p) {
             q[0] = f2bf(p.accumulate ? bf2f(q[0]) + o[0] : o[0]);
         }
     });
+}
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void actnorm_apply_kernel(const ANB p) { actnorm_apply_body<T, VEC>(p, (int)blockIdx.x, (int)gridDim.x); }
+// two independent apply passes of one batch in ONE launch (a residual block's shortcut norm and the norm in front of its second convolution:
+// their statistics are complete at the same point of the backward sweep and nothing orders their outputs): workgroups [0, g1) serve p1
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void actnorm_apply2_kernel(const ANB p1, const ANB p2, const int g1) {
+    if ((int)blockIdx.x < g1) actnorm_apply_body<T, VEC>(p1, (int)blockIdx.x, g1);
+    else actnorm_apply_body<T, VEC>(p2, (int)blockIdx.x - g1, (int)gridDim.x - g1);
 }
 
 static int fill_anb(const vg_actnorm_bwd_desc* d, ANB& p, bool apply) {
@@ -387,6 +397,23 @@ extern "C" int vg_actnorm_bwd_apply(const vg_actnorm_bwd_desc* d, vg_stream_t st
         if (p.C == 1) hipLaunchKernelGGL((actnorm_apply_kernel<bf16_t, 1>), anb_grid(p), dim3(256), 0, (hipStream_t)stream, p);
         else hipLaunchKernelGGL((actnorm_apply_kernel<bf16_t, 8>), anb_grid(p), dim3(256), 0, (hipStream_t)stream, p);
     }
+    return vg_check_launch();
+}
+
+extern "C" int vg_actnorm_bwd_apply2(const vg_actnorm_bwd_desc* d1, const vg_actnorm_bwd_desc* d2, vg_stream_t stream) {
+    vg_begin();
+    ANB p1, p2;
+    int rc = fill_anb(d1, p1, true); if (rc != VG_OK) return rc;
+    rc = fill_anb(d2, p2, true); if (rc != VG_OK) return rc;
+    // one launch serves both only when they share the kernel instance and the sample axis; else two launches, in order
+    if (!vg_tune("ANB_APPLY2", 1) || d1->N != d2->N || (d1->f32 != 0) != (d2->f32 != 0) || d1->C == 1 || d2->C == 1) {
+        rc = vg_actnorm_bwd_apply(d1, stream);
+        return rc != VG_OK ? rc : vg_actnorm_bwd_apply(d2, stream);
+    }
+    const dim3 g1 = anb_grid(p1), g2 = anb_grid(p2);
+    const dim3 grid(g1.x + g2.x, g1.y);
+    if (d1->f32) hipLaunchKernelGGL((actnorm_apply2_kernel<float, 8>), grid, dim3(256), 0, (hipStream_t)stream, p1, p2, (int)g1.x);
+    else hipLaunchKernelGGL((actnorm_apply2_kernel<bf16_t, 8>), grid, dim3(256), 0, (hipStream_t)stream, p1, p2, (int)g1.x);
     return vg_check_launch();
 }
 

@@ -465,15 +465,21 @@ class ResUNet:
         d_out = out.grad
         cb1, cb2, short = L[name + '.cb1'], L[name + '.cb2'], L[name + '.short']
         mk = ar.mark()
-        # shortcut InstanceNorm (no activation): d_sc
+        # shortcut InstanceNorm (no activation): d_sc.  Its statistics pass goes first (it needs only d_out); its apply pass shares a
+        # launch with the apply pass of the norm in front of conv2 (ops.actnorm_apply2: nothing orders the two outputs, and both sets
+        # of statistics are complete once conv2's data gradient has run) -- one launch fewer on the lane's chain per block
         d_sc = ar.alloc(sc.data.shape, self.dtype)
         ssc = Src(sc.data, (N,) + sc.dims, sc.C)
-        self._norm_bwd(ar, d_out, False, ssc, c['ns'], Nn[name + '.short'], d_sc, ACT_NONE, accumulate=False)
+        dsc1 = self._norm_desc(ar, d_out, False, ssc, c['ns'], Nn[name + '.short'], d_sc, ACT_NONE, accumulate=False)
+        ops.actnorm_stats(dsc1)
         # conv2: weights + data gradient on the padded grid, folded through relu(IN(r))
         cb2.wgrad(c['s2'], d_out, inline)
         dp = ar.alloc((N,) + cb2.buf_dims + (r.C,), self.dtype)
         d_r = ar.alloc(r.data.shape, self.dtype)
-        self._dgrad_norm_bwd(ar, cb2, d_out, N, dp, c['s2'], c['n2'], Nn[name + '.cb2'], d_r, ACT_RELU, accumulate=False)
+        dsc2 = self._norm_desc(ar, dp, True, c['s2'], c['n2'], Nn[name + '.cb2'], d_r, ACT_RELU, accumulate=False)
+        if not cb2.dgrad(d_out, N, dp, accumulate=False, bstat=dsc2):
+            ops.actnorm_stats(dsc2)
+        ops.actnorm_apply2(dsc1, dsc2)
         # conv1 and shortcut conv read the block input (possibly the virtual concat)
         s1, raw = c['s1'], c['src_raw']
         cb1.wgrad(s1, d_r, inline)

@@ -1280,6 +1280,11 @@ def actnorm_run(d: ActNormBwdDesc, stats_done: bool = False):
         check(lib.vg_actnorm_bwd(C.byref(d), stream()), 'vg_actnorm_bwd')       # statistics (when norm) + apply behind one C call
 
 
+def actnorm_apply2(d1: ActNormBwdDesc, d2: ActNormBwdDesc):
+    """The apply passes of two independent norms (statistics of both done) in one launch (vg_actnorm_bwd_apply2)."""
+    check(lib.vg_actnorm_bwd_apply2(C.byref(d1), C.byref(d2), stream()), 'vg_actnorm_bwd_apply2')
+
+
 def actnorm_bwd(g, g_padded, x, dims, C_, dx, **kw):
     """stats + apply (+ parameter gradients) of the (InstanceNorm -> act -> dropout) backward (see actnorm_desc)."""
     actnorm_run(actnorm_desc(g, g_padded, x, dims, C_, dx, **kw))
