@@ -51,7 +51,7 @@ def variant_of(kernel_name: str):
         return 'pw_gemm_split<%s,%s>' % (args[0], args[1])
     if k == 'pw_gemm' and len(args) in (5, 6):
         return 'pw_gemm<%s,%s,g%s,a%s>' % (args[0], args[1], b(args[2]), b(args[3]))
-    if k == 'conv_dma' and len(args) == 3:                 # <NW, MW, GT>: the variant string names the tile (BN = 64 NW, BM = 128 MW); the GT instances share a row
+    if k == 'conv_dma' and len(args) in (3, 4):               # (4th: BSTAT -- the statistics epilogue; same row)                 # <NW, MW, GT>: the variant string names the tile (BN = 64 NW, BM = 128 MW); the GT instances share a row
         return 'conv_dma<%d,%d>' % (64 * int(args[0]), 128 * int(args[1]))
     if k == 'conv32' and len(args) == 4:
         return 'conv32<%s,%s,n%s,cp%s>' % (args[0], args[1], b(args[2]), b(args[3]))

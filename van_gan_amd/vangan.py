@@ -26,7 +26,8 @@ RESULT_KEYS = ['total_IS_loss', 'total_SI_loss', 'D_I_loss', 'D_S_loss', 'gen_IS
 _BFIRST = int(os.environ.get('VG_BFIRST', '5'))       # re-swept with the paired sweeps: 0: 22.27, 4: 21.98, 5: 21.83 ms
 _NOJOIN = os.environ.get('VG_NOJOIN', '1') != '0'
 _LAZY_AR = os.environ.get('VG_LAZY_AR', '1') != '0'
-_INLINE = int(os.environ.get('VG_WGRAD_INLINE', '0'))      # encoder blocks <= this and the stem; round 3 (DMA weight gradients): off 24.96, 1: 24.92, 2: 24.74, 3: 24.59, 4: 24.62 ms; round 4, final kernels, alternating: 2: 18.85 / 18.88 / 18.87, 3: 18.99 / 18.91 / 19.01; round 5 (wgrad_thin: the side streams are no longer behind at the end of a sweep), same box: -1: 17.78 / 17.79 / 17.94, 0: 17.84 / 17.89 / 17.89, 1: 17.82 / 17.92 / 17.96, 2: 17.93 / 17.97 / 18.08, 3: 17.95 / 18.00, 4: 18.07 / 18.08
+_INLINE_ENV = os.environ.get('VG_WGRAD_INLINE')
+_INLINE = int(_INLINE_ENV) if _INLINE_ENV is not None else 0      # encoder blocks <= this and the stem; round 3 (DMA weight gradients): off 24.96, 1: 24.92, 2: 24.74, 3: 24.59, 4: 24.62 ms; round 4, final kernels, alternating: 2: 18.85 / 18.88 / 18.87, 3: 18.99 / 18.91 / 19.01; round 5 (wgrad_thin: the side streams are no longer behind at the end of a sweep), same box: -1: 17.78 / 17.79 / 17.94, 0: 17.84 / 17.89 / 17.89, 1: 17.82 / 17.92 / 17.96, 2: 17.93 / 17.97 / 18.08, 3: 17.95 / 18.00, 4: 18.07 / 18.08; the data-parallel schedule (all-reduce of a bucket behind the side stream's weight gradients) wants 1: 18.08 / 18.08 against 18.21 / 18.26 for 0 and 18.09 / 18.11 for 2 -- VanGan.__init__ picks 1 when it synchronises gradients
 _PAIR_BWD = os.environ.get('VG_PAIR_BWD', '1') != '0'       # one 2B-sample backward sweep per generator (both applications) instead of two
 _AR_SPLIT = os.environ.get('VG_AR_SPLIT', '1') != '0'       # world > 1: a generator's finished gradient suffix is all-reduced while its sweep still runs
 _SKEL_BWD_A = int(os.environ.get('VG_SKEL_BWD_A', '0'))      # clDice backward on lane A: 1 before its discriminator sweeps, 2 right before its generator sweep
@@ -211,6 +212,7 @@ class VanGan:
         self.arena.lazy_ok = self._lane_b is not None
         self.sync = GradSync({k: s.g for k, s in self.stores.items()}, self.pg, {k: s.w for k, s in self.stores.items()}, stream=comm)
         self.ddp = self.sync.active
+        self._inline = _INLINE if (_INLINE_ENV is not None or not self.ddp) else 1      # (see _INLINE)
         self._tl = [] if os.environ.get('VG_TIMELINE') == '1' else None
         self._side_ev = {}
         # world > 1: the step does not end with a join of the optimizer stream -- the last buckets' all-reduce + Adam + repack run
@@ -598,7 +600,7 @@ class VanGan:
             def a_cyc():
                 if ev_bfwd is not None:
                     ops.wait_event(main, ev_bfwd)                                          # c3 and g_cS are lane B's
-                self.gen_IS.backward(ar, c3, g_cS, inline_from=_INLINE); ar.release(mk, defer=True)    # cycle application
+                self.gen_IS.backward(ar, c3, g_cS, inline_from=self._inline); ar.release(mk, defer=True)    # cycle application
                 self._mark('A G cyc bwd')
                 self._start_allreduce(['gen_IS'], lazy=apply)
                 if apply:
@@ -606,7 +608,7 @@ class VanGan:
 
             def b_cyc():
                 with laneB():
-                    self.gen_SI.backward(arB, c4, g_cI, inline_from=_INLINE); arB.release(mkb, defer=True)
+                    self.gen_SI.backward(arB, c4, g_cI, inline_from=self._inline); arB.release(mkb, defer=True)
                     self._mark('B G cyc bwd')
                     self._start_allreduce(['gen_SI'], lazy=apply)
                     if apply:
@@ -633,8 +635,8 @@ class VanGan:
                 split = self.ddp and apply and _AR_SPLIT
                 def early(name, gen):
                     return (lambda: self._start_allreduce([name], lazy=apply, lo=gen.grad_suffix_offset())) if split else None
-                order = ((laneB, self.gen_SI.backward_iter(arB, ccB, gI2, inline_from=_INLINE, on_suffix_done=early('gen_SI', self.gen_SI))),
-                         (contextlib.nullcontext, self.gen_IS.backward_iter(ar, ccA, gS2, inline_from=_INLINE, on_suffix_done=early('gen_IS', self.gen_IS))))
+                order = ((laneB, self.gen_SI.backward_iter(arB, ccB, gI2, inline_from=self._inline, on_suffix_done=early('gen_SI', self.gen_SI))),
+                         (contextlib.nullcontext, self.gen_IS.backward_iter(ar, ccA, gS2, inline_from=self._inline, on_suffix_done=early('gen_IS', self.gen_IS))))
                 interleave(*(order if (_BFIRST >> 2) & 1 else order[::-1]), on=_INTERLEAVE)
                 hiA = self.gen_IS.grad_suffix_offset() if split else None
                 hiB = self.gen_SI.grad_suffix_offset() if split else None
