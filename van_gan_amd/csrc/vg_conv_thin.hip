@@ -283,6 +283,20 @@ __global__ __launch_bounds__(256, VG_THIN_WPE) void conv_thin_kernel(const Gathe
         for (int q = 0; q < NP; ++q)
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[q][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // BSTAT (one panel): the pre-norm values of this lane's 8 output rows are requested HERE, ahead of the tile's staging and MFMA loop,
+        // and consumed in the epilogue -- issued there (round 3) every tile waited a full HBM round trip for them with nothing left to run
+        bf16x4 bxp[(BSTAT && NP == 1) ? 8 : 1];
+        if constexpr (BSTAT && NP == 1) {
+            auto fold = [&](int qq, int nn) { int i = qq - p.bs_pad; i = i < 0 ? -i : i; i = i >= nn ? 2 * nn - 2 - i : i; return min(max(i, 0), nn - 1); };
+            const int XH = p.bs_H >> b_sh[0], XW = p.bs_W >> b_sh[0];
+            const int id = fold(od0 + wave + p.ood, p.bs_D) >> b_sh[0], iw = fold(ow0 + li + p.oow, p.bs_W) >> b_sh[0];
+            const T* xcol = b_x[0] + ((size_t)id * XH * XW + iw) * b_cs[0];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int ih = fold(oh0 + j + p.ooh, p.bs_H) >> b_sh[0];
+                bxp[j] = *(const __attribute__((address_space(1))) bf16x4*)(uintptr_t)(xcol + (size_t)ih * XW * b_cs[0]);
+            }
+        }
         for (int chunk = 0; chunk < nchunks; ++chunk) {
             if (it | chunk) lds_only_barrier();                            // previous readers of the halo image / weight panel are done
             if (nchunks > 1) { stage_scale_shift(g, scs, n, chunk, tid); if (it | chunk) load_weights(chunk); lds_only_barrier(); }
@@ -397,8 +411,11 @@ __global__ __launch_bounds__(256, VG_THIN_WPE) void conv_thin_kernel(const Gathe
                 const T* xcol = b_x[q] + ((size_t)id * XH * XW + iw) * b_cs[q];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const int ih = fold(oh0 + j + p.ooh, p.bs_H) >> b_sh[q];
-                    bx[j] = *(const __attribute__((address_space(1))) bf16x4*)(uintptr_t)(xcol + (size_t)ih * XW * b_cs[q]);
+                    if constexpr (NP == 1) bx[j] = bxp[j];
+                    else {
+                        const int ih = fold(oh0 + j + p.ooh, p.bs_H) >> b_sh[q];
+                        bx[j] = *(const __attribute__((address_space(1))) bf16x4*)(uintptr_t)(xcol + (size_t)ih * XW * b_cs[q]);
+                    }
                 }
             }
 #pragma unroll
