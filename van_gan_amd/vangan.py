@@ -256,23 +256,32 @@ class VanGan:
             return None, None
         noise, drop = {}, {}
         if self.layer_noise > 0:
-            for k, shp in disc.noise_shapes(N).items():
-                t = ar.alloc(shp, torch.bfloat16)
-                if self._cap is not None:       # under graph capture: counter base and standard deviation come from the device block
-                    ops.randn_bf16_dev(t, self._cap.std_ptr, self.noise_key, self._cap.off_ptr, self.rng_offset - self._cap.base)
-                else:
-                    ops.randn_bf16(t, self.layer_noise, self.noise_key, self.rng_offset)
-                self.rng_offset += (t.numel() + 3) // 4
-                noise[k] = t
+            # the five noise tensors of an application are views of ONE buffer filled by ONE launch (they share sigma; five launches of
+            # ~15 us sat on the lane's chain in front of every discriminator application); sub-tensors start on 16-byte boundaries
+            shapes = disc.noise_shapes(N)
+            sizes = {k: int(math.prod(shp)) for k, shp in shapes.items()}
+            flat = ar.alloc((sum((n + 7) // 8 * 8 for n in sizes.values()),), torch.bfloat16)
+            if self._cap is not None:       # under graph capture: counter base and standard deviation come from the device block
+                ops.randn_bf16_dev(flat, self._cap.std_ptr, self.noise_key, self._cap.off_ptr, self.rng_offset - self._cap.base)
+            else:
+                ops.randn_bf16(flat, self.layer_noise, self.noise_key, self.rng_offset)
+            self.rng_offset += (flat.numel() + 3) // 4
+            o = 0
+            for k, shp in shapes.items():
+                noise[k] = flat[o:o + sizes[k]].view(shp)
+                o += (sizes[k] + 7) // 8 * 8
         if self.dropout_rate > 0:
-            for k, c in (('down0', 128), ('down1', 256), ('down2', 512)):
-                t = ar.alloc((N, c), torch.float32)
-                if self._cap is not None:
-                    ops.dropout_mask_dev(t, self.dropout_rate, self.drop_key, self._cap.off_ptr, self.rng_offset - self._cap.base)
-                else:
-                    ops.dropout_mask(t, self.dropout_rate, self.drop_key, self.rng_offset)
-                self.rng_offset += t.numel()
-                drop[k] = t
+            chans = (('down0', 128), ('down1', 256), ('down2', 512))
+            dflat = ar.alloc((N * sum(c for _, c in chans),), torch.float32)          # likewise: one launch for the three masks
+            if self._cap is not None:
+                ops.dropout_mask_dev(dflat, self.dropout_rate, self.drop_key, self._cap.off_ptr, self.rng_offset - self._cap.base)
+            else:
+                ops.dropout_mask(dflat, self.dropout_rate, self.drop_key, self.rng_offset)
+            self.rng_offset += dflat.numel()
+            o = 0
+            for k, c in chans:
+                drop[k] = dflat[o:o + N * c].view(N, c)
+                o += N * c
             if self.wasserstein:                 # Dropout(0.2) in front of the Dense head: elementwise over the flattened patch logits
                 t = ar.alloc((N, disc.n_patch), torch.float32)
                 if self._cap is not None:
