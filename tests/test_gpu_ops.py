@@ -800,17 +800,18 @@ def test_strided_single_channel_data_gradient_in_cell_form(dims, N):
         assert ((got - ref).abs() <= tol).all(), 'max err %.3e of %.3e' % (float((got - ref).abs().max()), float(ref.abs().max()))
 
 
-@pytest.mark.parametrize('cin,cat', [(16, None), (48, (32, 16))])
-def test_thin_layer_weight_gradient_families_agree_and_are_deterministic(cin, cat):
+@pytest.mark.parametrize('cin,cat,dims', [(16, None, (64, 64, 64)), (48, (32, 16), (64, 64, 64)), (16, None, (42, 70, 40)), (48, (32, 16), (34, 66, 40))])
+def test_thin_layer_weight_gradient_families_agree_and_are_deterministic(cin, cat, dims):
     """wgrad_thin_kernel (vg_conv_thin.hip: the waves split the voxels and hold the whole 27 x 16 x 16 slab; operand staged by the forward
     kernel's routine; slabs added in a fixed two-level order) against wgrad_dma_kernel<.,1,DIRECT> (VG_WGRAD_THIN=0) on a 64^3 layer
     with the decoder's virtual upsample + concat source, IN affine + ReLU on read: the same rounded operands, fp32 sums in a different
-    order (rel 1e-4); two launches of the new kernel give bitwise the same gradient (no float atomics between workgroups).  Parity with
-    the float64 oracle at the true layer shapes: tests/test_gpu_layers.py (every variant of the BASELINE configurations)."""
+    order (rel 1e-4); two launches of the new kernel give bitwise the same gradient (no float atomics between workgroups); grids that
+    are no multiple of the 16 x 8 x 4 tile in any axis (masked dY, clamped staging).  Parity with the float64 oracle at the true layer
+    shapes: tests/test_gpu_layers.py (every variant of the BASELINE configurations)."""
     from van_gan_amd import ops, _lib
     from van_gan_amd.ops import Src
     dev = _dev()
-    dims, N, cout = (64, 64, 64), 2, 16
+    N, cout = 2, 16
     st, lay = make_layer(3, cin, cout, 1, 'reflect', dims, seed=9)
     g = torch.Generator().manual_seed(4)
     scale, shift = (torch.rand(N, cin, generator=g) + 0.5).to(dev), (torch.randn(N, cin, generator=g) * 0.2).to(dev)
