@@ -33,6 +33,7 @@ _AR_SPLIT = os.environ.get('VG_AR_SPLIT', '1') != '0'       # world > 1: a gener
 _SKEL_BWD_A = int(os.environ.get('VG_SKEL_BWD_A', '0'))      # clDice backward on lane A: 1 before its discriminator sweeps, 2 right before its generator sweep
 _D_ONE_SWEEP = os.environ.get('VG_D_ONE_SWEEP', '1') != '0'    # one 3B-sample backward sweep per discriminator (PatchGAN.backward_both) instead of a 2B and a B sweep
 _SKEL_AUX = os.environ.get('VG_SKEL_AUX', '0') != '0'        # clDice backward from codes filed by the forward pass (streaming launches) instead of re-scanning
+_EARLY_ADAM = os.environ.get('VG_EARLY_ADAM', '1') != '0'     # a generator's finished parameter suffix (enc4 ... output head, 91 %) is updated and repacked while its sweep still runs
 _INTERLEAVE = os.environ.get('VG_INTERLEAVE', '0') != '0'   # the two lanes' enqueue sequences alternate block by block on the host: measured neutral (21.69 vs 21.63 ms), off
 
 
@@ -215,6 +216,7 @@ class VanGan:
         self._inline = _INLINE if (_INLINE_ENV is not None or not self.ddp) else 1      # (see _INLINE)
         self._tl = [] if os.environ.get('VG_TIMELINE') == '1' else None
         self._side_ev = {}
+        self._early_tab, self._early_done = {}, {}
         # world > 1: the step does not end with a join of the optimizer stream -- the last buckets' all-reduce + Adam + repack run
         # under the head of the NEXT step, whose consumers wait for the update event of the network they read (VG_XSTEP=0: join)
         self._xstep = (self.ddp or os.environ.get('VG_XSTEP_SINGLE', '0') == '1') and self._opt is not None and os.environ.get('VG_XSTEP', '1') != '0'
@@ -642,8 +644,14 @@ class VanGan:
                 # data parallel: the finished suffix of a generator's gradient bucket (enc4 ... output head, 34 of 38 MB) goes to the
                 # all-reduce when the sweep has passed enc4 -- with ~40 % of the sweep still ahead; only the last 4 MB wait for its end
                 split = self.ddp and apply and _AR_SPLIT
+                early_adam = (_EARLY_ADAM and apply and not self.ddp and self._opt is not None and self._cap is None and ops.PROF is None
+                              and ops.DRY is None and ops.REC is None)
                 def early(name, gen):
-                    return (lambda: self._start_allreduce([name], lazy=apply, lo=gen.grad_suffix_offset())) if split else None
+                    if split:
+                        return lambda: self._start_allreduce([name], lazy=apply, lo=gen.grad_suffix_offset())
+                    if early_adam and hasattr(gen, 'grad_suffix_offset'):
+                        return lambda: self._early_update(name)
+                    return None
                 order = ((laneB, self.gen_SI.backward_iter(arB, ccB, gI2, inline_from=self._inline, on_suffix_done=early('gen_SI', self.gen_SI))),
                          (contextlib.nullcontext, self.gen_IS.backward_iter(ar, ccA, gS2, inline_from=self._inline, on_suffix_done=early('gen_IS', self.gen_IS))))
                 interleave(*(order if (_BFIRST >> 2) & 1 else order[::-1]), on=_INTERLEAVE)
@@ -714,6 +722,14 @@ class VanGan:
     def _adam(self, name: str):
         """a22: per-variable clip-by-norm + Adam on the (reduced) flat gradient bucket of one network, then its bf16 repack."""
         st = self.stores[name]
+        early = self._early_done.pop(name, None)
+        if early is not None:                  # the suffix was updated and repacked when the sweep passed enc4 (_early_update): the prefix is left
+            ep, lr_t = early
+            off = ep['off']
+            ops.adam_clip(st.w[:off], st.g[:off], st.m[:off], st.v[:off], ep['seg_lo'], ep['T_lo'], ep['norms_lo'], lr_t, self.beta_1, self.beta_2,
+                          self.adam_eps, self.clipnorm, 1.0)
+            ep['ptab_lo'].run()
+            return
         st.step += 1
         t = st.step
         if self._cap is not None:              # under graph capture: lr_t of the replayed step comes from the device block
@@ -723,6 +739,48 @@ class VanGan:
             ops.adam_clip(st.w, st.g, st.m, st.v, st.seg_off, st.T, st.norms, self._lr_t(name, t), self.beta_1, self.beta_2,
                           self.adam_eps, self.clipnorm, 1.0)
         self.nets[name].pack()
+
+    def _early_parts(self, name: str):
+        """Split of a ResUNet generator's flat parameter buffer at the first parameter of enc4 (nets.ResUNet.grad_suffix_offset): segment
+        tables, norm scratch and repack tables of the two parts.  A backward sweep completes the gradients from the END of the buffer
+        (output head, decoder, bridge, enc4: 8.65 of 9.54 M parameters) with ~40 % of the sweep still ahead; clip-by-norm is per variable,
+        so the suffix can be updated then (vangan.py:426-438 applies the optimizers after the tape: the same update, earlier)."""
+        ep = self._early_tab.get(name)
+        if ep is None:
+            net, st = self.nets[name], self.stores[name]
+            off = net.grad_suffix_offset()
+            bounds = st.seg_off.cpu().tolist()
+            k = bounds.index(off)
+            dev = st.w.device
+            hi_names = ('enc4', 'bridge', 'dec3', 'dec2', 'dec1', 'dec0', 'out')
+            lay_hi = [l for n_, l in net.L.items() if n_.split('.')[0] in hi_names]
+            lay_lo = [l for n_, l in net.L.items() if n_.split('.')[0] not in hi_names]
+            assert off % 4 == 0 and len(lay_hi) + len(lay_lo) == len(net.L)
+            nrm = lambda n_el, T: torch.zeros(T + 2 * ((n_el + 4095) // 4096), dtype=torch.float32, device=dev)
+            ep = self._early_tab[name] = dict(
+                off=off, T_lo=k, T_hi=st.T - k,
+                seg_lo=torch.tensor(bounds[:k + 1], dtype=torch.int64, device=dev),
+                seg_hi=torch.tensor([b - off for b in bounds[k:]], dtype=torch.int64, device=dev),
+                norms_lo=nrm(off, k), norms_hi=nrm(st.total - off, st.T - k),
+                ptab_lo=ops.PackTable(lay_lo, dev), ptab_hi=ops.PackTable(lay_hi, dev))
+        return ep
+
+    def _early_update(self, name: str):
+        """Called on a generator's lane when its (last) backward sweep has passed block enc4: clip + Adam + repack of the finished suffix
+        on the optimizer stream, behind the lane and the weight gradients it has handed to its side stream so far."""
+        st, ep = self.stores[name], self._early_parts(name)
+        st.step += 1
+        lr_t = self._lr_t(name, st.step)
+        ops.wait_stream(self._opt, ops.current_stream_obj())
+        sev = ops.side_event()
+        if sev is not None:
+            ops.wait_event(self._opt, sev)
+        off = ep['off']
+        with torch.cuda.stream(self._opt):
+            ops.adam_clip(st.w[off:], st.g[off:], st.m[off:], st.v[off:], ep['seg_hi'], ep['T_hi'], ep['norms_hi'], lr_t, self.beta_1, self.beta_2,
+                          self.adam_eps, self.clipnorm, 1.0)
+            ep['ptab_hi'].run()
+        self._early_done[name] = (ep, lr_t)
 
     def _lr_t(self, name: str, t: int) -> float:
         """Adam's bias-corrected rate of network `name` at its step t (1-based); the base rate is self.lr, a per-network float or a
