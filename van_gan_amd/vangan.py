@@ -32,6 +32,7 @@ _PAIR_BWD = os.environ.get('VG_PAIR_BWD', '1') != '0'       # one 2B-sample back
 _AR_SPLIT = os.environ.get('VG_AR_SPLIT', '1') != '0'       # world > 1: a generator's finished gradient suffix is all-reduced while its sweep still runs
 _SKEL_BWD_A = int(os.environ.get('VG_SKEL_BWD_A', '0'))      # clDice backward on lane A: 1 before its discriminator sweeps, 2 right before its generator sweep
 _D_ONE_SWEEP = os.environ.get('VG_D_ONE_SWEEP', '1') != '0'    # one 3B-sample backward sweep per discriminator (PatchGAN.backward_both) instead of a 2B and a B sweep
+_SKEL_FWD_A = os.environ.get('VG_SKEL_FWD_A', '0') != '0'    # the predicted skeleton's forward pass on lane A (behind lane B's min-max of cycled_S)
 _SKEL_AUX = os.environ.get('VG_SKEL_AUX', '0') != '0'        # clDice backward from codes filed by the forward pass (streaming launches) instead of re-scanning
 _EARLY_ADAM = os.environ.get('VG_EARLY_ADAM', '1') != '0'     # a generator's finished parameter suffix (enc4 ... output head, 91 %) is updated and repacked while its sweep still runs
 _INTERLEAVE = os.environ.get('VG_INTERLEAVE', '0') != '0'   # the two lanes' enqueue sequences alternate block by block on the host: measured neutral (21.69 vs 21.63 ms), off
@@ -428,21 +429,39 @@ class VanGan:
 
         # ---- cycle / segmentation losses on cycled_S (loss_functions.py:185-190, 211-226): lane B; target skeleton: lane A ----
         imgs_t, skels_t = ar.alloc((it + 2,) + vol, f32), ar.alloc((it + 1,) + vol, f32)
+        # VG_SKEL_FWD_A: the PREDICTED skeleton's forward pass on lane A as well (behind lane B's min-max normalisation of cycled_S) -- lane B
+        # is the longer lane; its clDice then starts from the finished skeletons
+        skel_fwd_on_a = _SKEL_FWD_A and lane_b is not None
+        ev_ncS = None
+        if skel_fwd_on_a:
+            with laneB():
+                ops.wait_event(lane_b, ev_nS)
+                mmcS = ar.alloc((B, 4), f32)
+                ncS = ar.alloc(vol, f32)
+                ops.minmax(cyc_S, B, S, mmcS); ops.minmax_apply(cyc_S, mmcS, B, S, ncS)
+                ev_ncS = ops.record_event(lane_b)
         ops.soft_skel_fwd(nS, dims4, it, imgs_t, skels_t)                                # lane A
+        if skel_fwd_on_a:
+            imgs_p, skels_p = ar.alloc((it + 2,) + vol, f32), ar.alloc((it + 1,) + vol, f32)
+            aux_p = ar.alloc((ops.skel_aux_bytes(dims4, it),), torch.uint8) if (do_backward and _SKEL_AUX) else None
+            ops.wait_event(main, ev_ncS)
+            ops.soft_skel_fwd(ncS, dims4, it, imgs_p, skels_p, aux_p)                    # lane A
         ev_skel_t = ops.record_event(main) if lane_b is not None else None
         self._mark('A target skeleton')
         with laneB():
-            if lane_b is not None:
-                ops.wait_event(lane_b, ev_nS)
-            mmcS = ar.alloc((B, 4), f32)
-            ncS = ar.alloc(vol, f32)
-            ops.minmax(cyc_S, B, S, mmcS); ops.minmax_apply(cyc_S, mmcS, B, S, ncS)
+            if not skel_fwd_on_a:
+                if lane_b is not None:
+                    ops.wait_event(lane_b, ev_nS)
+                mmcS = ar.alloc((B, 4), f32)
+                ncS = ar.alloc(vol, f32)
+                ops.minmax(cyc_S, B, S, mmcS); ops.minmax_apply(cyc_S, mmcS, B, S, ncS)
             g_ncS = ar.alloc(vol, f32) if do_backward else None
             ops.bce(nS, ncS, acc[0:1], self.lambda_cycle / (B * S * gbs), g_ncS, accumulate=False)
-            imgs_p, skels_p = ar.alloc((it + 2,) + vol, f32), ar.alloc((it + 1,) + vol, f32)
-            # the predicted skeleton is differentiated: its forward pass files delta and the pooling arg-extrema codes (6 B per voxel and step)
-            aux_p = ar.alloc((ops.skel_aux_bytes(dims4, it),), torch.uint8) if (do_backward and _SKEL_AUX) else None
-            ops.soft_skel_fwd(ncS, dims4, it, imgs_p, skels_p, aux_p)
+            if not skel_fwd_on_a:
+                imgs_p, skels_p = ar.alloc((it + 2,) + vol, f32), ar.alloc((it + 1,) + vol, f32)
+                # the predicted skeleton is differentiated: its forward pass files delta and the pooling arg-extrema codes (6 B per voxel and step)
+                aux_p = ar.alloc((ops.skel_aux_bytes(dims4, it),), torch.uint8) if (do_backward and _SKEL_AUX) else None
+                ops.soft_skel_fwd(ncS, dims4, it, imgs_p, skels_p, aux_p)
             if lane_b is not None:
                 ops.wait_event(lane_b, ev_skel_t)
             skel_p, skel_t = skels_p[it], skels_t[it]
