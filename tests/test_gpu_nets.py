@@ -47,7 +47,8 @@ def perturb(P, seed):
     return P
 
 
-def grad_report(got: dict, ref: dict, label: str, rel_tol=1e-1, cos_tol=0.99, check=True, abs_tol=2e-3):
+def grad_report(got: dict, ref: dict, label: str, rel_tol=1e-1, cos_tol=0.99, check=True, abs_tol=2e-3, special=None):
+    """special: {tensor name: (rel_tol, cos_tol)} for tensors with a stated tolerance of their own."""
     gmax = max(float(v.double().norm()) for v in ref.values())
     rows, bad = [], []
     for k in ref:
@@ -59,7 +60,7 @@ def grad_report(got: dict, ref: dict, label: str, rel_tol=1e-1, cos_tol=0.99, ch
         if nb < 1e-2 * gmax:         # small tensors: absolute check against the largest gradient norm
             if err > abs_tol * gmax:
                 bad.append((k, 'abs', err, gmax))
-        elif err / nb > rel_tol or cos < cos_tol:
+        elif err / nb > (special or {}).get(k, (rel_tol, cos_tol))[0] or cos < (special or {}).get(k, (rel_tol, cos_tol))[1]:
             bad.append((k, 'rel', err / nb, cos))
     worst = sorted(rows, key=lambda r: -r[2])[:8]
     print('\n[%s] worst relative gradient errors:' % label)
