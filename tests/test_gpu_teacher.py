@@ -20,8 +20,9 @@ Stated tolerance (measured values are printed): every parameter tensor of all fo
 InstanceNorm: its output normalises to the same tensor whatever w is, so dL/dw exists only through eps -- an O(eps) quantity that the
 product path gets from the second moment of the norm's backward statistics (vg_in_scale_invariant_wgrad), i.e. from a sum over every
 voxel whose terms cancel to ~1e-4 of their size.  Run to run it moves with the order of the float atomics in the statistics of every
-block below it: 2e-2 .. 6e-2 in round 4; 3e-2 .. 1.2e-1 since round 5 (48 runs: 8 above 8e-2, none above 1.2e-1; at the round's first
-commit 0 of 16 above 8e-2 -- no single one of the round's kernel changes brings the spread back when switched off, tools/r05_flake.sh);
+block below it: 3e-2 .. 1.2e-1 over 80 runs of round 5's final sources (10 above the common 8e-2, none above 1.2e-1), with every switchable
+change of the round off still 1 of 16 above 8e-2; 0 of 16 at the round's first commit, which a 12 % rate produces one time in eight -- the
+2e-2 .. 6e-2 noted in round 4 came from a handful of runs (tools/r05_flake.sh);
 tensors whose gradient is analytically ~0 (biases in front of an InstanceNorm) absolutely, <= 5e-3 of the network's largest gradient
 norm; whole-network cosine >= 0.9995 (measured 0.99998-1.00000, rel 4e-4 discriminators / 3e-3 - 7e-3 generators).  A dropped term in a fused launch (first-writer bits, a missing accumulate, the wrong half of a paired
 tensor) moves single tensors by O(1) and fails this."""
@@ -32,7 +33,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-STEM_SHORT = {'stem.short.w': (2e-1, 0.98)}          # see the module docstring
+STEM_SHORT = {'stem.short.w': (2e-1, 0.98)} if os.environ.get('VG_TEST_STEM_TOL', '1') != '0' else None          # see the module docstring (VG_TEST_STEM_TOL=0: the common tolerance, for tools/r05_flake.sh)
 
 from oracle import vangan_oracle as O  # noqa: E402
 from test_gpu_nets import grad_report, perturb, rel_l2  # noqa: E402
