@@ -34,6 +34,7 @@ _SKEL_BWD_A = int(os.environ.get('VG_SKEL_BWD_A', '0'))      # clDice backward o
 _D_ONE_SWEEP = os.environ.get('VG_D_ONE_SWEEP', '1') != '0'    # one 3B-sample backward sweep per discriminator (PatchGAN.backward_both) instead of a 2B and a B sweep
 _SKEL_FWD_A = os.environ.get('VG_SKEL_FWD_A', '0') != '0'    # the predicted skeleton's forward pass on lane A (behind lane B's min-max of cycled_S)
 _SKEL_AUX = os.environ.get('VG_SKEL_AUX', '0') != '0'        # clDice backward from codes filed by the forward pass (streaming launches) instead of re-scanning
+_EARLY_ADAM_DDP = os.environ.get('VG_EARLY_ADAM_DDP', '1') != '0'     # ... under gradient synchronisation too, behind the suffix's early all-reduce
 _EARLY_ADAM = os.environ.get('VG_EARLY_ADAM', '1') != '0'     # a generator's finished parameter suffix (enc4 ... output head, 91 %) is updated and repacked while its sweep still runs
 _INTERLEAVE = os.environ.get('VG_INTERLEAVE', '0') != '0'   # the two lanes' enqueue sequences alternate block by block on the host: measured neutral (21.69 vs 21.63 ms), off
 
@@ -663,12 +664,17 @@ class VanGan:
                 # data parallel: the finished suffix of a generator's gradient bucket (enc4 ... output head, 34 of 38 MB) goes to the
                 # all-reduce when the sweep has passed enc4 -- with ~40 % of the sweep still ahead; only the last 4 MB wait for its end
                 split = self.ddp and apply and _AR_SPLIT
-                early_adam = (_EARLY_ADAM and apply and not self.ddp and self._opt is not None and self._cap is None and ops.PROF is None
-                              and ops.DRY is None and ops.REC is None)
+                early_adam = (_EARLY_ADAM and apply and self._opt is not None and self._cap is None and ops.PROF is None
+                              and ops.DRY is None and ops.REC is None and (not self.ddp or _EARLY_ADAM_DDP))
                 def early(name, gen):
+                    ea = early_adam and hasattr(gen, 'grad_suffix_offset')
                     if split:
-                        return lambda: self._start_allreduce([name], lazy=apply, lo=gen.grad_suffix_offset())
-                    if early_adam and hasattr(gen, 'grad_suffix_offset'):
+                        def f():
+                            self._start_allreduce([name], lazy=apply, lo=gen.grad_suffix_offset())
+                            if ea:
+                                self._early_update(name)         # behind the suffix's all-reduce (queued on / awaited by the optimizer stream)
+                        return f
+                    if ea and not self.ddp:
                         return lambda: self._early_update(name)
                     return None
                 order = ((laneB, self.gen_SI.backward_iter(arB, ccB, gI2, inline_from=self._inline, on_suffix_done=early('gen_SI', self.gen_SI))),
@@ -796,6 +802,7 @@ class VanGan:
             ops.wait_event(self._opt, sev)
         off = ep['off']
         with torch.cuda.stream(self._opt):
+            self.sync.finish([name])                     # data parallel: the suffix's all-reduce (no-op otherwise)
             ops.adam_clip(st.w[off:], st.g[off:], st.m[off:], st.v[off:], ep['seg_hi'], ep['T_hi'], ep['norms_hi'], lr_t, self.beta_1, self.beta_2,
                           self.adam_eps, self.clipnorm, 1.0)
             ep['ptab_hi'].run()
