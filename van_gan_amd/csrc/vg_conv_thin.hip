@@ -484,7 +484,7 @@ __global__ __launch_bounds__(256, VG_THIN_WPE) void conv_thin_kernel(const Gathe
             const int stripe = blockIdx.x & (VG_STRIPES - 1);
             if (co < p.Cout) atomicAdd(&p.sums[(((size_t)stripe * gridDim.z + n) * p.Cout + co) * 2 + (tid & 1)], stat[tid]);
         }
-        if constexpr (STATS && NP == 2) { if (p.fin.ticket) vg_fin_tail(p.fin, p.sums, gridDim.z, p.Cout, gridDim.x * gridDim.y * gridDim.z, (int*)stat); }
+        if constexpr (STATS && (NP == 2 || !RES)) { if (p.fin.ticket) vg_fin_tail(p.fin, p.sums, gridDim.z, p.Cout, gridDim.x * gridDim.y * gridDim.z, (int*)stat); }
     }
 }
 
@@ -538,7 +538,7 @@ static int launch_thin_np(const GatherIn& g, const ConvOut& k, int lds, hipStrea
     snprintf(name, sizeof name, "%s<m%%d,b%%d,r%%d,s%%d%s>|walk%%d|ch%%d", NP == 2 ? "conv_thin2" : "conv_thin", BSTAT ? (k.bs_x1 ? ",bs2" : ",bs1") : "");
     if (vg_dry(name, MODE, (int)BIAS, (int)RES, (int)STATS, tiles > bx ? 1 : 0, k.nchunks > 1 ? 1 : 0)) return VG_OK;
     // the two-panel instances (32-channel layers) finalise the InstanceNorm statistics of their output in the launch (last workgroup)
-    const bool fin_here = NP == 2 && STATS && k2.fin.ticket && k2.sums && vg_tune("CONV_THIN2_FIN", 1);
+    const bool fin_here = STATS && k2.fin.ticket && k2.sums && ((NP == 2 && vg_tune("CONV_THIN2_FIN", 1)) || (NP == 1 && !RES && vg_tune("CONV_THIN1_FIN", 1)));
     if (!fin_here) k2.fin.ticket = nullptr;
     hipLaunchKernelGGL((conv_thin_kernel<MODE, BIAS, RES, STATS, BSTAT, NP>), dim3(bx, ny, g.N), dim3(256), lds, s, g, k2);
     if (fin_here) vg_fin_done = true;
