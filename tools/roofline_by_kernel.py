@@ -45,8 +45,8 @@ def variant_of(kernel_name: str):
     if k == 'conv' and len(args) == 8:
         return 'conv<%s,%s,%s,n%s,wl%s,dma%s,mc%s,c1%s>' % (tname(args[0]), args[1], args[2], b(args[3]), b(args[4]), b(args[5]), args[6], b(args[7]))
     if k == 'conv_thin' and len(args) >= 4:
-        return '%s<m%s,b%s,r%s,s%s%s>' % ('conv_thin2' if len(args) > 5 and args[5] == '2' else 'conv_thin', args[0], b(args[1]), b(args[2]), b(args[3]),
-                                          ',bs' if len(args) > 4 and b(args[4]) == '1' else '')
+        return '%s<m%s,b%s,r%s,s%s%s%s>' % ('conv_thin2' if len(args) > 5 and args[5] == '2' else 'conv_thin', args[0], b(args[1]), b(args[2]), b(args[3]),
+                                            ',bs' if len(args) > 4 and b(args[4]) == '1' else '', ',pl' if len(args) > 6 and args[6] != '1' else '')       # pl: output panels looped over one staged halo
     if k == 'pw_gemm' and len(args) == 6 and args[5] == 'true':
         return 'pw_gemm_split<%s,%s>' % (args[0], args[1])
     if k == 'pw_gemm' and len(args) in (5, 6):

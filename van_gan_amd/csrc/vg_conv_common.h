@@ -11,6 +11,7 @@ struct ConvOut {
     int w_lds;          // 1: the BN x Ktot weight panel of this workgroup is copied to LDS once (row stride WRS bytes)
     int dma;            // 1: LDS-DMA double-buffered staging (planar bf16 image, weights in LDS)
     int xw;             // conv_thin_kernel: XCD-aware tile walk (set by its launcher)
+    int dbg;            // conv_thin_kernel, panel-loop instance: timing ablations (VG_THIN_DBG; 0 in production)
     int WRS;
     // IN-backward statistics of the output fused into the epilogue (conv_thin_kernel<..., BSTAT>; vg_conv_desc::bstat): the
     // pre-norm tensor(s) of the layer whose gradient this launch produces and its per-(sample, channel) constants
@@ -152,6 +153,6 @@ __device__ __forceinline__ void conv_mfma_chunk(f32x4 (&acc)[MW], WP w, const ch
 
 // vg_conv_thin.hip: specialist for the 16-channel-chunk 3x3x3 stride-1 layers with a fixed 16x8x4 tile
 bool vg_conv_thin_ok(const vg_conv_desc* d, const GatherIn& g, const ConvOut& k, const ConvCls& q, int np);       // np: 16-channel panels per workgroup (1 / 2)
-int vg_conv_thin_lds_bytes(const GatherIn& g, int np);
+int vg_conv_thin_lds_bytes(const GatherIn& g, int np, int pl = 1);       // pl: output panels looped inside a workgroup (1 / 3)
 // red != NULL: accumulate the IN-backward statistics (ConvOut::bs_*) into red in the epilogue when the instance exists (did_stats)
 int vg_launch_conv_thin(const GatherIn& g, const ConvOut& k, int np, hipStream_t s, float* red, bool& did_stats);       // VG_OK, < 0 on error, 1: not one of its combinations

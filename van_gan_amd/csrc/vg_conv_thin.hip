@@ -16,6 +16,7 @@
 //   * staging is the lean routine (vg_gather.h) with a compile-time transform, its 360 columns x 2 D-segments dealt out evenly.
 // Everything else (persistent workgroups, tables, InstanceNorm statistics carried in registers) follows conv_kernel.
 #include "vg_conv_common.h"
+#include "vg_dma_common.h"
 #include <type_traits>
 #include <cstdio>
 
@@ -154,8 +155,12 @@ __device__ __forceinline__ void thin_commit(const GatherIn& g, char* halo, const
 // BSTAT (data gradient): the epilogue also accumulates the statistics of the IN backward that consumes this output --
 // sum dn and sum dn * xhat with dn = g * mult * act'(x * scale + shift) taken at the reflect-folded position of the pre-norm
 // tensor x -- into p.sums (same striped layout as the forward statistics), so that the statistics pass need not re-read g.
-template <int MODE, bool BIAS, bool RES, bool STATS, bool BSTAT = false, int NP = 1>
+// PL (data gradient of a 16-channel tensor into 16 PL channels -- dec0.cb1's 16 -> 48): the PL output panels are LOOPED over one staged
+// halo image instead of being separate workgroups that each stage it; the 16 x 448 weight panel of the next use arrives by LDS-DMA
+// (two buffers) under the MFMA loop of the current one, the statistics of a panel are flushed to LDS per tile (registers).
+template <int MODE, bool BIAS, bool RES, bool STATS, bool BSTAT = false, int NP = 1, int PL = 1>
 __global__ __launch_bounds__(256, VG_THIN_WPE) void conv_thin_kernel(const GatherIn g, const ConvOut p) {
+    static_assert(PL == 1 || (NP == 1 && MODE == VG_STAGE_PLAIN && !BIAS && !RES && !STATS), "panel loop: plain data gradient only");
     // NP: 16-channel output panels per workgroup.  NP = 2 (the 32-channel layers at 64^3, conv_thin2 in the variant names): every B
     // fragment feeds two MFMAs -- 10 fragment reads per 16 MFMAs instead of 9 per 8 -- and the halo is staged once per 32 channels.
     typedef bf16_t T;
@@ -168,19 +173,29 @@ __global__ __launch_bounds__(256, VG_THIN_WPE) void conv_thin_kernel(const Gathe
     char* halo = smem;
     float* scs = (float*)(smem + HALO);
     float* stat = scs + 32;
-    int* tapb = (int*)(stat + 32 * NP);
+    float* bsc = stat + 32 * NP * PL;                    // BSTAT: [scale | shift | rstd | -mean * rstd][16 NP PL channels of this workgroup]
+    int* tapb = (int*)(bsc + 64 * NP * PL);
     int* utab = tapb + 32;
     constexpr int NCOLS = HH * HW * 2;
     int* xtab = utab + 2 * NCOLS;                        // axis tables of the whole grid (thin_axis_tables)
     const int NHt = g.tiles_h * TH + 2, NWt = g.tiles_w * TW + 2, NDt = g.tiles_d * TD + 2;
     char* wlds = (char*)(xtab + 2 * (NHt + NWt + NDt));
-    wlds = (char*)(((size_t)wlds + 15) & ~(size_t)15);
+    wlds = (char*)(((size_t)wlds + (PL > 1 ? 1023 : 15)) & ~(size_t)(PL > 1 ? 1023 : 15));
     const int Ktot = p.Ktot, nchunks = p.nchunks;
     constexpr int WRS = KCPAD * 2 + 16;                  // LDS row stride of the chunk panel (16 bytes of padding: bank spread)
-    const int cop = ntile * 16 * NP;                     // first output channel of this workgroup
+    const int cop = ntile * 16 * NP * PL;                // first output channel of this workgroup
 
     build_column_table(g, utab, tid);
-    if (tid < 32 * NP) stat[tid] = 0.f;
+    if (tid < 32 * NP * PL) stat[tid] = 0.f;
+    if constexpr (BSTAT) {
+        // per-channel constants of the statistics: from LDS in the epilogue (fetched from memory there, every tile waited an L2 round trip for them)
+        constexpr int CW = 16 * NP * PL;
+        if (tid < CW) {
+            const int nc = n * p.Cout + cop + tid;
+            const float rs = p.bs_rs[nc];
+            bsc[tid] = p.bs_sc[nc]; bsc[CW + tid] = p.bs_sf[nc]; bsc[2 * CW + tid] = rs; bsc[3 * CW + tid] = -p.bs_mu[nc] * rs;
+        }
+    }
     if (tid < 27) tapb[tid] = (g.td[tid] - g.tmin_d) * DSB + (g.th[tid] - g.tmin_h) * ROWB + (g.tw[tid] - g.tmin_w) * UNIT;
     // the (16 NP) x 448 weight panel of one chunk -> LDS: 16 NP rows x 56 units of 16 bytes, 3.5 NP per thread
     auto load_weights = [&](int chunk) {
@@ -199,17 +214,33 @@ __global__ __launch_bounds__(256, VG_THIN_WPE) void conv_thin_kernel(const Gathe
             if (u < NU) { const int r = u / 56, c = u - r * 56; *(f32x4*)(wlds + r * WRS + c * 16) = v[k]; }
         }
     };
-    load_weights(0);
+    // PL: one use's panel as 15 LDS-DMA pieces of 64 x 16 bytes, dealt to the waves; unit u = row * 57 + c (c == 56: the row's padding)
+    constexpr int WBUF = 15 * 1024;
+    const unsigned wlds_a = (unsigned)(uintptr_t)(lds_void_d*)wlds;
+    auto dma_weights = [&](int panel, int buf) {
+        const char* src = (const char*)p.wp + (size_t)(cop + 16 * panel) * Ktot * 2;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int piece = wave + 4 * k;
+            if (piece < 15) {
+                const int u = piece * 64 + lane, r = min(u / 57, 15), c = min(u - (u / 57) * 57, 55);
+                glds16(src, r * Ktot * 2 + c * 16, wlds_a + buf * WBUF + piece * 1024);
+            }
+        }
+    };
+    if constexpr (PL > 1) dma_weights(0, 0); else load_weights(0);
     // ---- per-lane constants of the MFMA loop: B-fragment base of every K-step (tap and channel group of this lane's k-group)
     const int wbase = li * WRS + kg * 16;                                // A fragment: row li of panel 0, k-group kg (panel q: + 16 q rows)
     const int co0 = cop + 4 * kg;                                        // this lane's 4 output channels of panel 0 (panel q: + 16 q)
-    float s1[NP][4], s2[NP][4];
+    float s1[NP * PL][4], s2[NP * PL][4];              // PL: [0] is the panel in work, [1], [2] the next two (rotated after every panel)
     f32x2 e_b[NP][2], e_rs[NP][2], e_rb[NP][2];
+#pragma unroll
+    for (int q = 0; q < NP * PL; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s1[q][r] = 0.f; s2[q][r] = 0.f; }
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
         const int c = co0 + 16 * q;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { s1[q][r] = 0.f; s2[q][r] = 0.f; }
         e_b[q][0] = (f32x2){0.f, 0.f}; e_b[q][1] = e_b[q][0];
         if (BIAS && NP == 1) { e_b[q][0] = (f32x2){p.bias[c], p.bias[c + 1]}; e_b[q][1] = (f32x2){p.bias[c + 2], p.bias[c + 3]}; }
         if (RES && NP == 1) {
@@ -222,15 +253,18 @@ __global__ __launch_bounds__(256, VG_THIN_WPE) void conv_thin_kernel(const Gathe
     const T* b_x[NP]; int b_cs[NP], b_sh[NP]; float b_slope = 1.f;
 #pragma unroll
     for (int q = 0; q < NP; ++q) { b_x[q] = nullptr; b_cs[q] = 0; b_sh[q] = 0; }
-    if (BSTAT) {
+    auto bstat_panel = [&](const int pn16) {
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
-            const int c = co0 + 16 * q;
+            const int c = co0 + 16 * q + pn16;
             const bool lo = c < p.bs_c0;                                 // panel-uniform (bs_c0 is a multiple of 16)
             b_sh[q] = lo ? p.bs_sh : 0; b_cs[q] = lo ? p.bs_c0 : p.Cout - p.bs_c0;
             b_x[q] = (lo ? (const T*)p.bs_x0 + c : (const T*)p.bs_x1 + (c - p.bs_c0))
                      + (size_t)n * (p.bs_D >> b_sh[q]) * (p.bs_H >> b_sh[q]) * (p.bs_W >> b_sh[q]) * b_cs[q];
         }
+    };
+    if (BSTAT) {
+        if constexpr (PL == 1) bstat_panel(0);
         b_slope = p.bs_act == VG_ACT_RELU ? 0.f : (p.bs_act == VG_ACT_LRELU ? VG_LRELU : 1.f);
     }
     // 16-byte stores: after the row swap an even k-group lane holds channels 8*(kg/2)..+7 of sub-tile j, an odd one of j+1
@@ -272,6 +306,8 @@ __global__ __launch_bounds__(256, VG_THIN_WPE) void conv_thin_kernel(const Gathe
     constexpr bool PF = MODE == VG_STAGE_RELU && (NP == 1 || VG_THIN_PF2);
     Raw8<T> raw[3][HD / 2];
     if (PF && t0 < tend) thin_issue<MODE>(g, utab, tabat(ti_d * TD, ti_h * TH, ti_w * TW), n, 0, tid, raw);
+    bf16x4 bxp[(BSTAT && NP == 1) ? 8 : 1];
+    bf16x4 bxn[(BSTAT && PL > 1) ? 8 : 1];                                 // (PL: the rows requested a panel ahead)
     for (int tile = t0; tile < tend; tile += tstep, ++it) {
         const int od0 = ti_d * TD, oh0 = ti_h * TH, ow0 = ti_w * TW;
         ti_w += gs_w; if (ti_w >= g.tiles_w) { ti_w -= g.tiles_w; ++ti_h; }
@@ -285,8 +321,7 @@ __global__ __launch_bounds__(256, VG_THIN_WPE) void conv_thin_kernel(const Gathe
             for (int j = 0; j < 8; ++j) acc[q][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         // BSTAT (one panel): the pre-norm values of this lane's 8 output rows are requested HERE, ahead of the tile's staging and MFMA loop,
         // and consumed in the epilogue -- issued there (round 3) every tile waited a full HBM round trip for them with nothing left to run
-        bf16x4 bxp[(BSTAT && NP == 1) ? 8 : 1];
-        if constexpr (BSTAT && NP == 1) {
+        auto issue_bxp = [&]() {
             auto fold = [&](int qq, int nn) { int i = qq - p.bs_pad; i = i < 0 ? -i : i; i = i >= nn ? 2 * nn - 2 - i : i; return min(max(i, 0), nn - 1); };
             const int XH = p.bs_H >> b_sh[0], XW = p.bs_W >> b_sh[0];
             const int id = fold(od0 + wave + p.ood, p.bs_D) >> b_sh[0], iw = fold(ow0 + li + p.oow, p.bs_W) >> b_sh[0];
@@ -296,7 +331,49 @@ __global__ __launch_bounds__(256, VG_THIN_WPE) void conv_thin_kernel(const Gathe
                 const int ih = fold(oh0 + j + p.ooh, p.bs_H) >> b_sh[0];
                 bxp[j] = *(const __attribute__((address_space(1))) bf16x4*)(uintptr_t)(xcol + (size_t)ih * XW * b_cs[0]);
             }
-        }
+        };
+        if constexpr (BSTAT && NP == 1 && PL == 1) issue_bxp();
+        // PL: the pre-norm rows of the NEXT panel (or the next tile's first) are requested row pair by row pair inside the epilogue, as soon as
+        // the pair's registers are free -- a whole MFMA loop ahead of their use (requested in front of the loop they were waited for: 12 %)
+        const T* n_xcol = nullptr; int n_rowp = 0, n_sh = 0, n_oh0 = 0;
+        auto bx_prepare = [&](const int pn16, const int od0_, const int oh0_, const int ow0_) {
+            auto fold = [&](int qq, int nn) { int i = qq - p.bs_pad; i = i < 0 ? -i : i; i = i >= nn ? 2 * nn - 2 - i : i; return min(max(i, 0), nn - 1); };
+            bstat_panel(pn16);
+            const int XH = p.bs_H >> b_sh[0], XW = p.bs_W >> b_sh[0];
+            const int id = fold(od0_ + wave + p.ood, p.bs_D) >> b_sh[0], iw = fold(ow0_ + li + p.oow, p.bs_W) >> b_sh[0];
+            n_xcol = b_x[0] + ((size_t)id * XH * XW + iw) * b_cs[0];
+            n_rowp = XW * b_cs[0]; n_sh = b_sh[0]; n_oh0 = oh0_;
+        };
+        auto bx_addr = [&](const int j) {
+            auto fold = [&](int qq, int nn) { int i = qq - p.bs_pad; i = i < 0 ? -i : i; i = i >= nn ? 2 * nn - 2 - i : i; return min(max(i, 0), nn - 1); };
+            const int ih = fold(n_oh0 + j + p.ooh, p.bs_H) >> n_sh;
+            return n_xcol + (size_t)ih * n_rowp;
+        };
+        auto bx_row = [&](const int j) { return *(const __attribute__((address_space(1))) bf16x4*)(uintptr_t)bx_addr(j); };
+        // the MFMA loop of one panel: 14 K-steps x 8 sub-tiles, every address an immediate, the fragments of the next K-step in flight
+        auto mfma_panel = [&](const char* wb) {
+            constexpr int PD = VG_THIN_PD, NB = PD + 1;
+            bf16x8 a[NB], b[NB][8];
+#pragma unroll
+            for (int u = 0; u < PD; ++u) {
+                a[u] = *(lds_frag*)(wb + u * 64);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) b[u][j] = *(lds_frag*)(halo + boff[u] + j * ROWB);
+            }
+#pragma unroll
+            for (int s = 0; s < KSTEPS; ++s) {
+                if (s + PD < KSTEPS) {
+                    a[(s + PD) % NB] = *(lds_frag*)(wb + (s + PD) * 64);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) b[(s + PD) % NB][j] = *(lds_frag*)(halo + boff[s + PD] + j * ROWB);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[0][j] = VG_MFMA16(a[s % NB], b[s % NB][j], acc[0][j]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        if constexpr (PL == 1)
         for (int chunk = 0; chunk < nchunks; ++chunk) {
             if (it | chunk) lds_only_barrier();                            // previous readers of the halo image / weight panel are done
             if (nchunks > 1) { stage_scale_shift(g, scs, n, chunk, tid); if (it | chunk) load_weights(chunk); lds_only_barrier(); }
@@ -372,7 +449,7 @@ __global__ __launch_bounds__(256, VG_THIN_WPE) void conv_thin_kernel(const Gathe
         const size_t rowpitch = (size_t)p.BW * p.Cout;                                       // elements per output H row (ostr == 1)
         const size_t obase = (((size_t)(n * p.BD + od + p.ood) * p.BH + oh0 + p.ooh) * p.BW + ow + p.oow) * p.Cout;
         const bool full = od0 + TD <= p.OD && oh0 + TH <= p.OH && ow0 + TW <= p.OW;
-        auto epilogue = [&](auto masked_tag) {
+        auto epilogue = [&](auto masked_tag, const int pn16) {
             constexpr bool MASKED = decltype(masked_tag)::value;
             const bool dw_ok = !MASKED || (od < p.OD && ow < p.OW);
             const int nrow = MASKED ? p.OH - oh0 : TH;                                        // valid H rows of this tile
@@ -380,7 +457,7 @@ __global__ __launch_bounds__(256, VG_THIN_WPE) void conv_thin_kernel(const Gathe
             typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 #pragma unroll
             for (int q = 0; q < NP; ++q) {
-            T* const optr = (T*)p.out + obase + cst + 16 * q;
+            T* const optr = (T*)p.out + obase + cst + 16 * q + pn16;
             const T* const rptr = RES ? (const T*)p.res + obase + co0 + 16 * q : nullptr;
             f32x2 eb[2], ers[2], erb[2];
             if constexpr (NP == 1) { eb[0] = e_b[0][0]; eb[1] = e_b[0][1]; if (RES) { ers[0] = e_rs[0][0]; ers[1] = e_rs[0][1]; erb[0] = e_rb[0][0]; erb[1] = e_rb[0][1]; } }
@@ -396,13 +473,12 @@ __global__ __launch_bounds__(256, VG_THIN_WPE) void conv_thin_kernel(const Gathe
             bf16x4 bx[BSTAT ? 8 : 1];
             f32x2 b_sc[2], b_sf[2], b_rs[2], b_nm[2];
             if (BSTAT) {
-                const int nc = n * p.Cout + co0 + 16 * q;
-                typedef const __attribute__((address_space(1))) f32x4 gf4;
-                const f32x4 c_sc = *(gf4*)(uintptr_t)(p.bs_sc + nc), c_sf = *(gf4*)(uintptr_t)(p.bs_sf + nc), c_rs = *(gf4*)(uintptr_t)(p.bs_rs + nc),
-                            c_mu = *(gf4*)(uintptr_t)(p.bs_mu + nc);
+                constexpr int CW = 16 * NP * PL;
+                const float* bq = bsc + 4 * kg + 16 * q + pn16;
+                const f32x4 c_sc = *(const f32x4*)bq, c_sf = *(const f32x4*)(bq + CW), c_rs = *(const f32x4*)(bq + 2 * CW), c_nm = *(const f32x4*)(bq + 3 * CW);
                 b_sc[0] = (f32x2){c_sc[0], c_sc[1]}; b_sc[1] = (f32x2){c_sc[2], c_sc[3]}; b_sf[0] = (f32x2){c_sf[0], c_sf[1]}; b_sf[1] = (f32x2){c_sf[2], c_sf[3]};
                 b_rs[0] = (f32x2){c_rs[0], c_rs[1]}; b_rs[1] = (f32x2){c_rs[2], c_rs[3]};
-                b_nm[0] = (f32x2){-c_mu[0] * c_rs[0], -c_mu[1] * c_rs[1]}; b_nm[1] = (f32x2){-c_mu[2] * c_rs[2], -c_mu[3] * c_rs[3]};
+                b_nm[0] = (f32x2){c_nm[0], c_nm[1]}; b_nm[1] = (f32x2){c_nm[2], c_nm[3]};
                 // padded output coordinate -> interior coordinate -> transpose of the reflection pad (-1 -> 1, n -> n-2); rows of a
                 // masked tile that lie outside are clamped (their contribution is zeroed below).  All 8 loads are issued up front.
                 auto fold = [&](int qq, int nn) { int i = qq - p.bs_pad; i = i < 0 ? -i : i; i = i >= nn ? 2 * nn - 2 - i : i; return min(max(i, 0), nn - 1); };
@@ -463,14 +539,64 @@ __global__ __launch_bounds__(256, VG_THIN_WPE) void conv_thin_kernel(const Gathe
                 const u32x4 outv = {x0[0], x1[0], x0[1], x1[1]};
                 const int j = jp + jodd;
                 if (!MASKED || (dw_ok && j < nrow)) *(u32x4*)(optr + j * rowpitch) = outv;
+                if constexpr (BSTAT && PL > 1) { __builtin_amdgcn_sched_barrier(0); bxn[jp] = bx_row(jp); bxn[jp + 1] = bx_row(jp + 1); __builtin_amdgcn_sched_barrier(0); }   // the next panel's rows (bx_prepare)
             }
             }
         };
-        if (full) epilogue(std::false_type{}); else epilogue(std::true_type{});
+        if constexpr (PL == 1) { if (full) epilogue(std::false_type{}, 0); else epilogue(std::true_type{}, 0); }
+        else {
+            if (it) lds_only_barrier();                                    // the previous tile's last MFMA loop is done with the halo image
+            // The pre-norm rows of the NEXT panel (or of the next tile's first) are requested inside the epilogue, row pair by row pair, into
+            // bxn -- a whole MFMA loop ahead of their use -- and move to bxp behind the vmcnt(0) that follows that loop.  (Requested straight
+            // into bxp, the loop-carried rows got fresh registers and were copied home at the END of the epilogue behind an s_waitcnt
+            // vmcnt(0): the whole round trip in the open, 163 of 399 us.  Written in place by an asm load, the compiler copied registers
+            // with the load still pending.  With the three panels unrolled -- no loop-carried rows at all -- 83 registers spilled.)
+            if constexpr (BSTAT) {
+                if (it == 0) {
+                    bx_prepare(0, od0, oh0, ow0);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) bxn[j] = bx_row(j);
+                }
+            }
+            if (!(p.dbg & 16) || it == 0) {
+            thin_issue<MODE>(g, utab, tabat(od0, oh0, ow0), n, 0, tid, raw);
+            thin_commit<MODE>(g, halo, scs, utab, tabat(od0, oh0, ow0), 0, tid, raw);
+            }
+#pragma unroll 1
+            for (int pn = 0; pn < PL; ++pn) {
+                const int use = it * PL + pn;
+                // every wave has waited for its pieces of this use's panel (below / ahead of the first tile) and is done with the other buffer
+                if (use == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                lds_only_barrier();
+                if (pn + 1 < PL || more) dma_weights(pn + 1 < PL ? pn + 1 : 0, (use + 1) & 1);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[0][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (!(p.dbg & 4)) mfma_panel(wlds + (use & 1) * WBUF + wbase);
+                __builtin_amdgcn_s_waitcnt(0x0F70);                        // vmcnt(0), as an instruction the compiler's own counting sees: the next use's
+                asm volatile("" ::: "memory");                             // pieces and this panel's pre-norm rows have landed
+                if constexpr (BSTAT) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) asm volatile("v_mov_b64 %0, %1" : "=&v"(bxp[j]) : "v"(bxn[j]));   // a copy the compiler cannot fold: bxn's registers must be free for the requests below
+                    // (the last panel of the last tile requests its own rows again: no branch around the requests)
+                    if (pn + 1 < PL) bx_prepare(16 * (pn + 1), od0, oh0, ow0); else if (more) bx_prepare(0, ti_d * TD, ti_h * TH, ti_w * TW);
+                }
+                if (full) epilogue(std::false_type{}, 16 * pn); else epilogue(std::true_type{}, 16 * pn);
+                if constexpr (BSTAT) {                                      // the running sums of the next panel move into place (back where they were after PL panels)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float a = s1[0][r], b = s2[0][r];
+#pragma unroll
+                        for (int q = 0; q + 1 < PL; ++q) { s1[q][r] = s1[q + 1][r]; s2[q][r] = s2[q + 1][r]; }
+                        s1[PL - 1][r] = a; s2[PL - 1][r] = b;
+                    }
+                }
+            }
+        }
     }
+    if constexpr (PL > 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (a workgroup without tiles still has its first panel in flight)
     if ((STATS || BSTAT) && p.sums) {
 #pragma unroll
-        for (int q = 0; q < NP; ++q)
+        for (int q = 0; q < NP * PL; ++q)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float a = s1[q][r], b = s2[q][r];
@@ -479,7 +605,7 @@ __global__ __launch_bounds__(256, VG_THIN_WPE) void conv_thin_kernel(const Gathe
                 if (li == 0) { atomicAdd(&stat[(16 * q + 4 * kg + r) * 2], a); atomicAdd(&stat[(16 * q + 4 * kg + r) * 2 + 1], b); }
             }
         __syncthreads();
-        if (tid < 32 * NP) {
+        if (tid < 32 * NP * PL) {
             const int co = cop + (tid >> 1);
             const int stripe = blockIdx.x & (VG_STRIPES - 1);
             if (co < p.Cout) atomicAdd(&p.sums[(((size_t)stripe * gridDim.z + n) * p.Cout + co) * 2 + (tid & 1)], stat[tid]);
@@ -491,9 +617,11 @@ __global__ __launch_bounds__(256, VG_THIN_WPE) void conv_thin_kernel(const Gathe
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-int vg_conv_thin_lds_bytes(const GatherIn& g, int np) {
+int vg_conv_thin_lds_bytes(const GatherIn& g, int np, int pl) {
     const int AL = (g.tiles_h * TH + 2) + (g.tiles_w * TW + 2) + (g.tiles_d * TD + 2);          // axis tables of the whole grid, two sources
-    return HALO + (32 + 32 * np + 32) * 4 + (2 * HH * HW * 2 + 2 * AL) * 4 + 16 + 16 * np * (KCPAD * 2 + 16);
+    const int head = HALO + (32 + 32 * np * pl + 64 * np * pl + 32) * 4 + (2 * HH * HW * 2 + 2 * AL) * 4;
+    if (pl > 1) return head + 1024 + 2 * 15 * 1024;                                             // two LDS-DMA buffers of one 16-row panel
+    return head + 16 + 16 * np * (KCPAD * 2 + 16);
 }
 
 // Does this launch have the one shape the specialist serves?  (g from fill_gather for a 512-voxel tile; np: 16-channel panels per workgroup)
@@ -517,30 +645,30 @@ bool vg_conv_thin_ok(const vg_conv_desc* d, const GatherIn& g, const ConvOut& k,
     return true;
 }
 
-template <int MODE, bool BIAS, bool RES, bool STATS, bool BSTAT, int NP>
+template <int MODE, bool BIAS, bool RES, bool STATS, bool BSTAT, int NP, int PL = 1>
 static int launch_thin_np(const GatherIn& g, const ConvOut& k, int lds, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_thin_kernel<MODE, BIAS, RES, STATS, BSTAT, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, VG_LDS_LIMIT);
+        (void)hipFuncSetAttribute((const void*)conv_thin_kernel<MODE, BIAS, RES, STATS, BSTAT, NP, PL>, hipFuncAttributeMaxDynamicSharedMemorySize, VG_LDS_LIMIT);
         attr_set = true;
     }
     int per_cu = 2;
     if (lds > 0 && VG_LDS_LIMIT / lds < per_cu) per_cu = VG_LDS_LIMIT / lds;
     if (per_cu < 1) per_cu = 1;
     const int tiles = g.tiles_d * g.tiles_h * g.tiles_w;
-    const int ny = k.Cout / (16 * NP);
+    const int ny = k.Cout / (16 * NP * PL);
     const int wg = vg_tune("CONV_THIN_WGS", 0) > 0 ? vg_tune("CONV_THIN_WGS", 0) : 256 * per_cu;
     int bx = wg / (ny * g.N); if (bx < 1) bx = 1; if (bx > tiles) bx = tiles;
-    ConvOut k2 = k; k2.xw = 0;
+    ConvOut k2 = k; k2.xw = 0; k2.dbg = PL > 1 ? vg_tune("THIN_DBG", 0) : 0;
     if (vg_tune("CONV_THIN_XCD", 1) && bx >= 16 && tiles >= 4 * bx) { bx &= ~7; k2.xw = 1; }
     // bs1 / bs2: IN-backward statistics in the epilogue, of a plain / a virtually concatenated (half-resolution + skip) pre-norm tensor
     char name[96];
-    snprintf(name, sizeof name, "%s<m%%d,b%%d,r%%d,s%%d%s>|walk%%d|ch%%d", NP == 2 ? "conv_thin2" : "conv_thin", BSTAT ? (k.bs_x1 ? ",bs2" : ",bs1") : "");
+    snprintf(name, sizeof name, "%s<m%%d,b%%d,r%%d,s%%d%s%s>|walk%%d|ch%%d", NP == 2 ? "conv_thin2" : "conv_thin", BSTAT ? (k.bs_x1 ? ",bs2" : ",bs1") : "", PL > 1 ? ",pl" : "");
     if (vg_dry(name, MODE, (int)BIAS, (int)RES, (int)STATS, tiles > bx ? 1 : 0, k.nchunks > 1 ? 1 : 0)) return VG_OK;
     // the two-panel instances (32-channel layers) finalise the InstanceNorm statistics of their output in the launch (last workgroup)
     const bool fin_here = STATS && k2.fin.ticket && k2.sums && ((NP == 2 && vg_tune("CONV_THIN2_FIN", 1)) || (NP == 1 && !RES && vg_tune("CONV_THIN1_FIN", 1)));
     if (!fin_here) k2.fin.ticket = nullptr;
-    hipLaunchKernelGGL((conv_thin_kernel<MODE, BIAS, RES, STATS, BSTAT, NP>), dim3(bx, ny, g.N), dim3(256), lds, s, g, k2);
+    hipLaunchKernelGGL((conv_thin_kernel<MODE, BIAS, RES, STATS, BSTAT, NP, PL>), dim3(bx, ny, g.N), dim3(256), lds, s, g, k2);
     if (fin_here) vg_fin_done = true;
     // (no finalisation tail in the one-panel instances: with it the 16 -> 16 residual instance ran 17 % slower even when the tail was not taken --
     // code placement, not registers: the allocation was unchanged -- and the sliding-window inference lost 1.5 ms per volume; vg_conv3d
@@ -549,6 +677,12 @@ static int launch_thin_np(const GatherIn& g, const ConvOut& k, int lds, hipStrea
 }
 template <int MODE, bool BIAS, bool RES, bool STATS, bool BSTAT = false>
 static int launch_thin(const GatherIn& g, const ConvOut& k, int np, hipStream_t s) {
+    if constexpr (BSTAT && MODE == VG_STAGE_PLAIN) {
+        // 16 -> 48 (dec0.cb1's data gradient): the three output panels looped over one staged halo
+        const int lds3 = vg_conv_thin_lds_bytes(g, 1, 3);
+        if (np == 1 && k.Cout == 48 && k.nchunks == 1 && 2 * lds3 <= VG_LDS_LIMIT && vg_tune("CONV_THIN_PL", 1))
+            return launch_thin_np<MODE, BIAS, RES, STATS, BSTAT, 1, 3>(g, k, lds3, s);
+    }
     const int lds = vg_conv_thin_lds_bytes(g, np);
     if (lds > VG_LDS_LIMIT) return VG_ELDS;
     if constexpr (!BSTAT) { if (np == 2) return launch_thin_np<MODE, BIAS, RES, STATS, BSTAT, 2>(g, k, lds, s); }

@@ -239,7 +239,7 @@ class KernelProfile:
         if variant:
             # one row per kernel TEMPLATE, as rocprofv3 names kernels: the run-time regimes behind '|' and the bs1 / bs2 flavour of the
             # thin specialist's statistics epilogue (one template, a kernel argument) are summed
-            tmpl = variant.split('|')[0].replace(',bs1>', ',bs>').replace(',bs2>', ',bs>')
+            tmpl = variant.split('|')[0].replace(',bs1>', ',bs>').replace(',bs2>', ',bs>').replace(',bs1,pl>', ',bs,pl>').replace(',bs2,pl>', ',bs,pl>')
             v = self.vrows.setdefault((kind, tmpl), [0, 0.0, [], 0.0])
             v[0] += 1; v[1] += flops; v[2].append((e0, e1)); v[3] += nbytes
             if layer:
