@@ -605,27 +605,49 @@ __global__ __launch_bounds__(256, 2) void conv32_kernel(const GatherIn g, const 
                 const f32x4 q4 = *(const __attribute__((address_space(1))) f32x4*)(uintptr_t)(p.rb + n * p.Cout + co);
                 for (int r = 0; r < 4; ++r) { rs4[r] = r4[r]; rb4[r] = q4[r]; }
             }
+            // the residual / accumulate operands of all the group's sub-tiles are requested up front: loaded where they are used, every sub-tile
+            // waited its own round trip (the loads cannot move above the stores of the sub-tiles before: p.out and p.res may alias)
+            bool inr_[MW];
+            float addv[MW][4];
 #pragma unroll
             for (int i = 0; i < MW; ++i) {
-                const bool inr = (dhw[i] & 1023) < remd && ((dhw[i] >> 10) & 1023) < remh && (dhw[i] >> 20) < remw;
-                if (!inr) continue;
+                inr_[i] = (dhw[i] & 1023) < remd && ((dhw[i] >> 10) & 1023) < remh && (dhw[i] >> 20) < remw;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) addv[i][r] = bias4[r];
+            }
+            if (p.res) {
+                Vec4<T> rv[MW];
+#pragma unroll
+                for (int i = 0; i < MW; ++i) vec4_load(rv[i], (const T*)p.res + tbase + (inr_[i] ? ooff[i] : 0) + 8 * j);
+#pragma unroll
+                for (int i = 0; i < MW; ++i) {
+                    float x[4]; vec4_unpack(rv[i], x);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) addv[i][r] += x[r] * rs4[r] + rb4[r];
+                }
+            }
+            if (p.accumulate) {
+                if (p.out_f32) {
+                    Vec4<float> ov[MW];
+#pragma unroll
+                    for (int i = 0; i < MW; ++i) vec4_load(ov[i], (const float*)p.out + tbase + (inr_[i] ? ooff[i] : 0) + 8 * j);
+#pragma unroll
+                    for (int i = 0; i < MW; ++i) { float x[4]; vec4_unpack(ov[i], x); for (int r = 0; r < 4; ++r) addv[i][r] += x[r]; }
+                } else {
+                    Vec4<bf16_t> ov[MW];
+#pragma unroll
+                    for (int i = 0; i < MW; ++i) vec4_load(ov[i], (const bf16_t*)p.out + tbase + (inr_[i] ? ooff[i] : 0) + 8 * j);
+#pragma unroll
+                    for (int i = 0; i < MW; ++i) { float x[4]; vec4_unpack(ov[i], x); for (int r = 0; r < 4; ++r) addv[i][r] += x[r]; }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < MW; ++i) {
+                if (!inr_[i]) continue;
                 const size_t o = tbase + ooff[i] + 8 * j;
                 float v[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = acc[i][4 * j + r] + bias4[r];
-                if (p.res) {
-                    Vec4<T> rv; vec4_load(rv, (const T*)p.res + o);
-                    float x[4]; vec4_unpack(rv, x);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += x[r] * rs4[r] + rb4[r];
-                }
-                if (p.accumulate) {
-                    float x[4];
-                    if (p.out_f32) { Vec4<float> ov; vec4_load(ov, (const float*)p.out + o); vec4_unpack(ov, x); }
-                    else { Vec4<bf16_t> ov; vec4_load(ov, (const bf16_t*)p.out + o); vec4_unpack(ov, x); }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += x[r];
-                }
+                for (int r = 0; r < 4; ++r) v[r] = acc[i][4 * j + r] + addv[i][r];
                 if (p.out_f32) {
                     *(f32x4*)((float*)p.out + o) = (f32x4){v[0], v[1], v[2], v[3]};
                 } else {

@@ -174,7 +174,8 @@ __global__ __launch_bounds__(256, VG_THIN_WPE) void conv_thin_kernel(const Gathe
     float* scs = (float*)(smem + HALO);
     float* stat = scs + 32;
     float* bsc = stat + 32 * NP * PL;                    // BSTAT: [scale | shift | rstd | -mean * rstd][16 NP PL channels of this workgroup]
-    int* tapb = (int*)(bsc + 64 * NP * PL);
+    float* ebs = bsc + 64 * NP * PL;                     // two panels: [bias | residual scale | residual shift][32 channels] (read in the epilogue)
+    int* tapb = (int*)(ebs + (NP > 1 ? 48 * NP : 0));
     int* utab = tapb + 32;
     constexpr int NCOLS = HH * HW * 2;
     int* xtab = utab + 2 * NCOLS;                        // axis tables of the whole grid (thin_axis_tables)
@@ -187,6 +188,13 @@ __global__ __launch_bounds__(256, VG_THIN_WPE) void conv_thin_kernel(const Gathe
 
     build_column_table(g, utab, tid);
     if (tid < 32 * NP * PL) stat[tid] = 0.f;
+    if constexpr (NP > 1 && (BIAS || RES)) {
+        if (tid < 16 * NP) {
+            const int c = cop + tid;
+            ebs[tid] = BIAS ? p.bias[c] : 0.f;
+            if (RES) { ebs[16 * NP + tid] = p.rs[n * p.Cout + c]; ebs[32 * NP + tid] = p.rb[n * p.Cout + c]; }
+        }
+    }
     if constexpr (BSTAT) {
         // per-channel constants of the statistics: from LDS in the epilogue (fetched from memory there, every tile waited an L2 round trip for them)
         constexpr int CW = 16 * NP * PL;
@@ -461,12 +469,12 @@ __global__ __launch_bounds__(256, VG_THIN_WPE) void conv_thin_kernel(const Gathe
             const T* const rptr = RES ? (const T*)p.res + obase + co0 + 16 * q : nullptr;
             f32x2 eb[2], ers[2], erb[2];
             if constexpr (NP == 1) { eb[0] = e_b[0][0]; eb[1] = e_b[0][1]; if (RES) { ers[0] = e_rs[0][0]; ers[1] = e_rs[0][1]; erb[0] = e_rb[0][0]; erb[1] = e_rb[0][1]; } }
-            else {              // (two panels: fetched here -- held across the MFMA loop they cost 24 registers the accumulators need)
-                const int c = co0 + 16 * q;
-                typedef const __attribute__((address_space(1))) f32x4 gf4;
-                if (BIAS) { const f32x4 t = *(gf4*)(uintptr_t)(p.bias + c); eb[0] = (f32x2){t[0], t[1]}; eb[1] = (f32x2){t[2], t[3]}; }
+            else {              // (two panels: fetched here, from LDS -- held across the MFMA loop they cost 24 registers the accumulators need;
+                                //  fetched from memory every tile waited an L2 round trip for them)
+                const float* eq = ebs + 4 * kg + 16 * q;
+                if (BIAS) { const f32x4 t = *(const f32x4*)eq; eb[0] = (f32x2){t[0], t[1]}; eb[1] = (f32x2){t[2], t[3]}; }
                 if (RES) {
-                    const f32x4 t = *(gf4*)(uintptr_t)(p.rs + n * p.Cout + c), u = *(gf4*)(uintptr_t)(p.rb + n * p.Cout + c);
+                    const f32x4 t = *(const f32x4*)(eq + 16 * NP), u = *(const f32x4*)(eq + 32 * NP);
                     ers[0] = (f32x2){t[0], t[1]}; ers[1] = (f32x2){t[2], t[3]}; erb[0] = (f32x2){u[0], u[1]}; erb[1] = (f32x2){u[2], u[3]};
                 }
             }
@@ -494,8 +502,22 @@ __global__ __launch_bounds__(256, VG_THIN_WPE) void conv_thin_kernel(const Gathe
                     }
                 }
             }
+            // RES: all eight rows of the residual are requested up front.  (Loaded where they are used, the compiler could not move them above
+            // the stores of the rows before -- p.out and p.res may alias for all it knows -- and every row pair waited its own round trip.)
+            // (Two panels: four rows at a time -- eight more registers spill there.)
+            constexpr int RRN = NP == 1 ? 8 : 4;
+            bf16x4 rr[RES ? 8 : 1];
 #pragma unroll
             for (int jp = 0; jp < 8; jp += 2) {
+                if constexpr (RES) {
+                    if (jp % RRN == 0) {
+#pragma unroll
+                        for (int j = jp; j < jp + RRN; ++j) {
+                            const bool ok = !MASKED || (dw_ok && j < nrow);
+                            rr[j] = *(const __attribute__((address_space(1))) bf16x4*)(uintptr_t)(ok ? rptr + j * rowpitch : rptr);
+                        }
+                    }
+                }
                 bf16x4 pk[2];
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
@@ -504,7 +526,7 @@ __global__ __launch_bounds__(256, VG_THIN_WPE) void conv_thin_kernel(const Gathe
                     f32x2 v0 = {acc[q][j][0], acc[q][j][1]}, v1 = {acc[q][j][2], acc[q][j][3]};
                     if (BIAS) { v0 += eb[0]; v1 += eb[1]; }
                     if (RES) {
-                        const bf16x4 r = *(const __attribute__((address_space(1))) bf16x4*)(uintptr_t)(ok ? rptr + j * rowpitch : rptr);
+                        const bf16x4 r = rr[RES ? j : 0];
                         const f32x2 r0 = {bf2f((bf16_t)r[0]), bf2f((bf16_t)r[1])}, r1 = {bf2f((bf16_t)r[2]), bf2f((bf16_t)r[3])};
                         v0 += r0 * ers[0] + erb[0]; v1 += r1 * ers[1] + erb[1];
                     }
@@ -619,7 +641,7 @@ __global__ __launch_bounds__(256, VG_THIN_WPE) void conv_thin_kernel(const Gathe
 // ------------------------------------------------------------------------------------------------
 int vg_conv_thin_lds_bytes(const GatherIn& g, int np, int pl) {
     const int AL = (g.tiles_h * TH + 2) + (g.tiles_w * TW + 2) + (g.tiles_d * TD + 2);          // axis tables of the whole grid, two sources
-    const int head = HALO + (32 + 32 * np * pl + 64 * np * pl + 32) * 4 + (2 * HH * HW * 2 + 2 * AL) * 4;
+    const int head = HALO + (32 + 32 * np * pl + 64 * np * pl + (np > 1 ? 48 * np : 0) + 32) * 4 + (2 * HH * HW * 2 + 2 * AL) * 4;
     if (pl > 1) return head + 1024 + 2 * 15 * 1024;                                             // two LDS-DMA buffers of one 16-row panel
     return head + 16 + 16 * np * (KCPAD * 2 + 16);
 }
