@@ -68,17 +68,23 @@ def time_infer(eng, device, steps, warmup, precision):
     vol = (torch.rand(256, 256, 128, 1, generator=torch.Generator().manual_seed(1)) * 2 - 1).to(device)
     kw = dict(stride=(50, 50, 50), complete=True, padFactor=0.1, process_img=True, window_batch=2, precision=precision)
     out = None
-    for _ in range(max(warmup, 1)):
+    for _ in range(max(warmup, 2)):                     # >= 2: the first volume of a precision loads its library / repacks / grows the arena
         out = eng.stitch_subvolumes('gen_IS', vol, (128, 128, 128), **kw)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
+    steps = max(steps, 5)
+    per = []
+    for _ in range(steps):                              # volume by volume: min and median are reported beside the mean
+        t0 = time.perf_counter()
         out = eng.stitch_subvolumes('gen_IS', vol, (128, 128, 128), **kw)
-    torch.cuda.synchronize()
-    el = (time.perf_counter() - t0) / steps
+        torch.cuda.synchronize()
+        per.append(time.perf_counter() - t0)
+    el = sum(per) / steps
+    med = sorted(per)[steps // 2]
     return {'workload': 'GanMonitor.stitch_subvolumes 256x256x128, 50 windows of 128^3, stride 50, pad 0.1 (BASELINE config 5)',
-            'dtype': precision or 'bf16', 'ms_per_volume': el * 1e3, 'volumes_per_sec': 1.0 / el, 'Mvoxels_per_sec': 256 * 256 * 128 / el / 1e6,
-            'generator_tflops': 50 * 2 * 149.65e9 / el / 1e12, 'windows': 50, 'steps': steps, 'finite': bool(torch.isfinite(out).all())}
+            'dtype': precision or 'bf16', 'ms_per_volume': el * 1e3, 'ms_per_volume_min': min(per) * 1e3, 'ms_per_volume_median': med * 1e3,
+            'volumes_per_sec': 1.0 / el, 'Mvoxels_per_sec': 256 * 256 * 128 / el / 1e6,
+            'generator_tflops': 50 * 2 * 149.65e9 / el / 1e12, 'windows': 50, 'steps': steps, 'warmup': max(warmup, 2),
+            'finite': bool(torch.isfinite(out).all())}
 
 
 def time_config(dims, B, device, steps=20, warmup=5, graph=True, generator='resUnet'):
@@ -201,8 +207,8 @@ def bench_infer(args, device):
     import torch  # noqa: F401
     from van_gan_amd import VanGan
     eng = VanGan((128, 128, 128), batch_size=2, device=device, seed=0)
-    r = time_infer(eng, device, args.steps, args.warmup, 'fp16')
     rb = time_infer(eng, device, args.steps, args.warmup, None)
+    r = time_infer(eng, device, args.steps, args.warmup, 'fp16')
     print(json.dumps({'metric': 'sliding-window inference Mvoxels/s (256x256x128 volume, 50 windows of 128^3, fp16)',
                       'value': r['Mvoxels_per_sec'], 'unit': 'Mvoxels/s', 'volumes_per_sec': r['volumes_per_sec'], 'n_gpus': 1,
                       'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': r['ms_per_volume'], 'higher_is_better': True,
@@ -355,8 +361,11 @@ def main():
     infer = None
     if rank == 0 and world == 1 and args.size == 128 and not args.no_infer:
         # BASELINE config 5 beside the headline: the same engine's gen_IS, fp16 storage (and the bf16 figure next to it)
-        infer = time_infer(eng, device, 3, 1, 'fp16')
-        infer['bf16_ms_per_volume'] = time_infer(eng, device, 3, 1, None)['ms_per_volume']
+        # bf16 first (the engine's own library is warm), then the fp16 build; 2 warm-up volumes + 5 timed ones each
+        inf_b = time_infer(eng, device, 5, 2, None)
+        infer = time_infer(eng, device, 5, 2, 'fp16')
+        infer['bf16_ms_per_volume'] = inf_b['ms_per_volume']
+        infer['bf16_ms_per_volume_median'] = inf_b['ms_per_volume_median']
     roof = None
     summ = None
     byvar = None
@@ -427,7 +436,11 @@ def main():
     if rank == 0 and world == 1 and args.size == 128 and not args.no_ddp_path:
         ddp = ddp_fake(args)
 
+    dev_names = None
     if world > 1:
+        mine = '%d:cuda:%d:%s' % (rank, local, torch.cuda.get_device_name(local))
+        dev_names = [None] * world
+        dist.all_gather_object(dev_names, mine)
         dist.barrier()
     if rank == 0:
         out = {
@@ -441,6 +454,10 @@ def main():
             'losses': res, 'roofline': roof, 'cpu_baseline': cpu, 'inference': infer,
             'arena_peak_gb': eng.arena.peak / 1e9, 'ddp_path': ddp,
         }
+        if world > 1:
+            # what the process group actually was (the driver can check it against --gpus): backend, ranks, devices
+            out['distributed'] = {'backend': dist.get_backend(), 'world_size': dist.get_world_size(), 'device_count': torch.cuda.device_count(),
+                                  'devices': dev_names, 'one_device_debug': one_dev}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

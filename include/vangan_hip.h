@@ -284,16 +284,20 @@ int vg_actnorm_bwd_apply(const vg_actnorm_bwd_desc* d, vg_stream_t stream);
 int vg_actnorm_bwd_apply2(const vg_actnorm_bwd_desc* d1, const vg_actnorm_bwd_desc* d2, vg_stream_t stream);
 /* both passes in one call (statistics only when d->norm) */
 int vg_actnorm_bwd(const vg_actnorm_bwd_desc* d, vg_stream_t stream);
-/* The kernel gradient of a 1x1x1 convolution of a SINGLE-channel input x followed by InstanceNorm (no activation), WITHOUT the gradient
- * of its output: the stem's shortcut (resunet_model.py:96-99; its input is the volume, so no data gradient exists).  Its output
- * w[c]*x + b[c] normalises to xhat = w[c]*rstd*(x - mean x): the loss depends on w[c] only through eps in rstd, and
- *     dL/dw[c] = sum_n eps * gamma[c] * rstd[n][c]^2 * (sum_v dn*xhat)[n][c] / w[c],        dL/db[c] = 0 identically,
- * with sum_v dn*xhat the second moment of vg_actnorm_bwd_stats (red: [VG_STRIPES][N][C][2]).  Well conditioned where the explicit path
- * (apply pass -> gradient tensor -> weight-gradient launch) sums a million cancelling terms.  w: the C kernel weights as the forward
- * used them (round16 != 0: rounded to the library's 16-bit storage format first); adds dw[C]; dgamma / dbeta (optional) as the apply
- * pass would add them. */
-int vg_in_scale_invariant_wgrad(const float* red, const float* rstd, const float* gamma, const float* w, int N, int C, float eps,
-                                int round16, float* dw, float* dgamma, float* dbeta, vg_stream_t stream);
+/* The stem's shortcut in the backward pass (resunet_model.py:96-99: Conv3D(16, 1x1x1)(x) -> InstanceNorm, no activation; its input is the
+ * single-channel volume, so no data gradient exists).  The branch's output w[c]*x + b[c] normalises to
+ * xhat[c] = w[c]*rs[c]*(x - mean x), rs[c] = (w[c]^2 var x + eps)^-1/2: the loss sees w[c] only through eps, and with the two moments
+ * R0 = sum_v g, T = sum_v g*x of the gradient g of the block output [N][S][C] (16-bit storage or fp32) against x [N][S] (fp32),
+ *     dL/dw[c] += sum_n eps*gamma[c]*rs^3*(T - mean(x) R0),   dgamma[c] += sum_n w[c]*rs*(T - mean(x) R0),   dbeta[c] += sum_n R0,
+ *     dL/db[c] = 0 identically
+ * -- no apply pass, no gradient tensor, no weight-gradient launch, and no read of the stored branch output (whose 16-bit rounding the
+ * 1/w of the older statistics-based form amplified to 6-13 % of this gradient).  Deterministic: part[N][G][2C+2] doubles receive one
+ * partial sum per workgroup, the workgroup drawing the last of the N*G tickets (*ticket zeroed by the caller) adds them in a fixed
+ * order.  G = vg_stem_short_bwd_workgroups(N, S, C); C in {8, 16, 32, 64}.  w: the C kernel weights as the forward used them
+ * (round16 != 0: rounded to the library's 16-bit storage format first). */
+int vg_stem_short_bwd_workgroups(int N, int64_t S, int C);
+int vg_stem_short_bwd(const void* g, int g_f32, const float* x, int N, int64_t S, int C, const float* w, const float* gamma, float eps,
+                      int round16, float* dw, float* dgamma, float* dbeta, double* part, int G, unsigned* ticket, vg_stream_t stream);
 /* dgamma[c] += sum_{stripes,n} red[.][n][c][1], dbeta[c] += sum red[.][n][c][0] */
 int vg_in_param_grads(const float* red, int N, int C, float* dgamma, float* dbeta, vg_stream_t stream);
 
@@ -442,6 +446,11 @@ int vg_dropout_mask_dev(float* out, int64_t n, float rate, uint64_t seed, const 
                         vg_stream_t stream);
 int vg_adam_clip_dev(float* w, const float* g, float* m, float* v, const int64_t* seg_off_dev, int T, int64_t total, float* norms,
                      const float* lr_t_dev, float beta1, float beta2, float eps, float clipnorm, float grad_scale, vg_stream_t stream);
+
+/* Writes that 32-byte parameter block: bytes [0, 8) the Philox counter base, [8, 12) the noise standard deviation, [16, 32) lr_t of
+ * gen_IS, gen_SI, disc_I, disc_S (the reference's four optimizers, vangan.py:220-235).  The values travel as KERNEL ARGUMENTS, i.e. they
+ * are bound at enqueue time: a host that enqueues step N+1 before step N has executed cannot disturb step N (block: 8-byte aligned). */
+int vg_set_step_params(void* block, uint64_t offset, float std, float lr0, float lr1, float lr2, float lr3, vg_stream_t stream);
 
 /* Stand-in for the RCCL SUM all-reduce of a gradient bucket (the implicit all-reduce of optimizer.minimize under MirroredStrategy,
  * vangan.py:426-438; main.py:22) on a box with ONE GPU, so that the data-parallel schedule -- communication stream, per-bucket

@@ -152,8 +152,8 @@ def test_stream_schedule_does_not_change_gradients():
 
 def test_stem_shortcut_backward_from_the_statistics_pass():
     """The stem shortcut (1x1x1 convolution of the single-channel volume + InstanceNorm, resunet_model.py:96-99) has no data gradient and
-    its normalised output does not depend on the kernel's magnitude, only on eps: dL/dw = eps * gamma * rstd^2 * sum(dn * xhat) / w, a closed
-    form in the statistics pass's second moment (vg_in_scale_invariant_wgrad), dL/db = 0.  Against float64 autograd through the oracle, and
+    its normalised output does not depend on the kernel's magnitude, only on eps: dL/dw = eps * gamma * rs^3 * sum(d_out * (x - mean x)), a
+    closed form in two moments of the block-output gradient against the volume (vg_stem_short_bwd), dL/db = 0.  Against float64 autograd through the oracle, and
     beside the explicit path (apply pass -> gradient tensor -> weight-gradient launch; nets._STEM_AUX = False), fp32 storage, batch 2: the
     closed form must be as close to the oracle as the explicit sum of a million terms, and everything else unchanged."""
     from van_gan_amd import nets

@@ -122,3 +122,58 @@ def test_launch_list_replay_follows_the_host_schedules_bf16():
     torch.cuda.synchronize()
     for n in rep.stores:
         assert torch.equal(rep.stores[n].w, w_before[n])
+
+
+def test_unsynchronised_replays_keep_their_own_step_scalars():
+    """with sync=False the host runs ahead of the device, so the per-step scalars must be bound when a replay is ENQUEUED
+    (vg_set_step_params carries them as kernel arguments).  Learning-rate sequence 0, 0, 2e-4, 0, 0 without a single synchronisation:
+    the one non-zero rate must reach exactly its own step -- a parameter block refreshed through a pinned mirror + asynchronous copy
+    hands step 2 the rate of step 3 (0: the weights would not move at all)."""
+    from van_gan_amd.vangan import NETS
+    eager, rep, rI, rS = _pair('fp32')
+    w0 = {n: rep.stores[n].w.clone() for n in NETS}
+    seq = (0.0, 0.0, 2e-4, 0.0, 0.0)
+    for lr in seq:
+        eager.lr = lr
+        eager.train_step(rI, rS, sync=False)
+    for lr in seq:
+        rep.lr = lr
+        rep.train_step_replay(rI, rS, sync=False)
+    torch.cuda.synchronize()
+    assert rep.rng_offset == eager.rng_offset
+    for n in NETS:
+        moved = float((rep.stores[n].w - w0[n]).abs().max())
+        assert moved > 1e-5, (n, 'the step with lr = 2e-4 did not update the weights', moved)
+        # one Adam step from zero moments moves every weight by ~ +-lr (the sign of its gradient): the two engines' updates agree except
+        # where a near-zero gradient changes sign with the order of the float atomics
+        ue, ur = (eager.stores[n].w - w0[n]).double(), (rep.stores[n].w - w0[n]).double()
+        d = float((ur - ue).norm() / ue.norm())
+        assert d < 0.2, (n, d)
+    # the same through the HIP graph
+    eager2, graph, rI, rS = _pair('fp32')
+    graph.capture_train_step()
+    w0 = {n: graph.stores[n].w.clone() for n in NETS}
+    for lr in seq:
+        graph.lr = lr
+        graph.train_step_graph(rI, rS, sync=False)
+    torch.cuda.synchronize()
+    for n in NETS:
+        assert float((graph.stores[n].w - w0[n]).abs().max()) > 1e-5, n
+
+
+def test_replay_recorded_after_forward_only_calls():
+    """test_step / generate before the FIRST train_step_replay leave a small high-water mark in the arenas' zero pools; the
+    recorded reset must still clear everything a train step takes from the pool (tickets of the InstanceNorm finalisation tails, loss
+    accumulators), or every replay after the recorded step runs on stale tickets.  Three steps with lr = 0 against an eager engine."""
+    from van_gan_amd.vangan import RESULT_KEYS
+    eager, rep, rI, rS = _pair('fp32')
+    for e in (eager, rep):
+        e.lr = 0.0
+        e.test_step(rI, rS)
+        e.generate('gen_IS', rI)
+    for step in range(3):
+        re = eager.train_step(rI, rS)
+        rr = rep.train_step_replay(rI, rS)
+        for k in RESULT_KEYS:
+            assert abs(re[k] - rr[k]) <= 2e-5 * abs(re[k]) + 1e-7, (step, k, re[k], rr[k])
+        _grads_agree(eager, rep, 'replay after test_step, step %d' % step)

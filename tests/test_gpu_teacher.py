@@ -15,14 +15,11 @@ storage of the HIP activation gradients (one rounding per layer on the way down)
 (sum, sum of squares) instead of two passes.
 
 Stated tolerance (measured values are printed): every parameter tensor of all four networks relative L2 <= 8e-2 and cosine >= 0.997
-(measured: all but the generators' stem tensors <= 3e-2 / >= 0.999).  ONE tensor has a tolerance of its own: the 16-element stem.short.w
-(relative L2 <= 2e-1, cosine >= 0.98).  The stem's shortcut is a 1x1x1 convolution of the single-channel volume in front of an
-InstanceNorm: its output normalises to the same tensor whatever w is, so dL/dw exists only through eps -- an O(eps) quantity that the
-product path gets from the second moment of the norm's backward statistics (vg_in_scale_invariant_wgrad), i.e. from a sum over every
-voxel whose terms cancel to ~1e-4 of their size.  Run to run it moves with the order of the float atomics in the statistics of every
-block below it: 3e-2 .. 1.2e-1 over 80 runs of round 5's final sources (10 above the common 8e-2, none above 1.2e-1), with every switchable
-change of the round off still 1 of 16 above 8e-2; 0 of 16 at the round's first commit, which a 12 % rate produces one time in eight -- the
-2e-2 .. 6e-2 noted in round 4 came from a handful of runs (tools/r05_flake.sh);
+(measured: all but the generators' stem tensors <= 3e-2 / >= 0.999) -- ONE tolerance for every tensor.  Round 5 had loosened it for the
+16-element stem.short.w (3e-2 .. 1.2e-1 run to run); round 6 found the cause (tools/r06_stem_probe.py: not the order of the float
+atomics -- float64 sums over the stored tensors reproduced the kernel to 1e-5 -- but the 16-bit rounding of the STORED shortcut output,
+which the closed form's 1/w amplified for channels with a small kernel weight) and removed it: vg_stem_short_bwd takes xhat from the
+fp32 volume itself, 5e-3 .. 2e-2 against the oracle, deterministic;
 tensors whose gradient is analytically ~0 (biases in front of an InstanceNorm) absolutely, <= 5e-3 of the network's largest gradient
 norm; whole-network cosine >= 0.9995 (measured 0.99998-1.00000, rel 4e-4 discriminators / 3e-3 - 7e-3 generators).  A dropped term in a fused launch (first-writer bits, a missing accumulate, the wrong half of a paired
 tensor) moves single tensors by O(1) and fails this."""
@@ -32,8 +29,6 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
-
-STEM_SHORT = {'stem.short.w': (2e-1, 0.98)} if os.environ.get('VG_TEST_STEM_TOL', '1') != '0' else None          # see the module docstring (VG_TEST_STEM_TOL=0: the common tolerance, for tools/r05_flake.sh)
 
 from oracle import vangan_oracle as O  # noqa: E402
 from test_gpu_nets import grad_report, perturb, rel_l2  # noqa: E402
@@ -129,8 +124,7 @@ def _run(dims, B, seed, env=None):
 
 def _check(got, grads, label):
     for net in ('disc_I', 'disc_S', 'gen_IS', 'gen_SI'):
-        cos = grad_report(got[net], grads[net], '%s %s (teacher-forced)' % (label, net), rel_tol=8e-2, cos_tol=0.997, abs_tol=5e-3,
-                          special=STEM_SHORT)
+        cos = grad_report(got[net], grads[net], '%s %s (teacher-forced)' % (label, net), rel_tol=8e-2, cos_tol=0.997, abs_tol=5e-3)
         assert cos >= 0.9995, (net, cos)
 
 
@@ -197,5 +191,5 @@ def test_teacher_forced_generator_128x128x64():
     # 1 M voxels; with that gradient STORED in bf16 the rounding errors do not cancel as the exact values do (measured 1.7e-2 of the
     # largest tensor norm on stem.conv1.b, which sums the full-resolution 16-channel gradient)
     cos = grad_report(st.export(st.g), {k: v.grad for k, v in Pr.items()}, 'generator 128x128x64 bf16 (teacher-forced)', rel_tol=8e-2, cos_tol=0.997,
-                      abs_tol=4e-2, special=STEM_SHORT)
+                      abs_tol=4e-2)
     assert cos >= 0.9995, cos

@@ -4,7 +4,9 @@
 #   the same tools as the 128^3 workload.  Output: gpurun_out/prof_<tag>_c3/ and profiles/<tag>_config3_*.
 tag=$1; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_${tag}_c3; mkdir -p $O
 export VG_NO_REBUILD=1
-A="--dims 128 128 64 --batch 2 --no-cpu-baseline --no-roofline --no-synced"
+# --no-replay: every rocprof pass must see exactly warmup + steps train steps (tools/hbm_pmc.py and tools/mfma_pmc.py divide by them;
+# round 5 ran the replay leg too and reported twice the launches and bytes "per step")
+A="--dims 128 128 64 --batch 2 --no-cpu-baseline --no-roofline --no-synced --no-replay"
 cd /tmp; export TMPDIR=/tmp
 VG_LANES=0 VG_SIDE_STREAM=0 VG_OPT_STREAM=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 5 --warmup 2 $A > $O/stats.log 2>&1
 VG_LANES=0 VG_SIDE_STREAM=0 VG_OPT_STREAM=0 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- python3 $R/bench.py --steps 1 --warmup 1 $A > $O/fetch.log 2>&1

@@ -1,4 +1,6 @@
 #!/bin/bash
+# needs a development build of the library: VG_EXTRA_DEFS=-DVG_DEBUG_ABLATE python -m van_gan_amd.build --force (the production library refuses the knob)
+export VG_EXTRA_DEFS=-DVG_DEBUG_ABLATE
 # timing ablations of the panel-loop thin data gradient (conv_thin_kernel<0,..,true,1,3>): VG_THIN_DBG bits 1 no statistics flush,
 # 2 no pre-norm loads, 4 no MFMA loop, 8 no epilogue, 16 staging only for a workgroup's first tile (results are wrong: timing only)
 for dbg in "$@"; do

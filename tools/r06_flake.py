@@ -1,0 +1,34 @@
+"""How often does the teacher-forced 32^3 batch-2 train step leave the COMMON tolerance (rel 8e-2 / cos 0.997 per tensor), and what is the
+error of the 16-element stem.short.w -- the tensor round 5 had given a tolerance of its own -- run by run?  One process, `runs` engines.
+usage: python tools/r06_flake.py [runs=25]"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import test_gpu_teacher as T  # noqa: E402
+
+runs = int(sys.argv[1]) if len(sys.argv) > 1 else 25
+fails, vals, worst_any = 0, [], []
+for i in range(runs):
+    got, grads = T._run((32, 32, 32), 2, seed=1234)
+    ok = True
+    for net in ('gen_IS', 'gen_SI'):
+        a, b = got[net]['stem.short.w'].double().flatten(), grads[net]['stem.short.w'].double().flatten()
+        vals.append(float((a - b).norm() / b.norm()))
+    try:
+        sys.stdout = open(os.devnull, 'w')
+        T._check(got, grads, 'run %d' % i)
+    except AssertionError as e:
+        ok = False
+        msg = str(e)[:300]
+    finally:
+        sys.stdout = sys.__stdout__
+    if not ok:
+        fails += 1
+        print('run %d FAILED: %s' % (i, msg), flush=True)
+    print('run %d  stem.short.w rel: gen_IS %.4f gen_SI %.4f  %s' % (i, vals[-2], vals[-1], 'ok' if ok else 'FAIL'), flush=True)
+    torch.cuda.empty_cache()
+print('failures %d / %d at the common tolerance; stem.short.w rel min %.4f median %.4f max %.4f' % (fails, runs, min(vals), sorted(vals)[len(vals) // 2], max(vals)))

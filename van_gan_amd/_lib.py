@@ -92,8 +92,9 @@ _SIGS = {
     'vg_actnorm_bwd_apply': ([C.POINTER(ActNormBwdDesc), c_void_p], c_int),
     'vg_actnorm_bwd_apply2': ([C.POINTER(ActNormBwdDesc), C.POINTER(ActNormBwdDesc), c_void_p], c_int),
     'vg_actnorm_bwd': ([C.POINTER(ActNormBwdDesc), c_void_p], c_int),
-    'vg_in_scale_invariant_wgrad': ([c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, C.c_float, c_int, c_void_p, c_void_p, c_void_p,
-                                    c_void_p], c_int),
+    'vg_stem_short_bwd_workgroups': ([c_int, c_i64, c_int], c_int),
+    'vg_stem_short_bwd': ([c_void_p, c_int, c_void_p, c_int, c_i64, c_int, c_void_p, c_void_p, C.c_float, c_int, c_void_p, c_void_p, c_void_p,
+                          c_void_p, c_int, c_void_p, c_void_p], c_int),
     'vg_in_param_grads': ([c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p], c_int),
     'vg_concat_bwd': ([c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p], c_int),
     'vg_shortcut_dgrad_concat': ([C.POINTER(ConvDesc), c_void_p, c_void_p, c_int, c_int, c_void_p], c_int),
@@ -131,6 +132,7 @@ _SIGS = {
     'vg_dropout_mask_dev': ([c_void_p, c_i64, c_float, c_u64, c_void_p, c_u64, c_void_p], c_int),
     'vg_adam_clip_dev': ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_i64, c_void_p, c_void_p, c_float,
                           c_float, c_float, c_float, c_float, c_void_p], c_int),
+    'vg_set_step_params': ([c_void_p, c_u64, c_float, c_float, c_float, c_float, c_float, c_void_p], c_int),
     'vg_memset_zero': ([c_void_p, c_i64, c_void_p], c_int),
     'vg_copy_bytes': ([c_void_p, c_void_p, c_i64, c_void_p], c_int),
     'vg_f32_to_bf16': ([c_void_p, c_void_p, c_i64, c_void_p], c_int),

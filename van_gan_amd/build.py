@@ -23,12 +23,33 @@ def _hipcc() -> str:
 
 
 HASHFILE = LIB + '.srchash'
+FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17']
+
+
+def _extra_defs():
+    """Development builds only, e.g. VG_EXTRA_DEFS=-DVG_DEBUG_ABLATE (the timing-ablation knobs of vg_conv_thin.hip, whose results are
+    wrong by design, exist only in such a build)."""
+    return os.environ.get('VG_EXTRA_DEFS', '').split()
+
+
+_CC_ID = None
+
+
+def _compiler_id() -> str:
+    """`hipcc --version`: objects of another compiler are never linked with fresh ones."""
+    global _CC_ID
+    if _CC_ID is None:
+        try:
+            _CC_ID = subprocess.run([_hipcc(), '--version'], stdout=subprocess.PIPE, stderr=subprocess.STDOUT).stdout.decode()
+        except OSError:
+            _CC_ID = 'unknown'
+    return _CC_ID
 
 
 def _src_hash() -> str:
     """Content hash of every source that goes into the library (mtimes do not survive the copy to the GPU box)."""
     import hashlib
-    h = hashlib.sha256()
+    h = hashlib.sha256(' '.join(_extra_defs()).encode())
     deps = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC)) + [os.path.join(HERE, '..', 'include', 'vangan_hip.h')]
     for d in deps:
         h.update(os.path.basename(d).encode())
@@ -61,9 +82,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 
 def _obj_hash(src: str, defs) -> str:
-    """What an object file depends on: its source, every header / include file of csrc/, the public header, the flags."""
+    """What an object file depends on: its source, every header / include file of csrc/, the public header, the whole command line
+    and the compiler's identity."""
     import hashlib
-    h = hashlib.sha256(' '.join(defs).encode())
+    h = hashlib.sha256((' '.join(FLAGS + list(defs)) + '\n' + _compiler_id()).encode())
     deps = [os.path.join(CSRC, src)] + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if not f.endswith('.hip'))
     deps.append(os.path.join(HERE, '..', 'include', 'vangan_hip.h'))
     for d in deps:
@@ -82,6 +104,7 @@ def _build_locked(verbose: bool) -> str:
         for s in SOURCES:
             o = os.path.join(HERE, 'build', tag + s.replace('.hip', '.o'))
             objs[lib].append(o)
+            defs = defs + _extra_defs()
             oh = _obj_hash(s, defs)
             try:                                  # incremental: an object whose inputs did not change is kept
                 with open(o + '.hash') as f:
@@ -89,14 +112,22 @@ def _build_locked(verbose: bool) -> str:
                         continue
             except OSError:
                 pass
-            cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17'] + defs + ['-c', os.path.join(CSRC, s), '-o', o]
+            # the object is written beside its final name and renamed on success, and its old hash goes first: a compile that is
+            # killed half-way leaves neither a truncated object under the final name nor a hash that vouches for one
+            try:
+                os.remove(o + '.hash')
+            except OSError:
+                pass
+            otmp = o + '.tmp.%d' % os.getpid()
+            cmd = [hipcc] + FLAGS + defs + ['-c', os.path.join(CSRC, s), '-o', otmp]
             if verbose:
                 print(' '.join(cmd))
-            procs.append((tag + s, o, oh, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-    for s, o, oh, p in procs:
+            procs.append((tag + s, o, otmp, oh, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for s, o, otmp, oh, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError('hipcc failed on %s:\n%s' % (s, out.decode()))
+        os.replace(otmp, o)
         with open(o + '.hash', 'w') as f:
             f.write(oh)
     for _, lib, _ in variants:

@@ -16,6 +16,21 @@
 //   * staging is the lean routine (vg_gather.h) with a compile-time transform, its 360 columns x 2 D-segments dealt out evenly.
 // Everything else (persistent workgroups, tables, InstanceNorm statistics carried in registers) follows conv_kernel.
 #include "vg_conv_common.h"
+#include <stdio.h>
+
+// Timing-ablation knobs (VG_THIN_DBG, VG_WT_DBG: skip the MFMA loop / the commit / the statistics flush -- the RESULTS ARE WRONG, timing
+// only, tools/r05_*_dbg.sh).  They act only in a development build (VG_EXTRA_DEFS=-DVG_DEBUG_ABLATE, van_gan_amd/build.py); the
+// production library refuses the call (VG_EINVAL, loudly) when one of them is set, so that a stray environment variable cannot corrupt
+// the gradients of dec0.cb1 / stem.cb silently.
+static int vg_ablate_knob(const char* key) {
+    const int v = vg_tune(key, 0);
+#ifdef VG_DEBUG_ABLATE
+    return v;
+#else
+    if (v != 0) { fprintf(stderr, "libvangan_hip: VG_%s=%d is a timing-ablation knob of a -DVG_DEBUG_ABLATE build; this library refuses it\n", key, v); return -1; }
+    return 0;
+#endif
+}
 #include "vg_dma_common.h"
 #include <type_traits>
 #include <cstdio>
@@ -681,7 +696,8 @@ static int launch_thin_np(const GatherIn& g, const ConvOut& k, int lds, hipStrea
     const int ny = k.Cout / (16 * NP * PL);
     const int wg = vg_tune("CONV_THIN_WGS", 0) > 0 ? vg_tune("CONV_THIN_WGS", 0) : 256 * per_cu;
     int bx = wg / (ny * g.N); if (bx < 1) bx = 1; if (bx > tiles) bx = tiles;
-    ConvOut k2 = k; k2.xw = 0; k2.dbg = PL > 1 ? vg_tune("THIN_DBG", 0) : 0;
+    ConvOut k2 = k; k2.xw = 0; k2.dbg = PL > 1 ? vg_ablate_knob("THIN_DBG") : 0;
+    if (k2.dbg < 0) return VG_EINVAL;
     if (vg_tune("CONV_THIN_XCD", 1) && bx >= 16 && tiles >= 4 * bx) { bx &= ~7; k2.xw = 1; }
     // bs1 / bs2: IN-backward statistics in the epilogue, of a plain / a virtually concatenated (half-resolution + skip) pre-norm tensor
     char name[96];
@@ -991,7 +1007,9 @@ int vg_wgrad_thin(const vg_conv_desc* d, const void* dy, int dy_f32, const int32
     if (vg_dry("wgrad_thin<m%d>|ch%d|walk%d", g.lean, nchunks > 1 ? 1 : 0, tiles > bx ? 1 : 0)) return VG_OK;
     float* part2 = scratch + slab_f;
     unsigned* tickets = (unsigned*)(part2 + part2_f);
-    WgThin p = {dy, scratch, dw, db, Cin, nslab, vg_tune("WT_DBG", 0), tickets, nchunks * 28, xw};
+    const int wt_dbg = vg_ablate_knob("WT_DBG");
+    if (wt_dbg < 0) return VG_EINVAL;
+    WgThin p = {dy, scratch, dw, db, Cin, nslab, wt_dbg, tickets, nchunks * 28, xw};
     const dim3 grid(bx, nchunks, d->N);
     if (g.lean == VG_STAGE_PLAIN) {
         static bool a0 = false;

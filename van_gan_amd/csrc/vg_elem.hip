@@ -432,31 +432,114 @@ __global__ void in_param_grads_kernel(const float* red, int N, int C, float* dga
     for (int n = 0; n < N * VG_STRIPES; ++n) { a += red[((size_t)n * C + c) * 2]; b += red[((size_t)n * C + c) * 2 + 1]; }
     dbeta[c] += a; dgamma[c] += b;
 }
-__global__ void in_scale_invariant_wgrad_kernel(const float* red, const float* rstd, const float* gamma, const float* w, int N, int C,
-                                                float eps, int round16, float* dw, float* dgamma, float* dbeta) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float acc = 0.f, dg = 0.f, db = 0.f;
-    for (int n = 0; n < N; ++n) {
-        float r0 = 0.f, r1 = 0.f;
-        for (int t = 0; t < VG_STRIPES; ++t) { const float* r = red + (((size_t)t * N + n) * C + c) * 2; r0 += r[0]; r1 += r[1]; }
-        const float rs = rstd[n * C + c];
-        acc += rs * rs * r1;
-        db += r0; dg += r1;
+// Kernel gradient (+ the norm's gamma / beta gradients) of the stem's shortcut: a 1x1x1 convolution of the SINGLE-channel volume x in
+// front of an InstanceNorm.  Its output w*x + b normalises to xhat[c] = w[c]*rs[c]*(x - mean x), rs[c] = (w[c]^2 var x + eps)^-1/2, so
+// everything the backward needs is two per-channel moments of the output gradient g against the volume itself,
+//     R0[n][c] = sum_v g[n][v][c],       T[n][c] = sum_v g[n][v][c] * x[n][v],       A = T - mean(x) * R0
+//     dL/dw[c] += sum_n eps * gamma[c] * rs^3 * A,    dL/dgamma[c] += sum_n w[c] * rs * A,    dL/dbeta[c] += sum_n R0,    dL/db = 0.
+// Round 5 took xhat from the STORED shortcut tensor instead; for a channel with a small kernel weight that tensor is b + w*x rounded to
+// 16 bits -- a handful of levels -- and the closed form, which has 1/w in it, amplified the quantisation to 6-13 % of the gradient's norm
+// (tools/r06_stem_probe.py: float64 sums over the stored tensors reproduce the old kernel to 1e-5, so it was never the summation order).
+// x is exact (fp32), 8x fewer bytes than the stored tensor, and the result is deterministic: per-workgroup partial sums in double, added
+// up in a fixed order by the workgroup that draws the last ticket.
+template <typename T>
+__global__ __launch_bounds__(256) void stem_short_bwd_kernel(const T* g, const float* x, int N, int64_t S, int C, const float* w, const float* gamma,
+                                                             float eps, int round16, float* dw, float* dgamma, float* dbeta, double* part,
+                                                             unsigned* ticket) {
+    __shared__ double sm[4][8][18];
+    __shared__ double fin[256][4];
+    __shared__ int last;
+    const int gpc = C >> 3, vpb = 256 / gpc, tid = threadIdx.x, cg = tid % gpc, vl = tid / gpc, n = blockIdx.y, G = gridDim.x, NV = 2 * C + 2;
+    float r0[8], t[8], sx = 0.f, sxx = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { r0[j] = 0.f; t[j] = 0.f; }
+    const T* gn = g + (size_t)n * S * C + cg * 8;
+    const float* xn = x + (size_t)n * S;
+    for (int64_t v = (int64_t)blockIdx.x * vpb + vl; v < S; v += (int64_t)G * vpb) {
+        float gv[8];
+        load8<T>(gn + v * C, gv);
+        const float xv = xn[v];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { r0[j] += gv[j]; t[j] = fmaf(gv[j], xv, t[j]); }
+        sx += xv; sxx = fmaf(xv, xv, sxx);
     }
-    const float wc = round16 ? bf2f(f2bf(w[c])) : w[c];
-    // w -> 0 (a pruned / zero-initialised checkpoint, or a weight that underflows in the 16-bit format): the closed form is 0/0 -- xhat
-    // and with it sum dn*xhat vanish with w -- and one NaN here would reach every generator parameter through the clip norm.  The
-    // channel's output is constant then (normalises to beta): the statistics carry no gradient for it, and none is added.
-    if (fabsf(wc) >= 1e-30f) dw[c] += eps * gamma[c] * acc / wc;
-    if (dgamma) { dgamma[c] += dg; dbeta[c] += db; }
+    double d[18];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { d[j] = r0[j]; d[8 + j] = t[j]; }
+    d[16] = sx; d[17] = sxx;
+    for (int o = 32; o >= gpc; o >>= 1) {
+#pragma unroll
+        for (int k = 0; k < 18; ++k) d[k] += __shfl_xor(d[k], o);
+    }
+    const int lane = tid & 63, wv = tid >> 6;
+    if (lane < gpc) {
+#pragma unroll
+        for (int k = 0; k < 18; ++k) sm[wv][lane][k] = d[k];
+    }
+    __syncthreads();
+    if (tid < NV) {
+        int cgi, k;
+        if (tid < C) { cgi = tid >> 3; k = tid & 7; }
+        else if (tid < 2 * C) { cgi = (tid - C) >> 3; k = 8 + ((tid - C) & 7); }
+        else { cgi = 0; k = 16 + tid - 2 * C; }
+        part[((size_t)n * G + blockIdx.x) * NV + tid] = ((sm[0][cgi][k] + sm[1][cgi][k]) + sm[2][cgi][k]) + sm[3][cgi][k];
+    }
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) last = atomicAdd(ticket, 1u) == (unsigned)(N * G - 1) ? 1 : 0;
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    const int P = 256 / C, c = tid % C, pk = tid / C;
+    double adw = 0., adg = 0., adb = 0.;
+    for (int nn = 0; nn < N; ++nn) {
+        double a0 = 0., a1 = 0., a2 = 0., a3 = 0.;
+        const int g0 = (int)((int64_t)pk * G / P), g1 = (int)((int64_t)(pk + 1) * G / P);
+        for (int gi = g0; gi < g1; ++gi) {
+            const double* q = part + ((size_t)nn * G + gi) * NV;
+            a0 += q[c]; a1 += q[C + c]; a2 += q[2 * C]; a3 += q[2 * C + 1];
+        }
+        fin[tid][0] = a0; fin[tid][1] = a1; fin[tid][2] = a2; fin[tid][3] = a3;
+        __syncthreads();
+        if (tid < C) {
+            double R0 = 0., Tt = 0., Sx = 0., Sxx = 0.;
+            for (int k = 0; k < P; ++k) { const double* f = fin[k * C + c]; R0 += f[0]; Tt += f[1]; Sx += f[2]; Sxx += f[3]; }
+            const double mu = Sx / (double)S;
+            double var = Sxx / (double)S - mu * mu;
+            var = var < 0. ? 0. : var;
+            const double wc = round16 ? (double)bf2f(f2bf(w[c])) : (double)w[c];
+            const double rs = 1. / sqrt(wc * wc * var + (double)eps);
+            const double A = Tt - mu * R0;
+            adw += (double)eps * (double)gamma[c] * rs * rs * rs * A;
+            adg += wc * rs * A;
+            adb += R0;
+        }
+        __syncthreads();
+    }
+    if (tid < C) {
+        dw[c] += (float)adw;
+        if (dgamma) { dgamma[c] += (float)adg; dbeta[c] += (float)adb; }
+    }
 }
-extern "C" int vg_in_scale_invariant_wgrad(const float* red, const float* rstd, const float* gamma, const float* w, int N, int C, float eps,
-                                           int round16, float* dw, float* dgamma, float* dbeta, vg_stream_t stream) {
+extern "C" int vg_stem_short_bwd_workgroups(int N, int64_t S, int C) {
+    if (N < 1 || S < 1 || C < 8 || C > 64 || (256 % C)) return VG_EINVAL;
+    const int vpb = 256 / (C >> 3);
+    int64_t gx = (S + vpb - 1) / vpb;
+    // resident at once, and an ODD count: the voxels a thread has in flight are G*vpb apart (fill_anb's remark on HBM channels)
+    int cap = vg_tune("STEM_BWD_GRID", 1021) / N;
+    if (cap < 1) cap = 1;
+    if (gx > cap) gx = cap;
+    return (int)gx;
+}
+extern "C" int vg_stem_short_bwd(const void* g, int g_f32, const float* x, int N, int64_t S, int C, const float* w, const float* gamma, float eps,
+                                 int round16, float* dw, float* dgamma, float* dbeta, double* part, int G, unsigned* ticket, vg_stream_t stream) {
     vg_begin();
-    if (!red || !rstd || !gamma || !w || !dw || N < 1 || C < 1 || (dgamma && !dbeta)) return VG_EINVAL;
-    hipLaunchKernelGGL(in_scale_invariant_wgrad_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, red, rstd, gamma, w, N, C, eps,
-                       round16, dw, dgamma, dbeta);
+    if (!g || !x || !w || !gamma || !dw || !part || !ticket || (dgamma && !dbeta)) return VG_EINVAL;
+    if (G != vg_stem_short_bwd_workgroups(N, S, C) || G < 1) return VG_EINVAL;
+    if (g_f32) hipLaunchKernelGGL((stem_short_bwd_kernel<float>), dim3(G, N), dim3(256), 0, (hipStream_t)stream, (const float*)g, x, N, S, C, w, gamma,
+                                  eps, round16, dw, dgamma, dbeta, part, ticket);
+    else hipLaunchKernelGGL((stem_short_bwd_kernel<bf16_t>), dim3(G, N), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)g, x, N, S, C, w, gamma,
+                            eps, round16, dw, dgamma, dbeta, part, ticket);
     return vg_check_launch();
 }
 extern "C" int vg_in_param_grads(const float* red, int N, int C, float* dgamma, float* dbeta, vg_stream_t stream) {
@@ -702,6 +785,25 @@ extern "C" int vg_dropout_mask_dev(float* out, int64_t n, float rate, uint64_t s
     vg_begin();
     if (!out || n < 0 || rate < 0.f || rate >= 1.f || !offset_dev) return VG_EINVAL;
     hipLaunchKernelGGL(dropout_mask_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, out, n, rate, seed, offset_add, offset_dev);
+    return vg_check_launch();
+}
+
+// The 32-byte per-step parameter block of a replayed / graph-launched train step, written by a kernel whose ARGUMENTS carry the values:
+// they are bound when the launch is enqueued, so a host that runs ahead (sync=False) cannot overwrite step N's scalars with step N+1's
+// before step N's consumers have read them (a pinned host mirror + asynchronous copy could: the copy reads the mirror when it EXECUTES).
+__global__ void set_step_params_kernel(unsigned char* block, uint64_t offset, float std, float lr0, float lr1, float lr2, float lr3) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        *(uint64_t*)block = offset;
+        *(float*)(block + 8) = std;
+        *(float*)(block + 12) = 0.f;
+        float* lr = (float*)(block + 16);
+        lr[0] = lr0; lr[1] = lr1; lr[2] = lr2; lr[3] = lr3;
+    }
+}
+extern "C" int vg_set_step_params(void* block, uint64_t offset, float std, float lr0, float lr1, float lr2, float lr3, vg_stream_t stream) {
+    vg_begin();
+    if (!block || ((uintptr_t)block & 7)) return VG_EINVAL;
+    hipLaunchKernelGGL(set_step_params_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned char*)block, offset, std, lr0, lr1, lr2, lr3);
     return vg_check_launch();
 }
 

@@ -570,17 +570,13 @@ class ResUNet:
         stem_aux = _STEM_AUX
         if stem_aux:
             # the shortcut reads the single-channel volume and nobody needs its data gradient; its output normalises to
-            # w*rstd*(x - mean x), so the loss sees w only through eps: dL/dw = eps*gamma*rstd^2 * sum(dn*xhat) / w, dL/db = 0 -- a closed
-            # form in the statistics pass's second moment (vg_in_scale_invariant_wgrad).  No apply pass, no gradient tensor, no
-            # weight-gradient launch: two full-resolution 16-channel passes per sweep less, and a well-conditioned number where the
-            # explicit path sums a million cancelling terms.
-            nrm, st = Nn['stem.short'], s['ns']
-            red = ops.alloc_red(ar, N, ssc.C)
-            dsc = ops.actnorm_desc(d_out, False, ssc.x0, (N, ssc.D, ssc.H, ssc.W), ssc.C, None, scale=st['scale'], shift=st['shift'],
-                                   act=ACT_NONE, norm=True, gamma=nrm.gamma, mean=st['mean'], rstd=st['rstd'], red=red)
-            ops.actnorm_stats(dsc)
-            ops.in_scale_invariant_wgrad(red, st['rstd'], nrm.gamma, L['stem.short'].w, N, ssc.C, L['stem.short'].gw,
-                                         dgamma=nrm.dgamma, dbeta=nrm.dbeta, round16=self.dtype != torch.float32)
+            # w*rs*(x - mean x), so the loss sees w only through eps: dL/dw = eps*gamma*rs^3 * sum d_out*(x - mean x), dL/db = 0 -- a closed
+            # form in two moments of d_out against the volume itself (vg_stem_short_bwd).  No apply pass, no gradient tensor, no
+            # weight-gradient launch, no read of the stored shortcut tensor: two full-resolution 16-channel passes per sweep less, and a
+            # well-conditioned, deterministic number where the explicit path sums a million cancelling terms.
+            nrm = Nn['stem.short']
+            ops.stem_short_bwd(ar, d_out, s['sx'].x0, N, ssc.C, L['stem.short'].w, nrm.gamma, L['stem.short'].gw,
+                               dgamma=nrm.dgamma, dbeta=nrm.dbeta, round16=self.dtype != torch.float32)
         else:
             d_sc = ar.alloc(s['sc'].data.shape, self.dtype)
             self._norm_bwd(ar, d_out, False, ssc, s['ns'], Nn['stem.short'], d_sc, ACT_NONE, accumulate=False)

@@ -436,9 +436,10 @@ class Arena:
         self._cpos = 0
         self.off = 0
         self.zmax = max(getattr(self, 'zmax', 0), self.zoff)
-        # a RECORDED reset must clear what every later replay will have used, not what the step before the recording happened to use
-        # (nothing, on a fresh engine): the high-water mark of the pool, or all of it when no step has completed yet
-        nz = self.zoff if REC is None else (self.zmax or self.ZPOOL)
+        # a RECORDED reset must clear what every later replay will have used, not what the steps before the recording happened to use
+        # (a test_step / generate / inference call in front of the first train_step_replay leaves a small non-zero high-water mark, and
+        # a replayed train step would then run on stale tickets and accumulators): always the whole pool -- 8 MiB, a few microseconds
+        nz = self.zoff if REC is None else self.ZPOOL
         if nz:
             zero_fill(self.zpool[:nz])
         self.zoff = 0
@@ -1260,11 +1261,18 @@ def actnorm_stats(d: ActNormBwdDesc):
     check(lib.vg_actnorm_bwd_stats(C.byref(d), stream()), 'vg_actnorm_bwd_stats')
 
 
-def in_scale_invariant_wgrad(red, rstd, gamma, w, N, C_, dw, dgamma=None, dbeta=None, round16=True):
-    """Kernel gradient of a single-channel 1x1x1 convolution in front of an InstanceNorm from the norm's backward statistics alone
-    (vg_in_scale_invariant_wgrad); adds dgamma / dbeta too -- no apply pass, no gradient tensor, no weight-gradient launch."""
-    check(lib.vg_in_scale_invariant_wgrad(_p(red), _p(rstd), _p(gamma), _p(w), N, C_, IN_EPS, int(round16), _p(dw), _p(dgamma), _p(dbeta),
-                                          stream()), 'vg_in_scale_invariant_wgrad')
+def stem_short_bwd(ar: 'Arena', g, x, N, C_, w, gamma, dw, dgamma=None, dbeta=None, round16=True):
+    """Kernel gradient (+ gamma / beta gradients) of a single-channel 1x1x1 convolution in front of an InstanceNorm from two moments of
+    the block-output gradient g [N, D, H, W, C] against the volume x [N, D, H, W, 1] itself (vg_stem_short_bwd): no apply pass, no
+    gradient tensor, no weight-gradient launch; deterministic (partial table + fixed-order final sum)."""
+    S = g.numel() // (N * C_)
+    G = int(lib.vg_stem_short_bwd_workgroups(N, S, C_))
+    if G < 1:
+        raise _lib.VgError('vg_stem_short_bwd: unsupported shape N=%d S=%d C=%d' % (N, S, C_))
+    part = ar.alloc((N, G, 2 * C_ + 2), torch.float64)
+    ticket = ar.alloc((4,), torch.int32, zero=True)
+    check(lib.vg_stem_short_bwd(_p(g), int(g.dtype == torch.float32), _p(x), N, S, C_, _p(w), _p(gamma), IN_EPS, int(round16), _p(dw), _p(dgamma),
+                                _p(dbeta), _p(part), G, _p(ticket), stream()), 'vg_stem_short_bwd')
 
 
 def actnorm_set_dx(d: ActNormBwdDesc, dx: torch.Tensor):

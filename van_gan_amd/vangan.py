@@ -84,12 +84,13 @@ def _engine_stream(device, role: str):
 
 class _StepParams:
     """Device block of the per-step host scalars of a captured train step (include/vangan_hip.h: the *_dev entry points): bytes
-    [0, 8) the Philox counter base, [8, 12) the discriminator noise standard deviation, [16, 32) lr_t of the four networks; a pinned
-    host mirror is refreshed and copied before every replay."""
+    [0, 8) the Philox counter base, [8, 12) the discriminator noise standard deviation, [16, 32) lr_t of the four networks.  It is
+    rewritten before every replay by a one-thread launch that carries the values as kernel ARGUMENTS (vg_set_step_params): bound at
+    enqueue time, so a host that runs ahead of the device (sync=False) cannot hand step N the scalars of step N+1 -- a pinned mirror
+    + asynchronous copy could."""
 
     def __init__(self, device):
         self.dev = torch.zeros(32, dtype=torch.uint8, device=device)
-        self.host = torch.zeros(32, dtype=torch.uint8).pin_memory()
         self.base = 0                   # Philox counter at the start of the captured step: launches carry offsets relative to it
         self.per_step = 0               # counter advance of one step
         p = self.dev.data_ptr()
@@ -99,10 +100,10 @@ class _StepParams:
         return self.dev.data_ptr() + 16 + 4 * NETS.index(name)
 
     def refresh(self, offset: int, std: float, lr_t):
-        self.host[0:8].view(torch.int64)[0] = int(offset)
-        self.host[8:12].view(torch.float32)[0] = float(std)
-        self.host[16:32].view(torch.float32).copy_(torch.tensor(lr_t, dtype=torch.float32))
-        self.dev.copy_(self.host, non_blocking=True)
+        """On torch's current stream (the stream the replay / graph launch is issued on, in front of it)."""
+        lr = [float(v) for v in lr_t]
+        ops.check(ops._lib.lib.vg_set_step_params(self.dev.data_ptr(), int(offset), float(std), lr[0], lr[1], lr[2], lr[3], ops.stream()),
+                  'vg_set_step_params')
 
 
 class VanGan:
