@@ -292,7 +292,7 @@ int vg_actnorm_bwd(const vg_actnorm_bwd_desc* d, vg_stream_t stream);
  *     dL/db[c] = 0 identically
  * -- no apply pass, no gradient tensor, no weight-gradient launch, and no read of the stored branch output (whose 16-bit rounding the
  * 1/w of the older statistics-based form amplified to 6-13 % of this gradient).  Deterministic: part[N][G][2C+2] doubles receive one
- * partial sum per workgroup, the workgroup drawing the last of the N*G tickets (*ticket zeroed by the caller) adds them in a fixed
+ * partial sum per workgroup (fp32 inside a wave, double across waves), the workgroup drawing the last of the N*G tickets (*ticket zeroed by the caller) adds them in a fixed
  * order.  G = vg_stem_short_bwd_workgroups(N, S, C); C in {8, 16, 32, 64}.  w: the C kernel weights as the forward used them
  * (round16 != 0: rounded to the library's 16-bit storage format first). */
 int vg_stem_short_bwd_workgroups(int N, int64_t S, int C);

@@ -74,21 +74,29 @@ def _res(p, name, x, stride):
     return instance_norm(sc, p[name + '.short.in.gamma'], p[name + '.short.in.beta']) + r
 
 
-def resunet_forward(p: Dict[str, np.ndarray], x):
-    """resunet_model.py:185-249."""
+def resunet_forward(p: Dict[str, np.ndarray], x, taps: Optional[dict] = None):
+    """resunet_model.py:185-249.  taps: filled with the block outputs (stem, enc1..enc4, bridge, dec3..dec0), NDHWC."""
     c = conv3d(reflect_pad1(x), p['stem.conv1.w'], p['stem.conv1.b'], 1, 'valid')
     c = _cb(p, 'stem.cb', c, 1)
     sc = conv3d(x, p['stem.short.w'], p['stem.short.b'], 1, 'same')
     h = c + instance_norm(sc, p['stem.short.in.gamma'], p['stem.short.in.beta'])
     skips = [h]
+    if taps is not None:
+        taps['stem'] = h
     for e in range(1, 5):
         h = _res(p, 'enc%d' % e, h, 2)
         skips.append(h)
+        if taps is not None:
+            taps['enc%d' % e] = h
     h = _cb(p, 'bridge.cb1', h, 1)
     h = _cb(p, 'bridge.cb2', h, 1)
+    if taps is not None:
+        taps['bridge'] = h
     for d in (3, 2, 1, 0):
         up = h.repeat(2, axis=1).repeat(2, axis=2).repeat(2, axis=3)
         h = _res(p, 'dec%d' % d, np.concatenate([up, skips[d]], axis=-1), 1)
+        if taps is not None:
+            taps['dec%d' % d] = h
     return np.tanh(conv3d(h, p['out.w'], p['out.b'], 1, 'same'))
 
 
@@ -320,3 +328,89 @@ def res_block_backward(p, name, x, stride, gout):
     dx_1, g1 = _cb_backward(p, name + '.cb1', x, stride, gr)
     grads.update(g1)
     return dx_1 + dx_s, grads
+
+
+# ------------------------------------------------------------------------------------------------------
+# Hand-derived BACKWARD of the whole generator and discriminator (resunet_model.py:185-249, discriminator.py:7-124) from the closed
+# forms above: d(sum(net(x) * g_out)) / d(parameters, x).  Second author of what torch autograd computes through
+# oracle/vangan_oracle.py::resunet_forward / disc_forward (tests/golden/make_golden_np.py checks the two against each other and files
+# the results as fixtures).
+# ------------------------------------------------------------------------------------------------------
+def resunet_backward(p, x, gy):
+    """-> (dx, {parameter name: gradient}) for y = resunet_forward(p, x), upstream gradient gy = dL/dy (NDHWC)."""
+    w1, b1 = p['stem.conv1.w'], p['stem.conv1.b']
+    c1 = conv3d(reflect_pad1(x), w1, b1, 1, 'valid')
+    cbo = _cb(p, 'stem.cb', c1, 1)
+    sc = conv3d(x, p['stem.short.w'], p['stem.short.b'], 1, 'same')
+    h = cbo + instance_norm(sc, p['stem.short.in.gamma'], p['stem.short.in.beta'])
+    skips, enc_in = [h], {}
+    for e in range(1, 5):
+        enc_in[e] = h
+        h = _res(p, 'enc%d' % e, h, 2)
+        skips.append(h)
+    br_in = h
+    b1o = _cb(p, 'bridge.cb1', br_in, 1)
+    h = _cb(p, 'bridge.cb2', b1o, 1)
+    dec_in = {}
+    for d in (3, 2, 1, 0):
+        up = h.repeat(2, axis=1).repeat(2, axis=2).repeat(2, axis=3)
+        dec_in[d] = np.concatenate([up, skips[d]], axis=-1)
+        h = _res(p, 'dec%d' % d, dec_in[d], 1)
+    y = np.tanh(conv3d(h, p['out.w'], p['out.b'], 1, 'same'))
+    grads = {}
+    g = gy * (1.0 - y * y)
+    dh, grads['out.w'], grads['out.b'] = conv3d_backward(h, p['out.w'], g, 1, 'same')
+    gskip = [0.0] * 5
+    for d in (0, 1, 2, 3):
+        dcat, gr = res_block_backward(p, 'dec%d' % d, dec_in[d], 1, dh)
+        grads.update(gr)
+        cu = dcat.shape[-1] - skips[d].shape[-1]
+        gskip[d] = gskip[d] + dcat[..., cu:]
+        du = dcat[..., :cu]
+        N, D, H, W, C = du.shape
+        dh = du.reshape(N, D // 2, 2, H // 2, 2, W // 2, 2, C).sum(axis=(2, 4, 6))       # transpose of UpSampling3D(2)
+    dh, g2 = _cb_backward(p, 'bridge.cb2', b1o, 1, dh)
+    grads.update(g2)
+    dh, g1 = _cb_backward(p, 'bridge.cb1', br_in, 1, dh)
+    grads.update(g1)
+    for e in (4, 3, 2, 1):
+        gout = dh + (gskip[e] if e < 4 else 0.0)          # skips[e] feeds dec(e) for e = 1..3; enc4's output only the bridge
+        dh, gr = res_block_backward(p, 'enc%d' % e, enc_in[e], 2, gout)
+        grads.update(gr)
+    g0 = dh + gskip[0]
+    gsc, grads['stem.short.in.gamma'], grads['stem.short.in.beta'] = instance_norm_backward(sc, p['stem.short.in.gamma'], g0)
+    dx_s, grads['stem.short.w'], grads['stem.short.b'] = conv3d_backward(x, p['stem.short.w'], gsc, 1, 'same')
+    dc1, gcb = _cb_backward(p, 'stem.cb', c1, 1, g0)
+    grads.update(gcb)
+    dxp, grads['stem.conv1.w'], grads['stem.conv1.b'] = conv3d_backward(reflect_pad1(x), w1, dc1, 1, 'valid')
+    return reflect_pad1_backward(dxp) + dx_s, grads
+
+
+def disc_backward(p, x, glogits):
+    """-> (dx, {parameter name: gradient}) for logits = disc_forward(p, x) (no noise, no dropout: training=False wiring)."""
+    layers = []                                   # (name, conv input as fed to conv3d, pre-norm conv output, reflect padded?, stride, padding)
+    xp = reflect_pad1(x)
+    c = conv3d(xp, p['conv0.w'], p['conv0.b'], 2, 'valid')
+    layers.append(('conv0', xp, c, True, 2, 'valid'))
+    h = lrelu(instance_norm(c, p['conv0.in.gamma'], p['conv0.in.beta']))
+    for i in range(3):
+        k = 'down%d' % i
+        if i < 2:
+            xp = reflect_pad1(h)
+            c = conv3d(xp, p[k + '.w'], None, 2, 'valid')
+            layers.append((k, xp, c, True, 2, 'valid'))
+        else:
+            c = conv3d(h, p[k + '.w'], None, 1, 'same')
+            layers.append((k, h, c, False, 1, 'same'))
+        h = lrelu(instance_norm(c, p[k + '.in.gamma'], p[k + '.in.beta']))
+    grads = {}
+    dh, grads['out.w'], grads['out.b'] = conv3d_backward(h, p['out.w'], glogits, 1, 'same')
+    for k, xin, c, padded, stride, padding in reversed(layers):
+        n = instance_norm(c, p[k + '.in.gamma'], p[k + '.in.beta'])
+        gn = dh * np.where(n > 0, 1.0, 0.2)                     # TP: LeakyReLU gradient uses x > 0
+        dc, grads[k + '.in.gamma'], grads[k + '.in.beta'] = instance_norm_backward(c, p[k + '.in.gamma'], gn)
+        dxin, grads[k + '.w'], db = conv3d_backward(xin, p[k + '.w'], dc, stride, padding)
+        if k == 'conv0':
+            grads['conv0.b'] = db
+        dh = reflect_pad1_backward(dxin) if padded else dxin
+    return dh, grads

@@ -440,13 +440,13 @@ __global__ void in_param_grads_kernel(const float* red, int N, int C, float* dga
 // Round 5 took xhat from the STORED shortcut tensor instead; for a channel with a small kernel weight that tensor is b + w*x rounded to
 // 16 bits -- a handful of levels -- and the closed form, which has 1/w in it, amplified the quantisation to 6-13 % of the gradient's norm
 // (tools/r06_stem_probe.py: float64 sums over the stored tensors reproduce the old kernel to 1e-5, so it was never the summation order).
-// x is exact (fp32), 8x fewer bytes than the stored tensor, and the result is deterministic: per-workgroup partial sums in double, added
-// up in a fixed order by the workgroup that draws the last ticket.
+// x is exact (fp32), 8x fewer bytes than the stored tensor, and the result is deterministic: per-workgroup partial sums (fp32 inside a wave,
+// double from there on), added up in a fixed order by the workgroup that draws the last ticket.
 template <typename T>
 __global__ __launch_bounds__(256) void stem_short_bwd_kernel(const T* g, const float* x, int N, int64_t S, int C, const float* w, const float* gamma,
                                                              float eps, int round16, float* dw, float* dgamma, float* dbeta, double* part,
                                                              unsigned* ticket) {
-    __shared__ double sm[4][8][18];
+    __shared__ float sm[4][8][18];
     __shared__ double fin[256][4];
     __shared__ int last;
     const int gpc = C >> 3, vpb = 256 / gpc, tid = threadIdx.x, cg = tid % gpc, vl = tid / gpc, n = blockIdx.y, G = gridDim.x, NV = 2 * C + 2;
@@ -455,7 +455,24 @@ __global__ __launch_bounds__(256) void stem_short_bwd_kernel(const T* g, const f
     for (int j = 0; j < 8; ++j) { r0[j] = 0.f; t[j] = 0.f; }
     const T* gn = g + (size_t)n * S * C + cg * 8;
     const float* xn = x + (size_t)n * S;
-    for (int64_t v = (int64_t)blockIdx.x * vpb + vl; v < S; v += (int64_t)G * vpb) {
+    // eight voxels per trip, their sixteen loads issued before the first use (one load in flight per thread kept HBM at a third of its rate)
+    constexpr int UN = 8;
+    const int64_t vstep = (int64_t)G * vpb;
+    int64_t v = (int64_t)blockIdx.x * vpb + vl;
+    for (; v + (UN - 1) * vstep < S; v += UN * vstep) {
+        Raw8<T> raw[UN]; float xv[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) { raw_load(raw[u], gn + (v + u * vstep) * C); xv[u] = ld_global(xn + v + u * vstep); }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            float gv[8];
+            raw_unpack(raw[u], gv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { r0[j] += gv[j]; t[j] = fmaf(gv[j], xv[u], t[j]); }
+            sx += xv[u]; sxx = fmaf(xv[u], xv[u], sxx);
+        }
+    }
+    for (; v < S; v += vstep) {
         float gv[8];
         load8<T>(gn + v * C, gv);
         const float xv = xn[v];
@@ -463,7 +480,9 @@ __global__ __launch_bounds__(256) void stem_short_bwd_kernel(const T* g, const f
         for (int j = 0; j < 8; ++j) { r0[j] += gv[j]; t[j] = fmaf(gv[j], xv, t[j]); }
         sx += xv; sxx = fmaf(xv, xv, sxx);
     }
-    double d[18];
+    // Inside a wave the partial sums are added in fp32 (a wave's share is ~1 000 terms: far from the cancellation of the whole volume, which
+    // is what needs care -- fp32 here costs ~5e-7 of the result); across waves and workgroups in double, in a fixed order.
+    float d[18];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { d[j] = r0[j]; d[8 + j] = t[j]; }
     d[16] = sx; d[17] = sxx;
@@ -482,7 +501,7 @@ __global__ __launch_bounds__(256) void stem_short_bwd_kernel(const T* g, const f
         if (tid < C) { cgi = tid >> 3; k = tid & 7; }
         else if (tid < 2 * C) { cgi = (tid - C) >> 3; k = 8 + ((tid - C) & 7); }
         else { cgi = 0; k = 16 + tid - 2 * C; }
-        part[((size_t)n * G + blockIdx.x) * NV + tid] = ((sm[0][cgi][k] + sm[1][cgi][k]) + sm[2][cgi][k]) + sm[3][cgi][k];
+        part[((size_t)n * G + blockIdx.x) * NV + tid] = (((double)sm[0][cgi][k] + (double)sm[1][cgi][k]) + (double)sm[2][cgi][k]) + (double)sm[3][cgi][k];
     }
     __threadfence();
     __syncthreads();
@@ -490,15 +509,23 @@ __global__ __launch_bounds__(256) void stem_short_bwd_kernel(const T* g, const f
     __syncthreads();
     if (!last) return;
     __threadfence();
+    // final sum by the workgroup that drew the last ticket: thread (c, pk) adds the partials of workgroups [g0, g1) of its sample, eight
+    // loads at a time (issued together, added in order), then the P partitions are added in order
     const int P = 256 / C, c = tid % C, pk = tid / C;
     double adw = 0., adg = 0., adb = 0.;
     for (int nn = 0; nn < N; ++nn) {
         double a0 = 0., a1 = 0., a2 = 0., a3 = 0.;
         const int g0 = (int)((int64_t)pk * G / P), g1 = (int)((int64_t)(pk + 1) * G / P);
-        for (int gi = g0; gi < g1; ++gi) {
-            const double* q = part + ((size_t)nn * G + gi) * NV;
-            a0 += q[c]; a1 += q[C + c]; a2 += q[2 * C]; a3 += q[2 * C + 1];
+        const double* base = part + (size_t)nn * G * NV;
+        int gi = g0;
+        for (; gi + 8 <= g1; gi += 8) {
+            double q0[8], q1[8], q2[8], q3[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const double* q = base + (size_t)(gi + u) * NV; q0[u] = q[c]; q1[u] = q[C + c]; q2[u] = q[2 * C]; q3[u] = q[2 * C + 1]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { a0 += q0[u]; a1 += q1[u]; a2 += q2[u]; a3 += q3[u]; }
         }
+        for (; gi < g1; ++gi) { const double* q = base + (size_t)gi * NV; a0 += q[c]; a1 += q[C + c]; a2 += q[2 * C]; a3 += q[2 * C + 1]; }
         fin[tid][0] = a0; fin[tid][1] = a1; fin[tid][2] = a2; fin[tid][3] = a3;
         __syncthreads();
         if (tid < C) {
@@ -520,13 +547,14 @@ __global__ __launch_bounds__(256) void stem_short_bwd_kernel(const T* g, const f
         dw[c] += (float)adw;
         if (dgamma) { dgamma[c] += (float)adg; dbeta[c] += (float)adb; }
     }
+    if (tid == 0) *ticket = 0u;            // left at zero for the next launch that is handed this word
 }
 extern "C" int vg_stem_short_bwd_workgroups(int N, int64_t S, int C) {
     if (N < 1 || S < 1 || C < 8 || C > 64 || (256 % C)) return VG_EINVAL;
     const int vpb = 256 / (C >> 3);
     int64_t gx = (S + vpb - 1) / vpb;
     // resident at once, and an ODD count: the voxels a thread has in flight are G*vpb apart (fill_anb's remark on HBM channels)
-    int cap = vg_tune("STEM_BWD_GRID", 1021) / N;
+    int cap = vg_tune("STEM_BWD_GRID", 509) / N;
     if (cap < 1) cap = 1;
     if (gx > cap) gx = cap;
     return (int)gx;

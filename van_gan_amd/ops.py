@@ -65,7 +65,8 @@ class DryRun:
     a box without a GPU to list the kernels a configuration would run (tests/test_variant_coverage.py).
     records: [(kind, layer name, variant string)], kind in fwd / dgrad / wgrad."""
 
-    _PASS = ('vg_conv3d_dma_bn', 'vg_conv3d_scratch_bytes', 'vg_conv3d_thin_np', 'vg_conv3d_plan', 'vg_packed_ktot', 'vg_packed_rows', 'vg_conv3d_lds_bytes', 'vg_status_string', 'vg_set_tuning')
+    _PASS = ('vg_conv3d_dma_bn', 'vg_conv3d_scratch_bytes', 'vg_conv3d_thin_np', 'vg_conv3d_plan', 'vg_packed_ktot', 'vg_packed_rows', 'vg_conv3d_lds_bytes', 'vg_status_string', 'vg_set_tuning',
+             'vg_stem_short_bwd_workgroups')
 
     def __init__(self):
         self.records = []

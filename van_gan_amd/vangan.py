@@ -615,6 +615,7 @@ class VanGan:
 
             mk = ar.mark()
             mkb = arB.mark()
+            self._bwd_ctx = {'gen_IS': [c1, c3], 'gen_SI': [c2, c4]}        # what the sweeps store (gradient buffers hang on the Act objects): for tests
 
             def a_adv():
                 if pair:
@@ -662,6 +663,7 @@ class VanGan:
                     ops.wait_event(main, ev_bfwd)                                          # c3 and g_cS are lane B's
                 ccA = pair_ctx(ar, c1, bufI, (fake_S, cyc_S), self.gen_IS.lv[0])
                 ccB = pair_ctx(ar, c2, bufS, (fake_I, cyc_I), self.gen_SI.lv[0])
+                self._bwd_ctx = {'gen_IS': [ccA], 'gen_SI': [ccB]}
                 # data parallel: the finished suffix of a generator's gradient bucket (enc4 ... output head, 34 of 38 MB) goes to the
                 # all-reduce when the sweep has passed enc4 -- with ~40 % of the sweep still ahead; only the last 4 MB wait for its end
                 split = self.ddp and apply and _AR_SPLIT
