@@ -15,11 +15,12 @@ storage of the HIP activation gradients (one rounding per layer on the way down)
 (sum, sum of squares) instead of two passes.
 
 Stated tolerance (measured values are printed): every parameter tensor of all four networks relative L2 <= 8e-2 and cosine >= 0.997
-(measured: all but the generators' stem tensors <= 3e-2 / >= 0.999) -- ONE tolerance for every tensor.  Round 5 had loosened it for the
-16-element stem.short.w (3e-2 .. 1.2e-1 run to run); round 6 found the cause (tools/r06_stem_probe.py: not the order of the float
-atomics -- float64 sums over the stored tensors reproduced the kernel to 1e-5 -- but the 16-bit rounding of the STORED shortcut output,
-which the closed form's 1/w amplified for channels with a small kernel weight) and removed it: vg_stem_short_bwd takes xhat from the
-fp32 volume itself, 5e-3 .. 2e-2 against the oracle, deterministic;
+(measured: all but the generators' stem tensors <= 3e-2 / >= 0.999).  Round 5 had loosened it for the 16-element stem.short.w to 2e-1
+(3e-2 .. 1.2e-1 run to run, blamed on the order of the float atomics); round 6 found the cause -- the closed form took xhat from the
+STORED shortcut output, whose 16-bit rounding its 1/w amplified for channels with a small kernel weight (float64 sums over the stored
+tensors reproduced the old kernel to 1e-5: it was never the summation) -- and removed it (vg_stem_short_bwd: xhat from the fp32 volume,
+deterministic).  What is left for that tensor is the bf16 backward sweep above it, and the test now says so in two assertions: the kernel
+against float64 sums over the stored tensors at 2e-3, and the end-to-end bound STEM_SHORT_E2E below with its measured distribution;
 tensors whose gradient is analytically ~0 (biases in front of an InstanceNorm) absolutely, <= 5e-3 of the network's largest gradient
 norm; whole-network cosine >= 0.9995 (measured 0.99998-1.00000, rel 4e-4 discriminators / 3e-3 - 7e-3 generators).  A dropped term in a fused launch (first-writer bits, a missing accumulate, the wrong half of a paired
 tensor) moves single tensors by O(1) and fails this."""
@@ -123,46 +124,49 @@ def _run(dims, B, seed, env=None):
     return got, grads
 
 
-BF16_RMS = 2.0 ** -8 * 0.4247           # rms relative error of one round-to-nearest to 8 significant bits (mantissa log-uniform in [1, 2))
+def stem_short_from_stored(eng, net):
+    """d loss / d stem.short.w in float64 from the tensors the engine STORED (the gradient of the stem output as the backward sweep left
+    it, the input volume): gamma * eps * rs^3 * sum_v d_out * (x - mean x) per channel, summed over the sweep's contexts (one 2B-sample
+    context of a paired sweep, or the two applications').  What vg_stem_short_bwd has to reproduce to rounding."""
+    return _stem_short_f64(eng.stores[net], eng._bwd_ctx[net])
 
 
-def stem_short_noise_floor(eng, net):
-    """Standard deviation that the bf16 STORAGE of the stem-output gradient alone puts on the norm of d loss / d stem.short.w -- from the
-    tensors the engine stored.  The gradient is gamma * eps * rs^3 * sum_v d_out * (x - mean x) per channel (vg_stem_short_bwd), a sum whose
-    terms cancel to ~1e-4 of their size in a train step; d_out reaches the kernel after TWO roundings to bf16 (the skip path's overwrite,
-    then enc1's accumulate; the stride-2 shortcut adds a third on 1/8 of the voxels), each an independent relative error of rms
-    BF16_RMS per element, so var(dw_c) = (gamma eps)^2 sum_n rs^6 * 2 * BF16_RMS^2 * sum_v (d_out * (x - mean x))^2.  The oracle
-    differentiates in fp32: this is what the two sides cannot agree better than."""
-    st = eng.stores[net]
+def _stem_short_f64(st, ctxs):
     w = st.param('stem.short.w').flatten().float().to(torch.bfloat16).double()
     gamma = st.param('stem.short.in.gamma').double()
-    tot = 0.0
-    for c in eng._bwd_ctx[net]:                 # one 2B-sample context (paired sweep) or the two applications' B-sample contexts
+    tot = torch.zeros_like(w)
+    for c in ctxs:
         ctx = c['stem']
         g = ctx['out'].grad.double()
         N, C = g.shape[0], g.shape[-1]
         g = g.reshape(N, -1, C)
         x = ctx['sx'].x0.double().reshape(N, -1, 1)
         xc = x - x.mean(1, keepdim=True)
-        var = (xc ** 2).mean(1)                                        # [N, 1]
-        rs = (w[None, :] ** 2 * var + 1e-3).rsqrt()                    # [N, C]
-        s2 = ((g * xc) ** 2).sum(1)                                    # [N, C]
-        var_dw = ((gamma * 1e-3) ** 2)[None, :] * rs ** 6 * 2.0 * BF16_RMS ** 2 * s2
-        tot += float(var_dw.sum())
-    return tot ** 0.5
+        rs = (w[None, :] ** 2 * (xc ** 2).mean(1) + 1e-3).rsqrt()      # [N, C]
+        tot += 1e-3 * gamma * (rs ** 3 * (g * xc).sum(1)).sum(0)
+    return tot.cpu()
+
+
+# The ONE tensor with a bound of its own against the oracle, and why it is not a loosened check: d loss / d stem.short.w is
+# gamma * eps * rs^3 * sum_v d_out * (x - mean x), a sum whose terms cancel to ~1e-4 of their size in a train step, over a gradient d_out
+# that reaches the stem after a whole backward sweep in bf16 storage (the oracle differentiates in fp32).  (a) The KERNEL is held to
+# float64 sums over the very tensors the engine stored, at 2e-3 (measured 1e-5 .. 1e-7; deterministic) -- that pins its arithmetic;
+# (b) against the oracle the error is that of the bf16 sweep above it, not of this kernel: float64 explicit InstanceNorm backward +
+# weight gradient from the same stored tensors differs from the oracle by as much (tools/r06_stem_probe.py), 100 samples measured
+# min 0.2 %, median 2.2 %, max 9.4 % (tools/r06_flake.py, profiles/r06_teacher_flake_25runs.txt) -- bound 1.5e-1 / cos 0.985.
+STEM_SHORT_E2E = (1.5e-1, 0.985)
 
 
 def _check(got, grads, label, eng=None):
-    """One tolerance for every tensor.  For the generators' stem.short.w the bound is additionally never tighter than what bf16 storage
-    of the gradient that feeds it allows: 3.5 standard deviations of stem_short_noise_floor (computed, not chosen; printed)."""
     for net in ('disc_I', 'disc_S', 'gen_IS', 'gen_SI'):
         special = None
-        if eng is not None and net.startswith('gen') and getattr(eng, '_bwd_ctx', None):
-            ref = grads[net]['stem.short.w'].double()
-            floor = stem_short_noise_floor(eng, net) / float(ref.norm())
-            err = float((got[net]['stem.short.w'].double() - ref).norm() / ref.norm())
-            print('%s stem.short.w: rel error %.4f, bf16 gradient-storage noise floor (1 sigma) %.4f of the norm' % (net, err, floor))
-            special = {'stem.short.w': (max(8e-2, 3.5 * floor), 0.997 if err <= 8e-2 else 0.98)}
+        if net.startswith('gen'):
+            special = {'stem.short.w': STEM_SHORT_E2E}
+            if eng is not None and getattr(eng, '_bwd_ctx', None):
+                ref64 = stem_short_from_stored(eng, net)
+                err = float((got[net]['stem.short.w'].double().flatten() - ref64).norm() / ref64.norm())
+                print('%s stem.short.w: kernel vs float64 sums over the stored tensors: rel %.2e' % (net, err))
+                assert err <= 2e-3, (net, err)
         cos = grad_report(got[net], grads[net], '%s %s (teacher-forced)' % (label, net), rel_tol=8e-2, cos_tol=0.997, abs_tol=5e-3, special=special)
         assert cos >= 0.9995, (net, cos)
 
@@ -210,6 +214,10 @@ def test_teacher_forced_generator_128x128x64():
     st.g.zero_()
     net.backward(ar, ctx, gy.to(dev))
     torch.cuda.synchronize()
+    ref64 = _stem_short_f64(st, [ctx])
+    err64 = float((st.export(st.g)['stem.short.w'].double().flatten() - ref64).norm() / ref64.norm())
+    print('stem.short.w: kernel vs float64 sums over the stored tensors: rel %.2e' % err64)
+    assert err64 <= 2e-3, err64
     T = {key: O.to_ncdhw(ctx[blk][field].data.float().cpu()) for key, (blk, field) in _gen_keys()}
     T['y'] = O.to_ncdhw(y.float().cpu())
     used = set()
@@ -230,5 +238,5 @@ def test_teacher_forced_generator_128x128x64():
     # 1 M voxels; with that gradient STORED in bf16 the rounding errors do not cancel as the exact values do (measured 1.7e-2 of the
     # largest tensor norm on stem.conv1.b, which sums the full-resolution 16-channel gradient)
     cos = grad_report(st.export(st.g), {k: v.grad for k, v in Pr.items()}, 'generator 128x128x64 bf16 (teacher-forced)', rel_tol=8e-2, cos_tol=0.997,
-                      abs_tol=4e-2)
+                      abs_tol=4e-2, special={'stem.short.w': STEM_SHORT_E2E})
     assert cos >= 0.9995, cos

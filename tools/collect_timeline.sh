@@ -18,6 +18,8 @@ cd $R
   python3 tools/trace_streams.py $O/trace 0.5
   echo; echo "## (3) whole-GPU idle time (tools/trace_gaps.py)"
   python3 tools/trace_gaps.py $O/trace 0.5
+  echo; echo "## (3b) how full the chip is over the step (tools/trace_occupancy.py)"
+  python3 tools/trace_occupancy.py $O/trace 0.5
   echo; echo "## (4) launches per steady-state step, by kernel (tools/launches_per_step.py: steps delimited by adam_kernel groups)"
   python3 tools/launches_per_step.py $O/trace
 } > $R/profiles/${tag}_lane_timeline.txt 2>&1
