@@ -19,21 +19,30 @@ gamma = torch.ones(C, device=dev)
 dw, dg, db = (torch.zeros(C, device=dev) for _ in range(3))
 ar = Arena(64 << 20, dev)
 nbytes = g.numel() * 2 + x.numel() * 4
-for cap in (255, 509, 1021, 2045):
-    ops._lib.lib.vg_set_tuning(b'STEM_BWD_GRID', cap, 0)
-    for _ in range(3):
-        ar.reset(); ops.stem_short_bwd(ar, g, x, N, C, w, gamma, dw, dg, db)
+
+lib = ops._lib.lib
+S = D * D * D
+for cap in (255, 509, 767, 1021, 2045):
+    lib.vg_set_tuning(b'STEM_BWD_GRID', cap, 0)
+    G = int(lib.vg_stem_short_bwd_workgroups(N, S, 16))
+    part = torch.empty(N * G * 34, dtype=torch.float64, device=dev)
+    ticket = torch.zeros(4, dtype=torch.int32, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    args = (g.data_ptr(), 0, x.data_ptr(), N, S, 16, w.data_ptr(), gamma.data_ptr(), 1e-3, 1, dw.data_ptr(), dg.data_ptr(), db.data_ptr(), part.data_ptr(), G,
+            ticket.data_ptr(), st)
+    for _ in range(5):
+        assert lib.vg_stem_short_bwd(*args) == 0
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ar.reset()
     e0.record()
-    for _ in range(20):
-        ops.stem_short_bwd(ar, g, x, N, C, w, gamma, dw, dg, db)
+    for _ in range(50):
+        lib.vg_stem_short_bwd(*args)
     e1.record(); torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) / 20 * 1e3
-    print('grid cap %5d: %7.1f us per launch, %.2f TB/s' % (cap, us, nbytes / us / 1e6))
+    us = e0.elapsed_time(e1) / 50 * 1e3
+    print('grid cap %5d (G = %4d per sample): %7.1f us per launch, %.2f TB/s' % (cap, G, us, nbytes / us / 1e6))
+lib.vg_set_tuning(b'STEM_BWD_GRID', 0, 1)
 # reference value in float64
-gd, xd = g.double().reshape(N, -1, C), x.double().reshape(N, -1, 1)
+gd, xd = g.double().reshape(N, -1, 16), x.double().reshape(N, -1, 1)
 xc = xd - xd.mean(1, keepdim=True)
 wq = w.to(torch.bfloat16).double()
 rs = (wq[None] ** 2 * (xc ** 2).mean(1) + 1e-3).rsqrt()

@@ -501,16 +501,20 @@ __global__ __launch_bounds__(256) void stem_short_bwd_kernel(const T* g, const f
         if (tid < C) { cgi = tid >> 3; k = tid & 7; }
         else if (tid < 2 * C) { cgi = (tid - C) >> 3; k = 8 + ((tid - C) & 7); }
         else { cgi = 0; k = 16 + tid - 2 * C; }
-        part[((size_t)n * G + blockIdx.x) * NV + tid] = (((double)sm[0][cgi][k] + (double)sm[1][cgi][k]) + (double)sm[2][cgi][k]) + (double)sm[3][cgi][k];
+        // agent-scope store: the partial goes to the level the XCDs share (no __threadfence(): its L2 write-back / invalidate per workgroup cost
+        // more than the kernel's whole stream -- 50 -> 174 us from 254 to 2 044 workgroups)
+        __hip_atomic_store(part + ((size_t)n * G + blockIdx.x) * NV + tid,
+                           (((double)sm[0][cgi][k] + (double)sm[1][cgi][k]) + (double)sm[2][cgi][k]) + (double)sm[3][cgi][k], __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
     }
-    __threadfence();
+    // the exchange of vg_fin_tail (vg_common.h): stores acknowledged (vmcnt), workgroup barrier, one relaxed agent-scope ticket; the
+    // workgroup that draws the last one reads every partial with agent-scope loads
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) last = atomicAdd(ticket, 1u) == (unsigned)(N * G - 1) ? 1 : 0;
+    if (tid == 0) last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(N * G - 1) ? 1 : 0;
     __syncthreads();
     if (!last) return;
-    __threadfence();
-    // final sum by the workgroup that drew the last ticket: thread (c, pk) adds the partials of workgroups [g0, g1) of its sample, eight
-    // loads at a time (issued together, added in order), then the P partitions are added in order
+    auto ald = [](const double* q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
     const int P = 256 / C, c = tid % C, pk = tid / C;
     double adw = 0., adg = 0., adb = 0.;
     for (int nn = 0; nn < N; ++nn) {
@@ -521,11 +525,11 @@ __global__ __launch_bounds__(256) void stem_short_bwd_kernel(const T* g, const f
         for (; gi + 8 <= g1; gi += 8) {
             double q0[8], q1[8], q2[8], q3[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { const double* q = base + (size_t)(gi + u) * NV; q0[u] = q[c]; q1[u] = q[C + c]; q2[u] = q[2 * C]; q3[u] = q[2 * C + 1]; }
+            for (int u = 0; u < 8; ++u) { const double* q = base + (size_t)(gi + u) * NV; q0[u] = ald(q + c); q1[u] = ald(q + C + c); q2[u] = ald(q + 2 * C); q3[u] = ald(q + 2 * C + 1); }
 #pragma unroll
             for (int u = 0; u < 8; ++u) { a0 += q0[u]; a1 += q1[u]; a2 += q2[u]; a3 += q3[u]; }
         }
-        for (; gi < g1; ++gi) { const double* q = base + (size_t)gi * NV; a0 += q[c]; a1 += q[C + c]; a2 += q[2 * C]; a3 += q[2 * C + 1]; }
+        for (; gi < g1; ++gi) { const double* q = base + (size_t)gi * NV; a0 += ald(q + c); a1 += ald(q + C + c); a2 += ald(q + 2 * C); a3 += ald(q + 2 * C + 1); }
         fin[tid][0] = a0; fin[tid][1] = a1; fin[tid][2] = a2; fin[tid][3] = a3;
         __syncthreads();
         if (tid < C) {
@@ -547,14 +551,15 @@ __global__ __launch_bounds__(256) void stem_short_bwd_kernel(const T* g, const f
         dw[c] += (float)adw;
         if (dgamma) { dgamma[c] += (float)adg; dbeta[c] += (float)adb; }
     }
-    if (tid == 0) *ticket = 0u;            // left at zero for the next launch that is handed this word
+    if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);            // left at zero for the next launch that is handed this word
 }
 extern "C" int vg_stem_short_bwd_workgroups(int N, int64_t S, int C) {
     if (N < 1 || S < 1 || C < 8 || C > 64 || (256 % C)) return VG_EINVAL;
     const int vpb = 256 / (C >> 3);
     int64_t gx = (S + vpb - 1) / vpb;
-    // resident at once, and an ODD count: the voxels a thread has in flight are G*vpb apart (fill_anb's remark on HBM channels)
-    int cap = vg_tune("STEM_BWD_GRID", 509) / N;
+    // one workgroup per CU, an ODD count (the voxels a thread has in flight are G*vpb apart: fill_anb's remark on HBM channels); more
+    // workgroups only lengthen the last one's fixed-order sum (128^3 x 16, two samples: 36 us at 254 workgroups = 4.2 TB/s, 40 at 508, 50 at 1 020)
+    int cap = vg_tune("STEM_BWD_GRID", 255) / N;
     if (cap < 1) cap = 1;
     if (gx > cap) gx = cap;
     return (int)gx;
