@@ -166,6 +166,12 @@ typedef struct {
     /* Optional (forward launches with out_sums): finalise the InstanceNorm statistics of this launch's output for its consumers
        (see vg_fin_desc). */
     const vg_fin_desc* fin;
+    /* res_c1 != 0: `res` is a SINGLE-channel fp32 volume [N][BD][BH][BW] (same grid as the output, ostr == 1) whose value is broadcast
+       over the output channels: out += res[v] * res_scale[n][c] + res_shift[n][c].  The stem's shortcut Conv3D(16, 1x1x1)(x) ->
+       InstanceNorm (resunet_model.py:96-99) is an affine function of the input volume per channel, so the block's residual add reads
+       the 4-byte volume instead of a stored 16-channel tensor (vg_stem_short_fwd produces the scale / shift).  Served by the 16-channel
+       specialist and the generic kernel; other families return VG_EINVAL. */
+    int32_t res_c1;
 } vg_conv_desc;
 #define VG_SCRATCH_CTR_BYTES 16384
 
@@ -284,6 +290,16 @@ int vg_actnorm_bwd_apply(const vg_actnorm_bwd_desc* d, vg_stream_t stream);
 int vg_actnorm_bwd_apply2(const vg_actnorm_bwd_desc* d1, const vg_actnorm_bwd_desc* d2, vg_stream_t stream);
 /* both passes in one call (statistics only when d->norm) */
 int vg_actnorm_bwd(const vg_actnorm_bwd_desc* d, vg_stream_t stream);
+/* The stem's shortcut in the forward pass (resunet_model.py:96-99: Conv3D(C, 1x1x1)(x) -> InstanceNorm on the single-channel volume x [N][S],
+ * fp32) WITHOUT materialising its output: w[c]*x + b[c] normalises to gamma[c]*w[c]*rs*(x - mean x) + beta[c] with
+ * rs = (w[c]^2 var x + eps)^-1/2 (the convolution's bias cancels), i.e. the branch is  scale[n][c] * x + shift[n][c]  with
+ *     scale = gamma*w*rs,   shift = beta - scale * mean x.
+ * One launch: per-workgroup partial sums of x and x^2 in part[N][G][2] (doubles), fixed-order sum and the 2*N*C results by the
+ * workgroup that draws the last of the N*G tickets (*ticket zero on entry, left at zero).  G = vg_stem_short_fwd_workgroups(N, S).
+ * The consuming convolution adds the branch through vg_conv_desc::res_c1.  round16 as in vg_stem_short_bwd. */
+int vg_stem_short_fwd_workgroups(int N, int64_t S);
+int vg_stem_short_fwd(const float* x, int N, int64_t S, int C, const float* w, const float* gamma, const float* beta, float eps, int round16,
+                      float* scale, float* shift, double* part, int G, unsigned* ticket, vg_stream_t stream);
 /* The stem's shortcut in the backward pass (resunet_model.py:96-99: Conv3D(16, 1x1x1)(x) -> InstanceNorm, no activation; its input is the
  * single-channel volume, so no data gradient exists).  The branch's output w[c]*x + b[c] normalises to
  * xhat[c] = w[c]*rs[c]*(x - mean x), rs[c] = (w[c]^2 var x + eps)^-1/2: the loss sees w[c] only through eps, and with the two moments

@@ -838,3 +838,59 @@ def test_thin_layer_weight_gradient_families_agree_and_are_deterministic(cin, ca
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
     assert float(res[0][0].abs().max()) > 0
     assert rel_l2(res[0][0], res[2][0]) < 1e-4 and rel_l2(res[0][1], res[2][1]) < 1e-4
+
+
+@pytest.mark.parametrize('dims,N,f32', [((32, 32, 32), 2, False), ((16, 24, 40), 1, False), ((12, 10, 20), 2, False), ((16, 16, 32), 2, True)],
+                         ids=['32^3 thin specialist', '16x24x40 thin, ragged tiles', '12x10x20 generic kernel (masked)', 'fp32 generic kernel'])
+def test_stem_shortcut_as_an_affine_function_of_the_volume(dims, N, f32):
+    """The stem's shortcut (resunet_model.py:96-99: Conv3D(16, 1x1x1)(x) -> InstanceNorm on the single-channel volume) without its tensor:
+    vg_stem_short_fwd turns the volume's mean / variance into scale * x + shift per (sample, channel), and the block's second convolution
+    adds that in its epilogue from the fp32 volume (vg_conv_desc::res_c1) -- in the 16-channel specialist and in the generic kernel.
+    Against float64: conv(relu(IN(c1))) + IN(conv1x1(x)), computed the reference's way."""
+    from van_gan_amd import ops
+    from van_gan_amd.ops import Arena, Src
+    dev = _dev()
+    dt = torch.float32 if f32 else torch.bfloat16
+    g = torch.Generator().manual_seed(11)
+    from van_gan_amd.nets import ParamStore
+    from van_gan_amd.ops import ConvLayer
+    specs = [('c.w', (3, 3, 3, 16, 16), 'x'), ('c.b', (16,), 'x')]
+    st = ParamStore(specs, dev)
+    st.param('c.w').copy_(torch.randn(3, 3, 3, 16, 16, generator=g) / math.sqrt(27 * 16))
+    st.param('c.b').copy_(torch.randn(16, generator=g) * 0.1)
+    lay = ConvLayer(st, 'c', 3, 16, 16, 1, 'reflect', True, dims, dtype=dt)
+    lay.pack()
+    x = torch.rand(N, *dims, 1, generator=g) * 2 - 1
+    x[1 % N] = x[1 % N] * 0.3 + 0.5                            # samples with different mean / variance
+    c1 = torch.randn(N, *dims, 16, generator=g).to(dt)
+    scale, shift = torch.rand(N, 16, generator=g) + 0.5, torch.randn(N, 16, generator=g) * 0.3
+    ws = torch.randn(16, generator=g) * 0.4
+    ws[3] = 0.01                                               # a channel whose stored 16-bit branch would have had a handful of levels
+    bs, gam, bet = torch.randn(16, generator=g) * 0.2, torch.rand(16, generator=g) + 0.5, torch.randn(16, generator=g) * 0.1
+    ar = Arena(64 << 20, dev)
+    sc_scale, sc_shift = torch.zeros(N, 16, device=dev), torch.zeros(N, 16, device=dev)
+    xd = x.to(dev)
+    ops.stem_short_fwd(ar, xd, N, 16, ws.to(dev), gam.to(dev), bet.to(dev), sc_scale, sc_shift, round16=not f32)
+    src = Src(c1.to(dev), (N,) + dims, 16, scale=scale.to(dev), shift=shift.to(dev), act=ops.ACT_RELU)
+    out = torch.zeros(N, *dims, 16, dtype=dt, device=dev)
+    sums = torch.zeros(8, N, 16, 2, device=dev)
+    lay.forward(src, out, sums=sums, res=xd, res_scale=sc_scale, res_shift=sc_shift, res_c1=True)
+    torch.cuda.synchronize()
+    q = (lambda t: t.double()) if f32 else bf
+    wq = q(ws)
+    sc = x.double() * wq.view(1, 1, 1, 1, -1) + bs.double().view(1, 1, 1, 1, -1)                  # the branch as the reference computes it
+    scn = O.to_ndhwc(O.instance_norm(O.to_ncdhw(sc), gam.double(), bet.double()))
+    # scale / shift themselves
+    mu, var = x.double().mean((1, 2, 3, 4)), x.double().var((1, 2, 3, 4), unbiased=False)
+    rs = (wq[None] ** 2 * var[:, None] + 1e-3).rsqrt()
+    assert rel_l2(sc_scale, gam.double()[None] * wq[None] * rs) < 1e-5
+    assert rel_l2(sc_shift, bet.double()[None] - gam.double()[None] * wq[None] * rs * mu[:, None]) < 1e-5
+    a = F.relu(c1.double() * scale.double().view(N, 1, 1, 1, -1) + shift.double().view(N, 1, 1, 1, -1))
+    y = O.to_ndhwc(ref_conv(O.to_ncdhw(q(a)), q(st.param('c.w').cpu()), st.param('c.b').cpu().double(), 1, 'reflect')) + scn
+    if f32:
+        assert rel_l2(out, y) < 1e-4
+    else:
+        close_bf16(out, y, 'stem.cb + shortcut on read')
+    # the output statistics the launch accumulated are those of the stored values
+    o = out.double().cpu()
+    assert rel_l2(sums.sum(0)[..., 0], o.sum((1, 2, 3))) < 1e-4 and rel_l2(sums.sum(0)[..., 1], (o ** 2).sum((1, 2, 3))) < 1e-4

@@ -36,7 +36,7 @@ from test_gpu_nets import grad_report, perturb, rel_l2  # noqa: E402
 
 
 def _gen_keys():
-    ks = [('stem.conv1', ('stem', 'c1')), ('stem.short', ('stem', 'sc')), ('stem', ('stem', 'out'))]
+    ks = [('stem.conv1', ('stem', 'c1')), ('stem', ('stem', 'out'))]          # (the stem's shortcut is not stored: nets._STEM_FUSED)
     for b in ['enc%d' % e for e in range(1, 5)] + ['dec%d' % d for d in (3, 2, 1, 0)]:
         ks += [(b + '.cb1', (b, 'r')), (b + '.short', (b, 'sc')), (b, (b, 'out'))]
     ks += [('bridge.cb1', ('bridge', 'b1')), ('bridge.cb2', ('bridge', 'b2'))]

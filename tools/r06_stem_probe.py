@@ -5,6 +5,8 @@ teacher-forced oracle's.  usage: python tools/r06_stem_probe.py [D H W] [runs]""
 import os
 import sys
 
+os.environ['VG_STEM_FUSED'] = '0'        # the probe reads the STORED shortcut tensor (round 5's forward; the default no longer materialises it)
+
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -32,7 +32,7 @@ class ConvDesc(C.Structure):
         ('out', c_void_p), ('out_f32', c_int), ('accumulate', c_int), ('out_sums', c_void_p), ('f32', c_int),
         ('nclass', c_int), ('cls_tap0', c_int * 9), ('cls_w', c_void_p * 8), ('cls_ooff', (c_int * 3) * 8),
         ('cls_iters', (c_int * 3) * 8), ('wpack', c_int), ('wpack_wmin', c_int), ('bstat', c_void_p),
-        ('scratch', c_void_p), ('scratch_bytes', c_i64), ('wlayout', c_int), ('fin', c_void_p),
+        ('scratch', c_void_p), ('scratch_bytes', c_i64), ('wlayout', c_int), ('fin', c_void_p), ('res_c1', c_int),
     ]
 
 
@@ -92,6 +92,9 @@ _SIGS = {
     'vg_actnorm_bwd_apply': ([C.POINTER(ActNormBwdDesc), c_void_p], c_int),
     'vg_actnorm_bwd_apply2': ([C.POINTER(ActNormBwdDesc), C.POINTER(ActNormBwdDesc), c_void_p], c_int),
     'vg_actnorm_bwd': ([C.POINTER(ActNormBwdDesc), c_void_p], c_int),
+    'vg_stem_short_fwd_workgroups': ([c_int, c_i64], c_int),
+    'vg_stem_short_fwd': ([c_void_p, c_int, c_i64, c_int, c_void_p, c_void_p, c_void_p, C.c_float, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                          c_void_p], c_int),
     'vg_stem_short_bwd_workgroups': ([c_int, c_i64, c_int], c_int),
     'vg_stem_short_bwd': ([c_void_p, c_int, c_void_p, c_int, c_i64, c_int, c_void_p, c_void_p, C.c_float, c_int, c_void_p, c_void_p, c_void_p,
                           c_void_p, c_int, c_void_p, c_void_p], c_int),

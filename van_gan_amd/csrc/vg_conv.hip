@@ -814,6 +814,8 @@ static int fill_conv(const vg_conv_desc* d, GatherIn& g, ConvOut& k, ConvCls& q,
     k.BD = d->BD; k.BH = d->BH; k.BW = d->BW; k.Cout = d->Cout;
     k.wp = d->wpacked;
     k.bias = d->bias; k.res = d->res; k.rs = d->res_scale; k.rb = d->res_shift; k.tanh_out = d->tanh_out;
+    k.res1 = (d->res && d->res_c1) ? 1 : 0;
+    if (d->res_c1 && (!d->res || d->ostr != 1 || q.ncls > 1)) return VG_EINVAL;
     k.out = d->out; k.out_f32 = (d->out_f32 || d->f32) ? 1 : 0; k.accumulate = d->accumulate; k.sums = d->out_sums;
     k.bs_x0 = nullptr; k.xw = 0;
     k.ks = 1; k.ks_part = nullptr; k.ks_cnt = nullptr;
@@ -831,7 +833,7 @@ static int fill_conv(const vg_conv_desc* d, GatherIn& g, ConvOut& k, ConvCls& q,
 static int plan_conv32(const vg_conv_desc* d, const ConvOut& k, const ConvCls& q, GatherIn& g, int& BN, int& MSUB, int& lds) {
     const int use32 = vg_tune("CONV32", 1);
     const int Cin = d->c_src0 + d->c_src1;
-    if (!use32 || d->f32 || (q.ncls != 1 && !q.par) || (d->Cout % 64) || Cin < 64 || Cin == 1 || d->tanh_out || (d->CK % 16)) return VG_EINVAL;
+    if (!use32 || d->f32 || d->res_c1 || (q.ncls != 1 && !q.par) || (d->Cout % 64) || Cin < 64 || Cin == 1 || d->tanh_out || (d->CK % 16)) return VG_EINVAL;
     const int ncp = q.par ? q.ncls : 1;
     if ((long)d->OD * d->OH * d->OW * d->N * (d->Cout / 64) * ncp < 256 * 64) return VG_EINVAL;     // too small to fill the chip with 64-wide panels
     BN = (d->Cout % 128 == 0) ? 128 : 64;
@@ -1017,7 +1019,7 @@ extern "C" int vg_conv3d_thin_np(const vg_conv_desc* d0) {
 // did_stats: set when the launched kernel accumulated the IN-backward statistics of d->bstat itself (striped, unfolded)
 static int conv3d_impl(const vg_conv_desc* d, vg_stream_t stream, bool& did_stats) {
     if (d && d->wlayout) return vg_conv_dma(d, (hipStream_t)stream, &did_stats);   // LDS-DMA family (weights in its block layout): served there or an error
-    if (d && d->out && d->wpacked && d->src0) {           // 1x1x1 with a single channel on one side: HBM-bound VALU kernels
+    if (d && d->out && d->wpacked && d->src0 && !d->res_c1) {           // 1x1x1 with a single channel on one side: HBM-bound VALU kernels
         const int prc = vg_pointwise_conv(d, (hipStream_t)stream);
         if (prc <= 0) return prc;
     }
@@ -1025,7 +1027,7 @@ static int conv3d_impl(const vg_conv_desc* d, vg_stream_t stream, bool& did_stat
     int rc = fill_conv(d, g, k, q, BN, MSUB, lds);
     if (rc != VG_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
-    if (thin2_shape(d, k, q)) {        // 32-channel panels of the thin-channel specialist (weights packed with 16-channel chunks for it)
+    if (!d->res_c1 && thin2_shape(d, k, q)) {        // 32-channel panels of the thin-channel specialist (weights packed with 16-channel chunks for it)
         GatherIn g2;
         if (fill_gather(d, g2, 16, 512) == VG_OK && vg_conv_thin_ok(d, g2, k, q, 2)) {
             const int trc = vg_launch_conv_thin(g2, k, 2, s, d->bstat ? d->bstat->red : nullptr, did_stats);

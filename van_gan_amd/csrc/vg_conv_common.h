@@ -7,6 +7,7 @@ struct ConvOut {
     int OD, OH, OW, ostr, ood, ooh, oow, BD, BH, BW, Cout;
     const void* wp; int Ktot, nchunks, kc_pad;
     const float* bias; const void* res; const float* rs; const float* rb; int tanh_out;
+    int res1;           // vg_conv_desc::res_c1: res is a single-channel fp32 volume broadcast over the output channels
     void* out; int out_f32, accumulate; float* sums;
     int w_lds;          // 1: the BN x Ktot weight panel of this workgroup is copied to LDS once (row stride WRS bytes)
     int dma;            // 1: LDS-DMA double-buffered staging (planar bf16 image, weights in LDS)

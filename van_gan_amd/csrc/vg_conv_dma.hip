@@ -606,6 +606,7 @@ extern "C" int64_t vg_conv3d_scratch_bytes(const vg_conv_desc* d) {
 
 // VG_OK: served; 1: not one of this family's shapes (only possible when d->wlayout == 0); < 0: error
 int vg_conv_dma(const vg_conv_desc* d, hipStream_t s, bool* did_stats) {
+    if (d->res_c1) return d->wlayout ? VG_EINVAL : 1;      // (single-channel residual: the 16-channel specialist / the generic kernel)
     CdPlan pl;
     const int BN = cd_plan(d, pl);
     if (!BN) return d->wlayout ? VG_EINVAL : 1;

@@ -482,6 +482,8 @@ __global__ __launch_bounds__(256, VG_THIN_WPE) void conv_thin_kernel(const Gathe
             for (int q = 0; q < NP; ++q) {
             T* const optr = (T*)p.out + obase + cst + 16 * q + pn16;
             const T* const rptr = RES ? (const T*)p.res + obase + co0 + 16 * q : nullptr;
+            // (vg_conv_desc::res_c1: the residual is a single-channel fp32 volume -- one value per voxel row, kept in the first word of rr[j])
+            const float* const r1ptr = RES ? (const float*)p.res + (((size_t)(n * p.BD + od + p.ood) * p.BH + oh0 + p.ooh) * p.BW + ow + p.oow) : nullptr;
             f32x2 eb[2], ers[2], erb[2];
             if constexpr (NP == 1) { eb[0] = e_b[0][0]; eb[1] = e_b[0][1]; if (RES) { ers[0] = e_rs[0][0]; ers[1] = e_rs[0][1]; erb[0] = e_rb[0][0]; erb[1] = e_rb[0][1]; } }
             else {              // (two panels: fetched here, from LDS -- held across the MFMA loop they cost 24 registers the accumulators need;
@@ -529,6 +531,10 @@ __global__ __launch_bounds__(256, VG_THIN_WPE) void conv_thin_kernel(const Gathe
 #pragma unroll
                         for (int j = jp; j < jp + RRN; ++j) {
                             const bool ok = !MASKED || (dw_ok && j < nrow);
+                            if (p.res1) {
+                                const float xv = ld_global(ok ? r1ptr + (size_t)j * p.BW : r1ptr);
+                                rr[j] = __builtin_bit_cast(bf16x4, (u32x2){__float_as_uint(xv), 0u});
+                            } else
                             rr[j] = *(const __attribute__((address_space(1))) bf16x4*)(uintptr_t)(ok ? rptr + j * rowpitch : rptr);
                         }
                     }
@@ -542,7 +548,8 @@ __global__ __launch_bounds__(256, VG_THIN_WPE) void conv_thin_kernel(const Gathe
                     if (BIAS) { v0 += eb[0]; v1 += eb[1]; }
                     if (RES) {
                         const bf16x4 r = rr[RES ? j : 0];
-                        const f32x2 r0 = {bf2f((bf16_t)r[0]), bf2f((bf16_t)r[1])}, r1 = {bf2f((bf16_t)r[2]), bf2f((bf16_t)r[3])};
+                        f32x2 r0 = {bf2f((bf16_t)r[0]), bf2f((bf16_t)r[1])}, r1 = {bf2f((bf16_t)r[2]), bf2f((bf16_t)r[3])};
+                        if (p.res1) { const float xv = __uint_as_float(__builtin_bit_cast(u32x2, r)[0]); r0 = (f32x2){xv, xv}; r1 = r0; }
                         v0 += r0 * ers[0] + erb[0]; v1 += r1 * ers[1] + erb[1];
                     }
                     pk[e] = (bf16x4){(short)f2bf(v0[0]), (short)f2bf(v0[1]), (short)f2bf(v1[0]), (short)f2bf(v1[1])};

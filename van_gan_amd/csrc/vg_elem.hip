@@ -553,6 +553,85 @@ __global__ __launch_bounds__(256) void stem_short_bwd_kernel(const T* g, const f
     }
     if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);            // left at zero for the next launch that is handed this word
 }
+// The stem's shortcut in the forward pass, never materialised (include/vangan_hip.h: vg_stem_short_fwd): mean and variance of the volume ->
+// the per-(sample, channel) affine  scale * x + shift  that the block's second convolution adds in its epilogue (vg_conv_desc::res_c1).
+__global__ __launch_bounds__(256) void stem_short_fwd_kernel(const float* x, int N, int64_t S, int C, const float* w, const float* gamma,
+                                                             const float* beta, float eps, int round16, float* scale, float* shift, double* part,
+                                                             unsigned* ticket) {
+    __shared__ float sm[4][2];
+    __shared__ double fin[256][2];
+    __shared__ double mom[2];
+    __shared__ int last;
+    const int tid = threadIdx.x, n = blockIdx.y, G = gridDim.x;
+    const float* xn = x + (size_t)n * S;
+    float sx = 0.f, sxx = 0.f;
+    const int64_t S4 = (((uintptr_t)xn & 15) == 0) ? S >> 2 : 0;
+    const int64_t step = (int64_t)G * 256;
+    int64_t i = (int64_t)blockIdx.x * 256 + tid;
+    for (; i + 3 * step < S4; i += 4 * step) {
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *(const __attribute__((address_space(1))) f32x4*)(uintptr_t)(xn + 4 * (i + u * step));
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { sx += v[u][j]; sxx = fmaf(v[u][j], v[u][j], sxx); }
+    }
+    for (; i < S4; i += step) {
+        const f32x4 v = *(const __attribute__((address_space(1))) f32x4*)(uintptr_t)(xn + 4 * i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { sx += v[j]; sxx = fmaf(v[j], v[j], sxx); }
+    }
+    for (int64_t k = 4 * S4 + (int64_t)blockIdx.x * 256 + tid; k < S; k += step) { const float v = xn[k]; sx += v; sxx = fmaf(v, v, sxx); }
+    sx = wave_sum(sx); sxx = wave_sum(sxx);
+    if ((tid & 63) == 0) { sm[tid >> 6][0] = sx; sm[tid >> 6][1] = sxx; }
+    __syncthreads();
+    if (tid < 2)
+        __hip_atomic_store(part + ((size_t)n * G + blockIdx.x) * 2 + tid, (((double)sm[0][tid] + (double)sm[1][tid]) + (double)sm[2][tid]) + (double)sm[3][tid],
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(N * G - 1) ? 1 : 0;
+    __syncthreads();
+    if (!last) return;
+    for (int nn = 0; nn < N; ++nn) {
+        double a0 = 0., a1 = 0.;
+        for (int gi = tid; gi < G; gi += 256) {
+            a0 += __hip_atomic_load(part + ((size_t)nn * G + gi) * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            a1 += __hip_atomic_load(part + ((size_t)nn * G + gi) * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        fin[tid][0] = a0; fin[tid][1] = a1;
+        __syncthreads();
+        if (tid < 2) { double a = 0.; for (int k = 0; k < 256; ++k) a += fin[k][tid]; mom[tid] = a; }       // fixed order
+        __syncthreads();
+        const double mu = mom[0] / (double)S;
+        double var = mom[1] / (double)S - mu * mu;
+        var = var < 0. ? 0. : var;
+        for (int c = tid; c < C; c += 256) {
+            const double wc = round16 ? (double)bf2f(f2bf(w[c])) : (double)w[c];
+            const double sc = (double)gamma[c] * wc / sqrt(wc * wc * var + (double)eps);
+            scale[nn * C + c] = (float)sc;
+            shift[nn * C + c] = (float)((double)beta[c] - sc * mu);
+        }
+        __syncthreads();
+    }
+    if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+extern "C" int vg_stem_short_fwd_workgroups(int N, int64_t S) {
+    if (N < 1 || S < 1) return VG_EINVAL;
+    int64_t g = S / 32768;                  // 32 float4 per thread
+    if (g < 1) g = 1;
+    if (g > 128) g = 128;
+    return (int)g;
+}
+extern "C" int vg_stem_short_fwd(const float* x, int N, int64_t S, int C, const float* w, const float* gamma, const float* beta, float eps, int round16,
+                                 float* scale, float* shift, double* part, int G, unsigned* ticket, vg_stream_t stream) {
+    vg_begin();
+    if (!x || !w || !gamma || !beta || !scale || !shift || !part || !ticket || C < 1) return VG_EINVAL;
+    if (G < 1 || G != vg_stem_short_fwd_workgroups(N, S)) return VG_EINVAL;
+    hipLaunchKernelGGL(stem_short_fwd_kernel, dim3(G, N), dim3(256), 0, (hipStream_t)stream, x, N, S, C, w, gamma, beta, eps, round16, scale, shift, part, ticket);
+    return vg_check_launch();
+}
 extern "C" int vg_stem_short_bwd_workgroups(int N, int64_t S, int C) {
     if (N < 1 || S < 1 || C < 8 || C > 64 || (256 % C)) return VG_EINVAL;
     const int vpb = 256 / (C >> 3);

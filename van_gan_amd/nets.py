@@ -19,6 +19,11 @@ from .ops import ACT_LRELU, ACT_NONE, ACT_RELU, Arena, ConvLayer, Src
 
 GEN_F = [16, 32, 64, 128, 256]
 _STEM_AUX = os.environ.get('VG_STEM_AUX', '1') != '0'      # the stem shortcut's kernel gradient in closed form from the statistics pass (backward_iter)
+# The stem's shortcut is never materialised: Conv3D(16, 1x1x1)(x) -> InstanceNorm of the single-channel volume is an affine function of x per
+# (sample, channel) -- vg_stem_short_fwd gives scale / shift from the volume's mean and variance, stem.cb's epilogue adds scale * x + shift
+# (vg_conv_desc::res_c1).  No 1 -> 16 launch, no 16-channel tensor written and read back (64 B per voxel and application), and the branch
+# is exact where the stored tensor was rounded to 16 bits.  0: the materialised branch (needed by the explicit backward, VG_STEM_AUX=0).
+_STEM_FUSED = os.environ.get('VG_STEM_FUSED', '1') != '0'
 
 
 def gen_param_specs() -> List[Tuple[str, Tuple[int, ...], str]]:
@@ -395,14 +400,21 @@ class ResUNet:
         sx = Src(x, (N,) + lv[0], 1, f32=True)
         c1 = Act(ar, N, lv[0], f[0], dtype=self.dtype)
         L['stem.conv1'].forward(sx, c1.data, sums=c1.sums, fin=ops.fin_desc(ar, c1.count, [Nn['stem.cb'].job(pre['stem.cb'])]) if tail else None)
-        sc = Act(ar, N, lv[0], f[0], dtype=self.dtype)
-        L['stem.short'].forward(sx, sc.data, sums=sc.sums, fin=ops.fin_desc(ar, sc.count, [Nn['stem.short'].job(pre['stem.short'])]) if tail else None)
-        ns = pre['stem.short'] if tail else Nn['stem.short'].finalize(ar, sc)
+        fused = _STEM_FUSED and _STEM_AUX
+        if fused:
+            sc = None
+            ns = dict(scale=ar.alloc((N, f[0]), torch.float32), shift=ar.alloc((N, f[0]), torch.float32), mean=None, rstd=None, mult=None)
+            ops.stem_short_fwd(ar, x, N, f[0], L['stem.short'].w, Nn['stem.short'].gamma, Nn['stem.short'].beta, ns['scale'], ns['shift'],
+                               round16=self.dtype != torch.float32)
+        else:
+            sc = Act(ar, N, lv[0], f[0], dtype=self.dtype)
+            L['stem.short'].forward(sx, sc.data, sums=sc.sums, fin=ops.fin_desc(ar, sc.count, [Nn['stem.short'].job(pre['stem.short'])]) if tail else None)
+            ns = pre['stem.short'] if tail else Nn['stem.short'].finalize(ar, sc)
         n1 = pre['stem.cb'] if tail else Nn['stem.cb'].finalize(ar, c1)
         s1 = Src(c1.data, (N,) + lv[0], f[0], scale=n1['scale'], shift=n1['shift'], act=ACT_RELU)
         h = Act(ar, N, lv[0], f[0], dtype=self.dtype)
-        L['stem.cb'].forward(s1, h.data, sums=h.sums, res=sc.data, res_scale=ns['scale'], res_shift=ns['shift'],
-                             fin=ops.fin_desc(ar, h.count, jobs['stem']) if tail else None)
+        L['stem.cb'].forward(s1, h.data, sums=h.sums, res=x if fused else sc.data, res_scale=ns['scale'], res_shift=ns['shift'],
+                             fin=ops.fin_desc(ar, h.count, jobs['stem']) if tail else None, res_c1=fused)
         ctx['stem'] = dict(sx=sx, c1=c1, sc=sc, ns=ns, n1=n1, s1=s1, out=h)
         yield
         skips = [h]
@@ -566,8 +578,8 @@ class ResUNet:
         # stem
         s = ctx['stem']
         d_out = s['out'].grad
-        ssc = Src(s['sc'].data, (N,) + s['sc'].dims, s['sc'].C)
-        stem_aux = _STEM_AUX
+        stem_aux = _STEM_AUX or s['sc'] is None             # (a fused forward has no stored shortcut tensor to run the explicit path on)
+        ssc = None if s['sc'] is None else Src(s['sc'].data, (N,) + s['sc'].dims, s['sc'].C)
         if stem_aux:
             # the shortcut reads the single-channel volume and nobody needs its data gradient; its output normalises to
             # w*rs*(x - mean x), so the loss sees w only through eps: dL/dw = eps*gamma*rs^3 * sum d_out*(x - mean x), dL/db = 0 -- a closed
@@ -575,7 +587,7 @@ class ResUNet:
             # weight-gradient launch, no read of the stored shortcut tensor: two full-resolution 16-channel passes per sweep less, and a
             # well-conditioned, deterministic number where the explicit path sums a million cancelling terms.
             nrm = Nn['stem.short']
-            ops.stem_short_bwd(ar, d_out, s['sx'].x0, N, ssc.C, L['stem.short'].w, nrm.gamma, L['stem.short'].gw,
+            ops.stem_short_bwd(ar, d_out, s['sx'].x0, N, GEN_F[0], L['stem.short'].w, nrm.gamma, L['stem.short'].gw,
                                dgamma=nrm.dgamma, dbeta=nrm.dbeta, round16=self.dtype != torch.float32)
         else:
             d_sc = ar.alloc(s['sc'].data.shape, self.dtype)

@@ -66,7 +66,7 @@ class DryRun:
     records: [(kind, layer name, variant string)], kind in fwd / dgrad / wgrad."""
 
     _PASS = ('vg_conv3d_dma_bn', 'vg_conv3d_scratch_bytes', 'vg_conv3d_thin_np', 'vg_conv3d_plan', 'vg_packed_ktot', 'vg_packed_rows', 'vg_conv3d_lds_bytes', 'vg_status_string', 'vg_set_tuning',
-             'vg_stem_short_bwd_workgroups')
+             'vg_stem_short_bwd_workgroups', 'vg_stem_short_fwd_workgroups')
 
     def __init__(self):
         self.records = []
@@ -844,8 +844,9 @@ class ConvLayer:
         return d
 
     def forward(self, src: Src, out: torch.Tensor, sums=None, res=None, res_scale=None, res_shift=None,
-                tanh: bool = False, accumulate: bool = False, fin: Optional[FinDesc] = None):
-        """fin (ops.fin_desc, with sums): the launch also finalises the InstanceNorm statistics of `out` for its consuming norm(s)."""
+                tanh: bool = False, accumulate: bool = False, fin: Optional[FinDesc] = None, res_c1: bool = False):
+        """fin (ops.fin_desc, with sums): the launch also finalises the InstanceNorm statistics of `out` for its consuming norm(s).
+        res_c1: `res` is a single-channel fp32 volume [N, D, H, W, 1] broadcast over the output channels (vg_conv_desc::res_c1)."""
         assert src.C == self.cin and (src.D, src.H, src.W) == tuple(self.in_dims)
         d = self._fwd_desc(src)
         if fin is not None:
@@ -856,6 +857,8 @@ class ConvLayer:
                 REC.keep.append(fin)
         d.bias = _p(self.b)
         d.res, d.res_scale, d.res_shift = _p(res), _p(res_scale), _p(res_shift)
+        d.res_c1 = int(bool(res_c1) and res is not None)
+        assert not d.res_c1 or res.dtype == torch.float32
         d.tanh_out = int(tanh)
         d.out, d.out_f32, d.accumulate = _p(out), int(out.dtype == torch.float32), int(bool(accumulate))
         d.out_sums = _p(sums)
@@ -863,7 +866,7 @@ class ConvLayer:
         conv_scratch(d, s_, out.device.index)
         if DRY is not None:
             DRY.tag = ('fwd', self.name)
-            DRY.recipe = dict(kind='fwd', layer=self.ctor, src=src.recipe(), res=res is not None, tanh=bool(tanh),
+            DRY.recipe = dict(kind='fwd', layer=self.ctor, src=src.recipe(), res=res is not None, res_c1=bool(res_c1), tanh=bool(tanh),
                               sums=sums is not None, out_f32=out.dtype == torch.float32)
         e0 = PROF.begin() if PROF is not None else None
         check(lib.vg_conv3d(C.byref(d), s_), 'vg_conv3d ' + self.name)
@@ -1260,6 +1263,20 @@ def actnorm_desc(g, g_padded, x, dims, C_, dx, *, scale=None, shift=None, mult=N
 
 def actnorm_stats(d: ActNormBwdDesc):
     check(lib.vg_actnorm_bwd_stats(C.byref(d), stream()), 'vg_actnorm_bwd_stats')
+
+
+def stem_short_fwd(ar: 'Arena', x, N, C_, w, gamma, beta, scale, shift, round16=True):
+    """The stem's shortcut (1x1x1 convolution of the single-channel volume + InstanceNorm) as the affine  scale * x + shift  per (sample,
+    channel), from the mean and variance of the volume (vg_stem_short_fwd): the branch is never materialised, the block's second
+    convolution adds it in its epilogue (ConvLayer.forward(res=x, res_c1=True))."""
+    S = x.numel() // N
+    G = int(lib.vg_stem_short_fwd_workgroups(N, S))
+    if G < 1:
+        raise _lib.VgError('vg_stem_short_fwd: unsupported shape N=%d S=%d' % (N, S))
+    part = ar.alloc((N, G, 2), torch.float64)
+    ticket = ar.alloc((4,), torch.int32, zero=True)
+    check(lib.vg_stem_short_fwd(_p(x), N, S, C_, _p(w), _p(gamma), _p(beta), IN_EPS, int(round16), _p(scale), _p(shift), _p(part), G, _p(ticket),
+                                stream()), 'vg_stem_short_fwd')
 
 
 def stem_short_bwd(ar: 'Arena', g, x, N, C_, w, gamma, dw, dgamma=None, dbeta=None, round16=True):
