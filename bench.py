@@ -24,7 +24,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
-PMC_SUMMARY = 'r05_hbm_pmc.json'   # tools/hbm_pmc.py output for the current kernels (stamped with their source hash)
+PMC_SUMMARY = 'r06_hbm_pmc.json'   # tools/hbm_pmc.py output for the current kernels (stamped with their source hash)
 CONV_FLOP_PER_VOXEL = 2530548.0    # 12 F_G + 14 F_D per voxel-sample-step
 
 
