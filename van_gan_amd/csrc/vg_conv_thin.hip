@@ -531,7 +531,7 @@ __global__ __launch_bounds__(256, VG_THIN_WPE) void conv_thin_kernel(const Gathe
 #pragma unroll
                         for (int j = jp; j < jp + RRN; ++j) {
                             const bool ok = !MASKED || (dw_ok && j < nrow);
-                            if (p.res1) {
+                            if (NP == 1 && p.res1) {                    // (one-panel instances only: the 16-channel stem; the two-panel epilogue has no register to spare)
                                 const float xv = ld_global(ok ? r1ptr + (size_t)j * p.BW : r1ptr);
                                 rr[j] = __builtin_bit_cast(bf16x4, (u32x2){__float_as_uint(xv), 0u});
                             } else
@@ -549,7 +549,7 @@ __global__ __launch_bounds__(256, VG_THIN_WPE) void conv_thin_kernel(const Gathe
                     if (RES) {
                         const bf16x4 r = rr[RES ? j : 0];
                         f32x2 r0 = {bf2f((bf16_t)r[0]), bf2f((bf16_t)r[1])}, r1 = {bf2f((bf16_t)r[2]), bf2f((bf16_t)r[3])};
-                        if (p.res1) { const float xv = __uint_as_float(__builtin_bit_cast(u32x2, r)[0]); r0 = (f32x2){xv, xv}; r1 = r0; }
+                        if (NP == 1 && p.res1) { const float xv = __uint_as_float(__builtin_bit_cast(u32x2, r)[0]); r0 = (f32x2){xv, xv}; r1 = r0; }
                         v0 += r0 * ers[0] + erb[0]; v1 += r1 * ers[1] + erb[1];
                     }
                     pk[e] = (bf16x4){(short)f2bf(v0[0]), (short)f2bf(v0[1]), (short)f2bf(v1[0]), (short)f2bf(v1[1])};
@@ -677,6 +677,7 @@ bool vg_conv_thin_ok(const vg_conv_desc* d, const GatherIn& g, const ConvOut& k,
     if (!g.planar || g.HW != HW || g.HH != HH || g.HD != HD || g.HWp != HW || g.HHp != HH || g.DS != DSB || g.PSB != PSB) return false;
     if ((1 << g.twl) != TW || (1 << g.thl) != TH || (1 << g.tdl) != TD) return false;
     if (d->res && (d->bias == nullptr)) return false;                  // (instantiated combinations only)
+    if (d->res_c1 && np != 1) return false;                           // (the single-channel residual lives in the one-panel epilogue)
     if (k.Ktot != k.nchunks * KCPAD) return false;
     for (int i = 0; i < 27; ++i)                                       // a full 3x3x3 stencil (any order)
         if (d->tap_d[i] - g.tmin_d > 2 || d->tap_h[i] - g.tmin_h > 2 || d->tap_w[i] - g.tmin_w > 2) return false;
