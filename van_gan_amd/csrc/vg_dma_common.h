@@ -71,18 +71,24 @@ __device__ __forceinline__ void vg_pack_dma_units(const float* __restrict__ w, c
                                   int ntaps, int transpose, int bn, int u0, int ustride) {
     const int NR = transpose ? Cin : Cout, C = transpose ? Cout : Cin;
     const int npl = C >> 4;
-    const long units = (long)NR * npl * ntaps * 2;
-    for (long u = u0; u < units; u += ustride) {
-        long t = u;
-        const int row = (int)(t % bn); t /= bn;
-        const int half = (int)(t & 1); t >>= 1;
-        const int tap = (int)(t % ntaps); t /= ntaps;
-        const int plane = (int)(t % npl); const int cob = (int)(t / npl);
+    // 32-bit index arithmetic (units = NR * npl * ntaps * 2 <= 2^22 for the widest layer; the 64-bit divisions of the first version
+    // were most of this kernel's time) and, for the data-gradient layout, the unit's 8 contraction channels as two 16-byte loads
+    const unsigned units = (unsigned)NR * (unsigned)npl * (unsigned)ntaps * 2u;
+    const bool vec = transpose && (((uintptr_t)w & 15) == 0) && (Cout % 8) == 0;
+    for (unsigned u = (unsigned)u0; u < units; u += (unsigned)ustride) {
+        unsigned t = u;
+        const int row = (int)(t % (unsigned)bn); t /= (unsigned)bn;
+        const int half = (int)(t & 1u); t >>= 1;
+        const int tap = (int)(t % (unsigned)ntaps); t /= (unsigned)ntaps;
+        const int plane = (int)(t % (unsigned)npl); const int cob = (int)(t / (unsigned)npl);
         const int r = cob * bn + row, c0 = plane * 16 + half * 8, ts = tap_idx[tap];
         float v[8];
+        if (vec) load8<float>(w + ((size_t)ts * Cin + r) * Cout + c0, v);
+        else {
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
-            v[e] = transpose ? w[((size_t)ts * Cin + r) * Cout + c0 + e] : w[((size_t)ts * Cin + c0 + e) * Cout + r];
-        store8<bf16_t>(out + u * 8, v);
+            for (int e = 0; e < 8; ++e)
+                v[e] = transpose ? w[((size_t)ts * Cin + r) * Cout + c0 + e] : w[((size_t)ts * Cin + c0 + e) * Cout + r];
+        }
+        store8<bf16_t>(out + (size_t)u * 8, v);
     }
 }
