@@ -172,6 +172,12 @@ typedef struct {
        the 4-byte volume instead of a stored 16-channel tensor (vg_stem_short_fwd produces the scale / shift).  Served by the 16-channel
        specialist and the generic kernel; other families return VG_EINVAL. */
     int32_t res_c1;
+    /* Optional, forward launches whose src0 is the virtually upsampled half-resolution tensor (src0_shift != 0, c_src0 a multiple of 16,
+       reflection pad, 3x3x3): the class panels of vg_pack_up_weights for the c_src0 / 16 upsampled channel chunks.  The 16-channel
+       specialist then contracts those chunks over the half-resolution image with the D / H taps collapsed (12 instead of 27 taps per
+       chunk; UpSampling3D + IN + ReLU + reflect pad + Conv3D of resunet_model.py:175-181 and :42-66 -- IN and ReLU commute with the
+       upsampling, the reflection pad becomes edge replication at half resolution).  NULL: the plain 27-tap form. */
+    const void* wpacked_up;
 } vg_conv_desc;
 #define VG_SCRATCH_CTR_BYTES 16384
 
@@ -195,6 +201,13 @@ int vg_conv3d_variant(const vg_conv_desc* d, char* buf, int buflen);
    environment variable that sets the same switch, e.g. ("CONV_MSUB", 4).  reset != 0: back to environment / default.
    Testing and tuning aid; the defaults are what the benchmarks run. */
 int vg_set_tuning(const char* key, int value, int reset);
+
+/* Class panels of the collapsed upsampled chunks (vg_conv_desc::wpacked_up) from the fp32 DHWIO kernel w[3][3][3][Cin][Cout] of a decoder
+ * block's first convolution whose first c_up input channels (a multiple of 16) are the upsampled tensor:
+ *   out[chunk][class = pd*2 + ph][co][(td*2 + th)*3 + tw][16 channels of the chunk]   (16-bit storage format of the build), where for an
+ *   output voxel of parity p along an axis the collapsed tap t = 0 sums the original taps {-1} (p = 0) or {-1, 0} (p = 1) and t = 1 sums
+ *   {0, +1} (p = 0) or {+1} (p = 1); sums in fp32, one rounding. */
+int vg_pack_up_weights(const float* w, int Cin, int Cout, int c_up, void* out, vg_stream_t stream);
 
 /* Pack fp32 Keras DHWIO weights [T][Cin][Cout] to the bf16 layout vg_conv3d reads.
  * transpose=0: rows = Cout, contraction = Cin (forward); transpose=1: rows = Cin, contraction =

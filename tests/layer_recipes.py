@@ -129,6 +129,8 @@ def make_layer_from(ctor, dev, seed=0, dtype=torch.bfloat16):
         st.param('c.b').copy_(torch.randn(cout, generator=g) * 0.1)
     lay = ConvLayer(st, 'c', k, cin, cout, ctor['stride'], ctor['pad'], ctor['bias'], ctor['in_dims'],
                     need_dgrad=ctor['need_dgrad'], dtype=dtype)
+    if ctor.get('c_up'):
+        lay.enable_up(ctor['c_up'])
     return st, lay
 
 

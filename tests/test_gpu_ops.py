@@ -894,3 +894,52 @@ def test_stem_shortcut_as_an_affine_function_of_the_volume(dims, N, f32):
     # the output statistics the launch accumulated are those of the stored values
     o = out.double().cpu()
     assert rel_l2(sums.sum(0)[..., 0], o.sum((1, 2, 3))) < 1e-4 and rel_l2(sums.sum(0)[..., 1], (o ** 2).sum((1, 2, 3))) < 1e-4
+
+
+def test_collapsed_upsampled_chunks_of_the_decoder_convolution():
+    """conv_thin_kernel<..., UP> (off by default, VG_CONV_THIN_UP=1): the upsampled channel chunks of a decoder block's first convolution
+    contracted over the half-resolution image with the D / H taps collapsed (UpSampling3D -> concatenate -> IN -> ReLU -> reflect pad ->
+    3x3x3 convolution, resunet_model.py:175-181, 42-66): against the plain 27-tap form of the SAME launch (bitwise-close: only the single
+    rounding of the summed weights differs) and against the float64 oracle on the virtual concat, incl. the grid's border tiles where the
+    reflection pad turns into edge replication at half resolution."""
+    from van_gan_amd import ops
+    from van_gan_amd.ops import Src
+    dev = _dev()
+    N, dims, cu, cs, cout = 1, (64, 64, 64), 32, 16, 16             # (the layer planner hands this shape to the specialist with 16-channel chunks)
+    old = os.environ.get('VG_CONV_THIN_UP')
+    outs = {}
+    try:
+        for up in (0, 1):
+            os.environ['VG_CONV_THIN_UP'] = str(up)
+            ops._lib.lib.vg_set_tuning(b'CONV_THIN_UP', up, 0)
+            st, lay = make_layer(3, cu + cs, cout, 1, 'reflect', dims, seed=5)
+            lay.enable_up(cu)
+            lay.pack()
+            assert (lay.wp_up is not None) == bool(up)
+            g = torch.Generator().manual_seed(2)
+            low = torch.randn(N, *(n // 2 for n in dims), cu, generator=g).to(torch.bfloat16)
+            skip = torch.randn(N, *dims, cs, generator=g).to(torch.bfloat16)
+            scale = torch.rand(N, cu + cs, generator=g) + 0.5
+            shift = torch.randn(N, cu + cs, generator=g) * 0.3
+            src = Src(low.to(dev), (N,) + dims, cu, skip.to(dev), cs, shift0=1, scale=scale.to(dev), shift=shift.to(dev), act=ops.ACT_RELU)
+            out = torch.zeros(N, *dims, cout, dtype=torch.bfloat16, device=dev)
+            sums = torch.zeros(8, N, cout, 2, device=dev)
+            with ops.DryRun() as dr:
+                lay.forward(src, out, sums=sums)
+            assert (',up>' in dr.records[0][2]) == bool(up), dr.records
+            lay.forward(src, out, sums=sums)
+            torch.cuda.synchronize()
+            outs[up] = out.double().cpu()
+    finally:
+        ops._lib.lib.vg_set_tuning(b'CONV_THIN_UP', 0, 1)
+        if old is None:
+            os.environ.pop('VG_CONV_THIN_UP', None)
+        else:
+            os.environ['VG_CONV_THIN_UP'] = old
+    upx = low.double().repeat_interleave(2, 1).repeat_interleave(2, 2).repeat_interleave(2, 3)
+    cat = torch.cat([upx, skip.double()], dim=-1)
+    a = F.relu(cat * scale.double().view(N, 1, 1, 1, -1) + shift.double().view(N, 1, 1, 1, -1))
+    y = O.to_ndhwc(ref_conv(O.to_ncdhw(bf(a)), bf(st.param('c.w').cpu()), st.param('c.b').cpu().double(), 1, 'reflect'))
+    close_bf16(outs[0], y, '27-tap form')
+    close_bf16(outs[1], y, 'collapsed form')
+    assert rel_l2(outs[1], outs[0]) < 6e-3          # two bf16 results of the same sums, one with the weights summed before rounding

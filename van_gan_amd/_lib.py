@@ -32,7 +32,7 @@ class ConvDesc(C.Structure):
         ('out', c_void_p), ('out_f32', c_int), ('accumulate', c_int), ('out_sums', c_void_p), ('f32', c_int),
         ('nclass', c_int), ('cls_tap0', c_int * 9), ('cls_w', c_void_p * 8), ('cls_ooff', (c_int * 3) * 8),
         ('cls_iters', (c_int * 3) * 8), ('wpack', c_int), ('wpack_wmin', c_int), ('bstat', c_void_p),
-        ('scratch', c_void_p), ('scratch_bytes', c_i64), ('wlayout', c_int), ('fin', c_void_p), ('res_c1', c_int),
+        ('scratch', c_void_p), ('scratch_bytes', c_i64), ('wlayout', c_int), ('fin', c_void_p), ('res_c1', c_int), ('wpacked_up', c_void_p),
     ]
 
 
@@ -136,6 +136,7 @@ _SIGS = {
     'vg_adam_clip_dev': ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_i64, c_void_p, c_void_p, c_float,
                           c_float, c_float, c_float, c_float, c_void_p], c_int),
     'vg_set_step_params': ([c_void_p, c_u64, c_float, c_float, c_float, c_float, c_float, c_void_p], c_int),
+    'vg_pack_up_weights': ([c_void_p, c_int, c_int, c_int, c_void_p, c_void_p], c_int),
     'vg_memset_zero': ([c_void_p, c_i64, c_void_p], c_int),
     'vg_copy_bytes': ([c_void_p, c_void_p, c_i64, c_void_p], c_int),
     'vg_f32_to_bf16': ([c_void_p, c_void_p, c_i64, c_void_p], c_int),

@@ -33,6 +33,7 @@ static int vg_ablate_knob(const char* key) {
 }
 #include "vg_dma_common.h"
 #include <type_traits>
+#include <algorithm>
 #include <cstdio>
 
 #ifndef VG_THIN_WPE
@@ -40,6 +41,9 @@ static int vg_ablate_knob(const char* key) {
 #endif
 #ifndef VG_THIN_PF2
 #define VG_THIN_PF2 0     // prefetch of the next halo under the MFMA loop in the two-panel forward instances too: spills 14-58 registers there
+#endif
+#ifndef VG_THIN_UP_NOPF
+#define VG_THIN_UP_NOPF 0
 #endif
 #ifndef VG_THIN_PD
 #define VG_THIN_PD 1      // K-steps of fragments in flight ahead of the MFMAs (2 measured the same; 1 leaves the registers for the staged loads)
@@ -166,6 +170,94 @@ __device__ __forceinline__ void thin_commit(const GatherIn& g, char* halo, const
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// UP: channel chunks that come from the virtually UPSAMPLED half-resolution tensor of a decoder block's first convolution
+// (resunet_model.py:175-181: UpSampling3D(2) -> concatenate -> IN -> ReLU -> reflect pad -> 3^3 convolution).  IN and ReLU act per
+// voxel and channel, so they commute with the nearest-neighbour upsampling, and along D and H the three taps of a fine output voxel of
+// parity p read only TWO half-resolution voxels: p = 0 -> (i - 1) with weight W[-1] and i with W[0] + W[1]; p = 1 -> i with
+// W[-1] + W[0] and (i + 1) with W[1]; the reflection pad at fine resolution is edge replication at half resolution.  A sub-tile of this
+// kernel is one fine row (fixed d, h): its 16 columns share the (D, H) parity class, so the accumulator layout and the whole epilogue
+// stay as they are -- only the operand changes: the halo image holds 4 half-resolution planes x 6 half-resolution rows x 18 FINE
+// columns (W is not collapsed: the columns of a sub-tile alternate in W parity), 13.8 instead of 34.6 KB staged and transformed per
+// chunk, and the contraction is 12 collapsed taps x 16 channels = 6 K-steps instead of 14, with one weight panel per class (vg_pack_up_weights).
+// ------------------------------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int UPD = 4, UPH = 6;                         // half-resolution planes / rows of a tile's halo
+constexpr int UPCOLS = UPH * HW * 2;                   // (row, column, channel group) columns of one plane: 216
+constexpr int UPITEMS = UPCOLS * 2;                    // x 2 plane pairs
+constexpr int KUP = 192;                               // 12 collapsed taps x 16 channels
+constexpr int KSUP = 6;                                // K-steps of an upsampled chunk
+constexpr int WRSU = KUP * 2 + 16;                     // LDS row stride of a class panel
+}
+// column table of the half-resolution image (same plane geometry as the fine one: row stride ROWB, plane stride DSB)
+__device__ __forceinline__ void build_up_table(int* utu, int tid) {
+    for (int col = tid; col < UPCOLS; col += 256) {
+        const int cg = col / (UPH * HW), v = col - cg * (UPH * HW);
+        const int lr = v / HW, hw = v - lr * HW;
+        utu[2 * col] = lr | (hw << 10) | (cg << 20);
+        utu[2 * col + 1] = cg * PSB + (lr * HW + hw) * UNIT;
+    }
+}
+// half-resolution axis tables of src0 for the whole grid: entry j of an axis is half-resolution position (j - 1), edge-replicated
+__device__ __forceinline__ void thin_up_axis_tables(const GatherIn& g, int* lowtab, int NHl, int NDl, int tid) {
+    const int Hs = g.H >> 1, Ws = g.W >> 1, Ds = g.D >> 1;
+    for (int i = tid; i < NHl + NDl; i += 256) {
+        const bool isH = i < NHl;
+        int L = (isH ? i : i - NHl) - 1;
+        const int n_ax = isH ? Hs : Ds;
+        L = L < 0 ? 0 : (L >= n_ax ? n_ax - 1 : L);
+        const long off = isH ? (long)L * Ws * g.c0 : (long)L * Hs * Ws * g.c0;
+        lowtab[i] = (int)(off * 2);
+    }
+}
+struct ThinUpTab { const int* wtab; const int* lowH; const int* lowD; };          // wtab: the fine W axis table of src0 at this tile's origin
+template <int MODE>
+__device__ __forceinline__ void thin_issue_up(const GatherIn& g, const int* utu, const ThinUpTab& t, int n, int chunk, int tid, Raw8<bf16_t> (&raw)[3][HD / 2]) {
+    const char* b0 = (const char*)g.src0 + (size_t)n * (g.D >> 1) * (g.H >> 1) * (g.W >> 1) * g.c0 * 2;
+    asm volatile("" : "+v"(tid));             // (nothing of the per-thread item decode is to live across the tile loop)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int item = tid + 256 * i;
+        if (i < 1 || item < UPITEMS) {
+            const int seg = item >= UPCOLS ? 1 : 0, col = item - seg * UPCOLS;
+            const int e = utu[2 * col];
+            const int lr = e & 1023, hw = (e >> 10) & 1023, cg = e >> 20;
+            const char* pc = b0 + (size_t)(chunk * 16 + cg * 8) * 2 + (t.lowH[lr] + max(t.wtab[hw], 0));
+#pragma unroll
+            for (int k = 0; k < 2; ++k) raw_load(raw[i][k], (const bf16_t*)(pc + (unsigned)t.lowD[seg * 2 + k]));
+        }
+    }
+}
+__device__ __forceinline__ void thin_commit_up(char* halo, const float* scs, const int* utu, int tid, Raw8<bf16_t> (&raw)[3][HD / 2]) {
+    asm volatile("" : "+v"(tid));
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int item = tid + 256 * i;
+        if (i < 1 || item < UPITEMS) {
+            const int seg = item >= UPCOLS ? 1 : 0, col = item - seg * UPCOLS;
+            const int cg = utu[2 * col] >> 20, hoff = utu[2 * col + 1] + seg * 2 * DSB;
+            f32x2 sc[4], sf[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                sc[j] = (f32x2){scs[cg * 8 + 2 * j], scs[cg * 8 + 2 * j + 1]};
+                sf[j] = (f32x2){scs[16 + cg * 8 + 2 * j], scs[16 + cg * 8 + 2 * j + 1]};
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                float x[8];
+                raw_unpack(raw[i][k], x);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x2 v = {x[2 * j], x[2 * j + 1]};
+                    v = v * sc[j] + sf[j];
+                    x[2 * j] = fmaxf(v[0], 0.f); x[2 * j + 1] = fmaxf(v[1], 0.f);
+                }
+                store8<bf16_t>((bf16_t*)(halo + hoff + k * DSB), x);
+            }
+        }
+    }
+}
+
 // MODE: VG_STAGE_PLAIN (data-gradient operand, zero padded) or VG_STAGE_RELU (forward: IN affine + ReLU, reflect padded)
 // BSTAT (data gradient): the epilogue also accumulates the statistics of the IN backward that consumes this output --
 // sum dn and sum dn * xhat with dn = g * mult * act'(x * scale + shift) taken at the reflect-folded position of the pre-norm
@@ -173,9 +265,10 @@ __device__ __forceinline__ void thin_commit(const GatherIn& g, char* halo, const
 // PL (data gradient of a 16-channel tensor into 16 PL channels -- dec0.cb1's 16 -> 48): the PL output panels are LOOPED over one staged
 // halo image instead of being separate workgroups that each stage it; the 16 x 448 weight panel of the next use arrives by LDS-DMA
 // (two buffers) under the MFMA loop of the current one, the statistics of a panel are flushed to LDS per tile (registers).
-template <int MODE, bool BIAS, bool RES, bool STATS, bool BSTAT = false, int NP = 1, int PL = 1>
+template <int MODE, bool BIAS, bool RES, bool STATS, bool BSTAT = false, int NP = 1, int PL = 1, bool UP = false>
 __global__ __launch_bounds__(256, VG_THIN_WPE) void conv_thin_kernel(const GatherIn g, const ConvOut p) {
     static_assert(PL == 1 || (NP == 1 && MODE == VG_STAGE_PLAIN && !BIAS && !RES && !STATS), "panel loop: plain data gradient only");
+    static_assert(!UP || (MODE == VG_STAGE_RELU && !RES && !BSTAT && PL == 1), "collapsed upsampled chunks: the decoder's first convolution, forward");
     // NP: 16-channel output panels per workgroup.  NP = 2 (the 32-channel layers at 64^3, conv_thin2 in the variant names): every B
     // fragment feeds two MFMAs -- 10 fragment reads per 16 MFMAs instead of 9 per 8 -- and the halo is staged once per 32 channels.
     typedef bf16_t T;
@@ -195,7 +288,11 @@ __global__ __launch_bounds__(256, VG_THIN_WPE) void conv_thin_kernel(const Gathe
     constexpr int NCOLS = HH * HW * 2;
     int* xtab = utab + 2 * NCOLS;                        // axis tables of the whole grid (thin_axis_tables)
     const int NHt = g.tiles_h * TH + 2, NWt = g.tiles_w * TW + 2, NDt = g.tiles_d * TD + 2;
-    char* wlds = (char*)(xtab + 2 * (NHt + NWt + NDt));
+    // UP: half-resolution axis tables of src0 [NHl + NDl] and the column table of the half-resolution image
+    const int NHl = UP ? g.tiles_h * (TH / 2) + 2 : 0, NDl = UP ? g.tiles_d * (TD / 2) + 2 : 0;
+    int* lowtab = xtab + 2 * (NHt + NWt + NDt);
+    int* utu = lowtab + NHl + NDl;
+    char* wlds = (char*)(utu + (UP ? 2 * UPCOLS + 16 : 0));
     wlds = (char*)(((size_t)wlds + (PL > 1 ? 1023 : 15)) & ~(size_t)(PL > 1 ? 1023 : 15));
     const int Ktot = p.Ktot, nchunks = p.nchunks;
     constexpr int WRS = KCPAD * 2 + 16;                  // LDS row stride of the chunk panel (16 bytes of padding: bank spread)
@@ -225,6 +322,8 @@ __global__ __launch_bounds__(256, VG_THIN_WPE) void conv_thin_kernel(const Gathe
         const char* src = (const char*)p.wp + ((size_t)cop * Ktot + (size_t)chunk * KCPAD) * 2;
         constexpr int NU = 16 * NP * 56, NK = (NU + 255) / 256;
         f32x4 v[NK];
+        int tid = threadIdx.x;
+        if constexpr (UP) asm volatile("" : "+v"(tid));          // (see load_weights_up: no hoisting of the per-thread addresses in the UP instances)
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
             const int u = min(tid + k * 256, NU - 1);
@@ -251,9 +350,10 @@ __global__ __launch_bounds__(256, VG_THIN_WPE) void conv_thin_kernel(const Gathe
             }
         }
     };
-    if constexpr (PL > 1) dma_weights(0, 0); else load_weights(0);
+    if constexpr (PL > 1) dma_weights(0, 0); else if constexpr (!UP) load_weights(0);        // (UP: chunk 0 is an upsampled one: loaded in the chunk loop, the lambda needs the tables)
     // ---- per-lane constants of the MFMA loop: B-fragment base of every K-step (tap and channel group of this lane's k-group)
     const int wbase = li * WRS + kg * 16;                                // A fragment: row li of panel 0, k-group kg (panel q: + 16 q rows)
+    const int wbase_up = li * WRSU + kg * 16;                            // ... of a class panel of an upsampled chunk (UP)
     const int co0 = cop + 4 * kg;                                        // this lane's 4 output channels of panel 0 (panel q: + 16 q)
     float s1[NP * PL][4], s2[NP * PL][4];              // PL: [0] is the panel in work, [1], [2] the next two (rotated after every panel)
     f32x2 e_b[NP][2], e_rs[NP][2], e_rb[NP][2];
@@ -309,6 +409,7 @@ __global__ __launch_bounds__(256, VG_THIN_WPE) void conv_thin_kernel(const Gathe
     { int t = t0; ti_w = t % g.tiles_w; t /= g.tiles_w; ti_h = t % g.tiles_h; ti_d = t / g.tiles_h; }
     if (nchunks == 1) stage_scale_shift(g, scs, n, 0, tid);
     thin_axis_tables(g, xtab, NHt, NWt, NDt, tid);
+    if constexpr (UP) { build_up_table(utu, tid); thin_up_axis_tables(g, lowtab, NHl, NDl, tid); }
     lds_only_barrier();
     auto tabat = [&](int od0_, int oh0_, int ow0_) { return ThinTab{xtab, NHt + NWt + NDt, NHt, NWt, od0_, oh0_, ow0_}; };
     int boff[KSTEPS];
@@ -321,14 +422,47 @@ __global__ __launch_bounds__(256, VG_THIN_WPE) void conv_thin_kernel(const Gathe
         }
     }
 
+    // UP: B-fragment base of the 6 K-steps of an upsampled chunk: k-group G = 4 s + kg -> collapsed tap G / 2 = (td * 2 + th) * 3 + tw
+    // of the 2 x 2 x 3 stencil on the half-resolution image, channel group G & 1; this wave's fine plane `wave` reads half-resolution
+    // planes ((wave + 1) >> 1) + td, sub-tile (fine row) j rows ((j + 1) >> 1) + th (the row part is an immediate of the read)
+    // (not kept in registers across the tile loop -- the instance has none to spare: the six bases are rebuilt from a 12-entry LDS table
+    //  at the head of every upsampled chunk's MFMA loop)
+    int* tapu = utu + 2 * UPCOLS;
+    if constexpr (UP) { if (tid < 12) { const int cdh = tid / 3, cw = tid - cdh * 3; tapu[tid] = (cdh >> 1) * DSB + (cdh & 1) * ROWB + cw * UNIT; } }
+    const int pd_cls = UP ? (wave & 1) * 2 : 0;                          // class = pd * 2 + ph; this wave's plane parity
+    constexpr int CLSB = 16 * NP * WRSU;                                 // bytes of one class panel in LDS
+    // the four class panels of one upsampled chunk -> LDS: 64 NP rows x 24 units of 16 bytes
+    auto load_weights_up = [&](int chunk) {
+        const char* src = (const char*)p.wp_up + ((size_t)chunk * 4 * p.Cout + cop) * KUP * 2;
+        constexpr int NU = 4 * 16 * NP * 24, NK = (NU + 255) / 256;
+        f32x4 v[NK];
+        int tl = tid;
+        asm volatile("" : "+v"(tl));          // opaque: the per-thread source / destination addresses are rebuilt here, not hoisted out of the tile loop
+                                              // (hoisted they are 6 NP 64-bit + 32-bit values per thread held across everything: 60-190 spilled registers)
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const int u = min(tl + k * 256, NU - 1);
+            const int r = u / 24, c = u - r * 24, cls = r / (16 * NP), rr = r - cls * 16 * NP;
+            v[k] = *(const __attribute__((address_space(1))) f32x4*)(uintptr_t)(src + ((size_t)cls * p.Cout + rr) * KUP * 2 + c * 16);
+        }
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const int u = tl + k * 256;
+            if (u < NU) { const int r = u / 24, c = u - r * 24; *(f32x4*)(wlds + r * WRSU + c * 16) = v[k]; }
+        }
+    };
+    auto uptab = [&](int od0_, int oh0_, int ow0_) { return ThinUpTab{xtab + NHt + ow0_, lowtab + (oh0_ >> 1), lowtab + NHl + (od0_ >> 1)}; };
     typedef const __attribute__((address_space(3))) bf16x8 lds_frag;
     int it = 0;
     // PF: the loads of the NEXT (tile, chunk) are issued ahead of the MFMA loop and stay in registers across it.  Forward instances
     // only (16 -> 16: 68 -> 64 us, 48 -> 16: 148 -> 142 us); the data-gradient instances got SLOWER with it (16 -> 48: 178 -> 195 us;
     // the BSTAT one sits at the register cap and spilled the nine units): they load, then commit, back to back.
-    constexpr bool PF = MODE == VG_STAGE_RELU && (NP == 1 || VG_THIN_PF2);
+    constexpr bool PF = MODE == VG_STAGE_RELU && (NP == 1 || VG_THIN_PF2) && !(UP && VG_THIN_UP_NOPF);
     Raw8<T> raw[3][HD / 2];
-    if (PF && t0 < tend) thin_issue<MODE>(g, utab, tabat(ti_d * TD, ti_h * TH, ti_w * TW), n, 0, tid, raw);
+    if (PF && t0 < tend) {
+        if constexpr (UP) thin_issue_up<MODE>(g, utu, uptab(ti_d * TD, ti_h * TH, ti_w * TW), n, 0, tid, raw);
+        else thin_issue<MODE>(g, utab, tabat(ti_d * TD, ti_h * TH, ti_w * TW), n, 0, tid, raw);
+    }
     bf16x4 bxp[(BSTAT && NP == 1) ? 8 : 1];
     bf16x4 bxn[(BSTAT && PL > 1) ? 8 : 1];                                 // (PL: the rows requested a panel ahead)
     for (int tile = t0; tile < tend; tile += tstep, ++it) {
@@ -398,15 +532,70 @@ __global__ __launch_bounds__(256, VG_THIN_WPE) void conv_thin_kernel(const Gathe
         };
         if constexpr (PL == 1)
         for (int chunk = 0; chunk < nchunks; ++chunk) {
+            const bool upc = UP && chunk < p.nup;                          // (workgroup-uniform) this chunk comes from the upsampled half-resolution tensor
             if (it | chunk) lds_only_barrier();                            // previous readers of the halo image / weight panel are done
-            if (nchunks > 1) { stage_scale_shift(g, scs, n, chunk, tid); if (it | chunk) load_weights(chunk); lds_only_barrier(); }
+            if (nchunks > 1) {
+                stage_scale_shift(g, scs, n, chunk, tid);
+                if constexpr (UP) { if (upc) load_weights_up(chunk); else load_weights(chunk); }
+                else if (it | chunk) load_weights(chunk);
+                lds_only_barrier();
+            }
+            if constexpr (UP) {
+                if (upc) { if (!PF) thin_issue_up<MODE>(g, utu, uptab(od0, oh0, ow0), n, chunk, tid, raw); thin_commit_up(halo, scs, utu, tid, raw); }
+                else { if (!PF) thin_issue<MODE>(g, utab, tabat(od0, oh0, ow0), n, chunk, tid, raw); thin_commit<MODE>(g, halo, scs, utab, tabat(od0, oh0, ow0), chunk, tid, raw); }
+            } else {
             if (!PF) thin_issue<MODE>(g, utab, tabat(od0, oh0, ow0), n, chunk, tid, raw);
             thin_commit<MODE>(g, halo, scs, utab, tabat(od0, oh0, ow0), chunk, tid, raw);
+            }
             lds_only_barrier();
             // the next (tile, chunk)'s loads go out now and land under the MFMA loop
             if (PF) {
+                if constexpr (UP) {
+                    if (chunk + 1 < nchunks) {
+                        if (chunk + 1 < p.nup) thin_issue_up<MODE>(g, utu, uptab(od0, oh0, ow0), n, chunk + 1, tid, raw);
+                        else thin_issue<MODE>(g, utab, tabat(od0, oh0, ow0), n, chunk + 1, tid, raw);
+                    } else if (more) thin_issue_up<MODE>(g, utu, uptab(ti_d * TD, ti_h * TH, ti_w * TW), n, 0, tid, raw);
+                } else {
                 if (chunk + 1 < nchunks) thin_issue<MODE>(g, utab, tabat(od0, oh0, ow0), n, chunk + 1, tid, raw);
                 else if (more) thin_issue<MODE>(g, utab, tabat(ti_d * TD, ti_h * TH, ti_w * TW), n, 0, tid, raw);
+                }
+            }
+            if constexpr (UP) {
+                if (upc) {
+                    // ---- MFMA loop of an upsampled chunk: 6 K-steps; per K-step two weight fragments per panel (the two H-parity classes of
+                    //      this wave's plane) and FIVE image fragments -- fine rows 2 r - 1 and 2 r read the same half-resolution rows
+                    const char* wbu = wlds + pd_cls * CLSB + wbase_up;
+                    int boff_up[KSUP];
+                    {
+                        const int upbase = ((wave + 1) >> 1) * DSB + li * UNIT;
+#pragma unroll
+                        for (int s_ = 0; s_ < KSUP; ++s_) { const int G = 4 * s_ + kg; boff_up[s_] = upbase + tapu[G >> 1] + (G & 1) * PSB; }
+                    }
+                    bf16x8 ae[2][NP], ao[2][NP], bu[2][5];
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) { ae[0][q] = *(lds_frag*)(wbu + q * 16 * WRSU); ao[0][q] = *(lds_frag*)(wbu + CLSB + q * 16 * WRSU); }
+#pragma unroll
+                    for (int r = 0; r < 5; ++r) bu[0][r] = *(lds_frag*)(halo + boff_up[0] + r * ROWB);
+#pragma unroll
+                    for (int s_ = 0; s_ < KSUP; ++s_) {
+                        if (s_ + 1 < KSUP) {
+#pragma unroll
+                            for (int q = 0; q < NP; ++q) {
+                                ae[(s_ + 1) & 1][q] = *(lds_frag*)(wbu + q * 16 * WRSU + (s_ + 1) * 64);
+                                ao[(s_ + 1) & 1][q] = *(lds_frag*)(wbu + CLSB + q * 16 * WRSU + (s_ + 1) * 64);
+                            }
+#pragma unroll
+                            for (int r = 0; r < 5; ++r) bu[(s_ + 1) & 1][r] = *(lds_frag*)(halo + boff_up[s_ + 1] + r * ROWB);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int q = 0; q < NP; ++q)
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) acc[q][j] = VG_MFMA16((j & 1) ? ao[s_ & 1][q] : ae[s_ & 1][q], bu[s_ & 1][(j + 1) >> 1], acc[q][j]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    continue;
+                }
             }
             // ---- MFMA loop: 14 K-steps x 8 sub-tiles x NP panels, every address an immediate, the fragments of the next K-step in flight
             const char* wb = wlds + wbase;
@@ -661,10 +850,14 @@ __global__ __launch_bounds__(256, VG_THIN_WPE) void conv_thin_kernel(const Gathe
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-int vg_conv_thin_lds_bytes(const GatherIn& g, int np, int pl) {
+int vg_conv_thin_lds_bytes(const GatherIn& g, int np, int pl, bool up) {
     const int AL = (g.tiles_h * TH + 2) + (g.tiles_w * TW + 2) + (g.tiles_d * TD + 2);          // axis tables of the whole grid, two sources
-    const int head = HALO + (32 + 32 * np * pl + 64 * np * pl + (np > 1 ? 48 * np : 0) + 32) * 4 + (2 * HH * HW * 2 + 2 * AL) * 4;
+    int head = HALO + (32 + 32 * np * pl + 64 * np * pl + (np > 1 ? 48 * np : 0) + 32) * 4 + (2 * HH * HW * 2 + 2 * AL) * 4;
     if (pl > 1) return head + 1024 + 2 * 15 * 1024;                                             // two LDS-DMA buffers of one 16-row panel
+    if (up) {           // half-resolution axis tables + column table; the weight area holds the four class panels of an upsampled chunk
+        head += (g.tiles_h * (TH / 2) + 2 + g.tiles_d * (TD / 2) + 2 + 2 * UPCOLS + 16) * 4;
+        return head + 16 + std::max(16 * np * (KCPAD * 2 + 16), 4 * 16 * np * WRSU);
+    }
     return head + 16 + 16 * np * (KCPAD * 2 + 16);
 }
 
@@ -690,11 +883,11 @@ bool vg_conv_thin_ok(const vg_conv_desc* d, const GatherIn& g, const ConvOut& k,
     return true;
 }
 
-template <int MODE, bool BIAS, bool RES, bool STATS, bool BSTAT, int NP, int PL = 1>
+template <int MODE, bool BIAS, bool RES, bool STATS, bool BSTAT, int NP, int PL = 1, bool UP = false>
 static int launch_thin_np(const GatherIn& g, const ConvOut& k, int lds, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_thin_kernel<MODE, BIAS, RES, STATS, BSTAT, NP, PL>, hipFuncAttributeMaxDynamicSharedMemorySize, VG_LDS_LIMIT);
+        (void)hipFuncSetAttribute((const void*)conv_thin_kernel<MODE, BIAS, RES, STATS, BSTAT, NP, PL, UP>, hipFuncAttributeMaxDynamicSharedMemorySize, VG_LDS_LIMIT);
         attr_set = true;
     }
     int per_cu = 2;
@@ -709,12 +902,13 @@ static int launch_thin_np(const GatherIn& g, const ConvOut& k, int lds, hipStrea
     if (vg_tune("CONV_THIN_XCD", 1) && bx >= 16 && tiles >= 4 * bx) { bx &= ~7; k2.xw = 1; }
     // bs1 / bs2: IN-backward statistics in the epilogue, of a plain / a virtually concatenated (half-resolution + skip) pre-norm tensor
     char name[96];
-    snprintf(name, sizeof name, "%s<m%%d,b%%d,r%%d,s%%d%s%s>|walk%%d|ch%%d", NP == 2 ? "conv_thin2" : "conv_thin", BSTAT ? (k.bs_x1 ? ",bs2" : ",bs1") : "", PL > 1 ? ",pl" : "");
+    snprintf(name, sizeof name, "%s<m%%d,b%%d,r%%d,s%%d%s%s%s>|walk%%d|ch%%d", NP == 2 ? "conv_thin2" : "conv_thin", BSTAT ? (k.bs_x1 ? ",bs2" : ",bs1") : "", PL > 1 ? ",pl" : "", UP ? ",up" : "");
     if (vg_dry(name, MODE, (int)BIAS, (int)RES, (int)STATS, tiles > bx ? 1 : 0, k.nchunks > 1 ? 1 : 0)) return VG_OK;
     // the two-panel instances (32-channel layers) finalise the InstanceNorm statistics of their output in the launch (last workgroup)
     const bool fin_here = STATS && k2.fin.ticket && k2.sums && ((NP == 2 && vg_tune("CONV_THIN2_FIN", 1)) || (NP == 1 && !RES && vg_tune("CONV_THIN1_FIN", 1)));
     if (!fin_here) k2.fin.ticket = nullptr;
-    hipLaunchKernelGGL((conv_thin_kernel<MODE, BIAS, RES, STATS, BSTAT, NP, PL>), dim3(bx, ny, g.N), dim3(256), lds, s, g, k2);
+    if constexpr (!UP) k2.nup = 0;
+    hipLaunchKernelGGL((conv_thin_kernel<MODE, BIAS, RES, STATS, BSTAT, NP, PL, UP>), dim3(bx, ny, g.N), dim3(256), lds, s, g, k2);
     if (fin_here) vg_fin_done = true;
     // (no finalisation tail in the one-panel instances: with it the 16 -> 16 residual instance ran 17 % slower even when the tail was not taken --
     // code placement, not registers: the allocation was unchanged -- and the sliding-window inference lost 1.5 ms per volume; vg_conv3d
@@ -728,6 +922,16 @@ static int launch_thin(const GatherIn& g, const ConvOut& k, int np, hipStream_t 
         const int lds3 = vg_conv_thin_lds_bytes(g, 1, 3);
         if (np == 1 && k.Cout == 48 && k.nchunks == 1 && 2 * lds3 <= VG_LDS_LIMIT && vg_tune("CONV_THIN_PL", 1))
             return launch_thin_np<MODE, BIAS, RES, STATS, BSTAT, 1, 3>(g, k, lds3, s);
+    }
+    if constexpr (MODE == VG_STAGE_RELU && BIAS && !RES && !BSTAT) {
+        // the decoder's first convolution: its upsampled chunks contracted over the half-resolution image (conv_thin_kernel<..., UP>)
+        if (k.nup > 0 && k.nup < k.nchunks && vg_tune("CONV_THIN_UP", 0)) {        // (off by default: see ops.ConvLayer.enable_up for the measurement)
+            const int ldsu = vg_conv_thin_lds_bytes(g, np, 1, true);
+            if (2 * ldsu <= VG_LDS_LIMIT) {
+                if (np == 1) return launch_thin_np<MODE, BIAS, RES, STATS, BSTAT, 1, 1, true>(g, k, ldsu, s);
+                if (np == 2 && vg_tune("CONV_THIN_UP2", 1)) return launch_thin_np<MODE, BIAS, RES, STATS, BSTAT, 2, 1, true>(g, k, ldsu, s);
+            }
+        }
     }
     const int lds = vg_conv_thin_lds_bytes(g, np);
     if (lds > VG_LDS_LIMIT) return VG_ELDS;
@@ -755,6 +959,34 @@ int vg_launch_conv_thin(const GatherIn& g, const ConvOut& k, int np, hipStream_t
     if (k.bias == nullptr) return 1;
     if (k.res != nullptr) return st ? launch_thin<VG_STAGE_RELU, true, true, true>(g, k, np, s) : launch_thin<VG_STAGE_RELU, true, true, false>(g, k, np, s);
     return st ? launch_thin<VG_STAGE_RELU, true, false, true>(g, k, np, s) : launch_thin<VG_STAGE_RELU, true, false, false>(g, k, np, s);
+}
+
+// vg_pack_up_weights (include/vangan_hip.h): the class panels of the collapsed upsampled chunks.  One thread per packed element.
+__global__ void pack_up_weights_kernel(const float* __restrict__ w, int Cin, int Cout, int nup, bf16_t* __restrict__ out) {
+    const int total = nup * 4 * Cout * KUP;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        int t = i;
+        const int kk = t % KUP; t /= KUP;
+        const int co = t % Cout; t /= Cout;
+        const int cls = t & 3, chunk = t >> 2;
+        const int t12 = kk >> 4, cl = kk & 15, cdh = t12 / 3, cw = t12 - cdh * 3;
+        const int cd = cdh >> 1, ch = cdh & 1, pd = cls >> 1, ph = cls & 1;
+        // original taps (index 0..2 = offset -1..+1) summed into collapsed tap c for parity p: p = 0: {0}, {1, 2}; p = 1: {0, 1}, {2}
+        const int d0 = pd == 0 ? (cd == 0 ? 0 : 1) : (cd == 0 ? 0 : 2), d1 = pd == 0 ? (cd == 0 ? 0 : 2) : (cd == 0 ? 1 : 2);
+        const int h0 = ph == 0 ? (ch == 0 ? 0 : 1) : (ch == 0 ? 0 : 2), h1 = ph == 0 ? (ch == 0 ? 0 : 2) : (ch == 0 ? 1 : 2);
+        const int ci = chunk * 16 + cl;
+        float a = 0.f;
+        for (int a_ = d0; a_ <= d1; ++a_)
+            for (int b_ = h0; b_ <= h1; ++b_) a += w[((size_t)((a_ * 3 + b_) * 3 + cw) * Cin + ci) * Cout + co];
+        out[i] = f2bf(a);
+    }
+}
+extern "C" int vg_pack_up_weights(const float* w, int Cin, int Cout, int c_up, void* out, vg_stream_t stream) {
+    vg_begin();
+    if (!w || !out || Cin < 16 || Cout < 1 || c_up < 16 || (c_up % 16) || c_up > Cin) return VG_EINVAL;
+    const int nup = c_up / 16, total = nup * 4 * Cout * KUP;
+    hipLaunchKernelGGL(pack_up_weights_kernel, dim3(std::min((total + 255) / 256, 2048)), dim3(256), 0, (hipStream_t)stream, w, Cin, Cout, nup, (bf16_t*)out);
+    return vg_check_launch();
 }
 
 // ================================================================================================================================

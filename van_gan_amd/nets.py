@@ -308,6 +308,7 @@ class ResUNet:
             Nn[b] = Norm(store, b + '.in', f[4])
         for d in (3, 2, 1, 0):
             resblock('dec%d' % d, f[d + 1] + f[d], f[d], 1, lv[d], lv[d])
+            L['dec%d.cb1' % d].enable_up(f[d + 1])            # its first f[d+1] input channels are the upsampled low-resolution tensor
         L['out'] = ConvLayer(store, 'out', 1, f[0], 1, 1, 'same', True, lv[0], dtype=self.dtype)
 
     def pack(self):

@@ -799,6 +799,27 @@ class ConvLayer:
             items.append((self.w, c['idx'], c['wp'], self.cin, self.cout, len(c['taps']), 1, c['ck'], self.f32, self.d_bn))
         return items
 
+    def enable_up(self, c_up: int):
+        """This layer's first c_up input channels are the virtually upsampled half-resolution tensor of a decoder block (UpSampling3D ->
+        concatenate -> IN -> ReLU -> reflect pad -> 3x3x3 convolution, resunet_model.py:175-181, 42-66): the 16-channel specialist then
+        contracts those chunks over the half-resolution image with the D / H taps collapsed (vg_conv_desc::wpacked_up; 12 taps instead of
+        27, 40 % of the staging).  A no-op for layers the specialist does not serve.
+        OFF by default (VG_CONV_THIN_UP=1 enables it): measured at 128^3, the launch with 38 % fewer MFMAs and 40 % less staging is 3 % faster
+        (117.8 vs 121 us) and the step and the sliding-window inference 0.5-2 % SLOWER with the four extra repack launches -- a chunk
+        pass of this kernel costs ~5 us whatever it multiplies (load round trip + commit + three barriers against 0.3-0.75 us of MFMAs),
+        so removing work inside a pass buys nothing; removing PASSES would."""
+        self.wp_up, self.c_up = None, 0
+        if (self.f32 or self.k != 3 or self.stride != 1 or self.pad_mode != PAD_REFLECT or c_up <= 0 or c_up % 16 or c_up >= self.cin
+                or self.f_bn or self.f_ck != 16 or self.wpack or os.environ.get('VG_CONV_THIN_UP', '0') == '0'):
+            return
+        self.c_up = c_up
+        self.ctor = dict(self.ctor, c_up=c_up)
+        self.wp_up = torch.zeros((c_up // 16) * 4 * self.cout * 192, dtype=self.f_wp.dtype, device=self.f_wp.device)
+
+    def pack_up(self):
+        if getattr(self, 'wp_up', None) is not None:
+            check(lib.vg_pack_up_weights(_p(self.w), self.cin, self.cout, self.c_up, _p(self.wp_up), stream()), 'vg_pack_up_weights ' + self.name)
+
     def pack_cell(self):
         """The packed operand of the cell form of the data gradient (dgrad_input) from the fp32 master weights."""
         if getattr(self, 'cell', None) is not None:
@@ -809,6 +830,7 @@ class ConvLayer:
         T = self.f_T
         s = stream()
         self.pack_cell()
+        self.pack_up()
         if self.f_bn:
             check(lib.vg_pack_weights_dma(_p(self.w), T, self.f_cin, self.cout, _p(self.f_idx), T, 0, self.f_bn, _p(self.f_wp), s), 'pack')
         else:
@@ -841,6 +863,8 @@ class ConvLayer:
         d = ConvDesc()
         C.memmove(C.byref(d), C.byref(t), C.sizeof(ConvDesc))
         src.fill(d)
+        if getattr(self, 'wp_up', None) is not None and d.src0_shift and d.c_src0 == self.c_up:
+            d.wpacked_up = _p(self.wp_up)
         return d
 
     def forward(self, src: Src, out: torch.Tensor, sums=None, res=None, res_scale=None, res_shift=None,
@@ -1194,11 +1218,14 @@ class PackTable:
         self.n = len(items)
         self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
         self.cells = [l for l in layers if getattr(l, 'cell', None) is not None]
+        self.ups = [l for l in layers if getattr(l, 'wp_up', None) is not None]
 
     def run(self):
         check(lib.vg_pack_weights_multi(_p(self.table), self.n, self.total_blocks, stream()), 'vg_pack_weights_multi')
         for l in self.cells:
             l.pack_cell()
+        for l in self.ups:
+            l.pack_up()
 
 
 # ------------------------------------------------------------------------------------------------------
