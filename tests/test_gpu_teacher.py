@@ -120,7 +120,7 @@ def _run(dims, B, seed, env=None):
     for k in O.RESULT_KEYS:
         print('   %-24s hip %.6f  oracle(teacher-forced) %.6f' % (k, res[k], ref[k]))
         assert abs(res[k] - ref[k]) <= 2e-3 * abs(ref[k]) + 1e-5, k
-    _run.eng = eng                      # the engine of the last run (its stored tensors: stem_short_noise_floor)
+    _run.eng = eng                      # the engine of the last run (its stored tensors: stem_short_from_stored)
     return got, grads
 
 
