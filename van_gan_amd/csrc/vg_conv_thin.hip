@@ -42,9 +42,6 @@ static int vg_ablate_knob(const char* key) {
 #ifndef VG_THIN_PF2
 #define VG_THIN_PF2 0     // prefetch of the next halo under the MFMA loop in the two-panel forward instances too: spills 14-58 registers there
 #endif
-#ifndef VG_THIN_UP_NOPF
-#define VG_THIN_UP_NOPF 0
-#endif
 #ifndef VG_THIN_PD
 #define VG_THIN_PD 1      // K-steps of fragments in flight ahead of the MFMAs (2 measured the same; 1 leaves the registers for the staged loads)
 #endif
@@ -268,7 +265,7 @@ __device__ __forceinline__ void thin_commit_up(char* halo, const float* scs, con
 template <int MODE, bool BIAS, bool RES, bool STATS, bool BSTAT = false, int NP = 1, int PL = 1, bool UP = false>
 __global__ __launch_bounds__(256, VG_THIN_WPE) void conv_thin_kernel(const GatherIn g, const ConvOut p) {
     static_assert(PL == 1 || (NP == 1 && MODE == VG_STAGE_PLAIN && !BIAS && !RES && !STATS), "panel loop: plain data gradient only");
-    static_assert(!UP || (MODE == VG_STAGE_RELU && !RES && !BSTAT && PL == 1), "collapsed upsampled chunks: the decoder's first convolution, forward");
+    static_assert(!UP || (MODE == VG_STAGE_RELU && !RES && !BSTAT && PL == 1 && NP == 1), "collapsed upsampled chunks: the decoder's first convolution, forward, one panel");
     // NP: 16-channel output panels per workgroup.  NP = 2 (the 32-channel layers at 64^3, conv_thin2 in the variant names): every B
     // fragment feeds two MFMAs -- 10 fragment reads per 16 MFMAs instead of 9 per 8 -- and the halo is staged once per 32 channels.
     typedef bf16_t T;
@@ -457,7 +454,7 @@ __global__ __launch_bounds__(256, VG_THIN_WPE) void conv_thin_kernel(const Gathe
     // PF: the loads of the NEXT (tile, chunk) are issued ahead of the MFMA loop and stay in registers across it.  Forward instances
     // only (16 -> 16: 68 -> 64 us, 48 -> 16: 148 -> 142 us); the data-gradient instances got SLOWER with it (16 -> 48: 178 -> 195 us;
     // the BSTAT one sits at the register cap and spilled the nine units): they load, then commit, back to back.
-    constexpr bool PF = MODE == VG_STAGE_RELU && (NP == 1 || VG_THIN_PF2) && !(UP && VG_THIN_UP_NOPF);
+    constexpr bool PF = MODE == VG_STAGE_RELU && (NP == 1 || VG_THIN_PF2);
     Raw8<T> raw[3][HD / 2];
     if (PF && t0 < tend) {
         if constexpr (UP) thin_issue_up<MODE>(g, utu, uptab(ti_d * TD, ti_h * TH, ti_w * TW), n, 0, tid, raw);
@@ -928,8 +925,8 @@ static int launch_thin(const GatherIn& g, const ConvOut& k, int np, hipStream_t 
         if (k.nup > 0 && k.nup < k.nchunks && vg_tune("CONV_THIN_UP", 0)) {        // (off by default: see ops.ConvLayer.enable_up for the measurement)
             const int ldsu = vg_conv_thin_lds_bytes(g, np, 1, true);
             if (2 * ldsu <= VG_LDS_LIMIT) {
+                // (one-panel instance only: the two-panel form needs 93 KB of LDS per workgroup and spills 60-90 registers)
                 if (np == 1) return launch_thin_np<MODE, BIAS, RES, STATS, BSTAT, 1, 1, true>(g, k, ldsu, s);
-                if (np == 2 && vg_tune("CONV_THIN_UP2", 1)) return launch_thin_np<MODE, BIAS, RES, STATS, BSTAT, 2, 1, true>(g, k, ldsu, s);
             }
         }
     }
