@@ -815,6 +815,7 @@ static int fill_conv(const vg_conv_desc* d, GatherIn& g, ConvOut& k, ConvCls& q,
     k.wp = d->wpacked;
     k.bias = d->bias; k.res = d->res; k.rs = d->res_scale; k.rb = d->res_shift; k.tanh_out = d->tanh_out;
     k.res1 = (d->res && d->res_c1) ? 1 : 0;
+    k.wdma = 0;
     k.wp_up = d->wpacked_up; k.nup = (d->wpacked_up && d->src0_shift && d->pad_mode == VG_PAD_REFLECT && d->c_src0 > 0 && (d->c_src0 % 16) == 0) ? d->c_src0 / 16 : 0;
     if (d->res_c1 && (!d->res || d->ostr != 1 || q.ncls > 1)) return VG_EINVAL;
     k.out = d->out; k.out_f32 = (d->out_f32 || d->f32) ? 1 : 0; k.accumulate = d->accumulate; k.sums = d->out_sums;

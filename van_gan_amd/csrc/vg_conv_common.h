@@ -8,6 +8,7 @@ struct ConvOut {
     const void* wp; int Ktot, nchunks, kc_pad;
     const float* bias; const void* res; const float* rs; const float* rb; int tanh_out;
     int res1;           // vg_conv_desc::res_c1: res is a single-channel fp32 volume broadcast over the output channels
+    int wdma;           // conv_thin_kernel, one-panel forward with several chunks: weight panels double-buffered by LDS-DMA
     const void* wp_up; int nup;   // conv_thin_kernel<..., UP>: class panels of the collapsed upsampled chunks (vg_conv_desc::wpacked_up), their number
     void* out; int out_f32, accumulate; float* sums;
     int w_lds;          // 1: the BN x Ktot weight panel of this workgroup is copied to LDS once (row stride WRS bytes)
@@ -155,6 +156,6 @@ __device__ __forceinline__ void conv_mfma_chunk(f32x4 (&acc)[MW], WP w, const ch
 
 // vg_conv_thin.hip: specialist for the 16-channel-chunk 3x3x3 stride-1 layers with a fixed 16x8x4 tile
 bool vg_conv_thin_ok(const vg_conv_desc* d, const GatherIn& g, const ConvOut& k, const ConvCls& q, int np);       // np: 16-channel panels per workgroup (1 / 2)
-int vg_conv_thin_lds_bytes(const GatherIn& g, int np, int pl = 1, bool up = false);       // pl: output panels looped inside a workgroup (1 / 3); up: collapsed upsampled chunks
+int vg_conv_thin_lds_bytes(const GatherIn& g, int np, int pl = 1, bool up = false, bool wdma = false);       // pl: output panels looped inside a workgroup (1 / 3); up: collapsed upsampled chunks
 // red != NULL: accumulate the IN-backward statistics (ConvOut::bs_*) into red in the epilogue when the instance exists (did_stats)
 int vg_launch_conv_thin(const GatherIn& g, const ConvOut& k, int np, hipStream_t s, float* red, bool& did_stats);       // VG_OK, < 0 on error, 1: not one of its combinations

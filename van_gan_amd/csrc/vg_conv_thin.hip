@@ -290,7 +290,10 @@ __global__ __launch_bounds__(256, VG_THIN_WPE) void conv_thin_kernel(const Gathe
     int* lowtab = xtab + 2 * (NHt + NWt + NDt);
     int* utu = lowtab + NHl + NDl;
     char* wlds = (char*)(utu + (UP ? 2 * UPCOLS + 16 : 0));
-    wlds = (char*)(((size_t)wlds + (PL > 1 ? 1023 : 15)) & ~(size_t)(PL > 1 ? 1023 : 15));
+    // WDMA (one-panel forward instances with several channel chunks): the next pass's 16 x 448 weight panel arrives by LDS-DMA in a second
+    // buffer under the MFMA loop of the current pass, instead of a global -> register -> LDS copy in the open at the head of every pass
+    const bool wdma = MODE == VG_STAGE_RELU && NP == 1 && PL == 1 && !UP && p.wdma;
+    wlds = (char*)(((size_t)wlds + ((PL > 1 || wdma) ? 1023 : 15)) & ~(size_t)((PL > 1 || wdma) ? 1023 : 15));
     const int Ktot = p.Ktot, nchunks = p.nchunks;
     constexpr int WRS = KCPAD * 2 + 16;                  // LDS row stride of the chunk panel (16 bytes of padding: bank spread)
     const int cop = ntile * 16 * NP * PL;                // first output channel of this workgroup
@@ -336,8 +339,8 @@ __global__ __launch_bounds__(256, VG_THIN_WPE) void conv_thin_kernel(const Gathe
     // PL: one use's panel as 15 LDS-DMA pieces of 64 x 16 bytes, dealt to the waves; unit u = row * 57 + c (c == 56: the row's padding)
     constexpr int WBUF = 15 * 1024;
     const unsigned wlds_a = (unsigned)(uintptr_t)(lds_void_d*)wlds;
-    auto dma_weights = [&](int panel, int buf) {
-        const char* src = (const char*)p.wp + (size_t)(cop + 16 * panel) * Ktot * 2;
+    auto dma_weights = [&](int panel, int buf, int chunk_ = 0) {
+        const char* src = (const char*)p.wp + ((size_t)(cop + 16 * panel) * Ktot + (size_t)chunk_ * KCPAD) * 2;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int piece = wave + 4 * k;
@@ -347,7 +350,7 @@ __global__ __launch_bounds__(256, VG_THIN_WPE) void conv_thin_kernel(const Gathe
             }
         }
     };
-    if constexpr (PL > 1) dma_weights(0, 0); else if constexpr (!UP) load_weights(0);        // (UP: chunk 0 is an upsampled one: loaded in the chunk loop, the lambda needs the tables)
+    if constexpr (PL > 1) dma_weights(0, 0); else if constexpr (!UP) { if (wdma) dma_weights(0, 0, 0); else load_weights(0); }        // (UP: chunk 0 is an upsampled one: loaded in the chunk loop, the lambda needs the tables)
     // ---- per-lane constants of the MFMA loop: B-fragment base of every K-step (tap and channel group of this lane's k-group)
     const int wbase = li * WRS + kg * 16;                                // A fragment: row li of panel 0, k-group kg (panel q: + 16 q rows)
     const int wbase_up = li * WRSU + kg * 16;                            // ... of a class panel of an upsampled chunk (UP)
@@ -534,7 +537,7 @@ __global__ __launch_bounds__(256, VG_THIN_WPE) void conv_thin_kernel(const Gathe
             if (nchunks > 1) {
                 stage_scale_shift(g, scs, n, chunk, tid);
                 if constexpr (UP) { if (upc) load_weights_up(chunk); else load_weights(chunk); }
-                else if (it | chunk) load_weights(chunk);
+                else if ((it | chunk) && !wdma) load_weights(chunk);
                 lds_only_barrier();
             }
             if constexpr (UP) {
@@ -544,6 +547,7 @@ __global__ __launch_bounds__(256, VG_THIN_WPE) void conv_thin_kernel(const Gathe
             if (!PF) thin_issue<MODE>(g, utab, tabat(od0, oh0, ow0), n, chunk, tid, raw);
             thin_commit<MODE>(g, halo, scs, utab, tabat(od0, oh0, ow0), chunk, tid, raw);
             }
+            if (wdma) __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): this wave's pieces of THIS pass's panel (requested a pass ago) have landed
             lds_only_barrier();
             // the next (tile, chunk)'s loads go out now and land under the MFMA loop
             if (PF) {
@@ -557,6 +561,8 @@ __global__ __launch_bounds__(256, VG_THIN_WPE) void conv_thin_kernel(const Gathe
                 else if (more) thin_issue<MODE>(g, utab, tabat(ti_d * TD, ti_h * TH, ti_w * TW), n, 0, tid, raw);
                 }
             }
+            const int wuse = it * nchunks + chunk;                         // pass counter: its panel sits in buffer wuse & 1
+            if (wdma && (chunk + 1 < nchunks || more)) dma_weights(0, (wuse + 1) & 1, chunk + 1 < nchunks ? chunk + 1 : 0);
             if constexpr (UP) {
                 if (upc) {
                     // ---- MFMA loop of an upsampled chunk: 6 K-steps; per K-step two weight fragments per panel (the two H-parity classes of
@@ -595,7 +601,7 @@ __global__ __launch_bounds__(256, VG_THIN_WPE) void conv_thin_kernel(const Gathe
                 }
             }
             // ---- MFMA loop: 14 K-steps x 8 sub-tiles x NP panels, every address an immediate, the fragments of the next K-step in flight
-            const char* wb = wlds + wbase;
+            const char* wb = wlds + wbase + (wdma ? (wuse & 1) * WBUF : 0);
             constexpr int PD = VG_THIN_PD, NB = PD + 1;                    // K-steps of fragments in flight ahead of the MFMAs
             if constexpr (NP == 1) {
                 bf16x8 a[NB][NP], b[NB][8];
@@ -847,10 +853,10 @@ __global__ __launch_bounds__(256, VG_THIN_WPE) void conv_thin_kernel(const Gathe
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-int vg_conv_thin_lds_bytes(const GatherIn& g, int np, int pl, bool up) {
+int vg_conv_thin_lds_bytes(const GatherIn& g, int np, int pl, bool up, bool wdma) {
     const int AL = (g.tiles_h * TH + 2) + (g.tiles_w * TW + 2) + (g.tiles_d * TD + 2);          // axis tables of the whole grid, two sources
     int head = HALO + (32 + 32 * np * pl + 64 * np * pl + (np > 1 ? 48 * np : 0) + 32) * 4 + (2 * HH * HW * 2 + 2 * AL) * 4;
-    if (pl > 1) return head + 1024 + 2 * 15 * 1024;                                             // two LDS-DMA buffers of one 16-row panel
+    if (pl > 1 || wdma) return head + 1024 + 2 * 15 * 1024;                                     // two LDS-DMA buffers of one 16-row panel
     if (up) {           // half-resolution axis tables + column table; the weight area holds the four class panels of an upsampled chunk
         head += (g.tiles_h * (TH / 2) + 2 + g.tiles_d * (TD / 2) + 2 + 2 * UPCOLS + 16) * 4;
         return head + 16 + std::max(16 * np * (KCPAD * 2 + 16), 4 * 16 * np * WRSU);
@@ -900,7 +906,7 @@ static int launch_thin_np(const GatherIn& g, const ConvOut& k, int lds, hipStrea
     // bs1 / bs2: IN-backward statistics in the epilogue, of a plain / a virtually concatenated (half-resolution + skip) pre-norm tensor
     char name[96];
     snprintf(name, sizeof name, "%s<m%%d,b%%d,r%%d,s%%d%s%s%s>|walk%%d|ch%%d", NP == 2 ? "conv_thin2" : "conv_thin", BSTAT ? (k.bs_x1 ? ",bs2" : ",bs1") : "", PL > 1 ? ",pl" : "", UP ? ",up" : "");
-    if (vg_dry(name, MODE, (int)BIAS, (int)RES, (int)STATS, tiles > bx ? 1 : 0, k.nchunks > 1 ? 1 : 0)) return VG_OK;
+    if (vg_dry(name, MODE, (int)BIAS, (int)RES, (int)STATS, tiles > bx ? 1 : 0, k.nchunks > 1 ? (k.wdma ? 2 : 1) : 0)) return VG_OK;      // ch2: chunk panels by LDS-DMA
     // the two-panel instances (32-channel layers) finalise the InstanceNorm statistics of their output in the launch (last workgroup)
     const bool fin_here = STATS && k2.fin.ticket && k2.sums && ((NP == 2 && vg_tune("CONV_THIN2_FIN", 1)) || (NP == 1 && !RES && vg_tune("CONV_THIN1_FIN", 1)));
     if (!fin_here) k2.fin.ticket = nullptr;
@@ -928,6 +934,14 @@ static int launch_thin(const GatherIn& g, const ConvOut& k, int np, hipStream_t 
                 // (one-panel instance only: the two-panel form needs 93 KB of LDS per workgroup and spills 60-90 registers)
                 if (np == 1) return launch_thin_np<MODE, BIAS, RES, STATS, BSTAT, 1, 1, true>(g, k, ldsu, s);
             }
+        }
+    }
+    if constexpr (MODE == VG_STAGE_RELU && !BSTAT) {
+        // one-panel forward with several channel chunks (dec0.cb1: 48 -> 16): the weight panels double-buffered by LDS-DMA
+        const int ldsw = vg_conv_thin_lds_bytes(g, 1, 1, false, true);
+        if (np == 1 && k.nchunks > 1 && 2 * ldsw <= VG_LDS_LIMIT && vg_tune("CONV_THIN_WDMA", 1)) {
+            ConvOut kw = k; kw.wdma = 1;
+            return launch_thin_np<MODE, BIAS, RES, STATS, BSTAT, 1>(g, kw, ldsw, s);
         }
     }
     const int lds = vg_conv_thin_lds_bytes(g, np);
